@@ -1,0 +1,302 @@
+"""ctypes bindings for the CHECKERS: liboracle.so (the repo's C restatement) and
+_ref/libmlvfs_ref.so (the reference's own sources compiled by oracle/Makefile).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from the mlvfs_amd package.
+Both classes expose the same method names so a test can be parameterised over
+(oracle, reference).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libmlvfs_ref.so")
+
+u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+def build(quiet: bool = True) -> None:
+    """(Re)build the checkers; the reference part only when /root/reference exists."""
+    subprocess.run(["make", "-C", HERE] + (["-s"] if quiet else []), check=True)
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_SO)
+
+
+class PixelList(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32)]
+
+
+class Oracle:
+    """liboracle.so"""
+    kind = "port"
+
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            build()
+        L = self.L = C.CDLL(ORACLE_SO)
+        L.orc_unpack_bits.restype = C.c_size_t
+        L.orc_unpack_bits.argtypes = [u16p, u8p, C.c_int64, C.c_size_t, C.c_int]
+        L.orc_chroma_smooth.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_detect_bad_pixels.restype = C.c_size_t
+        L.orc_detect_bad_pixels.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            i32p, C.c_size_t]
+        L.orc_apply_bad_pixels.argtypes = [u16p, C.c_int, C.c_int, C.c_int, i32p, C.c_size_t,
+                                           C.c_int, C.c_int, C.c_int]
+        L.orc_apply_focus_pixels.argtypes = L.orc_apply_bad_pixels.argtypes
+        L.orc_stripes_compute.restype = C.c_int
+        L.orc_stripes_compute.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          i32p, C.c_void_p, C.c_void_p]
+        L.orc_stripes_apply.argtypes = [u16p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, i32p, C.c_int64]
+        L.orc_hdr_preview.restype = C.c_int
+        L.orc_hdr_preview.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.orc_fix_pattern_noise.argtypes = [i16p, C.c_int, C.c_int, C.c_int]
+        L.orc_build_raw2ev.argtypes = [C.c_int, i32p, C.c_int]
+        L.orc_build_ev2raw.argtypes = [i32p]
+        L.orc_rand_seed.argtypes = [C.c_void_p, C.c_uint]
+        L.orc_rand_next.argtypes = [C.c_void_p]
+        L.orc_rand_next.restype = C.c_int
+        self._libc = C.CDLL(None)
+
+    # -- tables
+    def raw2ev(self, black: int, n: int = 16384) -> np.ndarray:
+        out = np.empty(n, np.int32)
+        self.L.orc_build_raw2ev(black, out, n)
+        return out
+
+    def ev2raw(self) -> np.ndarray:
+        out = np.empty(24 * 32768, np.int32)
+        self.L.orc_build_ev2raw(out)
+        return out
+
+    # -- stages (all return new arrays; inputs are not modified)
+    def unpack(self, packed: np.ndarray, w: int, h: int, bpp: int = 14, offset: int = 0,
+               max_size: int | None = None) -> np.ndarray:
+        max_size = w * h * 2 if max_size is None else max_size
+        out = np.zeros(max_size, np.uint8)
+        self.L.orc_unpack_bits(np.ascontiguousarray(packed, np.uint16), out, offset, max_size, bpp)
+        return out.view(np.uint16)
+
+    def chroma_smooth(self, img: np.ndarray, black: int, method: int) -> np.ndarray:
+        out = np.ascontiguousarray(img, np.uint16).copy()
+        h, w = out.shape
+        self.L.orc_chroma_smooth(out, w, h, black, method)
+        return out
+
+    def detect_bad_pixels(self, img, black, aggressive=0, crop=(0, 0)) -> np.ndarray:
+        img = np.ascontiguousarray(img, np.uint16)
+        h, w = img.shape
+        cap = 1 << 16
+        while True:
+            buf = np.zeros((cap, 2), np.int32)
+            n = self.L.orc_detect_bad_pixels(img, w, h, black, aggressive, crop[0], crop[1], buf.reshape(-1), cap)
+            if n <= cap:
+                return buf[:n].copy()
+            cap = int(n)
+
+    def apply_bad_pixels(self, img, black, pixels, crop=(0, 0), dual_iso=0) -> np.ndarray:
+        out = np.ascontiguousarray(img, np.uint16).copy()
+        h, w = out.shape
+        px = np.ascontiguousarray(pixels, np.int32).reshape(-1)
+        self.L.orc_apply_bad_pixels(out, w, h, black, px if px.size else np.zeros(2, np.int32), px.size // 2,
+                                    crop[0], crop[1], dual_iso)
+        return out
+
+    def apply_focus_pixels(self, img, black, pixels, crop=(0, 0), dual_iso=0) -> np.ndarray:
+        out = np.ascontiguousarray(img, np.uint16).copy()
+        h, w = out.shape
+        px = np.ascontiguousarray(pixels, np.int32).reshape(-1)
+        self.L.orc_apply_focus_pixels(out, w, h, black, px if px.size else np.zeros(2, np.int32), px.size // 2,
+                                      crop[0], crop[1], dual_iso)
+        return out
+
+    def fix_bad_pixels(self, img, black, aggressive=0, dual_iso=0, crop=(0, 0)) -> np.ndarray:
+        return self.apply_bad_pixels(img, black, self.detect_bad_pixels(img, black, aggressive, crop), crop, dual_iso)
+
+    def stripes_compute(self, img, black, white, frame_size=None, coeffs=None, reseed: bool = True,
+                        want_hist: bool = False):
+        """Returns (needed, coeffs[8]) (+ hist[8,65536], num[8] when want_hist)."""
+        img = np.ascontiguousarray(img, np.uint16)
+        h, w = img.shape
+        if frame_size is None:
+            frame_size = w * h * 14 // 8
+        co = np.zeros(8, np.int32) if coeffs is None else np.array(coeffs, np.int32)
+        if reseed:
+            self._libc.srand(1)            # a fresh process starts at seed 1
+        hist = np.zeros((8, 65536), np.int32) if want_hist else None
+        num = np.zeros(8, np.int32) if want_hist else None
+        needed = self.L.orc_stripes_compute(img, w, h, black, white, frame_size, None, co,
+                                            hist.ctypes.data if want_hist else None,
+                                            num.ctypes.data if want_hist else None)
+        return (needed, co, hist, num) if want_hist else (needed, co)
+
+    def stripes_apply(self, img, black, white, needed, coeffs) -> np.ndarray:
+        out = np.ascontiguousarray(img, np.uint16).copy()
+        h, w = out.shape
+        self.L.orc_stripes_apply(out, w * h, w, black, white, int(needed), np.array(coeffs, np.int32), 0)
+        return out
+
+    def hdr_preview(self, img, black, white):
+        """Returns (converted?, image, (black, white) after conversion)."""
+        out = np.ascontiguousarray(img, np.uint16).copy()
+        h, w = out.shape
+        a, b, s = C.c_double(), C.c_double(), C.c_int()
+        r = self.L.orc_hdr_preview(out, w, h, black, white, w * h * 2, C.byref(a), C.byref(b), C.byref(s))
+        lv = (black * 4, white * 4) if r else (black, white)
+        return r, out, lv
+
+    def fix_pattern_noise(self, img, white) -> np.ndarray:
+        out = np.ascontiguousarray(img).view(np.int16).copy()
+        h, w = out.shape
+        self.L.orc_fix_pattern_noise(out, w, h, white)
+        return out.view(np.uint16)
+
+    def glibc_rand(self, n: int, seed: int = 1) -> np.ndarray:
+        st = (C.c_int32 * 32)()
+        self.L.orc_rand_seed(st, seed)
+        return np.array([self.L.orc_rand_next(st) for _ in range(n)], np.int64)
+
+    def process_frame(self, packed, w, h, black, white, cs=0, bad_pix=0, stripes=0, bpp=14,
+                      correction=None):
+        """process_frame order (mlvfs/main.c:942-997); correction = (needed, coeffs) of the
+        clip or None for a clip's first frame.  Returns (image, correction)."""
+        img = self.unpack(packed, w, h, bpp).reshape(h, w)
+        if bad_pix:
+            img = self.fix_bad_pixels(img, black, aggressive=int(bad_pix == 2))
+        if cs:
+            img = self.chroma_smooth(img, black, cs)
+        if stripes:
+            if correction is None:
+                correction = self.stripes_compute(img, black, white, frame_size=w * h * bpp // 8)
+            img = self.stripes_apply(img, black, white, *correction)
+        return img, correction
+
+
+class Reference:
+    """_ref/libmlvfs_ref.so -- the reference's own code behind oracle/ref_adapter.c."""
+    kind = "reference"
+
+    def __init__(self):
+        if not have_ref():
+            build()
+        if not have_ref():
+            raise FileNotFoundError(REF_SO)
+        L = self.L = C.CDLL(REF_SO)
+        L.ref_unpack.restype = C.c_size_t
+        L.ref_unpack.argtypes = [u16p, u8p, C.c_int64, C.c_size_t, C.c_int, C.c_int, C.c_int]
+        L.ref_chroma_smooth.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ref_fix_bad_pixels.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_uint64]
+        L.ref_fix_focus_pixels.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int,
+                                           C.c_int, C.c_int]
+        L.ref_stripes_compute.restype = C.c_int
+        L.ref_stripes_compute.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, i32p]
+        L.ref_stripes_apply.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p]
+        L.ref_hdr_preview.restype = C.c_int
+        L.ref_hdr_preview.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, i32p]
+        L.ref_cr2hdr20.restype = C.c_int
+        L.ref_cr2hdr20.argtypes = [u16p] + [C.c_int] * 9 + [i32p]
+        L.ref_fix_pattern_noise.argtypes = [i16p, C.c_int, C.c_int, C.c_int]
+        L.ref_hist_median_of.restype = C.c_uint16
+        L.ref_hist_median_of.argtypes = [u16p, C.c_uint32, C.c_uint16, C.c_uint16]
+        L.ref_sizeof_frame_headers.restype = C.c_size_t
+        L.ref_process_frame.argtypes = [u16p, u16p] + [C.c_int] * 8 + [C.c_uint64, i32p, C.POINTER(C.c_int), C.c_int]
+        L.get_raw2ev.restype = C.POINTER(C.c_int)
+        L.get_raw2ev.argtypes = [C.c_int]
+        L.get_ev2raw.restype = C.POINTER(C.c_int)
+        self._libc = C.CDLL(None)
+
+    def raw2ev(self, black: int, n: int = 16384) -> np.ndarray:
+        p = self.L.get_raw2ev(black)
+        return np.array([p[i] for i in range(n)], np.int32)
+
+    def ev2raw(self) -> np.ndarray:
+        p = self.L.get_ev2raw()
+        addr = C.addressof(p.contents) - 10 * 32768 * 4
+        return np.ctypeslib.as_array((C.c_int32 * (24 * 32768)).from_address(addr)).copy()
+
+    def unpack(self, packed, w, h, bpp=14, offset=0, max_size=None) -> np.ndarray:
+        max_size = w * h * 2 if max_size is None else max_size
+        out = np.zeros(max_size, np.uint8)
+        self.L.ref_unpack(np.ascontiguousarray(packed, np.uint16), out, offset, max_size, w, h, bpp)
+        return out.view(np.uint16)
+
+    def chroma_smooth(self, img, black, method) -> np.ndarray:
+        out = np.ascontiguousarray(img, np.uint16).copy()
+        h, w = out.shape
+        self.L.ref_chroma_smooth(out, w, h, black, method)
+        return out
+
+    def fix_bad_pixels(self, img, black, aggressive=0, dual_iso=0, crop=(0, 0)) -> np.ndarray:
+        """crop is given as (panPosX, panPosY); guid 0 forces re-detection."""
+        out = np.ascontiguousarray(img, np.uint16).copy()
+        h, w = out.shape
+        self.L.ref_fix_bad_pixels(out, w, h, black, aggressive, dual_iso, crop[0], crop[1], 0)
+        return out
+
+    def fix_focus_pixels(self, img, black, dual_iso, camera, raw_w, raw_h, pan=(0, 0)) -> np.ndarray:
+        out = np.ascontiguousarray(img, np.uint16).copy()
+        h, w = out.shape
+        self.L.ref_fix_focus_pixels(out, w, h, black, dual_iso, camera, raw_w, raw_h, pan[0], pan[1])
+        return out
+
+    def stripes_compute(self, img, black, white, frame_size=None, coeffs=None, reseed=True):
+        img = np.ascontiguousarray(img, np.uint16)
+        h, w = img.shape
+        co = np.zeros(8, np.int32) if coeffs is None else np.array(coeffs, np.int32)
+        if reseed:
+            self._libc.srand(1)
+        needed = self.L.ref_stripes_compute(img, w, h, black, white, co)
+        return needed, co
+
+    def stripes_apply(self, img, black, white, needed, coeffs) -> np.ndarray:
+        out = np.ascontiguousarray(img, np.uint16).copy()
+        h, w = out.shape
+        self.L.ref_stripes_apply(out, w, h, black, white, int(needed), np.array(coeffs, np.int32))
+        return out
+
+    def hdr_preview(self, img, black, white):
+        out = np.ascontiguousarray(img, np.uint16).copy()
+        h, w = out.shape
+        lv = np.zeros(2, np.int32)
+        r = self.L.ref_hdr_preview(out, w, h, black, white, lv)
+        return r, out, (int(lv[0]), int(lv[1]))
+
+    def cr2hdr20(self, img, black, white, interp_method=0, fullres=1, alias_map=1, chroma_smooth=0, bad_pix=0):
+        out = np.ascontiguousarray(img, np.uint16).copy()
+        h, w = out.shape
+        lv = np.zeros(2, np.int32)
+        r = self.L.ref_cr2hdr20(out, w, h, black, white, interp_method, fullres, alias_map, chroma_smooth,
+                                bad_pix, lv)
+        return r, out, (int(lv[0]), int(lv[1]))
+
+    def fix_pattern_noise(self, img, white) -> np.ndarray:
+        out = np.ascontiguousarray(img).view(np.int16).copy()
+        h, w = out.shape
+        self.L.ref_fix_pattern_noise(out, w, h, white)
+        return out.view(np.uint16)
+
+    def hist_median(self, data, skip, white) -> int:
+        d = np.ascontiguousarray(data, np.uint16)
+        return int(self.L.ref_hist_median_of(d, d.size, skip, white))
+
+    def process_frame(self, packed, w, h, black, white, cs=0, bad_pix=0, stripes=0, bpp=14, correction=None):
+        img = np.zeros((h, w), np.uint16)
+        co = np.zeros(8, np.int32) if correction is None else np.array(correction[1], np.int32)
+        needed = C.c_int(0 if correction is None else int(correction[0]))
+        if correction is None:
+            self._libc.srand(1)
+        self.L.ref_process_frame(np.ascontiguousarray(packed, np.uint16), img, w, h, bpp, black, white,
+                                 cs, bad_pix, stripes, 0, co, C.byref(needed), int(correction is None))
+        return img, ((needed.value, co) if stripes else None)
