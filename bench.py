@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MLVFS per-frame hot path on MI355X.
+
+Metric (BASELINE.json): Mpix/s for 3584x1320 14-bit unpack + cs5x5 + stripes
+(+ bad-pixel repair: configs[2]) with the packed stream already resident in HBM.
+
+  step      = one fused pass (k_pixfix + k_frame) over one batch of --frames-per-step
+              synthetic frames of the resident stream
+  value     = all ranks' pixels / wall time of exactly --steps steps (barrier +
+              synchronize on both sides, max over ranks)
+  roofline  = dominant kernel k_frame<5,packed,patch,stripes>: algorithmic bytes per launch
+              (3.75 B/px x pixels per launch) / mean launch duration measured with HIP
+              events on the launching stream inside the timed region; peak 8 TB/s
+  cpu_baseline = the reference's own code (oracle/_ref, kind "reference") or the C
+              restatement (kind "port") on the host cores, bounded sample, rank 0 @ N=1
+
+Multi-GPU (torchrun, one rank per GPU): frames are sharded over ranks (weak
+scaling: every rank owns its own stream of the same size); the only collective is
+the once-per-clip row-sharded stripes histogram all-reduce over RCCL, outside the
+timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H, BPP = 3584, 1320, 14
+BYTES_PER_PX = 14 / 8 + 2            # packed in + 16-bit out
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(threads: int, frames_per_thread: int = 2):
+    """Reference CPU path, steady state (map + coefficients known), one frame per thread
+    the way libfuse parallelises process_frame."""
+    from concurrent.futures import ThreadPoolExecutor
+    from mlvfs_amd import synth
+    from oracle import bindings               # checker / baseline only
+    distinct = [synth.normal_frame(W, H, seed=1, frame=k) for k in range(2)]
+    packed = [synth.pack14(f).astype("<u2") for f in distinct]
+    packed = [np.concatenate([p, np.zeros(4, "<u2")]) for p in packed]
+    npx = W * H
+    if bindings.have_ref():
+        kind, impl = "reference", bindings.Reference()
+        co = np.zeros(8, np.int32)
+        needed = C.c_int(0)
+        out0 = np.zeros((H, W), np.uint16)
+        C.CDLL(None).srand(1)
+        impl.L.ref_process_frame.argtypes = None
+        def run(p, out, compute):
+            impl.L.ref_process_frame(p.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), W, H, BPP,
+                                     synth.BLACK, synth.WHITE, 5, 1, 1, C.c_uint64(0x1234), co.ctypes.data_as(C.c_void_p),
+                                     C.byref(needed), compute)
+        run(packed[0], out0, 1)                # first frame of the clip: detect + stripes compute (not timed)
+    else:
+        kind, impl = "port", bindings.Oracle()
+        img0, corr = impl.process_frame(packed[0], W, H, synth.BLACK, synth.WHITE, cs=5, bad_pix=0, stripes=1)
+        pixels = impl.detect_bad_pixels(impl.unpack(packed[0], W, H).reshape(H, W), synth.BLACK, 0)
+        def run(p, out, compute):
+            img = impl.unpack(p, W, H).reshape(H, W)
+            img = impl.apply_bad_pixels(img, synth.BLACK, pixels)
+            img = impl.chroma_smooth(img, synth.BLACK, 5)
+            out[:] = impl.stripes_apply(img, synth.BLACK, synth.WHITE, *corr)
+    n = threads * frames_per_thread
+    outs = [np.zeros((H, W), np.uint16) for _ in range(threads)]
+    def worker(t):
+        for k in range(frames_per_thread):
+            run(packed[(t + k) % len(packed)], outs[t], 0)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(worker, range(threads)))
+    dt = time.perf_counter() - t0
+    return {"value": round(n * npx / dt / 1e6, 2), "unit": "Mpix/s", "cores": threads, "kind": kind,
+            "fps": round(n / dt, 3),
+            "sample": f"{n} frames of {W}x{H} (2 distinct synthetic frames), steady state unpack+badpix+cs5x5+stripes, "
+                      f"one frame per thread, gcc -O2"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames-per-step", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cs", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mlvfs_amd import dist as mdist
+    from mlvfs_amd import lib, synth
+    from mlvfs_amd.stream import ClipStream
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    dev = torch.device(f"cuda:{local}")
+    F, K, Wm = args.frames_per_step, args.steps, args.warmup
+
+    s = ClipStream(W, H, BPP, synth.BLACK, synth.WHITE, device=local)
+    L = s.L
+    # the resident stream: K*F frames per rank (every rank owns its own clip: weak scaling);
+    # built in HBM from at most 64 distinct synthetic frames per rank
+    # one clip of world*K*F frames, rank r owns frames [r*K*F, (r+1)*K*F)
+    distinct = min(K * F, 64)
+    base = s.synth_packed(distinct, seed=1, first_frame=rank * K * F)
+    packed = s.alloc_packed(K * F)
+    for i in range(0, K * F, distinct):
+        n = min(distinct, K * F - i)
+        packed[i:i + n] = base[:n]
+    out = s.alloc_out(K * F)
+
+    # ---- first frame of the clip (once per clip, not in the timed region) ------------
+    # main.c:969-988: the clip's pixel map and stripe coefficients come from frame 0, which
+    # lives on rank 0; the other ranks receive the map and the post-chroma-smooth frame, and
+    # the stripes histogram of that frame is row-sharded over all ranks
+    t0 = time.perf_counter()
+    if rank == 0:
+        frame0 = s.unpack(packed[:1])
+        pix = s.detect_bad_pixels(frame0[0], 0)
+        s.fix_pixels(frame0)
+        frame0 = s.chroma_smooth(frame0, args.cs) if args.cs else frame0
+    else:
+        frame0 = s.alloc_out(1)
+    if world > 1:
+        n_pix = torch.tensor([len(pix) if rank == 0 else 0], dtype=torch.int64, device=dev)
+        dist.broadcast(n_pix, src=0)
+        pix_t = torch.from_numpy(pix.copy()).to(dev) if rank == 0 else \
+            torch.zeros((int(n_pix.item()), 2), dtype=torch.int32, device=dev)
+        dist.broadcast(pix_t, src=0)
+        dist.broadcast(frame0.view(torch.uint8), src=0)
+        if rank != 0:
+            s.set_pixel_map(pix_t.cpu().numpy())
+    count_rows, hist_rows = mdist.gpu_callbacks(s, frame0[0])
+    hist, num, calls = mdist.sharded_stripes_histogram(count_rows, hist_rows, H, dev)
+    needed, coeffs = mdist.solve_coefficients(hist, num, s.frame_size)
+    s.set_stripes(needed, coeffs)
+    torch.cuda.synchronize()
+    first_frame_ms = (time.perf_counter() - t0) * 1e3
+
+    def step(b):
+        s.process(packed[b * F:(b + 1) * F], out[b * F:(b + 1) * F], cs=args.cs, fix_pixels=True, stripes=True)
+
+    for i in range(Wm):
+        step(i % K)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    lib.check(L.mlvfs_amd_timer_begin(K), "timer_begin")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ms = np.zeros(K, np.float32)
+    n_timed = L.mlvfs_amd_timer_end(lib.ptr(ms), K)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    npx = W * H
+    total_px = world * K * F * npx
+    kern_ms = float(ms[:n_timed].mean()) if n_timed else float("nan")
+    achieved = F * npx * BYTES_PER_PX / (kern_ms * 1e-3) / 1e9 if n_timed else None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_frame_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "Mpix/s, 3584x1320 14-bit unpack+badpix+cs5x5+stripes (fused, stream resident in HBM)",
+        "value": round(total_px / dt / 1e6, 1),
+        "unit": "Mpix/s",
+        "fps": round(world * K * F / dt, 1),
+        "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": round(dt / K * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u16/int32", "data": "synthetic",
+        "config": {"workload": "configs[2]: 3584x1320 unpack + cs5x5 + stripes + bad-pix, frame stream resident in HBM",
+                   "frames_per_step": F, "frames_per_rank": K * F, "chroma_smooth": args.cs,
+                   "bad_pixels_in_map": int(len(s.get_pixel_map())), "stripe_coeffs": [int(c) for c in coeffs],
+                   "parallelism": f"frames x{world}", "first_frame_ms": round(first_frame_ms, 2)},
+        "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": traffic, "kernel": "k_frame<5,packed,patch,stripes>",
+                     "kernel_ms_per_launch": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(F * npx * BYTES_PER_PX)},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                result["cpu_baseline"] = {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+    s.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,176 @@
+/*
+ * mlvfs_amd.h -- C ABI of libmlvfs_amd.so, the MI355X (gfx950) implementation of
+ * MLVFS's per-frame raw-processing path.  Plain pointers and sizes only.
+ *
+ * PART 1 -- drop-in symbols.  Same names, prototypes, ownership and error
+ *   behaviour as the reference's dng.o / cs.o / stripes.o / hdr.o / histogram.o /
+ *   patternnoise.o for the hot path, so MLVFS's unchanged main.c links against
+ *   this library instead (the binding a maintainer adds is shown in
+ *   INTEGRATION.md).  They work IN PLACE ON HOST MEMORY and are synchronous:
+ *   each call stages the frame to the GPU, runs the HIP kernels and copies back.
+ *   Any HIP failure is reported on stderr and returns the reference's failure
+ *   value (0 / no-op) -- there is NO CPU fallback in this library.
+ *
+ * PART 2 -- device-resident API (mlvfs_amd_*).  The same stages on frames that
+ *   already live in HBM, batched over many frames per launch, plus the fused
+ *   steady-state pipeline.  This is what bench.py times and what a frame
+ *   prefetcher would call.  All device calls are asynchronous
+ *   on the given hipStream_t (passed as void*; NULL = HIP's default stream)
+ *   unless stated otherwise.
+ */
+#ifndef MLVFS_AMD_H
+#define MLVFS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <sys/types.h>
+
+#include "mlvfs_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ======================================================================== */
+/* PART 1: drop-in symbols                                                   */
+
+/* replaces mlvfs/dng.h:31 (dng.c:854-872): unpack bpp-bit packed pixels to u16 */
+size_t dng_get_image_data(struct frame_headers *frame_headers, uint16_t *packed_bits,
+                          uint8_t *output_buffer, off_t offset, size_t max_size);
+/* replaces mlvfs/dng.h:30,32,33 (dng.c:797-800, 879-891) */
+size_t dng_get_header_size(void);
+size_t dng_get_image_size(struct frame_headers *frame_headers);
+size_t dng_get_size(struct frame_headers *frame_headers);
+
+/* replaces mlvfs/cs.h:27-30 (cs.c:49-84, 220-331, 336-503) */
+void chroma_smooth(struct frame_headers *frame_headers, uint16_t *image_data, int method);
+void fix_bad_pixels(struct frame_headers *frame_headers, uint16_t *image_data, int aggressive, int dual_iso);
+void fix_focus_pixels(struct frame_headers *frame_headers, uint16_t *image_data, int dual_iso);
+void free_focus_pixel_maps(void);
+
+/* replaces mlvfs/stripes.h:30-43 (stripes.c:29-266) */
+struct stripes_correction {
+    struct stripes_correction *next;
+    char *mlv_filename;
+    int correction_needed;
+    int coeffficients[8];          /* sic: the reference's spelling is part of the ABI */
+};
+struct stripes_correction *stripes_get_correction(const char *mlv_filename);
+struct stripes_correction *stripes_new_correction(const char *mlv_filename);
+void stripes_free_corrections(void);
+void stripes_compute_correction(struct frame_headers *frame_headers, struct stripes_correction *correction,
+                                uint16_t *image_data, off_t offset, size_t size);
+void stripes_apply_correction(struct frame_headers *frame_headers, struct stripes_correction *correction,
+                              uint16_t *image_data, off_t offset, size_t size);
+
+/* replaces mlvfs/hdr.h:27 (hdr.c:40-227): fast dual-ISO preview; 1 = converted */
+int hdr_convert_data(struct frame_headers *frame_headers, uint16_t *image_data, off_t offset, size_t max_size);
+
+/* replaces mlvfs/patternnoise.h:16 (patternnoise.c:357-380) */
+void fix_pattern_noise(int16_t *raw, int w, int h, int white, int debug_flags);
+
+/* replaces mlvfs/histogram.h:26-36 (histogram.c:33-84); host-side helper used by
+ * main.c's deflicker (main.c:895-906)                                         */
+struct histogram { uint16_t white; uint32_t count; uint16_t *data; };
+struct histogram *hist_create(uint16_t white);
+void hist_add(struct histogram *hist, uint16_t *data, uint32_t size, uint16_t skip);
+uint16_t hist_median(struct histogram *hist);
+void hist_destroy(struct histogram *hist);
+
+/* Imported from the caller when present (weak): mlvfs/mlvfs.h:90-92, defined in
+ * main.c:128-196.  When the caller provides them the device tables are built
+ * from the caller's arrays; otherwise from the same formulas with the host libm. */
+int *get_raw2ev(int black);
+int *get_ev2raw(void);
+
+/* ======================================================================== */
+/* PART 2: device-resident API                                               */
+
+#define MLVFS_AMD_OK            0
+#define MLVFS_AMD_ERR_HIP      -1     /* a HIP call failed (see mlvfs_amd_last_error) */
+#define MLVFS_AMD_ERR_ARG      -2     /* bad geometry / argument                      */
+#define MLVFS_AMD_ERR_LUT      -3     /* host libm tables fail the compression check  */
+#define MLVFS_AMD_ERR_NOMEM    -4
+
+typedef struct {
+    int32_t width, height;        /* rawi_hdr.xRes / yRes                         */
+    int32_t bpp;                  /* raw_info.bits_per_pixel                       */
+    int32_t black, white;         /* raw_info.black_level / white_level            */
+    int32_t pan_x, pan_y;         /* vidf_hdr.panPosX / panPosY (pixel-map crop)   */
+} mlvfs_amd_geom_t;
+
+/* context: one per (host thread, device); created lazily */
+int         mlvfs_amd_device_count(void);
+int         mlvfs_amd_init(int device);              /* binds the calling thread to `device` */
+const char *mlvfs_amd_last_error(void);
+const char *mlvfs_amd_version(void);
+
+/* per-clip artefacts: stripe coefficients + ordered pixel map */
+typedef struct mlvfs_amd_clip mlvfs_amd_clip_t;
+mlvfs_amd_clip_t *mlvfs_amd_clip_create(const mlvfs_amd_geom_t *geom);
+void   mlvfs_amd_clip_destroy(mlvfs_amd_clip_t *clip);
+int    mlvfs_amd_clip_set_stripes(mlvfs_amd_clip_t *clip, int needed, const int32_t coeffs[8]);
+int    mlvfs_amd_clip_get_stripes(const mlvfs_amd_clip_t *clip, int *needed, int32_t coeffs[8]);
+/* xy = count (x,y) pairs in sensor coordinates (crop offsets included), list order
+ * is application order.  kind: 0 = bad-pixel rules (cs.c:314-330), 1 = focus-pixel
+ * rules incl. edges (cs.c:463-500).                                            */
+int    mlvfs_amd_clip_set_pixel_map(mlvfs_amd_clip_t *clip, const int32_t *xy, size_t count, int kind, int dual_iso);
+size_t mlvfs_amd_clip_get_pixel_map(const mlvfs_amd_clip_t *clip, int32_t *xy, size_t cap);
+
+/* -- single stages on device frames ---------------------------------------- */
+/* frames are `nframes` buffers spaced by the given strides (bytes)           */
+int mlvfs_amd_unpack_dev(const mlvfs_amd_geom_t *geom, const void *d_packed, size_t packed_stride,
+                         void *d_out, size_t out_stride, int nframes, void *stream);
+int mlvfs_amd_chroma_smooth_dev(const mlvfs_amd_geom_t *geom, const void *d_in, void *d_out, size_t stride,
+                                int method, int nframes, void *stream);
+/* detection on one frame; fills the clip's pixel map (synchronises the stream) */
+int mlvfs_amd_detect_bad_pixels_dev(mlvfs_amd_clip_t *clip, const void *d_frame, int aggressive, void *stream);
+/* ordered repair with the clip's pixel map, in place                         */
+int mlvfs_amd_fix_pixels_dev(mlvfs_amd_clip_t *clip, void *d_frames, size_t stride, int nframes, void *stream);
+/* stripes: histogram of rows [row0,row1) of one frame.
+ *   count pass  -> number of accepted add_pixel calls (synchronises)
+ *   hist  pass  -> adds into d_hist (int32[8][65536]) and d_num (int32[8]);
+ *                  d_rand = device array of rand()%1024 values (uint16), entry
+ *                  2*k and 2*k+1 belong to this shard's k-th accepted call     */
+int mlvfs_amd_stripes_count_dev(const mlvfs_amd_geom_t *geom, const void *d_frame, int row0, int row1,
+                                int64_t *accepted, void *stream);
+int mlvfs_amd_stripes_hist_dev(const mlvfs_amd_geom_t *geom, const void *d_frame, int row0, int row1,
+                               const void *d_rand, int64_t n_rand, void *d_hist, void *d_num, void *stream);
+/* host: histograms -> coefficients (stripes.c:207-246); coeffs of under-filled
+ * histograms are left as passed in                                           */
+int mlvfs_amd_stripes_solve(const int32_t *hist, const int32_t num[8], int frame_size, int32_t coeffs[8]);
+/* whole computation for one device frame into the clip.  rand_mode 0: consume
+ * libc rand() like the reference; 1: private glibc-compatible stream, seed 1   */
+int mlvfs_amd_stripes_compute_dev(mlvfs_amd_clip_t *clip, const void *d_frame, int frame_size, int rand_mode,
+                                  void *stream);
+int mlvfs_amd_stripes_apply_dev(const mlvfs_amd_clip_t *clip, void *d_frames, size_t stride, int nframes,
+                                void *stream);
+/* glibc TYPE_3 rand() restatement: out[i] = rand()%1024 for calls skip..skip+n-1
+ * after srand(seed)                                                            */
+void mlvfs_amd_rand_stream(uint16_t *out, size_t n, uint64_t skip, unsigned seed);
+
+/* -- fused steady-state pipeline (process_frame order, main.c:942-997) ------ */
+/* packed 14-bit stream -> [pixel map repair] -> [chroma smooth] -> [stripes
+ * apply] -> 16-bit frames, one pass over HBM (3.75 B/px).  Stages are enabled
+ * by cs_method (0,2,3,5), fix_pixels and apply_stripes (uses the clip state). */
+int mlvfs_amd_process_frames_dev(mlvfs_amd_clip_t *clip, const void *d_packed, size_t packed_stride,
+                                 void *d_out, size_t out_stride, int nframes,
+                                 int cs_method, int fix_pixels, int apply_stripes, void *stream);
+
+/* dual-ISO preview on one device frame (hdr.c:40-227); returns 1 / 0 / <0    */
+int mlvfs_amd_hdr_preview_dev(const mlvfs_amd_geom_t *geom, void *d_frame, size_t max_size, void *stream);
+
+/* HIP-event timer around the dominant kernel (k_frame) of the calling thread's
+ * launches, recorded on the stream the kernel is launched on (bench.py's
+ * roofline figure).  begin: arm for up to max_launches launches.  end: waits for
+ * the events, writes one duration in milliseconds per launch, returns the count. */
+int mlvfs_amd_timer_begin(int max_launches);
+int mlvfs_amd_timer_end(float *ms, int cap);
+
+/* self tests that need no GPU (selection networks, LUT identities): 0 = pass */
+int mlvfs_amd_selftest_host(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,95 @@
+// clip.h -- per-clip state (stripe coefficients + ordered pixel map) and the
+// launcher prototypes shared between the host files and the kernel files.
+#pragma once
+
+#include "common.h"
+
+#include <mutex>
+#include <vector>
+
+namespace mlv {
+
+struct PixEntry {
+    int pos;        // y * w + x in frame coordinates (-1: not applied)
+    int kind;       // 0 skip, 1 cross (interpolate_pixel), 2 along x, 3 along y, 4 copy x+2, 5 copy x-2
+    int emit;       // 1: this entry's value is the final value of its position
+    int dep[12];    // per tap: index of the entry whose repaired value must be read, or -1
+};
+
+struct Clip {
+    Geom g{};
+    int pan_x = 0, pan_y = 0;
+    int device = 0;
+    std::mutex mu;
+    // stripes (mlvfs/stripes.h:30-36)
+    int needed = 0;
+    int32_t coef[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    // pixel map
+    std::vector<int32_t> xy;
+    int rules = 0, dual_iso = 0;
+    int n_entries = 0, n_levels = 0;
+    PixEntry *d_entries = nullptr;
+    int *d_level_off = nullptr;
+    void *d_patches = nullptr;
+    size_t patch_bytes = 0;
+    void *d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+
+    ~Clip();
+    int set_pixel_map(const int32_t *xy, size_t count, int rules, int dual_iso);
+    int ensure_patches(int nframes);
+    int ensure_scratch(size_t bytes);
+    int detect_bad_pixels(const void *d_frame, int aggressive, int dual_iso, hipStream_t stream);
+    int fix_pixels(void *d_frames, size_t stride, int nframes, hipStream_t stream);
+    int stripes_compute(const void *d_frame, int frame_size, int rand_mode, hipStream_t stream);
+};
+
+// one shard (rows [row0,row1)) of the stripes histogram computation
+struct StripesWork {
+    static constexpr int RECHECK_CAP = 1 << 16;
+    Clip *owner = nullptr;
+    Geom g{};
+    int row0 = 0, row1 = 0, gpr = 0, n_groups = 0, nblk = 0;
+    size_t o_counts = 0, o_bsum = 0, o_boff = 0, o_total = 0, o_hist = 0, o_num = 0, o_nre = 0, o_re = 0, bytes = 0;
+    uint8_t *base = nullptr;
+    int init(Clip *owner, const Geom &g, int row0, int row1);
+    int count(const void *d_frame, long long *accepted, hipStream_t stream);
+    int hist_dev(const void *d_frame, const void *d_rand, long long n_rand, int *d_hist, int *d_num, hipStream_t stream);
+    int recheck_into(int32_t *hist_host_or_null, int *d_hist, hipStream_t stream);
+    int hist_to_host(const void *d_frame, const void *d_rand, long long n_rand, int32_t *hist, int32_t num[8],
+                     hipStream_t stream);
+};
+
+void glibc_rand_stream(uint16_t *out, size_t n, uint64_t skip, unsigned seed);
+int stripes_solve(const int32_t *hist, const int32_t num[8], int frame_size, int32_t coeffs[8]);
+
+// optional HIP-event timing of the dominant kernel (mlvfs_amd_timer_*)
+struct KernelTimer {
+    std::vector<hipEvent_t> ev;      // pairs: start, stop
+    int used = 0;
+    bool on = false;
+};
+KernelTimer &kernel_timer();
+
+// kernel launchers (k_*.hip)
+int launch_unpack(const void *d_packed, size_t packed_stride, void *d_out, size_t out_stride, uint32_t first_px,
+                  uint32_t npix, int bpp, int nframes, hipStream_t stream);
+int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src, size_t src_stride, void *dst,
+                 size_t dst_stride, int nframes, int method, const int2 *patches, int n_patch, bool stripes,
+                 const int32_t *coef, hipStream_t stream);
+int launch_pixfix(bool packed, const void *frames, size_t stride, int w, int black, const void *entries,
+                  const int *level_off, int n_levels, int n_entries, void *patches, void *scatter, size_t scatter_stride,
+                  int nframes, const DeviceLuts &luts, hipStream_t stream);
+int launch_badpix_detect(const void *d_frame, int w, int h, int black, int aggressive, int crop_x, int crop_y,
+                         void *d_mask, int words_per_row, int *d_row_count, void *d_list, int cap,
+                         const DeviceLuts &luts, hipStream_t stream);
+int stripes_groups_per_row(int w);
+int launch_stripes_count(const void *d_frame, int w, int row0, int row1, int black, int white, unsigned char *d_counts,
+                         int *d_block_sum, long long *d_block_off, long long *d_total, hipStream_t stream);
+int launch_stripes_hist(const void *d_frame, int w, int row0, int row1, int black, int white, const unsigned char *d_counts,
+                        const long long *d_block_off, const void *d_rand, long long n_rand, int *d_hist, int *d_num,
+                        void *d_recheck, int recheck_cap, int *d_n_recheck, hipStream_t stream);
+int launch_stripes_apply(void *d_frames, size_t stride, size_t npix, int w, int black, int white, const int32_t *coef,
+                         int nframes, hipStream_t stream);
+
+}  // namespace mlv

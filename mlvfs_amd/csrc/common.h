@@ -1,0 +1,117 @@
+// common.h -- shared declarations of libmlvfs_amd.so (host + device).
+//
+// Device-side EV arithmetic.  The reference works in "EV space" through two
+// host tables (mlvfs/main.c:128-196):
+//     raw2ev[p]  = (int)(log2(p - black) * 32768)          (INT_MIN at p == black, 0 below)
+//     ev2raw[ev] = (int)pow(2, (float)ev / 32768)           ev in [-10*32768, 14*32768)
+// On the GPU both are served from two small 16-bit tables that are exact
+// re-encodings of those host tables (checked entry by entry when the context is
+// created, see luts.cpp):
+//     T16[j - 8192] = raw2ev_lin[j] - 13*32768   for j in [8192, 16384)   (16 KiB)
+//        raw2ev_lin[i] = T16[(i << (13 - e)) - 8192] + e*32768,  e = floor(log2 i)
+//     U16[f]        = ev2raw[13*32768 + f]       for f in [0, 32768)       (64 KiB)
+//        ev2raw[q*32768 + f] = U16[f] >> (13 - q)                 for q in [0, 14)
+// T16 is staged into LDS by the stencil kernels; U16 is gathered from L2.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mlvfs_amd.h"
+
+#define MLV_EV_RES 32768
+#define MLV_EV_MAX (14 * MLV_EV_RES - 1)
+
+#define MLV_T16_N 8192
+#define MLV_U16_N 32768
+
+namespace mlv {
+
+// ---------------------------------------------------------------- error plumbing
+void set_error(const char *fmt, ...);
+#define MLV_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            mlv::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return MLVFS_AMD_ERR_HIP;                                                   \
+        }                                                                               \
+    } while (0)
+
+// ---------------------------------------------------------------- device state
+struct DeviceLuts {
+    const uint16_t *t16;   // [8192]
+    const uint16_t *u16;   // [32768]
+};
+
+struct Device {            // one per GPU, created once
+    int id = -1;
+    DeviceLuts luts{};
+    int num_cu = 0;
+};
+
+struct ThreadCtx {         // one per (host thread, device)
+    Device *dev = nullptr;
+    hipStream_t stream = nullptr;
+    // grow-only staging buffers for the host-memory (drop-in) entry points
+    void *d_a = nullptr, *d_b = nullptr;
+    size_t cap_a = 0, cap_b = 0;
+    void *h_pin = nullptr;
+    size_t cap_pin = 0;
+    int ensure(size_t need_a, size_t need_b);
+};
+
+// returns nullptr (and sets the error string) on failure
+ThreadCtx *thread_ctx();
+int bind_device(int device);
+
+// host copies of the reference tables (built once; luts.cpp)
+const int32_t *host_raw2ev_lin();   // [16384]  index = p - black
+const int32_t *host_ev2raw();       // [24*32768] index 0 is ev = -10*32768
+const uint16_t *host_t16();
+const uint16_t *host_u16();
+int luts_ok();
+
+struct Geom {
+    int w, h, bpp, black, white;
+};
+
+// device API: the caller's stream; NULL is HIP's default (null) stream, which orders
+// against everything else the caller enqueued
+inline hipStream_t pick_stream(void *s, ThreadCtx *) { return (hipStream_t)s; }
+
+// ---------------------------------------------------------------- device helpers
+#if defined(__HIPCC__)
+
+// wrap-around arithmetic: the reference's signed overflow is de-facto two's
+// complement (SURVEY.md 8a notes); unsigned arithmetic makes that defined.
+__device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__device__ __forceinline__ int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+__device__ __forceinline__ int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+__device__ __forceinline__ int wabs(int a) { return a > 0 ? a : (int)(0u - (unsigned)a); }
+// C's truncating /2 on a possibly negative int
+__device__ __forceinline__ int half_trunc(int s) { return (s + (int)((unsigned)s >> 31)) >> 1; }
+
+// raw2ev of a pixel value (table pointer may be LDS or global)
+template <typename TablePtr>
+__device__ __forceinline__ int ev_of_pixel(int p, int black, TablePtr t16)
+{
+    const int lin = p - black;
+    if (lin <= 0 || lin >= 16384) return lin == 0 ? (int)0x80000000 : 0;
+    const int e = 31 - __clz(lin);
+    const int j = lin << (13 - e);
+    return (int)t16[j - 8192] + (e << 15);
+}
+
+// ev2raw[clamp(ev)] + black, as the uint16 the reference stores
+__device__ __forceinline__ uint16_t pixel_of_ev(int ev, int black, const uint16_t *__restrict__ u16)
+{
+    ev = ev < 0 ? 0 : (ev > MLV_EV_MAX ? MLV_EV_MAX : ev);
+    const int q = ev >> 15, f = ev & 32767;
+    return (uint16_t)((((int)u16[f]) >> (13 - q)) + black);
+}
+
+#endif  // __HIPCC__
+
+}  // namespace mlv

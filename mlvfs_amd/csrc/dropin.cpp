@@ -1,0 +1,373 @@
+// dropin.cpp -- PART 1 of include/mlvfs_amd.h: the symbols MLVFS's main.c links
+// against (dng.h / cs.h / stripes.h / histogram.h), working in place on HOST
+// memory exactly like the reference objects they replace.  Each call stages the
+// frame into HBM, runs the HIP kernels on the calling thread's stream and copies
+// the result back before returning (synchronous, caller keeps ownership).
+//
+// Error behaviour: never abort, never errno; diagnostics on
+// stderr; on a HIP failure the frame is left untouched and the function returns
+// the reference's failure value.  There is deliberately no CPU fallback.
+#include "clip.h"
+
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace mlv;
+
+namespace {
+
+struct FrameView {
+    int w, h, bpp, black, white, pan_x, pan_y, frame_size;
+    uint64_t guid;
+};
+
+FrameView view_of(const struct frame_headers *fh)
+{
+    FrameView v;
+    v.w = fh->rawi_hdr.xRes;
+    v.h = fh->rawi_hdr.yRes;
+    v.bpp = fh->rawi_hdr.raw_info.bits_per_pixel;
+    v.black = fh->rawi_hdr.raw_info.black_level;
+    v.white = fh->rawi_hdr.raw_info.white_level;
+    v.frame_size = fh->rawi_hdr.raw_info.frame_size;
+    v.pan_x = fh->vidf_hdr.panPosX;
+    v.pan_y = fh->vidf_hdr.panPosY;
+    v.guid = fh->file_hdr.fileGuid;
+    return v;
+}
+
+Clip *make_clip(const FrameView &v, ThreadCtx *c)
+{
+    Clip *clip = new Clip;
+    clip->g = Geom{ v.w, v.h, v.bpp, v.black, v.white };
+    clip->pan_x = v.pan_x;
+    clip->pan_y = v.pan_y;
+    clip->device = c->dev->id;
+    return clip;
+}
+
+// host <-> device staging of one 16-bit frame on the thread's stream
+int upload(ThreadCtx *c, const void *host, size_t bytes)
+{
+    int rc = c->ensure(bytes, bytes);
+    if (rc) return rc;
+    MLV_HIP(hipMemcpyAsync(c->d_a, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return MLVFS_AMD_OK;
+}
+
+int download(ThreadCtx *c, void *host, const void *dev, size_t bytes)
+{
+    MLV_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    MLV_HIP(hipStreamSynchronize(c->stream));
+    return MLVFS_AMD_OK;
+}
+
+// ---- per-clip caches of the reference (cs.c:215-217, 333-334) ---------------
+struct BadMap {
+    uint64_t guid = 0;
+    int aggressive = 0;
+    int w = 0, h = 0, dual_iso = -1;
+    Clip *clip = nullptr;
+};
+constexpr int BAD_PIXEL_MAP_COUNT = 8;
+BadMap g_bad_maps[BAD_PIXEL_MAP_COUNT];
+int g_bad_next = 0;
+std::mutex g_bad_mutex;
+
+struct FocusMap {
+    uint32_t camera;
+    int raw_w, raw_h;
+    std::vector<int32_t> xy;             // as read from the .fpm file
+    std::map<std::string, Clip *> clips; // per frame geometry / crop / mode
+};
+std::vector<FocusMap *> g_focus_maps;
+std::mutex g_focus_mutex;
+
+}  // namespace
+
+extern "C" {
+
+// ============================================================== dng.h
+size_t dng_get_header_size(void) { return 65536; }                                   // dng.c:797-800 (HEADER_SIZE)
+
+size_t dng_get_image_size(struct frame_headers *fh)                                  // dng.c:879-882
+{
+    return (size_t)fh->rawi_hdr.xRes * fh->rawi_hdr.yRes * 2;
+}
+
+size_t dng_get_size(struct frame_headers *fh) { return dng_get_header_size() + dng_get_image_size(fh); }
+
+size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8_t *output_buffer, off_t offset,
+                          size_t max_size)
+{
+    const int bpp = fh->rawi_hdr.raw_info.bits_per_pixel;
+    // window arithmetic of dng.c:815-826
+    const uint32_t first_px = (uint32_t)(offset > 0 ? offset : 0) / 2;
+    const size_t lead = offset < 0 ? (size_t)(-offset) : 0;
+    if (max_size <= lead) return max_size;
+    const size_t out_bytes = max_size - lead;
+    const uint32_t npix = (uint32_t)(out_bytes / 2);
+    if (npix == 0) return max_size;
+    if (bpp < 1 || bpp > 16) { set_error("dng_get_image_data: unsupported bits_per_pixel %d", bpp); return 0; }
+    ThreadCtx *c = thread_ctx();
+    if (!c) return 0;
+    // the reference fetches, per pixel, the two 16-bit words that hold it; packed_bits
+    // starts at the word of the first requested pixel
+    const uint32_t first_word = first_px * (uint32_t)bpp / 16;
+    const uint64_t last_bit = (uint64_t)(first_px + npix - 1) * bpp;
+    const size_t words = (size_t)(last_bit / 16 - first_word) + 2;
+    const size_t in_bytes = words * 2, out_b = (size_t)npix * 2;
+    if (c->ensure((in_bytes + 15) / 16 * 16, out_b)) return 0;
+    if (hipMemcpyAsync(c->d_a, packed_bits, in_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+        set_error("dng_get_image_data: upload failed");
+        return 0;
+    }
+    if (launch_unpack(c->d_a, 0, c->d_b, 0, first_px, npix, bpp, 1, c->stream)) return 0;
+    if (download(c, output_buffer + lead + offset % 2, c->d_b, out_b)) return 0;
+    return max_size;
+}
+
+// ============================================================== cs.h
+void chroma_smooth(struct frame_headers *fh, uint16_t *image_data, int method)
+{
+    const FrameView v = view_of(fh);
+    if (v.black > 16384) { fprintf(stderr, "Black level too large for processing\n"); return; }   // main.c:170-174
+    if (method != 2 && method != 3 && method != 5) { fprintf(stderr, "Unsupported chroma smooth method\n"); return; }
+    ThreadCtx *c = thread_ctx();
+    if (!c) return;
+    const size_t bytes = (size_t)v.w * v.h * 2;
+    if (upload(c, image_data, bytes)) return;
+    if (launch_frame(c->dev, Geom{ v.w, v.h, v.bpp, v.black, v.white }, false, c->d_a, bytes, c->d_b, bytes, 1, method,
+                     nullptr, 0, false, nullptr, c->stream))
+        return;
+    download(c, image_data, c->d_b, bytes);
+}
+
+void fix_bad_pixels(struct frame_headers *fh, uint16_t *image_data, int aggressive, int dual_iso)
+{
+    const FrameView v = view_of(fh);
+    if (v.black > 16384) { fprintf(stderr, "Black level too large for processing\n"); return; }
+    ThreadCtx *c = thread_ctx();
+    if (!c) return;
+    const size_t bytes = (size_t)v.w * v.h * 2;
+    std::lock_guard<std::mutex> lk(g_bad_mutex);
+
+    BadMap *map = nullptr;
+    for (int i = 0; i < BAD_PIXEL_MAP_COUNT; i++)                                    // cs.c:233-239
+        if (v.guid && v.guid == g_bad_maps[i].guid && aggressive == g_bad_maps[i].aggressive && g_bad_maps[i].clip &&
+            g_bad_maps[i].w == v.w && g_bad_maps[i].h == v.h && g_bad_maps[i].clip->device == c->dev->id)
+            map = &g_bad_maps[i];
+    bool uploaded = false;
+    if (!map) {
+        map = &g_bad_maps[g_bad_next];
+        g_bad_next = (g_bad_next + 1) % BAD_PIXEL_MAP_COUNT;
+        delete map->clip;
+        map->clip = make_clip(v, c);
+        map->guid = v.guid; map->aggressive = aggressive; map->w = v.w; map->h = v.h; map->dual_iso = dual_iso;
+        if (upload(c, image_data, bytes)) return;
+        uploaded = true;
+        if (map->clip->detect_bad_pixels(c->d_a, aggressive, dual_iso, c->stream)) return;
+        const int crop_x = (v.pan_x + 7) & ~7, crop_y = v.pan_y & ~1;
+        const size_t n = map->clip->xy.size() / 2;
+        printf("%zu bad pixels found for %llx (crop: %d, %d):\n", n, (unsigned long long)v.guid, crop_x, crop_y);   // cs.c:307-311
+        for (size_t m = 0; m < n; m++) printf("%d %d\n", map->clip->xy[2 * m], map->clip->xy[2 * m + 1]);
+    } else if (map->dual_iso != dual_iso) {
+        std::vector<int32_t> xy = map->clip->xy;
+        map->clip->pan_x = v.pan_x; map->clip->pan_y = v.pan_y;
+        if (map->clip->set_pixel_map(xy.data(), xy.size() / 2, 0, dual_iso)) return;
+        map->dual_iso = dual_iso;
+    }
+    if (map->clip->n_entries == 0) return;                                           // nothing to repair
+    map->clip->g.black = v.black;
+    if (!uploaded && upload(c, image_data, bytes)) return;
+    if (map->clip->fix_pixels(c->d_a, bytes, 1, c->stream)) return;
+    download(c, image_data, c->d_a, bytes);
+}
+
+static FocusMap *load_focus_map(uint32_t camera, int raw_w, int raw_h)               // cs.c:356-401
+{
+    FocusMap *m = new FocusMap;
+    m->camera = camera; m->raw_w = raw_w; m->raw_h = raw_h;
+    g_focus_maps.push_back(m);
+    char filename[1024];
+    snprintf(filename, sizeof filename, "%x_%ix%i.fpm", camera, raw_w, raw_h);
+    FILE *f = fopen(filename, "r+");                                                 // relative to the CWD, like the reference
+    if (!f) return m;
+    printf("Loading focus pixel map '%s'...\n", filename);
+    int x = 0, y = 0, ret = 2;
+    while (ret != EOF) {
+        ret = fscanf(f, "%i %i", &x, &y);
+        if (ret == 2) { m->xy.push_back(x); m->xy.push_back(y); }
+        else if (ferror(f)) { fprintf(stderr, "file error: %s\n", strerror(errno)); break; }
+        else if (ret != EOF) break;                                                  // unparsable token: stop instead of spinning
+    }
+    fclose(f);
+    return m;
+}
+
+void fix_focus_pixels(struct frame_headers *fh, uint16_t *image_data, int dual_iso)
+{
+    const FrameView v = view_of(fh);
+    const uint32_t camera = fh->idnt_hdr.cameraModel;
+    const int raw_w = fh->rawi_hdr.raw_info.width, raw_h = fh->rawi_hdr.raw_info.height;
+    std::lock_guard<std::mutex> lk(g_focus_mutex);
+    FocusMap *fm = nullptr;
+    for (FocusMap *m : g_focus_maps)
+        if (m->camera == camera && m->raw_w == raw_w && m->raw_h == raw_h) fm = m;
+    if (!fm) fm = load_focus_map(camera, raw_w, raw_h);
+    if (fm->xy.empty()) return;                                                      // no map for this camera: no-op
+    if (v.black > 16384) { fprintf(stderr, "raw2ev LUT error\n"); return; }
+    ThreadCtx *c = thread_ctx();
+    if (!c) return;
+    char key[128];
+    snprintf(key, sizeof key, "%d:%dx%d:%d,%d:%d", c->dev->id, v.w, v.h, v.pan_x, v.pan_y, dual_iso);
+    Clip *&clip = fm->clips[key];
+    if (!clip) {
+        clip = make_clip(v, c);
+        if (clip->set_pixel_map(fm->xy.data(), fm->xy.size() / 2, 1, dual_iso)) return;
+    }
+    if (clip->n_entries == 0) return;
+    clip->g.black = v.black;
+    const size_t bytes = (size_t)v.w * v.h * 2;
+    if (upload(c, image_data, bytes)) return;
+    if (clip->fix_pixels(c->d_a, bytes, 1, c->stream)) return;
+    download(c, image_data, c->d_a, bytes);
+}
+
+void free_focus_pixel_maps(void)                                                     // cs.c:403-418
+{
+    {
+        std::lock_guard<std::mutex> lk(g_focus_mutex);
+        for (FocusMap *m : g_focus_maps) {
+            for (auto &kv : m->clips) delete kv.second;
+            delete m;
+        }
+        g_focus_maps.clear();
+    }
+    std::lock_guard<std::mutex> lk(g_bad_mutex);
+    for (auto &bm : g_bad_maps) { delete bm.clip; bm = BadMap(); }
+}
+
+// ============================================================== stripes.h
+static struct stripes_correction *g_corrections = nullptr;
+static std::mutex g_corr_mutex;
+
+struct stripes_correction *stripes_get_correction(const char *mlv_filename)          // stripes.c:31-38
+{
+    std::lock_guard<std::mutex> lk(g_corr_mutex);
+    for (struct stripes_correction *cur = g_corrections; cur; cur = cur->next)
+        if (!strcmp(cur->mlv_filename, mlv_filename)) return cur;
+    return nullptr;
+}
+
+struct stripes_correction *stripes_new_correction(const char *mlv_filename)          // stripes.c:40-69
+{
+    // the reference leaves the coefficients uninitialised; they start at 0 here
+    // (a 0 coefficient means "leave this column alone", stripes.c:261)
+    struct stripes_correction *n = (struct stripes_correction *)calloc(1, sizeof *n);
+    if (!n) return nullptr;
+    n->mlv_filename = (char *)malloc(strlen(mlv_filename) + 2);
+    if (!n->mlv_filename) { free(n); return nullptr; }
+    strcpy(n->mlv_filename, mlv_filename);
+    std::lock_guard<std::mutex> lk(g_corr_mutex);
+    if (!g_corrections) g_corrections = n;
+    else {
+        struct stripes_correction *cur = g_corrections;
+        while (cur->next) cur = cur->next;
+        cur->next = n;
+    }
+    return n;
+}
+
+void stripes_free_corrections(void)                                                  // stripes.c:71-83
+{
+    std::lock_guard<std::mutex> lk(g_corr_mutex);
+    struct stripes_correction *cur = g_corrections;
+    while (cur) {
+        struct stripes_correction *next = cur->next;
+        free(cur->mlv_filename);
+        free(cur);
+        cur = next;
+    }
+    g_corrections = nullptr;
+}
+
+void stripes_compute_correction(struct frame_headers *fh, struct stripes_correction *correction, uint16_t *image_data,
+                                off_t offset, size_t size)
+{
+    (void)offset; (void)size;                       // the reference ignores both and walks xRes x yRes (stripes.c:153-156)
+    if (!correction) return;
+    const FrameView v = view_of(fh);
+    ThreadCtx *c = thread_ctx();
+    if (!c) return;
+    const size_t bytes = (size_t)v.w * v.h * 2;
+    if (upload(c, image_data, bytes)) return;
+    Clip *clip = make_clip(v, c);
+    memcpy(clip->coef, correction->coeffficients, sizeof clip->coef);
+    if (clip->stripes_compute(c->d_a, v.frame_size, /*rand_mode=*/0, c->stream) == MLVFS_AMD_OK) {
+        memcpy(correction->coeffficients, clip->coef, sizeof clip->coef);
+        correction->correction_needed = clip->needed;
+    }
+    delete clip;
+}
+
+void stripes_apply_correction(struct frame_headers *fh, struct stripes_correction *correction, uint16_t *image_data,
+                              off_t offset, size_t size)
+{
+    if (!correction || !correction->correction_needed) return;                       // stripes.c:252-253
+    const FrameView v = view_of(fh);
+    if (v.w % 8 != 0 || size == 0) return;
+    ThreadCtx *c = thread_ctx();
+    if (!c) return;
+    // pixel i uses coefficient (i + offset % 8) % 8: rotate the table instead
+    int32_t coef[8];
+    const int start = (int)(((offset % 8) + 8) % 8);
+    for (int k = 0; k < 8; k++) coef[k] = correction->coeffficients[(k + start) % 8];
+    const size_t padded = (size + 7) / 8 * 8, bytes = padded * 2;
+    if (c->ensure(bytes, 0)) return;
+    if (padded != size && hipMemsetAsync(c->d_a, 0, bytes, c->stream) != hipSuccess) return;
+    if (hipMemcpyAsync(c->d_a, image_data, size * 2, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+        set_error("stripes_apply_correction: upload failed");
+        return;
+    }
+    if (launch_stripes_apply(c->d_a, bytes, padded, v.w, v.black, v.white, coef, 1, c->stream)) return;
+    download(c, image_data, c->d_a, size * 2);
+}
+
+// ============================================================== histogram.h (host only)
+struct histogram *hist_create(uint16_t white)                                        // histogram.c:33-47
+{
+    struct histogram *h = (struct histogram *)malloc(sizeof *h);
+    if (!h) return nullptr;
+    h->white = white;
+    h->count = 0;
+    h->data = (uint16_t *)calloc((size_t)white + 1, sizeof(uint16_t));
+    return h;
+}
+
+void hist_add(struct histogram *h, uint16_t *data, uint32_t size, uint16_t skip)     // histogram.c:52-59
+{
+    const uint32_t step = (uint32_t)skip + 1;
+    for (uint32_t i = 0; i < size; i += step) h->data[data[i] < h->white ? data[i] : h->white]++;   // 16-bit counters wrap
+    h->count += size / step;
+}
+
+uint16_t hist_median(struct histogram *h)                                            // histogram.c:64-75
+{
+    const uint32_t middle = h->count / 2;
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i <= h->white; i++) {
+        acc += h->data[i];
+        if (acc > middle) return (uint16_t)i;
+    }
+    return 0;
+}
+
+void hist_destroy(struct histogram *h) { if (h) { free(h->data); free(h); } }
+
+}  // extern "C"

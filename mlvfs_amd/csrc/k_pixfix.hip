@@ -1,0 +1,210 @@
+// k_pixfix.hip -- bad-pixel detection and ORDERED pixel repair.
+//
+// Replaces mlvfs/cs.c:87-168 (interpolate_horizontal/vertical/pixel),
+// cs.c:255-306 (detection loop of fix_bad_pixels) and the application loops of
+// fix_bad_pixels (cs.c:314-330) and fix_focus_pixels (cs.c:463-500).
+//
+// Ordering.  The reference repairs the list sequentially in place, so an entry
+// may read a pixel that an EARLIER entry already rewrote (taps at +-1,+-2,+-3
+// along x and y).  The host (clip.cpp) turns the list into a dependency graph
+// once per clip: per entry and tap the index of the latest earlier entry at that
+// position (or -1), and a level = 1 + max(level of its dependencies).  The GPU
+// then processes level after level in parallel; a tap with a dependency reads the
+// dependency's repaired value, every other tap reads the ORIGINAL frame (nothing
+// is written back until all levels are done), which is exactly the sequential
+// semantics.  The result is a per-frame patch list {position, value}; it is
+// either scattered into the 16-bit frame (in-place entry points) or consumed by
+// the fused kernel's tile loader (k_frame.hip), which never materialises the
+// intermediate frame.
+#include "clip.h"
+
+namespace mlv {
+
+
+// tap order: x-3, x-2, x-1, x+1, x+2, x+3, y-3, y-2, y-1, y+1, y+2, y+3
+__device__ __forceinline__ int tap_offset(int t, int w)
+{
+    const int d = (t % 6) < 3 ? (t % 6) - 3 : (t % 6) - 2;
+    return t < 6 ? d : d * w;
+}
+
+template <bool PACKED>
+__device__ __forceinline__ int fetch_px(const uint8_t *frame, int pos)
+{
+    if (PACKED) {
+        const uint16_t *s = (const uint16_t *)frame;
+        const size_t bit = (size_t)pos * 14;
+        const uint32_t two = ((uint32_t)s[bit >> 4] << 16) | s[(bit >> 4) + 1];
+        return (int)((two >> (32 - 14 - (bit & 15))) & 0x3FFFu);
+    }
+    return ((const uint16_t *)frame)[pos];
+}
+
+__device__ __forceinline__ int sdiv_safe(int a, int b) { return (a == (int)0x80000000 && b == -1) ? a : a / b; }
+
+// one repaired value; tap(t) returns the pixel value the sequential algorithm would see
+template <typename Tap>
+__device__ __forceinline__ int repair_value(int kind, int black, const uint16_t *t16, const uint16_t *u16, Tap tap)
+{
+    auto ev = [&](int t) { return ev_of_pixel(tap(t), black, t16); };
+    if (kind == 4) return tap(4);
+    if (kind == 5) return tap(1);
+    if (kind == 2 || kind == 3) {                       // cs.c:87-129
+        const int b = kind == 2 ? 0 : 6;                // tap base: x taps 0..5, y taps 6..11
+        const int dp = wabs(wsub(ev(b + 5), ev(b + 3)));
+        const int dm = wabs(wsub(ev(b + 2), ev(b + 0)));
+        const int sum = wadd(dp, dm);
+        if (sum == 0) return tap(b + 4);
+        const int cp = sdiv_safe((int)((unsigned)wsub(sum, dp) << 8), sum);
+        const int cm = sdiv_safe((int)((unsigned)wsub(sum, dm) << 8), sum);
+        const int e = wadd(wmul(ev(b + 4), cp) >> 8, wmul(ev(b + 1), cm) >> 8);
+        return pixel_of_ev(e, black, u16);
+    }
+    // cross, cs.c:131-168
+    const int vp = wabs(wsub(ev(11), ev(9))), vm = wabs(wsub(ev(8), ev(6)));
+    const int hp = wabs(wsub(ev(5), ev(3))), hm = wabs(wsub(ev(2), ev(0)));
+    const int sum = wadd(wadd(hp, hm), wadd(vp, vm));
+    if (sum == 0) return tap(4);
+    const int den = wmul(3, sum);
+    const int cvp = sdiv_safe((int)((unsigned)wsub(sum, vp) << 8), den);
+    const int cvm = sdiv_safe((int)((unsigned)wsub(sum, vm) << 8), den);
+    const int chp = sdiv_safe((int)((unsigned)wsub(sum, hp) << 8), den);
+    const int chm = sdiv_safe((int)((unsigned)wsub(sum, hm) << 8), den);
+    const int e = wadd(wadd(wmul(ev(10), cvp) >> 8, wmul(ev(7), cvm) >> 8),
+                       wadd(wmul(ev(4), chp) >> 8, wmul(ev(1), chm) >> 8));
+    return pixel_of_ev(e, black, u16);
+}
+
+// one workgroup per frame; levels are separated by workgroup barriers
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_pixfix(const uint8_t *__restrict__ frames, size_t stride, int w, int black,
+                                                const PixEntry *__restrict__ entries, const int *__restrict__ level_off,
+                                                int n_levels, int n_entries, int2 *__restrict__ patches,
+                                                uint16_t *scatter_base, size_t scatter_stride,
+                                                const uint16_t *__restrict__ t16, const uint16_t *__restrict__ u16)
+{
+    const uint8_t *frame = frames + (size_t)blockIdx.x * stride;
+    int2 *out = patches + (size_t)blockIdx.x * n_entries;
+    for (int lv = 0; lv < n_levels; lv++) {
+        const int beg = level_off[lv], end = level_off[lv + 1];
+        for (int m = beg + threadIdx.x; m < end; m += blockDim.x) {
+            const PixEntry e = entries[m];
+            int val = 0;
+            if (e.kind != 0) {
+                auto tap = [&](int t) {
+                    const int d = e.dep[t];
+                    return d >= 0 ? out[d].y : fetch_px<PACKED>(frame, e.pos + tap_offset(t, w));
+                };
+                val = repair_value(e.kind, black, t16, u16, tap) & 0xFFFF;
+            }
+            out[m] = make_int2((e.kind != 0 && e.emit) ? e.pos : -1, val);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (scatter_base) {
+        uint16_t *img = (uint16_t *)((uint8_t *)scatter_base + (size_t)blockIdx.x * scatter_stride);
+        for (int m = threadIdx.x; m < n_entries; m += blockDim.x) {
+            const int2 p = out[m];
+            if (p.x >= 0) img[p.x] = (uint16_t)p.y;
+        }
+    }
+}
+
+int launch_pixfix(bool packed, const void *frames, size_t stride, int w, int black, const void *entries,
+                  const int *level_off, int n_levels, int n_entries, void *patches, void *scatter, size_t scatter_stride,
+                  int nframes, const DeviceLuts &luts, hipStream_t stream)
+{
+    if (n_entries <= 0 || nframes <= 0) return MLVFS_AMD_OK;
+    if (packed)
+        hipLaunchKernelGGL(k_pixfix<true>, dim3(nframes), dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
+                           (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches,
+                           (uint16_t *)scatter, scatter_stride, luts.t16, luts.u16);
+    else
+        hipLaunchKernelGGL(k_pixfix<false>, dim3(nframes), dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
+                           (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches,
+                           (uint16_t *)scatter, scatter_stride, luts.t16, luts.u16);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+// ------------------------------------------------------------------ detection
+// pass 1: one lane per pixel; per 64-pixel span a ballot word, per row a count
+__global__ __launch_bounds__(256) void k_badpix_flags(const uint16_t *__restrict__ img, int w, int h, int black,
+                                                      int aggressive, unsigned long long *__restrict__ mask,
+                                                      int words_per_row, int *__restrict__ row_count,
+                                                      const uint16_t *__restrict__ t16)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    bool bad = false;
+    if (x >= 6 && x < w - 6 && y >= 6 && y < h - 6) {
+        const int p = img[x + (size_t)y * w];
+        int t0 = -1, t1 = -1, t2 = -1;                 // three largest same-colour neighbours
+#pragma unroll
+        for (int dy = -2; dy <= 2; dy += 2)
+#pragma unroll
+            for (int dx = -2; dx <= 2; dx += 2) {
+                if (dx == 0 && dy == 0) continue;
+                const int q = img[(x + dx) + (size_t)(y + dy) * w];
+                if (q >= t0) { t2 = t1; t1 = t0; t0 = q; }
+                else if (q >= t1) { t2 = t1; t1 = q; }
+                else if (q > t2) { t2 = q; }
+            }
+        const int dark_lo = black - 96, dark_hi = black + 96;       // cs.c:255-257
+        if (p < dark_lo) bad = true;
+        else {
+            const int ep = ev_of_pixel(p, black, t16);
+            const int d1 = wsub(ep, ev_of_pixel(t1, black, t16));
+            if (d1 > 2 * MLV_EV_RES && p > dark_hi) bad = true;
+            else if (aggressive) {
+                const int d2 = wsub(ep, ev_of_pixel(t2, black, t16));
+                if ((d1 > MLV_EV_RES || d2 > MLV_EV_RES) && p > dark_hi) bad = true;
+            }
+        }
+    }
+    const unsigned long long b = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && x < words_per_row * 64) {
+        mask[(size_t)y * words_per_row + x / 64] = b;
+        if (b) atomicAdd(&row_count[y], __popcll(b));
+    }
+}
+
+// pass 2: one workgroup per row; raster order = rows in order, bits in order
+__global__ __launch_bounds__(64) void k_badpix_compact(const unsigned long long *__restrict__ mask, int words_per_row,
+                                                       const int *__restrict__ row_count, int crop_x, int crop_y,
+                                                       int2 *__restrict__ list, int cap)
+{
+    const int y = blockIdx.x;
+    if (row_count[y] == 0) return;
+    int part = 0;
+    for (int r = threadIdx.x; r < y; r += 64) part += row_count[r];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (threadIdx.x != 0) return;
+    int at = part;
+    for (int wd = 0; wd < words_per_row; wd++) {
+        unsigned long long b = mask[(size_t)y * words_per_row + wd];
+        while (b) {
+            const int bit = __ffsll((long long)b) - 1;
+            b &= b - 1;
+            if (at < cap) list[at] = make_int2(wd * 64 + bit + crop_x, y + crop_y);
+            at++;
+        }
+    }
+}
+
+int launch_badpix_detect(const void *d_frame, int w, int h, int black, int aggressive, int crop_x, int crop_y,
+                         void *d_mask, int words_per_row, int *d_row_count, void *d_list, int cap,
+                         const DeviceLuts &luts, hipStream_t stream)
+{
+    MLV_HIP(hipMemsetAsync(d_row_count, 0, sizeof(int) * h, stream));
+    dim3 grid(words_per_row * 64 / 256 + ((words_per_row * 64) % 256 ? 1 : 0), h);
+    hipLaunchKernelGGL(k_badpix_flags, grid, dim3(256), 0, stream, (const uint16_t *)d_frame, w, h, black, aggressive,
+                       (unsigned long long *)d_mask, words_per_row, d_row_count, luts.t16);
+    hipLaunchKernelGGL(k_badpix_compact, dim3(h), dim3(64), 0, stream, (const unsigned long long *)d_mask, words_per_row,
+                       d_row_count, crop_x, crop_y, (int2 *)d_list, cap);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+}  // namespace mlv

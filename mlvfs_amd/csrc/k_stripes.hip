@@ -1,0 +1,235 @@
+// k_stripes.hip -- vertical-stripe correction: histogram pass for the per-clip
+// coefficients and the stand-alone apply pass.
+//
+// Replaces stripes_compute_correction's raster loop (mlvfs/stripes.c:143-205,
+// add_pixel :108-140) and stripes_apply_correction (:250-266).
+//
+// Bit-exactness of the histogram:
+//  * every ACCEPTED add_pixel call consumes two rand() values in raster order.
+//    Pass 1 counts the accepted calls per 8-pixel group, an exclusive scan turns
+//    the counts into each group's offset into the rand() stream, pass 2 indexes
+//    a pre-generated stream of rand()%1024 values (host: libc rand() itself or
+//    the glibc-compatible generator in stripes_host.cpp).
+//  * the bin is (int)(32768 + log2(af/bf) * 32768) in double.  The division and
+//    the final add are IEEE-exact on the GPU; the device log2 may differ from
+//    glibc's in the last ulp, so a sample whose bin position lies within 1e-6 of
+//    a bin edge is not binned on the device: it is appended to a small "recheck"
+//    list and the host bins it with its own libm (mlvfs_amd_stripes_* in clip.cpp).
+#include "clip.h"
+
+namespace mlv {
+
+// the 24 add_pixel calls of a group (stripes.c:175-203): histogram, reference px, corrected px
+// pixel slots 0..9 = pa..ph, pa2, pb2
+__constant__ unsigned char k_call[24][3] = {
+    {2,0,2},{2,0,2},{2,0,2},{2,8,2},  {3,1,3},{3,1,3},{3,1,3},{3,9,3},
+    {4,0,4},{4,0,4},{4,8,4},{4,8,4},  {5,1,5},{5,1,5},{5,9,5},{5,9,5},
+    {6,0,6},{6,8,6},{6,8,6},{6,8,6},  {7,1,7},{7,9,7},{7,9,7},{7,9,7},
+};
+
+struct Recheck { int hist, a, b, r1, r2; };
+
+__device__ __forceinline__ bool accepted(int a, int b, double too_bright)
+{
+    const int lo = min(a, b), hi = max(a, b);
+    return !(lo < 32) && !((double)hi > too_bright);            // stripes.c:113-117
+}
+
+__device__ __forceinline__ void load_group(const uint16_t *row, int x, int black, int (&px)[10])
+{
+#pragma unroll
+    for (int k = 0; k < 10; k++) px[k] = (int)row[x + k] - black;
+}
+
+// pass 1: accepted calls per group; per-block totals
+__global__ __launch_bounds__(256) void k_stripes_count(const uint16_t *__restrict__ img, int w, int row0, int groups_per_row,
+                                                       int n_groups, int black, double too_bright,
+                                                       unsigned char *__restrict__ counts, int *__restrict__ block_sum)
+{
+    __shared__ int wsum[4];
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    int c = 0;
+    if (g < n_groups) {
+        const int y = row0 + g / groups_per_row, x = (g % groups_per_row) * 8;
+        int px[10];
+        load_group(img + (size_t)y * w, x, black, px);
+#pragma unroll
+        for (int i = 0; i < 24; i++) c += accepted(px[k_call[i][1]], px[k_call[i][2]], too_bright) ? 1 : 0;
+        counts[g] = (unsigned char)c;
+    }
+    int s = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of the block totals (single workgroup, n up to a few thousand)
+__global__ __launch_bounds__(1024) void k_scan_blocks(const int *__restrict__ block_sum, int n,
+                                                      long long *__restrict__ block_off, long long *__restrict__ total)
+{
+    __shared__ long long carry;
+    __shared__ long long wtot[16];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const long long v = i < n ? block_sum[i] : 0;
+        long long inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long up = __shfl_up(inc, o);
+            if ((threadIdx.x & 63) >= o) inc += up;
+        }
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        long long before = carry;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); k++) before += wtot[k];
+        if (i < n) block_off[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+// pass 2: histogram
+__global__ __launch_bounds__(256) void k_stripes_hist(const uint16_t *__restrict__ img, int w, int row0, int groups_per_row,
+                                                      int n_groups, int black, double too_bright,
+                                                      const unsigned char *__restrict__ counts,
+                                                      const long long *__restrict__ block_off,
+                                                      const uint16_t *__restrict__ rnd, long long n_rand,
+                                                      int *__restrict__ hist, int *__restrict__ num,
+                                                      Recheck *__restrict__ recheck, int recheck_cap, int *__restrict__ n_recheck)
+{
+    __shared__ int wtot[4];
+    __shared__ int lnum[8];
+    if (threadIdx.x < 8) lnum[threadIdx.x] = 0;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int c = g < n_groups ? counts[g] : 0;
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o);
+        if ((threadIdx.x & 63) >= o) inc += up;
+    }
+    if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    long long call = block_off[blockIdx.x] + (inc - c);          // accepted calls before this group
+    for (int k = 0; k < (int)(threadIdx.x >> 6); k++) call += wtot[k];
+
+    if (g < n_groups && c > 0) {
+        const int y = row0 + g / groups_per_row, x = (g % groups_per_row) * 8;
+        int px[10];
+        load_group(img + (size_t)y * w, x, black, px);
+#pragma unroll 1
+        for (int i = 0; i < 24; i++) {
+            const int j = k_call[i][0], a = px[k_call[i][1]], b = px[k_call[i][2]];
+            if (!accepted(a, b, too_bright)) continue;
+            const long long ri = 2 * call;
+            call++;
+            if (ri + 1 >= n_rand) continue;                         // host sized the stream; never taken
+            const int r1 = rnd[ri], r2 = rnd[ri + 1];
+            const double af = a + r1 / 1024.0 - 0.5;               // stripes.c:129-130
+            const double bf = b + r2 / 1024.0 - 0.5;
+            const double ev = log2(af / bf);
+            const double pos = 65536 / 2 + ev * 65536 / 2;          // F2H, stripes.c:105
+            const double nearest = rint(pos);
+            if (fabs(pos - nearest) < 1e-6) {
+                const int slot = atomicAdd(n_recheck, 1);
+                if (slot < recheck_cap) recheck[slot] = Recheck{ j, a, b, r1, r2 };
+            } else {
+                int bin = (int)pos;
+                bin = bin < 0 ? 0 : (bin > 65535 ? 65535 : bin);
+                atomicAdd(&hist[j * 65536 + bin], 1);
+            }
+            atomicAdd(&lnum[j], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && lnum[threadIdx.x]) atomicAdd(&num[threadIdx.x], lnum[threadIdx.x]);
+}
+
+// stand-alone apply (the fused kernel has its own epilogue): 8 px per lane
+__global__ __launch_bounds__(256) void k_stripes_apply(uint8_t *__restrict__ frames, size_t stride, size_t n_vec,
+                                                       int black16, int white16, int c0, int c1, int c2, int c3, int c4,
+                                                       int c5, int c6, int c7)
+{
+    const int coef[8] = { c0, c1, c2, c3, c4, c5, c6, c7 };
+    uint4 *img = (uint4 *)(frames + (size_t)blockIdx.y * stride);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * blockDim.x) {
+        uint4 v = img[i];
+        uint32_t d[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t lo = d[k] & 0xFFFFu, hi = d[k] >> 16;
+            {
+                const int cf = coef[2 * k];
+                if (cf != 0 && (int)lo > black16 + 64) {
+                    const long long nm = (long long)((int)lo - black16) * cf + ((long long)black16 << 16);
+                    lo = (((long long)white16 << 16) < nm) ? (uint32_t)white16 : ((uint32_t)(int)(nm / 65536) & 0xFFFFu);
+                }
+            }
+            {
+                const int cf = coef[2 * k + 1];
+                if (cf != 0 && (int)hi > black16 + 64) {
+                    const long long nm = (long long)((int)hi - black16) * cf + ((long long)black16 << 16);
+                    hi = (((long long)white16 << 16) < nm) ? (uint32_t)white16 : ((uint32_t)(int)(nm / 65536) & 0xFFFFu);
+                }
+            }
+            d[k] = lo | (hi << 16);
+        }
+        img[i] = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+int stripes_groups_per_row(int w) { return w > 10 ? (w - 10 + 7) / 8 : 0; }
+
+int launch_stripes_count(const void *d_frame, int w, int row0, int row1, int black, int white, unsigned char *d_counts,
+                         int *d_block_sum, long long *d_block_off, long long *d_total, hipStream_t stream)
+{
+    const int gpr = stripes_groups_per_row(w), n_groups = gpr * (row1 - row0);
+    if (n_groups <= 0) { MLV_HIP(hipMemsetAsync(d_total, 0, sizeof(long long), stream)); return MLVFS_AMD_OK; }
+    const int nblk = (n_groups + 255) / 256;
+    hipLaunchKernelGGL(k_stripes_count, dim3(nblk), dim3(256), 0, stream, (const uint16_t *)d_frame, w, row0, gpr, n_groups,
+                       black, white / 1.5, d_counts, d_block_sum);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, d_block_sum, nblk, d_block_off, d_total);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+int launch_stripes_hist(const void *d_frame, int w, int row0, int row1, int black, int white, const unsigned char *d_counts,
+                        const long long *d_block_off, const void *d_rand, long long n_rand, int *d_hist, int *d_num,
+                        void *d_recheck, int recheck_cap, int *d_n_recheck, hipStream_t stream)
+{
+    const int gpr = stripes_groups_per_row(w), n_groups = gpr * (row1 - row0);
+    if (n_groups <= 0) return MLVFS_AMD_OK;
+    const int nblk = (n_groups + 255) / 256;
+    hipLaunchKernelGGL(k_stripes_hist, dim3(nblk), dim3(256), 0, stream, (const uint16_t *)d_frame, w, row0, gpr, n_groups,
+                       black, white / 1.5, d_counts, d_block_off, (const uint16_t *)d_rand, n_rand, d_hist, d_num,
+                       (Recheck *)d_recheck, recheck_cap, d_n_recheck);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+int launch_stripes_apply(void *d_frames, size_t stride, size_t npix, int w, int black, int white, const int32_t *coef,
+                         int nframes, hipStream_t stream)
+{
+    if (w % 8 != 0) return MLVFS_AMD_OK;                 // stripes.c:253
+    if (npix % 8 != 0 || ((uintptr_t)d_frames % 16) != 0 || (nframes > 1 && stride % 16 != 0)) {
+        set_error("stripes apply needs 16-byte aligned frames of a multiple of 8 pixels");
+        return MLVFS_AMD_ERR_ARG;
+    }
+    const size_t n_vec = npix / 8;
+    dim3 grid((unsigned)((n_vec + 255) / 256), nframes);
+    if (grid.x > 4096) grid.x = 4096;
+    hipLaunchKernelGGL(k_stripes_apply, grid, dim3(256), 0, stream, (uint8_t *)d_frames, stride, n_vec,
+                       (int)(uint16_t)black, (int)(uint16_t)white, coef[0], coef[1], coef[2], coef[3], coef[4], coef[5],
+                       coef[6], coef[7]);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+}  // namespace mlv

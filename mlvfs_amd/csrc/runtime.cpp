@@ -1,0 +1,203 @@
+// runtime.cpp -- host runtime of libmlvfs_amd.so: error string, EV tables and
+// their exact 16-bit re-encodings, per-device state, per-thread contexts.
+//
+// Threading model (SURVEY.md 8b "Threading"): libfuse calls the exported
+// functions from a pool of worker threads, one frame per call.  Each host thread
+// gets its own HIP stream and staging buffers per device (thread_local), devices
+// are shared read-only (tables), per-clip state is guarded by its own mutex.
+// Threads that never called mlvfs_amd_init() are spread round-robin over the
+// visible GPUs, which is the frame-parallel multi-GPU mode of the drop-in path.
+#include "common.h"
+
+#include <atomic>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+// caller-provided tables (mlvfs/mlvfs.h:90-92); absent when the library is used
+// stand-alone (tests, bench)
+extern "C" {
+int *get_raw2ev(int black) __attribute__((weak));
+int *get_ev2raw(void) __attribute__((weak));
+}
+
+namespace mlv {
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "mlvfs_amd: %s\n", g_err);
+}
+
+// ------------------------------------------------------------------ tables
+static std::once_flag g_lut_once;
+static std::vector<int32_t> g_raw2ev_lin, g_ev2raw;
+static std::vector<uint16_t> g_t16, g_u16;
+static int g_luts_ok = 0;
+
+static void build_luts()
+{
+    g_raw2ev_lin.assign(16384, 0);
+    g_ev2raw.assign(24 * MLV_EV_RES, 0);
+    int *caller_r2e = get_raw2ev ? get_raw2ev(0) : nullptr;
+    int *caller_e2r = get_ev2raw ? get_ev2raw() : nullptr;
+    for (int i = 0; i < 16384; i++) {
+        if (caller_r2e) g_raw2ev_lin[i] = caller_r2e[i];
+        else g_raw2ev_lin[i] = i == 0 ? INT_MIN : (int32_t)(log2((double)i) * MLV_EV_RES);   // main.c:163-167
+    }
+    for (int i = -10 * MLV_EV_RES; i < 14 * MLV_EV_RES; i++) {
+        if (caller_e2r) g_ev2raw[i + 10 * MLV_EV_RES] = caller_e2r[i];
+        else g_ev2raw[i + 10 * MLV_EV_RES] = (int32_t)pow(2.0, (double)((float)i / MLV_EV_RES));   // main.c:189-192
+    }
+    // 16-bit re-encodings + exhaustive identity check against the full tables
+    g_t16.resize(MLV_T16_N);
+    g_u16.resize(MLV_U16_N);
+    int ok = 1;
+    for (int j = 8192; j < 16384; j++) {
+        int v = g_raw2ev_lin[j] - 13 * MLV_EV_RES;
+        if (v < 0 || v > 65535) ok = 0;
+        g_t16[j - 8192] = (uint16_t)v;
+    }
+    for (int f = 0; f < MLV_U16_N; f++) {
+        int v = g_ev2raw[(13 + 10) * MLV_EV_RES + f];
+        if (v < 0 || v > 65535) ok = 0;
+        g_u16[f] = (uint16_t)v;
+    }
+    if (g_raw2ev_lin[0] != INT_MIN) ok = 0;
+    for (int i = 1; i < 16384 && ok; i++) {
+        int e = 31 - __builtin_clz(i);
+        int rec = (int)g_t16[(i << (13 - e)) - 8192] + (e << 15);
+        if (rec != g_raw2ev_lin[i]) ok = 0;
+    }
+    for (int ev = 0; ev < 14 * MLV_EV_RES && ok; ev++) {
+        int q = ev >> 15, f = ev & 32767;
+        if ((g_u16[f] >> (13 - q)) != g_ev2raw[ev + 10 * MLV_EV_RES]) ok = 0;
+    }
+    g_luts_ok = ok;
+    if (!ok) set_error("host EV tables do not admit the 16-bit re-encoding (unexpected libm)");
+}
+
+static void ensure_luts() { std::call_once(g_lut_once, build_luts); }
+const int32_t *host_raw2ev_lin() { ensure_luts(); return g_raw2ev_lin.data(); }
+const int32_t *host_ev2raw() { ensure_luts(); return g_ev2raw.data(); }
+const uint16_t *host_t16() { ensure_luts(); return g_t16.data(); }
+const uint16_t *host_u16() { ensure_luts(); return g_u16.data(); }
+int luts_ok() { ensure_luts(); return g_luts_ok; }
+
+// ------------------------------------------------------------------ devices
+static std::mutex g_dev_mutex;
+static std::map<int, Device *> g_devices;
+
+static Device *get_device(int id)
+{
+    std::lock_guard<std::mutex> lk(g_dev_mutex);
+    auto it = g_devices.find(id);
+    if (it != g_devices.end()) return it->second;
+    if (!luts_ok()) return nullptr;
+    if (hipSetDevice(id) != hipSuccess) { set_error("hipSetDevice(%d) failed", id); return nullptr; }
+    Device *d = new Device;
+    d->id = id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, id) == hipSuccess) d->num_cu = prop.multiProcessorCount;
+    uint16_t *t16 = nullptr, *u16 = nullptr;
+    if (hipMalloc(&t16, MLV_T16_N * 2) != hipSuccess || hipMalloc(&u16, MLV_U16_N * 2) != hipSuccess ||
+        hipMemcpy(t16, host_t16(), MLV_T16_N * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(u16, host_u16(), MLV_U16_N * 2, hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("device %d: table upload failed", id);
+        delete d;
+        return nullptr;
+    }
+    d->luts.t16 = t16;
+    d->luts.u16 = u16;
+    g_devices[id] = d;
+    return d;
+}
+
+// ------------------------------------------------------------------ thread contexts
+static std::atomic<int> g_thread_counter{0};
+static thread_local int t_device = -1;
+static thread_local std::map<int, ThreadCtx *> *t_ctxs = nullptr;
+
+static int visible_devices()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bind_device(int device)
+{
+    int n = visible_devices();
+    if (n <= 0) { set_error("no HIP device visible (libmlvfs_amd has no CPU fallback)"); return MLVFS_AMD_ERR_HIP; }
+    if (device < 0 || device >= n) { set_error("device %d out of range (%d visible)", device, n); return MLVFS_AMD_ERR_ARG; }
+    t_device = device;
+    return thread_ctx() ? MLVFS_AMD_OK : MLVFS_AMD_ERR_HIP;
+}
+
+ThreadCtx *thread_ctx()
+{
+    if (t_device < 0) {
+        int n = visible_devices();
+        if (n <= 0) { set_error("no HIP device visible (libmlvfs_amd has no CPU fallback)"); return nullptr; }
+        const char *env = getenv("MLVFS_AMD_DEVICE");
+        t_device = env ? atoi(env) % n : (g_thread_counter.fetch_add(1) % n);
+    }
+    if (!t_ctxs) t_ctxs = new std::map<int, ThreadCtx *>;
+    auto it = t_ctxs->find(t_device);
+    if (it != t_ctxs->end()) {
+        if (hipSetDevice(t_device) != hipSuccess) return nullptr;
+        return it->second;
+    }
+    Device *dev = get_device(t_device);
+    if (!dev) return nullptr;
+    if (hipSetDevice(t_device) != hipSuccess) return nullptr;
+    ThreadCtx *c = new ThreadCtx;
+    c->dev = dev;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("hipStreamCreate failed");
+        delete c;
+        return nullptr;
+    }
+    (*t_ctxs)[t_device] = c;
+    return c;
+}
+
+int ThreadCtx::ensure(size_t need_a, size_t need_b)
+{
+    if (need_a > cap_a) {
+        if (d_a) (void)hipFree(d_a);
+        d_a = nullptr; cap_a = 0;
+        MLV_HIP(hipMalloc(&d_a, need_a));
+        cap_a = need_a;
+    }
+    if (need_b > cap_b) {
+        if (d_b) (void)hipFree(d_b);
+        d_b = nullptr; cap_b = 0;
+        MLV_HIP(hipMalloc(&d_b, need_b));
+        cap_b = need_b;
+    }
+    return MLVFS_AMD_OK;
+}
+
+}  // namespace mlv
+
+// ------------------------------------------------------------------ C ABI
+extern "C" {
+
+int mlvfs_amd_device_count(void) { return mlv::visible_devices(); }
+int mlvfs_amd_init(int device) { return mlv::bind_device(device); }
+const char *mlvfs_amd_last_error(void) { return mlv::g_err; }
+const char *mlvfs_amd_version(void) { return "mlvfs_amd 0.1.0 (gfx950)"; }
+
+}

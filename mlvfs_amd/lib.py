@@ -1,0 +1,148 @@
+"""ctypes binding of libmlvfs_amd.so (include/mlvfs_amd.h).
+
+The library is the product: if it is missing this module raises -- there is no
+Python/CPU fallback.  `build()` compiles it in-tree with hipcc for gfx950.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libmlvfs_amd.so")
+
+OK = 0
+
+
+class Geom(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bpp", C.c_int32), ("black", C.c_int32),
+                ("white", C.c_int32), ("pan_x", C.c_int32), ("pan_y", C.c_int32)]
+
+
+# every symbol include/mlvfs_amd.h declares (tests/test_cabi.py checks the export table against the header)
+DROPIN_SYMBOLS = [
+    "dng_get_image_data", "dng_get_header_size", "dng_get_image_size", "dng_get_size",
+    "chroma_smooth", "fix_bad_pixels", "fix_focus_pixels", "free_focus_pixel_maps",
+    "stripes_get_correction", "stripes_new_correction", "stripes_free_corrections",
+    "stripes_compute_correction", "stripes_apply_correction",
+    "hdr_convert_data", "fix_pattern_noise",
+    "hist_create", "hist_add", "hist_median", "hist_destroy",
+]
+DEVICE_SYMBOLS = [
+    "mlvfs_amd_device_count", "mlvfs_amd_init", "mlvfs_amd_last_error", "mlvfs_amd_version",
+    "mlvfs_amd_clip_create", "mlvfs_amd_clip_destroy", "mlvfs_amd_clip_set_stripes", "mlvfs_amd_clip_get_stripes",
+    "mlvfs_amd_clip_set_pixel_map", "mlvfs_amd_clip_get_pixel_map",
+    "mlvfs_amd_unpack_dev", "mlvfs_amd_chroma_smooth_dev", "mlvfs_amd_detect_bad_pixels_dev",
+    "mlvfs_amd_fix_pixels_dev", "mlvfs_amd_stripes_count_dev", "mlvfs_amd_stripes_hist_dev",
+    "mlvfs_amd_stripes_solve", "mlvfs_amd_stripes_compute_dev", "mlvfs_amd_stripes_apply_dev",
+    "mlvfs_amd_rand_stream", "mlvfs_amd_process_frames_dev", "mlvfs_amd_hdr_preview_dev",
+    "mlvfs_amd_timer_begin", "mlvfs_amd_timer_end", "mlvfs_amd_selftest_host",
+]
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into mlvfs_amd/libmlvfs_amd.so."""
+    cmd = ["make", "-C", os.path.join(HERE, "csrc"), "-j8"]
+    res = subprocess.run(cmd, capture_output=not verbose, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libmlvfs_amd.so failed:\n" + (res.stdout or "") + (res.stderr or ""))
+    return SO_PATH
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise FileNotFoundError(
+            f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(mlvfs_amd has no CPU fallback)")
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.  If our
+    # library pulled in /opt/rocm's copy first, torch (imported later for device memory and
+    # streams) would bring up a second runtime that sees no GPU.  Importing torch first makes
+    # the dynamic linker resolve our DT_NEEDED libamdhip64.so.* to the copy already loaded.
+    # (A C host such as MLVFS has no torch and simply uses the system runtime.)
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the drop-in symbols
+        pass
+    L = C.CDLL(SO_PATH)
+    vp, sz, i, i64 = C.c_void_p, C.c_size_t, C.c_int, C.c_int64
+    gp = C.POINTER(Geom)
+    fhp = C.POINTER(abi.FrameHeaders)
+    scp = C.POINTER(abi.StripesCorrection)
+
+    def sig(name, res, args):
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+
+    # drop-in symbols
+    sig("dng_get_image_data", sz, [fhp, vp, vp, C.c_long, sz])
+    sig("dng_get_header_size", sz, [])
+    sig("dng_get_image_size", sz, [fhp])
+    sig("dng_get_size", sz, [fhp])
+    sig("chroma_smooth", None, [fhp, vp, i])
+    sig("fix_bad_pixels", None, [fhp, vp, i, i])
+    sig("fix_focus_pixels", None, [fhp, vp, i])
+    sig("free_focus_pixel_maps", None, [])
+    sig("stripes_get_correction", scp, [C.c_char_p])
+    sig("stripes_new_correction", scp, [C.c_char_p])
+    sig("stripes_free_corrections", None, [])
+    sig("stripes_compute_correction", None, [fhp, scp, vp, C.c_long, sz])
+    sig("stripes_apply_correction", None, [fhp, scp, vp, C.c_long, sz])
+    sig("hdr_convert_data", i, [fhp, vp, C.c_long, sz])
+    sig("fix_pattern_noise", None, [vp, i, i, i, i])
+    sig("hist_create", vp, [C.c_uint16])
+    sig("hist_add", None, [vp, vp, C.c_uint32, C.c_uint16])
+    sig("hist_median", C.c_uint16, [vp])
+    sig("hist_destroy", None, [vp])
+    # device API
+    sig("mlvfs_amd_device_count", i, [])
+    sig("mlvfs_amd_init", i, [i])
+    sig("mlvfs_amd_last_error", C.c_char_p, [])
+    sig("mlvfs_amd_version", C.c_char_p, [])
+    sig("mlvfs_amd_clip_create", vp, [gp])
+    sig("mlvfs_amd_clip_destroy", None, [vp])
+    sig("mlvfs_amd_clip_set_stripes", i, [vp, i, vp])
+    sig("mlvfs_amd_clip_get_stripes", i, [vp, C.POINTER(i), vp])
+    sig("mlvfs_amd_clip_set_pixel_map", i, [vp, vp, sz, i, i])
+    sig("mlvfs_amd_clip_get_pixel_map", sz, [vp, vp, sz])
+    sig("mlvfs_amd_unpack_dev", i, [gp, vp, sz, vp, sz, i, vp])
+    sig("mlvfs_amd_chroma_smooth_dev", i, [gp, vp, vp, sz, i, i, vp])
+    sig("mlvfs_amd_detect_bad_pixels_dev", i, [vp, vp, i, vp])
+    sig("mlvfs_amd_fix_pixels_dev", i, [vp, vp, sz, i, vp])
+    sig("mlvfs_amd_stripes_count_dev", i, [gp, vp, i, i, C.POINTER(i64), vp])
+    sig("mlvfs_amd_stripes_hist_dev", i, [gp, vp, i, i, vp, i64, vp, vp, vp])
+    sig("mlvfs_amd_stripes_solve", i, [vp, vp, i, vp])
+    sig("mlvfs_amd_stripes_compute_dev", i, [vp, vp, i, i, vp])
+    sig("mlvfs_amd_stripes_apply_dev", i, [vp, vp, sz, i, vp])
+    sig("mlvfs_amd_rand_stream", None, [vp, sz, C.c_uint64, C.c_uint])
+    sig("mlvfs_amd_process_frames_dev", i, [vp, vp, sz, vp, sz, i, i, i, i, vp])
+    sig("mlvfs_amd_hdr_preview_dev", i, [gp, vp, sz, vp])
+    sig("mlvfs_amd_timer_begin", i, [i])
+    sig("mlvfs_amd_timer_end", i, [vp, i])
+    sig("mlvfs_amd_selftest_host", i, [])
+    _lib = L
+    return L
+
+
+class MlvfsAmdError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != OK:
+        raise MlvfsAmdError(f"{what} failed ({rc}): {load().mlvfs_amd_last_error().decode()}")
+
+
+def ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)

@@ -58,6 +58,9 @@ class Oracle:
         L.orc_stripes_compute.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           i32p, C.c_void_p, C.c_void_p]
         L.orc_stripes_apply.argtypes = [u16p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, i32p, C.c_int64]
+        L.orc_stripes_hist_rows.restype = C.c_int64
+        L.orc_stripes_hist_rows.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                            C.c_void_p, C.c_void_p]
         L.orc_hdr_preview.restype = C.c_int
         L.orc_hdr_preview.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -140,6 +143,19 @@ class Oracle:
                                             hist.ctypes.data if want_hist else None,
                                             num.ctypes.data if want_hist else None)
         return (needed, co, hist, num) if want_hist else (needed, co)
+
+    def stripes_hist_rows(self, img, row0, row1, black, white, rnd=None):
+        """Shard form: returns accepted-call count (rnd None) or (count, hist[8*65536], num[8])."""
+        img = np.ascontiguousarray(img, np.uint16)
+        h, w = img.shape
+        if rnd is None:
+            return int(self.L.orc_stripes_hist_rows(img, w, row0, row1, black, white, None, 0, None, None))
+        rnd = np.ascontiguousarray(rnd, np.uint16)
+        hist = np.zeros(8 * 65536, np.int32)
+        num = np.zeros(8, np.int32)
+        n = self.L.orc_stripes_hist_rows(img, w, row0, row1, black, white, rnd.ctypes.data, rnd.size,
+                                         hist.ctypes.data, num.ctypes.data)
+        return int(n), hist, num
 
     def stripes_apply(self, img, black, white, needed, coeffs) -> np.ndarray:
         out = np.ascontiguousarray(img, np.uint16).copy()

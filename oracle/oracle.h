@@ -77,6 +77,9 @@ void orc_apply_focus_pixels(uint16_t *img, int w, int h, int black,
 int orc_stripes_compute(const uint16_t *img, int w, int h, int black, int white,
                         int frame_size, int (*rand_fn)(void), int32_t coeffs[8],
                         int32_t *hist_out, int32_t *num_out);
+/* rows [row0,row1) with an explicit dither stream (multi-GPU host-logic tests)   */
+int64_t orc_stripes_hist_rows(const uint16_t *img, int w, int row0, int row1, int black, int white,
+                              const uint16_t *rnd, int64_t n_rnd, int32_t *hist, int32_t *num);
 void orc_stripes_apply(uint16_t *img, size_t npix, int w, int black, int white,
                        int needed, const int32_t coeffs[8], int64_t offset);
 

@@ -450,3 +450,36 @@ int orc_rand_next(orc_rand_t *st)
     st->pos = (st->pos + 1) % 31;
     return (int)(v >> 1);
 }
+
+/* ------------------------------------------------------------------------ */
+/* Row-shard form of the stripes histogram (for the multi-GPU host logic tests):
+ * rows [row0,row1) only, dither values taken from a caller-supplied stream of
+ * rand()%1024 values (two per accepted call, in raster order).  rnd == NULL just
+ * counts the accepted calls.  Same arithmetic as orc_stripes_compute above.      */
+int64_t orc_stripes_hist_rows(const uint16_t *img, int w, int row0, int row1, int black, int white,
+                              const uint16_t *rnd, int64_t n_rnd, int32_t *hist, int32_t *num)
+{
+    const double too_bright = white / 1.5;
+    int64_t calls = 0;
+    for (int y = row0; y < row1; y++) {
+        const uint16_t *row = img + (size_t)y * w;
+        for (int x = 0; x < w - 10; x += 8) {
+            int px[10];
+            for (int k = 0; k < 10; k++) px[k] = row[x + k] - black;
+            for (int c = 0; c < 24; c++) {
+                int a = px[k_pairs[c][1]], b = px[k_pairs[c][2]];
+                int lo = a < b ? a : b, hi = a < b ? b : a;
+                if (lo < 32 || hi > too_bright) continue;
+                if (rnd && 2 * calls + 1 < n_rnd) {
+                    double af = a + rnd[2 * calls] / 1024.0 - 0.5;
+                    double bf = b + rnd[2 * calls + 1] / 1024.0 - 0.5;
+                    int bin = clampi((int)(65536 / 2 + log2(af / bf) * 65536 / 2), 0, 65535);
+                    hist[k_pairs[c][0] * 65536 + bin]++;
+                    num[k_pairs[c][0]]++;
+                }
+                calls++;
+            }
+        }
+    }
+    return calls;
+}

@@ -1,0 +1,232 @@
+"""GPU parity: libmlvfs_amd.so (HIP, through the C ABI) against the oracle.
+
+Bit-exact is the bar for every stage here (integer / byte work).  Where the
+reference build (oracle/_ref) travelled to the GPU box it is checked too.
+All tests are @pytest.mark.gpu and call through the C ABI: the drop-in symbols
+the way MLVFS's main.c calls them (mlvfs_amd.pipeline) and the device-resident
+API (mlvfs_amd.stream).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from mlvfs_amd import abi, lib, pipeline, synth
+
+pytestmark = pytest.mark.gpu
+
+BLACK, WHITE = synth.BLACK, synth.WHITE
+SIZES = [(64, 48), (136, 72), (256, 130), (416, 264)]          # 136: not a multiple of 16 -> generic loaders
+KINDS = ["normal", "adversarial"]
+
+
+def frame_of(kind, w, h, **kw):
+    return getattr(synth, kind + "_frame")(w, h, **kw)
+
+
+def fh_for(w, h, bpp=14, **kw):
+    return abi.make_frame_headers(w, h, bpp=bpp, black=BLACK, white=WHITE, **kw)
+
+
+# ------------------------------------------------------------------ unpack
+@pytest.mark.parametrize("bpp", [14, 12, 10, 8, 16])
+@pytest.mark.parametrize("w,h", [(64, 48), (136, 72), (1920, 1080)])
+def test_unpack_dropin(gpu, oracle, w, h, bpp):
+    f = frame_of("normal", w, h) & ((1 << bpp) - 1)
+    packed = synth.pack_bits(f, bpp)
+    fh = fh_for(w, h, bpp)
+    got = pipeline.get_image_data(fh, packed).reshape(h, w)
+    assert np.array_equal(got, f)
+    assert np.array_equal(got.ravel(), oracle.unpack(packed, w, h, bpp))
+
+
+@pytest.mark.parametrize("offset,size", [(0, 4096), (2 * 1000, 6000), (2 * 4097, 2 * 999), (-64, 4096)])
+def test_unpack_window(gpu, oracle, offset, size):
+    """offset/max_size window of dng_get_image_data (dng.c:815-826); the caller hands in
+    the packed words starting at the first requested pixel's word (main.c:689)."""
+    w, h, bpp = 256, 130, 14
+    f = frame_of("normal", w, h)
+    packed = synth.pack_bits(f, bpp)
+    first_word = (max(offset, 0) // 2) * bpp // 16
+    want = oracle.unpack(packed[first_word:], w, h, bpp, offset=offset, max_size=size)
+    fh = fh_for(w, h, bpp)
+    got = pipeline.get_image_data(fh, packed[first_word:], offset=offset, max_size=size)
+    assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------ chroma smooth
+@pytest.mark.parametrize("method", [2, 3, 5])
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("w,h", SIZES)
+def test_chroma_smooth_dropin(gpu, oracle, w, h, kind, method):
+    f = frame_of(kind, w, h)
+    want = oracle.chroma_smooth(f, BLACK, method)
+    got = f.copy()
+    gpu.chroma_smooth(C.byref(fh_for(w, h)), lib.ptr(got), method)
+    assert np.array_equal(got, want), f"{(got != want).sum()} px differ"
+    assert (want != f).any()
+
+
+def test_chroma_smooth_bad_method_is_noop(gpu):
+    f = frame_of("normal", 64, 48)
+    got = f.copy()
+    gpu.chroma_smooth(C.byref(fh_for(64, 48)), lib.ptr(got), 4)
+    assert np.array_equal(got, f)
+
+
+def test_chroma_smooth_other_black_levels(gpu, oracle):
+    for black in (0, 1024, 4000):
+        f = synth.adversarial_frame(128, 64, black=black)
+        fh = abi.make_frame_headers(128, 64, black=black, white=WHITE)
+        got = f.copy()
+        gpu.chroma_smooth(C.byref(fh), lib.ptr(got), 5)
+        assert np.array_equal(got, oracle.chroma_smooth(f, black, 5))
+
+
+# ------------------------------------------------------------------ bad / focus pixels
+@pytest.mark.parametrize("aggressive", [0, 1])
+@pytest.mark.parametrize("dual_iso", [0, 1])
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("w,h", SIZES[:3])
+def test_fix_bad_pixels_dropin(gpu, oracle, w, h, kind, dual_iso, aggressive):
+    f = frame_of(kind, w, h)
+    want = oracle.fix_bad_pixels(f, BLACK, aggressive, dual_iso)
+    got = f.copy()
+    gpu.fix_bad_pixels(C.byref(fh_for(w, h)), lib.ptr(got), aggressive, dual_iso)      # guid 0: detect every call
+    assert np.array_equal(got, want), f"{(got != want).sum()} px differ"
+    assert (want != f).any()
+
+
+def test_fix_bad_pixels_map_cache_and_crop(gpu, oracle):
+    """A clip (fileGuid != 0) detects once; later frames reuse the map (cs.c:233-253).  panPos
+    shifts the stored coordinates and is subtracted again on application."""
+    w, h = 256, 130
+    f0, f1 = synth.normal_frame(w, h, frame=0), synth.normal_frame(w, h, frame=1)
+    fh = fh_for(w, h, guid=0xABCDEF01, pan=(13, 7))
+    crop = ((13 + 7) & ~7, 7 & ~1)
+    pixels = oracle.detect_bad_pixels(f0, BLACK, 0, crop)
+    got0, got1 = f0.copy(), f1.copy()
+    gpu.fix_bad_pixels(C.byref(fh), lib.ptr(got0), 0, 0)
+    gpu.fix_bad_pixels(C.byref(fh), lib.ptr(got1), 0, 0)            # uses frame 0's map
+    assert np.array_equal(got0, oracle.apply_bad_pixels(f0, BLACK, pixels, crop))
+    assert np.array_equal(got1, oracle.apply_bad_pixels(f1, BLACK, pixels, crop))
+    gpu.free_focus_pixel_maps()
+
+
+@pytest.mark.parametrize("dual_iso", [0, 1])
+def test_fix_focus_pixels_dropin(gpu, oracle, tmp_path, monkeypatch, dual_iso):
+    """Focus maps are read from '<camera hex>_<w>x<h>.fpm' in the CWD (cs.c:369-370);
+    the list is applied in file order, with the frame-edge rules of cs.c:479-500."""
+    w, h = 136, 72
+    rng = np.random.default_rng(5)
+    pts = [(rng.integers(0, w), rng.integers(0, h)) for _ in range(300)]
+    pts += [(0, 10), (1, 1), (w - 1, 30), (w - 2, h - 1), (50, 0), (51, h - 1), (3, 3), (w - 4, h - 4),
+            (60, 30), (62, 30), (61, 30), (60, 32), (60, 30)]          # dependent + duplicate entries
+    camera = 0x80000331
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / f"{camera:x}_{w}x{h}.fpm").write_text("".join(f"{x} \t {y}\n" for x, y in pts))
+    gpu.free_focus_pixel_maps()
+    f = synth.normal_frame(w, h)
+    want = oracle.apply_focus_pixels(f, BLACK, np.array(pts, np.int32), (0, 0), dual_iso)
+    got = f.copy()
+    gpu.fix_focus_pixels(C.byref(fh_for(w, h, camera=camera)), lib.ptr(got), dual_iso)
+    assert np.array_equal(got, want), f"{(got != want).sum()} px differ"
+    assert (want != f).any()
+    gpu.free_focus_pixel_maps()
+
+
+# ------------------------------------------------------------------ stripes
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("w,h", [(64, 48), (256, 130), (416, 264)])
+def test_stripes_dropin(gpu, oracle, w, h, kind):
+    f = frame_of(kind, w, h)
+    needed, coeffs = oracle.stripes_compute(f, BLACK, WHITE)          # srand(1) + libc rand()
+    libc = C.CDLL(None)
+    libc.srand(1)
+    name = f"clip_{kind}_{w}x{h}.MLV".encode()
+    corr = gpu.stripes_new_correction(name)
+    fh = fh_for(w, h)
+    gpu.stripes_compute_correction(C.byref(fh), corr, lib.ptr(f), 0, f.size)
+    assert corr.contents.correction_needed == needed
+    assert list(corr.contents.coeffficients) == list(coeffs)
+    # the libc generator must have been advanced by exactly the reference's number of calls
+    after_gpu = libc.rand()
+    libc.srand(1)
+    oracle.stripes_compute(f, BLACK, WHITE, reseed=False)
+    assert libc.rand() == after_gpu
+    got = f.copy()
+    gpu.stripes_apply_correction(C.byref(fh), corr, lib.ptr(got), 0, got.size)
+    assert np.array_equal(got, oracle.stripes_apply(f, BLACK, WHITE, needed, coeffs))
+    assert gpu.stripes_get_correction(name)
+    gpu.stripes_free_corrections()
+    assert not gpu.stripes_get_correction(name)
+
+
+def test_stripes_apply_noop_cases(gpu):
+    w, h = 68, 16                                                       # xRes % 8 != 0 -> untouched (stripes.c:253)
+    f = synth.normal_frame(w, h)
+    corr = gpu.stripes_new_correction(b"x.MLV")
+    corr.contents.correction_needed = 1
+    for k in range(8):
+        corr.contents.coeffficients[k] = 70000
+    got = f.copy()
+    gpu.stripes_apply_correction(C.byref(fh_for(w, h)), corr, lib.ptr(got), 0, got.size)
+    assert np.array_equal(got, f)
+    gpu.stripes_free_corrections()
+
+
+# ------------------------------------------------------------------ dual-ISO preview
+@pytest.mark.parametrize("w,h", [(64, 48), (136, 72), (416, 264)])
+def test_hdr_preview_dropin(gpu, oracle, w, h):
+    f = synth.dual_iso_frame(w, h)
+    ok, want, levels = oracle.hdr_preview(f, BLACK, WHITE)
+    assert ok == 1
+    fh = fh_for(w, h)
+    got = f.copy()
+    r = gpu.hdr_convert_data(C.byref(fh), lib.ptr(got), 0, got.nbytes)
+    assert r == 1
+    assert np.array_equal(got, want), f"{(got != want).sum()} px differ"
+    assert (fh.rawi_hdr.raw_info.black_level, fh.rawi_hdr.raw_info.white_level) == levels
+    # a normal frame is not dual ISO: untouched, returns 0 (caller then runs the normal path)
+    n = synth.normal_frame(w, h)
+    got = n.copy()
+    fh = fh_for(w, h)
+    assert gpu.hdr_convert_data(C.byref(fh), lib.ptr(got), 0, got.nbytes) == 0
+    assert np.array_equal(got, n) and fh.rawi_hdr.raw_info.black_level == BLACK
+
+
+# ------------------------------------------------------------------ process_frame order through the drop-in symbols
+@pytest.mark.parametrize("cs,bad,stripes", [(0, 0, 0), (2, 0, 0), (5, 1, 1), (3, 2, 1), (5, 0, 1)])
+def test_process_frame_dropin(gpu, oracle, cs, bad, stripes):
+    w, h = 256, 130
+    opt = pipeline.MlvfsOptions(chroma_smooth=cs, fix_bad_pixels=bad, fix_stripes=stripes)
+    libc = C.CDLL(None)
+    corr = None
+    gpu.stripes_free_corrections()
+    gpu.free_focus_pixel_maps()
+    for fr in range(2):                                                # frame 0 computes the clip state, frame 1 reuses it
+        f = synth.normal_frame(w, h, frame=fr)
+        packed = synth.pack_bits(f)
+        if fr == 0:
+            libc.srand(1)
+        want, corr = oracle.process_frame(packed, w, h, BLACK, WHITE, cs=cs, bad_pix=bad, stripes=stripes, correction=corr)
+        if fr == 0:
+            libc.srand(1)
+        got = pipeline.process_frame(packed, fh_for(w, h), opt, "a.MLV")     # guid 0: bad pixels re-detected per frame, like the oracle
+        assert np.array_equal(got, want), f"frame {fr}: {(got != want).sum()} px differ"
+    gpu.stripes_free_corrections()
+
+
+def test_against_reference_build(gpu, reference):
+    """Where oracle/_ref travelled to this box: HIP == the reference's own code."""
+    w, h = 256, 130
+    for kind in KINDS:
+        f = frame_of(kind, w, h)
+        for m in (2, 3, 5):
+            got = f.copy()
+            gpu.chroma_smooth(C.byref(fh_for(w, h)), lib.ptr(got), m)
+            assert np.array_equal(got, reference.chroma_smooth(f, BLACK, m))
+        got = f.copy()
+        gpu.fix_bad_pixels(C.byref(fh_for(w, h)), lib.ptr(got), 1, 0)
+        assert np.array_equal(got, reference.fix_bad_pixels(f, BLACK, 1, 0))

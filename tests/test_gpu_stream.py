@@ -1,0 +1,206 @@
+"""GPU parity of the device-resident API and the fused pipeline (mlvfs_amd.stream),
+plus size-independent properties at BASELINE.json's full frame size.
+
+Everything is bit-exact (u16 / int32 work).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mlvfs_amd import lib, synth
+
+pytestmark = pytest.mark.gpu
+
+BLACK, WHITE = synth.BLACK, synth.WHITE
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(gpu):
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def make_stream(w, h):
+    from mlvfs_amd.stream import ClipStream
+    return ClipStream(w, h, 14, BLACK, WHITE, device=0)
+
+
+def oracle_clip(oracle, frames, w, h, cs, bad, stripes):
+    """Reference semantics for a clip: frame 0 fixes the pixel map and the stripe
+    coefficients (main.c:969-988), later frames reuse them."""
+    out, pixels, corr = [], None, None
+    for k, f in enumerate(frames):
+        img = f.copy()
+        if bad:
+            if pixels is None:
+                pixels = oracle.detect_bad_pixels(img, BLACK, int(bad == 2))
+            img = oracle.apply_bad_pixels(img, BLACK, pixels)
+        if cs:
+            img = oracle.chroma_smooth(img, BLACK, cs)
+        if stripes:
+            if corr is None:
+                corr = oracle.stripes_compute(img, BLACK, WHITE, frame_size=w * h * 14 // 8)
+            img = oracle.stripes_apply(img, BLACK, WHITE, *corr)
+        out.append(img)
+    return out, pixels, corr
+
+
+@pytest.mark.parametrize("w,h", [(256, 130), (136, 72), (416, 264)])
+@pytest.mark.parametrize("cs,bad,stripes", [(5, 1, 1), (2, 0, 0), (3, 2, 1), (0, 1, 1), (0, 0, 0)])
+def test_fused_pipeline_matches_oracle(torch_cuda, oracle, w, h, cs, bad, stripes):
+    from mlvfs_amd.stream import to_numpy_u16
+    frames = [synth.normal_frame(w, h, frame=k) for k in range(3)]
+    want, pixels, corr = oracle_clip(oracle, frames, w, h, cs, bad, stripes)
+    s = make_stream(w, h)
+    packed = s.upload_packed([synth.pack_bits(f) for f in frames])
+    first = s.analyse_first_frame(packed, cs=cs, bad_pix=bad, stripes=bool(stripes), rand_mode=1)
+    assert np.array_equal(to_numpy_u16(first)[0], want[0]), "first-frame path"
+    if bad:
+        assert np.array_equal(s.get_pixel_map(), pixels)
+    if stripes:
+        needed, co = s.get_stripes()
+        assert needed == corr[0] and list(co) == list(corr[1])
+    got = to_numpy_u16(s.process(packed, cs=cs, fix_pixels=bool(bad), stripes=bool(stripes)))
+    for k in range(3):
+        assert np.array_equal(got[k], want[k]), f"frame {k}: {(got[k] != want[k]).sum()} px differ"
+    s.close()
+
+
+def test_fused_adversarial(torch_cuda, oracle):
+    """INT_MIN-heavy frame (40 % of pixels at black+-4) with thousands of bad pixels:
+    exercises wrap-around EV arithmetic and multi-level ordered repair."""
+    from mlvfs_amd.stream import to_numpy_u16
+    w, h = 256, 130
+    frames = [synth.adversarial_frame(w, h, frame=k) for k in range(2)]
+    want, pixels, corr = oracle_clip(oracle, frames, w, h, 5, 2, 1)
+    s = make_stream(w, h)
+    packed = s.upload_packed([synth.pack_bits(f) for f in frames])
+    s.analyse_first_frame(packed, cs=5, bad_pix=2, stripes=True)
+    assert len(pixels) > 500 and np.array_equal(s.get_pixel_map(), pixels)
+    got = to_numpy_u16(s.process(packed, cs=5, fix_pixels=True, stripes=True))
+    for k in range(2):
+        assert np.array_equal(got[k], want[k])
+    s.close()
+
+
+def test_stage_api_matches_fused(torch_cuda, oracle):
+    """unpack_dev -> fix_pixels_dev -> chroma_smooth_dev -> stripes_apply_dev == fused launch."""
+    from mlvfs_amd.stream import to_numpy_u16
+    w, h = 416, 264
+    frames = [synth.normal_frame(w, h, frame=k) for k in range(4)]
+    s = make_stream(w, h)
+    packed = s.upload_packed([synth.pack_bits(f) for f in frames])
+    s.analyse_first_frame(packed, cs=5, bad_pix=1, stripes=True)
+    staged = s.unpack(packed)
+    assert np.array_equal(to_numpy_u16(staged), np.stack(frames))
+    staged = s.stripes_apply(s.chroma_smooth(s.fix_pixels(staged), 5))
+    fused = s.process(packed, cs=5, fix_pixels=True, stripes=True)
+    assert np.array_equal(to_numpy_u16(staged), to_numpy_u16(fused))
+    s.close()
+
+
+def test_device_synth_equals_numpy(torch_cuda):
+    """bench.py builds its stream on the GPU with the same generator the tests use on numpy."""
+    w, h = 256, 128
+    s = make_stream(w, h)
+    dev = s.synth_packed(2, seed=1, first_frame=5).cpu().numpy()
+    for k in range(2):
+        words = synth.pack14(synth.normal_frame(w, h, seed=1, frame=5 + k)).astype("<u2").view(np.uint8)
+        assert np.array_equal(dev[k, : words.size], words)
+    s.close()
+
+
+def test_row_sharded_histogram_is_shard_invariant(torch_cuda, oracle):
+    """frame 0 row-sharded over G ranks -> per-shard accepted counts give the
+    rand() offsets, partial histograms add up to the single-GPU histogram (here: shards run
+    one after the other on one GPU; the integer adds commute)."""
+    import torch
+    from mlvfs_amd.stream import _dptr
+    w, h = 256, 130
+    f = synth.normal_frame(w, h)
+    needed, coeffs, hist_ref, num_ref = oracle.stripes_compute(f, BLACK, WHITE, want_hist=True)
+    s = make_stream(w, h)
+    frame = torch.from_numpy(f.view(np.int16)).cuda()
+    L = s.L
+    for shards in (1, 2, 3):
+        edges = [h * k // shards for k in range(shards + 1)]
+        counts = []
+        for k in range(shards):
+            acc = C.c_int64(0)
+            lib.check(L.mlvfs_amd_stripes_count_dev(C.byref(s.geom), _dptr(frame), edges[k], edges[k + 1], C.byref(acc), None))
+            counts.append(acc.value)
+        total = sum(counts)
+        assert total == int(num_ref.sum())
+        rnd = np.zeros(2 * total + 2, np.uint16)
+        L.mlvfs_amd_rand_stream(lib.ptr(rnd), 2 * total, 0, 1)
+        d_rnd = torch.from_numpy(rnd.view(np.int16)).cuda()
+        d_hist = torch.zeros(8 * 65536, dtype=torch.int32, device="cuda")
+        d_num = torch.zeros(8, dtype=torch.int32, device="cuda")
+        off = 0
+        for k in range(shards):
+            acc = C.c_int64(0)
+            lib.check(L.mlvfs_amd_stripes_count_dev(C.byref(s.geom), _dptr(frame), edges[k], edges[k + 1], C.byref(acc), None))
+            lib.check(L.mlvfs_amd_stripes_hist_dev(C.byref(s.geom), _dptr(frame), edges[k], edges[k + 1],
+                                                   C.c_void_p(d_rnd.data_ptr() + 4 * off), 2 * counts[k],
+                                                   _dptr(d_hist), _dptr(d_num), None))
+            off += counts[k]
+        torch.cuda.synchronize()
+        assert np.array_equal(d_hist.cpu().numpy().reshape(8, 65536), hist_ref)
+        assert np.array_equal(d_num.cpu().numpy(), num_ref)
+        co = np.zeros(8, np.int32)
+        hh = np.ascontiguousarray(d_hist.cpu().numpy())
+        nn = np.ascontiguousarray(d_num.cpu().numpy())
+        assert L.mlvfs_amd_stripes_solve(lib.ptr(hh), lib.ptr(nn), w * h * 14 // 8, lib.ptr(co)) == needed
+        assert list(co) == list(coeffs)
+    s.close()
+
+
+# ------------------------------------------------------------------ full size (BASELINE.json configs 2 and 3)
+FULL_W, FULL_H = 3584, 1320
+
+
+@pytest.mark.parametrize("cs", [2, 5])
+def test_full_size_against_oracle(torch_cuda, oracle, cs):
+    """One 3584x1320 frame through the fused path == oracle (cs5x5 takes ~1 s on the CPU)."""
+    from mlvfs_amd.stream import to_numpy_u16
+    w, h = FULL_W, FULL_H
+    frames = [synth.normal_frame(w, h, frame=k) for k in range(2)]
+    want, pixels, corr = oracle_clip(oracle, frames, w, h, cs, 1, 1)
+    s = make_stream(w, h)
+    packed = s.upload_packed([synth.pack14(f).astype("<u2") for f in frames])
+    s.analyse_first_frame(packed, cs=cs, bad_pix=1, stripes=True)
+    assert np.array_equal(s.get_pixel_map(), pixels)
+    needed, co = s.get_stripes()
+    assert needed == corr[0] == 1 and list(co) == list(corr[1])
+    got = to_numpy_u16(s.process(packed, cs=cs, fix_pixels=True, stripes=True))
+    for k in range(2):
+        assert np.array_equal(got[k], want[k]), f"frame {k}: {(got[k] != want[k]).sum()} px differ"
+    s.close()
+
+
+def test_full_size_properties(torch_cuda):
+    """Size-independent checks on a 16-frame 3584x1320 stream built in HBM:
+      * unpack(pack(x)) == x for every frame (round trip),
+      * batch invariance: frame k of a 16-frame launch == the same frame launched alone,
+      * green pixels are never touched by chroma smoothing (SURVEY.md 8a notes 5),
+      * stripes-apply with unit coefficients is the identity."""
+    import torch
+    from mlvfs_amd.stream import to_numpy_u16
+    w, h, n = FULL_W, FULL_H, 16
+    s = make_stream(w, h)
+    packed = s.synth_packed(n, seed=11)
+    dev = torch.zeros(1, device="cuda")
+    unp = s.unpack(packed)
+    for k in (0, 7, 15):
+        ref = synth.normal_frame(w, h, seed=11, frame=k, like=dev).to(torch.int16)
+        assert torch.equal(unp[k].reshape(-1), ref.reshape(-1))
+    s.set_stripes(1, [65536] * 8)
+    batch = s.process(packed, cs=5, stripes=True)
+    alone = s.process(packed[9:10], cs=5)
+    assert torch.equal(batch[9], alone[0])
+    assert torch.equal(batch[:, 0::2, 1::2], unp[:, 0::2, 1::2])        # G1
+    assert torch.equal(batch[:, 1::2, 0::2], unp[:, 1::2, 0::2])        # G2
+    assert (batch != unp).any()
+    s.close()
