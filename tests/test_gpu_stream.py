@@ -185,7 +185,7 @@ def test_full_size_properties(torch_cuda):
       * unpack(pack(x)) == x for every frame (round trip),
       * batch invariance: frame k of a 16-frame launch == the same frame launched alone,
       * green pixels are never touched by chroma smoothing (SURVEY.md 8a notes 5),
-      * stripes-apply with unit coefficients is the identity."""
+      * stripes-apply with unit coefficients only clamps to the white level (stripes.c:263)."""
     import torch
     from mlvfs_amd.stream import to_numpy_u16
     w, h, n = FULL_W, FULL_H, 16
@@ -198,9 +198,11 @@ def test_full_size_properties(torch_cuda):
         assert torch.equal(unp[k].reshape(-1), ref.reshape(-1))
     s.set_stripes(1, [65536] * 8)
     batch = s.process(packed, cs=5, stripes=True)
-    alone = s.process(packed[9:10], cs=5)
+    alone = s.process(packed[9:10], cs=5, stripes=True)
     assert torch.equal(batch[9], alone[0])
-    assert torch.equal(batch[:, 0::2, 1::2], unp[:, 0::2, 1::2])        # G1
-    assert torch.equal(batch[:, 1::2, 0::2], unp[:, 1::2, 0::2])        # G2
-    assert (batch != unp).any()
+    plain = s.process(packed, cs=5)
+    assert torch.equal(plain[:, 0::2, 1::2], unp[:, 0::2, 1::2])        # G1 untouched by chroma smoothing
+    assert torch.equal(plain[:, 1::2, 0::2], unp[:, 1::2, 0::2])        # G2
+    assert (plain != unp).any()
+    assert torch.equal(batch, plain.clamp(max=WHITE))                   # unit gains: min(white, p)
     s.close()
