@@ -162,10 +162,39 @@ int Clip::set_pixel_map(const int32_t *xy_in, size_t count, int rules_in, int du
     }
     for (int l = 0; l <= max_level; l++) off[l + 1] += off[l];
 
+    // per-tile lists for the fused kernel: an entry belongs to every tile whose plane
+    // rectangle (tile + 2-cell halo) contains its cell
+    const int tx_n = frame_tiles_x(w), ty_n = frame_tiles_y(h);
+    std::vector<std::vector<int>> per_tile((size_t)tx_n * ty_n);
+    for (size_t k = 0; k < count; k++) {
+        const PixEntry &e = sorted[k];
+        if (e.kind == 0 || !e.emit) continue;
+        const int cx = (e.pos % w) >> 1, cy = (e.pos / w) >> 1;
+        for (int ty = 0; ty < ty_n; ty++) {
+            if (cy < ty * FRAME_TCH - FRAME_HC || cy >= (ty + 1) * FRAME_TCH + FRAME_HC) continue;
+            for (int tx = 0; tx < tx_n; tx++) {
+                if (cx < tx * FRAME_TCW - FRAME_HC || cx >= (tx + 1) * FRAME_TCW + FRAME_HC) continue;
+                per_tile[(size_t)ty * tx_n + tx].push_back((int)k);
+            }
+        }
+    }
+    std::vector<int> tile_off(per_tile.size() + 1, 0), tile_ent;
+    for (size_t i = 0; i < per_tile.size(); i++) {
+        tile_off[i + 1] = tile_off[i] + (int)per_tile[i].size();
+        tile_ent.insert(tile_ent.end(), per_tile[i].begin(), per_tile[i].end());
+    }
+    if (tile_ent.empty()) tile_ent.push_back(0);
+
     ThreadCtx *c = thread_ctx();
     if (!c) return MLVFS_AMD_ERR_HIP;
     if (d_entries) { (void)hipFree(d_entries); d_entries = nullptr; }
     if (d_level_off) { (void)hipFree(d_level_off); d_level_off = nullptr; }
+    if (d_tile_off) { (void)hipFree(d_tile_off); d_tile_off = nullptr; }
+    if (d_tile_ent) { (void)hipFree(d_tile_ent); d_tile_ent = nullptr; }
+    MLV_HIP(hipMalloc(&d_tile_off, sizeof(int) * tile_off.size()));
+    MLV_HIP(hipMalloc(&d_tile_ent, sizeof(int) * tile_ent.size()));
+    MLV_HIP(hipMemcpy(d_tile_off, tile_off.data(), sizeof(int) * tile_off.size(), hipMemcpyHostToDevice));
+    MLV_HIP(hipMemcpy(d_tile_ent, tile_ent.data(), sizeof(int) * tile_ent.size(), hipMemcpyHostToDevice));
     MLV_HIP(hipMalloc(&d_entries, sizeof(PixEntry) * count));
     MLV_HIP(hipMalloc(&d_level_off, sizeof(int) * off.size()));
     MLV_HIP(hipMemcpy(d_entries, sorted.data(), sizeof(PixEntry) * count, hipMemcpyHostToDevice));
@@ -191,6 +220,8 @@ Clip::~Clip()
 {
     if (d_entries) (void)hipFree(d_entries);
     if (d_level_off) (void)hipFree(d_level_off);
+    if (d_tile_off) (void)hipFree(d_tile_off);
+    if (d_tile_ent) (void)hipFree(d_tile_ent);
     if (d_patches) (void)hipFree(d_patches);
     if (d_scratch) (void)hipFree(d_scratch);
 }
@@ -447,7 +478,7 @@ int mlvfs_amd_chroma_smooth_dev(const mlvfs_amd_geom_t *geom, const void *d_in, 
     if (!c) return MLVFS_AMD_ERR_HIP;
     if (method != 2 && method != 3 && method != 5) { set_error("Unsupported chroma smooth method"); return MLVFS_AMD_ERR_ARG; }
     if (geom->black > 16384) { set_error("Black level too large for processing"); return MLVFS_AMD_ERR_ARG; }
-    return launch_frame(c->dev, to_geom(geom), false, d_in, stride, d_out, stride, nframes, method, nullptr, 0, false,
+    return launch_frame(c->dev, to_geom(geom), false, d_in, stride, d_out, stride, nframes, method, nullptr, false,
                         nullptr, pick_stream(stream, c));
 }
 
@@ -572,8 +603,9 @@ int mlvfs_amd_process_frames_dev(mlvfs_amd_clip_t *clip_, const void *d_packed, 
                            clip->n_levels, clip->n_entries, clip->d_patches, nullptr, 0, nframes, c->dev->luts, s);
         if (rc) return rc;
     }
+    const PatchView pv{ clip->d_patches, clip->n_entries, clip->d_tile_off, clip->d_tile_ent };
     return launch_frame(c->dev, clip->g, true, d_packed, packed_stride, d_out, out_stride, nframes, cs_method,
-                        patch ? (const int2 *)clip->d_patches : nullptr, clip->n_entries, stripes, clip->coef, s);
+                        patch ? &pv : nullptr, stripes, clip->coef, s);
 }
 
 }  // extern "C"

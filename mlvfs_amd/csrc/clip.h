@@ -9,6 +9,19 @@
 
 namespace mlv {
 
+// tile geometry of the fused kernel (k_frame.hip); the per-tile patch lists are built
+// on the host with the same numbers
+constexpr int FRAME_TCW = 64, FRAME_TCH = 16, FRAME_HC = 2;
+inline int frame_tiles_x(int w) { return (w + 2 * FRAME_TCW - 1) / (2 * FRAME_TCW); }
+inline int frame_tiles_y(int h) { return (h + 2 * FRAME_TCH - 1) / (2 * FRAME_TCH); }
+
+struct PatchView {            // what the fused kernel needs to apply a clip's pixel map
+    const void *patches;      // int2[nframes][n_patch] {pos, value}
+    int n_patch;
+    const int *tile_off;      // CSR over tiles of one frame: entries whose cell lies in the tile + halo
+    const int *tile_ent;
+};
+
 struct PixEntry {
     int pos;        // y * w + x in frame coordinates (-1: not applied)
     int kind;       // 0 skip, 1 cross (interpolate_pixel), 2 along x, 3 along y, 4 copy x+2, 5 copy x-2
@@ -30,6 +43,7 @@ struct Clip {
     int n_entries = 0, n_levels = 0;
     PixEntry *d_entries = nullptr;
     int *d_level_off = nullptr;
+    int *d_tile_off = nullptr, *d_tile_ent = nullptr;
     void *d_patches = nullptr;
     size_t patch_bytes = 0;
     void *d_scratch = nullptr;
@@ -75,7 +89,7 @@ KernelTimer &kernel_timer();
 int launch_unpack(const void *d_packed, size_t packed_stride, void *d_out, size_t out_stride, uint32_t first_px,
                   uint32_t npix, int bpp, int nframes, hipStream_t stream);
 int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src, size_t src_stride, void *dst,
-                 size_t dst_stride, int nframes, int method, const int2 *patches, int n_patch, bool stripes,
+                 size_t dst_stride, int nframes, int method, const PatchView *pv, bool stripes,
                  const int32_t *coef, hipStream_t stream);
 int launch_pixfix(bool packed, const void *frames, size_t stride, int w, int black, const void *entries,
                   const int *level_off, int n_levels, int n_entries, void *patches, void *scatter, size_t scatter_stride,

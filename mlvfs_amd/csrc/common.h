@@ -41,7 +41,8 @@ void set_error(const char *fmt, ...);
 
 // ---------------------------------------------------------------- device state
 struct DeviceLuts {
-    const uint16_t *t16;   // [8192]
+    const uint16_t *t16;   // [8192]   mantissa-normalised raw2ev (sparse kernels, global memory)
+    const uint16_t *t16d;  // [16384]  direct raw2ev: raw2ev_lin[i] - (floor(log2 i) << 15) (LDS copy in k_frame)
     const uint16_t *u16;   // [32768]
 };
 
@@ -70,6 +71,7 @@ int bind_device(int device);
 const int32_t *host_raw2ev_lin();   // [16384]  index = p - black
 const int32_t *host_ev2raw();       // [24*32768] index 0 is ev = -10*32768
 const uint16_t *host_t16();
+const uint16_t *host_t16d();
 const uint16_t *host_u16();
 int luts_ok();
 

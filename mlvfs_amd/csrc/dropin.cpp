@@ -143,7 +143,7 @@ void chroma_smooth(struct frame_headers *fh, uint16_t *image_data, int method)
     const size_t bytes = (size_t)v.w * v.h * 2;
     if (upload(c, image_data, bytes)) return;
     if (launch_frame(c->dev, Geom{ v.w, v.h, v.bpp, v.black, v.white }, false, c->d_a, bytes, c->d_b, bytes, 1, method,
-                     nullptr, 0, false, nullptr, c->stream))
+                     nullptr, false, nullptr, c->stream))
         return;
     download(c, image_data, c->d_b, bytes);
 }

@@ -10,17 +10,28 @@
 //   stripes apply   mlvfs/stripes.c:250-266
 //
 // Work decomposition (gfx950: 256 CUs, 8 XCDs, wave64, 160 KiB LDS/CU):
-//   * tile = 64 x 32 Bayer cells (128 x 64 px) per 256-thread workgroup, halo of
-//     2 cells; raw tile (72 x 160 u16) staged in LDS
-//   * per cell (2x2 px) the EV triple {ge, dr = ev(R)-ge, db = ev(B)-ge} is
-//     computed ONCE into LDS planes; the 5x5 (3x3, plus-5) medians then run on
-//     the planes, one thread producing a strip of 8 horizontally adjacent cells
-//     with shared column sorts / pair merges / quad selections (median_nets.h)
-//   * T16 (raw2ev, 16 KiB) lives in LDS, U16 (ev2raw, 64 KiB) is gathered from L2
-//   * workgroups are persistent and walk the tile list; the block -> tile map
-//     keeps each XCD on a contiguous band of tiles so halo re-reads hit its L2
+//   * tile = 64 x 16 Bayer cells (128 x 32 px) per 256-thread workgroup, halo 2 cells;
+//     39 KiB of LDS and <= 128 VGPRs so that FOUR workgroups (16 waves) share a CU and
+//     cover each other's barriers, LDS and HBM latencies
+//   * LOADER: one thread = one "item" = 8 cells (2 rows x 16 px, i.e. 2 x 28 B of
+//     packed stream as 7 dwords each).  It unpacks in registers and writes, per
+//     cell, the EV triple {ge, dr = ev(R)-ge, db = ev(B)-ge} to LDS planes (the
+//     planes are what the medians run on; every pixel's EV is computed once).
+//     The 2-cell halo columns left and right are separate small "edge" items.
+//     The packed dwords of the NEXT tile are prefetched into registers before
+//     the median phase, so HBM latency hides behind the selection networks.
+//   * MEDIANS: one thread = a strip of 4 horizontally adjacent cells with shared
+//     column sorts / pair merges / quad selections (median_nets.h), 10 ds_read_b128
+//     per plane, conflict-free lane -> (row, strip) map.
+//   * raw2ev lives in LDS as the 8192-entry mantissa-normalised 16-bit table (common.h),
+//     ev2raw's 64 KiB table is gathered from L2 (all gathers of a strip in flight at once)
+//   * pixel-map patches: per-tile entry lists (built once per clip on the host)
+//     recompute just the cells they touch
+//   * persistent workgroups, XCD-aware tile walk (each XCD owns a contiguous band of
+//     tiles so halo re-reads hit its own L2)
 // No MFMA: this is a stencil / gather / selection path.
 #include "clip.h"
+#include <cstdlib>
 
 #define MLV_NET_FN __device__ __forceinline__
 #define mlv_mn(a, b) min((a), (b))
@@ -29,15 +40,16 @@
 
 namespace mlv {
 
-constexpr int TCW = 64;                 // tile width  in cells
-constexpr int TCH = 32;                 // tile height in cells
-constexpr int HC = 2;                   // halo in cells
+constexpr int TCW = FRAME_TCW;          // tile width  in cells (64)
+constexpr int TCH = FRAME_TCH;          // tile height in cells (16)
+constexpr int HC = FRAME_HC;            // halo in cells (2)
 constexpr int PW = TCW + 2 * HC;        // plane width  (68)
-constexpr int PH = TCH + 2 * HC;        // plane height (36)
-constexpr int RAW_W = 2 * TCW + 32;     // raw tile row: 16 px margin each side (160)
-constexpr int RAW_H = 2 * PH;           // 72
-constexpr int RAW_X0 = 16;              // raw column of the tile's first pixel
-constexpr int STRIP = 8;                // cells per thread in the median phase
+constexpr int PH = TCH + 2 * HC;        // plane height (20)
+constexpr int STRIP = 4;                // cells per thread in the median phase
+constexpr int GROUPS = TCW / 8;         // full items per plane row (8)
+constexpr int N_FULL = PH * GROUPS;     // 160 full items per tile  (threads 0..159)
+constexpr int N_ITEMS = N_FULL + PH;    // + 20 edge items = 180    (threads 160..179)
+static_assert(N_ITEMS <= 256 && TCH * (TCW / STRIP) == 256, "one item and one strip per thread");
 
 struct FrameArgs {
     const uint8_t *src;      // packed stream or u16 frames
@@ -48,20 +60,32 @@ struct FrameArgs {
     int nframes;
     int tiles_x, tiles_y;
     const uint16_t *t16, *u16;
-    // patches: per frame `n_patch` entries {pos, value}; pos = y*w + x (or -1)
+    // patches: per frame `n_patch` entries {pos, value}; per-tile entry lists (CSR)
     const int2 *patches;
     int n_patch;
+    const int *tile_off, *tile_ent;
     // stripes
     int coef[8];
+    int coef_fast;           // all |coef - 65536| < 32768: 32-bit epilogue
+    int patch, stripes;      // wave-uniform stage switches
+    int dbg;                 // MLVFS_AMD_DBG: timing-only ablation bits (outputs are wrong when set)
 };
 
 struct __align__(16) Smem {
-    uint16_t raw[RAW_H][RAW_W];
-    int dr[PH][PW];
+    uint16_t raw[2 * TCH][2 * TCW];     // interior pixels (post patch), 8 KiB
+    int dr[PH][PW];                     // 5.3 KiB
     int db[PH][PW];
-    int ge[TCH][TCW];
-    uint16_t t16[MLV_T16_N];
+    int ge[TCH][TCW];                   // 4 KiB
+    uint16_t t16[MLV_T16_N];            // mantissa-normalised raw2ev (common.h), 16 KiB
 };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
+// vector-memory counter, which would stall every wave on its own global stores (and
+// on the prefetch loads of the next tile) at each of the three barriers per tile.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ __forceinline__ int med3i(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
 
@@ -78,108 +102,251 @@ __device__ __forceinline__ void sort5(int (&v)[5])
     v[3] = max(max(p, mid), q);
 }
 
-// ---------------------------------------------------------------- phase 1: tile load
+// raw2ev through the LDS mantissa table (main.c:163-167 semantics, see common.h):
+//   ev(lin) = T16[(lin << (13 - e)) & 8191] + (e << 15),  e = floor(log2 lin)
+// Pixels at or below black (ev = INT_MIN / 0) or beyond the table are the rare case: a
+// wave-wide vote picks the branch-free fast path unless some lane needs the fix-up.
+__device__ __forceinline__ int ev_index(int l) { return (l << (__clz(l) - 18)) & 8191; }
+__device__ __forceinline__ int ev_value(int l, int tv) { return tv + ((31 - __clz(l)) << 15); }
+
+// EV triples of two adjacent Bayer cells (8 pixels): r/g1 on the top row, g2/b below
+__device__ __forceinline__ void cell_pair_ev(const uint32_t *p0, const uint32_t *p1, int black, const uint16_t *t,
+                                             int (&ge)[2], int (&dr)[2], int (&db)[2])
+{
+    const int px[8] = { (int)p0[0], (int)p0[1], (int)p1[0], (int)p1[1], (int)p0[2], (int)p0[3], (int)p1[2], (int)p1[3] };
+    int lin[8], l[8], tv[8], ev[8];
+    bool odd = false;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        lin[i] = px[i] - black;
+        odd |= (unsigned)(lin[i] - 1) >= 16383u;
+    }
+    const bool slow = __any(odd);                       // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 8; i++) l[i] = slow ? min(max(lin[i], 1), 16383) : lin[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) tv[i] = t[ev_index(l[i])];
+    // opaque use: keeps the eight LDS reads unconditional and back to back (the compiler
+    // otherwise sinks each read into a branch next to its use and waits for it there)
+    asm volatile("" :: "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]), "v"(tv[4]), "v"(tv[5]), "v"(tv[6]), "v"(tv[7]));
+#pragma unroll
+    for (int i = 0; i < 8; i++) ev[i] = ev_value(l[i], tv[i]);
+    if (slow) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            ev[i] = ((unsigned)(lin[i] - 1) < 16383u) ? ev[i] : (lin[i] == 0 ? (int)0x80000000 : 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        ge[c] = half_trunc(wadd(ev[4 * c + 1], ev[4 * c + 2]));             // chroma_smooth.c:32,54
+        dr[c] = wsub(ev[4 * c + 0], ge[c]);
+        db[c] = wsub(ev[4 * c + 3], ge[c]);
+    }
+}
+
+// single cell (patch path)
+__device__ __forceinline__ void cell_ev(int r, int g1, int g2, int b, int black, const uint16_t *t, int &ge, int &dr, int &db)
+{
+    const uint32_t p0[4] = { (uint32_t)r, (uint32_t)g1, (uint32_t)r, (uint32_t)g1 }, p1[4] = { (uint32_t)g2, (uint32_t)b, (uint32_t)g2, (uint32_t)b };
+    int g[2], a[2], c[2];
+    cell_pair_ev(p0, p1, black, t, g, a, c);
+    ge = g[0]; dr = a[0]; db = c[0];
+}
+
+// ---------------------------------------------------------------- loader
+// Thread t < 160 owns the full item (plane row t/8, group t%8); threads 160..179 own the
+// edge item (two halo cells left + right) of plane row t-160.  An item is NW dwords per
+// row in plain register arrays.  An edge item loads the two dwords that hold the right
+// halo's first 4 px into positions 0,1 and the two dwords that hold the left halo's last
+// 4 px into the last two positions, so the SAME unpack yields right halo = px 0..3 and
+// left halo = px 12..15: one uniform code path, no per-lane variant of the register layout.
+template <bool PACKED> struct Words { static constexpr int N = PACKED ? 7 : 8; };
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// byte offset of the 16-px group starting at pixel (x, y) inside a frame
 template <bool PACKED>
-__device__ __forceinline__ void load_tile(Smem &sm, const FrameArgs &a, const uint8_t *frame, int tx0, int ty0)
+__device__ __forceinline__ size_t group_offset(int w, int x, int y)
 {
-    const int w = a.w, h = a.h;
-    const bool vec = (w % 16) == 0;
-    // work item = (raw row, group of 16 px)
-    for (int it = threadIdx.x; it < RAW_H * (RAW_W / 16); it += blockDim.x) {
-        const int rr = it / (RAW_W / 16), g = it % (RAW_W / 16);
-        int y = ty0 - 2 * HC + rr;
-        int x = tx0 - RAW_X0 + 16 * g;
-        y = y < 0 ? 0 : (y >= h ? h - 1 : y);
-        uint32_t px[16];
-        if (vec) {
-            x = x < 0 ? 0 : (x > w - 16 ? w - 16 : x);
-            if (PACKED) {
-                const uint32_t *s = (const uint32_t *)(frame + ((size_t)y * w + x) / 16 * 28);
-                uint32_t sw[7];
+    const size_t px = (size_t)y * w + x;
+    return PACKED ? px / 16 * 28 : px * 2;
+}
+
+template <bool PACKED>
+__device__ __forceinline__ void issue_item(uint32_t (&r0)[Words<PACKED>::N], uint32_t (&r1)[Words<PACKED>::N],
+                                           const uint8_t *frame, int w, int h, int tx0, int ty0, int tid)
+{
+    constexpr int N = Words<PACKED>::N;
+    const bool edge = tid >= N_FULL;
+    const int pr = edge ? tid - N_FULL : tid >> 3;
+    const int y = ty0 - 2 * HC + 2 * pr;
+    const int x_main = edge ? clampi(tx0 - 16, 0, w - 16) : clampi(tx0 + 16 * (tid & 7), 0, w - 16);
+    const int x_right = clampi(tx0 + 2 * TCW, 0, w - 16);
 #pragma unroll
-                for (int i = 0; i < 7; i++) { uint32_t d = s[i]; sw[i] = (d << 16) | (d >> 16); }
+    for (int rr = 0; rr < 2; rr++) {
+        const int yy = clampi(y + rr, 0, h - 1);
+        const uint32_t *sm_ = (const uint32_t *)(frame + group_offset<PACKED>(w, x_main, yy));
+        const uint32_t *sr_ = (const uint32_t *)(frame + group_offset<PACKED>(w, x_right, yy));
+        uint32_t (&r)[N] = rr ? r1 : r0;
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const int bit = 14 * k, wi = bit >> 5, sh = bit & 31;
-                    if (sh + 14 <= 32) px[k] = (sw[wi] >> (32 - 14 - sh)) & 0x3FFFu;
-                    else px[k] = (uint32_t)((((uint64_t)sw[wi] << 32) | sw[wi + 1]) >> (64 - 14 - sh)) & 0x3FFFu;
-                }
-            } else {
-                const uint4 *s = (const uint4 *)(frame + ((size_t)y * w + x) * 2);
-                const uint4 v0 = s[0], v1 = s[1];
-                const uint32_t d[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+        for (int i = 0; i < N; i++) r[i] = ((edge && i < 2) ? sr_ : sm_)[i];
+    }
+}
+
+__device__ __forceinline__ uint32_t sw16(uint32_t d) { return (d << 16) | (d >> 16); }
+
+// pixel K (0..15) of a 16-pixel group from its seven MSB-first stream words
+template <int K>
+__device__ __forceinline__ uint32_t px14(const uint32_t (&s)[7])
+{
+    constexpr int bit = 14 * K, wi = bit >> 5, sh = bit & 31;
+    if constexpr (sh + 14 <= 32) return (s[wi] >> (32 - 14 - sh)) & 0x3FFFu;
+    else return (uint32_t)((((uint64_t)s[wi] << 32) | s[wi + 1]) >> (64 - 14 - sh)) & 0x3FFFu;
+}
+
+template <bool PACKED>
+__device__ __forceinline__ void unpack16(const uint32_t (&d)[Words<PACKED>::N], uint32_t (&px)[16])
+{
+    if constexpr (PACKED) {
+        uint32_t s[7];
 #pragma unroll
-                for (int k = 0; k < 8; k++) { px[2 * k] = d[k] & 0xFFFFu; px[2 * k + 1] = d[k] >> 16; }
-            }
-        } else {
-            // any width: per-pixel fetch with clamped coordinates
+        for (int i = 0; i < 7; i++) s[i] = sw16(d[i]);
+        px[0] = px14<0>(s);   px[1] = px14<1>(s);   px[2] = px14<2>(s);   px[3] = px14<3>(s);
+        px[4] = px14<4>(s);   px[5] = px14<5>(s);   px[6] = px14<6>(s);   px[7] = px14<7>(s);
+        px[8] = px14<8>(s);   px[9] = px14<9>(s);   px[10] = px14<10>(s); px[11] = px14<11>(s);
+        px[12] = px14<12>(s); px[13] = px14<13>(s); px[14] = px14<14>(s); px[15] = px14<15>(s);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { px[2 * k] = d[k] & 0xFFFFu; px[2 * k + 1] = d[k] >> 16; }
+    }
+}
+
+// any geometry: one pixel with clamped coordinates
+template <bool PACKED>
+__device__ __forceinline__ uint32_t fetch_clamped(const uint8_t *frame, int w, int h, int x, int y)
+{
+    x = clampi(x, 0, w - 1);
+    y = clampi(y, 0, h - 1);
+    const size_t i = (size_t)y * w + x;
+    if (PACKED) {
+        const uint16_t *s = (const uint16_t *)frame;
+        const size_t bit = i * 14;
+        const uint32_t two = ((uint32_t)s[bit >> 4] << 16) | s[(bit >> 4) + 1];
+        return (two >> (32 - 14 - (bit & 15))) & 0x3FFFu;
+    }
+    return ((const uint16_t *)frame)[i];
+}
+
+// slow path (w % 16 != 0): fill the two pixel rows of an item pixel by pixel
+template <bool PACKED>
+__device__ __forceinline__ void fetch_rows(const uint8_t *frame, int w, int h, int x, int y, bool edge, int tx0,
+                                           uint32_t (&p0)[16], uint32_t (&p1)[16])
+{
 #pragma unroll 1
-            for (int k = 0; k < 16; k++) {
-                int xx = x + k;
-                xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
-                const size_t i = (size_t)y * w + xx;
-                if (PACKED) {
-                    const uint16_t *s = (const uint16_t *)frame;
-                    const size_t bit = i * 14;
-                    const uint32_t two = ((uint32_t)s[bit >> 4] << 16) | s[(bit >> 4) + 1];
-                    px[k] = (two >> (32 - 14 - (bit & 15))) & 0x3FFFu;
-                } else {
-                    px[k] = ((const uint16_t *)frame)[i];
-                }
-            }
-        }
-        uint4 lo, hi;
-        lo.x = px[0] | (px[1] << 16);   lo.y = px[2] | (px[3] << 16);
-        lo.z = px[4] | (px[5] << 16);   lo.w = px[6] | (px[7] << 16);
-        hi.x = px[8] | (px[9] << 16);   hi.y = px[10] | (px[11] << 16);
-        hi.z = px[12] | (px[13] << 16); hi.w = px[14] | (px[15] << 16);
-        uint4 *d = (uint4 *)&sm.raw[rr][16 * g];
-        d[0] = lo;
-        d[1] = hi;
+    for (int k = 0; k < 16; k++) {
+        // edge items: px 0..3 = right halo, px 12..15 = left halo (same layout as the fast path)
+        const int xx = edge ? (k < 4 ? tx0 + 2 * TCW + k : tx0 - 16 + k) : x + k;
+        p0[k] = fetch_clamped<PACKED>(frame, w, h, xx, y);
+        p1[k] = fetch_clamped<PACKED>(frame, w, h, xx, y + 1);
     }
 }
 
-// ---------------------------------------------------------------- phase 2: EV planes
-__device__ __forceinline__ void build_planes(Smem &sm, int black)
+// EV triples of NCELL (even) cells into the planes: plane row r, first plane column col0
+template <int NCELL>
+__device__ __forceinline__ void store_cells(Smem &sm, int black, int r, int col0, const uint32_t *p0, const uint32_t *p1)
 {
-    for (int c = threadIdx.x; c < PH * PW; c += blockDim.x) {
-        const int j = c / PW, i = c % PW;
-        const int rx = RAW_X0 - 2 * HC + 2 * i;
-        const uint32_t top = *(const uint32_t *)&sm.raw[2 * j][rx];        // R | G1<<16
-        const uint32_t bot = *(const uint32_t *)&sm.raw[2 * j + 1][rx];    // G2 | B<<16
-        const int er = ev_of_pixel((int)(top & 0xFFFFu), black, sm.t16);
-        const int eg1 = ev_of_pixel((int)(top >> 16), black, sm.t16);
-        const int eg2 = ev_of_pixel((int)(bot & 0xFFFFu), black, sm.t16);
-        const int eb = ev_of_pixel((int)(bot >> 16), black, sm.t16);
-        const int ge = half_trunc(wadd(eg1, eg2));                          // chroma_smooth.c:32,54
-        sm.dr[j][i] = wsub(er, ge);
-        sm.db[j][i] = wsub(eb, ge);
-        const int ji = j - HC, ii = i - HC;
-        if (ji >= 0 && ji < TCH && ii >= 0 && ii < TCW) sm.ge[ji][ii] = ge;
+    const bool row_in = r >= HC && r < HC + TCH;
+#pragma unroll
+    for (int c = 0; c < NCELL; c += 2) {
+        int ge[2], dr[2], db[2];
+        cell_pair_ev(p0 + 2 * c, p1 + 2 * c, black, sm.t16, ge, dr, db);
+        *(int2 *)&sm.dr[r][col0 + c] = make_int2(dr[0], dr[1]);
+        *(int2 *)&sm.db[r][col0 + c] = make_int2(db[0], db[1]);
+        const int ci = col0 + c - HC;
+        if (row_in && ci >= 0 && ci < TCW) *(int2 *)&sm.ge[r - HC][ci] = make_int2(ge[0], ge[1]);
     }
 }
 
-// ---------------------------------------------------------------- phase 3: medians
-// 5x5: strip of 8 outputs from 12 sorted columns
+__device__ __forceinline__ void store_raw(Smem &sm, int row, int g, const uint32_t (&p)[16])
+{
+    uint4 *o = (uint4 *)&sm.raw[row][16 * g];
+    o[0] = make_uint4(p[0] | (p[1] << 16), p[2] | (p[3] << 16), p[4] | (p[5] << 16), p[6] | (p[7] << 16));
+    o[1] = make_uint4(p[8] | (p[9] << 16), p[10] | (p[11] << 16), p[12] | (p[13] << 16), p[14] | (p[15] << 16));
+}
+
+// pixels of one item -> planes (+ interior raw)
+template <int METHOD>
+__device__ __forceinline__ void emit_item(Smem &sm, int black, int pr, int g, bool edge, const uint32_t (&p0)[16], const uint32_t (&p1)[16])
+{
+    if (!edge) {
+        if (METHOD != 0) store_cells<8>(sm, black, pr, HC + 8 * g, p0, p1);
+        if (pr >= HC && pr < HC + TCH) {
+            store_raw(sm, 2 * (pr - HC), g, p0);
+            store_raw(sm, 2 * (pr - HC) + 1, g, p1);
+        }
+    } else if (METHOD != 0) {
+        store_cells<2>(sm, black, pr, 0, p0 + 12, p1 + 12);          // left halo  (px 12..15)
+        store_cells<2>(sm, black, pr, HC + TCW, p0, p1);             // right halo (px 0..3)
+    }
+}
+
+// ---------------------------------------------------------------- patches
+// recompute every cell of this tile that a pixel-map entry touches
+template <int METHOD, bool PACKED>
+__device__ __forceinline__ void apply_patches(Smem &sm, const FrameArgs &a, const uint8_t *frame, int f, int beg, int end, int tx0, int ty0)
+{
+    const int2 *pl = a.patches + (size_t)f * a.n_patch;
+    for (int k = beg + (int)threadIdx.x; k < end; k += blockDim.x) {
+        const int2 e = pl[a.tile_ent[k]];
+        if (e.x < 0) continue;
+        const int cx = (e.x % a.w) >> 1, cy = (e.x / a.w) >> 1;
+        const int i = cx - (tx0 / 2 - HC), j = cy - (ty0 / 2 - HC);
+        if (i < 0 || i >= PW || j < 0 || j >= PH) continue;
+        int px[4];                                              // r, g1, g2, b of that cell
+#pragma unroll
+        for (int q = 0; q < 4; q++) px[q] = (int)fetch_clamped<PACKED>(frame, a.w, a.h, 2 * cx + (q & 1), 2 * cy + (q >> 1));
+        for (int k2 = beg; k2 < end; k2++) {                    // all repaired pixels of this cell
+            const int2 e2 = pl[a.tile_ent[k2]];
+            if (e2.x < 0) continue;
+            const int x2 = e2.x % a.w, y2 = e2.x / a.w;
+            if ((x2 >> 1) == cx && (y2 >> 1) == cy) px[(x2 & 1) + 2 * (y2 & 1)] = e2.y & 0xFFFF;
+        }
+        int ge = 0, dr = 0, db = 0;
+        if (METHOD != 0) {
+            cell_ev(px[0], px[1], px[2], px[3], a.black, sm.t16, ge, dr, db);
+            sm.dr[j][i] = dr;
+            sm.db[j][i] = db;
+        }
+        const int ii = i - HC, jj = j - HC;
+        if (ii >= 0 && ii < TCW && jj >= 0 && jj < TCH) {
+            if (METHOD != 0) sm.ge[jj][ii] = ge;
+            *(uint32_t *)&sm.raw[2 * jj][2 * ii] = (uint32_t)px[0] | ((uint32_t)px[1] << 16);
+            *(uint32_t *)&sm.raw[2 * jj + 1][2 * ii] = (uint32_t)px[2] | ((uint32_t)px[3] << 16);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- medians
+// 5x5: strip of 4 outputs from 8 sorted columns
 __device__ __forceinline__ void strip_median25(const int (*plane)[PW], int row_top, int col_left, int (&med)[STRIP])
 {
-    int col[12][5];
+    int col[8][5];
 #pragma unroll
     for (int r = 0; r < 5; r++) {
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
+        for (int q = 0; q < 2; q++) {
             const int4 v = *(const int4 *)&plane[row_top + r][col_left + 4 * q];
             col[4 * q + 0][r] = v.x; col[4 * q + 1][r] = v.y; col[4 * q + 2][r] = v.z; col[4 * q + 3][r] = v.w;
         }
     }
 #pragma unroll
-    for (int c = 0; c < 12; c++) sort5(col[c]);
-    int pr[6][10];
+    for (int c = 0; c < 8; c++) sort5(col[c]);
+    int pr[4][10];
 #pragma unroll
-    for (int p = 0; p < 6; p++) mlv_merge55(col[2 * p], col[2 * p + 1], pr[p]);
-    int qd[5][6];
+    for (int p = 0; p < 4; p++) mlv_merge55(col[2 * p], col[2 * p + 1], pr[p]);
+    int qd[3][6];
 #pragma unroll
-    for (int q = 0; q < 5; q++) mlv_quad_mid6(pr[q], pr[q + 1], qd[q]);
+    for (int q = 0; q < 3; q++) mlv_quad_mid6(pr[q], pr[q + 1], qd[q]);
 #pragma unroll
     for (int c = 0; c < STRIP; c++) {
         const int x = c + 2;
@@ -193,9 +360,9 @@ __device__ __forceinline__ void strip_median25(const int (*plane)[PW], int row_t
 // 3x3: sorted columns of 3, classic max-of-mins / med-of-meds / min-of-maxes
 __device__ __forceinline__ void strip_median9(const int (*plane)[PW], int row_top, int col_left, int (&med)[STRIP])
 {
-    int lo[10], mi[10], hi[10];
+    int lo[STRIP + 2], mi[STRIP + 2], hi[STRIP + 2];
 #pragma unroll
-    for (int c = 0; c < 10; c++) {
+    for (int c = 0; c < STRIP + 2; c++) {
         const int a = plane[row_top][col_left + c], b = plane[row_top + 1][col_left + c], d = plane[row_top + 2][col_left + c];
         lo[c] = min(min(a, b), d);
         hi[c] = max(max(a, b), d);
@@ -222,16 +389,36 @@ __device__ __forceinline__ void strip_median5(const int (*plane)[PW], int row_to
 }
 
 // stripes.c:250-266: p' = (uint16)min(white, (p-black)*coef/65536 + black), exact in integers
+template <bool FAST>
 __device__ __forceinline__ uint32_t stripe_px(uint32_t p, int coef, int black16, int white16)
 {
+    if (FAST) {
+        // coef = 65536 + d with |d| < 2^15: ((p-black)*coef) >> 16 == (p-black) + (((p-black)*d) >> 16)
+        const int a = (int)p - black16;
+        const int v = (int)p + (__mul24(a, coef - 65536) >> 16);
+        return (a > 64) ? (uint32_t)min(v, white16) : p;
+    }
     if (coef == 0 || (int)p <= black16 + 64) return p;
     const long long num = (long long)((int)p - black16) * coef + ((long long)black16 << 16);   // value * 65536
     if (((long long)white16 << 16) < num) return (uint32_t)white16;
     return (uint32_t)(int)(num / 65536) & 0xFFFFu;
 }
 
-template <int METHOD, bool PACKED, bool PATCH, bool STRIPES>
-__global__ __launch_bounds__(256) void k_frame(const FrameArgs a)
+template <bool FAST>
+__device__ __forceinline__ void stripe_strip(uint32_t (&top)[STRIP], uint32_t (&bot)[STRIP], const int (&coef)[8], int black16, int white16)
+{
+#pragma unroll
+    for (int c = 0; c < STRIP; c++) {
+        const int p0 = (2 * c) & 7, p1 = (2 * c + 1) & 7;
+        top[c] = stripe_px<FAST>(top[c] & 0xFFFFu, coef[p0], black16, white16) |
+                 (stripe_px<FAST>(top[c] >> 16, coef[p1], black16, white16) << 16);
+        bot[c] = stripe_px<FAST>(bot[c] & 0xFFFFu, coef[p0], black16, white16) |
+                 (stripe_px<FAST>(bot[c] >> 16, coef[p1], black16, white16) << 16);
+    }
+}
+
+template <int METHOD, bool PACKED, bool VEC>
+__global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -245,49 +432,93 @@ __global__ __launch_bounds__(256) void k_frame(const FrameArgs a)
     // XCD-aware persistent tile walk: blocks b, b+8, b+16, ... share an XCD; give
     // every XCD a contiguous band of the tile list
     const int tiles_per_frame = a.tiles_x * a.tiles_y;
-    const long long total = (long long)tiles_per_frame * a.nframes;
+    const int total = tiles_per_frame * a.nframes;          // < 2^30 (checked by the launcher)
     const int nx = 8;
-    const long long band = (total + nx - 1) / nx;
+    const int band = (total + nx - 1) / nx;
     const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx, slots = (gridDim.x + nx - 1) / nx;
-    const long long band_end = min(total, (long long)(xcd + 1) * band);
+    const int band_end = min(total, (xcd + 1) * band);
     const int black16 = (int)(uint16_t)a.black, white16 = (int)(uint16_t)a.white;
+    constexpr bool vec = VEC;                            // w % 16 == 0: dword/vector loads and stores
 
-    for (long long t = (long long)xcd * band + slot; t < band_end; t += slots) {
-        const int f = (int)(t / tiles_per_frame), tr = (int)(t % tiles_per_frame);
-        const int tx0 = (tr % a.tiles_x) * 2 * TCW, ty0 = (tr / a.tiles_x) * 2 * TCH;
+    constexpr int NW = Words<PACKED>::N;
+    uint32_t r0[NW], r1[NW];                             // prefetch registers of this thread's item
+    const int tid = threadIdx.x;
+    const bool has_item = tid < N_ITEMS;
+    const bool edge = tid >= N_FULL;
+    const int item_row = edge ? tid - N_FULL : tid >> 3, item_g = tid & 7;
+
+    // median phase: lane -> (row, strip).  The 16 lanes that one ds_read_b128 pass serves
+    // together ({0-3,12-15,20-27} / {4-11,16-19,28-31} of each half wave) share one row and
+    // take its 16 strips, so their 16-byte accesses fall into 16 different bank groups.
+    const int lane = tid & 63;
+    const int la = (lane >> 4) & 1, lb = (lane >> 3) & 1, lc = (lane >> 2) & 1;
+    const int k = (la << 3) | (lb << 2) | (lane & 3);
+    const int j = (tid >> 6) * 4 + ((lane >> 5) << 1) + (la ^ lb ^ lc);
+
+    int t = xcd * band + slot;
+    auto tile_coords = [&](int tt, int &f, int &tr, int &tx0, int &ty0) {
+        f = tt / tiles_per_frame;
+        tr = tt - f * tiles_per_frame;
+        const int trow = tr / a.tiles_x;
+        tx0 = (tr - trow * a.tiles_x) * 2 * TCW;
+        ty0 = trow * 2 * TCH;
+    };
+    // The prefetch is unconditional on purpose: threads without an item and the last
+    // iteration re-load a valid item / tile.  A conditional load would need the old
+    // register value on the other path, and the copies the compiler inserts for that
+    // merge wait for the load right where it is issued.
+    const int load_tid = min(tid, N_ITEMS - 1);
+    auto issue_tile = [&](int tt) {
+        int f, tr, tx0, ty0;
+        tile_coords(tt, f, tr, tx0, ty0);
+        issue_item<PACKED>(r0, r1, a.src + (size_t)f * a.src_stride, a.w, a.h, tx0, ty0, load_tid);
+    };
+    // patch-list bounds of a tile travel with its prefetch (software pipelined like the data)
+    int nbeg = 0, nend = 0;
+    auto issue_bounds = [&](int tt) {
+        if (a.patch) {
+            const int tr = tt % tiles_per_frame;
+            nbeg = a.tile_off[tr];
+            nend = a.tile_off[tr + 1];
+        }
+    };
+    if (vec) issue_tile(min(t, max(total - 1, 0)));
+    issue_bounds(min(t, max(total - 1, 0)));
+    __syncthreads();                           // T16 copy complete
+
+    for (; t < band_end; t += slots) {
+        int f, tr, tx0, ty0;
+        tile_coords(t, f, tr, tx0, ty0);
         const uint8_t *frame = a.src + (size_t)f * a.src_stride;
         uint16_t *out = (uint16_t *)(a.dst + (size_t)f * a.dst_stride);
-
-        __syncthreads();                       // previous tile's readers are done (also covers the T16 copy)
-        load_tile<PACKED>(sm, a, frame, tx0, ty0);
-        if (PATCH) {
-            __syncthreads();
-            const int2 *pl = a.patches + (size_t)f * a.n_patch;
-            for (int i = threadIdx.x; i < a.n_patch; i += blockDim.x) {
-                const int2 e = pl[i];
-                if (e.x < 0) continue;
-                const int py = e.x / a.w - (ty0 - 2 * HC), px = e.x % a.w - (tx0 - RAW_X0);
-                if (py >= 0 && py < RAW_H && px >= 0 && px < RAW_W) sm.raw[py][px] = (uint16_t)e.y;
-            }
+        const int pbeg = nbeg, pend = nend;      // fetched one iteration ago, together with the tile data
+        // ---- loader: prefetched registers -> EV planes + interior raw pixels
+        if (has_item) {
+            uint32_t p0[16], p1[16];
+            if (vec) { unpack16<PACKED>(r0, p0); unpack16<PACKED>(r1, p1); }
+            else fetch_rows<PACKED>(frame, a.w, a.h, tx0 + 16 * item_g, ty0 - 2 * HC + 2 * item_row, edge, tx0, p0, p1);
+            if (!(a.dbg & 1)) emit_item<METHOD>(sm, a.black, item_row, item_g, edge, p0, p1);
+            else asm volatile("" :: "v"(p0[0] ^ p0[5] ^ p0[15] ^ p1[3] ^ p1[12]));
         }
-        __syncthreads();
-        if (METHOD != 0) {
-            build_planes(sm, a.black);
-            __syncthreads();
+        lds_barrier();
+        if (a.patch && pbeg != pend) {          // wave-uniform; list bounds were fetched at the top of the iteration
+            apply_patches<METHOD, PACKED>(sm, a, frame, f, pbeg, pend, tx0, ty0);
+            lds_barrier();
         }
+        // ---- prefetch the next tile while the medians run
+        if (vec) issue_tile(min(t + slots, band_end - 1));
+        issue_bounds(min(t + slots, band_end - 1));
 
-        // one thread = 8 cells = 16 px on two rows
-        const int k = threadIdx.x % (TCW / STRIP), j = threadIdx.x / (TCW / STRIP);
+        // ---- medians + output: one thread = 4 cells = 8 px on two rows
         const int y = ty0 + 2 * j, x = tx0 + 2 * STRIP * k;
         uint32_t top[STRIP], bot[STRIP];        // (R | G1<<16), (G2 | B<<16)
         {
-            const uint4 *r0 = (const uint4 *)&sm.raw[2 * (j + HC)][RAW_X0 + 2 * STRIP * k];
-            const uint4 *r1 = (const uint4 *)&sm.raw[2 * (j + HC) + 1][RAW_X0 + 2 * STRIP * k];
-            const uint4 a0 = r0[0], a1 = r0[1], b0 = r1[0], b1 = r1[1];
-            top[0] = a0.x; top[1] = a0.y; top[2] = a0.z; top[3] = a0.w; top[4] = a1.x; top[5] = a1.y; top[6] = a1.z; top[7] = a1.w;
-            bot[0] = b0.x; bot[1] = b0.y; bot[2] = b0.z; bot[3] = b0.w; bot[4] = b1.x; bot[5] = b1.y; bot[6] = b1.z; bot[7] = b1.w;
+            const uint4 v0 = *(const uint4 *)&sm.raw[2 * j][2 * STRIP * k];
+            const uint4 v1 = *(const uint4 *)&sm.raw[2 * j + 1][2 * STRIP * k];
+            top[0] = v0.x; top[1] = v0.y; top[2] = v0.z; top[3] = v0.w;
+            bot[0] = v1.x; bot[1] = v1.y; bot[2] = v1.z; bot[3] = v1.w;
         }
-        if (METHOD != 0 && y >= 4 && y < a.h - 5) {
+        if (METHOD != 0 && y >= 4 && y < a.h - 5 && !(a.dbg & 2)) {
             int mr[STRIP], mb[STRIP];
             if (METHOD == 5) {
                 strip_median25(sm.dr, j, STRIP * k, mr);
@@ -299,39 +530,40 @@ __global__ __launch_bounds__(256) void k_frame(const FrameArgs a)
                 strip_median5(sm.dr, j + 1, STRIP * k + 1, mr);
                 strip_median5(sm.db, j + 1, STRIP * k + 1, mb);
             }
+            const int4 g4 = *(const int4 *)&sm.ge[j][STRIP * k];
+            const int gev[STRIP] = { g4.x, g4.y, g4.z, g4.w };
+            // ev2raw gathers (64 KiB table in L2): all 8 issued before the first use
+            int er[STRIP], eb[STRIP], ur[STRIP], ub[STRIP];
+#pragma unroll
+            for (int c = 0; c < STRIP; c++) {
+                er[c] = wadd(gev[c], mr[c]);
+                eb[c] = wadd(gev[c], mb[c]);
+                ur[c] = a.u16[min(max(er[c], 0), MLV_EV_MAX) & 32767];
+                ub[c] = a.u16[min(max(eb[c], 0), MLV_EV_MAX) & 32767];
+            }
+            asm volatile("" :: "v"(ur[0]), "v"(ur[1]), "v"(ur[2]), "v"(ur[3]), "v"(ub[0]), "v"(ub[1]), "v"(ub[2]), "v"(ub[3]));
 #pragma unroll
             for (int c = 0; c < STRIP; c++) {
                 const int xc = x + 2 * c;
-                const int ge = sm.ge[j][STRIP * k + c];
-                const int er = wadd(ge, mr[c]), eb = wadd(ge, mb[c]);
                 // chroma_smooth.c:28, 35, 64-65
-                if (xc >= 4 && xc < a.w - 4 && ge >= 2 * MLV_EV_RES && er > MLV_EV_RES && eb > MLV_EV_RES) {
-                    top[c] = (top[c] & 0xFFFF0000u) | pixel_of_ev(er, a.black, a.u16);
-                    bot[c] = (bot[c] & 0x0000FFFFu) | ((uint32_t)pixel_of_ev(eb, a.black, a.u16) << 16);
-                }
+                const bool ok = xc >= 4 && xc < a.w - 4 && gev[c] >= 2 * MLV_EV_RES && er[c] > MLV_EV_RES && eb[c] > MLV_EV_RES;
+                const int qr = min(max(er[c], 0), MLV_EV_MAX) >> 15, qb = min(max(eb[c], 0), MLV_EV_MAX) >> 15;
+                const uint32_t pr_ = (uint32_t)((ur[c] >> (13 - qr)) + a.black) & 0xFFFFu;
+                const uint32_t pb_ = (uint32_t)((ub[c] >> (13 - qb)) + a.black) & 0xFFFFu;
+                top[c] = ok ? ((top[c] & 0xFFFF0000u) | pr_) : top[c];
+                bot[c] = ok ? ((bot[c] & 0x0000FFFFu) | (pb_ << 16)) : bot[c];
             }
         }
-        if (STRIPES) {
-#pragma unroll
-            for (int c = 0; c < STRIP; c++) {
-                const int p0 = (2 * c) & 7, p1 = (2 * c + 1) & 7;
-                top[c] = stripe_px(top[c] & 0xFFFFu, a.coef[p0], black16, white16) |
-                         (stripe_px(top[c] >> 16, a.coef[p1], black16, white16) << 16);
-                bot[c] = stripe_px(bot[c] & 0xFFFFu, a.coef[p0], black16, white16) |
-                         (stripe_px(bot[c] >> 16, a.coef[p1], black16, white16) << 16);
-            }
+        if (a.stripes) {
+            // a strip starts at an x that is a multiple of 8, so pixel n of the strip has column phase n
+            if (a.coef_fast) stripe_strip<true>(top, bot, a.coef, black16, white16);
+            else stripe_strip<false>(top, bot, a.coef, black16, white16);
         }
-        if (y < a.h) {
-            if ((a.w % 16) == 0) {
+        if (y < a.h && !(a.dbg & 4)) {
+            if (vec) {
                 if (x < a.w) {
-                    uint4 *o0 = (uint4 *)(out + (size_t)y * a.w + x);
-                    o0[0] = make_uint4(top[0], top[1], top[2], top[3]);
-                    o0[1] = make_uint4(top[4], top[5], top[6], top[7]);
-                    if (y + 1 < a.h) {
-                        uint4 *o1 = (uint4 *)(out + (size_t)(y + 1) * a.w + x);
-                        o1[0] = make_uint4(bot[0], bot[1], bot[2], bot[3]);
-                        o1[1] = make_uint4(bot[4], bot[5], bot[6], bot[7]);
-                    }
+                    *(uint4 *)(out + (size_t)y * a.w + x) = make_uint4(top[0], top[1], top[2], top[3]);
+                    if (y + 1 < a.h) *(uint4 *)(out + (size_t)(y + 1) * a.w + x) = make_uint4(bot[0], bot[1], bot[2], bot[3]);
                 }
             } else {
 #pragma unroll 1
@@ -346,42 +578,39 @@ __global__ __launch_bounds__(256) void k_frame(const FrameArgs a)
                 }
             }
         }
+        lds_barrier();                       // all strips done with the planes before the next tile's loader
     }
 }
 
 // ---------------------------------------------------------------- host launcher
-template <int METHOD, bool PACKED>
-static int launch_frame_t(const FrameArgs &a, bool patch, bool stripes, int num_cu, hipStream_t stream)
+template <int METHOD, bool PACKED, bool VEC>
+static int launch_frame_t(const FrameArgs &a, int num_cu, hipStream_t stream)
 {
     const long long total = (long long)a.tiles_x * a.tiles_y * a.nframes;
-    int grid = num_cu > 0 ? num_cu * 2 : 512;
+    int grid = num_cu > 0 ? num_cu * 4 : 1024;          // 4 workgroups per CU (39 KiB LDS, <= 128 VGPRs)
     grid = (grid + 7) / 8 * 8;
     if (grid > total) grid = (int)((total + 7) / 8 * 8);
     const size_t shmem = sizeof(Smem);
-#define MLV_LAUNCH(P, S)                                                                                  \
-    do {                                                                                                  \
-        auto kern = k_frame<METHOD, PACKED, P, S>;                                                        \
-        MLV_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-        KernelTimer &tm = kernel_timer();                                                                 \
-        const bool timed = tm.on && tm.used + 2 <= (int)tm.ev.size();                                     \
-        if (timed) MLV_HIP(hipEventRecord(tm.ev[tm.used], stream));                                       \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, stream, a);                                \
-        if (timed) { MLV_HIP(hipEventRecord(tm.ev[tm.used + 1], stream)); tm.used += 2; }                 \
-    } while (0)
-    if (patch && stripes) MLV_LAUNCH(true, true);
-    else if (patch) MLV_LAUNCH(true, false);
-    else if (stripes) MLV_LAUNCH(false, true);
-    else MLV_LAUNCH(false, false);
-#undef MLV_LAUNCH
+    auto kern = k_frame<METHOD, PACKED, VEC>;
+    MLV_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    KernelTimer &tm = kernel_timer();
+    const bool timed = tm.on && tm.used + 2 <= (int)tm.ev.size();
+    if (timed) MLV_HIP(hipEventRecord(tm.ev[tm.used], stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, stream, a);
+    if (timed) { MLV_HIP(hipEventRecord(tm.ev[tm.used + 1], stream)); tm.used += 2; }
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
 
 int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src, size_t src_stride, void *dst,
-                 size_t dst_stride, int nframes, int method, const int2 *patches, int n_patch, bool stripes,
+                 size_t dst_stride, int nframes, int method, const PatchView *pv, bool stripes,
                  const int32_t *coef, hipStream_t stream)
 {
     if (nframes <= 0) return MLVFS_AMD_OK;
+    if ((long long)frame_tiles_x(g.w) * frame_tiles_y(g.h) * nframes >= (1ll << 30)) {
+        set_error("too many tiles in one launch (%d frames): split the batch", nframes);
+        return MLVFS_AMD_ERR_ARG;
+    }
     if (g.w < 2 || g.h < 2 || (g.w & 1)) { set_error("frame geometry %dx%d unsupported", g.w, g.h); return MLVFS_AMD_ERR_ARG; }
     if (packed && g.bpp != 14) { set_error("fused path needs 14-bit input"); return MLVFS_AMD_ERR_ARG; }
     FrameArgs a{};
@@ -389,15 +618,26 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
     a.dst = (uint8_t *)dst; a.dst_stride = dst_stride;
     a.w = g.w; a.h = g.h; a.black = g.black; a.white = g.white;
     a.nframes = nframes;
-    a.tiles_x = (g.w + 2 * TCW - 1) / (2 * TCW);
-    a.tiles_y = (g.h + 2 * TCH - 1) / (2 * TCH);
+    a.tiles_x = frame_tiles_x(g.w);
+    a.tiles_y = frame_tiles_y(g.h);
     a.t16 = dev->luts.t16; a.u16 = dev->luts.u16;
-    a.patches = patches; a.n_patch = patches ? n_patch : 0;
-    for (int i = 0; i < 8; i++) a.coef[i] = (stripes && coef) ? coef[i] : 0;
-    const bool patch = a.n_patch > 0;
-#define MLV_DISPATCH(M)                                                                          \
-    return packed ? launch_frame_t<M, true>(a, patch, stripes, dev->num_cu, stream)              \
-                  : launch_frame_t<M, false>(a, patch, stripes, dev->num_cu, stream)
+    a.patch = pv && pv->n_patch > 0;
+    if (a.patch) { a.patches = (const int2 *)pv->patches; a.n_patch = pv->n_patch; a.tile_off = pv->tile_off; a.tile_ent = pv->tile_ent; }
+    a.stripes = stripes ? 1 : 0;
+    { const char *e = getenv("MLVFS_AMD_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.coef_fast = 1;
+    for (int i = 0; i < 8; i++) {
+        a.coef[i] = (stripes && coef) ? coef[i] : 0;
+        if (a.coef[i] - 65536 <= -32768 || a.coef[i] - 65536 >= 32768) a.coef_fast = 0;
+    }
+    // vector path: rows are whole 16-pixel groups and every row starts 16-byte aligned
+    const bool vec = (g.w % 16) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 &&
+                     (nframes == 1 || (src_stride % 16 == 0 && dst_stride % 16 == 0));
+#define MLV_DISPATCH(M)                                                                                   \
+    return packed ? (vec ? launch_frame_t<M, true, true>(a, dev->num_cu, stream)                          \
+                         : launch_frame_t<M, true, false>(a, dev->num_cu, stream))                        \
+                  : (vec ? launch_frame_t<M, false, true>(a, dev->num_cu, stream)                         \
+                         : launch_frame_t<M, false, false>(a, dev->num_cu, stream))
     switch (method) {
         case 0: MLV_DISPATCH(0);
         case 2: MLV_DISPATCH(2);

@@ -43,7 +43,7 @@ void set_error(const char *fmt, ...)
 // ------------------------------------------------------------------ tables
 static std::once_flag g_lut_once;
 static std::vector<int32_t> g_raw2ev_lin, g_ev2raw;
-static std::vector<uint16_t> g_t16, g_u16;
+static std::vector<uint16_t> g_t16, g_t16d, g_u16;
 static int g_luts_ok = 0;
 
 static void build_luts()
@@ -74,6 +74,12 @@ static void build_luts()
         if (v < 0 || v > 65535) ok = 0;
         g_u16[f] = (uint16_t)v;
     }
+    g_t16d.assign(16384, 0);
+    for (int i = 1; i < 16384; i++) {
+        const int v = g_raw2ev_lin[i] - ((31 - __builtin_clz(i)) << 15);
+        if (v < 0 || v > 65535) ok = 0;
+        g_t16d[i] = (uint16_t)v;
+    }
     if (g_raw2ev_lin[0] != INT_MIN) ok = 0;
     for (int i = 1; i < 16384 && ok; i++) {
         int e = 31 - __builtin_clz(i);
@@ -92,6 +98,7 @@ static void ensure_luts() { std::call_once(g_lut_once, build_luts); }
 const int32_t *host_raw2ev_lin() { ensure_luts(); return g_raw2ev_lin.data(); }
 const int32_t *host_ev2raw() { ensure_luts(); return g_ev2raw.data(); }
 const uint16_t *host_t16() { ensure_luts(); return g_t16.data(); }
+const uint16_t *host_t16d() { ensure_luts(); return g_t16d.data(); }
 const uint16_t *host_u16() { ensure_luts(); return g_u16.data(); }
 int luts_ok() { ensure_luts(); return g_luts_ok; }
 
@@ -110,8 +117,10 @@ static Device *get_device(int id)
     d->id = id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, id) == hipSuccess) d->num_cu = prop.multiProcessorCount;
-    uint16_t *t16 = nullptr, *u16 = nullptr;
+    uint16_t *t16 = nullptr, *t16d = nullptr, *u16 = nullptr;
     if (hipMalloc(&t16, MLV_T16_N * 2) != hipSuccess || hipMalloc(&u16, MLV_U16_N * 2) != hipSuccess ||
+        hipMalloc(&t16d, 16384 * 2) != hipSuccess ||
+        hipMemcpy(t16d, host_t16d(), 16384 * 2, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(t16, host_t16(), MLV_T16_N * 2, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(u16, host_u16(), MLV_U16_N * 2, hipMemcpyHostToDevice) != hipSuccess) {
         set_error("device %d: table upload failed", id);
@@ -119,6 +128,7 @@ static Device *get_device(int id)
         return nullptr;
     }
     d->luts.t16 = t16;
+    d->luts.t16d = t16d;
     d->luts.u16 = u16;
     g_devices[id] = d;
     return d;
