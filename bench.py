@@ -183,7 +183,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_frame_bytes_per_launch")
+            traffic = int(json.load(open(tpath)).get("k_frame_bytes_per_frame") * F)     # per launch, like `achieved`
         except Exception:
             traffic = None
 

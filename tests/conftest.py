@@ -55,7 +55,7 @@ def gpu(amd):
 
 def fnv1a(a: np.ndarray) -> str:
     """64-bit FNV-1a over 64-bit words (fast enough for full-size frames)."""
-    b = np.ascontiguousarray(a).view(np.uint8)
+    b = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
     pad = (-b.size) % 8
     if pad:
         b = np.concatenate([b, np.zeros(pad, np.uint8)])

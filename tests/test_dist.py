@@ -1,0 +1,73 @@
+"""Multi-GPU host logic on CPU: world_size-2 gloo processes run mlvfs_amd.dist with CPU
+callbacks (the oracle's row-shard histogram) in place of the HIP kernels.
+
+Checks SURVEY.md 8e: the row-sharded first-frame stripes histogram (all_gather of the
+accepted-call counts -> rand() offsets, all_reduce of int32[8][65536]) gives every rank
+the coefficients of the single-process reference, and frames shard without overlap."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, w, h, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mlvfs_amd import dist as mdist, synth
+    from oracle.bindings import Oracle           # CPU stand-in for the kernels (test only)
+    o = Oracle()
+    f = synth.normal_frame(w, h)
+    black, white = synth.BLACK, synth.WHITE
+
+    def count_rows(r0, r1):
+        return o.stripes_hist_rows(f, r0, r1, black, white)
+
+    def hist_rows(r0, r1, first, n):
+        rnd = mdist.glibc_rand_slice(first, n)
+        _, hist, num = o.stripes_hist_rows(f, r0, r1, black, white, rnd)
+        return torch.from_numpy(hist), torch.from_numpy(num)
+
+    hist, num, calls = mdist.sharded_stripes_histogram(count_rows, hist_rows, h, torch.device("cpu"))
+    needed, co = mdist.solve_coefficients(hist, num, w * h * 14 // 8)
+    lo, hi = mdist.frame_range(1000, rank, world)
+    q.put((rank, needed, [int(c) for c in co], calls, lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_stripes_over_gloo(oracle, world):
+    from mlvfs_amd import synth
+    w, h = 256, 130
+    want_needed, want_co, hist, num = oracle.stripes_compute(synth.normal_frame(w, h), synth.BLACK, synth.WHITE, want_hist=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    covered = []
+    for rank, needed, co, calls, lo, hi in res:
+        assert needed == want_needed and co == [int(c) for c in want_co]
+        assert calls == int(num.sum())
+        covered += list(range(lo, hi))
+    assert covered == list(range(1000))                      # frames: disjoint, complete
+
+
+def test_ranges():
+    from mlvfs_amd import dist as mdist
+    for n, world in ((1000, 8), (7, 3), (1, 4)):
+        got = [mdist.frame_range(n, r, world) for r in range(world)]
+        assert got[0][0] == 0 and got[-1][1] == n and all(a[1] == b[0] for a, b in zip(got, got[1:]))
+    assert mdist.row_range(1320, 3, 8) == (495, 660)

@@ -1,0 +1,124 @@
+"""Committed golden vectors (tests/golden/, generated from the reference's own code by
+make_golden.py): the oracle must reproduce them on CPU (-m "not gpu"); the HIP library
+must reproduce them on the GPU box, where /root/reference does not exist (-m gpu)."""
+import ctypes as C
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import fnv1a
+from mlvfs_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+SMALL = sorted(glob.glob(os.path.join(GOLD, "small_*.npz")))
+META = json.load(open(os.path.join(GOLD, "golden.json")))
+BLACK, WHITE = synth.BLACK, synth.WHITE
+
+
+def test_fixtures_present():
+    assert len(SMALL) >= 5 and "B_cs5_badpix_stripes_frame1" in META["full_size"]
+
+
+@pytest.mark.parametrize("path", SMALL, ids=[os.path.basename(p)[6:-4] for p in SMALL])
+def test_oracle_reproduces_small_vectors(oracle, path):
+    g = np.load(path)
+    f = g["frame"]
+    h, w = f.shape
+    assert np.array_equal(oracle.unpack(g["packed14"], w, h, 14).reshape(h, w), g["unpack14"])
+    assert np.array_equal(g["unpack14"], f)
+    for bpp in (10, 12):
+        assert np.array_equal(oracle.unpack(g[f"packed{bpp}"], w, h, bpp).reshape(h, w), g[f"unpack{bpp}"])
+    for m in (2, 3, 5):
+        assert np.array_equal(oracle.chroma_smooth(f, BLACK, m), g[f"cs{m}"])
+    for ag in (0, 1):
+        for di in (0, 1):
+            assert np.array_equal(oracle.fix_bad_pixels(f, BLACK, ag, di), g[f"badpix_a{ag}_d{di}"])
+    needed, co = oracle.stripes_compute(f, BLACK, WHITE)
+    assert needed == int(g["stripes_needed"][0]) and np.array_equal(co, g["stripes_coeffs"])
+    assert np.array_equal(oracle.stripes_apply(f, BLACK, WHITE, needed, co), g["stripes_apply"])
+    ok, img, lv = oracle.hdr_preview(f, BLACK, WHITE)
+    assert [ok, lv[0], lv[1]] == list(g["hdr_preview_ok"]) and np.array_equal(img, g["hdr_preview"])
+    assert np.array_equal(oracle.fix_pattern_noise(f, WHITE), g["pattern_noise"])
+    for cs, bad, st in ((5, 1, 1), (2, 0, 0), (3, 2, 1)):
+        img, _ = oracle.process_frame(g["packed14"], w, h, BLACK, WHITE, cs, bad, st)
+        assert np.array_equal(img, g[f"process_cs{cs}_bad{bad}_st{st}"])
+
+
+def test_oracle_reproduces_full_size_hashes(oracle):
+    """configs 1-2 at full size (cs5x5 full size runs in the GPU test below and in bench.py)."""
+    full = META["full_size"]
+    f = synth.normal_frame(1920, 1080, seed=1)
+    p = np.concatenate([synth.pack14(f).astype("<u2"), np.zeros(4, "<u2")])
+    assert fnv1a(oracle.unpack(p, 1920, 1080, 14)) == full["A_1920x1080_unpack"]
+    f = synth.normal_frame(3584, 1320, seed=1, frame=0)
+    assert fnv1a(oracle.chroma_smooth(f, BLACK, 2)) == full["B_cs2_frame0"]
+
+
+# ------------------------------------------------------------------ GPU side
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", SMALL, ids=[os.path.basename(p)[6:-4] for p in SMALL])
+def test_hip_reproduces_small_vectors(gpu, path):
+    from mlvfs_amd import abi, lib, pipeline
+    g = np.load(path)
+    f = g["frame"]
+    h, w = f.shape
+    fh = lambda **kw: abi.make_frame_headers(w, h, black=BLACK, white=WHITE, **kw)
+    assert np.array_equal(pipeline.get_image_data(fh(), g["packed14"]).reshape(h, w), g["unpack14"])
+    for bpp in (10, 12):
+        fhb = abi.make_frame_headers(w, h, bpp=bpp, black=BLACK, white=WHITE)
+        assert np.array_equal(pipeline.get_image_data(fhb, g[f"packed{bpp}"]).reshape(h, w), g[f"unpack{bpp}"])
+    for m in (2, 3, 5):
+        got = f.copy()
+        gpu.chroma_smooth(C.byref(fh()), lib.ptr(got), m)
+        assert np.array_equal(got, g[f"cs{m}"])
+    for ag in (0, 1):
+        for di in (0, 1):
+            got = f.copy()
+            gpu.fix_bad_pixels(C.byref(fh()), lib.ptr(got), ag, di)
+            assert np.array_equal(got, g[f"badpix_a{ag}_d{di}"])
+    C.CDLL(None).srand(1)
+    corr = gpu.stripes_new_correction(os.path.basename(path).encode())
+    gpu.stripes_compute_correction(C.byref(fh()), corr, lib.ptr(f), 0, f.size)
+    assert corr.contents.correction_needed == int(g["stripes_needed"][0])
+    assert list(corr.contents.coeffficients) == list(g["stripes_coeffs"])
+    got = f.copy()
+    gpu.stripes_apply_correction(C.byref(fh()), corr, lib.ptr(got), 0, got.size)
+    assert np.array_equal(got, g["stripes_apply"])
+    gpu.stripes_free_corrections()
+    got = f.copy()
+    hdr = fh()
+    ok = gpu.hdr_convert_data(C.byref(hdr), lib.ptr(got), 0, got.nbytes)
+    assert ok == int(g["hdr_preview_ok"][0])
+    if ok:
+        assert np.array_equal(got, g["hdr_preview"])
+        assert hdr.rawi_hdr.raw_info.black_level == int(g["hdr_preview_ok"][1])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_full_size_hashes(gpu):
+    """BASELINE.json configs 1-3 at full size against hashes of the reference's outputs."""
+    from mlvfs_amd.stream import ClipStream, to_numpy_u16
+    full = META["full_size"]
+    s = ClipStream(1920, 1080)
+    f = synth.normal_frame(1920, 1080, seed=1)
+    packed = s.upload_packed([synth.pack14(f).astype("<u2")])
+    assert fnv1a(to_numpy_u16(s.unpack(packed))[0]) == full["A_1920x1080_unpack"]
+    s.close()
+    W, H = 3584, 1320
+    frames = [synth.normal_frame(W, H, seed=1, frame=k) for k in range(2)]
+    s = ClipStream(W, H)
+    packed = s.upload_packed([synth.pack14(x).astype("<u2") for x in frames])
+    out = to_numpy_u16(s.process(packed, cs=2))
+    assert fnv1a(out[0]) == full["B_cs2_frame0"] and fnv1a(out[1]) == full["B_cs2_frame1"]
+    s.analyse_first_frame(packed, cs=5, bad_pix=1, stripes=True, rand_mode=1)
+    assert len(s.get_pixel_map()) == full["B_cs5_badpix_stripes_badpix_count"]
+    needed, co = s.get_stripes()
+    assert needed == full["B_cs5_badpix_stripes_needed"] and list(co) == full["B_cs5_badpix_stripes_coeffs"]
+    out = to_numpy_u16(s.process(packed, cs=5, fix_pixels=True, stripes=True))
+    assert fnv1a(out[0]) == full["B_cs5_badpix_stripes_frame0"]
+    assert fnv1a(out[1]) == full["B_cs5_badpix_stripes_frame1"]
+    s.close()
