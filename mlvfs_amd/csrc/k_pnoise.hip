@@ -1,0 +1,221 @@
+// k_pnoise.hip -- row/column pattern-noise correction (replaces fix_pattern_noise,
+// mlvfs/patternnoise.c:49-380, debug_flags = 0).
+//
+// One direction = "column pass" (patternnoise.c:312-355); the row pass is the same
+// pass on the transposed frame (patternnoise.c:371-378).  All values are int16 and
+// wrap like the reference's int16 stores; every median is the LOWER median
+// (wirth.h:129-131), obtained here by bisection on the value (the k-th smallest of n
+// values is the smallest v with #{x <= v} >= k+1), which needs no sorting, no
+// dynamic register arrays, and is exact for integers.
+//
+//   k_pn_transpose       frame <-> transposed frame
+//   k_pn_smooth          per half-res pixel: run of horizontally adjacent pixels whose
+//                        average green stays within thr of the centre (<= 25 left,
+//                        <= 24 right), lower medians of g1, g2, r-avg_g, b-avg_g over
+//                        the run (patternnoise.c:88-180); one workgroup per plane row,
+//                        the row's five int16 arrays staged in LDS
+//   k_pn_column_offsets  per plane column: lower median of (orig - smoothed) over the
+//                        unmasked rows (mask: |flat-array gradient| > 500 or >= white),
+//                        offset = -median when >= 10 samples (patternnoise.c:185-254)
+//   k_pn_offset_median   lower median of a plane's column offsets (patternnoise.c:268)
+//   k_pn_apply           add offsets (clamp +-32767), remove their median (clamp 0..32760)
+#include "clip.h"
+
+namespace mlv {
+
+__device__ __forceinline__ int plane_px(const int16_t *raw, int w, int c, int x, int y)
+{
+    return raw[(2 * x + (c & 1)) + (size_t)(2 * y + (c >> 1)) * w];
+}
+
+__global__ __launch_bounds__(256) void k_pn_transpose(const int16_t *__restrict__ in, int16_t *__restrict__ out, int w, int h)
+{
+    __shared__ int16_t tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int x = bx + threadIdx.x, y = by + r;
+        if (x < w && y < h) tile[r][threadIdx.x] = in[x + (size_t)y * w];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int x = bx + r, y = by + threadIdx.x;          // out[y + x*h] = in[x + y*w]
+        if (x < w && y < h) out[y + (size_t)x * h] = tile[threadIdx.x][r];
+    }
+}
+
+// lower median of v[lo..hi] (inclusive, LDS int16) by bisection
+__device__ __forceinline__ int lower_median_run(const int16_t *v, int lo, int hi)
+{
+    const int n = hi - lo + 1, need = (n - 1) / 2 + 1;
+    int a = -32768, b = 32767;
+    while (a < b) {
+        const int mid = (a + b) >> 1;                        // floor
+        int cnt = 0;
+        for (int i = lo; i <= hi; i++) cnt += (v[i] <= mid);
+        if (cnt >= need) b = mid; else a = mid + 1;
+    }
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_pn_smooth(const int16_t *__restrict__ raw, int w, int hw, int reach, int thr,
+                                                   int16_t *__restrict__ smooth /* [4][hh][hw] */, int hh)
+{
+    extern __shared__ int16_t row[];                          // avg, g1, g2, drg, dbg: 5 x hw
+    int16_t *avg = row, *g1 = row + hw, *g2 = row + 2 * hw, *drg = row + 3 * hw, *dbg = row + 4 * hw;
+    const int y = blockIdx.x;
+    for (int x = threadIdx.x; x < hw; x += blockDim.x) {
+        const int r = plane_px(raw, w, 0, x, y), a = plane_px(raw, w, 1, x, y), b2 = plane_px(raw, w, 2, x, y),
+                  b = plane_px(raw, w, 3, x, y);
+        const int16_t av = (int16_t)((a + b2) / 2);            // patternnoise.c:59-65 (C division)
+        avg[x] = av; g1[x] = (int16_t)a; g2[x] = (int16_t)b2;
+        drg[x] = (int16_t)(r - av);
+        dbg[x] = (int16_t)(b - av);
+    }
+    __syncthreads();
+    const size_t plane = (size_t)hw * hh;
+    for (int x = threadIdx.x; x < hw; x += blockDim.x) {
+        const int centre = avg[x];
+        const int hi_lim = min(x + reach, hw), lo_lim = max(x - reach, 0);
+        int xr = x + 1, xl = x - 1;
+        while (xr < hi_lim && abs(avg[xr] - centre) <= thr) xr++;
+        while (xl >= lo_lim && abs(avg[xl] - centre) <= thr) xl--;
+        const int lo = xl + 1, hi = xr - 1;
+        const int mg1 = lower_median_run(g1, lo, hi), mg2 = lower_median_run(g2, lo, hi);
+        const int mg = (mg1 + mg2) / 2;
+        const size_t at = (size_t)y * hw + x;
+        smooth[at] = (int16_t)(lower_median_run(drg, lo, hi) + mg);          // r
+        smooth[plane + at] = (int16_t)mg1;                                     // g1
+        smooth[2 * plane + at] = (int16_t)mg2;                                 // g2
+        smooth[3 * plane + at] = (int16_t)(lower_median_run(dbg, lo, hi) + mg);   // b
+    }
+}
+
+// noise sample of plane c at flat index i, or "masked"
+__device__ __forceinline__ bool noise_at(const int16_t *raw, int w, int hw, size_t n, int c, const int16_t *smooth_c,
+                                         size_t i, int white, int &noise)
+{
+    const int x = (int)(i % hw), y = (int)(i / hw);
+    const int o = plane_px(raw, w, c, x, y);
+    int grad = 0;
+    if (i >= 2 && i + 2 < n) {
+        const size_t im = i - 2, ip = i + 2;
+        grad = (int16_t)(plane_px(raw, w, c, (int)(im % hw), (int)(im / hw)) - plane_px(raw, w, c, (int)(ip % hw), (int)(ip / hw)));
+    }
+    noise = (int16_t)(o - smooth_c[i]);
+    return !((abs(grad) > 500) || (o >= white));
+}
+
+// one workgroup (256 threads) per (column, plane)
+__global__ __launch_bounds__(256) void k_pn_column_offsets(const int16_t *__restrict__ raw, int w, int hw, int hh, int white,
+                                                           const int16_t *__restrict__ smooth, int *__restrict__ offs /* [4][hw] */)
+{
+    __shared__ int red[4];
+    __shared__ int s_a, s_b, s_n;
+    const int x = blockIdx.x, c = blockIdx.y;
+    const size_t n = (size_t)hw * hh;
+    const int16_t *sm = smooth + (size_t)c * n;
+    auto block_sum = [&](int v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    // unmasked sample count
+    int cnt = 0;
+    for (int y = threadIdx.x; y < hh; y += blockDim.x) {
+        int nz;
+        cnt += noise_at(raw, w, hw, n, c, sm, (size_t)x + (size_t)y * hw, white, nz) ? 1 : 0;
+    }
+    const int k = block_sum(cnt);
+    if (k < 10) { if (threadIdx.x == 0) offs[c * hw + x] = 0; return; }      // patternnoise.c:250
+    const int need = (k - 1) / 2 + 1;
+    int a = -32768, b = 32767;
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        int le = 0;
+        for (int y = threadIdx.x; y < hh; y += blockDim.x) {
+            int nz;
+            if (noise_at(raw, w, hw, n, c, sm, (size_t)x + (size_t)y * hw, white, nz)) le += (nz <= mid);
+        }
+        if (block_sum(le) >= need) b = mid; else a = mid + 1;
+    }
+    if (threadIdx.x == 0) offs[c * hw + x] = -a;
+    (void)s_a; (void)s_b; (void)s_n;
+}
+
+// lower median of offs[c][0..hw) ; one workgroup per plane
+__global__ __launch_bounds__(256) void k_pn_offset_median(const int *__restrict__ offs, int hw, int *__restrict__ mc /* [4] */)
+{
+    __shared__ int red[4];
+    const int c = blockIdx.x;
+    const int need = (hw - 1) / 2 + 1;
+    int a = -40000, b = 40000;
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        int le = 0;
+        for (int x = threadIdx.x; x < hw; x += blockDim.x) le += (offs[c * hw + x] <= mid);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) le += __shfl_xor(le, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = le;
+        __syncthreads();
+        if (red[0] + red[1] + red[2] + red[3] >= need) b = mid; else a = mid + 1;
+    }
+    if (threadIdx.x == 0) mc[c] = a;
+}
+
+__global__ __launch_bounds__(256) void k_pn_apply(int16_t *__restrict__ raw, int w, int h, int hw, const int *__restrict__ offs,
+                                                  const int *__restrict__ mc)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= (w & ~1) || y >= (h & ~1)) return;
+    const int c = (x & 1) + 2 * (y & 1);
+    int v = (int)raw[x + (size_t)y * w] + offs[c * hw + (x >> 1)];
+    v = v < -32767 ? -32767 : (v > 32767 ? 32767 : v);                       // patternnoise.c:260
+    v = (int16_t)v - mc[c];
+    raw[x + (size_t)y * w] = (int16_t)(v < 0 ? 0 : (v > 32760 ? 32760 : v));  // patternnoise.c:273
+}
+
+// one direction on a device frame (w x h int16).  scratch: smooth 4*hw*hh int16, offs 4*hw int, mc 4 int
+static int column_pass(int16_t *d_raw, int w, int h, int white, int16_t *d_smooth, int *d_offs, int *d_mc, hipStream_t stream)
+{
+    const int hw = w / 2, hh = h / 2;
+    if (hw <= 0 || hh <= 0) return MLVFS_AMD_OK;
+    const size_t shmem = (size_t)5 * hw * sizeof(int16_t);
+    if (shmem > 150 * 1024) { set_error("fix_pattern_noise: rows of %d pixels do not fit in LDS", w); return MLVFS_AMD_ERR_ARG; }
+    MLV_HIP(hipFuncSetAttribute((const void *)k_pn_smooth, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(k_pn_smooth, dim3(hh), dim3(256), shmem, stream, d_raw, w, hw, 50 / 2, 500, d_smooth, hh);
+    hipLaunchKernelGGL(k_pn_column_offsets, dim3(hw, 4), dim3(256), 0, stream, d_raw, w, hw, hh, white, d_smooth, d_offs);
+    hipLaunchKernelGGL(k_pn_offset_median, dim3(4), dim3(256), 0, stream, d_offs, hw, d_mc);
+    hipLaunchKernelGGL(k_pn_apply, dim3((w + 255) / 256, h), dim3(256), 0, stream, d_raw, w, h, hw, d_offs, d_mc);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+size_t pattern_noise_scratch_bytes(int w, int h)
+{
+    const size_t n = (size_t)w * h;
+    return n * 2 /* transposed frame */ + n * 2 /* 4 smoothed half-res planes */ + (size_t)4 * (w > h ? w : h) * 4 + 64;
+}
+
+int launch_pattern_noise(void *d_raw, int w, int h, int white, void *d_scratch, hipStream_t stream)
+{
+    int16_t *raw = (int16_t *)d_raw;
+    const size_t n = (size_t)w * h;
+    int16_t *d_t = (int16_t *)d_scratch;
+    int16_t *d_smooth = d_t + n;
+    int *d_offs = (int *)(d_smooth + n);
+    int *d_mc = d_offs + (size_t)4 * (w > h ? w : h) / 2 + 4;
+    int rc = column_pass(raw, w, h, white, d_smooth, d_offs, d_mc, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pn_transpose, dim3((w + 31) / 32, (h + 31) / 32), dim3(32, 8), 0, stream, raw, d_t, w, h);
+    rc = column_pass(d_t, h, w, white, d_smooth, d_offs, d_mc, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pn_transpose, dim3((h + 31) / 32, (w + 31) / 32), dim3(32, 8), 0, stream, d_t, raw, h, w);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+}  // namespace mlv

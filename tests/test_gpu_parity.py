@@ -230,3 +230,30 @@ def test_against_reference_build(gpu, reference):
         got = f.copy()
         gpu.fix_bad_pixels(C.byref(fh_for(w, h)), lib.ptr(got), 1, 0)
         assert np.array_equal(got, reference.fix_bad_pixels(f, BLACK, 1, 0))
+
+
+# ------------------------------------------------------------------ pattern noise
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("w,h", [(64, 48), (136, 72), (258, 130), (416, 264)])
+def test_fix_pattern_noise_dropin(gpu, oracle, w, h, kind):
+    """patternnoise.c:357-380: column pass, then the same pass on the transposed frame;
+    int16 arithmetic, lower medians -- bit-exact."""
+    f = frame_of(kind, w, h)
+    want = oracle.fix_pattern_noise(f, WHITE)
+    got = f.copy()
+    gpu.fix_pattern_noise(lib.ptr(got), w, h, WHITE, 0)
+    assert np.array_equal(got, want), f"{(got != want).sum()} px differ"
+    assert (want != f).any()
+
+
+def test_fix_pattern_noise_full_size_hash(gpu):
+    """1920x1080 frame against the hash of the reference's output (tests/golden/golden.json)."""
+    import json
+    from conftest import fnv1a
+    meta = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))["full_size"]
+    if "A_1920x1080_pattern_noise" not in meta:
+        pytest.skip("golden.json predates the pattern-noise hash")
+    f = synth.normal_frame(1920, 1080, seed=1)
+    got = f.copy()
+    gpu.fix_pattern_noise(lib.ptr(got), 1920, 1080, WHITE, 0)
+    assert fnv1a(got) == meta["A_1920x1080_pattern_noise"]
