@@ -66,6 +66,12 @@ void stripes_apply_correction(struct frame_headers *frame_headers, struct stripe
 /* replaces mlvfs/hdr.h:27 (hdr.c:40-227): fast dual-ISO preview; 1 = converted */
 int hdr_convert_data(struct frame_headers *frame_headers, uint16_t *image_data, off_t offset, size_t max_size);
 
+/* replaces mlvfs/hdr.h:28 (hdr.c:1932-1957): full dual-ISO conversion (cr2hdr 20-bit).
+ * Built so far: interp_method 1 (mean23), fullres / alias map on or off, chroma_smooth 0.
+ * Other configurations report an error and return 0 (frame not converted).        */
+int cr2hdr20_convert_data(struct frame_headers *frame_headers, uint16_t *image_data, int interp_method, int fullres,
+                          int use_alias_map, int chroma_smooth, int fix_bad_pixels_mode);
+
 /* replaces mlvfs/patternnoise.h:16 (patternnoise.c:357-380) */
 void fix_pattern_noise(int16_t *raw, int w, int h, int white, int debug_flags);
 
@@ -159,6 +165,13 @@ int mlvfs_amd_process_frames_dev(mlvfs_amd_clip_t *clip, const void *d_packed, s
 
 /* dual-ISO preview on one device frame (hdr.c:40-227); returns 1 / 0 / <0    */
 int mlvfs_amd_hdr_preview_dev(const mlvfs_amd_geom_t *geom, void *d_frame, size_t max_size, void *stream);
+
+/* full dual-ISO conversion of one device frame, in place (hdr.c:1774-1957 without the
+ * pixel-map repairs); returns 1 converted / 0 not dual ISO or not convertible / <0 error.
+ * mlvfs_amd_dualiso_reset forgets the per-black-level table caches (a fresh process).  */
+int mlvfs_amd_cr2hdr20_dev(const mlvfs_amd_geom_t *geom, void *d_frame, int interp_method, int fullres, int use_alias_map,
+                           int chroma_smooth, void *stream);
+void mlvfs_amd_dualiso_reset(void);
 
 /* HIP-event timer around the dominant kernel (k_frame) of the calling thread's
  * launches, recorded on the stream the kernel is launched on (bench.py's

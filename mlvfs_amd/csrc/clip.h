@@ -74,6 +74,12 @@ struct StripesWork {
                      hipStream_t stream);
 };
 
+// device-level pixel repair shared by the drop-in symbols and the dual-ISO path (dropin.cpp)
+struct ThreadCtx;
+Clip *focus_clip_for(struct frame_headers *fh, ThreadCtx *c, int dual_iso);
+int focus_pixels_device(struct frame_headers *fh, ThreadCtx *c, void *d_frame, int dual_iso, bool *changed);
+int bad_pixels_device(struct frame_headers *fh, ThreadCtx *c, void *d_frame, int aggressive, int dual_iso, bool *changed);
+
 void glibc_rand_stream(uint16_t *out, size_t n, uint64_t skip, unsigned seed);
 int stripes_solve(const int32_t *hist, const int32_t num[8], int frame_size, int32_t coeffs[8]);
 

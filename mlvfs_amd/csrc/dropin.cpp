@@ -148,12 +148,16 @@ void chroma_smooth(struct frame_headers *fh, uint16_t *image_data, int method)
     download(c, image_data, c->d_b, bytes);
 }
 
-void fix_bad_pixels(struct frame_headers *fh, uint16_t *image_data, int aggressive, int dual_iso)
+// device-level forms (frame already in HBM at d_frame): shared with the dual-ISO path
+}  // extern "C"
+
+namespace mlv {
+
+int bad_pixels_device(struct frame_headers *fh, ThreadCtx *c, void *d_frame, int aggressive, int dual_iso, bool *changed)
 {
     const FrameView v = view_of(fh);
-    if (v.black > 16384) { fprintf(stderr, "Black level too large for processing\n"); return; }
-    ThreadCtx *c = thread_ctx();
-    if (!c) return;
+    if (changed) *changed = false;
+    if (v.black > 16384) { fprintf(stderr, "Black level too large for processing\n"); return MLVFS_AMD_OK; }
     const size_t bytes = (size_t)v.w * v.h * 2;
     std::lock_guard<std::mutex> lk(g_bad_mutex);
 
@@ -162,16 +166,14 @@ void fix_bad_pixels(struct frame_headers *fh, uint16_t *image_data, int aggressi
         if (v.guid && v.guid == g_bad_maps[i].guid && aggressive == g_bad_maps[i].aggressive && g_bad_maps[i].clip &&
             g_bad_maps[i].w == v.w && g_bad_maps[i].h == v.h && g_bad_maps[i].clip->device == c->dev->id)
             map = &g_bad_maps[i];
-    bool uploaded = false;
     if (!map) {
         map = &g_bad_maps[g_bad_next];
         g_bad_next = (g_bad_next + 1) % BAD_PIXEL_MAP_COUNT;
         delete map->clip;
         map->clip = make_clip(v, c);
         map->guid = v.guid; map->aggressive = aggressive; map->w = v.w; map->h = v.h; map->dual_iso = dual_iso;
-        if (upload(c, image_data, bytes)) return;
-        uploaded = true;
-        if (map->clip->detect_bad_pixels(c->d_a, aggressive, dual_iso, c->stream)) return;
+        int rc = map->clip->detect_bad_pixels(d_frame, aggressive, dual_iso, c->stream);
+        if (rc) return rc;
         const int crop_x = (v.pan_x + 7) & ~7, crop_y = v.pan_y & ~1;
         const size_t n = map->clip->xy.size() / 2;
         printf("%zu bad pixels found for %llx (crop: %d, %d):\n", n, (unsigned long long)v.guid, crop_x, crop_y);   // cs.c:307-311
@@ -179,14 +181,15 @@ void fix_bad_pixels(struct frame_headers *fh, uint16_t *image_data, int aggressi
     } else if (map->dual_iso != dual_iso) {
         std::vector<int32_t> xy = map->clip->xy;
         map->clip->pan_x = v.pan_x; map->clip->pan_y = v.pan_y;
-        if (map->clip->set_pixel_map(xy.data(), xy.size() / 2, 0, dual_iso)) return;
+        int rc = map->clip->set_pixel_map(xy.data(), xy.size() / 2, 0, dual_iso);
+        if (rc) return rc;
         map->dual_iso = dual_iso;
     }
-    if (map->clip->n_entries == 0) return;                                           // nothing to repair
+    if (map->clip->n_entries == 0) return MLVFS_AMD_OK;                              // nothing to repair
     map->clip->g.black = v.black;
-    if (!uploaded && upload(c, image_data, bytes)) return;
-    if (map->clip->fix_pixels(c->d_a, bytes, 1, c->stream)) return;
-    download(c, image_data, c->d_a, bytes);
+    int rc = map->clip->fix_pixels(d_frame, bytes, 1, c->stream);
+    if (rc == MLVFS_AMD_OK && changed) *changed = true;
+    return rc;
 }
 
 static FocusMap *load_focus_map(uint32_t camera, int raw_w, int raw_h)               // cs.c:356-401
@@ -210,7 +213,21 @@ static FocusMap *load_focus_map(uint32_t camera, int raw_w, int raw_h)          
     return m;
 }
 
-void fix_focus_pixels(struct frame_headers *fh, uint16_t *image_data, int dual_iso)
+// returns OK with *have_map = false when there is no map for this camera (nothing to do, nothing staged)
+int focus_pixels_device(struct frame_headers *fh, ThreadCtx *c, void *d_frame, int dual_iso, bool *changed)
+{
+    const FrameView v = view_of(fh);
+    if (changed) *changed = false;
+    Clip *clip = focus_clip_for(fh, c, dual_iso);
+    if (!clip || clip->n_entries == 0) return MLVFS_AMD_OK;
+    clip->g.black = v.black;
+    int rc = clip->fix_pixels(d_frame, (size_t)v.w * v.h * 2, 1, c->stream);
+    if (rc == MLVFS_AMD_OK && changed) *changed = true;
+    return rc;
+}
+
+// the clip (pixel map) for this frame's camera / geometry, or nullptr when no .fpm file exists
+Clip *focus_clip_for(struct frame_headers *fh, ThreadCtx *c, int dual_iso)
 {
     const FrameView v = view_of(fh);
     const uint32_t camera = fh->idnt_hdr.cameraModel;
@@ -220,23 +237,50 @@ void fix_focus_pixels(struct frame_headers *fh, uint16_t *image_data, int dual_i
     for (FocusMap *m : g_focus_maps)
         if (m->camera == camera && m->raw_w == raw_w && m->raw_h == raw_h) fm = m;
     if (!fm) fm = load_focus_map(camera, raw_w, raw_h);
-    if (fm->xy.empty()) return;                                                      // no map for this camera: no-op
-    if (v.black > 16384) { fprintf(stderr, "raw2ev LUT error\n"); return; }
-    ThreadCtx *c = thread_ctx();
-    if (!c) return;
+    if (fm->xy.empty()) return nullptr;                                              // no map for this camera: no-op
+    if (v.black > 16384) { fprintf(stderr, "raw2ev LUT error\n"); return nullptr; }
     char key[128];
     snprintf(key, sizeof key, "%d:%dx%d:%d,%d:%d", c->dev->id, v.w, v.h, v.pan_x, v.pan_y, dual_iso);
     Clip *&clip = fm->clips[key];
     if (!clip) {
         clip = make_clip(v, c);
-        if (clip->set_pixel_map(fm->xy.data(), fm->xy.size() / 2, 1, dual_iso)) return;
+        if (clip->set_pixel_map(fm->xy.data(), fm->xy.size() / 2, 1, dual_iso)) return nullptr;
     }
-    if (clip->n_entries == 0) return;
-    clip->g.black = v.black;
-    const size_t bytes = (size_t)v.w * v.h * 2;
+    return clip;
+}
+
+}  // namespace mlv
+
+extern "C" {
+
+void fix_bad_pixels(struct frame_headers *fh, uint16_t *image_data, int aggressive, int dual_iso)
+{
+    ThreadCtx *c = thread_ctx();
+    if (!c) return;
+    const size_t bytes = (size_t)fh->rawi_hdr.xRes * fh->rawi_hdr.yRes * 2;
     if (upload(c, image_data, bytes)) return;
-    if (clip->fix_pixels(c->d_a, bytes, 1, c->stream)) return;
-    download(c, image_data, c->d_a, bytes);
+    bool changed = false;
+    if (bad_pixels_device(fh, c, c->d_a, aggressive, dual_iso, &changed)) return;
+    if (changed) download(c, image_data, c->d_a, bytes);
+    else (void)hipStreamSynchronize(c->stream);
+}
+
+void fix_focus_pixels(struct frame_headers *fh, uint16_t *image_data, int dual_iso)
+{
+    ThreadCtx *c = nullptr;
+    // no map file for this camera is the common case: decide before touching the GPU
+    {
+        ThreadCtx *probe = thread_ctx();
+        if (!probe) return;
+        c = probe;
+    }
+    Clip *clip = focus_clip_for(fh, c, dual_iso);
+    if (!clip || clip->n_entries == 0) return;
+    const size_t bytes = (size_t)fh->rawi_hdr.xRes * fh->rawi_hdr.yRes * 2;
+    if (upload(c, image_data, bytes)) return;
+    bool changed = false;
+    if (focus_pixels_device(fh, c, c->d_a, dual_iso, &changed)) return;
+    if (changed) download(c, image_data, c->d_a, bytes);
 }
 
 void free_focus_pixel_maps(void)                                                     // cs.c:403-418

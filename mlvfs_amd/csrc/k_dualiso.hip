@@ -1,0 +1,374 @@
+// k_dualiso.hip -- kernels of the full dual-ISO conversion (cr2hdr 20-bit,
+// mlvfs/hdr.c:230-1957) with the mean23 interpolation (hdr.c:1231-1304).
+// The scalar decisions between the kernels (pattern, white levels, robust exposure
+// fit) run on the host from small device-built histograms (dualiso.cpp).
+//
+//   k_di_analyse    one pass over the 16-bit frame: hdr_check sum (hdr.c:407-439), the
+//                   four Bayer-phase histograms (identify_rggb_or_gbrg, :441-495), the
+//                   row-phase green histograms (:497-636) and the every-3rd-pixel white
+//                   histograms (:250-300), the latter two for both row parities
+//                   (RGGB and GBRG hypothesis) so one pass serves either outcome
+//   k_di_subsample  3x3-subsampled native/interpolated pairs + their histograms
+//                   (match_exposures, :650-722)
+//   k_di_score      RANSAC-like score of every candidate slope (:752-772)
+//   k_di_match      14 -> 20 bit and per-pixel exposure correction in double (:781-803, :825-837)
+//   k_di_interp     mean23 + borders + full-res pick + half-res mix + overexposure flag +
+//                   alias-map error, fused per pixel (:1231-1380, :1588-1612, :1404-1418, :1620-1626)
+//   k_di_alias_rank 6th largest of 37 neighbours (:1423-1443)
+//   k_di_alias_blur integer gaussian (:1446-1466)
+//   k_di_blend      2x2 max of the alias map, overexposure blur, final blend in EV space,
+//                   20 -> 16 bit (:1469-1483, :1631-1651, :1663-1772)
+// Doubles are evaluated operation by operation (no FMA contraction); the only
+// transcendental evaluated on the device is the cos() of the per-frame mixing curve.
+#include "clip.h"
+#include "dualiso.h"
+
+namespace mlv {
+
+#define DI_EVR 32768
+
+__device__ __forceinline__ int di_bright(const DiParams &p, int y) { return (p.is_bright_bits >> (y & 3)) & 1; }
+
+// ------------------------------------------------------------------ analysis
+__global__ __launch_bounds__(256) void k_di_analyse(const uint16_t *__restrict__ img, int w, int H, int black, int white,
+                                                    const double *__restrict__ evf /* [16384] log2(i)*32768 */,
+                                                    unsigned *__restrict__ hist /* DiHist layout */, double *__restrict__ check /* sum, count */)
+{
+    __shared__ double s_sum[4];
+    __shared__ double s_cnt[4];
+    double sum = 0, cnt = 0;
+    const size_t n = (size_t)w * H;
+    unsigned *h_bayer = hist + DI_H_BAYER, *h_g0 = hist + DI_H_GREEN0, *h_g1 = hist + DI_H_GREEN1, *h_w0 = hist + DI_H_WHITE0,
+             *h_w1 = hist + DI_H_WHITE1;
+    const int h1 = H - 1;                                        // frame height under the GBRG hypothesis
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w), y = (int)(i / w);
+        const int p = img[i];
+        if (y >= 2 && y < H - 2 && x >= 2 && x < w - 2) {        // hdr_check
+            const int p2 = img[i + 2 * (size_t)w];
+            if ((p > black + 32 || p2 > black + 32) && p < white && p2 < white) {
+                const int a = p - black, b = p2 - black;
+                const double ea = (a >= 0 && a < 16384) ? evf[a] : 0.0, eb = (b >= 0 && b < 16384) ? evf[b] : 0.0;
+                const double d = eb - ea;
+                sum += d > 0 ? d : -d;
+                cnt += 1;
+            }
+        }
+        const int v14 = p & 16383, vw = p < 32767 ? p : 32767;
+        if (y < H / 4 * 4) {
+            atomicAdd(&h_bayer[((y & 1) * 2 + (x & 1)) * 16384 + v14], 1u);
+            if ((x & 1) != (y & 1)) atomicAdd(&h_g0[(y & 3) * 16384 + v14], 1u);
+        }
+        if (y % 3 == 0 && x % 3 == 0) atomicAdd(&h_w0[(y & 3) * 32768 + vw], 1u);
+        const int y1 = y - 1;                                    // row index in the frame that starts one row lower
+        if (y1 >= 4 && y1 < h1 / 4 * 4 && (x & 1) != (y1 & 1)) atomicAdd(&h_g1[(y1 & 3) * 16384 + v14], 1u);
+        if (y1 >= 1 && y1 % 3 == 1 && x % 3 == 0) atomicAdd(&h_w1[(y1 & 3) * 32768 + vw], 1u);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); cnt += __shfl_xor(cnt, o); }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_cnt[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&check[0], s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+        atomicAdd(&check[1], s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+    }
+}
+
+// ------------------------------------------------------------------ exposure matching
+__device__ __forceinline__ int di_p16(const uint16_t *img, size_t i) { return (int)(((unsigned)img[i] << 2) & 0xFFFFu); }   // 14->20->16 bit
+
+__global__ __launch_bounds__(256) void k_di_subsample(const uint16_t *__restrict__ img, DiParams p, int nsx, int nsy,
+                                                      int *__restrict__ dark_s, int *__restrict__ bright_s,
+                                                      unsigned *__restrict__ hist_b, unsigned *__restrict__ hist_d)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nsx * nsy) return;
+    const int sx = idx % nsx, sy = idx / nsx;
+    const int x = 3 * sx, y = p.ay1 + 2 + 3 * sy, w = p.w;
+    const int black = p.black20 / 16, white = p.match_white20 / 16;
+    const int clip0 = white - black, clip = (int)(clip0 * 0.95);
+    const int pa = di_p16(img, x + (size_t)(y - 2) * w) - black, pb = di_p16(img, x + (size_t)(y + 2) * w) - black;
+    int pn = di_p16(img, x + (size_t)y * w) - black;
+    int pi = (pa + pb + 1) / 2;
+    if (pa >= clip || pb >= clip) pi = clip0;
+    if (pi >= clip) pn = clip0;
+    const int br = di_bright(p, y);
+    const int d = br ? pi : pn, b = br ? pn : pi;
+    dark_s[idx] = d;
+    bright_s[idx] = b;
+    if (b < clip) {
+        atomicAdd(&hist_b[min(max(b + DI_HIST_OFF, 0), DI_HIST_N - 1)], 1u);
+        atomicAdd(&hist_d[min(max(d + DI_HIST_OFF, 0), DI_HIST_N - 1)], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_di_score(const int *__restrict__ hd, const int *__restrict__ hb, int hi_n,
+                                                  const double *__restrict__ cand /* [2*ncand]: a, b */, int *__restrict__ score)
+{
+    __shared__ int red[4];
+    const double ta = cand[2 * blockIdx.x], tb = cand[2 * blockIdx.x + 1];
+    int s = 0;
+    for (int i = threadIdx.x; i < hi_n; i += blockDim.x) {
+        const int e = (int)(hd[i] - (hb[i] * ta + tb));
+        s += (e > 0 ? e : -e) < 50;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) score[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void k_di_match(const uint16_t *__restrict__ img, uint32_t *__restrict__ raw, DiParams p)
+{
+    const size_t n = (size_t)p.w * p.h;
+    const double a = p.a, b20 = p.b20;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int v = (int)(((uint32_t)img[i] << 6) & 0xFFFFFu);
+        if (v != 0) {
+            const int y = (int)(i / p.w);
+            double r;
+            if (di_bright(p, y)) r = (v - p.black20) * a + p.black20 + b20 * a;
+            else r = v - b20 + b20 * a;
+            v = (int)r;
+            v = v < 0 ? 0 : (v > 0xFFFFF ? 0xFFFFF : v);
+        }
+        raw[i] = (uint32_t)v;
+    }
+}
+
+// ------------------------------------------------------------------ interpolation + mix (per pixel)
+__device__ __forceinline__ int di_mean2(int a, int b, int white) { return (a >= white || b >= white) ? white : (a + b) / 2; }
+__device__ __forceinline__ int di_mean3(int a, int b, int c, int white)
+{
+    const int m = (a + b + c) / 3;
+    return (a >= white || b >= white || c >= white) ? max(m, white) : m;
+}
+
+__global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ raw, DiParams p, DiLuts L,
+                                                   uint32_t *__restrict__ dark, uint32_t *__restrict__ bright,
+                                                   uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
+                                                   uint16_t *__restrict__ over, uint16_t *__restrict__ amap)
+{
+    const int w = p.w, h = p.h;
+    const size_t n = (size_t)w * h;
+    const int *ir2e = L.interp_raw2ev, *ie2r = L.interp_ev2raw, *mr2e = L.mix_raw2ev, *me2r = L.mix_ev2raw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w), y = (int)(i / w);
+        const int br = di_bright(p, y);
+        auto R = [&](int xx, int yy) { return (int)raw[xx + (size_t)yy * w]; };
+        int native, interp;
+        // precedence of the reference's loops: column borders (y >= 2) over row borders over the interior
+        if (y >= 2 && x < 2) { interp = R(x, y - 2); native = R(x, y); }
+        else if (y >= 2 && x >= w - 3) { interp = R(x - 2, y - 2); native = R(x - 2, y); }
+        else if (y < 3) { interp = R(x, y + 2); native = R(x, y); }
+        else if (y >= h - 4) { interp = R(x, y - 2); native = R(x, y); }
+        else {
+            const int wl = !br ? p.white_darkened : p.white20;
+            const int wev = ir2e[wl];
+            const int s = (di_bright(p, y) == di_bright(p, y + 1)) ? -1 : 1;
+            const int xe = x & ~1;                                // the pair (xe, xe+1) is produced together
+            int ev;
+            if ((y & 1) == 0) {
+                if (x == xe) ev = di_mean2(ir2e[R(xe, y - 2)], ir2e[R(xe, y + 2)], wev);
+                else ev = di_mean3(ir2e[R(xe + 2, y + s)], ir2e[R(xe, y + s)], ir2e[R(xe + 1, y - 2 * s)], wev);
+            } else {
+                if (x == xe) ev = di_mean3(ir2e[R(xe + 1, y + s)], ir2e[R(xe - 1, y + s)], ir2e[R(xe, y - 2 * s)], wev);
+                else ev = di_mean2(ir2e[R(xe + 1, y - 2)], ir2e[R(xe + 1, y + 2)], wev);
+            }
+            interp = ie2r[ev];
+            native = R(x, y);
+        }
+        const int b = br ? native : interp, d = br ? interp : native;
+        bright[i] = (uint32_t)b;
+        dark[i] = (uint32_t)d;
+        int f = 0;
+        if (p.use_fullres) f = br ? (b < p.white_darkened ? b : max(b, d)) : d;         // hdr.c:1355-1380
+        fullres[i] = (uint32_t)f;
+        // half-res mix, hdr.c:1588-1612
+        const double ev = L.log2sig[b & 0xFFFFF] + p.corr_ev;
+        double t = ev - (p.max_ev - p.overlap);
+        t = t < p.overlap ? t : p.overlap;
+        t = t > 0 ? t : 0;
+        double k = (-cos(t * 3.14159265358979323846 / p.overlap) + 1) / 2;
+        k = k < 0 ? 0 : (k > 1 ? 1 : k);
+        const int mixed = (int)(mr2e[b] * (1 - k) + mr2e[d] * k);
+        const int hr = me2r[mixed];
+        halfres[i] = (uint32_t)hr;
+        over[i] = (b >= p.white_darkened || d >= p.white20) ? 100 : 0;                  // hdr.c:1620-1626
+        if (amap) {                                                                   // hdr.c:1404-1418
+            int e = 0;
+            if (!(L.fullres_curve[b] > 0.8)) {
+                int e_lin = f - hr;
+                e_lin = e_lin > 0 ? e_lin : -e_lin;
+                e_lin = max(e_lin - p.dark_noise * 3 / 2, 0);
+                int e_log = mr2e[f] - mr2e[hr];
+                e_log = e_log > 0 ? e_log : -e_log;
+                e = min(min(e_lin / 2, e_log / 16), 65530);
+            }
+            amap[i] = (uint16_t)e;
+        }
+    }
+}
+
+// 6th largest of the 37 neighbours (kth_smallest(negated, 37, 5)), hdr.c:1423-1443
+__global__ __launch_bounds__(256) void k_di_alias_rank(const uint16_t *__restrict__ amap, const uint32_t *__restrict__ bright,
+                                                       const double *__restrict__ fullres_curve, int w, int h,
+                                                       uint16_t *__restrict__ aux)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const size_t i = x + (size_t)y * w;
+    int out = amap[i];
+    if (x >= 6 && x < w - 6 && y >= 6 && y < h - 6 && !(fullres_curve[bright[i]] > 0.8)) {
+        int t0 = -1, t1 = -1, t2 = -1, t3 = -1, t4 = -1, t5 = -1;      // six largest, descending
+        auto push = [&](int v) {
+            if (v > t5) {
+                t5 = v;
+                int s;
+                if (t5 > t4) { s = t4; t4 = t5; t5 = s; }
+                if (t4 > t3) { s = t3; t3 = t4; t4 = s; }
+                if (t3 > t2) { s = t2; t2 = t3; t3 = s; }
+                if (t2 > t1) { s = t1; t1 = t2; t2 = s; }
+                if (t1 > t0) { s = t0; t0 = t1; t1 = s; }
+            }
+        };
+#pragma unroll
+        for (int dy = -6; dy <= 6; dy += 2) {
+            const int reach = (dy == -6 || dy == 6) ? 2 : ((dy == -4 || dy == 4) ? 4 : 6);
+#pragma unroll
+            for (int dx = -6; dx <= 6; dx += 2)
+                if (dx >= -reach && dx <= reach) push((int)amap[(x + dx) + (size_t)(y + dy) * w]);
+        }
+        out = t5;
+    }
+    aux[i] = (uint16_t)out;
+}
+
+// integer gaussian, hdr.c:1446-1466 (terms exactly as written there, duplicates included)
+__global__ __launch_bounds__(256) void k_di_alias_blur(const uint16_t *__restrict__ aux, const uint16_t *__restrict__ amap_in,
+                                                       const uint32_t *__restrict__ bright, const double *__restrict__ fullres_curve,
+                                                       int w, int h, uint16_t *__restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const size_t i = x + (size_t)y * w;
+    int v = amap_in[i];
+    if (x >= 6 && x < w - 6 && y >= 6 && y < h - 6 && !(fullres_curve[bright[i]] > 0.8)) {
+        auto A = [&](int dx, int dy) { return (int)aux[(x + dx) + (size_t)(y + dy) * w]; };
+        const int plus2 = A(0, -2) + A(-2, 0) + A(2, 0) + A(0, 2);
+        const int diag2 = A(-2, -2) + A(2, -2) + A(-2, 2) + A(2, 2);
+        const int twice = A(-2, -2) + A(2, -2) + A(-2, -2) + A(2, -2) + A(-2, 2) + A(2, 2) + A(-2, 2) + A(2, 2);
+        const int plus6 = A(0, -6) + A(-6, 0) + A(6, 0) + A(0, 6);
+        const int ring = A(-2, -6) + A(2, -6) + A(-6, -2) + A(6, -2) + A(-6, 2) + A(6, 2) + A(-2, 6) + A(2, 6);
+        v = A(0, 0) + plus2 * 820 / 1024 + diag2 * 657 / 1024 + plus2 * 421 / 1024 + twice * 337 / 1024 + diag2 * 173 / 1024 +
+            plus6 * 139 / 1024 + ring * 111 / 1024 + ring * 57 / 1024;
+    }
+    out[i] = (uint16_t)v;
+}
+
+// final blend + 20 -> 16 bit; amap = gaussian output (pre 2x2 max), over = raw 100/0 flags
+__global__ __launch_bounds__(256) void k_di_blend(const uint32_t *__restrict__ dark, const uint32_t *__restrict__ bright,
+                                                  const uint32_t *__restrict__ fullres, const uint32_t *__restrict__ halfres,
+                                                  const uint16_t *__restrict__ over, const uint16_t *__restrict__ amap,
+                                                  DiParams p, DiLuts L, uint16_t *__restrict__ img_out)
+{
+    const int w = p.w, h = p.h;
+    const size_t n = (size_t)w * h;
+    const int *r2e = L.blend_raw2ev, *e2r = L.blend_ev2raw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w), y = (int)(i / w);
+        const int b = (int)bright[i], d = (int)dark[i];
+        // overexposure blur, hdr.c:1631-1651
+        int ov = over[i];
+        if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
+            auto O = [&](int dx, int dy) { return (int)over[(x + dx) + (size_t)(y + dy) * w]; };
+            ov = (uint16_t)(O(0, 0) + (O(0, -1) + O(-1, 0) + O(1, 0) + O(0, 1)) * 820 / 1024 +
+                            (O(-1, -1) + O(1, -1) + O(-1, 1) + O(1, 1)) * 657 / 1024);
+        }
+        // alias map made "grayscale": max over the 2x2 cell, capped (hdr.c:1469-1483)
+        double c = 0;
+        if (amap) {
+            int co = amap[i];
+            const int cx = x & ~1, cy = y & ~1;
+            if (cx >= 2 && cx < w - 2 && cy >= 2 && cy < h - 2) {
+                const size_t o = cx + (size_t)cy * w;
+                co = min(max(max((int)amap[o], (int)amap[o + 1]), max((int)amap[o + w], (int)amap[o + w + 1])), 15000);
+            }
+            c = co / 15000.0;
+            c = c < 0 ? 0 : (c > 1 ? 1 : c);
+        }
+        const int hrev = r2e[halfres[i]], frev = r2e[fullres[i]], frsev = frev;     // no chroma smoothing: *_smooth == *
+        double f = L.fullres_curve[b & 0xFFFFF];
+        double ovf = ov / 200.0;
+        ovf = ovf < 0 ? 0 : (ovf > 1 ? 1 : ovf);
+        c = c > ovf ? c : ovf;
+        const double noisy = ovf > 1 - f ? ovf : 1 - f;
+        f = f > c ? f : c;
+        const double fev = noisy * frsev + (1 - noisy) * frev;
+        const int sig = (d + b) / 2;
+        const double lim = (double)(sig - p.black20) / (4 * p.dark_noise);
+        const double fm = f < lim ? f : lim;
+        f = fm > 0 ? fm : 0;
+        int out = (int)(hrev * (1 - f) + fev * f);
+        out = out < -10 * DI_EVR ? -10 * DI_EVR : (out > 14 * DI_EVR - 1 ? 14 * DI_EVR - 1 : out);
+        const int v20 = e2r[out];
+        int v = (int)(v20 / 16.0 + 0.0f + 0.5);                                      // hdr.c:243, dither term is 0
+        v = v < 0 ? 0 : (v > 0xFFFF ? 0xFFFF : v);
+        img_out[i] = (uint16_t)v;
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+static inline dim3 flat_grid(size_t n) { size_t b = (n + 255) / 256; if (b > 8192) b = 8192; return dim3((unsigned)b); }
+
+int di_launch_analyse(const void *d_img, int w, int H, int black, int white, const double *d_evf, unsigned *d_hist,
+                      double *d_check, hipStream_t s)
+{
+    MLV_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * DI_HIST_WORDS, s));
+    MLV_HIP(hipMemsetAsync(d_check, 0, 2 * sizeof(double), s));
+    hipLaunchKernelGGL(k_di_analyse, flat_grid((size_t)w * H), dim3(256), 0, s, (const uint16_t *)d_img, w, H, black, white, d_evf,
+                       d_hist, d_check);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+int di_launch_subsample(const void *d_img, const DiParams &p, int nsx, int nsy, int *d_dark_s, int *d_bright_s,
+                        unsigned *d_hist_b, unsigned *d_hist_d, hipStream_t s)
+{
+    MLV_HIP(hipMemsetAsync(d_hist_b, 0, sizeof(unsigned) * DI_HIST_N, s));
+    MLV_HIP(hipMemsetAsync(d_hist_d, 0, sizeof(unsigned) * DI_HIST_N, s));
+    if (nsx * nsy > 0)
+        hipLaunchKernelGGL(k_di_subsample, dim3((nsx * nsy + 255) / 256), dim3(256), 0, s, (const uint16_t *)d_img, p, nsx, nsy,
+                           d_dark_s, d_bright_s, d_hist_b, d_hist_d);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+int di_launch_score(const int *d_hd, const int *d_hb, int hi_n, const double *d_cand, int ncand, int *d_score, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_di_score, dim3(ncand), dim3(256), 0, s, d_hd, d_hb, hi_n, d_cand, d_score);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+int di_launch_convert(const void *d_img, const DiParams &p, const DiLuts &L, const DiPlanes &P, void *d_out, hipStream_t s)
+{
+    const size_t n = (size_t)p.w * p.h;
+    hipLaunchKernelGGL(k_di_match, flat_grid(n), dim3(256), 0, s, (const uint16_t *)d_img, P.raw, p);
+    hipLaunchKernelGGL(k_di_interp, flat_grid(n), dim3(256), 0, s, P.raw, p, L, P.dark, P.bright, P.fullres, P.halfres, P.over,
+                       p.use_alias_map ? P.amap : nullptr);
+    const uint16_t *amap_final = nullptr;
+    if (p.use_alias_map) {
+        dim3 g((p.w + 255) / 256, p.h);
+        hipLaunchKernelGGL(k_di_alias_rank, g, dim3(256), 0, s, P.amap, P.bright, L.fullres_curve, p.w, p.h, P.aux);
+        hipLaunchKernelGGL(k_di_alias_blur, g, dim3(256), 0, s, P.aux, P.amap, P.bright, L.fullres_curve, p.w, p.h, P.amap2);
+        amap_final = P.amap2;
+    }
+    hipLaunchKernelGGL(k_di_blend, flat_grid(n), dim3(256), 0, s, P.dark, P.bright, P.fullres, P.halfres, P.over, amap_final, p, L,
+                       (uint16_t *)d_out);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+}  // namespace mlv

@@ -30,7 +30,7 @@ DROPIN_SYMBOLS = [
     "chroma_smooth", "fix_bad_pixels", "fix_focus_pixels", "free_focus_pixel_maps",
     "stripes_get_correction", "stripes_new_correction", "stripes_free_corrections",
     "stripes_compute_correction", "stripes_apply_correction",
-    "hdr_convert_data", "fix_pattern_noise",
+    "hdr_convert_data", "cr2hdr20_convert_data", "fix_pattern_noise",
     "hist_create", "hist_add", "hist_median", "hist_destroy",
 ]
 DEVICE_SYMBOLS = [
@@ -41,6 +41,7 @@ DEVICE_SYMBOLS = [
     "mlvfs_amd_fix_pixels_dev", "mlvfs_amd_stripes_count_dev", "mlvfs_amd_stripes_hist_dev",
     "mlvfs_amd_stripes_solve", "mlvfs_amd_stripes_compute_dev", "mlvfs_amd_stripes_apply_dev",
     "mlvfs_amd_rand_stream", "mlvfs_amd_process_frames_dev", "mlvfs_amd_hdr_preview_dev",
+    "mlvfs_amd_cr2hdr20_dev", "mlvfs_amd_dualiso_reset",
     "mlvfs_amd_timer_begin", "mlvfs_amd_timer_end", "mlvfs_amd_selftest_host",
 ]
 
@@ -100,6 +101,7 @@ def load() -> C.CDLL:
     sig("stripes_compute_correction", None, [fhp, scp, vp, C.c_long, sz])
     sig("stripes_apply_correction", None, [fhp, scp, vp, C.c_long, sz])
     sig("hdr_convert_data", i, [fhp, vp, C.c_long, sz])
+    sig("cr2hdr20_convert_data", i, [fhp, vp, i, i, i, i, i])
     sig("fix_pattern_noise", None, [vp, i, i, i, i])
     sig("hist_create", vp, [C.c_uint16])
     sig("hist_add", None, [vp, vp, C.c_uint32, C.c_uint16])
@@ -128,6 +130,8 @@ def load() -> C.CDLL:
     sig("mlvfs_amd_rand_stream", None, [vp, sz, C.c_uint64, C.c_uint])
     sig("mlvfs_amd_process_frames_dev", i, [vp, vp, sz, vp, sz, i, i, i, i, vp])
     sig("mlvfs_amd_hdr_preview_dev", i, [gp, vp, sz, vp])
+    sig("mlvfs_amd_cr2hdr20_dev", i, [gp, vp, i, i, i, i, vp])
+    sig("mlvfs_amd_dualiso_reset", None, [])
     sig("mlvfs_amd_timer_begin", i, [i])
     sig("mlvfs_amd_timer_end", i, [vp, i])
     sig("mlvfs_amd_selftest_host", i, [])

@@ -64,7 +64,8 @@ def process_frame(packed: np.ndarray, fh: abi.FrameHeaders, opt: MlvfsOptions, m
     if opt.dual_iso == 1:
         is_dual_iso = L.hdr_convert_data(C.byref(fh), p, 0, img.nbytes)
     elif opt.dual_iso == 2:
-        raise NotImplementedError("full dual-ISO (cr2hdr20_convert_data) is not part of this build yet")
+        is_dual_iso = L.cr2hdr20_convert_data(C.byref(fh), p, opt.hdr_interpolation_method, int(not opt.hdr_no_fullres),
+                                              int(not opt.hdr_no_alias_map), opt.chroma_smooth, opt.fix_bad_pixels)
     if not is_dual_iso:
         L.fix_focus_pixels(C.byref(fh), p, 0)
         if opt.fix_bad_pixels:

@@ -65,6 +65,8 @@ class Oracle:
         L.orc_hdr_preview.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.orc_fix_pattern_noise.argtypes = [i16p, C.c_int, C.c_int, C.c_int]
+        L.orc_cr2hdr20.restype = C.c_int
+        L.orc_cr2hdr20.argtypes = [u16p] + [C.c_int] * 8 + [i32p, C.c_void_p]
         L.orc_build_raw2ev.argtypes = [C.c_int, i32p, C.c_int]
         L.orc_build_ev2raw.argtypes = [i32p]
         L.orc_rand_seed.argtypes = [C.c_void_p, C.c_uint]
@@ -171,6 +173,20 @@ class Oracle:
         r = self.L.orc_hdr_preview(out, w, h, black, white, w * h * 2, C.byref(a), C.byref(b), C.byref(s))
         lv = (black * 4, white * 4) if r else (black, white)
         return r, out, lv
+
+    def cr2hdr20(self, img, black, white, interp_method=1, fullres=1, alias_map=1, chroma_smooth=0, bad_pix=0,
+                 reset=True, want_scalars=False):
+        """Full dual-ISO conversion (mean23).  reset=True forgets the per-black table caches first
+        (a fresh process); returns (ret, image, (black, white))[, scalars]."""
+        out = np.ascontiguousarray(img, np.uint16).copy()
+        h, w = out.shape
+        if reset:
+            self.L.orc_dualiso_reset()
+        lv = np.zeros(2, np.int32)
+        sc = np.zeros(8, np.float64)
+        r = self.L.orc_cr2hdr20(out, w, h, black, white, interp_method, fullres, alias_map, chroma_smooth, lv, sc.ctypes.data)
+        res = (r, out, (int(lv[0]), int(lv[1])))
+        return res + (sc,) if want_scalars else res
 
     def fix_pattern_noise(self, img, white) -> np.ndarray:
         out = np.ascontiguousarray(img).view(np.int16).copy()

@@ -96,6 +96,14 @@ void orc_hist_destroy(orc_hist_t *h);
 int orc_hdr_preview(uint16_t *img, int w, int h, int black, int white,
                     size_t max_size, double *a_out, double *b_out, int *dark_row_start_out);
 
+/* ---- full dual-ISO (cr2hdr 20-bit): mlvfs/hdr.c:230-1957, interp_method 1 (mean23) ----- */
+/* returns 1 converted / 0 not dual-ISO or failed / -1 configuration not restated.
+ * levels_out = {black, white} the caller's frame_headers end up with (x4 on success);
+ * scalars_out (optional) = rggb, is_bright bits, white, white_bright, a, b, corr_ev, white_darkened */
+int orc_cr2hdr20(uint16_t *image, int w, int h, int black14, int white14, int interp_method, int use_fullres,
+                 int use_alias_map, int chroma_smooth_method, int levels_out[2], double scalars_out[8]);
+void orc_dualiso_reset(void);
+
 /* ---- pattern noise: mlvfs/patternnoise.c:49-380 -------------------------- */
 void orc_fix_pattern_noise(int16_t *raw, int w, int h, int white);
 

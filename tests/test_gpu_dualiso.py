@@ -1,0 +1,99 @@
+"""GPU parity of the full dual-ISO conversion (cr2hdr 20-bit, mlvfs/hdr.c:230-1957),
+mean23 interpolation, against the oracle (which tests/test_oracle_vs_ref.py pins
+byte-exact against the reference's own code).
+
+Tolerance: the pattern, white levels and exposure fit are integer /
+host-libm work and must be identical; the only device transcendental is the cos() of
+the per-frame mixing curve, so the output may differ by at most 1 LSB on at most 0.01 %
+of the pixels.  In practice the frames below come out bit-identical.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mlvfs_amd import abi, lib, synth
+
+pytestmark = pytest.mark.gpu
+BLACK, WHITE = synth.BLACK, synth.WHITE
+
+
+def convert(gpu, f, interp=1, fullres=1, alias=1, cs=0, bad=0, reset=True):
+    h, w = f.shape
+    if reset:
+        gpu.mlvfs_amd_dualiso_reset()
+    fh = abi.make_frame_headers(w, h, black=BLACK, white=WHITE)
+    out = f.copy()
+    r = gpu.cr2hdr20_convert_data(C.byref(fh), lib.ptr(out), interp, fullres, alias, cs, bad)
+    return r, out, (fh.rawi_hdr.raw_info.black_level, fh.rawi_hdr.raw_info.white_level)
+
+
+def check_close(got, want):
+    d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    assert d.max() <= 1, f"max |diff| = {d.max()}"
+    assert (d > 0).mean() <= 1e-4, f"{(d > 0).sum()} px differ"
+
+
+@pytest.mark.parametrize("fullres,alias", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("w,h", [(64, 48), (136, 72), (416, 264)])
+def test_cr2hdr20_mean23(gpu, oracle, w, h, fullres, alias):
+    f = synth.dual_iso_frame(w, h)
+    r0, want, lv0 = oracle.cr2hdr20(f, BLACK, WHITE, 1, fullres, alias, 0)
+    r1, got, lv1 = convert(gpu, f, 1, fullres, alias)
+    assert r0 == r1 == 1 and lv0 == lv1 == (BLACK * 4, WHITE * 4)
+    check_close(got, want)
+    assert (got != f).mean() > 0.9
+
+
+def test_cr2hdr20_gbrg_and_not_dual_iso(gpu, oracle):
+    f = synth.dual_iso_frame(136, 74)[1:73].copy()          # frame that starts on a GB row
+    r0, want, _ = oracle.cr2hdr20(f, BLACK, WHITE, 1, 1, 1, 0)
+    r1, got, _ = convert(gpu, f)
+    assert r0 == r1 == 1
+    check_close(got, want)
+    assert np.array_equal(got[0], f[0])                     # the skipped first row is untouched (hdr.c:1783-1790)
+    n = synth.normal_frame(136, 72)
+    r, got, lv = convert(gpu, n)
+    assert r == 0 and np.array_equal(got, n) and lv == (BLACK, WHITE)
+
+
+def test_cr2hdr20_unbuilt_configurations_fail_loudly(gpu):
+    f = synth.dual_iso_frame(64, 48)
+    for kw in (dict(interp=0), dict(cs=5)):
+        r, got, lv = convert(gpu, f, **kw)
+        assert r == 0 and np.array_equal(got, f) and lv == (BLACK, WHITE)
+        assert b"not implemented" in gpu.mlvfs_amd_last_error()
+
+
+def test_cr2hdr20_sticky_tables(gpu, oracle):
+    """The reference keeps the 20-bit tables of the first white level seen per black level
+    (hdr.c:1240,1575,1672); a second frame with a different white level reuses them."""
+    a, b = synth.dual_iso_frame(136, 72, seed=3), np.minimum(synth.dual_iso_frame(136, 72, seed=4), 12000).astype(np.uint16)
+    oracle.L.orc_dualiso_reset()
+    gpu.mlvfs_amd_dualiso_reset()
+    for f in (a, b):
+        _, want, _ = oracle.cr2hdr20(f, BLACK, WHITE, 1, 1, 1, 0, reset=False)
+        _, got, _ = convert(gpu, f, reset=False)
+        check_close(got, want)
+
+
+def test_cr2hdr20_full_size(gpu, oracle):
+    """BASELINE.json config 4 geometry (3584x1320), mean23 interpolation."""
+    f = synth.dual_iso_frame(3584, 1320)
+    r0, want, _ = oracle.cr2hdr20(f, BLACK, WHITE, 1, 1, 1, 0)
+    r1, got, _ = convert(gpu, f)
+    assert r0 == r1 == 1
+    check_close(got, want)
+
+
+def test_cr2hdr20_device_api(gpu, oracle):
+    import torch
+    w, h = 416, 264
+    f = synth.dual_iso_frame(w, h)
+    _, want, _ = oracle.cr2hdr20(f, BLACK, WHITE, 1, 1, 1, 0)
+    gpu.mlvfs_amd_dualiso_reset()
+    t = torch.from_numpy(f.view(np.int16)).cuda()
+    geom = lib.Geom(w, h, 14, BLACK, WHITE, 0, 0)
+    assert gpu.mlvfs_amd_cr2hdr20_dev(C.byref(geom), C.c_void_p(t.data_ptr()), 1, 1, 1, 0, None) == 1
+    torch.cuda.synchronize()
+    check_close(t.cpu().numpy().view(np.uint16), want)

@@ -163,3 +163,26 @@ def test_process_frame_order(oracle, reference, cs, bad, stripes):
         assert np.array_equal(a, b)
         if stripes:
             assert ca[0] == cb[0] and np.array_equal(ca[1], cb[1])
+
+
+# ------------------------------------------------------------------ full dual-ISO (mean23)
+@pytest.mark.parametrize("fullres,alias", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("w,h", [(64, 48), (136, 72), (416, 264)])
+def test_cr2hdr20_mean23(oracle, reference, w, h, fullres, alias):
+    """hdr.c:1932-1957 with --mean23.  Both implementations keep the 20-bit tables of the first
+    white level they see per black level; the synthetic dual-ISO frames share one white level,
+    so the order of the calls does not matter here."""
+    f = synth.dual_iso_frame(w, h)
+    a = oracle.cr2hdr20(f, BLACK, WHITE, 1, fullres, alias, 0, reset=False)
+    b = reference.cr2hdr20(f, BLACK, WHITE, 1, fullres, alias, 0)
+    assert a[0] == b[0] == 1 and a[2] == b[2]
+    assert np.array_equal(a[1], b[1])
+
+
+def test_cr2hdr20_gbrg_and_rejects(oracle, reference):
+    f = synth.dual_iso_frame(136, 74)[1:73].copy()
+    a, b = oracle.cr2hdr20(f, BLACK, WHITE, 1, 1, 1, 0, reset=False), reference.cr2hdr20(f, BLACK, WHITE, 1, 1, 1, 0)
+    assert a[0] == b[0] == 1 and np.array_equal(a[1], b[1])
+    n = synth.normal_frame(136, 72)
+    a, b = oracle.cr2hdr20(n, BLACK, WHITE, 1, 1, 1, 0, reset=False), reference.cr2hdr20(n, BLACK, WHITE, 1, 1, 1, 0)
+    assert a[0] == b[0] == 0 and np.array_equal(a[1], n) and np.array_equal(b[1], n) and a[2] == b[2] == (BLACK, WHITE)
