@@ -276,6 +276,9 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
                  o_hi_b = take(ns / 25 * 4 + 65536), o_cand = take(8 * 2 * 3100), o_score = take(4 * 3100);
     const size_t o_raw = take(N * 4), o_dark = take(N * 4), o_bright = take(N * 4), o_full = take(N * 4), o_half = take(N * 4),
                  o_over = take(N * 2), o_amap = take(N * 2), o_aux = take(N * 2), o_amap2 = take(N * 2);
+    // an unknown method only logs in the reference (hdr.c:1518) and leaves the "smoothed" copies unsmoothed
+    const bool cs = chroma_smooth_method == 2 || chroma_smooth_method == 3 || chroma_smooth_method == 5;
+    const size_t o_full_s = take(cs ? N * 4 : 0), o_half_s = take(cs ? N * 4 : 0), o_cells = take(cs ? N * 3 : 0);
     DiWork &wk = t_work[c->dev->id];
     rc = wk.ensure(off);
     if (rc) return rc;
@@ -315,10 +318,6 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
         set_error("cr2hdr20_convert_data: AMaZE edge-directed interpolation is not implemented yet (use --mean23); frame not converted");
         return 0;
     }
-    if (chroma_smooth_method != 0) {
-        set_error("cr2hdr20_convert_data: chroma smoothing inside the dual-ISO conversion is not implemented yet; frame not converted");
-        return 0;
-    }
 
     // ---- pattern (hdr.c:1783-1795)
     const bool rggb = is_rggb_from_hist(hist.data() + DI_H_BAYER);
@@ -346,7 +345,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     p.black20 = black; p.white20 = white;
     p.match_white20 = std::min(white, white_bright);
     p.dark_noise = dark_noise;
-    p.use_fullres = use_fullres; p.use_alias_map = use_alias_map;
+    p.use_fullres = use_fullres; p.use_alias_map = use_alias_map; p.chroma_smooth = cs ? chroma_smooth_method : 0;
 
     // ---- match_exposures (hdr.c:638-823)
     const int y0 = ay1 + 2;
@@ -428,12 +427,16 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     DiLuts L{};
     rc = prepare_tables(c->dev->id, black, white, &L, &d_evf);
     if (rc) return rc;
+    if (chroma_smooth_method) printf("Chroma smoothing...\n");
+    if (chroma_smooth_method && !cs) fprintf(stderr, "Unsupported chroma smooth method\nUnsupported chroma smooth method\n");
     if (use_alias_map) printf("Building alias map...\nFiltering alias map...\nSmoothing alias map...\n");
     printf("Final blending...\n");
     DiPlanes P{ (uint32_t *)(B + o_raw), (uint32_t *)(B + o_dark), (uint32_t *)(B + o_bright), (uint32_t *)(B + o_full),
-                (uint32_t *)(B + o_half), (uint16_t *)(B + o_over), (uint16_t *)(B + o_amap), (uint16_t *)(B + o_aux),
-                (uint16_t *)(B + o_amap2) };
-    rc = di_launch_convert(img, p, L, P, img, stream);
+                (uint32_t *)(B + o_half), (uint32_t *)(B + o_full_s), (uint32_t *)(B + o_half_s), (uint16_t *)(B + o_over),
+                (uint16_t *)(B + o_amap), (uint16_t *)(B + o_aux), (uint16_t *)(B + o_amap2), (int *)(B + o_cells) };
+    rc = di_launch_match(img, p, P, stream);
+    if (rc) return rc;
+    rc = di_launch_convert(p, L, P, false, img, stream);
     if (rc) return rc;
     printf("Noise level     : %.02f (20-bit), ideally %.02f\n", 8.0, 8.0);
     printf("Dynamic range   : %.02f EV (cooked)\n", log2(white - black) - log2(8.0));

@@ -22,7 +22,7 @@ struct DiParams {
     int match_white20;         // MIN(white, white_bright): the clip level of match_exposures
     int white_darkened;
     int dark_noise;            // 8 * 64 (hdr.c:329-333, 1817)
-    int use_fullres, use_alias_map;
+    int use_fullres, use_alias_map, chroma_smooth;   // chroma_smooth: 0, 2, 3, 5
     double a, b20, corr_ev, max_ev, overlap;
 };
 
@@ -35,8 +35,9 @@ struct DiLuts {                // device pointers; *_ev2raw are indexable from -
 };
 
 struct DiPlanes {
-    uint32_t *raw, *dark, *bright, *fullres, *halfres;
+    uint32_t *raw, *dark, *bright, *fullres, *halfres, *fullres_s, *halfres_s;
     uint16_t *over, *amap, *aux, *amap2;
+    int *cells;                // [3][h/2][w/2] work planes of the chroma smoothing
 };
 
 int di_launch_analyse(const void *d_img, int w, int H, int black, int white, const double *d_evf, unsigned *d_hist,
@@ -44,6 +45,7 @@ int di_launch_analyse(const void *d_img, int w, int H, int black, int white, con
 int di_launch_subsample(const void *d_img, const DiParams &p, int nsx, int nsy, int *d_dark_s, int *d_bright_s,
                         unsigned *d_hist_b, unsigned *d_hist_d, hipStream_t s);
 int di_launch_score(const int *d_hd, const int *d_hb, int hi_n, const double *d_cand, int ncand, int *d_score, hipStream_t s);
-int di_launch_convert(const void *d_img, const DiParams &p, const DiLuts &L, const DiPlanes &P, void *d_out, hipStream_t s);
+int di_launch_match(const void *d_img, const DiParams &p, const DiPlanes &P, hipStream_t s);
+int di_launch_convert(const DiParams &p, const DiLuts &L, const DiPlanes &P, bool interp_done, void *d_out, hipStream_t s);
 
 }  // namespace mlv

@@ -22,6 +22,8 @@
 // transcendental evaluated on the device is the cos() of the per-frame mixing curve.
 #include "clip.h"
 #include "dualiso.h"
+#define MLV_NET_FN __device__ __forceinline__
+#include "median_nets.h"
 
 namespace mlv {
 
@@ -145,6 +147,40 @@ __device__ __forceinline__ int di_mean3(int a, int b, int c, int white)
     return (a >= white || b >= white || c >= white) ? max(m, white) : m;
 }
 
+// alias-map error term of one pixel, hdr.c:1404-1418
+__device__ __forceinline__ int di_alias_err(const DiParams &p, const DiLuts &L, int b, int f, int hr)
+{
+    if (L.fullres_curve[b] > 0.8) return 0;
+    int e_lin = f - hr;
+    e_lin = e_lin > 0 ? e_lin : -e_lin;
+    e_lin = max(e_lin - p.dark_noise * 3 / 2, 0);
+    int e_log = L.mix_raw2ev[f] - L.mix_raw2ev[hr];
+    e_log = e_log > 0 ? e_log : -e_log;
+    return min(min(e_lin / 2, e_log / 16), 65530);
+}
+
+// everything that follows the interpolation for one pixel: full-res pick (hdr.c:1355-1380), half-res mix
+// (hdr.c:1588-1612), overexposure flag (hdr.c:1620-1626) and, when no chroma smoothing sits in between, the alias error
+__device__ __forceinline__ void di_mix_pixel(const DiParams &p, const DiLuts &L, size_t i, int br, int b, int d,
+                                             uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
+                                             uint16_t *__restrict__ over, uint16_t *__restrict__ amap)
+{
+    int f = 0;
+    if (p.use_fullres) f = br ? (b < p.white_darkened ? b : max(b, d)) : d;
+    fullres[i] = (uint32_t)f;
+    const double ev = L.log2sig[b & 0xFFFFF] + p.corr_ev;
+    double t = ev - (p.max_ev - p.overlap);
+    t = t < p.overlap ? t : p.overlap;
+    t = t > 0 ? t : 0;
+    double k = (-cos(t * 3.14159265358979323846 / p.overlap) + 1) / 2;
+    k = k < 0 ? 0 : (k > 1 ? 1 : k);
+    const int mixed = (int)(L.mix_raw2ev[b] * (1 - k) + L.mix_raw2ev[d] * k);
+    const int hr = L.mix_ev2raw[mixed];
+    halfres[i] = (uint32_t)hr;
+    over[i] = (b >= p.white_darkened || d >= p.white20) ? 100 : 0;
+    if (amap) amap[i] = (uint16_t)di_alias_err(p, L, b, f, hr);
+}
+
 __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ raw, DiParams p, DiLuts L,
                                                    uint32_t *__restrict__ dark, uint32_t *__restrict__ bright,
                                                    uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
@@ -152,7 +188,7 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
 {
     const int w = p.w, h = p.h;
     const size_t n = (size_t)w * h;
-    const int *ir2e = L.interp_raw2ev, *ie2r = L.interp_ev2raw, *mr2e = L.mix_raw2ev, *me2r = L.mix_ev2raw;
+    const int *ir2e = L.interp_raw2ev, *ie2r = L.interp_ev2raw;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % w), y = (int)(i / w);
         const int br = di_bright(p, y);
@@ -182,33 +218,77 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
         const int b = br ? native : interp, d = br ? interp : native;
         bright[i] = (uint32_t)b;
         dark[i] = (uint32_t)d;
-        int f = 0;
-        if (p.use_fullres) f = br ? (b < p.white_darkened ? b : max(b, d)) : d;         // hdr.c:1355-1380
-        fullres[i] = (uint32_t)f;
-        // half-res mix, hdr.c:1588-1612
-        const double ev = L.log2sig[b & 0xFFFFF] + p.corr_ev;
-        double t = ev - (p.max_ev - p.overlap);
-        t = t < p.overlap ? t : p.overlap;
-        t = t > 0 ? t : 0;
-        double k = (-cos(t * 3.14159265358979323846 / p.overlap) + 1) / 2;
-        k = k < 0 ? 0 : (k > 1 ? 1 : k);
-        const int mixed = (int)(mr2e[b] * (1 - k) + mr2e[d] * k);
-        const int hr = me2r[mixed];
-        halfres[i] = (uint32_t)hr;
-        over[i] = (b >= p.white_darkened || d >= p.white20) ? 100 : 0;                  // hdr.c:1620-1626
-        if (amap) {                                                                   // hdr.c:1404-1418
-            int e = 0;
-            if (!(L.fullres_curve[b] > 0.8)) {
-                int e_lin = f - hr;
-                e_lin = e_lin > 0 ? e_lin : -e_lin;
-                e_lin = max(e_lin - p.dark_noise * 3 / 2, 0);
-                int e_log = mr2e[f] - mr2e[hr];
-                e_log = e_log > 0 ? e_log : -e_log;
-                e = min(min(e_lin / 2, e_log / 16), 65530);
-            }
-            amap[i] = (uint16_t)e;
-        }
+        di_mix_pixel(p, L, i, br, b, d, fullres, halfres, over, amap);
     }
+}
+
+// the same mix for dark/bright planes produced by another interpolator (AMaZE)
+__global__ __launch_bounds__(256) void k_di_mix(const uint32_t *__restrict__ dark, const uint32_t *__restrict__ bright, DiParams p,
+                                                DiLuts L, uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
+                                                uint16_t *__restrict__ over, uint16_t *__restrict__ amap)
+{
+    const size_t n = (size_t)p.w * p.h;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        di_mix_pixel(p, L, i, di_bright(p, (int)(i / p.w)), (int)bright[i], (int)dark[i], fullres, halfres, over, amap);
+}
+
+// alias error from the chroma-smoothed planes (hdr.c:1620: build_alias_map gets fullres_smooth / halfres_smooth)
+__global__ __launch_bounds__(256) void k_di_alias_err(const uint32_t *__restrict__ bright, const uint32_t *__restrict__ fullres_s,
+                                                      const uint32_t *__restrict__ halfres_s, DiParams p, DiLuts L,
+                                                      uint16_t *__restrict__ amap)
+{
+    const size_t n = (size_t)p.w * p.h;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        amap[i] = (uint16_t)di_alias_err(p, L, (int)bright[i], (int)fullres_s[i], (int)halfres_s[i]);
+}
+
+// ------------------------------------------------------------------ chroma smoothing of a 20-bit plane
+// hdr.c:1488-1522 = chroma_smooth.c:22-71 for uint32_t pixels, black 0 and the 20-bit tables of mix_images.
+// Pass 1 turns every Bayer cell into (green EV, R - green, B - green); pass 2 takes the medians over the cell
+// neighbourhood and rewrites R and B of the cells the reference visits.  The planes stay L2-resident in between.
+__global__ __launch_bounds__(256) void k_di_cs_cells(const uint32_t *__restrict__ plane, int w, int cw, int ch,
+                                                     const int *__restrict__ r2e, int *__restrict__ cells /* [3][ch][cw] */)
+{
+    const int cx = blockIdx.x * blockDim.x + threadIdx.x, cy = blockIdx.y;
+    if (cx >= cw) return;
+    const uint32_t *c = plane + 2 * cx + (size_t)(2 * cy) * w;
+    const int ge = (r2e[c[1]] + r2e[c[w]]) / 2;
+    const size_t o = cx + (size_t)cy * cw, pl = (size_t)cw * ch;
+    cells[o] = ge;
+    cells[o + pl] = r2e[c[0]] - ge;
+    cells[o + 2 * pl] = r2e[c[w + 1]] - ge;
+}
+
+template <int METHOD>
+__global__ __launch_bounds__(256) void k_di_cs_apply(const int *__restrict__ cells, int w, int h, int cw, int ch,
+                                                     const int *__restrict__ e2r, uint32_t *__restrict__ out)
+{
+    const int cx = blockIdx.x * blockDim.x + threadIdx.x, cy = blockIdx.y;
+    const int x = 2 * cx, y = 2 * cy;
+    if (x < 4 || x >= w - 4 || y < 4 || y >= h - 5) return;
+    const size_t pl = (size_t)cw * ch;
+    const int *G = cells + cx + (size_t)cy * cw, *Rr = G + pl, *Bb = G + 2 * pl;
+    const int ge = G[0];
+    if (ge < 2 * DI_EVR) return;
+    constexpr int NV = METHOD == 5 ? 25 : (METHOD == 3 ? 9 : 5), REACH = METHOD == 5 ? 2 : 1;
+    int vr[NV], vb[NV], k = 0;
+#pragma unroll
+    for (int i = -REACH; i <= REACH; i++)
+#pragma unroll
+        for (int j = -REACH; j <= REACH; j++) {
+            if (METHOD == 2 && i != 0 && j != 0) continue;
+            vr[k] = Rr[i + j * cw];
+            vb[k] = Bb[i + j * cw];
+            k++;
+        }
+    int dr[1], db[1];
+    if constexpr (METHOD == 5) { mlv_median25(vr, dr); mlv_median25(vb, db); }
+    else if constexpr (METHOD == 3) { mlv_median9(vr, dr); mlv_median9(vb, db); }
+    else { mlv_median5(vr, dr); mlv_median5(vb, db); }
+    if (ge + dr[0] <= DI_EVR || ge + db[0] <= DI_EVR) return;
+    auto clampev = [](int v) { return v < 0 ? 0 : (v > 14 * DI_EVR - 1 ? 14 * DI_EVR - 1 : v); };
+    out[x + (size_t)y * w] = (uint32_t)e2r[clampev(ge + dr[0])];
+    out[x + 1 + (size_t)(y + 1) * w] = (uint32_t)e2r[clampev(ge + db[0])];
 }
 
 // 6th largest of the 37 neighbours (kth_smallest(negated, 37, 5)), hdr.c:1423-1443
@@ -269,9 +349,10 @@ __global__ __launch_bounds__(256) void k_di_alias_blur(const uint16_t *__restric
 
 // final blend + 20 -> 16 bit; amap = gaussian output (pre 2x2 max), over = raw 100/0 flags
 __global__ __launch_bounds__(256) void k_di_blend(const uint32_t *__restrict__ dark, const uint32_t *__restrict__ bright,
-                                                  const uint32_t *__restrict__ fullres, const uint32_t *__restrict__ halfres,
-                                                  const uint16_t *__restrict__ over, const uint16_t *__restrict__ amap,
-                                                  DiParams p, DiLuts L, uint16_t *__restrict__ img_out)
+                                                  const uint32_t *__restrict__ fullres, const uint32_t *__restrict__ fullres_s,
+                                                  const uint32_t *__restrict__ halfres_s, const uint16_t *__restrict__ over,
+                                                  const uint16_t *__restrict__ amap, DiParams p, DiLuts L,
+                                                  uint16_t *__restrict__ img_out)
 {
     const int w = p.w, h = p.h;
     const size_t n = (size_t)w * h;
@@ -298,7 +379,7 @@ __global__ __launch_bounds__(256) void k_di_blend(const uint32_t *__restrict__ d
             c = co / 15000.0;
             c = c < 0 ? 0 : (c > 1 ? 1 : c);
         }
-        const int hrev = r2e[halfres[i]], frev = r2e[fullres[i]], frsev = frev;     // no chroma smoothing: *_smooth == *
+        const int hrev = r2e[halfres_s[i]], frev = r2e[fullres[i]], frsev = r2e[fullres_s[i]];
         double f = L.fullres_curve[b & 0xFFFFF];
         double ovf = ov / 200.0;
         ovf = ovf < 0 ? 0 : (ovf > 1 ? 1 : ovf);
@@ -352,12 +433,54 @@ int di_launch_score(const int *d_hd, const int *d_hb, int hi_n, const double *d_
     return MLVFS_AMD_OK;
 }
 
-int di_launch_convert(const void *d_img, const DiParams &p, const DiLuts &L, const DiPlanes &P, void *d_out, hipStream_t s)
+static int di_chroma_smooth(const uint32_t *plane, uint32_t *plane_s, const DiParams &p, const DiLuts &L, int *cells, hipStream_t s)
+{
+    const int w = p.w, h = p.h, cw = w / 2, ch = h / 2;
+    MLV_HIP(hipMemcpyAsync(plane_s, plane, (size_t)w * h * 4, hipMemcpyDeviceToDevice, s));
+    if (cw <= 0 || ch <= 0) return MLVFS_AMD_OK;
+    dim3 g((cw + 255) / 256, ch);
+    hipLaunchKernelGGL(k_di_cs_cells, g, dim3(256), 0, s, plane, w, cw, ch, L.mix_raw2ev, cells);
+    switch (p.chroma_smooth) {
+    case 2: hipLaunchKernelGGL(k_di_cs_apply<2>, g, dim3(256), 0, s, cells, w, h, cw, ch, L.mix_ev2raw, plane_s); break;
+    case 3: hipLaunchKernelGGL(k_di_cs_apply<3>, g, dim3(256), 0, s, cells, w, h, cw, ch, L.mix_ev2raw, plane_s); break;
+    default: hipLaunchKernelGGL(k_di_cs_apply<5>, g, dim3(256), 0, s, cells, w, h, cw, ch, L.mix_ev2raw, plane_s); break;
+    }
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+// raw (exposure-matched 20-bit) -> dark/bright by mean23; returns with fullres/halfres/over (and the alias error) filled in
+int di_launch_match(const void *d_img, const DiParams &p, const DiPlanes &P, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_di_match, flat_grid((size_t)p.w * p.h), dim3(256), 0, s, (const uint16_t *)d_img, P.raw, p);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+// interp_done: dark/bright already hold the interpolated exposures (AMaZE path); otherwise mean23 runs here
+int di_launch_convert(const DiParams &p, const DiLuts &L, const DiPlanes &P, bool interp_done, void *d_out, hipStream_t s)
 {
     const size_t n = (size_t)p.w * p.h;
-    hipLaunchKernelGGL(k_di_match, flat_grid(n), dim3(256), 0, s, (const uint16_t *)d_img, P.raw, p);
-    hipLaunchKernelGGL(k_di_interp, flat_grid(n), dim3(256), 0, s, P.raw, p, L, P.dark, P.bright, P.fullres, P.halfres, P.over,
-                       p.use_alias_map ? P.amap : nullptr);
+    uint16_t *amap_fused = (p.use_alias_map && !p.chroma_smooth) ? P.amap : nullptr;
+    if (interp_done)
+        hipLaunchKernelGGL(k_di_mix, flat_grid(n), dim3(256), 0, s, P.dark, P.bright, p, L, P.fullres, P.halfres, P.over, amap_fused);
+    else
+        hipLaunchKernelGGL(k_di_interp, flat_grid(n), dim3(256), 0, s, P.raw, p, L, P.dark, P.bright, P.fullres, P.halfres, P.over,
+                           amap_fused);
+    MLV_HIP(hipGetLastError());
+    const uint32_t *fullres_s = P.fullres, *halfres_s = P.halfres;
+    if (p.chroma_smooth) {                                             // hdr.c:1612-1619
+        int rc = di_chroma_smooth(P.halfres, P.halfres_s, p, L, P.cells, s);
+        if (rc) return rc;
+        halfres_s = P.halfres_s;
+        if (p.use_fullres) {                                           // otherwise fullres_smooth aliases the all-zero fullres (hdr.c:1822)
+            rc = di_chroma_smooth(P.fullres, P.fullres_s, p, L, P.cells, s);
+            if (rc) return rc;
+            fullres_s = P.fullres_s;
+        }
+        if (p.use_alias_map)
+            hipLaunchKernelGGL(k_di_alias_err, flat_grid(n), dim3(256), 0, s, P.bright, fullres_s, halfres_s, p, L, P.amap);
+    }
     const uint16_t *amap_final = nullptr;
     if (p.use_alias_map) {
         dim3 g((p.w + 255) / 256, p.h);
@@ -365,8 +488,8 @@ int di_launch_convert(const void *d_img, const DiParams &p, const DiLuts &L, con
         hipLaunchKernelGGL(k_di_alias_blur, g, dim3(256), 0, s, P.aux, P.amap, P.bright, L.fullres_curve, p.w, p.h, P.amap2);
         amap_final = P.amap2;
     }
-    hipLaunchKernelGGL(k_di_blend, flat_grid(n), dim3(256), 0, s, P.dark, P.bright, P.fullres, P.halfres, P.over, amap_final, p, L,
-                       (uint16_t *)d_out);
+    hipLaunchKernelGGL(k_di_blend, flat_grid(n), dim3(256), 0, s, P.dark, P.bright, P.fullres, fullres_s, halfres_s, P.over, amap_final,
+                       p, L, (uint16_t *)d_out);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }

@@ -355,12 +355,40 @@ static void alias_map_build(uint16_t *amap, const uint32_t *fullres, const uint3
     free(aux);
 }
 
+/* ---------------------------------------------------------------- chroma smoothing of the 20-bit planes,
+ * hdr.c:1488-1522 (chroma_smooth.c:22-71 instantiated for uint32_t, black = 0, 20-bit tables) */
+static void chroma_smooth20(const uint32_t *inp, uint32_t *out, int w, int h, int method, const int *r2e, const int *e2r)
+{
+    const int reach = method == 5 ? 4 : 2;
+    for (int y = 4; y < h - 5; y += 2)
+        for (int x = 4; x < w - 4; x += 2) {
+            const int ge = (r2e[inp[x + 1 + y * w]] + r2e[inp[x + (y + 1) * w]]) / 2;
+            if (ge < 2 * EVR) continue;
+            int mr[25], mb[25], k = 0;
+            for (int i = -reach; i <= reach; i += 2)
+                for (int j = -reach; j <= reach; j += 2) {
+                    if (method == 2 && IABS(i) + IABS(j) == 4) continue;
+                    const uint32_t *c = inp + (x + i) + (size_t)(y + j) * w;
+                    const int g = (r2e[c[1]] + r2e[c[w]]) / 2;
+                    mr[k] = r2e[c[0]] - g;
+                    mb[k] = r2e[c[w + 1]] - g;
+                    k++;
+                }
+            const int dr = kth_smallest(mr, k, k / 2), db = kth_smallest(mb, k, k / 2);
+            if (ge + dr <= EVR || ge + db <= EVR) continue;
+            out[x + y * w] = e2r[CLAMP(ge + dr, 0, 14 * EVR - 1)];
+            out[x + 1 + (y + 1) * w] = e2r[CLAMP(ge + db, 0, 14 * EVR - 1)];
+        }
+}
+
 /* ---------------------------------------------------------------- whole conversion */
 int orc_cr2hdr20(uint16_t *image, int w_in, int h_in, int black14, int white14, int interp_method, int use_fullres,
                  int use_alias_map, int chroma_smooth_method, int levels_out[2], double scalars_out[8])
 {
     levels_out[0] = black14; levels_out[1] = white14;
-    if (interp_method != 1 || chroma_smooth_method != 0) return -1;      /* not restated (see file header) */
+    if (interp_method != 1) return -1;                                   /* not restated (see file header) */
+    if (chroma_smooth_method != 2 && chroma_smooth_method != 3 && chroma_smooth_method != 5)
+        chroma_smooth_method = 0;                    /* the reference only logs an error (hdr.c:1518) and keeps the unsmoothed copies */
     if (!looks_like_dual_iso(image, w_in, h_in, black14, white14)) return 0;
     int w = w_in, h = h_in;
     if (w <= 0 || h <= 0) return 0;
@@ -380,7 +408,7 @@ int orc_cr2hdr20(uint16_t *image, int w_in, int h_in, int black14, int white14, 
     uint32_t *raw = (uint32_t *)malloc(n * 4);
     for (size_t i = 0; i < n; i++) raw[i] = ((uint32_t)img[i] << 6) & 0xFFFFF;      /* hdr.c:825-837 */
     uint32_t *dark = (uint32_t *)calloc(n, 4), *bright = (uint32_t *)calloc(n, 4), *fullres = (uint32_t *)calloc(n, 4),
-             *halfres = (uint32_t *)calloc(n, 4);
+             *halfres = (uint32_t *)calloc(n, 4), *fullres_s = fullres, *halfres_s = halfres;
     uint16_t *over = (uint16_t *)calloc(n, 2), *amap = use_alias_map ? (uint16_t *)calloc(n, 2) : NULL;
 
     double corr_ev = 0, ma = 0, mb = 0;
@@ -414,7 +442,17 @@ int orc_cr2hdr20(uint16_t *image, int w_in, int h_in, int black14, int white14, 
                 int mixed = r2e[b] * (1 - k) + r2e[d] * k;
                 halfres[i] = e2r[mixed];
             }
-            if (amap) alias_map_build(amap, fullres, halfres, bright, w, h, (int)dark_noise, black, r2e);
+            if (chroma_smooth_method) {                      /* hdr.c:1612-1619; without fullres the "smooth" plane IS fullres (all zero) */
+                halfres_s = (uint32_t *)malloc(n * 4);
+                memcpy(halfres_s, halfres, n * 4);
+                chroma_smooth20(halfres, halfres_s, w, h, chroma_smooth_method, r2e, e2r);
+                if (use_fullres) {
+                    fullres_s = (uint32_t *)malloc(n * 4);
+                    memcpy(fullres_s, fullres, n * 4);
+                    chroma_smooth20(fullres, fullres_s, w, h, chroma_smooth_method, r2e, e2r);
+                }
+            }
+            if (amap) alias_map_build(amap, fullres_s, halfres_s, bright, w, h, (int)dark_noise, black, r2e);
             uint16_t *aux = (uint16_t *)malloc(n * 2);
             for (size_t i = 0; i < n; i++) over[i] = ((int)bright[i] >= white_darkened || (int)dark[i] >= white) ? 100 : 0;
             memcpy(aux, over, n * 2);
@@ -431,7 +469,7 @@ int orc_cr2hdr20(uint16_t *image, int w_in, int h_in, int black14, int white14, 
             const int *br2e = Lb->raw2ev, *be2r = Lb->ev2raw_base + 10 * EVR;
             for (size_t i = 0; i < n; i++) {
                 int b = bright[i];
-                int hrev = br2e[halfres[i]], frev = br2e[fullres[i]], frsev = br2e[fullres[i]];
+                int hrev = br2e[halfres_s[i]], frev = br2e[fullres[i]], frsev = br2e[fullres_s[i]];
                 double f = fc[b & 0xFFFFF], c = 0;
                 if (amap) { c = amap[i] / (double)15000; c = CLAMP(c, 0, 1); }
                 double ovf = over[i] / 200.0;
@@ -460,6 +498,8 @@ int orc_cr2hdr20(uint16_t *image, int w_in, int h_in, int black14, int white14, 
         scalars_out[2] = white; scalars_out[3] = white_bright; scalars_out[4] = ma; scalars_out[5] = mb;
         scalars_out[6] = corr_ev; scalars_out[7] = white_darkened;
     }
+    if (fullres_s != fullres) free(fullres_s);
+    if (halfres_s != halfres) free(halfres_s);
     free(raw); free(dark); free(bright); free(fullres); free(halfres); free(over); free(amap);
     if (ret) { levels_out[0] = black14 * 4; levels_out[1] = white14 * 4; }
     return ret;

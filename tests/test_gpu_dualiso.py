@@ -59,10 +59,23 @@ def test_cr2hdr20_gbrg_and_not_dual_iso(gpu, oracle):
 
 def test_cr2hdr20_unbuilt_configurations_fail_loudly(gpu):
     f = synth.dual_iso_frame(64, 48)
-    for kw in (dict(interp=0), dict(cs=5)):
+    for kw in (dict(interp=0),):
         r, got, lv = convert(gpu, f, **kw)
         assert r == 0 and np.array_equal(got, f) and lv == (BLACK, WHITE)
         assert b"not implemented" in gpu.mlvfs_amd_last_error()
+
+
+@pytest.mark.parametrize("fullres", [1, 0])
+@pytest.mark.parametrize("cs", [2, 3, 5, 4])
+@pytest.mark.parametrize("w,h", [(64, 48), (416, 264)])
+def test_cr2hdr20_chroma_smooth(gpu, oracle, w, h, cs, fullres):
+    """hdr_chroma_smooth on the 20-bit half-res / full-res planes (hdr.c:1488-1522, 1612-1619); method 4 is the
+    reference's "unsupported" branch, which converts without smoothing."""
+    f = synth.dual_iso_frame(w, h)
+    r0, want, _ = oracle.cr2hdr20(f, BLACK, WHITE, 1, fullres, 1, cs)
+    r1, got, _ = convert(gpu, f, 1, fullres, 1, cs)
+    assert r0 == r1 == 1
+    check_close(got, want)
 
 
 def test_cr2hdr20_sticky_tables(gpu, oracle):

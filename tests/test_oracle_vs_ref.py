@@ -186,3 +186,13 @@ def test_cr2hdr20_gbrg_and_rejects(oracle, reference):
     n = synth.normal_frame(136, 72)
     a, b = oracle.cr2hdr20(n, BLACK, WHITE, 1, 1, 1, 0, reset=False), reference.cr2hdr20(n, BLACK, WHITE, 1, 1, 1, 0)
     assert a[0] == b[0] == 0 and np.array_equal(a[1], n) and np.array_equal(b[1], n) and a[2] == b[2] == (BLACK, WHITE)
+
+
+@pytest.mark.parametrize("fullres", [1, 0])
+@pytest.mark.parametrize("cs", [2, 3, 5, 4])
+@pytest.mark.parametrize("w,h", [(64, 48), (416, 264)])
+def test_cr2hdr20_chroma_smooth(oracle, reference, w, h, cs, fullres):
+    f = synth.dual_iso_frame(w, h)
+    a = oracle.cr2hdr20(f, BLACK, WHITE, 1, fullres, 1, cs, reset=False)
+    b = reference.cr2hdr20(f, BLACK, WHITE, 1, fullres, 1, cs)
+    assert a[0] == b[0] == 1 and np.array_equal(a[1], b[1])
