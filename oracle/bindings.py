@@ -67,6 +67,9 @@ class Oracle:
         L.orc_fix_pattern_noise.argtypes = [i16p, C.c_int, C.c_int, C.c_int]
         L.orc_cr2hdr20.restype = C.c_int
         L.orc_cr2hdr20.argtypes = [u16p] + [C.c_int] * 8 + [i32p, C.c_void_p]
+        f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+        L.orc_amaze_demosaic.restype = C.c_int
+        L.orc_amaze_demosaic.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p]
         L.orc_build_raw2ev.argtypes = [C.c_int, i32p, C.c_int]
         L.orc_build_ev2raw.argtypes = [i32p]
         L.orc_rand_seed.argtypes = [C.c_void_p, C.c_uint]
@@ -188,6 +191,10 @@ class Oracle:
         res = (r, out, (int(lv[0]), int(lv[1])))
         return res + (sc,) if want_scalars else res
 
+    def amaze_demosaic(self, raw):
+        """raw: float32 (h, w) Bayer plane in the caller's scale; returns (red, green, blue) float32 (h, w)."""
+        return _amaze(self.L.orc_amaze_demosaic, raw)
+
     def fix_pattern_noise(self, img, white) -> np.ndarray:
         out = np.ascontiguousarray(img).view(np.int16).copy()
         h, w = out.shape
@@ -240,6 +247,8 @@ class Reference:
         L.ref_cr2hdr20.restype = C.c_int
         L.ref_cr2hdr20.argtypes = [u16p] + [C.c_int] * 9 + [i32p]
         L.ref_fix_pattern_noise.argtypes = [i16p, C.c_int, C.c_int, C.c_int]
+        f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+        L.ref_amaze_demosaic.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p]
         L.ref_hist_median_of.restype = C.c_uint16
         L.ref_hist_median_of.argtypes = [u16p, C.c_uint32, C.c_uint16, C.c_uint16]
         L.ref_sizeof_frame_headers.restype = C.c_size_t
@@ -305,6 +314,9 @@ class Reference:
         r = self.L.ref_hdr_preview(out, w, h, black, white, lv)
         return r, out, (int(lv[0]), int(lv[1]))
 
+    def amaze_demosaic(self, raw):
+        return _amaze(self.L.ref_amaze_demosaic, raw)
+
     def cr2hdr20(self, img, black, white, interp_method=0, fullres=1, alias_map=1, chroma_smooth=0, bad_pix=0):
         out = np.ascontiguousarray(img, np.uint16).copy()
         h, w = out.shape
@@ -332,3 +344,13 @@ class Reference:
         self.L.ref_process_frame(np.ascontiguousarray(packed, np.uint16), img, w, h, bpp, black, white,
                                  cs, bad_pix, stripes, 0, co, C.byref(needed), int(correction is None))
         return img, ((needed.value, co) if stripes else None)
+
+
+def _amaze(fn, raw):
+    raw = np.asarray(raw, np.float32)
+    h, w = raw.shape
+    pitch = w + 16
+    planes = [np.zeros((h, pitch), np.float32) for _ in range(4)]
+    planes[0][:, :w] = raw
+    fn(planes[0], w, h, pitch, planes[1], planes[2], planes[3])
+    return tuple(p[:, :w].copy() for p in planes[1:])

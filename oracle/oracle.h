@@ -96,7 +96,12 @@ void orc_hist_destroy(orc_hist_t *h);
 int orc_hdr_preview(uint16_t *img, int w, int h, int black, int white,
                     size_t max_size, double *a_out, double *b_out, int *dark_row_start_out);
 
-/* ---- full dual-ISO (cr2hdr 20-bit): mlvfs/hdr.c:230-1957, interp_method 1 (mean23) ----- */
+/* ---- AMaZE demosaic (SSE2 variant = what x86-64 builds of MLVFS run): mlvfs/amaze_demosaic_RT.c:113-1487 ----
+ * raw/red/green/blue: h rows of `pitch` floats, pitch >= w + 16 (hdr.c:969-975); values are the caller's scale
+ * (the demosaic divides by 65535 on load and multiplies back on store).  Returns 0, -1 on bad arguments.        */
+int orc_amaze_demosaic(const float *raw, int w, int h, int pitch, float *red, float *green, float *blue);
+
+/* ---- full dual-ISO (cr2hdr 20-bit): mlvfs/hdr.c:230-1957, interp_method 0 (AMaZE + edge-directed) and 1 (mean23) ----- */
 /* returns 1 converted / 0 not dual-ISO or failed / -1 configuration not restated.
  * levels_out = {black, white} the caller's frame_headers end up with (x4 on success);
  * scalars_out (optional) = rggb, is_bright bits, white, white_bright, a, b, corr_ev, white_darkened */

@@ -1,9 +1,8 @@
 /*
  * oracle_dualiso.c -- CPU restatement of the full dual-ISO conversion
- * (cr2hdr 20-bit), mlvfs/hdr.c:230-1957, for interp_method = 1 ("mean23",
- * hdr.c:1231-1304).  The AMaZE-based interpolation (interp_method = 0,
- * hdr.c:954-1229 + amaze_demosaic_RT.c) is NOT restated yet: for that method the
- * checker is the reference build itself (oracle/_ref).
+ * (cr2hdr 20-bit), mlvfs/hdr.c:230-1957: interp_method = 1 ("mean23",
+ * hdr.c:1231-1304) and interp_method = 0 (AMaZE + edge-directed interpolation,
+ * hdr.c:914-1229; the demosaic itself is oracle_amaze.c).
  *
  * TEST INFRASTRUCTURE ONLY (see oracle.h).  Own code, own structure; every stage
  * cites the reference lines it follows.  Behaviour reproduced on purpose:
@@ -62,13 +61,13 @@ static void lut_build(evlut_t *L, int black, int white)
     L->black = black;
 }
 
-static evlut_t g_lut_interp = { -1, 0, 0 }, g_lut_mix = { -1, 0, 0 }, g_lut_blend = { -1, 0, 0 };
+static evlut_t g_lut_interp = { -1, 0, 0 }, g_lut_amaze = { -1, 0, 0 }, g_lut_mix = { -1, 0, 0 }, g_lut_blend = { -1, 0, 0 };
 static double *g_fullres_curve;
 static int g_fullres_black = -1;
 
 void orc_dualiso_reset(void)
 {
-    g_lut_interp.black = g_lut_mix.black = g_lut_blend.black = -1;
+    g_lut_interp.black = g_lut_amaze.black = g_lut_mix.black = g_lut_blend.black = -1;
     g_fullres_black = -1;
 }
 
@@ -285,7 +284,13 @@ static void interpolate_mean23(const uint32_t *raw, uint32_t *dark, uint32_t *br
             native[x + 1 + y * w] = R(x + 1, y);
         }
     }
-    /* borders, hdr.c:1306-1353 */
+#undef R
+}
+
+/* borders (after either interpolator), hdr.c:1306-1353 */
+static void interpolate_borders(const uint32_t *raw, uint32_t *dark, uint32_t *bright, int w, int h, const int is_bright[4])
+{
+#define R(x, y) ((int)raw[(x) + (y) * w])
     for (int y = 0; y < 3; y++)
         for (int x = 0; x < w; x++) {
             uint32_t *native = is_bright[y % 4] ? bright : dark, *interp = is_bright[y % 4] ? dark : bright;
@@ -302,6 +307,99 @@ static void interpolate_mean23(const uint32_t *raw, uint32_t *dark, uint32_t *br
         for (int x = w - 3; x < w; x++) { interp[x + y * w] = R(x - 2, y - 2); native[x + y * w] = R(x - 2, y); }
     }
 #undef R
+}
+
+/* ---------------------------------------------------------------- AMaZE + edge-directed interpolation, hdr.c:914-1229 */
+static const struct { signed char ack[2], a[2], b[2], bck[2]; } k_edge_dirs[11] = {   /* y entries are multiplied by s */
+    { {-4, 2}, {-2, 1}, { 4, -2}, { 6, -3} }, { {-3, 2}, {-1, 1}, { 3, -2}, { 4, -3} }, { {-2, 2}, {-1, 1}, { 2, -2}, { 3, -3} },
+    { {-1, 2}, {-1, 1}, { 1, -2}, { 2, -3} }, { {-1, 2}, { 0, 1}, { 1, -2}, { 1, -3} }, { { 0, 2}, { 0, 1}, { 0, -2}, { 0, -3} },
+    { { 1, 2}, { 0, 1}, {-1, -2}, {-1, -3} }, { { 1, 2}, { 1, 1}, {-1, -2}, {-2, -3} }, { { 2, 2}, { 1, 1}, {-2, -2}, {-3, -3} },
+    { { 3, 2}, { 1, 1}, {-3, -2}, {-4, -3} }, { { 4, 2}, { 2, 1}, {-4, -2}, {-6, -3} } };
+
+static void interpolate_amaze(const uint32_t *raw, uint32_t *dark, uint32_t *bright, int w, int h, int black, int white_lvl,
+                              int white_darkened, const int is_bright[4], double stats_out[2])
+{
+    const int pitch = w + 16;                                /* hdr.c:969 */
+    int *squeezed = (int *)calloc(h, sizeof(int));
+    float *cfa = (float *)calloc((size_t)h * pitch, sizeof(float)), *red = (float *)calloc((size_t)h * pitch, sizeof(float)),
+          *green = (float *)calloc((size_t)h * pitch, sizeof(float)), *blue = (float *)calloc((size_t)h * pitch, sizeof(float));
+    /* squeeze: rows of one exposure become adjacent (dark from the top, bright from h/4*2), greens halved; hdr.c:977-1026 */
+    for (int pass = 0; pass < 2; pass++) {
+        int yh = -1;
+        for (int y = 0; y < h; y++) {
+            if (is_bright[y % 4] != pass) continue;
+            if (yh < 0) yh = pass ? h / 4 * 2 + y : y;
+            for (int x = 0; x < w; x++) {
+                int p = raw[x + y * w];
+                if (x % 2 != y % 2) p = (p - black) / 2 + black;
+                cfa[(size_t)yh * pitch + x] = p;
+            }
+            squeezed[y] = yh++;
+            if (pass && yh >= h) break;                      /* rows that do not fit keep squeezed[y] = 0 (reference quirk) */
+        }
+    }
+    orc_amaze_demosaic(cfa, w, h, pitch, red, green, blue);
+    uint32_t *gray = (uint32_t *)malloc((size_t)w * h * 4);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            size_t i = (size_t)y * pitch + x;
+            float g = (green[i] - black) * 2 + black;
+            green[i] = g < 0xFFFFF ? (g > 0 ? g : 0) : 0xFFFFF;              /* MAX(MIN(x,hi),lo), hdr.c:1046-1048 */
+            red[i] = red[i] < 0xFFFFF ? (red[i] > 0 ? red[i] : 0) : 0xFFFFF;
+            blue[i] = blue[i] < 0xFFFFF ? (blue[i] > 0 ? blue[i] : 0) : 0xFFFFF;
+        }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            size_t i = (size_t)squeezed[y] * pitch + x;
+            gray[x + y * w] = green[i] / 2 + red[i] / 4 + blue[i] / 4;
+        }
+    unsigned char *dir = (unsigned char *)malloc((size_t)w * h);
+    memset(dir, 5, (size_t)w * h);
+    const double *fc = fullres_curve(black);
+    evlut_t *L = lut_get(&g_lut_amaze, black, white_lvl);
+    const int *r2e = L->raw2ev, *e2r = L->ev2raw_base + 10 * EVR;
+    long semi = 0, notover = 0, deep = 0, notshadow = 0;
+    for (int y = 5; y < h - 5; y++) {
+        const int s = (is_bright[y % 4] == is_bright[(y + 1) % 4]) ? -1 : 1;
+        for (int x = 5; x < w - 5; x++) {
+            int search;
+            if (!is_bright[y % 4]) { search = !(fc[raw[x + y * w]] > 0.8); if (search) deep++; else notshadow++; }
+            else { search = !((int)raw[x + y * w] < white_darkened); if (search) semi++; else notover++; }
+            if (!search) continue;
+            int e_best = INT_MAX, d_best = 5;
+            for (int d = 0; d < 11; d++) {
+                int e = 0;
+                for (int j = -5; j <= 5; j++) {
+#define GEV(q) r2e[gray[x + k_edge_dirs[d].q[0] + j + (y + k_edge_dirs[d].q[1] * s) * w]]
+                    const int p1 = GEV(ack), p2 = GEV(a), p3 = GEV(b), p4 = GEV(bck);
+#undef GEV
+                    e += IABS(p1 - p2) + IABS(p2 - p3) + IABS(p3 - p4);
+                }
+                e += IABS(d - 5) * EVR / 8;
+                if (e < e_best) { e_best = e; d_best = d; }
+            }
+            dir[x + y * w] = (unsigned char)d_best;
+        }
+    }
+    if (stats_out) { stats_out[0] = semi * 100.0 / (semi + notover); stats_out[1] = deep * 100.0 / (deep + notshadow); }
+    for (int y = 2; y < h - 2; y++) {
+        uint32_t *native = is_bright[y % 4] ? bright : dark, *interp = is_bright[y % 4] ? dark : bright;
+        const int s = (is_bright[y % 4] == is_bright[(y + 1) % 4]) ? -1 : 1;
+        for (int x = 2; x < w - 2; x++) {
+            const float *plane = (y % 2 == 0) ? (x % 2 == 0 ? red : green) : (x % 2 == 0 ? green : blue);
+            const int d = dir[x + y * w], dd[3] = { d, IMIN(d + 1, 10), IMAX(d - 1, 0) };
+            int pi[3];
+            for (int k = 0; k < 3; k++) {
+                int pa = (int)plane[(size_t)squeezed[y + k_edge_dirs[dd[k]].a[1] * s] * pitch + x + k_edge_dirs[dd[k]].a[0]];
+                int pb = (int)plane[(size_t)squeezed[y + k_edge_dirs[dd[k]].b[1] * s] * pitch + x + k_edge_dirs[dd[k]].b[0]];
+                pa = CLAMP(pa, 0, 0xFFFFF); pb = CLAMP(pb, 0, 0xFFFFF);
+                pi[k] = (r2e[pa] * 2 + r2e[pb]) / 3;
+            }
+            interp[x + y * w] = e2r[(2 * pi[0] + pi[1] + pi[2]) / 4];
+            native[x + y * w] = raw[x + y * w];
+        }
+    }
+    free(dir); free(gray); free(cfa); free(red); free(green); free(blue); free(squeezed);
 }
 
 /* ---------------------------------------------------------------- alias map, hdr.c:1382-1486 */
@@ -386,7 +484,8 @@ int orc_cr2hdr20(uint16_t *image, int w_in, int h_in, int black14, int white14, 
                  int use_alias_map, int chroma_smooth_method, int levels_out[2], double scalars_out[8])
 {
     levels_out[0] = black14; levels_out[1] = white14;
-    if (interp_method != 1) return -1;                                   /* not restated (see file header) */
+    if (interp_method != 0 && interp_method != 1) return -1;
+    if (interp_method == 0 && (w_in % 4)) return -1;         /* the SSE2 reference leaves part of the green plane unwritten then */
     if (chroma_smooth_method != 2 && chroma_smooth_method != 3 && chroma_smooth_method != 5)
         chroma_smooth_method = 0;                    /* the reference only logs an error (hdr.c:1518) and keeps the unsmoothed copies */
     if (!looks_like_dual_iso(image, w_in, h_in, black14, white14)) return 0;
@@ -415,7 +514,9 @@ int orc_cr2hdr20(uint16_t *image, int w_in, int h_in, int black14, int white14, 
     int white_darkened = white_bright, ret = 0;
     if (match_exposures(raw, w, h, ay1, black, white, is_bright, &corr_ev, &white_darkened, &ma, &mb)) {
         const double lowiso_dr = log2(white - black) - dark_noise_ev;
-        interpolate_mean23(raw, dark, bright, w, h, black, white, white_darkened, is_bright);
+        if (interp_method == 0) interpolate_amaze(raw, dark, bright, w, h, black, white, white_darkened, is_bright, NULL);
+        else interpolate_mean23(raw, dark, bright, w, h, black, white, white_darkened, is_bright);
+        interpolate_borders(raw, dark, bright, w, h, is_bright);
         if (use_fullres)                                     /* hdr.c:1355-1380 */
             for (int y = 0; y < h; y++)
                 for (int x = 0; x < w; x++) {

@@ -126,6 +126,21 @@ int ref_cr2hdr20(uint16_t *img, int w, int h, int black, int white, int interp_m
     return r;
 }
 
+/* the reference's AMaZE on contiguous planes (amaze_demosaic_RT.c:113); rows are `pitch` floats apart */
+void amaze_demosaic_RT(float **rawData, float **red, float **green, float **blue, int winx, int winy, int winw, int winh);
+void ref_amaze_demosaic(float *raw, int w, int h, int pitch, float *red, float *green, float *blue)
+{
+    float **rows = (float **)malloc(sizeof(float *) * 4 * h);
+    for (int y = 0; y < h; y++) {
+        rows[y] = raw + (size_t)y * pitch;
+        rows[h + y] = red + (size_t)y * pitch;
+        rows[2 * h + y] = green + (size_t)y * pitch;
+        rows[3 * h + y] = blue + (size_t)y * pitch;
+    }
+    amaze_demosaic_RT(rows, rows + h, rows + 2 * h, rows + 3 * h, 0, 0, w, h);
+    free(rows);
+}
+
 void ref_fix_pattern_noise(int16_t *raw, int w, int h, int white)
 {
     fix_pattern_noise(raw, w, h, white, 0);
