@@ -173,6 +173,12 @@ int mlvfs_amd_cr2hdr20_dev(const mlvfs_amd_geom_t *geom, void *d_frame, int inte
                            int chroma_smooth, void *stream);
 void mlvfs_amd_dualiso_reset(void);
 
+/* AMaZE demosaic of a float RGGB plane in HBM (amaze_demosaic_RT.c:113, as called from hdr.c:1034 with
+ * winx = winy = 0): d_raw and the three outputs are height rows of width floats (no row padding), values in
+ * the caller's scale.  width must be a multiple of 4 (the reference's SSE2 build needs that for a fully
+ * written green plane) and the plane at least 36x36.  Bit-identical to the x86-64 reference build.        */
+int mlvfs_amd_amaze_demosaic_dev(const float *d_raw, int width, int height, float *d_red, float *d_green, float *d_blue, void *stream);
+
 /* HIP-event timer around the dominant kernel (k_frame) of the calling thread's
  * launches, recorded on the stream the kernel is launched on (bench.py's
  * roofline figure).  begin: arm for up to max_launches launches.  end: waits for

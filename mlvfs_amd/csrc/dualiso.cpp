@@ -2,17 +2,15 @@
 // mlvfs/hdr.c:230-1957): the scalar decisions between the kernels of k_dualiso.hip,
 // the libm-built tables, the drop-in cr2hdr20_convert_data and its device-resident form.
 //
-// Implemented: interp_method 1 (mean23), full-res on/off, alias map on/off, without
-// chroma smoothing.  interp_method 0 (AMaZE edge-directed) and chroma smoothing inside
-// the conversion are not built yet: both are reported loudly and return 0 ("not
-// converted"), after which MLVFS continues with its normal path (main.c:961-973).
+// Implemented: interp_method 0 (AMaZE + edge-directed interpolation, k_amaze.hip) and 1 (mean23),
+// full-res on/off, alias map on/off, chroma smoothing 0/2/3/5.
 //
 // Reference quirks reproduced on purpose:
 //  * active_area.x1 = 0 empties the noise loops: dark noise is the default 8.0;
 //  * the dither cache is never initialised: the 20 -> 16 bit step is deterministic;
 //  * the 20-bit EV tables are cached per black level, in one cache per consumer
-//    (interpolation / mix / final blend), and keep the white level they were first
-//    built with (hdr.c:1240,1575,1672).  The caches are process-global here too.
+//    (AMaZE interpolation / mean23 interpolation / mix / final blend), and keep the white
+//    level they were first built with (hdr.c:1080,1240,1575,1672).  Process-global here too.
 #include "clip.h"
 #include "dualiso.h"
 
@@ -65,13 +63,13 @@ struct HostCurves {              // build_fullres_curve (hdr.c:890-913) + the lo
 };
 
 static std::mutex g_di_mutex;
-static HostLut g_lut_interp, g_lut_mix, g_lut_blend;
+static HostLut g_lut_interp, g_lut_mix, g_lut_blend, g_lut_amaze;
 static HostCurves g_curves;
 static std::vector<double> g_evf;        // raw2evf_base: log2(i) * 32768, i = 0 gives -inf (main.c:136-148)
 
 struct DeviceTables {            // per device copies + the host version they mirror
-    int *raw2ev[3] = { nullptr, nullptr, nullptr }, *ev2raw[3] = { nullptr, nullptr, nullptr };
-    unsigned ver[3] = { 0, 0, 0 };
+    int *raw2ev[4] = { nullptr, nullptr, nullptr, nullptr }, *ev2raw[4] = { nullptr, nullptr, nullptr, nullptr };
+    unsigned ver[4] = { 0, 0, 0, 0 };
     double *fullres = nullptr, *log2sig = nullptr, *evf = nullptr;
     unsigned curves_ver = 0;
 };
@@ -91,7 +89,7 @@ static int upload_lut(DeviceTables &T, int k, const HostLut &H)
 }
 
 // tables for one conversion; caller holds no lock
-static int prepare_tables(int device, int black, int white, DiLuts *L, const double **d_evf)
+static int prepare_tables(int device, int black, int white, int interp_method, DiLuts *L, const double **d_evf)
 {
     std::lock_guard<std::mutex> lk(g_di_mutex);
     DeviceTables &T = g_dev_tables[device];
@@ -105,8 +103,11 @@ static int prepare_tables(int device, int black, int white, DiLuts *L, const dou
     }
     *d_evf = T.evf;
     if (!L) return MLVFS_AMD_OK;
-    HostLut *H[3] = { &g_lut_interp, &g_lut_mix, &g_lut_blend };
-    for (int k = 0; k < 3; k++) {
+    // each consumer function of the reference owns a cache; only the interpolator that runs touches its own
+    HostLut *H[4] = { &g_lut_interp, &g_lut_mix, &g_lut_blend, &g_lut_amaze };
+    const int ik = interp_method == 0 ? 3 : 0;
+    for (int k = 0; k < 4; k++) {
+        if ((k == 0 || k == 3) && k != ik) continue;
         if (H[k]->black != black) host_lut_build(*H[k], black, white);       // white is not part of the key
         int rc = upload_lut(T, k, *H[k]);
         if (rc) return rc;
@@ -134,7 +135,7 @@ static int prepare_tables(int device, int black, int white, DiLuts *L, const dou
         MLV_HIP(hipMemcpy(T.log2sig, g_curves.log2sig.data(), sizeof(double) * N20, hipMemcpyHostToDevice));
         T.curves_ver = g_curves.version;
     }
-    L->interp_raw2ev = T.raw2ev[0]; L->interp_ev2raw = T.ev2raw[0] + 10 * EVR;
+    L->interp_raw2ev = T.raw2ev[ik]; L->interp_ev2raw = T.ev2raw[ik] + 10 * EVR;
     L->mix_raw2ev = T.raw2ev[1];    L->mix_ev2raw = T.ev2raw[1] + 10 * EVR;
     L->blend_raw2ev = T.raw2ev[2];  L->blend_ev2raw = T.ev2raw[2] + 10 * EVR;
     L->fullres_curve = T.fullres;
@@ -157,6 +158,23 @@ struct DiWork {
     }
 };
 static thread_local std::map<int, DiWork> t_work;
+// AMaZE tile planes: zeroed when (re)allocated or when the plane geometry changes, like the reference's calloc per call
+// (for one geometry every tile rewrites exactly what it wrote before, so what must read as zero stays zero)
+struct AmazeWork : DiWork { int w = 0, h = 0; };
+static thread_local std::map<int, AmazeWork> t_amaze;
+static int amaze_scratch_for(int device, int w, int h, hipStream_t s, float **out)
+{
+    AmazeWork &aw = t_amaze[device];
+    const size_t need = amaze_scratch_bytes(w, h);
+    if (need > aw.cap || aw.w != w || aw.h != h) {
+        int rc = aw.ensure(need);
+        if (rc) return rc;
+        MLV_HIP(hipMemsetAsync(aw.base, 0, aw.cap, s));
+        aw.w = w; aw.h = h;
+    }
+    *out = (float *)aw.base;
+    return MLVFS_AMD_OK;
+}
 
 // ------------------------------------------------------------------ host analysis helpers
 static int kth_from_hist(const unsigned *hist, int bins, long long k)      // k-th smallest (0-based) bin index
@@ -262,7 +280,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     if (w <= 0 || H <= 8) return 0;
     const size_t N = (size_t)w * H;
     const double *d_evf = nullptr;
-    int rc = prepare_tables(c->dev->id, 0, 0, nullptr, &d_evf);
+    int rc = prepare_tables(c->dev->id, 0, 0, 1, nullptr, &d_evf);
     if (rc) return rc;
 
     // ---- work buffer layout
@@ -279,6 +297,10 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     // an unknown method only logs in the reference (hdr.c:1518) and leaves the "smoothed" copies unsmoothed
     const bool cs = chroma_smooth_method == 2 || chroma_smooth_method == 3 || chroma_smooth_method == 5;
     const size_t o_full_s = take(cs ? N * 4 : 0), o_half_s = take(cs ? N * 4 : 0), o_cells = take(cs ? N * 3 : 0);
+    const bool amaze = interp_method == 0;
+    const size_t o_cfa = take(amaze ? N * 4 : 0), o_red = take(amaze ? N * 4 : 0), o_green = take(amaze ? N * 4 : 0),
+                 o_blue = take(amaze ? N * 4 : 0), o_gray = take(amaze ? N * 4 : 0), o_dir = take(amaze ? N : 0),
+                 o_sq = take(amaze ? (size_t)H * 8 : 0), o_stats = take(16);
     DiWork &wk = t_work[c->dev->id];
     rc = wk.ensure(off);
     if (rc) return rc;
@@ -314,8 +336,10 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
             if (rc) return rc;
         }
     }
-    if (interp_method != 1) {
-        set_error("cr2hdr20_convert_data: AMaZE edge-directed interpolation is not implemented yet (use --mean23); frame not converted");
+    if (interp_method != 0 && interp_method != 1) { set_error("cr2hdr20_convert_data: unknown interpolation method"); return 0; }
+    if (amaze && ((w & 3) || w < 36 || H < 37)) {
+        // the reference's SSE2 AMaZE leaves green columns unwritten when w % 4 != 0 and mirrors from row/column 35
+        set_error("cr2hdr20_convert_data: the AMaZE interpolation needs a width that is a multiple of 4 and a frame of at least 36x37; frame not converted");
         return 0;
     }
 
@@ -411,7 +435,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     printf("Black delta     : %.2f\n", b / 4);
     const double lowiso_dr = log2(white - black) - dark_noise_ev, highiso_dr = log2(white_bright - black) - bright_noise_ev0;
     printf("Dynamic range   : %.02f (+) %.02f => %.02f EV (in theory)\n", lowiso_dr, highiso_dr, highiso_dr + corr_ev);
-    printf("Interpolation   : mean23\n");
+    printf("Interpolation   : %s\n", amaze ? "amaze-edge" : "mean23");
     if (use_fullres) printf("Full-res reconstruction...\n");
 
     // ---- mix_images preconditions (hdr.c:1539-1556)
@@ -425,7 +449,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     p.max_ev = log2(white / 64 - black / 64);
 
     DiLuts L{};
-    rc = prepare_tables(c->dev->id, black, white, &L, &d_evf);
+    rc = prepare_tables(c->dev->id, black, white, interp_method, &L, &d_evf);
     if (rc) return rc;
     if (chroma_smooth_method) printf("Chroma smoothing...\n");
     if (chroma_smooth_method && !cs) fprintf(stderr, "Unsupported chroma smooth method\nUnsupported chroma smooth method\n");
@@ -436,7 +460,47 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
                 (uint16_t *)(B + o_amap), (uint16_t *)(B + o_aux), (uint16_t *)(B + o_amap2), (int *)(B + o_cells) };
     rc = di_launch_match(img, p, P, stream);
     if (rc) return rc;
-    rc = di_launch_convert(p, L, P, false, img, stream);
+    if (amaze) {
+        // squeezed row map (hdr.c:977-1026): dark rows from the top, bright rows from h/4*2; rows that do not fit are dropped
+        std::vector<int> sq(2 * (size_t)h);
+        for (int y = 0; y < h; y++) { sq[y] = -1; sq[h + y] = 0; }
+        for (int pass = 0; pass < 2; pass++) {
+            int yh = -1;
+            for (int y = 0; y < h; y++) {
+                if (is_bright[y % 4] != pass) continue;
+                if (yh < 0) yh = pass ? h / 4 * 2 + y : y;
+                sq[y] = yh; sq[h + y] = yh;
+                yh++;
+                if (pass && yh >= h) break;
+            }
+        }
+        {   // the two exposures may claim the same squeezed row (odd geometries): the later writer, a bright row, wins
+            std::vector<int> owner((size_t)h, -1);
+            for (int pass = 0; pass < 2; pass++)
+                for (int y = 0; y < h; y++)
+                    if (is_bright[y % 4] == pass && sq[y] >= 0) owner[sq[y]] = y;
+            for (int y = 0; y < h; y++)
+                if (sq[y] >= 0 && owner[sq[y]] != y) sq[y] = -1;
+        }
+        MLV_HIP(hipMemcpyAsync(B + o_sq, sq.data(), sq.size() * 4, hipMemcpyHostToDevice, stream));
+        float *amaze_scratch = nullptr;
+        rc = amaze_scratch_for(c->dev->id, w, h, stream, &amaze_scratch);
+        if (rc) return rc;
+        P.cfa = (float *)(B + o_cfa); P.red = (float *)(B + o_red); P.green = (float *)(B + o_green); P.blue = (float *)(B + o_blue);
+        P.gray_ev = (int *)(B + o_gray); P.dir = (uint8_t *)(B + o_dir);
+        P.sq_dst = (const int *)(B + o_sq); P.sq_row = P.sq_dst + h;
+        P.stats = (unsigned *)(B + o_stats); P.amaze_scratch = amaze_scratch;
+        printf("AMaZE interpolation ...\n");
+        rc = di_launch_amaze_interp(p, L, P, stream);
+        if (rc) return rc;
+        unsigned st[4];
+        MLV_HIP(hipMemcpyAsync(st, P.stats, sizeof st, hipMemcpyDeviceToHost, stream));
+        MLV_HIP(hipStreamSynchronize(stream));               // also keeps `sq` alive until the upload has happened
+        printf("Edge-directed interpolation...\n");
+        printf("Semi-overexposed: %.02f%%\n", st[0] * 100.0 / (st[0] + st[1]));
+        printf("Deep shadows    : %.02f%%\n", st[2] * 100.0 / (st[2] + st[3]));
+    }
+    rc = di_launch_convert(p, L, P, amaze, img, stream);
     if (rc) return rc;
     printf("Noise level     : %.02f (20-bit), ideally %.02f\n", 8.0, 8.0);
     printf("Dynamic range   : %.02f EV (cooked)\n", log2(white - black) - log2(8.0));
@@ -483,11 +547,23 @@ int mlvfs_amd_cr2hdr20_dev(const mlvfs_amd_geom_t *geom, void *d_frame, int inte
                            use_alias_map, chroma_smooth, 0, pick_stream(stream, c), nullptr);
 }
 
+int mlvfs_amd_amaze_demosaic_dev(const float *d_raw, int width, int height, float *d_red, float *d_green, float *d_blue, void *stream)
+{
+    ThreadCtx *c = thread_ctx();
+    if (!c) return MLVFS_AMD_ERR_HIP;
+    if ((width & 3) || width < 36 || height < 36) { set_error("amaze_demosaic: width must be a multiple of 4 and the plane at least 36x36"); return MLVFS_AMD_ERR_ARG; }
+    hipStream_t s = pick_stream(stream, c);
+    float *scratch = nullptr;
+    const int rc = amaze_scratch_for(c->dev->id, width, height, s, &scratch);
+    if (rc) return rc;
+    return amaze_launch(d_raw, width, height, d_red, d_green, d_blue, scratch, s);
+}
+
 // test hook: forget the per-black table caches, as a fresh process would
 void mlvfs_amd_dualiso_reset(void)
 {
     std::lock_guard<std::mutex> lk(g_di_mutex);
-    g_lut_interp.black = g_lut_mix.black = g_lut_blend.black = -1;
+    g_lut_interp.black = g_lut_mix.black = g_lut_blend.black = g_lut_amaze.black = -1;
     g_curves.black = -1;
 }
 

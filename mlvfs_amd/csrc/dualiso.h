@@ -27,7 +27,7 @@ struct DiParams {
 };
 
 struct DiLuts {                // device pointers; *_ev2raw are indexable from -10*32768
-    const int *interp_raw2ev, *interp_ev2raw;
+    const int *interp_raw2ev, *interp_ev2raw;      // the interpolator's cache: mean23's (hdr.c:1240) or AMaZE's (hdr.c:1080)
     const int *mix_raw2ev, *mix_ev2raw;
     const int *blend_raw2ev, *blend_ev2raw;
     const double *fullres_curve;   // [2^20]
@@ -38,7 +38,20 @@ struct DiPlanes {
     uint32_t *raw, *dark, *bright, *fullres, *halfres, *fullres_s, *halfres_s;
     uint16_t *over, *amap, *aux, *amap2;
     int *cells;                // [3][h/2][w/2] work planes of the chroma smoothing
+    // AMaZE path only
+    float *cfa, *red, *green, *blue;   // squeezed Bayer plane and its demosaic, [h][w]
+    int *gray_ev;              // raw2ev of the de-squeezed gray image, [h][w]
+    uint8_t *dir;              // chosen edge direction, [h][w]
+    const int *sq_dst, *sq_row;        // per image row: squeezed row it is written to (-1 none) / looked up at (0 if none)
+    unsigned *stats;           // semi-overexposed, not overexposed, deep shadow, not shadow
+    float *amaze_scratch;
 };
+
+constexpr int AMAZE_TS = 160;                                              // tile side, amaze_demosaic_RT.c:136
+constexpr int AMAZE_TILE_FLOATS = 13 * AMAZE_TS * AMAZE_TS + 13 * AMAZE_TS * AMAZE_TS / 2;
+int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, float *d_scratch, hipStream_t s);
+size_t amaze_scratch_bytes(int w, int h);
+int di_launch_amaze_interp(const DiParams &p, const DiLuts &L, const DiPlanes &P, hipStream_t s);
 
 int di_launch_analyse(const void *d_img, int w, int H, int black, int white, const double *d_evf, unsigned *d_hist,
                       double *d_check, hipStream_t s);

@@ -12,6 +12,8 @@
 //                   (match_exposures, :650-722)
 //   k_di_score      RANSAC-like score of every candidate slope (:752-772)
 //   k_di_match      14 -> 20 bit and per-pixel exposure correction in double (:781-803, :825-837)
+//   k_di_squeeze, k_di_amaze_clamp, k_di_gray, k_di_edge_dir   the AMaZE-based interpolator around k_amaze.hip
+//                   (:954-1173); k_di_interp<true> then interpolates along the chosen edge direction (:1181-1208)
 //   k_di_interp     mean23 + borders + full-res pick + half-res mix + overexposure flag +
 //                   alias-map error, fused per pixel (:1231-1380, :1588-1612, :1404-1418, :1620-1626)
 //   k_di_alias_rank 6th largest of 37 neighbours (:1423-1443)
@@ -181,7 +183,20 @@ __device__ __forceinline__ void di_mix_pixel(const DiParams &p, const DiLuts &L,
     if (amap) amap[i] = (uint16_t)di_alias_err(p, L, b, f, hr);
 }
 
-__global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ raw, DiParams p, DiLuts L,
+// edge directions of the AMaZE-based interpolation, hdr.c:916-938: {ack, a, b, bck} x {x, y}; y is multiplied by s
+__constant__ signed char k_edge_dirs[11][8] = {
+    { -4, 2, -2, 1, 4, -2, 6, -3 }, { -3, 2, -1, 1, 3, -2, 4, -3 }, { -2, 2, -1, 1, 2, -2, 3, -3 }, { -1, 2, -1, 1, 1, -2, 2, -3 },
+    { -1, 2, 0, 1, 1, -2, 1, -3 },  { 0, 2, 0, 1, 0, -2, 0, -3 },   { 1, 2, 0, 1, -1, -2, -1, -3 }, { 1, 2, 1, 1, -1, -2, -2, -3 },
+    { 2, 2, 1, 1, -2, -2, -3, -3 }, { 3, 2, 1, 1, -3, -2, -4, -3 }, { 4, 2, 2, 1, -4, -2, -6, -3 } };
+
+struct DiAmazeIn {              // inputs of the edge-directed interpolation (null planes = mean23)
+    const float *red, *green, *blue;
+    const uint8_t *dir;
+    const int *sq_row;
+};
+
+template <bool AMAZE>
+__global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ raw, DiParams p, DiLuts L, DiAmazeIn A,
                                                    uint32_t *__restrict__ dark, uint32_t *__restrict__ bright,
                                                    uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
                                                    uint16_t *__restrict__ over, uint16_t *__restrict__ amap)
@@ -199,7 +214,24 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
         else if (y >= 2 && x >= w - 3) { interp = R(x - 2, y - 2); native = R(x - 2, y); }
         else if (y < 3) { interp = R(x, y + 2); native = R(x, y); }
         else if (y >= h - 4) { interp = R(x, y - 2); native = R(x, y); }
-        else {
+        else if (AMAZE) {                                         // hdr.c:940-952, 1181-1208
+            const int s = (di_bright(p, y) == di_bright(p, y + 1)) ? -1 : 1;
+            const float *plane = (y & 1) == 0 ? ((x & 1) == 0 ? A.red : A.green) : ((x & 1) == 0 ? A.green : A.blue);
+            const int d = A.dir[i];
+            const int dd[3] = { d, min(d + 1, 10), max(d - 1, 0) };
+            int pi[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const signed char *e = k_edge_dirs[dd[k]];
+                int pa = (int)plane[(size_t)A.sq_row[y + e[3] * s] * w + x + e[2]];
+                int pb = (int)plane[(size_t)A.sq_row[y + e[5] * s] * w + x + e[4]];
+                pa = pa < 0 ? 0 : (pa > 0xFFFFF ? 0xFFFFF : pa);
+                pb = pb < 0 ? 0 : (pb > 0xFFFFF ? 0xFFFFF : pb);
+                pi[k] = (ir2e[pa] * 2 + ir2e[pb]) / 3;
+            }
+            interp = ie2r[(2 * pi[0] + pi[1] + pi[2]) / 4];
+            native = R(x, y);
+        } else {
             const int wl = !br ? p.white_darkened : p.white20;
             const int wev = ir2e[wl];
             const int s = (di_bright(p, y) == di_bright(p, y + 1)) ? -1 : 1;
@@ -222,14 +254,89 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
     }
 }
 
-// the same mix for dark/bright planes produced by another interpolator (AMaZE)
-__global__ __launch_bounds__(256) void k_di_mix(const uint32_t *__restrict__ dark, const uint32_t *__restrict__ bright, DiParams p,
-                                                DiLuts L, uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
-                                                uint16_t *__restrict__ over, uint16_t *__restrict__ amap)
+// ------------------------------------------------------------------ AMaZE-based interpolation, hdr.c:954-1229
+// squeeze: rows of one exposure become adjacent, greens halved around black (hdr.c:977-1026)
+__global__ __launch_bounds__(256) void k_di_squeeze(const uint32_t *__restrict__ raw, DiParams p, const int *__restrict__ sq_dst,
+                                                    float *__restrict__ cfa)
 {
     const size_t n = (size_t)p.w * p.h;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        di_mix_pixel(p, L, i, di_bright(p, (int)(i / p.w)), (int)bright[i], (int)dark[i], fullres, halfres, over, amap);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % p.w), y = (int)(i / p.w);
+        const int yh = sq_dst[y];
+        if (yh < 0) continue;
+        int v = (int)raw[i];
+        if ((x & 1) != (y & 1)) v = (v - p.black20) / 2 + p.black20;
+        cfa[(size_t)yh * p.w + x] = (float)v;
+    }
+}
+
+// undo the green scaling, clamp (hdr.c:1041-1050), in place on the squeezed planes
+__global__ __launch_bounds__(256) void k_di_amaze_clamp(float *__restrict__ red, float *__restrict__ green, float *__restrict__ blue,
+                                                        size_t n, int black)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float fb = (float)black, hi = 1048575.0f;
+        const float g = (green[i] - fb) * 2.0f + fb, r = red[i], b = blue[i];
+        green[i] = g < hi ? (g > 0.0f ? g : 0.0f) : hi;
+        red[i] = r < hi ? (r > 0.0f ? r : 0.0f) : hi;
+        blue[i] = b < hi ? (b > 0.0f ? b : 0.0f) : hi;
+    }
+}
+
+// de-squeezed gray image in EV (hdr.c:1055-1059 + the raw2ev lookups of :1157-1168)
+__global__ __launch_bounds__(256) void k_di_gray(const float *__restrict__ red, const float *__restrict__ green,
+                                                 const float *__restrict__ blue, DiParams p, const int *__restrict__ sq_row,
+                                                 const int *__restrict__ r2e, int *__restrict__ gray_ev)
+{
+    const size_t n = (size_t)p.w * p.h;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % p.w), y = (int)(i / p.w);
+        const size_t o = (size_t)sq_row[y] * p.w + x;
+        const unsigned gray = (unsigned)(green[o] / 2 + red[o] / 4 + blue[o] / 4);
+        gray_ev[i] = r2e[gray];
+    }
+}
+
+// best of 11 edge directions where the interpolation has to be good (hdr.c:1096-1173)
+__global__ __launch_bounds__(256) void k_di_edge_dir(const uint32_t *__restrict__ raw, const int *__restrict__ gray_ev, DiParams p,
+                                                     const double *__restrict__ fullres_curve, uint8_t *__restrict__ dir,
+                                                     unsigned *__restrict__ stats)
+{
+    __shared__ unsigned s_stats[4];
+    if (threadIdx.x < 4) s_stats[threadIdx.x] = 0;
+    __syncthreads();
+    const int w = p.w, h = p.h;
+    const size_t n = (size_t)w * h;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w), y = (int)(i / w);
+        int best = 5;
+        if (x >= 5 && x < w - 5 && y >= 5 && y < h - 5) {
+            const int v = (int)raw[i];
+            bool search;
+            if (!di_bright(p, y)) { search = !(fullres_curve[v] > 0.8); atomicAdd(&s_stats[search ? 2 : 3], 1u); }
+            else { search = !(v < p.white_darkened); atomicAdd(&s_stats[search ? 0 : 1], 1u); }
+            if (search) {
+                const int s = (di_bright(p, y) == di_bright(p, y + 1)) ? -1 : 1;
+                int e_best = 0x7FFFFFFF;
+                for (int d = 0; d < 11; d++) {
+                    const signed char *e = k_edge_dirs[d];
+                    const int *r1 = gray_ev + (size_t)(y + e[1] * s) * w + x + e[0], *r2 = gray_ev + (size_t)(y + e[3] * s) * w + x + e[2];
+                    const int *r3 = gray_ev + (size_t)(y + e[5] * s) * w + x + e[4], *r4 = gray_ev + (size_t)(y + e[7] * s) * w + x + e[6];
+                    int err = 0;
+#pragma unroll
+                    for (int j = -5; j <= 5; j++) {
+                        const int p1 = r1[j], p2 = r2[j], p3 = r3[j], p4 = r4[j];
+                        err += abs(p1 - p2) + abs(p2 - p3) + abs(p3 - p4);
+                    }
+                    err += abs(d - 5) * DI_EVR / 8;
+                    if (err < e_best) { e_best = err; best = d; }
+                }
+            }
+        }
+        dir[i] = (uint8_t)best;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && s_stats[threadIdx.x]) atomicAdd(&stats[threadIdx.x], s_stats[threadIdx.x]);
 }
 
 // alias error from the chroma-smoothed planes (hdr.c:1620: build_alias_map gets fullres_smooth / halfres_smooth)
@@ -457,16 +564,34 @@ int di_launch_match(const void *d_img, const DiParams &p, const DiPlanes &P, hip
     return MLVFS_AMD_OK;
 }
 
-// interp_done: dark/bright already hold the interpolated exposures (AMaZE path); otherwise mean23 runs here
-int di_launch_convert(const DiParams &p, const DiLuts &L, const DiPlanes &P, bool interp_done, void *d_out, hipStream_t s)
+// squeeze -> AMaZE -> clamp -> gray -> edge directions; the planes feed k_di_interp<true>
+int di_launch_amaze_interp(const DiParams &p, const DiLuts &L, const DiPlanes &P, hipStream_t s)
+{
+    const size_t n = (size_t)p.w * p.h;
+    MLV_HIP(hipMemsetAsync(P.cfa, 0, n * sizeof(float), s));          // rows no exposure lands on stay zero (hdr.c:971)
+    MLV_HIP(hipMemsetAsync(P.stats, 0, 4 * sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_di_squeeze, flat_grid(n), dim3(256), 0, s, P.raw, p, P.sq_dst, P.cfa);
+    int rc = amaze_launch(P.cfa, p.w, p.h, P.red, P.green, P.blue, P.amaze_scratch, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_di_amaze_clamp, flat_grid(n), dim3(256), 0, s, P.red, P.green, P.blue, n, p.black20);
+    hipLaunchKernelGGL(k_di_gray, flat_grid(n), dim3(256), 0, s, P.red, P.green, P.blue, p, P.sq_row, L.interp_raw2ev, P.gray_ev);
+    hipLaunchKernelGGL(k_di_edge_dir, flat_grid(n), dim3(256), 0, s, P.raw, P.gray_ev, p, L.fullres_curve, P.dir, P.stats);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+// amaze: the planes of di_launch_amaze_interp are ready and the edge-directed interpolation replaces mean23
+int di_launch_convert(const DiParams &p, const DiLuts &L, const DiPlanes &P, bool amaze, void *d_out, hipStream_t s)
 {
     const size_t n = (size_t)p.w * p.h;
     uint16_t *amap_fused = (p.use_alias_map && !p.chroma_smooth) ? P.amap : nullptr;
-    if (interp_done)
-        hipLaunchKernelGGL(k_di_mix, flat_grid(n), dim3(256), 0, s, P.dark, P.bright, p, L, P.fullres, P.halfres, P.over, amap_fused);
+    const DiAmazeIn A{ P.red, P.green, P.blue, P.dir, P.sq_row };
+    if (amaze)
+        hipLaunchKernelGGL(k_di_interp<true>, flat_grid(n), dim3(256), 0, s, P.raw, p, L, A, P.dark, P.bright, P.fullres, P.halfres,
+                           P.over, amap_fused);
     else
-        hipLaunchKernelGGL(k_di_interp, flat_grid(n), dim3(256), 0, s, P.raw, p, L, P.dark, P.bright, P.fullres, P.halfres, P.over,
-                           amap_fused);
+        hipLaunchKernelGGL(k_di_interp<false>, flat_grid(n), dim3(256), 0, s, P.raw, p, L, A, P.dark, P.bright, P.fullres, P.halfres,
+                           P.over, amap_fused);
     MLV_HIP(hipGetLastError());
     const uint32_t *fullres_s = P.fullres, *halfres_s = P.halfres;
     if (p.chroma_smooth) {                                             // hdr.c:1612-1619

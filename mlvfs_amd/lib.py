@@ -41,7 +41,7 @@ DEVICE_SYMBOLS = [
     "mlvfs_amd_fix_pixels_dev", "mlvfs_amd_stripes_count_dev", "mlvfs_amd_stripes_hist_dev",
     "mlvfs_amd_stripes_solve", "mlvfs_amd_stripes_compute_dev", "mlvfs_amd_stripes_apply_dev",
     "mlvfs_amd_rand_stream", "mlvfs_amd_process_frames_dev", "mlvfs_amd_hdr_preview_dev",
-    "mlvfs_amd_cr2hdr20_dev", "mlvfs_amd_dualiso_reset",
+    "mlvfs_amd_cr2hdr20_dev", "mlvfs_amd_dualiso_reset", "mlvfs_amd_amaze_demosaic_dev",
     "mlvfs_amd_timer_begin", "mlvfs_amd_timer_end", "mlvfs_amd_selftest_host",
 ]
 
@@ -132,6 +132,7 @@ def load() -> C.CDLL:
     sig("mlvfs_amd_hdr_preview_dev", i, [gp, vp, sz, vp])
     sig("mlvfs_amd_cr2hdr20_dev", i, [gp, vp, i, i, i, i, vp])
     sig("mlvfs_amd_dualiso_reset", None, [])
+    sig("mlvfs_amd_amaze_demosaic_dev", i, [vp, i, i, vp, vp, vp, vp])
     sig("mlvfs_amd_timer_begin", i, [i])
     sig("mlvfs_amd_timer_end", i, [vp, i])
     sig("mlvfs_amd_selftest_host", i, [])

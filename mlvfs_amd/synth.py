@@ -190,3 +190,17 @@ def pack14(frame):
         ((g & 0x3) << 14) | hh,
     ], 1).reshape(-1)
     return words
+
+
+def amaze_plane(w: int, h: int, seed: int = 1) -> np.ndarray:
+    """Float RGGB plane in the scale the dual-ISO path hands to AMaZE (20-bit values, i.e. 0..16 after the
+    tile loader's /65535): smooth gradients, a checker, clipped patches (> 0.8 * 65535 takes the
+    Hamilton-Adams branches) and one-pixel textures (Nyquist branches)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = 30000 + 25000 * np.sin(xx * 0.05) * np.cos(yy * 0.07) + 8000 * ((xx // 16 + yy // 16) & 1)
+    raw = base * np.array([[0.6, 1.0], [1.0, 0.5]])[yy % 2, xx % 2] + rng.integers(-300, 300, (h, w))
+    raw[10:20, 10:30] = 70000
+    raw[h // 2:h // 2 + 12, w // 2:w // 2 + 40:2] = 500
+    raw[h // 3:h // 3 + 9:2, 8:w - 8] += 9000
+    return raw.clip(0, 0xFFFFF).astype(np.float32)

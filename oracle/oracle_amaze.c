@@ -68,10 +68,13 @@ static inline float quarter_exp(float d)
     return u.f;
 }
 
+/* The members follow the order of the reference's block (amaze_demosaic_RT.c:248-273) where it matters: its planes
+ * are 64 bytes apart, and two fills of the tile loader run past their plane -- a bottom fill that starts less than
+ * 16 rows before row 160 continues from cfa into pmwt and from rgbgreen into delhvsqsum. */
 typedef struct {
-    float cfa[TT], green[TT], delsq[TT], dw0[TT], dw1[TT], vcd[TT], hcd[TT], vcdalt[TT], hcdalt[TT], cdsq[TT], dgv[TT], dgh[TT];
-    float hvwt[HALF], dgrb0[HALF], dgrb1[HALF], delp[HALF], delm[HALF], rbint[HALF], curv_h[HALF], curv_v[HALF], sqm[HALF],
-        sqp[HALF], pmwt[HALF], rbm[HALF], rbp[HALF];
+    float green[TT], gap0[16], delsq[TT], dw0[TT], dw1[TT], vcd[TT], hcd[TT], vcdalt[TT], hcdalt[TT], cdsq[TT], dgv[TT], dgh[TT];
+    float hvwt[HALF], dgrb0[HALF], dgrb1[HALF], delp[HALF], delm[HALF], rbint[HALF], curv_h[HALF], curv_v[HALF], sqm[HALF], sqp[HALF];
+    float cfa[TT], gap1[16], pmwt[HALF], rbm[HALF], rbp[HALF];
     unsigned char nyq[HALF];
     float slack[64];               /* vector loops may touch a few floats past the last array */
 } tile_t;

@@ -57,12 +57,63 @@ def test_cr2hdr20_gbrg_and_not_dual_iso(gpu, oracle):
     assert r == 0 and np.array_equal(got, n) and lv == (BLACK, WHITE)
 
 
-def test_cr2hdr20_unbuilt_configurations_fail_loudly(gpu):
-    f = synth.dual_iso_frame(64, 48)
-    for kw in (dict(interp=0),):
-        r, got, lv = convert(gpu, f, **kw)
-        assert r == 0 and np.array_equal(got, f) and lv == (BLACK, WHITE)
-        assert b"not implemented" in gpu.mlvfs_amd_last_error()
+def test_cr2hdr20_amaze_refuses_widths_the_reference_cannot_handle(gpu):
+    """w % 4 != 0 leaves part of the reference's green plane unwritten (SSE2 store loop, amaze_demosaic_RT.c:1459):
+    no defined result to match, so the frame is reported and left alone."""
+    f = synth.dual_iso_frame(66, 48)
+    r, got, lv = convert(gpu, f, interp=0)
+    assert r == 0 and np.array_equal(got, f) and lv == (BLACK, WHITE)
+    assert b"multiple of 4" in gpu.mlvfs_amd_last_error()
+
+
+def amaze_gpu(gpu, raw):
+    import torch
+    h, w = raw.shape
+    d_raw = torch.from_numpy(raw).cuda()
+    out = [torch.full((h, w), float("nan"), dtype=torch.float32, device="cuda") for _ in range(3)]
+    rc = gpu.mlvfs_amd_amaze_demosaic_dev(C.c_void_p(d_raw.data_ptr()), w, h, *[C.c_void_p(o.data_ptr()) for o in out], None)
+    assert rc == 0, gpu.mlvfs_amd_last_error()
+    torch.cuda.synchronize()
+    return [o.cpu().numpy() for o in out]
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (136, 72), (160, 160), (300, 200), (128, 130), (416, 264), (1024, 700)])
+def test_amaze_planes_bit_identical(gpu, oracle, w, h):
+    """k_amaze.hip against the oracle's restatement of the SSE2 reference: all three float planes, bit for bit.
+    Run twice, smaller plane after a larger one, so that stale tile planes of an earlier call would show."""
+    for (ww, hh, seed) in ((w, h, 1), (max(w - 28, 36), max(h - 9, 36), 2)):
+        raw = synth.amaze_plane(ww, hh, seed)
+        for got, want in zip(amaze_gpu(gpu, raw), oracle.amaze_demosaic(raw)):
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("fullres,alias,cs", [(1, 1, 0), (0, 1, 0), (1, 0, 0), (1, 1, 5)])
+@pytest.mark.parametrize("w,h", [(64, 48), (136, 72), (416, 264), (640, 400)])
+def test_cr2hdr20_amaze_edge(gpu, oracle, w, h, fullres, alias, cs):
+    """BASELINE.json config 4 (--amaze-edge), hdr.c:954-1229."""
+    f = synth.dual_iso_frame(w, h)
+    r0, want, lv0 = oracle.cr2hdr20(f, BLACK, WHITE, 0, fullres, alias, cs)
+    r1, got, lv1 = convert(gpu, f, 0, fullres, alias, cs)
+    assert r0 == r1 == 1 and lv0 == lv1
+    check_close(got, want)
+
+
+def test_cr2hdr20_amaze_gbrg(gpu, oracle):
+    f = synth.dual_iso_frame(136, 74)[1:73].copy()
+    r0, want, _ = oracle.cr2hdr20(f, BLACK, WHITE, 0, 1, 1, 0)
+    r1, got, _ = convert(gpu, f, 0)
+    assert r0 == r1 == 1
+    check_close(got, want)
+
+
+def test_cr2hdr20_amaze_full_size(gpu, oracle):
+    """BASELINE.json config 4 at 3584x1320."""
+    f = synth.dual_iso_frame(3584, 1320)
+    r0, want, _ = oracle.cr2hdr20(f, BLACK, WHITE, 0, 1, 1, 0)
+    r1, got, _ = convert(gpu, f, 0)
+    assert r0 == r1 == 1
+    check_close(got, want)
+    assert np.array_equal(got, want)          # in practice bit-identical; check_close states the tolerance
 
 
 @pytest.mark.parametrize("fullres", [1, 0])

@@ -199,24 +199,10 @@ def test_cr2hdr20_chroma_smooth(oracle, reference, w, h, cs, fullres):
 
 
 # ------------------------------------------------------------------ AMaZE (SSE2 variant) and the edge-directed dual-ISO path
-def amaze_plane(w, h, seed=1):
-    """Bayer plane in the dual-ISO caller's scale (20-bit values, i.e. 0..16 after the /65535 of the tile loader):
-    smooth gradients, a checker, clipped patches (> 0.8 * 65535 takes the Hamilton-Adams branches) and a
-    one-pixel texture (Nyquist branches)."""
-    rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:h, 0:w]
-    base = 30000 + 25000 * np.sin(xx * 0.05) * np.cos(yy * 0.07) + 8000 * ((xx // 16 + yy // 16) & 1)
-    raw = base * np.array([[0.6, 1.0], [1.0, 0.5]])[yy % 2, xx % 2] + rng.integers(-300, 300, (h, w))
-    raw[10:20, 10:30] = 70000
-    raw[h // 2:h // 2 + 12, w // 2:w // 2 + 40:2] = 500
-    raw[h // 3:h // 3 + 9:2, 8:w - 8] += 9000
-    return raw.clip(0, 0xFFFFF).astype(np.float32)
-
-
 @pytest.mark.parametrize("w,h", [(64, 48), (136, 72), (160, 160), (300, 200), (128, 130), (416, 264)])
 def test_amaze_planes_bit_identical(oracle, reference, w, h):
     """amaze_demosaic_RT.c:113-1487 as built on x86-64 (SSE2 passes): all three float planes, bit for bit."""
-    raw = amaze_plane(w, h)
+    raw = synth.amaze_plane(w, h)
     for a, b in zip(oracle.amaze_demosaic(raw), reference.amaze_demosaic(raw)):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
