@@ -122,3 +122,80 @@ def test_hip_reproduces_full_size_hashes(gpu):
     assert fnv1a(out[0]) == full["B_cs5_badpix_stripes_frame0"]
     assert fnv1a(out[1]) == full["B_cs5_badpix_stripes_frame1"]
     s.close()
+
+
+# ------------------------------------------------------------------ full dual-ISO conversion and AMaZE (BASELINE.json config 4)
+DI = np.load(os.path.join(GOLD, "dualiso_136x72.npz"))
+DI_KEYS = [k for k in DI.files if k.startswith("i")]
+
+
+def _di_args(key):
+    p = key.split("_")
+    interp, fullres, alias, cs = int(p[0][1:]), int(p[1][1:]), int(p[2][1:]), int(p[3][2:])
+    gbrg = key.endswith("_gbrg")
+    f = synth.dual_iso_frame(136, 74)[1:73].copy() if gbrg else synth.dual_iso_frame(136, 72)
+    return f, interp, fullres, alias, cs
+
+
+@pytest.mark.parametrize("key", DI_KEYS)
+def test_oracle_reproduces_dual_iso_vectors(oracle, key):
+    """Every vector was made by the reference in a fresh process: reset=True gives the oracle the same table state."""
+    f, interp, fullres, alias, cs = _di_args(key)
+    r, img, lv = oracle.cr2hdr20(f, BLACK, WHITE, interp, fullres, alias, cs, reset=True)
+    assert r == 1 and lv == (BLACK * 4, WHITE * 4) and np.array_equal(img, DI[key])
+
+
+def test_oracle_reproduces_amaze_vectors(oracle):
+    for n, pl in zip(("amaze_red", "amaze_green", "amaze_blue"), oracle.amaze_demosaic(DI["amaze_raw"])):
+        assert np.array_equal(pl.view(np.uint32), DI[n].view(np.uint32))
+    for n, pl in zip("rgb", oracle.amaze_demosaic(synth.amaze_plane(416, 264, 1))):
+        assert fnv1a(pl.view(np.uint32)) == META["full_size"]["amaze_416x264_" + n]
+    f = synth.dual_iso_frame(416, 264)
+    assert fnv1a(oracle.cr2hdr20(f, BLACK, WHITE, 0, 1, 1, 0, reset=True)[1]) == META["full_size"]["dualiso_416x264_i0_f1_a1_cs0"]
+    assert fnv1a(oracle.cr2hdr20(f, BLACK, WHITE, 1, 1, 1, 0, reset=True)[1]) == META["full_size"]["dualiso_416x264_i1_f1_a1_cs0"]
+
+
+def _gpu_convert(gpu, f, interp, fullres, alias, cs):
+    from mlvfs_amd import abi, lib
+    h, w = f.shape
+    gpu.mlvfs_amd_dualiso_reset()
+    fh = abi.make_frame_headers(w, h, black=BLACK, white=WHITE)
+    out = f.copy()
+    r = gpu.cr2hdr20_convert_data(C.byref(fh), lib.ptr(out), interp, fullres, alias, cs, 0)
+    return r, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", DI_KEYS)
+def test_hip_reproduces_dual_iso_vectors(gpu, key):
+    """Bit-identical in practice; the stated tolerance of the path is 1 LSB on 0.01 % of the pixels (device cos())."""
+    f, interp, fullres, alias, cs = _di_args(key)
+    r, img = _gpu_convert(gpu, f, interp, fullres, alias, cs)
+    assert r == 1 and np.array_equal(img, DI[key])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_dual_iso_full_size_hashes(gpu):
+    full = META["full_size"]
+    for (w, h, interp, cs) in ((416, 264, 0, 0), (416, 264, 1, 0), (640, 400, 0, 5), (3584, 1320, 0, 0), (3584, 1320, 1, 0), (3584, 1320, 0, 5)):
+        r, img = _gpu_convert(gpu, synth.dual_iso_frame(w, h), interp, 1, 1, cs)
+        assert r == 1 and fnv1a(img) == full["dualiso_%dx%d_i%d_f1_a1_cs%d" % (w, h, interp, cs)]
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_amaze_vectors(gpu):
+    import torch
+
+    def run(raw):
+        h, w = raw.shape
+        d = torch.from_numpy(raw).cuda()
+        out = [torch.zeros((h, w), dtype=torch.float32, device="cuda") for _ in range(3)]
+        assert gpu.mlvfs_amd_amaze_demosaic_dev(C.c_void_p(d.data_ptr()), w, h, *[C.c_void_p(o.data_ptr()) for o in out], None) == 0
+        torch.cuda.synchronize()
+        return [o.cpu().numpy() for o in out]
+
+    for n, pl in zip(("amaze_red", "amaze_green", "amaze_blue"), run(DI["amaze_raw"])):
+        assert np.array_equal(pl.view(np.uint32), DI[n].view(np.uint32))
+    for (w, h) in ((416, 264), (1024, 700)):
+        for n, pl in zip("rgb", run(synth.amaze_plane(w, h, 1))):
+            assert fnv1a(pl.view(np.uint32)) == META["full_size"]["amaze_%dx%d_%s" % (w, h, n)]
