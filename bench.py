@@ -95,6 +95,12 @@ def main():
     ap.add_argument("--cs", type=int, default=5)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the result: everything else that writes to fd 1 while the bench runs (the bad-pixel
+    # list that fix_bad_pixels prints like the reference, cs.c:307-311, through C stdio) goes to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from mlvfs_amd import dist as mdist
@@ -211,7 +217,12 @@ def main():
                 result["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 result["cpu_baseline"] = {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(result))
+    sys.stdout.flush()
+    C.CDLL(None).fflush(None)
+    os.dup2(real_stdout, 1)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+        os.dup2(2, 1)                              # whatever is still buffered in C stdio at exit stays off stdout
     if world > 1:
         dist.destroy_process_group()
     s.close()

@@ -33,9 +33,15 @@
 #include "clip.h"
 #include <cstdlib>
 
+// two 16-bit lanes per register: v_pk_min_i16 / v_pk_max_i16 issue at the rate of v_min_i32 (tools/valu_rate.hip)
+typedef short mlv_pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int mlv_min_(int a, int b) { return min(a, b); }
+__device__ __forceinline__ int mlv_max_(int a, int b) { return max(a, b); }
+__device__ __forceinline__ mlv_pk16 mlv_min_(mlv_pk16 a, mlv_pk16 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ mlv_pk16 mlv_max_(mlv_pk16 a, mlv_pk16 b) { return __builtin_elementwise_max(a, b); }
 #define MLV_NET_FN __device__ __forceinline__
-#define mlv_mn(a, b) min((a), (b))
-#define mlv_mx(a, b) max((a), (b))
+#define mlv_mn(a, b) mlv_min_((a), (b))
+#define mlv_mx(a, b) mlv_max_((a), (b))
 #include "median_nets.h"
 
 namespace mlv {
@@ -357,6 +363,56 @@ __device__ __forceinline__ void strip_median25(const int (*plane)[PW], int row_t
     }
 }
 
+// 5x5 on both colour-difference planes at once: (dr, db) of a cell, taken relative to the strip's own centre cell
+// (saturating subtract) and saturated to a pair of 16-bit lanes (v_cvt_pk_i16_i32); the same sorted-column / merge /
+// rank-window networks then run on packed min/max.  Both saturations are monotone, so the packed median is the
+// saturated, shifted true median: exact unless it sits ON a 16-bit bound, which the caller treats as "unknown"
+// (returns true) and settles with the 32-bit networks.  The local reference keeps real footage (R and B one or two
+// EV below G before white balance) inside the 16-bit window; only strips across a hard colour edge fall back.
+__device__ __forceinline__ bool strip_median25_packed(const int (*pr_)[PW], const int (*pb_)[PW], int row_top, int col_left,
+                                                      int (&mr)[STRIP], int (&mb)[STRIP])
+{
+    const int ref_r = pr_[row_top + 2][col_left + 2], ref_b = pb_[row_top + 2][col_left + 2];
+    auto pack = [&](int r, int b) {
+        return __builtin_amdgcn_cvt_pk_i16(__builtin_elementwise_sub_sat(r, ref_r), __builtin_elementwise_sub_sat(b, ref_b));
+    };
+    mlv_pk16 col[8][5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int4 a = *(const int4 *)&pr_[row_top + r][col_left + 4 * q];
+            const int4 b = *(const int4 *)&pb_[row_top + r][col_left + 4 * q];
+            col[4 * q + 0][r] = pack(a.x, b.x);
+            col[4 * q + 1][r] = pack(a.y, b.y);
+            col[4 * q + 2][r] = pack(a.z, b.z);
+            col[4 * q + 3][r] = pack(a.w, b.w);
+        }
+    }
+    mlv_pk16 srt[8][5];
+#pragma unroll
+    for (int c = 0; c < 8; c++) mlv_sort5(col[c], srt[c]);
+    mlv_pk16 pr[4][10];
+#pragma unroll
+    for (int p = 0; p < 4; p++) mlv_merge55(srt[2 * p], srt[2 * p + 1], pr[p]);
+    mlv_pk16 qd[3][6];
+#pragma unroll
+    for (int q = 0; q < 3; q++) mlv_quad_mid6(pr[q], pr[q + 1], qd[q]);
+    bool unknown = false;
+#pragma unroll
+    for (int c = 0; c < STRIP; c++) {
+        const int x = c + 2;
+        mlv_pk16 o[1];
+        if (x % 2 == 0) mlv_final6of11(qd[(x - 2) / 2], srt[x + 2], o);
+        else            mlv_final6of11(qd[(x - 1) / 2], srt[x - 2], o);
+        const int vr = (int)o[0].x, vb = (int)o[0].y;
+        unknown |= (unsigned)(vr + 32767) >= 65534u || (unsigned)(vb + 32767) >= 65534u;   // -32768 or 32767
+        mr[c] = vr + ref_r;
+        mb[c] = vb + ref_b;
+    }
+    return unknown;
+}
+
 // 3x3: sorted columns of 3, classic max-of-mins / med-of-meds / min-of-maxes
 __device__ __forceinline__ void strip_median9(const int (*plane)[PW], int row_top, int col_left, int (&med)[STRIP])
 {
@@ -521,8 +577,14 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         if (METHOD != 0 && y >= 4 && y < a.h - 5 && !(a.dbg & 2)) {
             int mr[STRIP], mb[STRIP];
             if (METHOD == 5) {
-                strip_median25(sm.dr, j, STRIP * k, mr);
-                strip_median25(sm.db, j, STRIP * k, mb);
+                if (__any(strip_median25_packed(sm.dr, sm.db, j, STRIP * k, mr, mb))) {      // wave-uniform, rare
+                    // opaque zero: without it the compiler shares the plane loads of both paths and keeps all 80
+                    // 32-bit values alive across the packed networks (spills)
+                    int z = 0;
+                    asm volatile("" : "+s"(z));
+                    strip_median25(sm.dr, j + z, STRIP * k, mr);
+                    strip_median25(sm.db, j + z, STRIP * k, mb);
+                }
             } else if (METHOD == 3) {
                 strip_median9(sm.dr, j + 1, STRIP * k + 1, mr);
                 strip_median9(sm.db, j + 1, STRIP * k + 1, mb);

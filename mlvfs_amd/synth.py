@@ -192,6 +192,24 @@ def pack14(frame):
     return words
 
 
+def colour_cast_frame(w: int, h: int, seed: int = 11, black: int = BLACK) -> np.ndarray:
+    """What real footage looks like before white balance: R and B one to two EV below G (CFA gains .45/1/1/.3), a scene
+    made of flat patches whose colour balance jumps by several EV at the patch borders, noise, a few clipped and a few
+    black pixels.  Exercises the packed 16-bit medians of k_frame: inside a patch the colour differences stay within
+    the 16-bit window around the local reference, across a border they leave it (32-bit fallback)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    patch = ((xx // 24) * 7 + (yy // 20) * 13) % 5
+    lum = 600 + 2500 * ((xx // 24 + yy // 20) % 3) + 3000 * np.sin(xx * 0.01) ** 2
+    gains = np.array([[[0.45, 1.0], [1.0, 0.30]], [[1.6, 1.0], [1.0, 0.08]], [[0.06, 1.0], [1.0, 1.9]],
+                      [[0.9, 1.0], [1.0, 0.9]], [[0.2, 1.0], [1.0, 0.2]]])
+    v = lum * gains[patch, yy % 2, xx % 2] + rng.integers(-40, 41, (h, w))
+    v = v + black
+    v[rng.random((h, w)) < 0.002] = 16383
+    v[rng.random((h, w)) < 0.002] = black
+    return np.clip(v, 0, 16383).astype(np.uint16)
+
+
 def amaze_plane(w: int, h: int, seed: int = 1) -> np.ndarray:
     """Float RGGB plane in the scale the dual-ISO path hands to AMaZE (20-bit values, i.e. 0..16 after the
     tile loader's /65535): smooth gradients, a checker, clipped patches (> 0.8 * 65535 takes the

@@ -68,6 +68,19 @@ def test_chroma_smooth_dropin(gpu, oracle, w, h, kind, method):
     assert (want != f).any()
 
 
+@pytest.mark.parametrize("method", [2, 3, 5])
+@pytest.mark.parametrize("w,h", [(64, 48), (416, 264), (3584, 1320)])
+def test_chroma_smooth_colour_cast(gpu, oracle, w, h, method):
+    """Footage-like colour balance (R, B well below G) with hard colour edges: the packed 16-bit medians of the 5x5
+    kernel work relative to a local reference and fall back to 32 bits across the edges; both must be exact."""
+    f = synth.colour_cast_frame(w, h)
+    want = oracle.chroma_smooth(f, BLACK, method)
+    got = f.copy()
+    gpu.chroma_smooth(C.byref(fh_for(w, h)), lib.ptr(got), method)
+    assert np.array_equal(got, want), f"{(got != want).sum()} px differ"
+    assert (want != f).mean() > 0.2
+
+
 def test_chroma_smooth_bad_method_is_noop(gpu):
     f = frame_of("normal", 64, 48)
     got = f.copy()

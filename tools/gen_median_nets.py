@@ -106,18 +106,19 @@ class Net:
         k = 0
         params = []
         for gname, cnt in in_groups:
-            params.append(f"const int (&{gname})[{cnt}]")
+            params.append(f"const T (&{gname})[{cnt}]")
             for j in range(cnt):
                 names[k] = f"{gname}[{j}]"
                 k += 1
         assert k == self.n_in
-        lines = [f"// {nops} min/max ops", f"MLV_NET_FN void {name}({', '.join(params)}, int (&{out_name})[{len(outs)}])", "{"]
+        lines = [f"// {nops} min/max ops", "template <class T>",
+                 f"MLV_NET_FN void {name}({', '.join(params)}, T (&{out_name})[{len(outs)}])", "{"]
         for idx, (op, a, b) in enumerate(self.nodes):
             nid = self.n_in + idx
             if nid not in need:
                 continue
             names[nid] = f"t{idx}"
-            lines.append(f"    const int t{idx} = mlv_{op}({names[a]}, {names[b]});")
+            lines.append(f"    const T t{idx} = mlv_{op}({names[a]}, {names[b]});")
         for j, o in enumerate(outs):
             lines.append(f"    {out_name}[{j}] = {names[o]};")
         lines.append("}")
@@ -187,6 +188,14 @@ def main():
     parts.append(code)
     summary.append(("mlv_final6of11", ops))
 
+    # full sort of a column of 5 with two-input ops only (the packed 16-bit path has no three-input min/med/max)
+    n = Net(5)
+    res = n.sort(list(range(5)))
+    check_select(n, 5, res, list(range(5)))
+    code, ops = n.emit("mlv_sort5", [("v", 5)], res)
+    parts.append(code)
+    summary.append(("mlv_sort5", ops))
+
     # plain selection networks (used for the 5- and 9-element windows, and as the
     # 25-element cross-check in the self test)
     for cnt in (5, 9, 25):
@@ -201,7 +210,9 @@ def main():
         "// GENERATED by tools/gen_median_nets.py -- do not edit.",
         "// Exact min/max selection networks for the chroma-smoothing medians",
         "// (replaces opt_med5/9/25 of mlvfs/opt_med.h; values are ints, so any exact",
-        "// selector is bit-identical).  Verified at generation time (0-1 principle)",
+        "// selector is bit-identical).  Templates over the element type: int, or a pair",
+        "// of 16-bit lanes with element-wise mlv_mn/mlv_mx (k_frame's packed path).",
+        "// Verified at generation time (0-1 principle)",
         "// and again at run time by mlvfs_amd_selftest_host().",
         "#pragma once",
         "#ifndef MLV_NET_FN",

@@ -12,6 +12,9 @@ W, H, F = 3584, 1320, int(os.environ.get("KB_FRAMES", "50"))
 s = ClipStream(W, H)
 L = s.L
 base = s.synth_packed(8, seed=1)
+if os.environ.get("KB_KIND") == "colour_cast":          # footage-like colour balance with hard colour edges
+    fr = [synth.colour_cast_frame(W, H, seed=11 + i) for i in range(8)]
+    base = s.upload_packed([synth.pack_bits(f) for f in fr])
 packed = s.alloc_packed(F)
 for i in range(0, F, 8):
     packed[i:i + 8] = base[:min(8, F - i)]

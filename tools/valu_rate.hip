@@ -26,6 +26,15 @@ template <int OP> __global__ void k(int *out, int n, int seed)
                 if (OP == 11) asm volatile("v_ffbh_u32 %0, %0" : "+v"(a[i]));
                 if (OP == 12) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
                 if (OP == 13) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 14) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 15) asm volatile("v_med3_i16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(a[(i + 1) & 7]));
+                if (OP == 16) asm volatile("v_cvt_pk_i16_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 17) asm volatile("v_bfe_i32 %0, %0, 16, 16" : "+v"(a[i]));
+                if (OP == 18) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 19) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(a[(i + 1) & 7]));
+                if (OP == 20) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 21) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if (OP == 22) asm volatile("v_ashrrev_i32 %0, 16, %0" : "+v"(a[i]));
             }
         }
     }
@@ -55,6 +64,9 @@ int main()
         run<6>("v_and_b32", blocks, thr); run<7>("v_lshlrev_b32", blocks, thr); run<8>("v_alignbit", blocks, thr);
         run<9>("v_cndmask", blocks, thr); run<10>("v_mul_i32_i24", blocks, thr); run<11>("v_ffbh_u32", blocks, thr);
         run<12>("v_pk_min_i16", blocks, thr); run<13>("v_lshl_add_u32", blocks, thr);
+        run<14>("v_pk_max_i16", blocks, thr); run<15>("v_med3_i16", blocks, thr); run<16>("v_cvt_pk_i16_i32", blocks, thr);
+        run<17>("v_bfe_i32", blocks, thr); run<18>("v_pk_add_i16", blocks, thr); run<19>("v_perm_b32", blocks, thr);
+        run<20>("v_pk_min_u16", blocks, thr); run<21>("v_sub_u32", blocks, thr); run<22>("v_ashrrev_i32", blocks, thr);
     }
     return 0;
 }
