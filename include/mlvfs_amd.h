@@ -163,6 +163,16 @@ int mlvfs_amd_process_frames_dev(mlvfs_amd_clip_t *clip, const void *d_packed, s
                                  void *d_out, size_t out_stride, int nframes,
                                  int cs_method, int fix_pixels, int apply_stripes, void *stream);
 
+/* The same fused pipeline for frames in HOST memory (a reader that has MLV payloads in RAM): chunks
+ * of chunk_frames frames (<= 0: 8) travel H2D -> kernels -> D2H on three streams so that both copy directions and the
+ * kernels overlap; returns when h_out is complete.  Strides are bytes between frames.  Full PCIe speed needs page-locked
+ * buffers (mlvfs_amd_host_alloc, or memory the caller registered with the HIP runtime); pageable memory works, slower. */
+int mlvfs_amd_process_frames_host(mlvfs_amd_clip_t *clip, const void *h_packed, size_t packed_stride, void *h_out,
+                                  size_t out_stride, int nframes, int cs_method, int fix_pixels, int apply_stripes,
+                                  int chunk_frames);
+void *mlvfs_amd_host_alloc(size_t bytes);
+void mlvfs_amd_host_free(void *p);
+
 /* dual-ISO preview on one device frame (hdr.c:40-227); returns 1 / 0 / <0    */
 int mlvfs_amd_hdr_preview_dev(const mlvfs_amd_geom_t *geom, void *d_frame, size_t max_size, void *stream);
 

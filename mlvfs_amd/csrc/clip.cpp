@@ -2,6 +2,7 @@
 // include/mlvfs_amd.h): pixel-map dependency analysis, stripe-coefficient
 // computation around the histogram kernels, fused pipeline entry point.
 #include "clip.h"
+#include <map>
 
 #include <algorithm>
 #include <climits>
@@ -607,5 +608,93 @@ int mlvfs_amd_process_frames_dev(mlvfs_amd_clip_t *clip_, const void *d_packed, 
     return launch_frame(c->dev, clip->g, true, d_packed, packed_stride, d_out, out_stride, nframes, cs_method,
                         patch ? &pv : nullptr, stripes, clip->coef, s);
 }
+
+// ---- frames that live in HOST memory: chunked, triple-buffered H2D -> fused kernel -> D2H ------------------------
+namespace {
+struct HostPipe {                       // per host thread and device
+    static constexpr int NS = 3;
+    hipStream_t s[NS] = { nullptr, nullptr, nullptr };
+    void *d_in[NS] = { nullptr, nullptr, nullptr }, *d_out[NS] = { nullptr, nullptr, nullptr }, *d_patch[NS] = { nullptr, nullptr, nullptr };
+    size_t cap_in = 0, cap_out = 0, cap_patch = 0;
+    int ensure(size_t in_bytes, size_t out_bytes, size_t patch_bytes)
+    {
+        for (int k = 0; k < NS; k++)
+            if (!s[k]) MLV_HIP(hipStreamCreateWithFlags(&s[k], hipStreamNonBlocking));
+        auto grow = [&](void *(&buf)[NS], size_t &cap, size_t need) -> int {
+            if (need <= cap) return MLVFS_AMD_OK;
+            for (int k = 0; k < NS; k++) {
+                if (buf[k]) (void)hipFree(buf[k]);
+                buf[k] = nullptr;
+                MLV_HIP(hipMalloc(&buf[k], need));
+            }
+            cap = need;
+            return MLVFS_AMD_OK;
+        };
+        int rc = grow(d_in, cap_in, in_bytes);
+        if (!rc) rc = grow(d_out, cap_out, out_bytes);
+        if (!rc && patch_bytes) rc = grow(d_patch, cap_patch, patch_bytes);
+        return rc;
+    }
+};
+thread_local std::map<int, HostPipe> t_pipe;
+}  // namespace
+
+int mlvfs_amd_process_frames_host(mlvfs_amd_clip_t *clip_, const void *h_packed, size_t packed_stride, void *h_out,
+                                  size_t out_stride, int nframes, int cs_method, int fix_pixels, int apply_stripes,
+                                  int chunk_frames)
+{
+    ThreadCtx *c = thread_ctx();
+    if (!c) return MLVFS_AMD_ERR_HIP;
+    Clip *clip = reinterpret_cast<Clip *>(clip_);
+    if (nframes <= 0) return MLVFS_AMD_OK;
+    if (chunk_frames <= 0) chunk_frames = 8;
+    if (chunk_frames > nframes) chunk_frames = nframes;
+    if (clip->g.bpp != 14) { set_error("host pipeline needs 14-bit payloads (got %d)", clip->g.bpp); return MLVFS_AMD_ERR_ARG; }
+    if (cs_method != 0 && clip->g.black > 16384) cs_method = 0;
+    const bool patch = fix_pixels && clip->n_entries > 0;
+    const bool stripes = apply_stripes && clip->needed && (clip->g.w % 8 == 0);
+    const size_t dstride_in = (packed_stride + 15) / 16 * 16, dstride_out = ((size_t)clip->g.w * clip->g.h * 2 + 15) / 16 * 16;
+    HostPipe &hp = t_pipe[c->dev->id];
+    const size_t patch_bytes = patch ? (size_t)chunk_frames * clip->n_entries * sizeof(int2) : 0;
+    int rc = hp.ensure(dstride_in * chunk_frames + 16, dstride_out * chunk_frames, patch_bytes);
+    if (rc) return rc;
+    const size_t row_bytes = (size_t)clip->g.w * clip->g.h * 2;
+    for (int f0 = 0, k = 0; f0 < nframes; f0 += chunk_frames, k++) {
+        const int n = std::min(chunk_frames, nframes - f0), slot = k % HostPipe::NS;
+        hipStream_t s = hp.s[slot];
+        const uint8_t *src = (const uint8_t *)h_packed + (size_t)f0 * packed_stride;
+        uint8_t *dst = (uint8_t *)h_out + (size_t)f0 * out_stride;
+        // same-stream order makes the slot's buffers safe to reuse: this H2D is queued behind the slot's previous D2H
+        if (packed_stride == dstride_in) MLV_HIP(hipMemcpyAsync(hp.d_in[slot], src, packed_stride * n, hipMemcpyHostToDevice, s));
+        else MLV_HIP(hipMemcpy2DAsync(hp.d_in[slot], dstride_in, src, packed_stride, packed_stride, n, hipMemcpyHostToDevice, s));
+        if (!patch && !stripes && cs_method == 0) {
+            rc = launch_unpack(hp.d_in[slot], dstride_in, hp.d_out[slot], dstride_out, 0, (uint32_t)clip->g.w * clip->g.h, 14, n, s);
+        } else {
+            if (patch) {
+                rc = launch_pixfix(true, hp.d_in[slot], dstride_in, clip->g.w, clip->g.black, clip->d_entries, clip->d_level_off,
+                                   clip->n_levels, clip->n_entries, hp.d_patch[slot], nullptr, 0, n, c->dev->luts, s);
+                if (rc) return rc;
+            }
+            const PatchView pv{ hp.d_patch[slot], clip->n_entries, clip->d_tile_off, clip->d_tile_ent };
+            rc = launch_frame(c->dev, clip->g, true, hp.d_in[slot], dstride_in, hp.d_out[slot], dstride_out, n, cs_method,
+                              patch ? &pv : nullptr, stripes, clip->coef, s);
+        }
+        if (rc) return rc;
+        if (out_stride == dstride_out) MLV_HIP(hipMemcpyAsync(dst, hp.d_out[slot], out_stride * n, hipMemcpyDeviceToHost, s));
+        else MLV_HIP(hipMemcpy2DAsync(dst, out_stride, hp.d_out[slot], dstride_out, row_bytes, n, hipMemcpyDeviceToHost, s));
+    }
+    for (int k = 0; k < HostPipe::NS; k++) MLV_HIP(hipStreamSynchronize(hp.s[k]));
+    return MLVFS_AMD_OK;
+}
+
+void *mlvfs_amd_host_alloc(size_t bytes)
+{
+    if (!thread_ctx()) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+
+void mlvfs_amd_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 }  // extern "C"

@@ -156,6 +156,18 @@ class ClipStream:
                                                       _stream_ptr()), "process_frames_dev")
         return out
 
+    def process_host(self, packed: torch.Tensor, out: torch.Tensor | None = None, cs: int = 0, fix_pixels: bool = False,
+                     stripes: bool = False, chunk: int = 8) -> torch.Tensor:
+        """The same pass for frames in HOST memory (uint8 tensors, ideally pinned): chunked and triple-buffered over PCIe."""
+        assert packed.device.type == "cpu" and packed.dtype == torch.uint8 and packed.is_contiguous()
+        n = packed.shape[0]
+        if out is None:
+            out = torch.empty((n, self.out_stride), dtype=torch.uint8, pin_memory=True)
+        lib.check(self.L.mlvfs_amd_process_frames_host(self.clip, C.c_void_p(packed.data_ptr()), packed.stride(0),
+                                                       C.c_void_p(out.data_ptr()), out.stride(0), n, cs, int(fix_pixels),
+                                                       int(stripes), chunk), "process_frames_host")
+        return out
+
     # ------------------------------------------------------------------ first frame of a clip
     def analyse_first_frame(self, packed0: torch.Tensor, cs: int = 0, bad_pix: int = 0, stripes: bool = False,
                             rand_mode: int = 1) -> torch.Tensor:

@@ -206,3 +206,30 @@ def test_full_size_properties(torch_cuda):
     assert (plain != unp).any()
     assert torch.equal(batch, plain.clamp(max=WHITE))                   # unit gains: min(white, p)
     s.close()
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_host_pipeline_matches_device_pipeline(gpu, pinned):
+    """mlvfs_amd_process_frames_host (frames in host memory, chunked H2D / kernels / D2H on three streams) must give
+    exactly what the device-resident pass gives, for chunk sizes that do and do not divide the frame count."""
+    import torch
+    from mlvfs_amd.stream import ClipStream
+    w, h, n = 256, 130, 11
+    s = ClipStream(w, h, 14, synth.BLACK, synth.WHITE, device=0)
+    frames = [synth.normal_frame(w, h, frame=k) for k in range(n)]
+    packed = s.upload_packed([synth.pack_bits(f) for f in frames])
+    s.analyse_first_frame(packed, cs=5, bad_pix=1, stripes=True, rand_mode=1)
+    as_bytes = lambda t: t.cpu().contiguous().view(torch.uint8).reshape(n, -1)
+    want = as_bytes(s.process(packed, cs=5, fix_pixels=True, stripes=True))
+    host_in = packed.cpu()
+    if pinned:
+        host_in = host_in.pin_memory()
+    for chunk in (1, 4, 16):
+        out = torch.zeros((n, s.out_stride), dtype=torch.uint8)
+        if pinned:
+            out = out.pin_memory()
+        got = s.process_host(host_in, out, cs=5, fix_pixels=True, stripes=True, chunk=chunk)
+        assert torch.equal(got, want)
+    got = s.process_host(host_in, None, cs=0, fix_pixels=False, stripes=False, chunk=3)       # unpack only
+    assert torch.equal(got, as_bytes(s.process(packed)))
+    s.close()
