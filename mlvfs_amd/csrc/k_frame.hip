@@ -112,22 +112,22 @@ __device__ __forceinline__ void sort5(int (&v)[5])
 //   ev(lin) = T16[(lin << (13 - e)) & 8191] + (e << 15),  e = floor(log2 lin)
 // Pixels at or below black (ev = INT_MIN / 0) or beyond the table are the rare case: a
 // wave-wide vote picks the branch-free fast path unless some lane needs the fix-up.
-__device__ __forceinline__ int ev_index(int l) { return (l << (__clz(l) - 18)) & 8191; }
-__device__ __forceinline__ int ev_value(int l, int tv) { return tv + ((31 - __clz(l)) << 15); }
+// Exponent and 13-bit mantissa fraction come out of the float conversion (exact for l < 2^24): one v_cvt + one v_bfe
+// instead of count-leading-zeros, variable shift and mask.
+__device__ __forceinline__ int ev_index(int l) { return (int)((__float_as_uint((float)(unsigned)l) >> 10) & 8191u); }
+__device__ __forceinline__ int ev_value(int l, int tv)
+{
+    return tv + (int)((__float_as_uint((float)(unsigned)l) >> 8) & 0xFFFF8000u) - (127 << 15);
+}
 
 // EV triples of two adjacent Bayer cells (8 pixels): r/g1 on the top row, g2/b below
-__device__ __forceinline__ void cell_pair_ev(const uint32_t *p0, const uint32_t *p1, int black, const uint16_t *t,
+__device__ __forceinline__ void cell_pair_ev(const uint32_t *p0, const uint32_t *p1, int black, const uint16_t *t, bool slow,
                                              int (&ge)[2], int (&dr)[2], int (&db)[2])
 {
     const int px[8] = { (int)p0[0], (int)p0[1], (int)p1[0], (int)p1[1], (int)p0[2], (int)p0[3], (int)p1[2], (int)p1[3] };
     int lin[8], l[8], tv[8], ev[8];
-    bool odd = false;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        lin[i] = px[i] - black;
-        odd |= (unsigned)(lin[i] - 1) >= 16383u;
-    }
-    const bool slow = __any(odd);                       // wave-uniform
+    for (int i = 0; i < 8; i++) lin[i] = px[i] - black;
 #pragma unroll
     for (int i = 0; i < 8; i++) l[i] = slow ? min(max(lin[i], 1), 16383) : lin[i];
 #pragma unroll
@@ -155,7 +155,7 @@ __device__ __forceinline__ void cell_ev(int r, int g1, int g2, int b, int black,
 {
     const uint32_t p0[4] = { (uint32_t)r, (uint32_t)g1, (uint32_t)r, (uint32_t)g1 }, p1[4] = { (uint32_t)g2, (uint32_t)b, (uint32_t)g2, (uint32_t)b };
     int g[2], a[2], c[2];
-    cell_pair_ev(p0, p1, black, t, g, a, c);
+    cell_pair_ev(p0, p1, black, t, true, g, a, c);          // rare path: always with the out-of-table fix-ups
     ge = g[0]; dr = a[0]; db = c[0];
 }
 
@@ -259,13 +259,13 @@ __device__ __forceinline__ void fetch_rows(const uint8_t *frame, int w, int h, i
 
 // EV triples of NCELL (even) cells into the planes: plane row r, first plane column col0
 template <int NCELL>
-__device__ __forceinline__ void store_cells(Smem &sm, int black, int r, int col0, const uint32_t *p0, const uint32_t *p1)
+__device__ __forceinline__ void store_cells(Smem &sm, int black, bool slow, int r, int col0, const uint32_t *p0, const uint32_t *p1)
 {
     const bool row_in = r >= HC && r < HC + TCH;
 #pragma unroll
     for (int c = 0; c < NCELL; c += 2) {
         int ge[2], dr[2], db[2];
-        cell_pair_ev(p0 + 2 * c, p1 + 2 * c, black, sm.t16, ge, dr, db);
+        cell_pair_ev(p0 + 2 * c, p1 + 2 * c, black, sm.t16, slow, ge, dr, db);
         *(int2 *)&sm.dr[r][col0 + c] = make_int2(dr[0], dr[1]);
         *(int2 *)&sm.db[r][col0 + c] = make_int2(db[0], db[1]);
         const int ci = col0 + c - HC;
@@ -282,17 +282,18 @@ __device__ __forceinline__ void store_raw(Smem &sm, int row, int g, const uint32
 
 // pixels of one item -> planes (+ interior raw)
 template <int METHOD>
-__device__ __forceinline__ void emit_item(Smem &sm, int black, int pr, int g, bool edge, const uint32_t (&p0)[16], const uint32_t (&p1)[16])
+__device__ __forceinline__ void emit_item(Smem &sm, int black, bool slow, int pr, int g, bool edge, const uint32_t (&p0)[16],
+                                          const uint32_t (&p1)[16])
 {
     if (!edge) {
-        if (METHOD != 0) store_cells<8>(sm, black, pr, HC + 8 * g, p0, p1);
+        if (METHOD != 0) store_cells<8>(sm, black, slow, pr, HC + 8 * g, p0, p1);
         if (pr >= HC && pr < HC + TCH) {
             store_raw(sm, 2 * (pr - HC), g, p0);
             store_raw(sm, 2 * (pr - HC) + 1, g, p1);
         }
     } else if (METHOD != 0) {
-        store_cells<2>(sm, black, pr, 0, p0 + 12, p1 + 12);          // left halo  (px 12..15)
-        store_cells<2>(sm, black, pr, HC + TCW, p0, p1);             // right halo (px 0..3)
+        store_cells<2>(sm, black, slow, pr, 0, p0 + 12, p1 + 12);    // left halo  (px 12..15)
+        store_cells<2>(sm, black, slow, pr, HC + TCW, p0, p1);       // right halo (px 0..3)
     }
 }
 
@@ -553,7 +554,20 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             uint32_t p0[16], p1[16];
             if (vec) { unpack16<PACKED>(r0, p0); unpack16<PACKED>(r1, p1); }
             else fetch_rows<PACKED>(frame, a.w, a.h, tx0 + 16 * item_g, ty0 - 2 * HC + 2 * item_row, edge, tx0, p0, p1);
-            if (!(a.dbg & 1)) emit_item<METHOD>(sm, a.black, item_row, item_g, edge, p0, p1);
+            // Pixels at or below black (ev = INT_MIN / 0) or beyond the table need the fix-ups of cell_pair_ev: decided once
+            // per item from the extremes of its 32 pixels (three-input min/max), wave-uniformly.
+            bool odd = false;
+            if (METHOD != 0) {
+                uint32_t lo = min(p0[0], p1[0]), hi = max(p0[0], p1[0]);
+#pragma unroll
+                for (int i = 1; i < 16; i++) {
+                    lo = min(min(lo, p0[i]), p1[i]);
+                    if (!PACKED) hi = max(max(hi, p0[i]), p1[i]);
+                }
+                odd = (int)lo <= a.black || (!PACKED && (int)hi - a.black > 16383) || (PACKED && a.black < 0);
+            }
+            const bool slow = __any(odd);
+            if (!(a.dbg & 1)) emit_item<METHOD>(sm, a.black, slow, item_row, item_g, edge, p0, p1);
             else asm volatile("" :: "v"(p0[0] ^ p0[5] ^ p0[15] ^ p1[3] ^ p1[12]));
         }
         lds_barrier();
