@@ -14,6 +14,7 @@
 #include "clip.h"
 #include "dualiso.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -204,12 +205,18 @@ static int bright_dark_from_hist(const unsigned *hg, int black, int is_bright[4]
     long long acc[4] = { 0, 0, 0, 0 };
     int raw[4] = { 0, 0, 0, 0 }, off[4] = { 0, 0, 0, 0 };
     const int ref_max = (int)(total * 0.998), ref_off = (int)(total * 0.05);
-    for (int ref = 0; ref < ref_max; ref++) {
+    // The reference walks ref = 0, 1, 2, ... (hdr.c:563-589); between two values of ref at which some class advances
+    // nothing changes, so only those values are visited: same assignments, same exit.
+    for (long long ref = 0; ref < ref_max;) {
         for (int i = 0; i < 4; i++)
             while (acc[i] < ref && raw[i] < 16384) { acc[i] += hg[i * 16384 + raw[i]]; raw[i]++; }
         if (ref < ref_off && std::max(std::max(raw[0], raw[1]), std::max(raw[2], raw[3])) < black + (white - black) / 4)
             memcpy(off, raw, sizeof off);
         if (raw[0] >= white || raw[1] >= white || raw[2] >= white || raw[3] >= white) break;
+        long long next = ref_max;
+        for (int i = 0; i < 4; i++)
+            if (raw[i] < 16384) next = std::min(next, acc[i] + 1);     // first ref at which class i moves again
+        ref = std::max(next, ref + 1);
     }
     for (int i = 0; i < 4; i++) raw[i] -= off[i];
     int s[4];
@@ -269,6 +276,20 @@ static void whites_from_hist(const unsigned *hw, const int is_bright[4], int w, 
     printf("White levels    : %d %d\n", *white_dark, *white_bright);
 }
 
+// MLVFS_AMD_DI_TIMING=1: wall-clock of the host-visible phases of one conversion on stderr (tuning aid)
+struct PhaseTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    PhaseTimer() : on(getenv("MLVFS_AMD_DI_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[di] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 // ------------------------------------------------------------------ the conversion on a device frame
 // d_frame: w x H uint16 frame in HBM, converted in place.  Returns 1 converted, 0 not dual ISO / failed
 // like the reference, < 0 on an error of the library.
@@ -277,6 +298,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
                     hipStream_t stream, bool *frame_touched)
 {
     if (frame_touched) *frame_touched = false;
+    PhaseTimer pt;
     if (w <= 0 || H <= 8) return 0;
     const size_t N = (size_t)w * H;
     const double *d_evf = nullptr;
@@ -319,6 +341,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     };
     rc = analyse();
     if (rc) return rc;
+    pt.mark("analyse (kernel + D2H)");
     if (!(check[0] / check[1] > 0.5)) return 0;                         // hdr_check, hdr.c:432-438
 
     // ---- focus / bad pixels are repaired between the check and the analysis (hdr.c:1943-1947)
@@ -375,6 +398,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     const int y0 = ay1 + 2;
     const int nsy = (h - 2 > y0) ? (h - 2 - y0 + 2) / 3 : 0;
     const int nsamp = nsx * nsy;
+    pt.mark("pattern + whites (host)");
     rc = di_launch_subsample(img, p, nsx, nsy, (int *)(B + o_ds), (int *)(B + o_bs), (unsigned *)(B + o_hb), (unsigned *)(B + o_hd), stream);
     if (rc) return rc;
     std::vector<int> ds(std::max(nsamp, 1)), bs(std::max(nsamp, 1));
@@ -402,6 +426,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
             hi_d.push_back(d); hi_b.push_back(b);
             if ((int)hi_d.size() >= hi_nmax) break;                   // leaves the x loop only (hdr.c:744)
         }
+    pt.mark("subsample + D2H + quantiles");
     const int hi_n = (int)hi_d.size();
     std::vector<double> cand;
     for (double ev = 0; ev < 6; ev += 0.002) {
@@ -449,6 +474,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     p.max_ev = log2(white / 64 - black / 64);
 
     DiLuts L{};
+    pt.mark("score candidates");
     rc = prepare_tables(c->dev->id, black, white, interp_method, &L, &d_evf);
     if (rc) return rc;
     if (chroma_smooth_method) printf("Chroma smoothing...\n");
@@ -458,6 +484,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     DiPlanes P{ (uint32_t *)(B + o_raw), (uint32_t *)(B + o_dark), (uint32_t *)(B + o_bright), (uint32_t *)(B + o_full),
                 (uint32_t *)(B + o_half), (uint32_t *)(B + o_full_s), (uint32_t *)(B + o_half_s), (uint16_t *)(B + o_over),
                 (uint16_t *)(B + o_amap), (uint16_t *)(B + o_aux), (uint16_t *)(B + o_amap2), (int *)(B + o_cells) };
+    pt.mark("tables");
     rc = di_launch_match(img, p, P, stream);
     if (rc) return rc;
     if (amaze) {
@@ -500,8 +527,10 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
         printf("Semi-overexposed: %.02f%%\n", st[0] * 100.0 / (st[0] + st[1]));
         printf("Deep shadows    : %.02f%%\n", st[2] * 100.0 / (st[2] + st[3]));
     }
+    pt.mark("amaze + edge directions");
     rc = di_launch_convert(p, L, P, amaze, img, stream);
     if (rc) return rc;
+    if (pt.on) { (void)hipStreamSynchronize(stream); pt.mark("interp + mix + blend"); }
     printf("Noise level     : %.02f (20-bit), ideally %.02f\n", 8.0, 8.0);
     printf("Dynamic range   : %.02f EV (cooked)\n", log2(white - black) - log2(8.0));
     return 1;
