@@ -74,7 +74,6 @@ struct FrameArgs {
     int coef[8];
     int coef_fast;           // all |coef - 65536| < 32768: 32-bit epilogue
     int patch, stripes;      // wave-uniform stage switches
-    int dbg;                 // MLVFS_AMD_DBG: timing-only ablation bits (outputs are wrong when set)
 };
 
 struct __align__(16) Smem {
@@ -567,8 +566,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 odd = (int)lo <= a.black || (!PACKED && (int)hi - a.black > 16383) || (PACKED && a.black < 0);
             }
             const bool slow = __any(odd);
-            if (!(a.dbg & 1)) emit_item<METHOD>(sm, a.black, slow, item_row, item_g, edge, p0, p1);
-            else asm volatile("" :: "v"(p0[0] ^ p0[5] ^ p0[15] ^ p1[3] ^ p1[12]));
+            emit_item<METHOD>(sm, a.black, slow, item_row, item_g, edge, p0, p1);
         }
         lds_barrier();
         if (a.patch && pbeg != pend) {          // wave-uniform; list bounds were fetched at the top of the iteration
@@ -588,7 +586,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             top[0] = v0.x; top[1] = v0.y; top[2] = v0.z; top[3] = v0.w;
             bot[0] = v1.x; bot[1] = v1.y; bot[2] = v1.z; bot[3] = v1.w;
         }
-        if (METHOD != 0 && y >= 4 && y < a.h - 5 && !(a.dbg & 2)) {
+        if (METHOD != 0 && y >= 4 && y < a.h - 5) {
             int mr[STRIP], mb[STRIP];
             if (METHOD == 5) {
                 if (__any(strip_median25_packed(sm.dr, sm.db, j, STRIP * k, mr, mb))) {      // wave-uniform, rare
@@ -635,7 +633,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             if (a.coef_fast) stripe_strip<true>(top, bot, a.coef, black16, white16);
             else stripe_strip<false>(top, bot, a.coef, black16, white16);
         }
-        if (y < a.h && !(a.dbg & 4)) {
+        if (y < a.h) {
             if (vec) {
                 if (x < a.w) {
                     *(uint4 *)(out + (size_t)y * a.w + x) = make_uint4(top[0], top[1], top[2], top[3]);
@@ -700,7 +698,6 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
     a.patch = pv && pv->n_patch > 0;
     if (a.patch) { a.patches = (const int2 *)pv->patches; a.n_patch = pv->n_patch; a.tile_off = pv->tile_off; a.tile_ent = pv->tile_ent; }
     a.stripes = stripes ? 1 : 0;
-    { const char *e = getenv("MLVFS_AMD_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.coef_fast = 1;
     for (int i = 0; i < 8; i++) {
         a.coef[i] = (stripes && coef) ? coef[i] : 0;
