@@ -73,6 +73,7 @@ struct FrameArgs {
     // stripes
     int coef[8];
     int coef_fast;           // all |coef - 65536| < 32768: 32-bit epilogue
+    int coef_pk;             // additionally 14-bit input, white > black + 64, black <= 16384: packed 16-bit epilogue
     int patch, stripes;      // wave-uniform stage switches
 };
 
@@ -473,6 +474,32 @@ __device__ __forceinline__ void stripe_strip(uint32_t (&top)[STRIP], uint32_t (&
     }
 }
 
+// The same on both pixels of a dword with 16-bit lanes (14-bit input, |coef - 65536| < 2^15, white > black + 64, checked
+// by the launcher): a = p - black and the "a > 64" mask as packed ops, the two 24-bit products through SDWA operands, their
+// upper halves gathered by one v_perm_b32.  Where a <= 64 the masked correction is 0 and min(p, white) = p.
+__device__ __forceinline__ uint32_t stripe_pair(uint32_t x, int d0, int d1, uint32_t black_pk, uint32_t white_pk)
+{
+    typedef unsigned short upk16 __attribute__((ext_vector_type(2)));
+    const mlv_pk16 a = __builtin_bit_cast(mlv_pk16, x) - __builtin_bit_cast(mlv_pk16, black_pk);
+    const mlv_pk16 c64 = { 64, 64 }, s15 = { 15, 15 };
+    const mlv_pk16 m = (c64 - a) >> s15;                                                     // -1 where a > 64
+    const int p0 = __mul24((int)a.x, d0), p1 = __mul24((int)a.y, d1);                         // |.| < 2^29
+    const uint32_t delta = __builtin_amdgcn_perm((uint32_t)p1, (uint32_t)p0, 0x07060302u);    // {p1 >> 16, p0 >> 16}
+    const upk16 v = __builtin_bit_cast(upk16, x) + __builtin_bit_cast(upk16, delta & __builtin_bit_cast(uint32_t, m));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(v, __builtin_bit_cast(upk16, white_pk)));
+}
+
+__device__ __forceinline__ void stripe_strip_pk(uint32_t (&top)[STRIP], uint32_t (&bot)[STRIP], const int (&coef)[8], int black16, int white16)
+{
+    const uint32_t black_pk = (uint32_t)black16 * 0x10001u, white_pk = (uint32_t)white16 * 0x10001u;
+#pragma unroll
+    for (int c = 0; c < STRIP; c++) {
+        const int d0 = coef[(2 * c) & 7] - 65536, d1 = coef[(2 * c + 1) & 7] - 65536;
+        top[c] = stripe_pair(top[c], d0, d1, black_pk, white_pk);
+        bot[c] = stripe_pair(bot[c], d0, d1, black_pk, white_pk);
+    }
+}
+
 template <int METHOD, bool PACKED, bool VEC>
 __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 {
@@ -630,7 +657,8 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         }
         if (a.stripes) {
             // a strip starts at an x that is a multiple of 8, so pixel n of the strip has column phase n
-            if (a.coef_fast) stripe_strip<true>(top, bot, a.coef, black16, white16);
+            if (PACKED && a.coef_pk) stripe_strip_pk(top, bot, a.coef, black16, white16);
+            else if (a.coef_fast) stripe_strip<true>(top, bot, a.coef, black16, white16);
             else stripe_strip<false>(top, bot, a.coef, black16, white16);
         }
         if (y < a.h) {
@@ -703,6 +731,7 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
         a.coef[i] = (stripes && coef) ? coef[i] : 0;
         if (a.coef[i] - 65536 <= -32768 || a.coef[i] - 65536 >= 32768) a.coef_fast = 0;
     }
+    a.coef_pk = a.coef_fast && packed && (int)(uint16_t)g.white > (int)(uint16_t)g.black + 64 && g.black >= 0 && g.black <= 16384;
     // vector path: rows are whole 16-pixel groups and every row starts 16-byte aligned
     const bool vec = (g.w % 16) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 &&
                      (nframes == 1 || (src_stride % 16 == 0 && dst_stride % 16 == 0));
