@@ -159,6 +159,20 @@ struct DiWork {
     }
 };
 static thread_local std::map<int, DiWork> t_work;
+struct PinnedWork {              // page-locked host landing zone for the summaries the host decisions read
+    void *base = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return MLVFS_AMD_OK;
+        if (base) (void)hipHostFree(base);
+        base = nullptr; cap = 0;
+        MLV_HIP(hipHostMalloc(&base, bytes, hipHostMallocDefault));
+        cap = bytes;
+        return MLVFS_AMD_OK;
+    }
+};
+static thread_local std::map<int, PinnedWork> t_pinned;
 // AMaZE tile planes: zeroed when (re)allocated or when the plane geometry changes, like the reference's calloc per call
 // (for one geometry every tile rewrites exactly what it wrote before, so what must read as zero stays zero)
 struct AmazeWork : DiWork { int w = 0, h = 0; };
@@ -311,7 +325,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += up(bytes); return o; };
-    const size_t o_hist = take(sizeof(unsigned) * DI_HIST_WORDS), o_check = take(16), o_ds = take(ns * 4), o_bs = take(ns * 4),
+    const size_t o_hist = take(sizeof(unsigned) * DI_D_WORDS), o_check = take(16), o_ds = take(ns * 4), o_bs = take(ns * 4),
                  o_hb = take(sizeof(unsigned) * DI_HIST_N), o_hd = take(sizeof(unsigned) * DI_HIST_N), o_hi_d = take(ns / 25 * 4 + 65536),
                  o_hi_b = take(ns / 25 * 4 + 65536), o_cand = take(8 * 2 * 3100), o_score = take(4 * 3100);
     const size_t o_raw = take(N * 4), o_dark = take(N * 4), o_bright = take(N * 4), o_full = take(N * 4), o_half = take(N * 4),
@@ -329,14 +343,55 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     uint8_t *B = (uint8_t *)wk.base;
 
     // ---- hdr_check + all histograms in one pass
-    std::vector<unsigned> hist(DI_HIST_WORDS);
+    const size_t ph_hist = 0, ph_ds = ph_hist + sizeof(unsigned) * DI_HIST_WORDS, ph_bs = ph_ds + ns * 4, ph_hb = ph_bs + ns * 4,
+                 ph_hd = ph_hb + sizeof(unsigned) * DI_HIST_N, ph_tail = ph_hd + sizeof(unsigned) * DI_HIST_N,
+                 ph_dev = ph_tail + (size_t)32 * w * 2, ph_edge = ph_dev + sizeof(unsigned) * DI_D_WORDS,
+                 ph_end = ph_edge + (size_t)13 * w * 2;
+    PinnedWork &pw = t_pinned[c->dev->id];
+    rc = pw.ensure(ph_end);
+    if (rc) return rc;
+    uint8_t *PH = (uint8_t *)pw.base;
+    unsigned *hist_p = (unsigned *)(PH + ph_hist);
+    struct { unsigned *p; unsigned *data() const { return p; } } hist{ hist_p };
     double check[2];
+    // device block + the first 5 and last 8 rows of the frame (the row ranges of the three derived histograms differ
+    // from "all rows" only there: hdr.c:453 / :519 stop at a multiple of 4, the GBRG variant starts at row 5)
+    const int top_rows = std::min(5, H), bot_rows = std::min(8, H - top_rows);
     auto analyse = [&]() -> int {
         int r = di_launch_analyse(d_frame, w, H, black14, white14, d_evf, (unsigned *)(B + o_hist), (double *)(B + o_check), stream);
         if (r) return r;
-        MLV_HIP(hipMemcpyAsync(hist.data(), B + o_hist, sizeof(unsigned) * DI_HIST_WORDS, hipMemcpyDeviceToHost, stream));
+        unsigned *dev = (unsigned *)(PH + ph_dev);
+        uint16_t *edge = (uint16_t *)(PH + ph_edge);
+        MLV_HIP(hipMemcpyAsync(dev, B + o_hist, sizeof(unsigned) * DI_D_WORDS, hipMemcpyDeviceToHost, stream));
+        MLV_HIP(hipMemcpyAsync(edge, d_frame, (size_t)top_rows * w * 2, hipMemcpyDeviceToHost, stream));
+        MLV_HIP(hipMemcpyAsync(edge + (size_t)top_rows * w, (const uint16_t *)d_frame + (size_t)(H - bot_rows) * w, (size_t)bot_rows * w * 2,
+                               hipMemcpyDeviceToHost, stream));
         MLV_HIP(hipMemcpyAsync(check, B + o_check, 16, hipMemcpyDeviceToHost, stream));
         MLV_HIP(hipStreamSynchronize(stream));
+        unsigned *hb = hist.data() + DI_H_BAYER, *g0 = hist.data() + DI_H_GREEN0, *g1 = hist.data() + DI_H_GREEN1;
+        memset(hb, 0, sizeof(unsigned) * 4 * 16384);
+        for (int q = 0; q < 4; q++)
+            for (int px = 0; px < 2; px++) {
+                const unsigned *cl = dev + DI_D_CLASS + (size_t)(q * 2 + px) * 16384;
+                unsigned *bay = hb + (size_t)((q & 1) * 2 + px) * 16384;
+                for (int v = 0; v < 16384; v++) bay[v] += cl[v];
+                if (px == 1 - (q & 1)) memcpy(g0 + (size_t)q * 16384, cl, sizeof(unsigned) * 16384);              // greens: x & 1 != y & 1
+                if (px == (q & 1)) memcpy(g1 + (size_t)((q + 3) & 3) * 16384, cl, sizeof(unsigned) * 16384);     // greens of the frame one row lower
+            }
+        const int R0 = H / 4 * 4, h1 = H - 1, R1 = h1 / 4 * 4;
+        auto take_out = [&](int y, const uint16_t *row) {
+            const int y1 = y - 1;
+            const bool in0 = y < R0, in1 = y1 >= 4 && y1 < R1;
+            if (in0 && in1) return;
+            for (int x = 0; x < w; x++) {
+                const int v = row[x] & 16383;
+                if (!in0) { hb[(size_t)((y & 1) * 2 + (x & 1)) * 16384 + v]--; if ((x & 1) != (y & 1)) g0[(size_t)(y & 3) * 16384 + v]--; }
+                if (!in1 && (x & 1) == (y & 1)) g1[(size_t)(y1 & 3) * 16384 + v]--;
+            }
+        };
+        for (int y = 0; y < top_rows; y++) take_out(y, edge + (size_t)y * w);
+        for (int k = 0; k < bot_rows; k++) take_out(H - bot_rows + k, edge + (size_t)(top_rows + k) * w);
+        memcpy(hist.data() + DI_H_WHITE0, dev + DI_D_WHITE0, sizeof(unsigned) * 8 * 32768);
         return MLVFS_AMD_OK;
     };
     rc = analyse();
@@ -376,7 +431,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
 
     // ---- white levels (hdr.c:1806-1810)
     const int tail_rows = std::min(h, 32);
-    std::vector<uint16_t> tail((size_t)tail_rows * w);
+    struct { uint16_t *p; size_t n; uint16_t *data() const { return p; } size_t size() const { return n; } } tail{ (uint16_t *)(PH + ph_tail), (size_t)tail_rows * w };
     MLV_HIP(hipMemcpyAsync(tail.data(), img + (size_t)(h - tail_rows) * w, tail.size() * 2, hipMemcpyDeviceToHost, stream));
     MLV_HIP(hipStreamSynchronize(stream));
     int wd, wb;
@@ -401,8 +456,10 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     pt.mark("pattern + whites (host)");
     rc = di_launch_subsample(img, p, nsx, nsy, (int *)(B + o_ds), (int *)(B + o_bs), (unsigned *)(B + o_hb), (unsigned *)(B + o_hd), stream);
     if (rc) return rc;
-    std::vector<int> ds(std::max(nsamp, 1)), bs(std::max(nsamp, 1));
-    std::vector<unsigned> hb(DI_HIST_N), hd(DI_HIST_N);
+    struct IntSpan { int *p; int *data() const { return p; } int operator[](size_t i) const { return p[i]; } };
+    struct UintSpan { unsigned *p; size_t n; unsigned *data() const { return p; } const unsigned *begin() const { return p; } const unsigned *end() const { return p + n; } };
+    const IntSpan ds{ (int *)(PH + ph_ds) }, bs{ (int *)(PH + ph_bs) };
+    const UintSpan hb{ (unsigned *)(PH + ph_hb), (size_t)DI_HIST_N }, hd{ (unsigned *)(PH + ph_hd), (size_t)DI_HIST_N };
     MLV_HIP(hipMemcpyAsync(ds.data(), B + o_ds, (size_t)nsamp * 4, hipMemcpyDeviceToHost, stream));
     MLV_HIP(hipMemcpyAsync(bs.data(), B + o_bs, (size_t)nsamp * 4, hipMemcpyDeviceToHost, stream));
     MLV_HIP(hipMemcpyAsync(hb.data(), B + o_hb, sizeof(unsigned) * DI_HIST_N, hipMemcpyDeviceToHost, stream));

@@ -4,13 +4,18 @@
 
 namespace mlv {
 
-// histogram block produced by k_di_analyse (unsigned words)
+// histogram block the host decisions read (unsigned words), derived from the device block below
 constexpr size_t DI_H_BAYER = 0;                         // [4][16384]  (y%2)*2 + (x%2)
 constexpr size_t DI_H_GREEN0 = DI_H_BAYER + 4 * 16384;   // [4][16384]  greens by y%4, frame as is (RGGB)
 constexpr size_t DI_H_GREEN1 = DI_H_GREEN0 + 4 * 16384;  // [4][16384]  greens by y%4, frame minus its first row (GBRG)
 constexpr size_t DI_H_WHITE0 = DI_H_GREEN1 + 4 * 16384;  // [4][32768]  every 3rd pixel by y%4 (RGGB)
 constexpr size_t DI_H_WHITE1 = DI_H_WHITE0 + 4 * 32768;  // [4][32768]  (GBRG)
 constexpr size_t DI_HIST_WORDS = DI_H_WHITE1 + 4 * 32768;
+// what the device produces (k_di_analyse): class histograms [y % 4][x & 1][16384] over ALL rows + the two white blocks
+constexpr size_t DI_D_CLASS = 0;
+constexpr size_t DI_D_WHITE0 = DI_D_CLASS + 8 * 16384;
+constexpr size_t DI_D_WHITE1 = DI_D_WHITE0 + 4 * 32768;
+constexpr size_t DI_D_WORDS = DI_D_WHITE1 + 4 * 32768;
 
 constexpr int DI_HIST_OFF = 65536, DI_HIST_N = 131072;   // match_exposures histograms: value + OFF
 

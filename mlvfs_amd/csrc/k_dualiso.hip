@@ -3,11 +3,11 @@
 // The scalar decisions between the kernels (pattern, white levels, robust exposure
 // fit) run on the host from small device-built histograms (dualiso.cpp).
 //
-//   k_di_analyse    one pass over the 16-bit frame: hdr_check sum (hdr.c:407-439), the
-//                   four Bayer-phase histograms (identify_rggb_or_gbrg, :441-495), the
-//                   row-phase green histograms (:497-636) and the every-3rd-pixel white
-//                   histograms (:250-300), the latter two for both row parities
-//                   (RGGB and GBRG hypothesis) so one pass serves either outcome
+//   k_di_analyse    one pass over the 16-bit frame: hdr_check sum (hdr.c:407-439), value histograms per
+//                   (row phase, column parity) counted in LDS -- the host derives the four Bayer-phase
+//                   histograms (identify_rggb_or_gbrg, :441-495) and the row-phase green histograms
+//                   (:497-636) for both row parities (RGGB and GBRG hypothesis) from them -- and the
+//                   every-3rd-pixel white histograms (:250-300), also for both parities
 //   k_di_subsample  3x3-subsampled native/interpolated pairs + their histograms
 //                   (match_exposures, :650-722)
 //   k_di_score      RANSAC-like score of every candidate slope (:752-772)
@@ -34,19 +34,26 @@ namespace mlv {
 __device__ __forceinline__ int di_bright(const DiParams &p, int y) { return (p.is_bright_bits >> (y & 3)) & 1; }
 
 // ------------------------------------------------------------------ analysis
+// One workgroup = the rows of one phase (y % 4) of a 16-row band.  The 14-bit values of its pixels are counted per
+// column parity in LDS (two 16-bit counters per word: a band holds at most 4 * w / 2 < 65536 pixels per class), then
+// flushed with one global atomic per non-empty bin into the 8 class histograms [y % 4][x & 1][16384], from which the
+// host derives the Bayer-phase and the two green-by-row-phase histograms (dualiso.cpp).  The every-3rd-pixel "white"
+// histograms (1/9 of the pixels) and the hdr_check sum use global atomics directly.
+constexpr int DI_BAND = 16;
 __global__ __launch_bounds__(256) void k_di_analyse(const uint16_t *__restrict__ img, int w, int H, int black, int white,
                                                     const double *__restrict__ evf /* [16384] log2(i)*32768 */,
-                                                    unsigned *__restrict__ hist /* DiHist layout */, double *__restrict__ check /* sum, count */)
+                                                    unsigned *__restrict__ hist /* device layout, dualiso.h */, double *__restrict__ check /* sum, count */)
 {
-    __shared__ double s_sum[4];
-    __shared__ double s_cnt[4];
-    double sum = 0, cnt = 0;
-    const size_t n = (size_t)w * H;
-    unsigned *h_bayer = hist + DI_H_BAYER, *h_g0 = hist + DI_H_GREEN0, *h_g1 = hist + DI_H_GREEN1, *h_w0 = hist + DI_H_WHITE0,
-             *h_w1 = hist + DI_H_WHITE1;
-    const int h1 = H - 1;                                        // frame height under the GBRG hypothesis
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % w), y = (int)(i / w);
+    __shared__ unsigned cnt[16384];                          // slot = (x & 1) * 16384 + value; two slots per word
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    const int q = blockIdx.y, y_base = blockIdx.x * DI_BAND + q;
+    unsigned *h_w0 = hist + DI_D_WHITE0, *h_w1 = hist + DI_D_WHITE1;
+    double sum = 0, n = 0;
+    for (int k = threadIdx.x; k < (DI_BAND / 4) * w; k += blockDim.x) {
+        const int y = y_base + 4 * (k / w), x = k % w;
+        if (y >= H) break;
+        const size_t i = (size_t)y * w + x;
         const int p = img[i];
         if (y >= 2 && y < H - 2 && x >= 2 && x < w - 2) {        // hdr_check
             const int p2 = img[i + 2 * (size_t)w];
@@ -55,27 +62,26 @@ __global__ __launch_bounds__(256) void k_di_analyse(const uint16_t *__restrict__
                 const double ea = (a >= 0 && a < 16384) ? evf[a] : 0.0, eb = (b >= 0 && b < 16384) ? evf[b] : 0.0;
                 const double d = eb - ea;
                 sum += d > 0 ? d : -d;
-                cnt += 1;
+                n += 1;
             }
         }
-        const int v14 = p & 16383, vw = p < 32767 ? p : 32767;
-        if (y < H / 4 * 4) {
-            atomicAdd(&h_bayer[((y & 1) * 2 + (x & 1)) * 16384 + v14], 1u);
-            if ((x & 1) != (y & 1)) atomicAdd(&h_g0[(y & 3) * 16384 + v14], 1u);
-        }
+        const int slot = (x & 1) * 16384 + (p & 16383);
+        atomicAdd(&cnt[slot >> 1], 1u << (16 * (slot & 1)));
+        const int vw = p < 32767 ? p : 32767;
         if (y % 3 == 0 && x % 3 == 0) atomicAdd(&h_w0[(y & 3) * 32768 + vw], 1u);
         const int y1 = y - 1;                                    // row index in the frame that starts one row lower
-        if (y1 >= 4 && y1 < h1 / 4 * 4 && (x & 1) != (y1 & 1)) atomicAdd(&h_g1[(y1 & 3) * 16384 + v14], 1u);
         if (y1 >= 1 && y1 % 3 == 1 && x % 3 == 0) atomicAdd(&h_w1[(y1 & 3) * 32768 + vw], 1u);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); cnt += __shfl_xor(cnt, o); }
-    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_cnt[threadIdx.x >> 6] = cnt; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&check[0], s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
-        atomicAdd(&check[1], s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+    unsigned *cls = hist + DI_D_CLASS + (size_t)q * 2 * 16384;
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) {
+        const unsigned v = cnt[i];
+        if (v & 0xFFFFu) atomicAdd(&cls[2 * i], v & 0xFFFFu);
+        if (v >> 16) atomicAdd(&cls[2 * i + 1], v >> 16);
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); n += __shfl_xor(n, o); }
+    if ((threadIdx.x & 63) == 0 && n > 0) { atomicAdd(&check[0], sum); atomicAdd(&check[1], n); }
 }
 
 // ------------------------------------------------------------------ exposure matching
@@ -513,10 +519,10 @@ static inline dim3 flat_grid(size_t n) { size_t b = (n + 255) / 256; if (b > 819
 int di_launch_analyse(const void *d_img, int w, int H, int black, int white, const double *d_evf, unsigned *d_hist,
                       double *d_check, hipStream_t s)
 {
-    MLV_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * DI_HIST_WORDS, s));
+    MLV_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * DI_D_WORDS, s));
     MLV_HIP(hipMemsetAsync(d_check, 0, 2 * sizeof(double), s));
-    hipLaunchKernelGGL(k_di_analyse, flat_grid((size_t)w * H), dim3(256), 0, s, (const uint16_t *)d_img, w, H, black, white, d_evf,
-                       d_hist, d_check);
+    hipLaunchKernelGGL(k_di_analyse, dim3((H + DI_BAND - 1) / DI_BAND, 4), dim3(256), 0, s, (const uint16_t *)d_img, w, H, black, white,
+                       d_evf, d_hist, d_check);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
