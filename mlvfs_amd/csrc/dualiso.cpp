@@ -327,7 +327,8 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     auto take = [&](size_t bytes) { size_t o = off; off += up(bytes); return o; };
     const size_t o_hist = take(sizeof(unsigned) * DI_D_WORDS), o_check = take(16), o_ds = take(ns * 4), o_bs = take(ns * 4),
                  o_hb = take(sizeof(unsigned) * DI_HIST_N), o_hd = take(sizeof(unsigned) * DI_HIST_N), o_hi_d = take(ns / 25 * 4 + 65536),
-                 o_hi_b = take(ns / 25 * 4 + 65536), o_cand = take(8 * 2 * 3100), o_score = take(4 * 3100);
+                 o_hi_b = take(ns / 25 * 4 + 65536), o_cand = take(8 * 2 * 3100), o_score = take(4 * 3100),
+                 o_rows = take((size_t)nsy_max * 12);
     const size_t o_raw = take(N * 4), o_dark = take(N * 4), o_bright = take(N * 4), o_full = take(N * 4), o_half = take(N * 4),
                  o_over = take(N * 2), o_amap = take(N * 2), o_aux = take(N * 2), o_amap2 = take(N * 2);
     // an unknown method only logs in the reference (hdr.c:1518) and leaves the "smoothed" copies unsmoothed
@@ -346,7 +347,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     const size_t ph_hist = 0, ph_ds = ph_hist + sizeof(unsigned) * DI_HIST_WORDS, ph_bs = ph_ds + ns * 4, ph_hb = ph_bs + ns * 4,
                  ph_hd = ph_hb + sizeof(unsigned) * DI_HIST_N, ph_tail = ph_hd + sizeof(unsigned) * DI_HIST_N,
                  ph_dev = ph_tail + (size_t)32 * w * 2, ph_edge = ph_dev + sizeof(unsigned) * DI_D_WORDS,
-                 ph_end = ph_edge + (size_t)13 * w * 2;
+                 ph_rows = ph_edge + (size_t)13 * w * 2, ph_end = ph_rows + (size_t)nsy_max * 12;
     PinnedWork &pw = t_pinned[c->dev->id];
     rc = pw.ensure(ph_end);
     if (rc) return rc;
@@ -452,16 +453,11 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     // ---- match_exposures (hdr.c:638-823)
     const int y0 = ay1 + 2;
     const int nsy = (h - 2 > y0) ? (h - 2 - y0 + 2) / 3 : 0;
-    const int nsamp = nsx * nsy;
     pt.mark("pattern + whites (host)");
     rc = di_launch_subsample(img, p, nsx, nsy, (int *)(B + o_ds), (int *)(B + o_bs), (unsigned *)(B + o_hb), (unsigned *)(B + o_hd), stream);
     if (rc) return rc;
-    struct IntSpan { int *p; int *data() const { return p; } int operator[](size_t i) const { return p[i]; } };
     struct UintSpan { unsigned *p; size_t n; unsigned *data() const { return p; } const unsigned *begin() const { return p; } const unsigned *end() const { return p + n; } };
-    const IntSpan ds{ (int *)(PH + ph_ds) }, bs{ (int *)(PH + ph_bs) };
     const UintSpan hb{ (unsigned *)(PH + ph_hb), (size_t)DI_HIST_N }, hd{ (unsigned *)(PH + ph_hd), (size_t)DI_HIST_N };
-    MLV_HIP(hipMemcpyAsync(ds.data(), B + o_ds, (size_t)nsamp * 4, hipMemcpyDeviceToHost, stream));
-    MLV_HIP(hipMemcpyAsync(bs.data(), B + o_bs, (size_t)nsamp * 4, hipMemcpyDeviceToHost, stream));
     MLV_HIP(hipMemcpyAsync(hb.data(), B + o_hb, sizeof(unsigned) * DI_HIST_N, hipMemcpyDeviceToHost, stream));
     MLV_HIP(hipMemcpyAsync(hd.data(), B + o_hd, sizeof(unsigned) * DI_HIST_N, hipMemcpyDeviceToHost, stream));
     MLV_HIP(hipStreamSynchronize(stream));
@@ -474,17 +470,26 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     const int b_hi = kth_from_hist(hb.data(), DI_HIST_N, (long long)(n * 99.9 / 100)) - DI_HIST_OFF;
     const int dmed = kth_from_hist(hd.data(), DI_HIST_N, med_k(n)) - DI_HIST_OFF;
     const int nmax = (w + 2) * (h + 2) / 9, hi_nmax = nmax / 50;
-    std::vector<int> hi_d, hi_b;
-    hi_d.reserve(hi_nmax + nsy + 8); hi_b.reserve(hi_nmax + nsy + 8);
-    for (int sy = 0; sy < nsy; sy++)
-        for (int sx = 0; sx < nsx; sx++) {
-            const int d = ds[(size_t)sy * nsx + sx], b = bs[(size_t)sy * nsx + sx];
-            if (b >= b_hi || b <= b_lo) continue;
-            hi_d.push_back(d); hi_b.push_back(b);
-            if ((int)hi_d.size() >= hi_nmax) break;                   // leaves the x loop only (hdr.c:744)
-        }
+    // highlight pairs stay on the device: per-row counts -> what each row contributes.  A row appends its qualifying
+    // samples until the list has hi_nmax entries; the reference's `break` only leaves the inner loop (hdr.c:744), so
+    // once the cap is reached every further row still appends its first qualifying sample.
+    int *rowinfo = (int *)(PH + ph_rows);                       // counts | take | offset
+    rc = di_launch_hi_count((const int *)(B + o_bs), nsx, nsy, b_lo, b_hi, (int *)(B + o_rows), stream);
+    if (rc) return rc;
+    MLV_HIP(hipMemcpyAsync(rowinfo, B + o_rows, (size_t)nsy * 4, hipMemcpyDeviceToHost, stream));
+    MLV_HIP(hipStreamSynchronize(stream));
+    int hi_n = 0;
+    for (int sy = 0; sy < nsy; sy++) {
+        const int take = std::min(rowinfo[sy], std::max(hi_nmax - hi_n, 1));
+        rowinfo[nsy + sy] = take;
+        rowinfo[2 * nsy + sy] = hi_n;
+        hi_n += take;
+    }
+    MLV_HIP(hipMemcpyAsync(B + o_rows + (size_t)nsy * 4, rowinfo + nsy, (size_t)nsy * 8, hipMemcpyHostToDevice, stream));
+    rc = di_launch_hi_compact((const int *)(B + o_ds), (const int *)(B + o_bs), nsx, nsy, b_lo, b_hi, (const int *)(B + o_rows) + nsy,
+                              (const int *)(B + o_rows) + 2 * nsy, (int *)(B + o_hi_d), (int *)(B + o_hi_b), stream);
+    if (rc) return rc;
     pt.mark("subsample + D2H + quantiles");
-    const int hi_n = (int)hi_d.size();
     std::vector<double> cand;
     for (double ev = 0; ev < 6; ev += 0.002) {
         const double ta = pow(2, -ev);
@@ -494,8 +499,6 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     const int ncand = (int)cand.size() / 2;
     double a = 0, b = 0;
     if (hi_n > 0) {
-        MLV_HIP(hipMemcpyAsync(B + o_hi_d, hi_d.data(), (size_t)hi_n * 4, hipMemcpyHostToDevice, stream));
-        MLV_HIP(hipMemcpyAsync(B + o_hi_b, hi_b.data(), (size_t)hi_n * 4, hipMemcpyHostToDevice, stream));
         MLV_HIP(hipMemcpyAsync(B + o_cand, cand.data(), cand.size() * 8, hipMemcpyHostToDevice, stream));
         rc = di_launch_score((const int *)(B + o_hi_d), (const int *)(B + o_hi_b), hi_n, (const double *)(B + o_cand), ncand,
                              (int *)(B + o_score), stream);

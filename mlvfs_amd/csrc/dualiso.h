@@ -62,6 +62,9 @@ int di_launch_analyse(const void *d_img, int w, int H, int black, int white, con
                       double *d_check, hipStream_t s);
 int di_launch_subsample(const void *d_img, const DiParams &p, int nsx, int nsy, int *d_dark_s, int *d_bright_s,
                         unsigned *d_hist_b, unsigned *d_hist_d, hipStream_t s);
+int di_launch_hi_count(const int *d_bs, int nsx, int nsy, int b_lo, int b_hi, int *d_counts, hipStream_t s);
+int di_launch_hi_compact(const int *d_ds, const int *d_bs, int nsx, int nsy, int b_lo, int b_hi, const int *d_take, const int *d_offset,
+                         int *d_hd, int *d_hb, hipStream_t s);
 int di_launch_score(const int *d_hd, const int *d_hb, int hi_n, const double *d_cand, int ncand, int *d_score, hipStream_t s);
 int di_launch_match(const void *d_img, const DiParams &p, const DiPlanes &P, hipStream_t s);
 int di_launch_convert(const DiParams &p, const DiLuts &L, const DiPlanes &P, bool interp_done, void *d_out, hipStream_t s);

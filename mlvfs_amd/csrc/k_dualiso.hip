@@ -112,6 +112,54 @@ __global__ __launch_bounds__(256) void k_di_subsample(const uint16_t *__restrict
     }
 }
 
+// highlight pairs of match_exposures (hdr.c:735-746): the samples with b_lo < bright < b_hi in raster order.  One workgroup
+// per sample row counts them; the host turns the counts into how many each row contributes and where (the reference's
+// cap only leaves the inner loop, dualiso.cpp); the second kernel writes them in order.
+__device__ __forceinline__ bool di_hi_ok(int b, int b_lo, int b_hi) { return !(b >= b_hi || b <= b_lo); }
+
+__global__ __launch_bounds__(256) void k_di_hi_count(const int *__restrict__ bs, int nsx, int b_lo, int b_hi, int *__restrict__ counts)
+{
+    __shared__ int red[4];
+    const int *row = bs + (size_t)blockIdx.x * nsx;
+    int n = 0;
+    for (int x = threadIdx.x; x < nsx; x += blockDim.x) n += di_hi_ok(row[x], b_lo, b_hi);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void k_di_hi_compact(const int *__restrict__ ds, const int *__restrict__ bs, int nsx, int b_lo, int b_hi,
+                                                       const int *__restrict__ take, const int *__restrict__ offset,
+                                                       int *__restrict__ hd, int *__restrict__ hb)
+{
+    __shared__ int part[256];
+    const int lim = take[blockIdx.x];
+    if (lim <= 0) return;
+    const size_t base = (size_t)blockIdx.x * nsx;
+    const int per = (nsx + 255) / 256, x0 = threadIdx.x * per, x1 = min(x0 + per, nsx);     // consecutive samples per thread: keeps the order
+    int n = 0;
+    for (int x = x0; x < x1; x++) n += di_hi_ok(bs[base + x], b_lo, b_hi);
+    part[threadIdx.x] = n;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {                          // inclusive scan
+        const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int pos = part[threadIdx.x] - n;
+    const int out0 = offset[blockIdx.x];
+    for (int x = x0; x < x1 && pos < lim; x++) {
+        const int b = bs[base + x];
+        if (!di_hi_ok(b, b_lo, b_hi)) continue;
+        hd[out0 + pos] = ds[base + x];
+        hb[out0 + pos] = b;
+        pos++;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_di_score(const int *__restrict__ hd, const int *__restrict__ hb, int hi_n,
                                                   const double *__restrict__ cand /* [2*ncand]: a, b */, int *__restrict__ score)
 {
@@ -535,6 +583,21 @@ int di_launch_subsample(const void *d_img, const DiParams &p, int nsx, int nsy, 
     if (nsx * nsy > 0)
         hipLaunchKernelGGL(k_di_subsample, dim3((nsx * nsy + 255) / 256), dim3(256), 0, s, (const uint16_t *)d_img, p, nsx, nsy,
                            d_dark_s, d_bright_s, d_hist_b, d_hist_d);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+int di_launch_hi_count(const int *d_bs, int nsx, int nsy, int b_lo, int b_hi, int *d_counts, hipStream_t s)
+{
+    if (nsy > 0) hipLaunchKernelGGL(k_di_hi_count, dim3(nsy), dim3(256), 0, s, d_bs, nsx, b_lo, b_hi, d_counts);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+int di_launch_hi_compact(const int *d_ds, const int *d_bs, int nsx, int nsy, int b_lo, int b_hi, const int *d_take, const int *d_offset,
+                         int *d_hd, int *d_hb, hipStream_t s)
+{
+    if (nsy > 0) hipLaunchKernelGGL(k_di_hi_compact, dim3(nsy), dim3(256), 0, s, d_ds, d_bs, nsx, b_lo, b_hi, d_take, d_offset, d_hd, d_hb);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
