@@ -55,6 +55,7 @@ constexpr int STRIP = 4;                // cells per thread in the median phase
 constexpr int GROUPS = TCW / 8;         // full items per plane row (8)
 constexpr int N_FULL = PH * GROUPS;     // 160 full items per tile  (threads 0..159)
 constexpr int N_ITEMS = N_FULL + PH;    // + 20 edge items = 180    (threads 160..179)
+constexpr int PMAP_WORDS = 256;         // tiles per frame covered by the LDS patch bitmap: 8192 (3584x1320 has 1176)
 static_assert(N_ITEMS <= 256 && TCH * (TCW / STRIP) == 256, "one item and one strip per thread");
 
 struct FrameArgs {
@@ -83,6 +84,7 @@ struct __align__(16) Smem {
     int db[PH][PW];
     int ge[TCH][TCW];                   // 4 KiB
     uint16_t t16[MLV_T16_N];            // mantissa-normalised raw2ev (common.h), 16 KiB
+    uint32_t has_patch[PMAP_WORDS];     // one bit per tile of a frame: some pixel-map entry touches it (1 KiB)
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
@@ -511,6 +513,16 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         uint4 *dstl = (uint4 *)sm.t16;
         for (int i = threadIdx.x; i < MLV_T16_N * 2 / 16; i += blockDim.x) dstl[i] = src[i];
     }
+    // Which tiles of a frame have pixel-map entries: one bit per tile in LDS.  Reading the tile's list bounds from HBM in
+    // every iteration made each wave wait for ALL its outstanding loads (the prefetch of the next tile included) before the
+    // median phase; now only the few tiles that are touched fetch their bounds.
+    const bool pmap_ok = a.tiles_x * a.tiles_y <= PMAP_WORDS * 32;
+    if (a.patch && pmap_ok) {
+        for (int i = threadIdx.x; i < PMAP_WORDS; i += blockDim.x) sm.has_patch[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.tiles_x * a.tiles_y; i += blockDim.x)
+            if (a.tile_off[i + 1] != a.tile_off[i]) atomicOr(&sm.has_patch[i >> 5], 1u << (i & 31));
+    }
 
     // XCD-aware persistent tile walk: blocks b, b+8, b+16, ... share an XCD; give
     // every XCD a contiguous band of the tile list
@@ -556,17 +568,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         tile_coords(tt, f, tr, tx0, ty0);
         issue_item<PACKED>(r0, r1, a.src + (size_t)f * a.src_stride, a.w, a.h, tx0, ty0, load_tid);
     };
-    // patch-list bounds of a tile travel with its prefetch (software pipelined like the data)
-    int nbeg = 0, nend = 0;
-    auto issue_bounds = [&](int tt) {
-        if (a.patch) {
-            const int tr = tt % tiles_per_frame;
-            nbeg = a.tile_off[tr];
-            nend = a.tile_off[tr + 1];
-        }
-    };
     if (vec) issue_tile(min(t, max(total - 1, 0)));
-    issue_bounds(min(t, max(total - 1, 0)));
     __syncthreads();                           // T16 copy complete
 
     for (; t < band_end; t += slots) {
@@ -574,7 +576,6 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         tile_coords(t, f, tr, tx0, ty0);
         const uint8_t *frame = a.src + (size_t)f * a.src_stride;
         uint16_t *out = (uint16_t *)(a.dst + (size_t)f * a.dst_stride);
-        const int pbeg = nbeg, pend = nend;      // fetched one iteration ago, together with the tile data
         // ---- loader: prefetched registers -> EV planes + interior raw pixels
         if (has_item) {
             uint32_t p0[16], p1[16];
@@ -596,13 +597,13 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             emit_item<METHOD>(sm, a.black, slow, item_row, item_g, edge, p0, p1);
         }
         lds_barrier();
-        if (a.patch && pbeg != pend) {          // wave-uniform; list bounds were fetched at the top of the iteration
+        if (a.patch && (!pmap_ok || ((sm.has_patch[tr >> 5] >> (tr & 31)) & 1u))) {      // wave-uniform, rare
+            const int pbeg = a.tile_off[tr], pend = a.tile_off[tr + 1];
             apply_patches<METHOD, PACKED>(sm, a, frame, f, pbeg, pend, tx0, ty0);
             lds_barrier();
         }
         // ---- prefetch the next tile while the medians run
         if (vec) issue_tile(min(t + slots, band_end - 1));
-        issue_bounds(min(t + slots, band_end - 1));
 
         // ---- medians + output: one thread = 4 cells = 8 px on two rows
         const int y = ty0 + 2 * j, x = tx0 + 2 * STRIP * k;
