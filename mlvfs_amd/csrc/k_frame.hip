@@ -56,6 +56,7 @@ constexpr int GROUPS = TCW / 8;         // full items per plane row (8)
 constexpr int N_FULL = PH * GROUPS;     // 160 full items per tile  (threads 0..159)
 constexpr int N_ITEMS = N_FULL + PH;    // + 20 edge items = 180    (threads 160..179)
 constexpr int PMAP_WORDS = 256;         // tiles per frame covered by the LDS patch bitmap: 8192 (3584x1320 has 1176)
+constexpr int ENT_CAP = 32;             // pixel-map entries of one tile staged in LDS (more: the unstaged path)
 static_assert(N_ITEMS <= 256 && TCH * (TCW / STRIP) == 256, "one item and one strip per thread");
 
 struct FrameArgs {
@@ -85,6 +86,7 @@ struct __align__(16) Smem {
     int ge[TCH][TCW];                   // 4 KiB
     uint16_t t16[MLV_T16_N];            // mantissa-normalised raw2ev (common.h), 16 KiB
     uint32_t has_patch[PMAP_WORDS];     // one bit per tile of a frame: some pixel-map entry touches it (1 KiB)
+    int2 ent[ENT_CAP];                  // {pos, value} of the entries that touch the current tile (staged by the loader phase)
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
@@ -335,6 +337,40 @@ __device__ __forceinline__ void apply_patches(Smem &sm, const FrameArgs &a, cons
     }
 }
 
+// the same with the tile's `cnt` entries already staged in sm.ent (fetched while the loader phase ran)
+template <int METHOD, bool PACKED>
+__device__ __forceinline__ void apply_patches_staged(Smem &sm, const FrameArgs &a, const uint8_t *frame, int cnt, int tx0, int ty0)
+{
+    const int k = threadIdx.x;
+    if (k >= cnt) return;
+    const int2 e = sm.ent[k];
+    if (e.x < 0) return;
+    const int cx = (e.x % a.w) >> 1, cy = (e.x / a.w) >> 1;
+    const int i = cx - (tx0 / 2 - HC), j = cy - (ty0 / 2 - HC);
+    if (i < 0 || i >= PW || j < 0 || j >= PH) return;
+    int px[4];                                                  // r, g1, g2, b of that cell
+#pragma unroll
+    for (int q = 0; q < 4; q++) px[q] = (int)fetch_clamped<PACKED>(frame, a.w, a.h, 2 * cx + (q & 1), 2 * cy + (q >> 1));
+    for (int k2 = 0; k2 < cnt; k2++) {                          // all repaired pixels of this cell
+        const int2 e2 = sm.ent[k2];
+        if (e2.x < 0) continue;
+        const int x2 = e2.x % a.w, y2 = e2.x / a.w;
+        if ((x2 >> 1) == cx && (y2 >> 1) == cy) px[(x2 & 1) + 2 * (y2 & 1)] = e2.y & 0xFFFF;
+    }
+    int ge = 0, dr = 0, db = 0;
+    if (METHOD != 0) {
+        cell_ev(px[0], px[1], px[2], px[3], a.black, sm.t16, ge, dr, db);
+        sm.dr[j][i] = dr;
+        sm.db[j][i] = db;
+    }
+    const int ii = i - HC, jj = j - HC;
+    if (ii >= 0 && ii < TCW && jj >= 0 && jj < TCH) {
+        if (METHOD != 0) sm.ge[jj][ii] = ge;
+        *(uint32_t *)&sm.raw[2 * jj][2 * ii] = (uint32_t)px[0] | ((uint32_t)px[1] << 16);
+        *(uint32_t *)&sm.raw[2 * jj + 1][2 * ii] = (uint32_t)px[2] | ((uint32_t)px[3] << 16);
+    }
+}
+
 // ---------------------------------------------------------------- medians
 // 5x5: strip of 4 outputs from 8 sorted columns
 __device__ __forceinline__ void strip_median25(const int (*plane)[PW], int row_top, int col_left, int (&med)[STRIP])
@@ -576,6 +612,16 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         tile_coords(t, f, tr, tx0, ty0);
         const uint8_t *frame = a.src + (size_t)f * a.src_stride;
         uint16_t *out = (uint16_t *)(a.dst + (size_t)f * a.dst_stride);
+        // ---- pixel-map entries of this tile (few tiles have any): list bounds now -- the wait that the uniform load implies is
+        // for data the loader needs anyway --, the entries themselves in flight while the loader phase runs
+        const bool tile_patched = a.patch && (!pmap_ok || ((sm.has_patch[tr >> 5] >> (tr & 31)) & 1u));      // wave-uniform
+        int pbeg = 0, pend = 0;
+        int2 my_ent = make_int2(-1, 0);
+        if (tile_patched) {
+            pbeg = a.tile_off[tr];
+            pend = a.tile_off[tr + 1];
+            if (pend - pbeg <= ENT_CAP && pbeg + tid < pend) my_ent = (a.patches + (size_t)f * a.n_patch)[a.tile_ent[pbeg + tid]];
+        }
         // ---- loader: prefetched registers -> EV planes + interior raw pixels
         if (has_item) {
             uint32_t p0[16], p1[16];
@@ -596,10 +642,11 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             const bool slow = __any(odd);
             emit_item<METHOD>(sm, a.black, slow, item_row, item_g, edge, p0, p1);
         }
+        if (tile_patched && pend - pbeg <= ENT_CAP && tid < pend - pbeg) sm.ent[tid] = my_ent;
         lds_barrier();
-        if (a.patch && (!pmap_ok || ((sm.has_patch[tr >> 5] >> (tr & 31)) & 1u))) {      // wave-uniform, rare
-            const int pbeg = a.tile_off[tr], pend = a.tile_off[tr + 1];
-            apply_patches<METHOD, PACKED>(sm, a, frame, f, pbeg, pend, tx0, ty0);
+        if (tile_patched) {
+            if (pend - pbeg <= ENT_CAP) apply_patches_staged<METHOD, PACKED>(sm, a, frame, pend - pbeg, tx0, ty0);
+            else apply_patches<METHOD, PACKED>(sm, a, frame, f, pbeg, pend, tx0, ty0);
             lds_barrier();
         }
         // ---- prefetch the next tile while the medians run
