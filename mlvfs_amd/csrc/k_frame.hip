@@ -133,7 +133,12 @@ __device__ __forceinline__ void cell_pair_ev(const uint32_t *p0, const uint32_t 
 #pragma unroll
     for (int i = 0; i < 8; i++) lin[i] = px[i] - black;
 #pragma unroll
-    for (int i = 0; i < 8; i++) l[i] = slow ? min(max(lin[i], 1), 16383) : lin[i];
+    for (int i = 0; i < 8; i++) l[i] = lin[i];
+    if (slow) {                                         // wave-uniform BRANCH: the asm keeps it from becoming 16 selects on the fast path
+#pragma unroll
+        for (int i = 0; i < 8; i++) l[i] = min(max(lin[i], 1), 16383);
+        asm volatile("" ::: "memory");
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++) tv[i] = t[ev_index(l[i])];
     // opaque use: keeps the eight LDS reads unconditional and back to back (the compiler
@@ -541,8 +546,7 @@ __device__ __forceinline__ void stripe_strip_pk(uint32_t (&top)[STRIP], uint32_t
 template <int METHOD, bool PACKED, bool VEC>
 __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
+    __shared__ Smem sm;                                  // static: a compile-time LDS base (a dynamic one costs an add per access)
 
     if (METHOD != 0) {
         const uint4 *src = (const uint4 *)a.t16;
@@ -740,13 +744,12 @@ static int launch_frame_t(const FrameArgs &a, int num_cu, hipStream_t stream)
     int grid = num_cu > 0 ? num_cu * 4 : 1024;          // 4 workgroups per CU (39 KiB LDS, <= 128 VGPRs)
     grid = (grid + 7) / 8 * 8;
     if (grid > total) grid = (int)((total + 7) / 8 * 8);
-    const size_t shmem = sizeof(Smem);
+    static_assert(sizeof(Smem) <= 40 * 1024 + 192, "four workgroups per CU need <= 40 KiB of LDS each");
     auto kern = k_frame<METHOD, PACKED, VEC>;
-    MLV_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     KernelTimer &tm = kernel_timer();
     const bool timed = tm.on && tm.used + 2 <= (int)tm.ev.size();
     if (timed) MLV_HIP(hipEventRecord(tm.ev[tm.used], stream));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, stream, a);
     if (timed) { MLV_HIP(hipEventRecord(tm.ev[tm.used + 1], stream)); tm.used += 2; }
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
