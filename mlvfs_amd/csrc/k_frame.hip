@@ -129,27 +129,29 @@ __device__ __forceinline__ void cell_pair_ev(const uint32_t *p0, const uint32_t 
                                              int (&ge)[2], int (&dr)[2], int (&db)[2])
 {
     const int px[8] = { (int)p0[0], (int)p0[1], (int)p1[0], (int)p1[1], (int)p0[2], (int)p0[3], (int)p1[2], (int)p1[3] };
-    int lin[8], l[8], tv[8], ev[8];
+    int lin[8], tv[8], ev[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) lin[i] = px[i] - black;
+    if (!slow) {                                        // wave-uniform: two separate paths, so the common one carries no selects or copies
 #pragma unroll
-    for (int i = 0; i < 8; i++) l[i] = lin[i];
-    if (slow) {                                         // wave-uniform BRANCH: the asm keeps it from becoming 16 selects on the fast path
+        for (int i = 0; i < 8; i++) tv[i] = t[ev_index(lin[i])];
+        // opaque use: keeps the eight LDS reads unconditional and back to back (the compiler
+        // otherwise sinks each read next to its use and waits for it there)
+        asm volatile("" :: "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]), "v"(tv[4]), "v"(tv[5]), "v"(tv[6]), "v"(tv[7]));
+#pragma unroll
+        for (int i = 0; i < 8; i++) ev[i] = ev_value(lin[i], tv[i]);
+    } else {
+        int l[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) l[i] = min(max(lin[i], 1), 16383);
-        asm volatile("" ::: "memory");
-    }
 #pragma unroll
-    for (int i = 0; i < 8; i++) tv[i] = t[ev_index(l[i])];
-    // opaque use: keeps the eight LDS reads unconditional and back to back (the compiler
-    // otherwise sinks each read into a branch next to its use and waits for it there)
-    asm volatile("" :: "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]), "v"(tv[4]), "v"(tv[5]), "v"(tv[6]), "v"(tv[7]));
+        for (int i = 0; i < 8; i++) tv[i] = t[ev_index(l[i])];
+        asm volatile("" :: "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]), "v"(tv[4]), "v"(tv[5]), "v"(tv[6]), "v"(tv[7]));
 #pragma unroll
-    for (int i = 0; i < 8; i++) ev[i] = ev_value(l[i], tv[i]);
-    if (slow) {
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-            ev[i] = ((unsigned)(lin[i] - 1) < 16383u) ? ev[i] : (lin[i] == 0 ? (int)0x80000000 : 0);
+        for (int i = 0; i < 8; i++) {
+            const int e = ev_value(l[i], tv[i]);
+            ev[i] = ((unsigned)(lin[i] - 1) < 16383u) ? e : (lin[i] == 0 ? (int)0x80000000 : 0);
+        }
     }
 #pragma unroll
     for (int c = 0; c < 2; c++) {
