@@ -182,11 +182,12 @@ template <bool PACKED> struct Words { static constexpr int N = PACKED ? 7 : 8; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // byte offset of the 16-px group starting at pixel (x, y) inside a frame
+// (32-bit: a frame is far below 4 GiB, checked by the launcher; the 64-bit form cost ten 64-bit multiply-adds per prefetch)
 template <bool PACKED>
-__device__ __forceinline__ size_t group_offset(int w, int x, int y)
+__device__ __forceinline__ uint32_t group_offset(int w, int x, int y)
 {
-    const size_t px = (size_t)y * w + x;
-    return PACKED ? px / 16 * 28 : px * 2;
+    const uint32_t px = (uint32_t)y * (uint32_t)w + (uint32_t)x;
+    return PACKED ? (px >> 4) * 28u : px * 2u;
 }
 
 template <bool PACKED>
@@ -766,7 +767,10 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
         set_error("too many tiles in one launch (%d frames): split the batch", nframes);
         return MLVFS_AMD_ERR_ARG;
     }
-    if (g.w < 2 || g.h < 2 || (g.w & 1)) { set_error("frame geometry %dx%d unsupported", g.w, g.h); return MLVFS_AMD_ERR_ARG; }
+    if (g.w < 2 || g.h < 2 || (g.w & 1) || (long long)g.w * g.h >= (1ll << 30)) {      // 32-bit byte offsets inside a frame
+        set_error("frame geometry %dx%d unsupported", g.w, g.h);
+        return MLVFS_AMD_ERR_ARG;
+    }
     if (packed && g.bpp != 14) { set_error("fused path needs 14-bit input"); return MLVFS_AMD_ERR_ARG; }
     FrameArgs a{};
     a.src = (const uint8_t *)src; a.src_stride = src_stride;
