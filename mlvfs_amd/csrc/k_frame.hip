@@ -182,7 +182,7 @@ template <bool PACKED> struct Words { static constexpr int N = PACKED ? 7 : 8; }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // byte offset of the 16-px group starting at pixel (x, y) inside a frame
-// (32-bit: a frame is far below 4 GiB, checked by the launcher; the 64-bit form cost ten 64-bit multiply-adds per prefetch)
+// (32-bit: a frame has fewer than 2^28 pixels, checked by the launcher; the 64-bit form cost ten 64-bit multiply-adds per prefetch)
 template <bool PACKED>
 __device__ __forceinline__ uint32_t group_offset(int w, int x, int y)
 {
@@ -245,10 +245,10 @@ __device__ __forceinline__ uint32_t fetch_clamped(const uint8_t *frame, int w, i
 {
     x = clampi(x, 0, w - 1);
     y = clampi(y, 0, h - 1);
-    const size_t i = (size_t)y * w + x;
+    const uint32_t i = (uint32_t)y * (uint32_t)w + (uint32_t)x;
     if (PACKED) {
         const uint16_t *s = (const uint16_t *)frame;
-        const size_t bit = i * 14;
+        const uint32_t bit = i * 14u;                    // < 2^28 pixels per frame (launcher): fits
         const uint32_t two = ((uint32_t)s[bit >> 4] << 16) | s[(bit >> 4) + 1];
         return (two >> (32 - 14 - (bit & 15))) & 0x3FFFu;
     }
@@ -719,8 +719,9 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         if (y < a.h) {
             if (vec) {
                 if (x < a.w) {
-                    *(uint4 *)(out + (size_t)y * a.w + x) = make_uint4(top[0], top[1], top[2], top[3]);
-                    if (y + 1 < a.h) *(uint4 *)(out + (size_t)(y + 1) * a.w + x) = make_uint4(bot[0], bot[1], bot[2], bot[3]);
+                    const uint32_t o = (uint32_t)y * (uint32_t)a.w + (uint32_t)x;           // < 2^28 pixels per frame
+                    *(uint4 *)(out + o) = make_uint4(top[0], top[1], top[2], top[3]);
+                    if (y + 1 < a.h) *(uint4 *)(out + o + (uint32_t)a.w) = make_uint4(bot[0], bot[1], bot[2], bot[3]);
                 }
             } else {
 #pragma unroll 1
@@ -767,7 +768,7 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
         set_error("too many tiles in one launch (%d frames): split the batch", nframes);
         return MLVFS_AMD_ERR_ARG;
     }
-    if (g.w < 2 || g.h < 2 || (g.w & 1) || (long long)g.w * g.h >= (1ll << 30)) {      // 32-bit byte offsets inside a frame
+    if (g.w < 2 || g.h < 2 || (g.w & 1) || (long long)g.w * g.h >= (1ll << 28)) {      // 32-bit bit / byte offsets inside a frame
         set_error("frame geometry %dx%d unsupported", g.w, g.h);
         return MLVFS_AMD_ERR_ARG;
     }
