@@ -43,11 +43,12 @@ __global__ __launch_bounds__(256) void k_pn_transpose(const int16_t *__restrict_
     }
 }
 
-// lower median of v[lo..hi] (inclusive, LDS int16) by bisection
+// lower median of v[lo..hi] (inclusive, LDS int16) by bisection on the value, bracketed by the run's extremes
 __device__ __forceinline__ int lower_median_run(const int16_t *v, int lo, int hi)
 {
     const int n = hi - lo + 1, need = (n - 1) / 2 + 1;
-    int a = -32768, b = 32767;
+    int a = v[lo], b = a;
+    for (int i = lo + 1; i <= hi; i++) { const int x = v[i]; a = min(a, x); b = max(b, x); }
     while (a < b) {
         const int mid = (a + b) >> 1;                        // floor
         int cnt = 0;
@@ -105,44 +106,45 @@ __device__ __forceinline__ bool noise_at(const int16_t *raw, int w, int hw, size
     return !((abs(grad) > 500) || (o >= white));
 }
 
-// one workgroup (256 threads) per (column, plane)
+// one workgroup (256 threads) per (column, plane): the column's noise samples are computed once into LDS
+// (masked samples as a sentinel above every int16), then bisected between their extremes
+constexpr int PN_MAX_ROWS = 8192;
 __global__ __launch_bounds__(256) void k_pn_column_offsets(const int16_t *__restrict__ raw, int w, int hw, int hh, int white,
                                                            const int16_t *__restrict__ smooth, int *__restrict__ offs /* [4][hw] */)
 {
-    __shared__ int red[4];
-    __shared__ int s_a, s_b, s_n;
+    extern __shared__ int samples[];                         // hh entries
+    __shared__ int red[4], red2[4], red3[4];
     const int x = blockIdx.x, c = blockIdx.y;
     const size_t n = (size_t)hw * hh;
     const int16_t *sm = smooth + (size_t)c * n;
-    auto block_sum = [&](int v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-        __syncthreads();
-        return red[0] + red[1] + red[2] + red[3];
-    };
-    // unmasked sample count
-    int cnt = 0;
+    constexpr int MASKED = 1 << 20;
+    int cnt = 0, lo = 32767, hi = -32768;
     for (int y = threadIdx.x; y < hh; y += blockDim.x) {
         int nz;
-        cnt += noise_at(raw, w, hw, n, c, sm, (size_t)x + (size_t)y * hw, white, nz) ? 1 : 0;
+        const bool ok = noise_at(raw, w, hw, n, c, sm, (size_t)x + (size_t)y * hw, white, nz);
+        samples[y] = ok ? nz : MASKED;
+        if (ok) { cnt++; lo = min(lo, nz); hi = max(hi, nz); }
     }
-    const int k = block_sum(cnt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o); lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = cnt; red2[threadIdx.x >> 6] = lo; red3[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    const int k = red[0] + red[1] + red[2] + red[3];
     if (k < 10) { if (threadIdx.x == 0) offs[c * hw + x] = 0; return; }      // patternnoise.c:250
+    int a = min(min(red2[0], red2[1]), min(red2[2], red2[3])), b = max(max(red3[0], red3[1]), max(red3[2], red3[3]));
     const int need = (k - 1) / 2 + 1;
-    int a = -32768, b = 32767;
     while (a < b) {
         const int mid = (a + b) >> 1;
         int le = 0;
-        for (int y = threadIdx.x; y < hh; y += blockDim.x) {
-            int nz;
-            if (noise_at(raw, w, hw, n, c, sm, (size_t)x + (size_t)y * hw, white, nz)) le += (nz <= mid);
-        }
-        if (block_sum(le) >= need) b = mid; else a = mid + 1;
+        for (int y = threadIdx.x; y < hh; y += blockDim.x) le += (samples[y] <= mid);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) le += __shfl_xor(le, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = le;
+        __syncthreads();
+        if (red[0] + red[1] + red[2] + red[3] >= need) b = mid; else a = mid + 1;
     }
     if (threadIdx.x == 0) offs[c * hw + x] = -a;
-    (void)s_a; (void)s_b; (void)s_n;
 }
 
 // lower median of offs[c][0..hw) ; one workgroup per plane
@@ -187,7 +189,8 @@ static int column_pass(int16_t *d_raw, int w, int h, int white, int16_t *d_smoot
     if (shmem > 150 * 1024) { set_error("fix_pattern_noise: rows of %d pixels do not fit in LDS", w); return MLVFS_AMD_ERR_ARG; }
     MLV_HIP(hipFuncSetAttribute((const void *)k_pn_smooth, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(k_pn_smooth, dim3(hh), dim3(256), shmem, stream, d_raw, w, hw, 50 / 2, 500, d_smooth, hh);
-    hipLaunchKernelGGL(k_pn_column_offsets, dim3(hw, 4), dim3(256), 0, stream, d_raw, w, hw, hh, white, d_smooth, d_offs);
+    if (hh > PN_MAX_ROWS) { set_error("fix_pattern_noise: columns of %d pixels do not fit in LDS", h); return MLVFS_AMD_ERR_ARG; }
+    hipLaunchKernelGGL(k_pn_column_offsets, dim3(hw, 4), dim3(256), (size_t)hh * sizeof(int), stream, d_raw, w, hw, hh, white, d_smooth, d_offs);
     hipLaunchKernelGGL(k_pn_offset_median, dim3(4), dim3(256), 0, stream, d_offs, hw, d_mc);
     hipLaunchKernelGGL(k_pn_apply, dim3((w + 255) / 256, h), dim3(256), 0, stream, d_raw, w, h, hw, d_offs, d_mc);
     MLV_HIP(hipGetLastError());
