@@ -78,7 +78,8 @@ def glibc_rand_slice(first_call: int, n_calls: int) -> np.ndarray:
     """rand()%1024 values 2*first_call .. 2*(first_call+n_calls)-1 of a fresh process (seed 1)."""
     from . import lib
     L = lib.load()
-    out = np.zeros(2 * n_calls + 2, np.uint16)
+    out = np.empty(2 * n_calls + 2, np.uint16)       # filled (and first touched) by the library's generator threads
+    out[-2:] = 0
     L.mlvfs_amd_rand_stream(lib.ptr(out), 2 * n_calls, 2 * first_call, 1)
     return out
 
