@@ -52,6 +52,19 @@ struct Device {            // one per GPU, created once
     int num_cu = 0;
 };
 
+// The reference draws its stripes dither from the process-global libc rand() stream (stripes.c:129-130) and nothing else in
+// a CPU-only MLVFS touches that stream.  The HIP runtime does (measured: a plain C host that calls the drop-in symbols gets
+// other stripe coefficients than the reference because rand() values disappear during runtime initialisation), so every
+// drop-in entry point parks the application's generator state while HIP code may run and puts it back on return; the dither
+// itself is drawn from the application's state.  Nests across threads (first in switches, last out restores).
+struct LibcRandGuard {
+    LibcRandGuard();
+    ~LibcRandGuard();
+    LibcRandGuard(const LibcRandGuard &) = delete;
+    LibcRandGuard &operator=(const LibcRandGuard &) = delete;
+    static void draw_mod1024(uint16_t *out, long long n);      // n values of rand() % 1024 from the APPLICATION's stream
+};
+
 struct ThreadCtx {         // one per (host thread, device)
     Device *dev = nullptr;
     hipStream_t stream = nullptr;

@@ -105,6 +105,7 @@ size_t dng_get_size(struct frame_headers *fh) { return dng_get_header_size() + d
 size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8_t *output_buffer, off_t offset,
                           size_t max_size)
 {
+    LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     const int bpp = fh->rawi_hdr.raw_info.bits_per_pixel;
     // window arithmetic of dng.c:815-826
     const uint32_t first_px = (uint32_t)(offset > 0 ? offset : 0) / 2;
@@ -135,6 +136,7 @@ size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8
 // ============================================================== cs.h
 void chroma_smooth(struct frame_headers *fh, uint16_t *image_data, int method)
 {
+    LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     const FrameView v = view_of(fh);
     if (v.black > 16384) { fprintf(stderr, "Black level too large for processing\n"); return; }   // main.c:170-174
     if (method != 2 && method != 3 && method != 5) { fprintf(stderr, "Unsupported chroma smooth method\n"); return; }
@@ -255,6 +257,7 @@ extern "C" {
 
 void fix_bad_pixels(struct frame_headers *fh, uint16_t *image_data, int aggressive, int dual_iso)
 {
+    LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     ThreadCtx *c = thread_ctx();
     if (!c) return;
     const size_t bytes = (size_t)fh->rawi_hdr.xRes * fh->rawi_hdr.yRes * 2;
@@ -267,6 +270,7 @@ void fix_bad_pixels(struct frame_headers *fh, uint16_t *image_data, int aggressi
 
 void fix_focus_pixels(struct frame_headers *fh, uint16_t *image_data, int dual_iso)
 {
+    LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     ThreadCtx *c = nullptr;
     // no map file for this camera is the common case: decide before touching the GPU
     {
@@ -285,6 +289,7 @@ void fix_focus_pixels(struct frame_headers *fh, uint16_t *image_data, int dual_i
 
 void free_focus_pixel_maps(void)                                                     // cs.c:403-418
 {
+    LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     {
         std::lock_guard<std::mutex> lk(g_focus_mutex);
         for (FocusMap *m : g_focus_maps) {
@@ -330,6 +335,7 @@ struct stripes_correction *stripes_new_correction(const char *mlv_filename)     
 
 void stripes_free_corrections(void)                                                  // stripes.c:71-83
 {
+    LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     std::lock_guard<std::mutex> lk(g_corr_mutex);
     struct stripes_correction *cur = g_corrections;
     while (cur) {
@@ -344,6 +350,7 @@ void stripes_free_corrections(void)                                             
 void stripes_compute_correction(struct frame_headers *fh, struct stripes_correction *correction, uint16_t *image_data,
                                 off_t offset, size_t size)
 {
+    LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     (void)offset; (void)size;                       // the reference ignores both and walks xRes x yRes (stripes.c:153-156)
     if (!correction) return;
     const FrameView v = view_of(fh);
@@ -363,6 +370,7 @@ void stripes_compute_correction(struct frame_headers *fh, struct stripes_correct
 void stripes_apply_correction(struct frame_headers *fh, struct stripes_correction *correction, uint16_t *image_data,
                               off_t offset, size_t size)
 {
+    LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     if (!correction || !correction->correction_needed) return;                       // stripes.c:252-253
     const FrameView v = view_of(fh);
     if (v.w % 8 != 0 || size == 0) return;

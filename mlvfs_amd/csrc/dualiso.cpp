@@ -605,6 +605,7 @@ extern "C" {
 int cr2hdr20_convert_data(struct frame_headers *fh, uint16_t *image_data, int interp_method, int fullres, int use_alias_map,
                           int chroma_smooth, int fix_bad_pixels_mode)
 {
+    LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     const int w = fh->rawi_hdr.xRes, h = fh->rawi_hdr.yRes;
     ThreadCtx *c = thread_ctx();
     if (!c) return 0;

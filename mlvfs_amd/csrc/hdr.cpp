@@ -130,6 +130,7 @@ void fix_focus_pixels(struct frame_headers *fh, uint16_t *image_data, int dual_i
 
 int hdr_convert_data(struct frame_headers *fh, uint16_t *image_data, off_t offset, size_t max_size)
 {
+    LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     (void)offset;                                                       // unused by the reference as well
     const int w = fh->rawi_hdr.xRes, h = fh->rawi_hdr.yRes;
     const Geom g{ w, h, fh->rawi_hdr.raw_info.bits_per_pixel, fh->rawi_hdr.raw_info.black_level,

@@ -13,6 +13,7 @@ using namespace mlv;
 
 extern "C" void fix_pattern_noise(int16_t *raw, int w, int h, int white, int debug_flags)
 {
+    LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     printf("Fixing pattern noise...\n");                                   // patternnoise.c:359
     if (debug_flags != 0) { set_error("fix_pattern_noise: debug_flags %d not supported (frame left untouched)", debug_flags); return; }
     if (w < 2 || h < 2 || (w & 1) || (h & 1)) { set_error("fix_pattern_noise: %dx%d frame not supported", w, h); return; }

@@ -28,6 +28,39 @@ int *get_ev2raw(void) __attribute__((weak));
 
 namespace mlv {
 
+namespace {
+std::mutex g_rg_mu;
+int g_rg_depth = 0;
+bool g_rg_init = false;
+char *g_rg_app = nullptr;
+char g_rg_parked[128];                                  // a TYPE_3 state for whoever calls rand() while the application's is parked
+}  // namespace
+
+LibcRandGuard::LibcRandGuard()
+{
+    std::lock_guard<std::mutex> lk(g_rg_mu);
+    if (g_rg_depth++ == 0) {
+        if (!g_rg_init) { g_rg_app = initstate(0x5eedu, g_rg_parked, sizeof g_rg_parked); g_rg_init = true; }
+        else g_rg_app = setstate(g_rg_parked);
+    }
+}
+
+LibcRandGuard::~LibcRandGuard()
+{
+    std::lock_guard<std::mutex> lk(g_rg_mu);
+    if (--g_rg_depth == 0 && g_rg_app) (void)setstate(g_rg_app);
+}
+
+void LibcRandGuard::draw_mod1024(uint16_t *out, long long n)
+{
+    std::lock_guard<std::mutex> lk(g_rg_mu);
+    const bool parked = g_rg_depth > 0 && g_rg_app;
+    if (parked) (void)setstate(g_rg_app);
+    for (long long i = 0; i < n; i++) out[i] = (uint16_t)(rand() % 1024);
+    if (parked) (void)setstate(g_rg_parked);
+}
+
+
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
 

@@ -1,0 +1,54 @@
+/* A plain C host -- no Python, no torch -- that links libmlvfs_amd.so the way MLVFS would
+ * and runs process_frame's call sequence (mlvfs/main.c:942-997) on one frame read from a file.
+ *   c_host <in: packed 14-bit words> <out: u16 pixels> w h black white cs bad_pixels stripes
+ * The caller's table accessors (get_raw2ev / get_ev2raw, mlvfs/main.c:128-196) are deliberately NOT provided: the
+ * library then builds the tables itself, as it does under Python.  tests/test_gpu_c_host.py compares the output with
+ * the oracle. */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "mlvfs_abi.h"
+#include "mlvfs_amd.h"
+
+int main(int argc, char **argv)
+{
+    if (argc != 10) { fprintf(stderr, "usage\n"); return 2; }
+    const int w = atoi(argv[3]), h = atoi(argv[4]), black = atoi(argv[5]), white = atoi(argv[6]);
+    const int cs = atoi(argv[7]), bad = atoi(argv[8]), stripes = atoi(argv[9]);
+    struct frame_headers fh;
+    memset(&fh, 0, sizeof fh);
+    fh.rawi_hdr.xRes = (uint16_t)w; fh.rawi_hdr.yRes = (uint16_t)h;
+    fh.rawi_hdr.raw_info.width = w; fh.rawi_hdr.raw_info.height = h;
+    fh.rawi_hdr.raw_info.bits_per_pixel = 14;
+    fh.rawi_hdr.raw_info.pitch = w * 14 / 8;
+    fh.rawi_hdr.raw_info.frame_size = w * h * 14 / 8;
+    fh.rawi_hdr.raw_info.black_level = black; fh.rawi_hdr.raw_info.white_level = white;
+    const size_t npix = (size_t)w * h, nwords = (npix * 14 + 15) / 16 + 4;
+    uint16_t *packed = calloc(nwords, 2), *img = malloc(npix * 2);
+    FILE *f = fopen(argv[1], "rb");
+    if (!f || !packed || !img) return 3;
+    const size_t got = fread(packed, 2, nwords, f);
+    fclose(f);
+    (void)got;
+    if (dng_get_image_data(&fh, packed, (uint8_t *)img, 0, npix * 2) != npix * 2) { fprintf(stderr, "unpack failed\n"); return 4; }
+    fix_focus_pixels(&fh, img, 0);
+    if (bad) fix_bad_pixels(&fh, img, bad == 2, 0);
+    if (cs) chroma_smooth(&fh, img, cs);
+    if (stripes) {
+        struct stripes_correction *c = stripes_get_correction("c_host.MLV");
+        if (!c) {
+            c = stripes_new_correction("c_host.MLV");
+            if (c) stripes_compute_correction(&fh, c, img, 0, npix);
+        }
+        stripes_apply_correction(&fh, c, img, 0, npix);
+    }
+    f = fopen(argv[2], "wb");
+    if (!f) return 5;
+    fwrite(img, 2, npix, f);
+    fclose(f);
+    stripes_free_corrections();
+    free_focus_pixel_maps();
+    free(packed); free(img);
+    return 0;
+}

@@ -1,0 +1,43 @@
+"""The drop-in boundary from a plain C program: tests/c_host.c is compiled with gcc against include/*.h, linked with
+libmlvfs_amd.so and the system HIP runtime, and run as its own process (no Python, no torch in it) through
+process_frame's call sequence.  Its output must equal the oracle's."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from mlvfs_amd import lib, synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+BLACK, WHITE = synth.BLACK, synth.WHITE
+
+
+@pytest.fixture(scope="module")
+def c_host(tmp_path_factory, gpu):
+    exe = tmp_path_factory.mktemp("c_host") / "c_host"
+    so_dir = os.path.dirname(lib.SO_PATH)
+    cmd = ["gcc", "-std=gnu99", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "c_host.c"), "-o", str(exe),
+           "-L", so_dir, "-lmlvfs_amd", "-Wl,-rpath," + so_dir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"]
+    subprocess.run(cmd, check=True)
+    return str(exe)
+
+
+@pytest.mark.parametrize("cs,bad,stripes", [(5, 1, 1), (2, 0, 0), (3, 2, 1)])
+def test_c_program_through_the_drop_in_symbols(c_host, oracle, tmp_path, cs, bad, stripes):
+    w, h = 416, 264
+    f = synth.normal_frame(w, h, seed=21)
+    packed = synth.pack_bits(f)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    np.ascontiguousarray(packed, "<u2").tofile(fin)
+    res = subprocess.run([c_host, str(fin), str(fout), str(w), str(h), str(BLACK), str(WHITE), str(cs), str(bad), str(stripes)],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    got = np.fromfile(fout, "<u2").reshape(h, w)
+    # The C process starts from srand(1) like a fresh MLVFS and the oracle's stripes_compute does the same.  The HIP runtime
+    # consumes rand() values of its own while it initialises: the library parks the caller's generator state around its HIP
+    # work (LibcRandGuard), otherwise the stripe coefficients here would differ from the reference's.
+    want, _ = oracle.process_frame(packed, w, h, BLACK, WHITE, cs, bad, stripes)
+    assert np.array_equal(got, want), f"{(got != want).sum()} px differ (column phases {np.unique(np.nonzero(got != want)[1] % 8)})"
