@@ -15,12 +15,17 @@ ROOT = os.path.dirname(HERE)
 BLACK, WHITE = synth.BLACK, synth.WHITE
 
 
-@pytest.fixture(scope="module")
-def c_host(tmp_path_factory, gpu):
+@pytest.fixture(scope="module", params=["library builds the tables", "caller provides get_raw2ev / get_ev2raw"])
+def c_host(request, tmp_path_factory, gpu):
+    """Two hosts: a bare one, and one that -- like MLVFS's main.c (mlvfs.h:90-92) -- exports the table accessors the library
+    imports weakly (their definitions come from oracle/ref_luts.c, the caller's part of the reference build)."""
     exe = tmp_path_factory.mktemp("c_host") / "c_host"
     so_dir = os.path.dirname(lib.SO_PATH)
-    cmd = ["gcc", "-std=gnu99", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "c_host.c"), "-o", str(exe),
-           "-L", so_dir, "-lmlvfs_amd", "-Wl,-rpath," + so_dir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"]
+    srcs = [os.path.join(HERE, "c_host.c")]
+    if request.param.startswith("caller"):
+        srcs.append(os.path.join(ROOT, "oracle", "ref_luts.c"))
+    cmd = ["gcc", "-std=gnu99", "-O1", "-rdynamic", "-I", os.path.join(ROOT, "include"), *srcs, "-o", str(exe),
+           "-L", so_dir, "-lmlvfs_amd", "-Wl,-rpath," + so_dir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-lm"]
     subprocess.run(cmd, check=True)
     return str(exe)
 
