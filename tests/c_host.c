@@ -1,6 +1,6 @@
 /* A plain C host -- no Python, no torch -- that links libmlvfs_amd.so the way MLVFS would
  * and runs process_frame's call sequence (mlvfs/main.c:942-997) on one frame read from a file.
- *   c_host <in: packed 14-bit words> <out: u16 pixels> w h black white cs bad_pixels stripes
+ *   c_host <in: packed 14-bit words> <out: u16 pixels> w h black white cs bad_pixels stripes [dual_iso: 1 preview, 2 full]
  * The caller's table accessors (get_raw2ev / get_ev2raw, mlvfs/main.c:128-196) are deliberately NOT provided: the
  * library then builds the tables itself, as it does under Python.  tests/test_gpu_c_host.py compares the output with
  * the oracle. */
@@ -13,7 +13,8 @@
 
 int main(int argc, char **argv)
 {
-    if (argc != 10) { fprintf(stderr, "usage\n"); return 2; }
+    if (argc != 10 && argc != 11) { fprintf(stderr, "usage\n"); return 2; }
+    const int dual_iso = argc == 11 ? atoi(argv[10]) : 0;
     const int w = atoi(argv[3]), h = atoi(argv[4]), black = atoi(argv[5]), white = atoi(argv[6]);
     const int cs = atoi(argv[7]), bad = atoi(argv[8]), stripes = atoi(argv[9]);
     struct frame_headers fh;
@@ -32,9 +33,14 @@ int main(int argc, char **argv)
     fclose(f);
     (void)got;
     if (dng_get_image_data(&fh, packed, (uint8_t *)img, 0, npix * 2) != npix * 2) { fprintf(stderr, "unpack failed\n"); return 4; }
-    fix_focus_pixels(&fh, img, 0);
-    if (bad) fix_bad_pixels(&fh, img, bad == 2, 0);
-    if (cs) chroma_smooth(&fh, img, cs);
+    int is_dual_iso = 0;                                       /* main.c:951-973 */
+    if (dual_iso == 1) is_dual_iso = hdr_convert_data(&fh, img, 0, npix * 2);
+    else if (dual_iso == 2) is_dual_iso = cr2hdr20_convert_data(&fh, img, 0, 1, 1, cs, bad);
+    if (!is_dual_iso) {
+        fix_focus_pixels(&fh, img, 0);
+        if (bad) fix_bad_pixels(&fh, img, bad == 2, 0);
+    }
+    if (cs && dual_iso != 2) chroma_smooth(&fh, img, cs);
     if (stripes) {
         struct stripes_correction *c = stripes_get_correction("c_host.MLV");
         if (!c) {
@@ -46,6 +52,7 @@ int main(int argc, char **argv)
     f = fopen(argv[2], "wb");
     if (!f) return 5;
     fwrite(img, 2, npix, f);
+    fprintf(stderr, "levels %d %d dual_iso %d\n", fh.rawi_hdr.raw_info.black_level, fh.rawi_hdr.raw_info.white_level, is_dual_iso);
     fclose(f);
     stripes_free_corrections();
     free_focus_pixel_maps();

@@ -46,3 +46,23 @@ def test_c_program_through_the_drop_in_symbols(c_host, oracle, tmp_path, cs, bad
     # work (LibcRandGuard), otherwise the stripe coefficients here would differ from the reference's.
     want, _ = oracle.process_frame(packed, w, h, BLACK, WHITE, cs, bad, stripes)
     assert np.array_equal(got, want), f"{(got != want).sum()} px differ (column phases {np.unique(np.nonzero(got != want)[1] % 8)})"
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_c_program_dual_iso(c_host, oracle, tmp_path, mode):
+    """hdr_convert_data / cr2hdr20_convert_data from C: pixels and the levels written back into frame_headers."""
+    w, h = 416, 264
+    f = synth.dual_iso_frame(w, h)
+    packed = synth.pack_bits(f)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    np.ascontiguousarray(packed, "<u2").tofile(fin)
+    res = subprocess.run([c_host, str(fin), str(fout), str(w), str(h), str(BLACK), str(WHITE), "0", "0", "0", str(mode)],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    got = np.fromfile(fout, "<u2").reshape(h, w)
+    if mode == 1:
+        ok, want, lv = oracle.hdr_preview(f, BLACK, WHITE)
+    else:
+        ok, want, lv = oracle.cr2hdr20(f, BLACK, WHITE, 0, 1, 1, 0, reset=True)
+    assert ok == 1 and f"levels {lv[0]} {lv[1]} dual_iso 1" in res.stderr
+    assert np.array_equal(got, want), f"{(got != want).sum()} px differ"
