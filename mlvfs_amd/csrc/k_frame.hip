@@ -124,6 +124,16 @@ __device__ __forceinline__ int ev_value(int l, int tv)
     return tv + (int)((__float_as_uint((float)(unsigned)l) >> 8) & 0xFFFF8000u) - (127 << 15);
 }
 
+// v_bfe_u32 as written: the optimiser otherwise re-expands a bit-field extract whose result is shifted or scaled into
+// shift + and (two quarter-rate instructions instead of one)
+template <int OFF, int WIDTH>
+__device__ __forceinline__ uint32_t bfe_asm(uint32_t v)
+{
+    uint32_t r;
+    asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "n"(OFF), "n"(WIDTH));
+    return r;
+}
+
 // EV triples of two adjacent Bayer cells (8 pixels): r/g1 on the top row, g2/b below
 __device__ __forceinline__ void cell_pair_ev(const uint32_t *p0, const uint32_t *p1, int black, const uint16_t *t, bool slow,
                                              int (&ge)[2], int (&dr)[2], int (&db)[2])
@@ -133,14 +143,33 @@ __device__ __forceinline__ void cell_pair_ev(const uint32_t *p0, const uint32_t 
 #pragma unroll
     for (int i = 0; i < 8; i++) lin[i] = px[i] - black;
     if (!slow) {                                        // wave-uniform: two separate paths, so the common one carries no selects or copies
+        // Every lin is in [1, 16383]: its float has at most 13 mantissa bits below the leading one, so bits 0..9 are zero and
+        // bits 9..22 ARE the byte offset of the table entry (one v_bfe).  The EVs carry the exponent bias (127 << 15): it
+        // cancels in dr and db, the sum of two biased EVs is positive (a plain shift halves it) and ge drops it at the end.
+        uint32_t fb[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) tv[i] = t[ev_index(lin[i])];
+        for (int i = 0; i < 8; i++) fb[i] = __float_as_uint((float)(unsigned)lin[i]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) tv[i] = *(const uint16_t *)((const char *)t + bfe_asm<9, 14>(fb[i]));
         // opaque use: keeps the eight LDS reads unconditional and back to back (the compiler
         // otherwise sinks each read next to its use and waits for it there)
+        uint32_t ex[8], eb[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) ex[i] = bfe_asm<23, 8>(fb[i]);                                    // while the reads are in flight
+        asm volatile("" :: "v"(ex[0]), "v"(ex[1]), "v"(ex[2]), "v"(ex[3]), "v"(ex[4]), "v"(ex[5]), "v"(ex[6]), "v"(ex[7]));
         asm volatile("" :: "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]), "v"(tv[4]), "v"(tv[5]), "v"(tv[6]), "v"(tv[7]));
 #pragma unroll
-        for (int i = 0; i < 8; i++) ev[i] = ev_value(lin[i], tv[i]);
-    } else {
+        for (int i = 0; i < 8; i++) eb[i] = (ex[i] << 15) + (uint32_t)tv[i];                          // v_lshl_add_u32
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint32_t gb = (eb[4 * c + 1] + eb[4 * c + 2]) >> 1;           // chroma_smooth.c:32,54 (both EVs >= 0: trunc == floor)
+            ge[c] = (int)(gb - (127u << 15));
+            dr[c] = (int)(eb[4 * c + 0] - gb);
+            db[c] = (int)(eb[4 * c + 3] - gb);
+        }
+        return;
+    }
+    {
         int l[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) l[i] = min(max(lin[i], 1), 16383);
