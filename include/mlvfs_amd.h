@@ -37,6 +37,12 @@ extern "C" {
 /* replaces mlvfs/dng.h:31 (dng.c:854-872): unpack bpp-bit packed pixels to u16 */
 size_t dng_get_image_data(struct frame_headers *frame_headers, uint16_t *packed_bits,
                           uint8_t *output_buffer, off_t offset, size_t max_size);
+/* replaces mlvfs/dng.h:29 (dng.c:597-789): the 65536-byte CinemaDNG header (TIFF IFD0 + EXIF IFD) of one frame,
+ * built on the host from the MLV block headers; copies min(max_size, 65536) bytes starting at `offset` and returns
+ * that count.  May rewrite frame_headers->rawi_hdr.raw_info.active_area like the reference does.  Host only:
+ * works without a HIP device.                                                       */
+size_t dng_get_header_data(struct frame_headers *frame_headers, uint8_t *output_buffer, off_t offset, size_t max_size,
+                           double fps_override, char *mlv_basename);
 /* replaces mlvfs/dng.h:30,32,33 (dng.c:797-800, 879-891) */
 size_t dng_get_header_size(void);
 size_t dng_get_image_size(struct frame_headers *frame_headers);

@@ -26,7 +26,7 @@ class Geom(C.Structure):
 
 # every symbol include/mlvfs_amd.h declares (tests/test_cabi.py checks the export table against the header)
 DROPIN_SYMBOLS = [
-    "dng_get_image_data", "dng_get_header_size", "dng_get_image_size", "dng_get_size",
+    "dng_get_image_data", "dng_get_header_data", "dng_get_header_size", "dng_get_image_size", "dng_get_size",
     "chroma_smooth", "fix_bad_pixels", "fix_focus_pixels", "free_focus_pixel_maps",
     "stripes_get_correction", "stripes_new_correction", "stripes_free_corrections",
     "stripes_compute_correction", "stripes_apply_correction",
@@ -89,6 +89,7 @@ def load() -> C.CDLL:
 
     # drop-in symbols
     sig("dng_get_image_data", sz, [fhp, vp, vp, C.c_long, sz])
+    sig("dng_get_header_data", sz, [fhp, vp, C.c_long, sz, C.c_double, C.c_char_p])
     sig("dng_get_header_size", sz, [])
     sig("dng_get_image_size", sz, [fhp])
     sig("dng_get_size", sz, [fhp])

@@ -222,3 +222,61 @@ def amaze_plane(w: int, h: int, seed: int = 1) -> np.ndarray:
     raw[h // 2:h // 2 + 12, w // 2:w // 2 + 40:2] = 500
     raw[h // 3:h // 3 + 9:2, 8:w - 8] += 9000
     return raw.clip(0, 0xFFFFF).astype(np.float32)
+
+
+# ---------------------------------------------------------------- DNG header cases
+HEADER_CAMERAS = ["Canon EOS 5D Mark III", "Canon EOS 5D Mark II", "Canon EOS 7D", "Canon EOS 6D", "Canon EOS 70D",
+                  "Canon EOS 60D", "Canon EOS 50D", "Canon EOS 500D", "Canon EOS 550D", "Canon EOS 600D",
+                  "Canon EOS 650D", "Canon EOS 700D", "Canon EOS 1100D", "Canon EOS M", "Canon EOS 100D", "X", "ab",
+                  "Nikon D800 test body"]
+
+
+def header_case(k: int):
+    """Deterministic `frame_headers` for the header writer: case k -> (FrameHeaders, fps_override, basename).
+
+    Cycles through every camera row (and unknown / very short names), every white-balance mode, crop / line-skipping /
+    full-sensor geometries, frames with and without optical-black borders, zero and non-zero frame rates.
+    """
+    from . import abi
+    state = [0]
+
+    def r(n):
+        state[0] += 1
+        return int(_mix32((state[0] * 0x9E3779B1 + (k + 1) * 0x85EBCA6B) & _M32)) % n
+
+    geoms = [(1920, 1080, 1920 + 146, 1080 + 28), (3584, 1320, 5936, 3950), (1728, 972, 1808, 1190), (1920, 672, 2080, 702),
+             (1280, 434, 2080, 720), (640, 480, 720, 500), (2560, 1090, 2560, 1090)]
+    w, h, rw, rh = geoms[k % len(geoms)]
+    fh = abi.make_frame_headers(w, h, black=[2048, 1024, 2047, 0][r(4)], white=[15000, 16383, 60000][r(3)], guid=r(1 << 30),
+                                raw_size=(rw, rh))
+    ri = fh.rawi_hdr.raw_info
+    x1, y1 = [(0, 0), (146, 28), (72, 26)][r(3)]
+    ri.active_area[0], ri.active_area[1], ri.active_area[2], ri.active_area[3] = y1, x1, rh, rw   # y1, x1, y2, x2
+    ri.crop[0], ri.crop[1], ri.crop[2], ri.crop[3] = r(200), r(100), w - r(16), h - r(16)
+    ri.exposure_bias[0], ri.exposure_bias[1] = r(7) - 3, [0, 1, 2, 3][r(4)]
+    name = HEADER_CAMERAS[k % len(HEADER_CAMERAS)].encode()
+    for i, c in enumerate(name[:31]):
+        fh.idnt_hdr.cameraName[i] = c
+    fh.idnt_hdr.cameraModel = 0x80000285 + r(64)
+    serial = ("%08X%08X%08X%08X" % (r(1 << 32), r(1 << 32), r(1 << 32), r(1 << 32))).encode()[: r(33)]
+    for i, c in enumerate(serial):
+        fh.idnt_hdr.cameraSerial[i] = c
+    lens = [b"EF24-70mm f/2.8L II USM", b"", b"50", b"EF-S18-55mm f/3.5-5.6 IS STM kit"][r(4)][:31]
+    for i, c in enumerate(lens):
+        fh.lens_hdr.lensName[i] = c
+    fh.lens_hdr.focalLength, fh.lens_hdr.focalDist, fh.lens_hdr.aperture = 10 + r(400), r(65535), 100 + r(2100)
+    fh.expo_hdr.isoValue = [100, 1600, 25600, 102400][r(4)]
+    fh.expo_hdr.shutterValue = [20000, 33333, 1000000, 250, 5_000_000_000][r(5)]
+    fh.wbal_hdr.wb_mode = [0, 1, 2, 3, 4, 5, 6, 8, 9, 7][k % 10]
+    fh.wbal_hdr.kelvin = 1700 + r(11000)
+    fh.wbal_hdr.wbgain_r, fh.wbal_hdr.wbgain_g, fh.wbal_hdr.wbgain_b = 400 + r(800), 1024, 400 + r(1200)
+    t = fh.rtci_hdr
+    t.tm_sec, t.tm_min, t.tm_hour, t.tm_mday, t.tm_mon, t.tm_year = r(60), r(60), r(24), 1 + r(28), r(12), 110 + r(20)
+    t.timestamp = r(1 << 20)
+    fh.vidf_hdr.timestamp = t.timestamp + r(1 << 36)
+    fh.vidf_hdr.frameNumber = [0, 1, 23, 24, 1439, 86400, 2_592_001][r(7)]
+    nom, den = [(23976, 1000), (24000, 1001), (25000, 1000), (60000, 1000), (0, 0), (500, 1000), (30000, 0)][r(7)]
+    fh.file_hdr.sourceFpsNom, fh.file_hdr.sourceFpsDenom = nom, den
+    fps_override = [0.0, 0.0, 24.0, 23.976, 0.5][r(5)]
+    base = [b"M27-1337", b"a", b"abc", b"/Volumes/CARD/DCIM/100EOS5D/M27-1337.MLV", b""][r(5)]
+    return fh, fps_override, base

@@ -256,7 +256,17 @@ class Reference:
         L.get_raw2ev.restype = C.POINTER(C.c_int)
         L.get_raw2ev.argtypes = [C.c_int]
         L.get_ev2raw.restype = C.POINTER(C.c_int)
+        L.ref_header_data.restype = C.c_size_t
+        L.ref_header_data.argtypes = [u8p, u8p, C.c_int64, C.c_size_t, C.c_double, C.c_char_p]
         self._libc = C.CDLL(None)
+
+    def header_data(self, fh_blob: np.ndarray, offset: int = 0, max_size: int = 65536, fps_override: float = 0.0,
+                    basename: bytes = b"clip"):
+        """dng_get_header_data on a 592-byte frame_headers image -> (bytes written, header bytes, frame_headers after)."""
+        blob = np.ascontiguousarray(fh_blob, np.uint8).copy()
+        out = np.zeros(max(max_size, 1), np.uint8)
+        n = self.L.ref_header_data(blob, out, offset, max_size, fps_override, basename)
+        return n, out[:max_size], blob
 
     def raw2ev(self, black: int, n: int = 16384) -> np.ndarray:
         p = self.L.get_raw2ev(black)

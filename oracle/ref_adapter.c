@@ -179,3 +179,12 @@ int ref_process_frame(const uint16_t *packed, uint16_t *img, int w, int h, int b
     }
     return 1;
 }
+
+/* dng_get_header_data on a caller-supplied frame_headers image (592 bytes, the layout
+ * tests/test_abi.py pins); the reference may rewrite the active area inside it. */
+size_t ref_header_data(void *frame_headers_blob, uint8_t *out, int64_t offset, size_t max_size, double fps_override,
+                       const char *mlv_basename)
+{
+    return dng_get_header_data((struct frame_headers *)frame_headers_blob, out, (off_t)offset, max_size, fps_override,
+                               (char *)mlv_basename);
+}
