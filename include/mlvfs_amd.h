@@ -179,6 +179,26 @@ int mlvfs_amd_process_frames_host(mlvfs_amd_clip_t *clip, const void *h_packed, 
 void *mlvfs_amd_host_alloc(size_t bytes);
 void mlvfs_amd_host_free(void *p);
 
+/* -- MLV container reader and prefetcher (host code) -------- */
+/* Opens <name>.MLV and its chunks .M00, .M01, ... (index.c:367-424) and builds, once, what MLVFS rebuilds for every
+ * frame it serves: the XREF index (index.c:216-341; use_idx_file != 0: taken from <name>.IDX when that exists, written
+ * there otherwise, like get_index) and the block headers that belong to each video frame (main.c:429-558).  NULL on
+ * failure.  Needs no HIP device except for mlvfs_amd_mlv_process.                                                     */
+void  *mlvfs_amd_mlv_open(const char *mlv_path, int use_idx_file);
+void   mlvfs_amd_mlv_close(void *reader);
+int    mlvfs_amd_mlv_frame_count(const void *reader);            /* = mlv_get_frame_count, index.c:488-527 */
+int    mlvfs_amd_mlv_chunk_count(const void *reader);
+/* the XREF block (header + entries) exactly as make_index builds it; returns its size, copies if cap suffices */
+size_t mlvfs_amd_mlv_xref(const void *reader, void *dst, size_t cap);
+/* = mlv_get_frame_headers(path, index, out): 1 = found and a RAWI block precedes it, 0 otherwise */
+int    mlvfs_amd_mlv_frame_headers(const void *reader, int index, struct frame_headers *out);
+/* payloads of `count` frames (uncompressed clips) into dst, `stride` bytes apart, read by io_threads threads (<= 0: 8) */
+int    mlvfs_amd_mlv_read_frames(const void *reader, int first, int count, void *dst, size_t stride, int io_threads);
+/* file -> fused pipeline -> h_out: batches of batch_frames frames (<= 0: 32) are read into page-locked staging by
+ * io_threads threads while the previous batch goes through mlvfs_amd_process_frames_host                            */
+int    mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first, int count, void *h_out, size_t out_stride,
+                             int cs_method, int fix_pixels, int apply_stripes, int batch_frames, int io_threads);
+
 /* dual-ISO preview on one device frame (hdr.c:40-227); returns 1 / 0 / <0    */
 int mlvfs_amd_hdr_preview_dev(const mlvfs_amd_geom_t *geom, void *d_frame, size_t max_size, void *stream);
 

@@ -1,0 +1,375 @@
+// mlvreader.cpp -- MLV container walk and frame prefetch.
+//
+// What MLVFS does per frame read, done once per clip here and kept in memory:
+//   chunk files   <name>.MLV + <name>.M00 .. M98                 mlvfs/index.c:367-424 (load_chunks)
+//   XREF index    every block of every chunk, NULL blocks left out, MLVI at time 0, stable order by timestamp
+//                                                                  mlvfs/index.c:78-99, 216-341 (xref_sort, make_index)
+//   .IDX file     MLVI (blockSize 52, frame counts 0, fileNum = chunks + 1) followed by the XREF block
+//                                                                  mlvfs/index.c:101-214 (load_index, save_index)
+//   frame headers the MLVI / RTCI / IDNT / RAWI / EXPO / LENS / WBAL blocks that precede the n-th VIDF in XREF order,
+//                 each copied over the previous one of its kind     mlvfs/main.c:429-558 (mlv_get_frame_headers)
+//   payload       position + sizeof(VIDF header) + frameSpace       mlvfs/main.c:688-702 (get_image_data, uncompressed)
+// and, what MLVFS's README lists as missing (`--prefetch`): payloads of a whole batch of frames are read by a pool of
+// threads into page-locked memory while the previous batch is on the GPU (mlvfs_amd_mlv_process).
+//
+// The reference opens, indexes and walks the clip again for every frame it serves; results are the same, the cost is not.
+// Compressed payloads (LZMA, LJ92: SURVEY.md 8f N3) are refused.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+using mlv::set_error;
+
+#pragma pack(push, 1)
+struct BlockHead { uint8_t type[4]; uint32_t size; uint64_t timestamp; };                       // mlv.h:42-46
+struct XrefHead { uint8_t type[4]; uint32_t size; uint64_t timestamp; uint32_t frame_type, entries; };   // mlv.h:166-173
+struct XrefEntry { uint16_t file; uint8_t empty, kind; uint64_t offset; };                       // mlv.h:159-164
+#pragma pack(pop)
+static_assert(sizeof(BlockHead) == 16 && sizeof(XrefHead) == 24 && sizeof(XrefEntry) == 12, "MLV v2.0 layouts");
+
+enum : uint8_t { KIND_OTHER = 0, KIND_VIDF = 1, KIND_AUDF = 2 };
+constexpr uint16_t CLASS_LZMA = 0x80, CLASS_LJ92 = 0x20;                                          // mlv.h:30-33
+
+bool read_at(int fd, void *dst, size_t n, uint64_t off)
+{
+    uint8_t *p = (uint8_t *)dst;
+    while (n) {
+        const ssize_t r = pread(fd, p, n, (off_t)off);
+        if (r <= 0) return false;
+        p += r; off += (uint64_t)r; n -= (size_t)r;
+    }
+    return true;
+}
+
+struct Reader {
+    std::string path;
+    std::vector<int> fds;
+    std::vector<XrefEntry> xref;
+    std::vector<uint32_t> vidf;                 // XREF position of the n-th video frame
+    // frame_headers as mlv_get_frame_headers leaves them, without the VIDF part: one snapshot per run of frames between
+    // two metadata blocks (a clip has a handful; a clip with per-frame EXPO/LENS blocks one per frame)
+    std::vector<frame_headers> snap;
+    std::vector<uint32_t> snap_of;              // per frame
+    std::vector<uint8_t> has_rawi;              // per snapshot
+    frame_headers last;                         // state after every block (what an index past the last frame leaves behind)
+
+    ~Reader() { for (int fd : fds) if (fd >= 0) close(fd); }
+};
+
+// ---- chunks ---------------------------------------------------------------------------------------------------------
+bool open_chunks(Reader &r)
+{
+    int fd = open(r.path.c_str(), O_RDONLY);
+    if (fd < 0) { set_error("mlv: cannot open %s: %s", r.path.c_str(), strerror(errno)); return false; }
+    r.fds.push_back(fd);
+    if (r.path.size() < 3) return true;
+    std::string name = r.path;
+    for (int seq = 0; seq < 99; seq++) {                            // .M00, .M01, ... until one is missing
+        char two[8];
+        snprintf(two, sizeof two, "%02d", seq);
+        name.replace(name.size() - 2, 2, two);
+        fd = open(name.c_str(), O_RDONLY);
+        if (fd < 0) break;
+        r.fds.push_back(fd);
+    }
+    return true;
+}
+
+// ---- index ----------------------------------------------------------------------------------------------------------
+struct Timed { uint64_t time; XrefEntry e; };
+
+void scan_chunks(Reader &r)
+{
+    std::vector<Timed> all;
+    mlv_file_hdr_t first{};                                         // the MLVI with fileNum 0; all zero until one is seen
+    for (size_t c = 0; c < r.fds.size(); c++) {
+        uint64_t pos = 0;
+        for (;;) {
+            BlockHead h;
+            if (!read_at(r.fds[c], &h, sizeof h, pos)) break;
+            if (h.size < sizeof h || h.size > (1u << 30)) {
+                fprintf(stderr, "Invalid header size: %d bytes at 0x%08llX\n", (int)h.size, (unsigned long long)pos);
+                break;
+            }
+            uint64_t t = h.timestamp;
+            if (!memcmp(h.type, "MLVI", 4)) {
+                mlv_file_hdr_t fh{};
+                if (!read_at(r.fds[c], &fh, std::min<size_t>(sizeof fh, h.size), pos)) break;
+                if (fh.fileNum == 0) first = fh;
+                else if (first.fileGuid != fh.fileGuid) break;      // a chunk of another recording: stop reading it
+                t = 0;                                               // the bytes at the timestamp's place are the version string
+            }
+            if (memcmp(h.type, "NULL", 4)) {
+                Timed x{};
+                x.time = t;
+                x.e.file = (uint16_t)c;
+                x.e.kind = !memcmp(h.type, "VIDF", 4) ? KIND_VIDF : !memcmp(h.type, "AUDF", 4) ? KIND_AUDF : KIND_OTHER;
+                x.e.offset = pos;
+                all.push_back(x);
+            }
+            pos += h.size;
+        }
+    }
+    // the reference bubble-sorts on `>`: equal timestamps keep their scan order
+    std::stable_sort(all.begin(), all.end(), [](const Timed &a, const Timed &b) { return a.time < b.time; });
+    r.xref.resize(all.size());
+    for (size_t i = 0; i < all.size(); i++) r.xref[i] = all[i].e;
+}
+
+std::string idx_name(const std::string &path)
+{
+    std::string n = path;
+    if (n.size() >= 3) n.replace(n.size() - 3, 3, "IDX");
+    return n;
+}
+
+bool load_idx(Reader &r)
+{
+    const int fd = open(idx_name(r.path).c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    bool ok = false;
+    uint64_t pos = 0;
+    for (;;) {                                                      // walk the blocks of the .IDX until an XREF is found
+        BlockHead h;
+        if (!read_at(fd, &h, sizeof h, pos) || h.size < sizeof h) break;
+        if (!memcmp(h.type, "XREF", 4)) {
+            XrefHead xh;
+            if (h.size >= sizeof xh && read_at(fd, &xh, sizeof xh, pos) &&
+                (uint64_t)xh.entries * sizeof(XrefEntry) + sizeof xh <= h.size) {
+                r.xref.resize(xh.entries);
+                ok = xh.entries == 0 || read_at(fd, r.xref.data(), xh.entries * sizeof(XrefEntry), pos + sizeof xh);
+            }
+            break;
+        }
+        pos += h.size;
+    }
+    close(fd);
+    if (ok)
+        for (const XrefEntry &e : r.xref)
+            if (e.file >= r.fds.size()) ok = false;                 // an index of a clip with more chunks than are here
+    if (!ok) r.xref.clear();
+    return ok;
+}
+
+std::vector<uint8_t> xref_block(const Reader &r)
+{
+    std::vector<uint8_t> b(sizeof(XrefHead) + r.xref.size() * sizeof(XrefEntry), 0);
+    XrefHead h{};
+    memcpy(h.type, "XREF", 4);
+    h.size = (uint32_t)b.size();
+    h.entries = (uint32_t)r.xref.size();
+    memcpy(b.data(), &h, sizeof h);
+    if (!r.xref.empty()) memcpy(b.data() + sizeof h, r.xref.data(), r.xref.size() * sizeof(XrefEntry));
+    return b;
+}
+
+bool save_idx(const Reader &r)
+{
+    mlv_file_hdr_t fh{};
+    (void)read_at(r.fds[0], &fh, sizeof fh, 0);                     // the first chunk's first 52 bytes, whatever they are
+    fh.blockSize = sizeof fh;
+    fh.videoFrameCount = 0;
+    fh.audioFrameCount = 0;
+    fh.fileNum = (uint16_t)(r.fds.size() + 1);
+    const std::vector<uint8_t> x = xref_block(r);
+    FILE *f = fopen(idx_name(r.path).c_str(), "wb+");
+    if (!f) return false;
+    const bool ok = fwrite(&fh, sizeof fh, 1, f) == 1 && fwrite(x.data(), x.size(), 1, f) == 1;
+    fclose(f);
+    return ok;
+}
+
+// ---- frame headers ----------------------------------------------------------------------------------------------------
+// One pass over the index in XREF order with the running state of mlv_get_frame_headers; a snapshot is taken whenever a
+// video frame follows a change.
+void gather_headers(Reader &r)
+{
+    frame_headers cur;
+    memset(&cur, 0, sizeof cur);
+    bool rawi = false, dirty = true;
+    for (uint32_t i = 0; i < r.xref.size(); i++) {
+        const XrefEntry &e = r.xref[i];
+        const int fd = r.fds[e.file];
+        if (e.kind == KIND_VIDF) {
+            if (dirty) { r.snap.push_back(cur); r.has_rawi.push_back(rawi); dirty = false; }
+            r.vidf.push_back(i);
+            r.snap_of.push_back((uint32_t)r.snap.size() - 1);
+            continue;
+        }
+        if (e.kind == KIND_AUDF) continue;
+        BlockHead h;
+        if (!read_at(fd, &h, sizeof h, e.offset)) continue;
+        struct { const char *tag; void *dst; size_t cap; } kinds[] = {
+            { "MLVI", &cur.file_hdr, sizeof cur.file_hdr }, { "RTCI", &cur.rtci_hdr, sizeof cur.rtci_hdr },
+            { "IDNT", &cur.idnt_hdr, sizeof cur.idnt_hdr }, { "RAWI", &cur.rawi_hdr, sizeof cur.rawi_hdr },
+            { "EXPO", &cur.expo_hdr, sizeof cur.expo_hdr }, { "LENS", &cur.lens_hdr, sizeof cur.lens_hdr },
+            { "WBAL", &cur.wbal_hdr, sizeof cur.wbal_hdr },
+        };
+        for (auto &k : kinds) {
+            if (memcmp(h.type, k.tag, 4)) continue;
+            const bool got = read_at(fd, k.dst, std::min<size_t>(k.cap, h.size), e.offset);
+            if (k.dst == (void *)&cur.rawi_hdr && got) rawi = true;
+            dirty = true;
+            break;
+        }
+    }
+    r.last = cur;
+}
+
+int frame_headers_of(const Reader &r, int index, frame_headers *out)
+{
+    if (index < 0 || (size_t)index >= r.vidf.size()) {
+        *out = r.last;                                              // the reference has walked every block by now
+        fprintf(stderr, "%s: Error reading frame headers: vidf block for frame %d was not found\n", r.path.c_str(), index);
+        return 0;
+    }
+    *out = r.snap[r.snap_of[index]];
+    const XrefEntry &e = r.xref[r.vidf[index]];
+    out->fileNumber = e.file;
+    out->position = e.offset;
+    BlockHead h;
+    if (read_at(r.fds[e.file], &h, sizeof h, e.offset))
+        (void)read_at(r.fds[e.file], &out->vidf_hdr, std::min<size_t>(sizeof out->vidf_hdr, h.size), e.offset);
+    if (!r.has_rawi[r.snap_of[index]]) {
+        fprintf(stderr, "%s: Error reading frame headers: no rawi block was found\n", r.path.c_str());
+        return 0;
+    }
+    return 1;
+}
+
+// ---- payloads ---------------------------------------------------------------------------------------------------------
+struct Span { int fd; uint64_t off; size_t bytes; };
+
+bool payload_span(const Reader &r, int index, Span *s)
+{
+    frame_headers fh;
+    if (!frame_headers_of(r, index, &fh)) { set_error("mlv: frame %d has no usable headers", index); return false; }
+    if (fh.file_hdr.videoClass & (CLASS_LZMA | CLASS_LJ92)) {
+        set_error("mlv: compressed video class 0x%x (LZMA / LJ92 payloads are not decoded here)", fh.file_hdr.videoClass);
+        return false;
+    }
+    const uint64_t bits = (uint64_t)fh.rawi_hdr.xRes * fh.rawi_hdr.yRes * (uint64_t)fh.rawi_hdr.raw_info.bits_per_pixel;
+    s->fd = r.fds[fh.fileNumber];
+    s->off = fh.position + sizeof(mlv_vidf_hdr_t) + fh.vidf_hdr.frameSpace;
+    s->bytes = (size_t)((bits + 7) / 8);
+    const uint64_t in_block = fh.vidf_hdr.blockSize > sizeof(mlv_vidf_hdr_t) + fh.vidf_hdr.frameSpace
+                                  ? fh.vidf_hdr.blockSize - sizeof(mlv_vidf_hdr_t) - fh.vidf_hdr.frameSpace : 0;
+    if (in_block < s->bytes) { set_error("mlv: frame %d: VIDF block holds %llu payload bytes, geometry needs %zu", index,
+                                         (unsigned long long)in_block, s->bytes); return false; }
+    return true;
+}
+
+int read_frames(const Reader &r, int first, int count, uint8_t *dst, size_t stride, int threads)
+{
+    if (count <= 0) return MLVFS_AMD_OK;
+    std::vector<Span> spans(count);
+    for (int k = 0; k < count; k++) {
+        if (!payload_span(r, first + k, &spans[k])) return MLVFS_AMD_ERR_ARG;
+        if (spans[k].bytes > stride) { set_error("mlv: stride %zu smaller than a frame payload (%zu)", stride, spans[k].bytes); return MLVFS_AMD_ERR_ARG; }
+    }
+    threads = std::max(1, std::min(threads <= 0 ? 8 : threads, count));
+    std::atomic<int> next{ 0 }, failed{ -1 };
+    auto work = [&]() {
+        for (int k; (k = next.fetch_add(1)) < count;) {
+            uint8_t *d = dst + (size_t)k * stride;
+            if (!read_at(spans[k].fd, d, spans[k].bytes, spans[k].off)) { failed = first + k; continue; }
+            if (stride > spans[k].bytes) memset(d + spans[k].bytes, 0, std::min<size_t>(stride - spans[k].bytes, 64));   // the 2-pixel over-read of main.c:579 sees zeros
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    if (failed >= 0) { set_error("mlv: short read in the payload of frame %d", (int)failed); return MLVFS_AMD_ERR_ARG; }
+    return MLVFS_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void *mlvfs_amd_mlv_open(const char *mlv_path, int use_idx_file)
+{
+    if (!mlv_path) { set_error("mlv: no path"); return nullptr; }
+    Reader *r = new Reader;
+    r->path = mlv_path;
+    if (!open_chunks(*r)) { delete r; return nullptr; }
+    if (!(use_idx_file && load_idx(*r))) {
+        scan_chunks(*r);
+        if (use_idx_file) (void)save_idx(*r);
+    }
+    gather_headers(*r);
+    return r;
+}
+
+void mlvfs_amd_mlv_close(void *reader) { delete (Reader *)reader; }
+
+int mlvfs_amd_mlv_frame_count(const void *reader) { return reader ? (int)((const Reader *)reader)->vidf.size() : 0; }
+
+int mlvfs_amd_mlv_chunk_count(const void *reader) { return reader ? (int)((const Reader *)reader)->fds.size() : 0; }
+
+size_t mlvfs_amd_mlv_xref(const void *reader, void *dst, size_t cap)
+{
+    if (!reader) return 0;
+    const std::vector<uint8_t> b = xref_block(*(const Reader *)reader);
+    if (dst && cap >= b.size()) memcpy(dst, b.data(), b.size());
+    return b.size();
+}
+
+int mlvfs_amd_mlv_frame_headers(const void *reader, int index, struct frame_headers *out)
+{
+    if (!reader || !out) return 0;
+    return frame_headers_of(*(const Reader *)reader, index, out);
+}
+
+int mlvfs_amd_mlv_read_frames(const void *reader, int first, int count, void *dst, size_t stride, int io_threads)
+{
+    if (!reader || !dst) { set_error("mlv: null argument"); return MLVFS_AMD_ERR_ARG; }
+    return read_frames(*(const Reader *)reader, first, count, (uint8_t *)dst, stride, io_threads);
+}
+
+int mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first, int count, void *h_out, size_t out_stride,
+                          int cs_method, int fix_pixels, int apply_stripes, int batch_frames, int io_threads)
+{
+    if (!reader || !clip || !h_out) { set_error("mlv: null argument"); return MLVFS_AMD_ERR_ARG; }
+    const Reader &r = *(const Reader *)reader;
+    if (count <= 0) return MLVFS_AMD_OK;
+    if (first < 0 || (size_t)first + (size_t)count > r.vidf.size()) { set_error("mlv: frames %d..%d outside the clip (%zu frames)", first, first + count - 1, r.vidf.size()); return MLVFS_AMD_ERR_ARG; }
+    Span s0;
+    if (!payload_span(r, first, &s0)) return MLVFS_AMD_ERR_ARG;
+    const size_t stride = (s0.bytes + 2 + 15) / 16 * 16;
+    if (batch_frames <= 0) batch_frames = 32;
+    batch_frames = std::min(batch_frames, count);
+    uint8_t *stage[2] = { (uint8_t *)mlvfs_amd_host_alloc(stride * batch_frames), (uint8_t *)mlvfs_amd_host_alloc(stride * batch_frames) };
+    int rc = (stage[0] && stage[1]) ? MLVFS_AMD_OK : MLVFS_AMD_ERR_NOMEM;
+    if (rc == MLVFS_AMD_OK) rc = read_frames(r, first, batch_frames, stage[0], stride, io_threads);
+    for (int f0 = 0, k = 0; rc == MLVFS_AMD_OK && f0 < count; f0 += batch_frames, k++) {
+        const int n = std::min(batch_frames, count - f0), n_next = std::min(batch_frames, count - f0 - n);
+        int rc_io = MLVFS_AMD_OK;
+        std::thread io;                                             // the next batch is read while this one is on the GPU
+        if (n_next > 0) io = std::thread([&, k, f0, n, n_next]() { rc_io = read_frames(r, first + f0 + n, n_next, stage[(k + 1) & 1], stride, io_threads); });
+        rc = mlvfs_amd_process_frames_host(clip, stage[k & 1], stride, (uint8_t *)h_out + (size_t)f0 * out_stride, out_stride, n,
+                                           cs_method, fix_pixels, apply_stripes, 0);
+        if (io.joinable()) io.join();
+        if (rc == MLVFS_AMD_OK && rc_io != MLVFS_AMD_OK) {          // the reader thread's message lives in its own thread
+            set_error("mlv: prefetch of frames %d..%d failed", first + f0 + n, first + f0 + n + n_next - 1);
+            rc = rc_io;
+        }
+    }
+    mlvfs_amd_host_free(stage[0]);
+    mlvfs_amd_host_free(stage[1]);
+    return rc;
+}
+
+}  // extern "C"

@@ -44,6 +44,8 @@ DEVICE_SYMBOLS = [
     "mlvfs_amd_host_alloc", "mlvfs_amd_host_free", "mlvfs_amd_hdr_preview_dev",
     "mlvfs_amd_cr2hdr20_dev", "mlvfs_amd_dualiso_reset", "mlvfs_amd_amaze_demosaic_dev",
     "mlvfs_amd_timer_begin", "mlvfs_amd_timer_end", "mlvfs_amd_selftest_host",
+    "mlvfs_amd_mlv_open", "mlvfs_amd_mlv_close", "mlvfs_amd_mlv_frame_count", "mlvfs_amd_mlv_chunk_count",
+    "mlvfs_amd_mlv_xref", "mlvfs_amd_mlv_frame_headers", "mlvfs_amd_mlv_read_frames", "mlvfs_amd_mlv_process",
 ]
 
 
@@ -141,6 +143,14 @@ def load() -> C.CDLL:
     sig("mlvfs_amd_timer_begin", i, [i])
     sig("mlvfs_amd_timer_end", i, [vp, i])
     sig("mlvfs_amd_selftest_host", i, [])
+    sig("mlvfs_amd_mlv_open", vp, [C.c_char_p, i])
+    sig("mlvfs_amd_mlv_close", None, [vp])
+    sig("mlvfs_amd_mlv_frame_count", i, [vp])
+    sig("mlvfs_amd_mlv_chunk_count", i, [vp])
+    sig("mlvfs_amd_mlv_xref", sz, [vp, vp, sz])
+    sig("mlvfs_amd_mlv_frame_headers", i, [vp, i, fhp])
+    sig("mlvfs_amd_mlv_read_frames", i, [vp, i, i, vp, sz, i])
+    sig("mlvfs_amd_mlv_process", i, [vp, vp, i, i, vp, sz, i, i, i, i, i])
     _lib = L
     return L
 

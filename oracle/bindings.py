@@ -256,9 +256,23 @@ class Reference:
         L.get_raw2ev.restype = C.POINTER(C.c_int)
         L.get_raw2ev.argtypes = [C.c_int]
         L.get_ev2raw.restype = C.POINTER(C.c_int)
+        for f in (L.ref_mlv_new_index, L.ref_mlv_get_index):
+            f.restype = C.c_size_t
+            f.argtypes = [C.c_char_p, u8p, C.c_size_t]
+        L.ref_mlv_frame_count.argtypes = [C.c_char_p]
         L.ref_header_data.restype = C.c_size_t
         L.ref_header_data.argtypes = [u8p, u8p, C.c_int64, C.c_size_t, C.c_double, C.c_char_p]
         self._libc = C.CDLL(None)
+
+    def mlv_index(self, path: str, with_idx_file: bool = False) -> bytes:
+        """XREF block of a clip from the reference's index.c (with_idx_file: get_index, reads or writes <name>.IDX)."""
+        buf = np.zeros(1 << 22, np.uint8)
+        f = self.L.ref_mlv_get_index if with_idx_file else self.L.ref_mlv_new_index
+        n = f(path.encode(), buf, buf.size)
+        return buf[:n].tobytes()
+
+    def mlv_frame_count(self, path: str) -> int:
+        return self.L.ref_mlv_frame_count(path.encode())
 
     def header_data(self, fh_blob: np.ndarray, offset: int = 0, max_size: int = 65536, fps_override: float = 0.0,
                     basename: bytes = b"clip"):

@@ -188,3 +188,18 @@ size_t ref_header_data(void *frame_headers_blob, uint8_t *out, int64_t offset, s
     return dng_get_header_data((struct frame_headers *)frame_headers_blob, out, (off_t)offset, max_size, fps_override,
                                (char *)mlv_basename);
 }
+
+/* The reference's MLV index (index.c builds from its own single source file): the XREF block without / with the
+ * .IDX file beside the clip, and the frame count derived from it. */
+#include "index.h"
+static size_t copy_xref(mlv_xref_hdr_t *x, uint8_t *out, size_t cap)
+{
+    if (!x) return 0;
+    size_t n = x->blockSize;
+    if (out && n <= cap) memcpy(out, x, n);
+    free(x);
+    return n;
+}
+size_t ref_mlv_new_index(const char *path, uint8_t *out, size_t cap) { return copy_xref(get_new_index(path), out, cap); }
+size_t ref_mlv_get_index(const char *path, uint8_t *out, size_t cap) { return copy_xref(get_index(path), out, cap); }
+int ref_mlv_frame_count(const char *path) { return mlv_get_frame_count(path); }

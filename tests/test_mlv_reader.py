@@ -1,0 +1,176 @@
+"""MLV container reader + prefetcher (csrc/mlvreader.cpp).
+
+CPU (`-m "not gpu"`): index, .IDX file and frame count against the reference's own index.c (oracle/_ref) and against the
+restatement oracle/mlv_container.py; per-frame headers against the restatement of main.c:429-558; payload reads.
+GPU: file -> fused pipeline equals the oracle's process_frame on the same frames.
+"""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from mlvfs_amd import mlvfile, synth
+from oracle import mlv_container as orc
+
+W, H = 64, 48
+
+
+def payloads(n, w=W, h=H, seed=3):
+    return [synth.pack_bits(synth.normal_frame(w, h, seed=seed, frame=k)).tobytes() for k in range(n)]
+
+
+CLIPS = {
+    "plain": dict(n=9),
+    "plain_no_extras": dict(n=4, extras=False),
+    "frame_space": dict(n=7, frame_space=96),
+    "three_chunks": dict(n=11, chunks=3),
+    "shuffled": dict(n=10, shuffle=True),
+    "shuffled_chunks_space": dict(n=13, chunks=2, shuffle=True, frame_space=32),
+}
+
+
+@pytest.fixture(scope="module", params=sorted(CLIPS))
+def clip(request, tmp_path_factory):
+    kw = dict(CLIPS[request.param])
+    n = kw.pop("n")
+    d = tmp_path_factory.mktemp(request.param)
+    pl = payloads(n)
+    names = mlvfile.write_clip(str(d / "M27-1337.MLV"), pl, W, H, **kw)
+    return names, pl, kw
+
+
+def test_index_equals_reference_and_restatement(clip, reference):
+    names, pl, _ = clip
+    with mlvfile.MlvReader(names[0]) as r:
+        got = r.xref()
+        assert r.frame_count == len(pl) and r.chunk_count == len(names)
+    assert got == orc.make_index(names)
+    assert got == reference.mlv_index(names[0])                                    # index.c:216-341, 458-486
+    assert not os.path.exists(names[0][:-3] + "IDX")
+
+
+def test_index_equals_committed_reference_vectors(request, clip, tmp_path):
+    """tests/golden/mlv_index.npz (made by the reference's index.c, tests/golden/make_mlv_golden.py)."""
+    names, pl, _ = clip
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mlv_index.npz"))
+    key = request.node.callspec.params["clip"]
+    with mlvfile.MlvReader(names[0]) as r:
+        assert r.xref() == gold[key + "_xref"].tobytes() == orc.make_index(names)
+    assert orc.idx_file(names) == gold[key + "_idx"].tobytes()
+
+
+def test_idx_file_equals_reference(clip, reference, tmp_path):
+    names, pl, _ = clip
+    a, b = tmp_path / "ours", tmp_path / "theirs"
+    for d in (a, b):
+        d.mkdir()
+        for nm in names:
+            shutil.copy(nm, d / os.path.basename(nm))
+    base = os.path.basename(names[0])
+    with mlvfile.MlvReader(str(a / base), use_idx_file=True) as r:                  # no .IDX yet: scan and save (index.c:426-456)
+        ours = r.xref()
+    assert reference.mlv_frame_count(str(b / base)) == len(pl)                      # the reference writes its own .IDX here
+    idx_ours, idx_ref = (a / (base[:-3] + "IDX")).read_bytes(), (b / (base[:-3] + "IDX")).read_bytes()
+    assert idx_ours == idx_ref == orc.idx_file([str(a / os.path.basename(nm)) for nm in names])
+    assert reference.mlv_index(str(b / base), with_idx_file=True) == ours
+    # an existing .IDX is believed (load_index, index.c:101-165), even when it lists fewer frames than the clip holds
+    n_ent = (len(idx_ref) - 52 - 24) // 12
+    cut = bytearray(idx_ref[: 52 + 24 + 12 * (n_ent - 1)])
+    cut[52 + 4:52 + 8] = (24 + 12 * (n_ent - 1)).to_bytes(4, "little")
+    cut[52 + 20:52 + 24] = (n_ent - 1).to_bytes(4, "little")
+    (a / (base[:-3] + "IDX")).write_bytes(bytes(cut))
+    (b / (base[:-3] + "IDX")).write_bytes(bytes(cut))
+    with mlvfile.MlvReader(str(a / base), use_idx_file=True) as r:
+        assert r.xref() == reference.mlv_index(str(b / base), with_idx_file=True) == bytes(cut[52:])
+
+
+def test_frame_headers_equal_restatement(clip):
+    names, pl, kw = clip
+    with mlvfile.MlvReader(names[0]) as r:
+        for k in list(range(len(pl))) + [len(pl), len(pl) + 5, -1]:
+            ok, fh = r.frame_headers(k)
+            want_ok, want = orc.frame_headers(names, k)
+            assert ok == want_ok and bytes(fh) == want, k
+        ok, fh = r.frame_headers(len(pl) - 1)
+        assert ok == 1 and fh.rawi_hdr.xRes == W and fh.vidf_hdr.frameSpace == kw.get("frame_space", 0)
+        if kw.get("extras", True) and not kw.get("shuffle"):
+            assert fh.expo_hdr.isoValue == 800 and fh.lens_hdr.focalLength == 35          # the mid-clip EXPO / LENS blocks
+            assert r.frame_headers(0)[1].expo_hdr.isoValue == 100
+        if len(names) > 1:
+            assert fh.file_hdr.fileNum == len(names) - 1                                    # the LAST chunk's MLVI wins (main.c:496-500)
+
+
+def test_payloads(clip):
+    names, pl, _ = clip
+    stride = (len(pl[0]) + 2 + 15) // 16 * 16
+    with mlvfile.MlvReader(names[0]) as r:
+        got = r.read_frames(0, len(pl), stride, io_threads=3)
+        for k, p in enumerate(pl):
+            assert got[k, :len(p)].tobytes() == p and not got[k, len(p):].any(), k
+        one = r.read_frames(len(pl) - 1, 1, stride)
+        assert one[0, :len(pl[-1])].tobytes() == pl[-1]
+        with pytest.raises(Exception):
+            r.read_frames(len(pl) - 1, 2, stride)                                       # past the last frame
+        with pytest.raises(Exception):
+            r.read_frames(0, 1, len(pl[0]) - 16)                                        # stride smaller than a payload
+
+
+def test_damaged_and_foreign_files(tmp_path, reference):
+    pl = payloads(5)
+    names = mlvfile.write_clip(str(tmp_path / "A.MLV"), pl, W, H, chunks=2)
+    # truncated in the middle of the last frame: the index still lists the block, the payload read fails
+    data = open(names[0], "rb").read()
+    open(names[0], "wb").write(data[:-100])
+    with mlvfile.MlvReader(names[0]) as r:
+        assert r.xref() == reference.mlv_index(names[0]) == orc.make_index(names)
+        stride = (len(pl[0]) + 2 + 15) // 16 * 16
+        with pytest.raises(Exception):
+            r.read_frames(0, r.frame_count, stride)
+    # a second chunk from another recording (GUID mismatch) contributes nothing (index.c:271-279)
+    other = mlvfile.write_clip(str(tmp_path / "B.MLV"), pl, W, H, chunks=2, guid=0x9999)
+    shutil.copy(other[1], names[1])
+    with mlvfile.MlvReader(names[0]) as r:
+        assert r.xref() == reference.mlv_index(names[0]) == orc.make_index(names)
+        assert r.frame_count == 3
+    # garbage block size stops the scan of that chunk
+    open(names[0], "ab").write(b"VIDF" + (5).to_bytes(4, "little") + bytes(8))
+    with mlvfile.MlvReader(names[0]) as r:
+        assert r.xref() == reference.mlv_index(names[0]) == orc.make_index(names)
+    with pytest.raises(Exception):
+        mlvfile.MlvReader(str(tmp_path / "missing.MLV"))
+
+
+def test_compressed_clips_are_refused(tmp_path):
+    names = mlvfile.write_clip(str(tmp_path / "C.MLV"), payloads(2), W, H, video_class=1 | 0x20)
+    with mlvfile.MlvReader(names[0]) as r:
+        assert r.frame_count == 2 and r.frame_headers(0)[0] == 1
+        with pytest.raises(Exception, match="compressed"):
+            r.read_frames(0, 1, 8192)
+
+
+@pytest.mark.gpu
+def test_file_to_gpu_pipeline_equals_oracle(gpu, oracle, tmp_path):
+    from mlvfs_amd.stream import ClipStream, to_numpy_u16
+    w, h, n = 256, 130, 23
+    frames = [synth.normal_frame(w, h, seed=5, frame=k) for k in range(n)]
+    pl = [synth.pack_bits(f).tobytes() for f in frames]
+    names = mlvfile.write_clip(str(tmp_path / "G.MLV"), pl, w, h, chunks=2, frame_space=64, shuffle=True)
+    s = ClipStream(w, h, 14, synth.BLACK, synth.WHITE, device=0)
+    packed0 = s.upload_packed([synth.pack_bits(frames[0])])
+    s.analyse_first_frame(packed0, cs=5, bad_pix=1, stripes=True, rand_mode=1)
+    pixels = oracle.detect_bad_pixels(frames[0], synth.BLACK, 0)
+    want, corr = [], None
+    for f in frames:
+        img = oracle.chroma_smooth(oracle.apply_bad_pixels(f, synth.BLACK, pixels), synth.BLACK, 5)
+        if corr is None:
+            corr = oracle.stripes_compute(img, synth.BLACK, synth.WHITE, frame_size=w * h * 14 // 8)
+        want.append(oracle.stripes_apply(img, synth.BLACK, synth.WHITE, *corr))
+    with mlvfile.MlvReader(names[0]) as r:
+        assert r.frame_count == n
+        for batch, first, count in ((4, 0, n), (32, 3, 11), (1, n - 2, 2)):
+            out = np.zeros((count, h, w), np.uint16)
+            r.process(s.clip, first, count, out, cs=5, fix_pixels=True, stripes=True, batch=batch, io_threads=3)
+            for k in range(count):
+                assert np.array_equal(out[k], want[first + k]), (batch, first + k)
+    s.close()
