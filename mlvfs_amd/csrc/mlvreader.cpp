@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -63,8 +64,17 @@ struct Reader {
     std::vector<uint32_t> snap_of;              // per frame
     std::vector<uint8_t> has_rawi;              // per snapshot
     frame_headers last;                         // state after every block (what an index past the last frame leaves behind)
+    // page-locked staging of mlvfs_amd_mlv_process, kept between calls (locking pages costs about as much as reading them)
+    mutable uint8_t *stage[2] = { nullptr, nullptr };
+    mutable size_t stage_bytes = 0;
+    mutable std::mutex stage_mu;
 
-    ~Reader() { for (int fd : fds) if (fd >= 0) close(fd); }
+    ~Reader()
+    {
+        for (int fd : fds) if (fd >= 0) close(fd);
+        mlvfs_amd_host_free(stage[0]);
+        mlvfs_amd_host_free(stage[1]);
+    }
 };
 
 // ---- chunks ---------------------------------------------------------------------------------------------------------
@@ -351,8 +361,16 @@ int mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first,
     const size_t stride = (s0.bytes + 2 + 15) / 16 * 16;
     if (batch_frames <= 0) batch_frames = 32;
     batch_frames = std::min(batch_frames, count);
-    uint8_t *stage[2] = { (uint8_t *)mlvfs_amd_host_alloc(stride * batch_frames), (uint8_t *)mlvfs_amd_host_alloc(stride * batch_frames) };
-    int rc = (stage[0] && stage[1]) ? MLVFS_AMD_OK : MLVFS_AMD_ERR_NOMEM;
+    std::lock_guard<std::mutex> lk(r.stage_mu);                     // one streaming call per reader at a time
+    if (r.stage_bytes < stride * batch_frames) {
+        mlvfs_amd_host_free(r.stage[0]);
+        mlvfs_amd_host_free(r.stage[1]);
+        r.stage[0] = (uint8_t *)mlvfs_amd_host_alloc(stride * batch_frames);
+        r.stage[1] = (uint8_t *)mlvfs_amd_host_alloc(stride * batch_frames);
+        r.stage_bytes = (r.stage[0] && r.stage[1]) ? stride * batch_frames : 0;
+    }
+    uint8_t *const *stage = r.stage;
+    int rc = r.stage_bytes ? MLVFS_AMD_OK : MLVFS_AMD_ERR_NOMEM;
     if (rc == MLVFS_AMD_OK) rc = read_frames(r, first, batch_frames, stage[0], stride, io_threads);
     for (int f0 = 0, k = 0; rc == MLVFS_AMD_OK && f0 < count; f0 += batch_frames, k++) {
         const int n = std::min(batch_frames, count - f0), n_next = std::min(batch_frames, count - f0 - n);
@@ -367,8 +385,6 @@ int mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first,
             rc = rc_io;
         }
     }
-    mlvfs_amd_host_free(stage[0]);
-    mlvfs_amd_host_free(stage[1]);
     return rc;
 }
 
