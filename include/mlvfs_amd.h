@@ -179,6 +179,17 @@ int mlvfs_amd_process_frames_host(mlvfs_amd_clip_t *clip, const void *h_packed, 
 void *mlvfs_amd_host_alloc(size_t bytes);
 void mlvfs_amd_host_free(void *p);
 
+/* -- LJ92 payloads ---------------------------------------- */
+/* Lossless-JPEG frames of a compressed clip (MLV_VIDEO_CLASS_FLAG_LJ92; main.c:617-681: lj92_open + lj92_decode + the
+ * untiling loop) decoded on the GPU.  streams[i] / sizes[i]: frame i's JPEG stream in HOST memory (the VIDF payload
+ * behind its 4-byte size word); output: xres x yres 16-bit pixels per frame at d_out + i * out_stride, in the layout
+ * dng_get_image_data produces, ready for the stages above.  Predictor 6 (what MLV writers use) and 1; one component,
+ * one Huffman table, like the reference's decoder.  Synchronises `stream` before returning.  dims of mlvfs_amd_lj92_info:
+ * {width, height, bits, predictor} of the JPEG itself.                                                             */
+int mlvfs_amd_lj92_info(const void *stream, size_t size, int dims[4]);
+int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_t *sizes, int nframes, int xres, int yres,
+                              void *d_out, size_t out_stride, void *stream);
+
 /* -- MLV container reader and prefetcher (host code) -------- */
 /* Opens <name>.MLV and its chunks .M00, .M01, ... (index.c:367-424) and builds, once, what MLVFS rebuilds for every
  * frame it serves: the XREF index (index.c:216-341; use_idx_file != 0: taken from <name>.IDX when that exists, written

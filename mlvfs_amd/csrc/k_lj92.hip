@@ -1,0 +1,413 @@
+// k_lj92.hip -- lossless-JPEG ("LJ92") frame payloads decoded on the GPU.
+//
+// Replaces, per frame of a compressed clip (mlvfs/main.c:617-681):
+//   lj92_open / lj92_decode    mlvfs/lj92.c:344-406 (nextdiff), 408-593 (parsePred6, parseScan), 650-702
+//   the untiling loop          mlvfs/main.c:646-667
+// Header parsing and the Huffman look-up table stay on the host (csrc/lj92.cpp).
+//
+// The reference decodes one symbol after the other: a Huffman code, then `ssss` raw bits, then a prediction from the pixel
+// just reconstructed.  Both dependencies are taken apart here, exactly:
+//
+// 1. WHERE THE SYMBOLS START.  The unstuffed bit stream is cut into chunks of 256 bits.  A symbol is at most 32 bits long,
+//    so whatever came before, the first symbol that starts inside a chunk starts at one of its first 32 bits.  For each of
+//    those 32 entry offsets a thread decodes to the end of its chunk and records {offset at which the next chunk is
+//    entered, symbols decoded}: a 32-entry map per chunk (k_lj_chunk_maps).  Maps compose (entry -> exit of one chunk is
+//    the entry of the next), so 32 lanes walking 256 chunk maps give the map of a workgroup's 8 KiB, 32 lanes walking 32 of
+//    those the map of a group (k_lj_group_maps), and a single walk over the few dozen groups from offset 0 (the scan
+//    starts on a symbol) gives every group's true entry offset and first symbol index (k_lj_top); two more walks hand
+//    these down to workgroups and chunks (k_lj_group_starts, k_lj_decode).  Every chunk then decodes only its true symbols
+//    and stores each difference at its index.
+// 2. THE PREDICTOR.  Predictor 6, the one MLV files use (lj92.c:951), is  x = above + ((left - above_left) >> 1) + d.
+//    With e = x - above it reads  e[c] = (e[c-1] >> 1) + d[c]  along a row, and nested floor divisions collapse:
+//        e[c0 + i] = (e[c0] + sum_{j=1..i} d[c0+j] * 2^j) >> i        (exact in 64 bits for i <= 32)
+//    so a row is 32-column blocks with one carried value between them (k_lj_rows), rows are independent of each other,
+//    and x is the running sum of e down each column (k_lj_columns), which also writes the pixel to its untiled position.
+//    Predictor 1 (left) is a prefix sum along each row plus one down the first column.  The first row is always a prefix
+//    sum (lj92.c:533-537), the first pixel is predicted by 2^(bits-1).
+// No MFMA: bit-stream and integer work.
+#include "lj92.h"
+
+namespace mlv {
+
+namespace {
+
+constexpr int CHUNK_BITS = 256, CHUNK_BYTES = 32, ENTRIES = 32;
+constexpr int WG_CHUNKS = 256;                          // chunks per workgroup (8 KiB of stream)
+constexpr int GROUP_WGS = 32;                           // workgroup maps per group map
+constexpr int UNSTUFF_BYTES = 16;                       // bytes per thread in the unstuff kernels
+
+__device__ __forceinline__ uint32_t bswap(uint32_t v) { return __builtin_bswap32(v); }
+
+// ---------------------------------------------------------------- byte unstuffing (0xFF 0x00 -> 0xFF)
+// a byte is dropped iff it is 0x00 and the byte before it is 0xFF (lj92.c:358-370)
+__device__ __forceinline__ int dropped_in(const uint8_t *raw, uint32_t len, uint32_t p0, uint32_t *keep_mask)
+{
+    int n = 0;
+    uint32_t mask = 0;
+    uint8_t prev = p0 ? raw[p0 - 1] : 0;
+    for (int i = 0; i < UNSTUFF_BYTES; i++) {
+        const uint32_t p = p0 + i;
+        if (p >= len) break;
+        const uint8_t b = raw[p];
+        const bool drop = b == 0 && prev == 0xFF;
+        n += drop;
+        mask |= (drop ? 0u : 1u) << i;
+        prev = b;
+    }
+    *keep_mask = mask;
+    return n;
+}
+
+__global__ __launch_bounds__(256) void k_lj_unstuff_count(const LjFrame *frames)
+{
+    const LjFrame &f = frames[blockIdx.y];
+    const uint32_t p0 = (blockIdx.x * 256u + threadIdx.x) * UNSTUFF_BYTES;
+    if (blockIdx.x * 256u * UNSTUFF_BYTES >= f.raw_len) return;
+    uint32_t mask;
+    int n = p0 < f.raw_len ? dropped_in(f.raw, f.raw_len, p0, &mask) : 0;
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    if (n) atomicAdd(&total, n);
+    __syncthreads();
+    if (threadIdx.x == 0) f.blk_drop[blockIdx.x] = (uint32_t)total;
+}
+
+// exclusive scan of the per-block drop counts (a few hundred to a few thousand values per frame)
+__global__ __launch_bounds__(256) void k_lj_unstuff_scan(const LjFrame *frames)
+{
+    const LjFrame &f = frames[blockIdx.x];
+    const uint32_t nblk = (f.raw_len + 256u * UNSTUFF_BYTES - 1) / (256u * UNSTUFF_BYTES);
+    __shared__ uint32_t part[256];
+    const uint32_t per = (nblk + 255) / 256, b0 = threadIdx.x * per, b1 = min(nblk, b0 + per);
+    uint32_t s = 0;
+    for (uint32_t b = b0; b < b1; b++) s += f.blk_drop[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 256; i++) { const uint32_t v = part[i]; part[i] = run; run += v; }
+        *f.ust_len = f.raw_len - run;
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t b = b0; b < b1; b++) { const uint32_t v = f.blk_drop[b]; f.blk_drop[b] = run; run += v; }
+}
+
+__global__ __launch_bounds__(256) void k_lj_unstuff_scatter(const LjFrame *frames)
+{
+    const LjFrame &f = frames[blockIdx.y];
+    if (blockIdx.x * 256u * UNSTUFF_BYTES >= f.raw_len) {
+        // the first idle workgroup clears the look-ahead tail behind the unstuffed data
+        if ((blockIdx.x - 1) * 256u * UNSTUFF_BYTES < f.raw_len || f.raw_len == 0) {
+            const uint32_t n = *f.ust_len;
+            for (uint32_t i = threadIdx.x; i < LJ_TAIL; i += 256) f.ust[n + i] = 0;
+        }
+        return;
+    }
+    const uint32_t p0 = (blockIdx.x * 256u + threadIdx.x) * UNSTUFF_BYTES;
+    uint32_t mask = 0;
+    const int n = p0 < f.raw_len ? dropped_in(f.raw, f.raw_len, p0, &mask) : 0;
+    __shared__ uint32_t sc[256];
+    sc[threadIdx.x] = (uint32_t)n;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {                  // inclusive scan of 256 small counts
+        const uint32_t v = threadIdx.x >= (unsigned)d ? sc[threadIdx.x - d] : 0;
+        __syncthreads();
+        sc[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (p0 >= f.raw_len) return;
+    uint32_t dst = p0 - (f.blk_drop[blockIdx.x] + sc[threadIdx.x] - (uint32_t)n);
+    for (int i = 0; i < UNSTUFF_BYTES; i++) {
+        if (p0 + i >= f.raw_len) break;
+        if ((mask >> i) & 1u) f.ust[dst++] = f.raw[p0 + i];
+    }
+}
+
+// ---------------------------------------------------------------- symbol walk
+// big-endian words of a workgroup's 8 KiB (+ look-ahead) in LDS; the 32 stream bits starting at bit `p` of the workgroup
+struct Window {
+    const uint32_t *w;
+    __device__ __forceinline__ uint32_t at(uint32_t p) const
+    {
+        const uint32_t i = p >> 5, s = p & 31;
+        const uint64_t two = ((uint64_t)w[i] << 32) | w[i + 1];
+        return (uint32_t)(two >> (32 - s));
+    }
+};
+
+// one symbol at bit p: returns its length in bits (code + ssss raw bits) and the decoded difference
+template <typename Lut>
+__device__ __forceinline__ uint32_t symbol(const Window &win, const Lut lut, int huffbits, uint32_t p, int *diff, bool *bad)
+{
+    const uint32_t bits = win.at(p);
+    const uint32_t e = lut[bits >> (32 - huffbits)];
+    const uint32_t used = e & 0xFFu, t = e >> 8;
+    if (used == 0 || t > 16) { *bad = true; *diff = 0; return 1; }           // no such code: step on, the frame is reported corrupt
+    int d = 0;
+    if (t) {
+        d = (int)((bits << used) >> (32 - t));
+        if (d < (1 << (t - 1))) d += (int)(0xFFFFFFFFu << t) + 1;
+    }
+    *diff = d;
+    return used + t;
+}
+
+constexpr int WG_WORDS = WG_CHUNKS * CHUNK_BYTES / 4;   // 2048
+constexpr int LUT_LDS_BITS = 13;                        // tables up to 2^13 entries (16 KiB) are copied to LDS
+
+struct WalkSmem {
+    uint32_t words[WG_WORDS + 4];
+    uint16_t cmap[WG_CHUNKS][ENTRIES];                  // exit offset | symbols << 5
+    uint16_t lut[1 << LUT_LDS_BITS];
+    uint32_t cstart[WG_CHUNKS][2];                      // true entry offset, index of the first symbol (k_lj_decode)
+};
+
+__device__ __forceinline__ void load_window(const LjFrame &f, uint32_t wg, WalkSmem &sm)
+{
+    const uint32_t *src = (const uint32_t *)(f.ust + (size_t)wg * WG_CHUNKS * CHUNK_BYTES);      // ust is 16-byte aligned
+    for (int i = threadIdx.x; i < WG_WORDS + 4; i += blockDim.x) sm.words[i] = bswap(src[i]);
+    if (f.huffbits <= LUT_LDS_BITS)
+        for (int i = threadIdx.x; i < (1 << f.huffbits); i += blockDim.x) sm.lut[i] = f.lut[i];
+}
+
+// chunk maps of one workgroup + their composition
+__global__ __launch_bounds__(256) void k_lj_chunk_maps(const LjFrame *frames)
+{
+    const LjFrame &f = frames[blockIdx.y];
+    const uint32_t wg = blockIdx.x;
+    if (wg >= f.nwg) return;
+    __shared__ WalkSmem sm;
+    load_window(f, wg, sm);
+    __syncthreads();
+    const Window win{ sm.words };
+    const uint32_t c0 = threadIdx.x * CHUNK_BITS;
+    for (int e = 0; e < ENTRIES; e++) {
+        uint32_t p = c0 + e, n = 0;
+        while (p < c0 + CHUNK_BITS) {
+            int d;
+            bool bad = false;
+            p += f.huffbits <= LUT_LDS_BITS ? symbol(win, (const uint16_t *)sm.lut, f.huffbits, p, &d, &bad)
+                                            : symbol(win, f.lut, f.huffbits, p, &d, &bad);
+            n++;
+        }
+        sm.cmap[threadIdx.x][e] = (uint16_t)((p - c0 - CHUNK_BITS) | (n << 5));
+    }
+    __syncthreads();
+    uint32_t *dst = (uint32_t *)(f.cmap + (size_t)wg * WG_CHUNKS * ENTRIES);
+    const uint32_t *srcm = (const uint32_t *)&sm.cmap[0][0];
+    for (int i = threadIdx.x; i < WG_CHUNKS * ENTRIES / 2; i += blockDim.x) dst[i] = srcm[i];
+    if (threadIdx.x < ENTRIES) {                         // 32 lanes walk the 256 chunk maps
+        uint32_t e = threadIdx.x, n = 0;
+        for (int c = 0; c < WG_CHUNKS; c++) {
+            const uint32_t m = sm.cmap[c][e];
+            e = m & 31u;
+            n += m >> 5;
+        }
+        f.wmap[(size_t)wg * ENTRIES + threadIdx.x] = make_uint2(e, n);
+    }
+}
+
+// map of GROUP_WGS consecutive workgroup maps
+__global__ __launch_bounds__(64) void k_lj_group_maps(const LjFrame *frames)
+{
+    const LjFrame &f = frames[blockIdx.y];
+    const uint32_t g = blockIdx.x;
+    if (g >= f.ngrp || threadIdx.x >= ENTRIES) return;
+    uint32_t e = threadIdx.x, n = 0;
+    const uint32_t w1 = min(f.nwg, (g + 1) * GROUP_WGS);
+    for (uint32_t w = g * GROUP_WGS; w < w1; w++) {
+        const uint2 m = f.wmap[(size_t)w * ENTRIES + e];
+        e = m.x;
+        n += m.y;
+    }
+    f.gmap[(size_t)g * ENTRIES + threadIdx.x] = make_uint2(e, n);
+}
+
+// the scan starts on a symbol: offset 0 of group 0.  One thread per frame walks the group maps.
+__global__ void k_lj_top(const LjFrame *frames, int nframes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nframes) return;
+    const LjFrame &f = frames[i];
+    uint32_t e = 0, n = 0;
+    for (uint32_t g = 0; g < f.ngrp; g++) {
+        f.gstart[g] = make_uint2(e, n);
+        const uint2 m = f.gmap[(size_t)g * ENTRIES + e];
+        e = m.x;
+        n += m.y;
+    }
+    if (n < (uint32_t)f.W * (uint32_t)f.H) atomicOr(f.err, LJ_ERR_SHORT);           // fewer symbols than pixels
+}
+
+__global__ __launch_bounds__(64) void k_lj_group_starts(const LjFrame *frames)
+{
+    const LjFrame &f = frames[blockIdx.y];
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= f.ngrp) return;
+    uint2 s = f.gstart[g];
+    const uint32_t w1 = min(f.nwg, (g + 1) * GROUP_WGS);
+    for (uint32_t w = g * GROUP_WGS; w < w1; w++) {
+        f.wstart[w] = s;
+        const uint2 m = f.wmap[(size_t)w * ENTRIES + s.x];
+        s.x = m.x;
+        s.y += m.y;
+    }
+}
+
+// every chunk decodes its true symbols and stores the differences at their pixel index
+__global__ __launch_bounds__(256) void k_lj_decode(const LjFrame *frames)
+{
+    const LjFrame &f = frames[blockIdx.y];
+    const uint32_t wg = blockIdx.x;
+    if (wg >= f.nwg) return;
+    const uint32_t npx = (uint32_t)f.W * (uint32_t)f.H;
+    const uint2 start = f.wstart[wg];
+    if (start.y >= npx) return;                          // everything behind the last pixel is padding / the EOI marker
+    __shared__ WalkSmem sm;
+    load_window(f, wg, sm);
+    const uint32_t *srcm = (const uint32_t *)(f.cmap + (size_t)wg * WG_CHUNKS * ENTRIES);
+    uint32_t *dstm = (uint32_t *)&sm.cmap[0][0];
+    for (int i = threadIdx.x; i < WG_CHUNKS * ENTRIES / 2; i += blockDim.x) dstm[i] = srcm[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t e = start.x, n = start.y;
+        for (int c = 0; c < WG_CHUNKS; c++) {
+            sm.cstart[c][0] = e;
+            sm.cstart[c][1] = n;
+            const uint32_t m = sm.cmap[c][e];
+            e = m & 31u;
+            n += m >> 5;
+        }
+    }
+    __syncthreads();
+    const Window win{ sm.words };
+    const uint32_t c0 = threadIdx.x * CHUNK_BITS;
+    uint32_t p = c0 + sm.cstart[threadIdx.x][0], idx = sm.cstart[threadIdx.x][1];
+    const uint64_t end_bit = (uint64_t)*f.ust_len * 8, wg_bit0 = (uint64_t)wg * WG_CHUNKS * CHUNK_BITS;
+    bool bad_any = false;
+    while (p < c0 + CHUNK_BITS && idx < npx) {
+        int d;
+        bool bad = false;
+        const uint32_t len = f.huffbits <= LUT_LDS_BITS ? symbol(win, (const uint16_t *)sm.lut, f.huffbits, p, &d, &bad)
+                                                        : symbol(win, f.lut, f.huffbits, p, &d, &bad);
+        if (wg_bit0 + p + len > end_bit) bad = true;      // a pixel decoded from bits behind the end of the data
+        bad_any |= bad;
+        f.diff[idx++] = d;
+        p += len;
+    }
+    if (bad_any) atomicOr(f.err, LJ_ERR_CODE);
+}
+
+// ---------------------------------------------------------------- prediction
+// one workgroup per row.  HALVING rows (predictor 6, r >= 1): e[c] = (e[c-1] >> 1) + d[c] in blocks of 32 columns.
+// SCAN rows (row 0 always, every row of predictor 1): inclusive prefix sum; row 0 also carries the base 2^(bits-1).
+// The row is rewritten in place (diff -> e).
+__global__ __launch_bounds__(256) void k_lj_rows(const LjFrame *frames)
+{
+    const LjFrame &f = frames[blockIdx.y];
+    const int r = blockIdx.x;
+    if (r >= f.H) return;
+    int *row = f.diff + (size_t)r * f.W;
+    const int W = f.W;
+    __shared__ long long carry[2048 + 1];               // W <= 65535: at most 2048 blocks of 32 columns
+    if (r == 0 || f.pred == 1) {
+        // predictor 1, r >= 1: e[0] = d[0] stays, e[c] = d[1] + .. + d[c];  row 0: x[c] = base + d[0] + .. + d[c]
+        const int first = r == 0 ? 0 : 1;
+        const int nblk = (W - first + 31) / 32;
+        for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+            long long s = 0;
+            const int c0 = first + b * 32;
+            for (int i = 0; i < 32 && c0 + i < W; i++) s += row[c0 + i];
+            carry[b + 1] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long run = r == 0 ? (1ll << (f.bits - 1)) : 0;
+            for (int b = 0; b < nblk; b++) { const long long v = carry[b + 1]; carry[b] = run; run += v; }
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+            long long s = carry[b];
+            const int c0 = first + b * 32;
+            for (int i = 0; i < 32 && c0 + i < W; i++) { s += row[c0 + i]; row[c0 + i] = (int)s; }
+        }
+        return;
+    }
+    // A[b] = sum_{i=1..n} d[c0+i] << i over block b = columns c0+1 .. c0+n (c0 = 32 b)
+    const int nblk = (W - 1 + 31) / 32;
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+        long long a = 0;
+        const int c0 = b * 32;
+        for (int i = 1; i <= 32 && c0 + i < W; i++) a += (long long)row[c0 + i] << i;
+        carry[b + 1] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long e = row[0];                            // e[0] = d[0]: the first column is predicted by the pixel above
+        for (int b = 0; b < nblk; b++) {
+            const long long a = carry[b + 1];
+            carry[b] = e;                                // e at column 32 b
+            const int n = min(32, W - 1 - b * 32);
+            e = (e + a) >> n;
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+        const long long e0 = carry[b];
+        long long s = 0;
+        const int c0 = b * 32;
+        for (int i = 1; i <= 32 && c0 + i < W; i++) {
+            s += (long long)row[c0 + i] << i;
+            row[c0 + i] = (int)((e0 + s) >> i);
+        }
+    }
+}
+
+// one thread per column: running sums down the rows, pixel written (as 16 bits) to its untiled position
+__global__ __launch_bounds__(256) void k_lj_columns(const LjFrame *frames)
+{
+    const LjFrame &f = frames[blockIdx.y];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= f.W) return;
+    const uint32_t xres = (uint32_t)f.xres, yres = (uint32_t)f.yres;
+    int x = 0, x0 = 0;
+    for (int r = 0; r < f.H; r++) {
+        const int e = f.diff[(size_t)r * f.W + c];
+        int px;
+        if (r == 0) { x = e; px = e; x0 = f.diff[0]; }
+        else if (f.pred == 1) {
+            x0 += f.diff[(size_t)r * f.W];                // first column: predicted by the pixel above
+            px = c ? x0 + e : x0;
+        } else { x += e; px = x; }
+        // main.c:646-667 reads the decoded image as yres rows of xres values, whatever the JPEG's own dimensions are
+        const uint32_t i = (uint32_t)r * (uint32_t)f.W + (uint32_t)c;
+        const uint32_t sy = i / xres, sx = i - sy * xres;
+        const uint32_t dy = (2 * sy) % yres + (2 * sy) / yres, dx = (2 * sx) % xres + (2 * sx) / xres;
+        f.out[(size_t)dy * xres + dx] = (uint16_t)px;
+    }
+}
+
+}  // namespace
+
+int lj92_launch(const LjFrame *d_frames, int nframes, uint32_t max_raw, uint32_t max_nwg, uint32_t max_ngrp, int max_w, int max_h,
+                hipStream_t s)
+{
+    if (nframes <= 0) return MLVFS_AMD_OK;
+    const uint32_t ublk = (max_raw + 256u * UNSTUFF_BYTES - 1) / (256u * UNSTUFF_BYTES);
+    hipLaunchKernelGGL(k_lj_unstuff_count, dim3(ublk, nframes), dim3(256), 0, s, d_frames);
+    hipLaunchKernelGGL(k_lj_unstuff_scan, dim3(nframes), dim3(256), 0, s, d_frames);
+    hipLaunchKernelGGL(k_lj_unstuff_scatter, dim3(ublk + 1, nframes), dim3(256), 0, s, d_frames);
+    hipLaunchKernelGGL(k_lj_chunk_maps, dim3(max_nwg, nframes), dim3(256), 0, s, d_frames);
+    hipLaunchKernelGGL(k_lj_group_maps, dim3(max_ngrp, nframes), dim3(64), 0, s, d_frames);
+    hipLaunchKernelGGL(k_lj_top, dim3((nframes + 63) / 64), dim3(64), 0, s, d_frames, nframes);
+    hipLaunchKernelGGL(k_lj_group_starts, dim3((max_ngrp + 63) / 64, nframes), dim3(64), 0, s, d_frames);
+    hipLaunchKernelGGL(k_lj_decode, dim3(max_nwg, nframes), dim3(256), 0, s, d_frames);
+    hipLaunchKernelGGL(k_lj_rows, dim3(max_h, nframes), dim3(256), 0, s, d_frames);
+    hipLaunchKernelGGL(k_lj_columns, dim3((max_w + 255) / 256, nframes), dim3(256), 0, s, d_frames);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+}  // namespace mlv

@@ -1,0 +1,214 @@
+// lj92.cpp -- host side of the LJ92 decoder: JPEG marker parsing, the Huffman look-up table, work buffers.
+//
+//   stream structure   mlvfs/lj92.c:82-94 (marker search), 276-290 (SOF3, skipped blocks), 595-626 (marker loop), 512-520 (SOS)
+//   look-up table      mlvfs/lj92.c:222-270 (direct table indexed by the longest code's worth of bits)
+//   kernels            csrc/k_lj92.hip
+// Supported: what the reference's decoder supports (one component, one table, 16-bit look-ups) with predictor 6 -- the only
+// one the reference's own encoder writes (lj92.c:951) -- or predictor 1.  Other predictors are refused with an error.
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "lj92.h"
+
+namespace mlv {
+namespace {
+
+struct Parsed {
+    int width = 0, height = 0, bits = 0, pred = -1, huffbits = 0, scan = 0;
+    uint8_t count[17] = { 0 };
+    const uint8_t *vals = nullptr;
+    int nvals = 0;
+};
+
+int be16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
+
+// The reference looks for the next 0xFF from wherever the previous segment left it (it does not skip over a DHT's body) and
+// takes the byte behind it as the marker; same here, so that the same streams are accepted.
+bool parse(const uint8_t *d, int len, Parsed *h, const char **why)
+{
+    int ix = 0;
+    auto marker = [&]() -> int {
+        int i = ix;
+        while (i < len - 1 && d[i] != 0xFF) i++;
+        i += 2;
+        if (i >= len) return -1;
+        ix = i;
+        return d[i - 1];
+    };
+    *why = "not a lossless JPEG stream";
+    if (len < 8 || marker() != 0xD8) return false;
+    bool table = false;
+    for (;;) {
+        const int m = marker();
+        if (m < 0) return false;
+        if (m == 0xC4) {
+            if (ix + be16(d + ix) >= len || ix + 19 > len) return false;
+            int n = 0;
+            for (int i = 1; i <= 16; i++) { h->count[i] = d[ix + 2 + i]; n += h->count[i]; }
+            if (n > 256 || ix + 19 + n > len) return false;
+            h->vals = d + ix + 19;
+            h->nvals = n;
+            for (h->huffbits = 16; h->huffbits > 0 && !h->count[h->huffbits];) h->huffbits--;
+            table = true;
+        } else if (m == 0xC3) {
+            if (ix + 6 >= len) return false;
+            h->bits = d[ix + 2];
+            h->height = be16(d + ix + 3);
+            h->width = be16(d + ix + 5);
+            ix += be16(d + ix);
+        } else if (m == 0xDA) {
+            if (ix + 3 >= len) return false;
+            const int nc = d[ix + 2];
+            if (ix + 3 + 2 * nc >= len) return false;
+            h->pred = d[ix + 3 + 2 * nc];
+            h->scan = ix + be16(d + ix);
+            break;
+        } else if (m == 0xD9) {
+            *why = "no scan before the end-of-image marker";
+            return false;
+        } else {
+            ix += be16(d + ix);
+            if (ix >= len) return false;
+        }
+    }
+    if (!table || h->huffbits < 1 || h->width <= 0 || h->height <= 0 || h->bits < 1 || h->bits > 16 || h->scan >= len) return false;
+    return true;
+}
+
+void build_lut(const Parsed &h, uint16_t *lut)
+{
+    const int n = 1 << h.huffbits;
+    memset(lut, 0, sizeof(uint16_t) * n);
+    int i = 0, v = 0;
+    for (int len = 1; len <= h.huffbits; len++)
+        for (int k = 0; k < h.count[len] && v < h.nvals; k++, v++)
+            for (int r = 0; r < (1 << (h.huffbits - len)) && i < n; r++) lut[i++] = (uint16_t)((h.vals[v] << 8) | len);
+}
+
+struct Work {                              // per host thread and device, grow-only
+    uint8_t *d_arena = nullptr, *h_stage = nullptr;
+    size_t cap_arena = 0, cap_stage = 0;
+    int ensure(size_t arena, size_t stage)
+    {
+        if (arena > cap_arena) {
+            if (d_arena) (void)hipFree(d_arena);
+            d_arena = nullptr; cap_arena = 0;
+            MLV_HIP(hipMalloc(&d_arena, arena));
+            cap_arena = arena;
+        }
+        if (stage > cap_stage) {
+            if (h_stage) (void)hipHostFree(h_stage);
+            h_stage = nullptr; cap_stage = 0;
+            MLV_HIP(hipHostMalloc(&h_stage, stage, hipHostMallocDefault));
+            cap_stage = stage;
+        }
+        return MLVFS_AMD_OK;
+    }
+};
+thread_local std::map<int, Work> t_work;
+
+size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+}  // namespace mlv
+
+using namespace mlv;
+
+extern "C" int mlvfs_amd_lj92_info(const void *stream, size_t size, int dims[4])
+{
+    Parsed h;
+    const char *why = "";
+    if (!stream || size > 0x7FFFFFFF || !parse((const uint8_t *)stream, (int)size, &h, &why)) { set_error("lj92: %s", why); return MLVFS_AMD_ERR_ARG; }
+    dims[0] = h.width; dims[1] = h.height; dims[2] = h.bits; dims[3] = h.pred;
+    return MLVFS_AMD_OK;
+}
+
+extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_t *sizes, int nframes, int xres, int yres,
+                                         void *d_out, size_t out_stride, void *stream)
+{
+    ThreadCtx *c = thread_ctx();
+    if (!c) return MLVFS_AMD_ERR_HIP;
+    if (nframes <= 0) return MLVFS_AMD_OK;
+    if (!streams || !sizes || !d_out || xres <= 0 || yres <= 0 || out_stride < (size_t)xres * yres * 2) { set_error("lj92: bad argument"); return MLVFS_AMD_ERR_ARG; }
+    hipStream_t s = pick_stream(stream, c);
+    std::vector<Parsed> hdr(nframes);
+    // ---- layout: one staging block (raw scans, tables, frame records) and one device arena
+    size_t stage = 0, arena = 0;
+    struct Off { size_t raw, lut, ust, ust_len, blk, cmap, wmap, gmap, wstart, gstart, diff, err; uint32_t raw_len, nwg, ngrp; };
+    std::vector<Off> off(nframes);
+    uint32_t max_raw = 0, max_nwg = 0, max_ngrp = 0;
+    int max_w = 0, max_h = 0;
+    for (int i = 0; i < nframes; i++) {
+        const char *why = "";
+        Parsed &h = hdr[i];
+        if (!streams[i] || sizes[i] > 0x7FFFFFFF || !parse((const uint8_t *)streams[i], (int)sizes[i], &h, &why)) { set_error("lj92: frame %d: %s", i, why); return MLVFS_AMD_ERR_ARG; }
+        if (h.pred != 6 && h.pred != 1) { set_error("lj92: frame %d: predictor %d is not supported (1 and 6 are)", i, h.pred); return MLVFS_AMD_ERR_ARG; }
+        if ((long long)h.width * h.height != (long long)xres * yres) {
+            set_error("lj92: frame %d: %dx%d values decoded, the video frame is %dx%d", i, h.width, h.height, xres, yres);
+            return MLVFS_AMD_ERR_ARG;
+        }
+        Off &o = off[i];
+        o.raw_len = (uint32_t)(sizes[i] - (size_t)h.scan);
+        o.nwg = (o.raw_len + 8191) / 8192;
+        if (o.nwg == 0) o.nwg = 1;
+        o.ngrp = (o.nwg + 31) / 32;
+        o.raw = stage; stage += up(o.raw_len + 16, 256);
+        o.lut = stage; stage += up(sizeof(uint16_t) << h.huffbits, 256);
+        max_raw = std::max(max_raw, o.raw_len); max_nwg = std::max(max_nwg, o.nwg); max_ngrp = std::max(max_ngrp, o.ngrp);
+        max_w = std::max(max_w, h.width); max_h = std::max(max_h, h.height);
+    }
+    const size_t frames_at = stage;
+    stage += up(sizeof(LjFrame) * nframes, 256);
+    arena = stage;                                           // the staging block is mirrored at the start of the arena
+    for (int i = 0; i < nframes; i++) {
+        Off &o = off[i];
+        const Parsed &h = hdr[i];
+        o.ust = arena; arena += up((size_t)o.nwg * 8192 + 8192, 256);
+        o.ust_len = arena; arena += 256;
+        o.blk = arena; arena += up(((size_t)o.raw_len / 4096 + 2) * 4, 256);
+        o.cmap = arena; arena += (size_t)o.nwg * 256 * 32 * 2;
+        o.wmap = arena; arena += up((size_t)o.nwg * 32 * 8, 256);
+        o.gmap = arena; arena += up((size_t)o.ngrp * 32 * 8, 256);
+        o.wstart = arena; arena += up((size_t)o.nwg * 8, 256);
+        o.gstart = arena; arena += up((size_t)o.ngrp * 8, 256);
+        o.diff = arena; arena += up((size_t)h.width * h.height * 4, 256);
+        o.err = arena; arena += 256;
+    }
+    Work &w = t_work[c->dev->id];
+    int rc = w.ensure(arena, stage + (size_t)nframes * sizeof(int));
+    if (rc) return rc;
+    LjFrame *fr = (LjFrame *)(w.h_stage + frames_at);
+    for (int i = 0; i < nframes; i++) {
+        const Off &o = off[i];
+        const Parsed &h = hdr[i];
+        memcpy(w.h_stage + o.raw, (const uint8_t *)streams[i] + h.scan, o.raw_len);
+        memset(w.h_stage + o.raw + o.raw_len, 0, 16);
+        build_lut(h, (uint16_t *)(w.h_stage + o.lut));
+        LjFrame &f = fr[i];
+        uint8_t *A = w.d_arena;
+        f.raw = A + o.raw; f.raw_len = o.raw_len;
+        f.ust = A + o.ust; f.ust_len = (uint32_t *)(A + o.ust_len); f.blk_drop = (uint32_t *)(A + o.blk);
+        f.lut = (const uint16_t *)(A + o.lut); f.huffbits = h.huffbits;
+        f.cmap = (uint16_t *)(A + o.cmap); f.wmap = (uint2 *)(A + o.wmap); f.gmap = (uint2 *)(A + o.gmap);
+        f.wstart = (uint2 *)(A + o.wstart); f.gstart = (uint2 *)(A + o.gstart);
+        f.diff = (int32_t *)(A + o.diff);
+        f.out = (uint16_t *)((uint8_t *)d_out + (size_t)i * out_stride);
+        f.W = h.width; f.H = h.height; f.bits = h.bits; f.pred = h.pred; f.xres = xres; f.yres = yres;
+        f.nwg = o.nwg; f.ngrp = o.ngrp;
+        f.err = (int *)(A + o.err);
+    }
+    MLV_HIP(hipMemcpyAsync(w.d_arena, w.h_stage, stage, hipMemcpyHostToDevice, s));
+    for (int i = 0; i < nframes; i++) MLV_HIP(hipMemsetAsync(w.d_arena + off[i].err, 0, sizeof(int), s));
+    rc = lj92_launch((const LjFrame *)(w.d_arena + frames_at), nframes, max_raw, max_nwg, max_ngrp, max_w, max_h, s);
+    if (rc) return rc;
+    int *errs = (int *)(w.h_stage + stage);
+    for (int i = 0; i < nframes; i++) MLV_HIP(hipMemcpyAsync(&errs[i], w.d_arena + off[i].err, sizeof(int), hipMemcpyDeviceToHost, s));
+    MLV_HIP(hipStreamSynchronize(s));                        // the staging block is reused by the next call
+    for (int i = 0; i < nframes; i++)
+        if (errs[i]) {
+            set_error("lj92: frame %d is damaged (%s)", i, (errs[i] & LJ_ERR_SHORT) ? "fewer symbols than pixels" : "invalid code or data ends early");
+            return MLVFS_AMD_ERR_ARG;
+        }
+    return MLVFS_AMD_OK;
+}

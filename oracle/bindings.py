@@ -67,6 +67,9 @@ class Oracle:
         L.orc_fix_pattern_noise.argtypes = [i16p, C.c_int, C.c_int, C.c_int]
         L.orc_cr2hdr20.restype = C.c_int
         L.orc_cr2hdr20.argtypes = [u16p] + [C.c_int] * 8 + [i32p, C.c_void_p]
+        L.orc_lj92_decode.argtypes = [u8p, C.c_int, u16p]
+        L.orc_lj92_info.argtypes = [u8p, C.c_int, C.c_void_p]
+        L.orc_lj92_untile.argtypes = [u16p, u16p, C.c_int, C.c_int]
         f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
         L.orc_amaze_demosaic.restype = C.c_int
         L.orc_amaze_demosaic.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p]
@@ -89,6 +92,29 @@ class Oracle:
         return out
 
     # -- stages (all return new arrays; inputs are not modified)
+    def lj92_info(self, data: bytes) -> dict | None:
+        buf = np.frombuffer(data, np.uint8).copy()
+        raw = np.zeros(320, np.uint8)
+        if self.L.orc_lj92_info(buf, buf.size, raw.ctypes.data) != 0:
+            return None
+        w, h, bits, pred, hb, off = raw[:24].view(np.int32)
+        return dict(width=int(w), height=int(h), bits=int(bits), predictor=int(pred), huffbits=int(hb), scan_offset=int(off))
+
+    def lj92_decode(self, data: bytes):
+        """-> (status, width x height uint16 image or None)."""
+        info = self.lj92_info(data)
+        if info is None:
+            return -1, None
+        buf = np.frombuffer(data, np.uint8).copy()
+        out = np.zeros((info["height"], info["width"]), np.uint16)
+        return self.L.orc_lj92_decode(buf, buf.size, out), out
+
+    def lj92_untile(self, img: np.ndarray, xres: int, yres: int) -> np.ndarray:
+        src = np.ascontiguousarray(img, np.uint16).reshape(-1)
+        dst = np.zeros(xres * yres, np.uint16)
+        self.L.orc_lj92_untile(src, dst, xres, yres)
+        return dst.reshape(yres, xres)
+
     def unpack(self, packed: np.ndarray, w: int, h: int, bpp: int = 14, offset: int = 0,
                max_size: int | None = None) -> np.ndarray:
         max_size = w * h * 2 if max_size is None else max_size
@@ -260,9 +286,27 @@ class Reference:
             f.restype = C.c_size_t
             f.argtypes = [C.c_char_p, u8p, C.c_size_t]
         L.ref_mlv_frame_count.argtypes = [C.c_char_p]
+        L.ref_lj92_decode.argtypes = [u8p, C.c_int, u16p, C.c_int, i32p]
+        L.ref_lj92_encode.argtypes = [u16p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
         L.ref_header_data.restype = C.c_size_t
         L.ref_header_data.argtypes = [u8p, u8p, C.c_int64, C.c_size_t, C.c_double, C.c_char_p]
         self._libc = C.CDLL(None)
+
+    def lj92_encode(self, img: np.ndarray, bits: int = 14) -> bytes:
+        img = np.ascontiguousarray(img, np.uint16)
+        h, w = img.shape
+        out = np.zeros(w * h * 3 + 200, np.uint8)
+        n = self.L.ref_lj92_encode(img, w, h, bits, out, out.size)
+        assert n > 0, n
+        return out[:n].tobytes()
+
+    def lj92_decode(self, data: bytes, cap_px: int = 1 << 24):
+        buf = np.frombuffer(data, np.uint8).copy()                 # the reference writes into its input (bits[0] = 0)
+        dims = np.zeros(3, np.int32)
+        out = np.zeros(cap_px, np.uint16)
+        st = self.L.ref_lj92_decode(buf, buf.size, out, cap_px, dims)
+        w, h = int(dims[0]), int(dims[1])
+        return st, (out[: w * h].reshape(h, w).copy() if st == 0 else None)
 
     def mlv_index(self, path: str, with_idx_file: bool = False) -> bytes:
         """XREF block of a clip from the reference's index.c (with_idx_file: get_index, reads or writes <name>.IDX)."""

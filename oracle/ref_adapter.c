@@ -203,3 +203,26 @@ static size_t copy_xref(mlv_xref_hdr_t *x, uint8_t *out, size_t cap)
 size_t ref_mlv_new_index(const char *path, uint8_t *out, size_t cap) { return copy_xref(get_new_index(path), out, cap); }
 size_t ref_mlv_get_index(const char *path, uint8_t *out, size_t cap) { return copy_xref(get_index(path), out, cap); }
 int ref_mlv_frame_count(const char *path) { return mlv_get_frame_count(path); }
+
+/* The reference's LJ92 codec (lj92.c builds from its single source file). */
+#include "lj92.h"
+int ref_lj92_decode(uint8_t *data, int len, uint16_t *out, int cap_px, int dims[3])
+{
+    lj92 h;
+    int ret = lj92_open(&h, data, len, &dims[0], &dims[1], &dims[2]);
+    if (ret != LJ92_ERROR_NONE) return ret;
+    if ((long long)dims[0] * dims[1] > cap_px) { lj92_close(h); return -100; }
+    ret = lj92_decode(h, out, dims[0] * dims[1], 0, NULL, 0);
+    lj92_close(h);
+    return ret;
+}
+int ref_lj92_encode(uint16_t *img, int w, int h, int bits, uint8_t *out, int cap)
+{
+    uint8_t *enc = NULL;
+    int n = 0;
+    int ret = lj92_encode(img, w, h, bits, w * h, 0, NULL, 0, &enc, &n);
+    if (ret != LJ92_ERROR_NONE) return ret;
+    if (n <= cap) memcpy(out, enc, n);
+    free(enc);
+    return n <= cap ? n : -100;
+}

@@ -1,0 +1,136 @@
+"""LJ92 payload decoder.
+
+CPU: the restatement oracle/oracle_lj92.c against the reference's own lj92.c (oracle/_ref) on streams from the reference's
+encoder and on hand-made streams with every predictor; the host parser of the library.
+GPU: csrc/k_lj92.hip against the oracle (and, where present, the reference), bit for bit."""
+import numpy as np
+import pytest
+
+from mlvfs_amd import synth
+from oracle import lj92_testenc as enc
+
+
+def quadrants(f):
+    """What an MLV writer compresses: the four Bayer channels as the quadrants of one image."""
+    return np.ascontiguousarray(np.block([[f[0::2, 0::2], f[0::2, 1::2]], [f[1::2, 0::2], f[1::2, 1::2]]]))
+
+
+def images(w, h, seed=3):
+    rng = np.random.default_rng(seed)
+    f = synth.normal_frame(w, h, seed=seed)
+    return {"smooth": quadrants(f), "noise": rng.integers(0, 16384, (h, w)).astype(np.uint16), "flat": np.full((h, w), 2048, np.uint16),
+            "dark": quadrants(synth.adversarial_frame(w, h, seed=seed))}
+
+
+SIZES = [(64, 48), (136, 72), (256, 130)]
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_oracle_equals_reference(oracle, reference, w, h):
+    for name, img in images(w, h).items():
+        s = reference.lj92_encode(img, 14)                                     # lj92.c:1104-1146: predictor 6
+        st_r, dr = reference.lj92_decode(s)
+        st_o, do = oracle.lj92_decode(s)
+        assert st_r == st_o == 0 and np.array_equal(dr, img) and np.array_equal(do, img), name
+        assert oracle.lj92_info(s) == dict(width=w, height=h, bits=14, predictor=6, huffbits=oracle.lj92_info(s)["huffbits"],
+                                           scan_offset=oracle.lj92_info(s)["scan_offset"])
+        for p in range(8):                                                     # every branch of parseScan (lj92.c:546-563)
+            s = enc.encode(img, p, 14, comment=b"made by tests" if p == 3 else None)
+            st_r, dr = reference.lj92_decode(s)
+            st_o, do = oracle.lj92_decode(s)
+            assert st_r == st_o == 0 and np.array_equal(dr, do), (name, p)
+            assert np.array_equal(do, img), (name, p)
+    wide = np.random.default_rng(1).integers(0, 65536, (h, w)).astype(np.uint16)
+    for p in (1, 2, 3):                                                        # 16-bit samples, differences up to 16 bits long
+        s = enc.encode(wide, p, 16)
+        st_r, dr = reference.lj92_decode(s)
+        st_o, do = oracle.lj92_decode(s)
+        assert st_r == st_o == 0 and np.array_equal(dr, do) and np.array_equal(do, wide), p
+
+
+def test_untile_restatement(oracle):
+    w, h = 64, 48
+    f = synth.normal_frame(w, h, seed=2)
+    assert np.array_equal(oracle.lj92_untile(quadrants(f), w, h), f)           # main.c:646-667 undoes the quadrant layout
+    # the JPEG's own dimensions do not matter, only the flat order does
+    assert np.array_equal(oracle.lj92_untile(quadrants(f).reshape(h // 2, w * 2), w, h), f)
+
+
+def test_host_parser(amd, reference):
+    from mlvfs_amd import lj92
+    img = images(64, 48)["smooth"]
+    assert lj92.info(reference.lj92_encode(img, 14)) == dict(width=64, height=48, bits=14, predictor=6)
+    assert lj92.info(enc.encode(img, 1, 12, comment=b"x" * 40)) == dict(width=64, height=48, bits=12, predictor=1)
+    for junk in (b"", b"\xff\xd8\xff\xd9", b"not a jpeg at all, not even close", enc.encode(img, 6, 14)[:30]):
+        with pytest.raises(Exception):
+            lj92.info(junk)
+
+
+# ---------------------------------------------------------------- GPU
+def gpu_decode(streams, xres, yres):
+    from mlvfs_amd import lj92
+    return lj92.decode_frames(streams, xres, yres).cpu().numpy().view(np.uint16)
+
+
+def want(oracle, stream, xres, yres):
+    st, img = oracle.lj92_decode(stream)
+    assert st == 0
+    return oracle.lj92_untile(img, xres, yres)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", SIZES + [(18, 6), (2, 2), (1920, 18)])
+def test_gpu_equals_oracle(gpu, oracle, w, h):
+    rng = np.random.default_rng(w * h)
+    imgs = images(w, h) if w >= 64 else {"noise": rng.integers(0, 16384, (h, w)).astype(np.uint16)}
+    streams, names = [], []
+    for name, img in imgs.items():
+        for p in (6, 1):
+            streams.append(enc.encode(img, p, 14, comment=b"c" if p == 1 else None))
+            names.append((name, p))
+    streams.append(enc.encode(imgs["noise"], 6, 14, ramp=True))               # codes up to 15 bits: the table stays in global memory
+    names.append(("noise-ramp", 6))
+    got = gpu_decode(streams, w, h)                                            # one batch, streams of different lengths
+    for k, s in enumerate(streams):
+        assert np.array_equal(got[k], want(oracle, s, w, h)), names[k]
+
+
+@pytest.mark.gpu
+def test_gpu_reference_encoder_streams_and_odd_shapes(gpu, oracle, reference):
+    w, h = 256, 130
+    f = synth.normal_frame(w, h, seed=9)
+    q = quadrants(f)
+    for shape in ((h, w), (h // 2, w * 2), (h * 2, w // 2)):                   # JPEG dimensions != video dimensions (main.c:646-667)
+        s = reference.lj92_encode(np.ascontiguousarray(q.reshape(shape)), 14)
+        got = gpu_decode([s], w, h)[0]
+        assert np.array_equal(got, f) and np.array_equal(got, want(oracle, s, w, h)), shape
+    wide = np.random.default_rng(5).integers(0, 65536, (h, w)).astype(np.uint16)   # 0xFF bytes galore, 16-bit differences
+    for p in (1,):
+        s = enc.encode(wide, p, 16)
+        assert s.count(b"\xff\x00") > 50
+        assert np.array_equal(gpu_decode([s], w, h)[0], want(oracle, s, w, h))
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_frame(gpu, oracle, reference):
+    w, h = 3584, 1320
+    frames = [synth.normal_frame(w, h, seed=1, frame=k) for k in range(2)]
+    streams = [reference.lj92_encode(quadrants(f), 14) for f in frames]
+    got = gpu_decode(streams, w, h)
+    for k in range(2):
+        assert np.array_equal(got[k], frames[k])
+    assert np.array_equal(got[0], want(oracle, streams[0], w, h))
+
+
+@pytest.mark.gpu
+def test_gpu_rejects_damage_and_unsupported(gpu, oracle):
+    w, h = 136, 72
+    img = images(w, h)["smooth"]
+    good = enc.encode(img, 6, 14)
+    assert np.array_equal(gpu_decode([good], w, h)[0], want(oracle, good, w, h))
+    with pytest.raises(Exception, match="damaged"):
+        gpu_decode([good[: len(good) // 2]], w, h)                             # the data ends before the last pixel
+    with pytest.raises(Exception, match="predictor"):
+        gpu_decode([enc.encode(img, 4, 14)], w, h)
+    with pytest.raises(Exception, match="video frame"):
+        gpu_decode([good], w + 2, h)
