@@ -161,7 +161,10 @@ struct WalkSmem {
     uint32_t words[WG_WORDS + 4];
     uint16_t cmap[WG_CHUNKS][ENTRIES];                  // exit offset | symbols << 5
     uint16_t lut[1 << LUT_LDS_BITS];
-    uint32_t cstart[WG_CHUNKS][2];                      // true entry offset, index of the first symbol (k_lj_decode)
+    union {
+        uint32_t cstart[WG_CHUNKS][2];                  // true entry offset, index of the first symbol (k_lj_decode)
+        uint16_t ring[32][WG_CHUNKS];                   // k_lj_chunk_maps: {exit, symbols} of the 32 positions ahead, per thread
+    };
 };
 
 __device__ __forceinline__ void load_window(const LjFrame &f, uint32_t wg, WalkSmem &sm)
@@ -183,16 +186,18 @@ __global__ __launch_bounds__(256) void k_lj_chunk_maps(const LjFrame *frames)
     __syncthreads();
     const Window win{ sm.words };
     const uint32_t c0 = threadIdx.x * CHUNK_BITS;
-    for (int e = 0; e < ENTRIES; e++) {
-        uint32_t p = c0 + e, n = 0;
-        while (p < c0 + CHUNK_BITS) {
-            int d;
-            bool bad = false;
-            p += f.huffbits <= LUT_LDS_BITS ? symbol(win, (const uint16_t *)sm.lut, f.huffbits, p, &d, &bad)
-                                            : symbol(win, f.lut, f.huffbits, p, &d, &bad);
-            n++;
-        }
-        sm.cmap[threadIdx.x][e] = (uint16_t)((p - c0 - CHUNK_BITS) | (n << 5));
+    // From the last bit of the chunk backwards: a walk that starts at bit q continues at q + length(q), which is at most 32
+    // bits ahead, so {exit offset, symbols} of the 32 positions ahead (a ring in LDS) are all that is needed.  256 symbol
+    // look-ups per chunk instead of one walk per entry offset (~30 symbols each, 32 of them).
+    for (int q = 0; q < 32; q++) sm.ring[q][threadIdx.x] = (uint16_t)q;              // positions 256..287: already outside
+    for (int q = CHUNK_BITS - 1; q >= 0; q--) {
+        int d;
+        bool bad = false;
+        const uint32_t len = f.huffbits <= LUT_LDS_BITS ? symbol(win, (const uint16_t *)sm.lut, f.huffbits, c0 + q, &d, &bad)
+                                                        : symbol(win, f.lut, f.huffbits, c0 + q, &d, &bad);
+        const uint16_t v = (uint16_t)(sm.ring[(q + len) & 31][threadIdx.x] + 32);    // one more symbol on that walk
+        sm.ring[q & 31][threadIdx.x] = v;            // (q + 32) & 31 == q & 31: read above before it is overwritten here
+        if (q < ENTRIES) sm.cmap[threadIdx.x][q] = v;
     }
     __syncthreads();
     uint32_t *dst = (uint32_t *)(f.cmap + (size_t)wg * WG_CHUNKS * ENTRIES);
@@ -365,27 +370,58 @@ __global__ __launch_bounds__(256) void k_lj_rows(const LjFrame *frames)
     }
 }
 
-// one thread per column: running sums down the rows, pixel written (as 16 bits) to its untiled position
+// Column sums in SEGMENTS of rows so that a single frame still fills the chip: k_lj_column_sums adds up each segment of
+// each column, k_lj_columns starts every segment from the sum of the segments above it and writes the pixels (as 16 bits)
+// to their untiled positions.  Predictor 6 sums e down every column; predictor 1 only down the first one.
+constexpr int COL_SEGS = 16;
+
+__device__ __forceinline__ void seg_rows(const LjFrame &f, int seg, int *r0, int *r1)
+{
+    const int per = (f.H - 1 + COL_SEGS - 1) / COL_SEGS;          // rows 1 .. H-1 (row 0 holds pixel values already)
+    *r0 = 1 + seg * per;
+    *r1 = min(f.H, *r0 + per);
+}
+
+__global__ __launch_bounds__(256) void k_lj_column_sums(const LjFrame *frames)
+{
+    const LjFrame &f = frames[blockIdx.y];
+    const int seg = blockIdx.x % COL_SEGS, c = (blockIdx.x / COL_SEGS) * 256 + threadIdx.x;
+    if (c >= f.W || (f.pred == 1 && c != 0)) return;
+    int r0, r1, s = 0;
+    seg_rows(f, seg, &r0, &r1);
+    for (int r = r0; r < r1; r++) s += f.diff[(size_t)r * f.W + c];
+    f.colsum[(size_t)seg * f.W + c] = s;
+}
+
 __global__ __launch_bounds__(256) void k_lj_columns(const LjFrame *frames)
 {
     const LjFrame &f = frames[blockIdx.y];
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int seg = blockIdx.x % COL_SEGS, c = (blockIdx.x / COL_SEGS) * 256 + threadIdx.x;
     if (c >= f.W) return;
-    const uint32_t xres = (uint32_t)f.xres, yres = (uint32_t)f.yres;
-    int x = 0, x0 = 0;
-    for (int r = 0; r < f.H; r++) {
-        const int e = f.diff[(size_t)r * f.W + c];
+    const uint32_t xres = (uint32_t)f.xres, yres = (uint32_t)f.yres, W = (uint32_t)f.W;
+    int r0, r1;
+    seg_rows(f, seg, &r0, &r1);
+    if (seg == 0) r0 = 0;                                   // the first segment also emits row 0
+    // value carried into this segment: row 0's pixel plus the sums of the segments above
+    const int cc = f.pred == 1 ? 0 : c;
+    int x = f.diff[cc];
+    for (int k = 0; k < seg; k++) x += f.colsum[(size_t)k * W + cc];
+    // main.c:646-667 reads the decoded values as yres rows of xres, whatever the JPEG's own dimensions are: position of
+    // element (r, c) in that reading, advanced row by row without divisions
+    const uint32_t i0 = (uint32_t)r0 * W + (uint32_t)c, qW = W / xres, mW = W - qW * xres;
+    uint32_t sy = i0 / xres, sx = i0 - sy * xres;
+    for (int r = r0; r < r1; r++) {
         int px;
-        if (r == 0) { x = e; px = e; x0 = f.diff[0]; }
-        else if (f.pred == 1) {
-            x0 += f.diff[(size_t)r * f.W];                // first column: predicted by the pixel above
-            px = c ? x0 + e : x0;
-        } else { x += e; px = x; }
-        // main.c:646-667 reads the decoded image as yres rows of xres values, whatever the JPEG's own dimensions are
-        const uint32_t i = (uint32_t)r * (uint32_t)f.W + (uint32_t)c;
-        const uint32_t sy = i / xres, sx = i - sy * xres;
-        const uint32_t dy = (2 * sy) % yres + (2 * sy) / yres, dx = (2 * sx) % xres + (2 * sx) / xres;
+        if (r == 0) px = f.diff[c];
+        else {
+            const int e = f.diff[(size_t)r * W + c];
+            if (f.pred == 1) { x += c ? f.diff[(size_t)r * W] : e; px = c ? x + e : x; }      // first column carries, the row sum rides on it
+            else { x += e; px = x; }
+        }
+        const uint32_t dy = 2 * sy < yres ? 2 * sy : 2 * sy - yres + 1, dx = 2 * sx < xres ? 2 * sx : 2 * sx - xres + 1;
         f.out[(size_t)dy * xres + dx] = (uint16_t)px;
+        sy += qW; sx += mW;
+        if (sx >= xres) { sx -= xres; sy++; }
     }
 }
 
@@ -405,7 +441,8 @@ int lj92_launch(const LjFrame *d_frames, int nframes, uint32_t max_raw, uint32_t
     hipLaunchKernelGGL(k_lj_group_starts, dim3((max_ngrp + 63) / 64, nframes), dim3(64), 0, s, d_frames);
     hipLaunchKernelGGL(k_lj_decode, dim3(max_nwg, nframes), dim3(256), 0, s, d_frames);
     hipLaunchKernelGGL(k_lj_rows, dim3(max_h, nframes), dim3(256), 0, s, d_frames);
-    hipLaunchKernelGGL(k_lj_columns, dim3((max_w + 255) / 256, nframes), dim3(256), 0, s, d_frames);
+    hipLaunchKernelGGL(k_lj_column_sums, dim3((max_w + 255) / 256 * COL_SEGS, nframes), dim3(256), 0, s, d_frames);
+    hipLaunchKernelGGL(k_lj_columns, dim3((max_w + 255) / 256 * COL_SEGS, nframes), dim3(256), 0, s, d_frames);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }

@@ -135,7 +135,7 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
     std::vector<Parsed> hdr(nframes);
     // ---- layout: one staging block (raw scans, tables, frame records) and one device arena
     size_t stage = 0, arena = 0;
-    struct Off { size_t raw, lut, ust, ust_len, blk, cmap, wmap, gmap, wstart, gstart, diff, err; uint32_t raw_len, nwg, ngrp; };
+    struct Off { size_t raw, lut, ust, ust_len, blk, cmap, wmap, gmap, wstart, gstart, diff, colsum, err; uint32_t raw_len, nwg, ngrp; };
     std::vector<Off> off(nframes);
     uint32_t max_raw = 0, max_nwg = 0, max_ngrp = 0;
     int max_w = 0, max_h = 0;
@@ -153,17 +153,17 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
         o.nwg = (o.raw_len + 8191) / 8192;
         if (o.nwg == 0) o.nwg = 1;
         o.ngrp = (o.nwg + 31) / 32;
-        o.raw = stage; stage += up(o.raw_len + 16, 256);
         o.lut = stage; stage += up(sizeof(uint16_t) << h.huffbits, 256);
         max_raw = std::max(max_raw, o.raw_len); max_nwg = std::max(max_nwg, o.nwg); max_ngrp = std::max(max_ngrp, o.ngrp);
         max_w = std::max(max_w, h.width); max_h = std::max(max_h, h.height);
     }
     const size_t frames_at = stage;
     stage += up(sizeof(LjFrame) * nframes, 256);
-    arena = stage;                                           // the staging block is mirrored at the start of the arena
+    arena = stage;                                           // the staging block (tables, frame records) is mirrored at the start of the arena
     for (int i = 0; i < nframes; i++) {
         Off &o = off[i];
         const Parsed &h = hdr[i];
+        o.raw = arena; arena += up(o.raw_len + 16, 256);
         o.ust = arena; arena += up((size_t)o.nwg * 8192 + 8192, 256);
         o.ust_len = arena; arena += 256;
         o.blk = arena; arena += up(((size_t)o.raw_len / 4096 + 2) * 4, 256);
@@ -173,6 +173,7 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
         o.wstart = arena; arena += up((size_t)o.nwg * 8, 256);
         o.gstart = arena; arena += up((size_t)o.ngrp * 8, 256);
         o.diff = arena; arena += up((size_t)h.width * h.height * 4, 256);
+        o.colsum = arena; arena += up((size_t)h.width * 16 * 4, 256);
         o.err = arena; arena += 256;
     }
     Work &w = t_work[c->dev->id];
@@ -182,8 +183,6 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
     for (int i = 0; i < nframes; i++) {
         const Off &o = off[i];
         const Parsed &h = hdr[i];
-        memcpy(w.h_stage + o.raw, (const uint8_t *)streams[i] + h.scan, o.raw_len);
-        memset(w.h_stage + o.raw + o.raw_len, 0, 16);
         build_lut(h, (uint16_t *)(w.h_stage + o.lut));
         LjFrame &f = fr[i];
         uint8_t *A = w.d_arena;
@@ -193,12 +192,16 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
         f.cmap = (uint16_t *)(A + o.cmap); f.wmap = (uint2 *)(A + o.wmap); f.gmap = (uint2 *)(A + o.gmap);
         f.wstart = (uint2 *)(A + o.wstart); f.gstart = (uint2 *)(A + o.gstart);
         f.diff = (int32_t *)(A + o.diff);
+        f.colsum = (int32_t *)(A + o.colsum);
         f.out = (uint16_t *)((uint8_t *)d_out + (size_t)i * out_stride);
         f.W = h.width; f.H = h.height; f.bits = h.bits; f.pred = h.pred; f.xres = xres; f.yres = yres;
         f.nwg = o.nwg; f.ngrp = o.ngrp;
         f.err = (int *)(A + o.err);
     }
     MLV_HIP(hipMemcpyAsync(w.d_arena, w.h_stage, stage, hipMemcpyHostToDevice, s));
+    // the entropy-coded bytes go straight from the caller's memory (page-locked when they come from the reader's staging)
+    for (int i = 0; i < nframes; i++)
+        MLV_HIP(hipMemcpyAsync(w.d_arena + off[i].raw, (const uint8_t *)streams[i] + hdr[i].scan, off[i].raw_len, hipMemcpyHostToDevice, s));
     for (int i = 0; i < nframes; i++) MLV_HIP(hipMemsetAsync(w.d_arena + off[i].err, 0, sizeof(int), s));
     rc = lj92_launch((const LjFrame *)(w.d_arena + frames_at), nframes, max_raw, max_nwg, max_ngrp, max_w, max_h, s);
     if (rc) return rc;

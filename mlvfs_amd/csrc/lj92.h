@@ -21,6 +21,7 @@ struct LjFrame {
     uint2 *wmap, *gmap;        // [nwg][32], [ngrp][32]: {exit offset, symbols}
     uint2 *wstart, *gstart;    // [nwg], [ngrp]: {true entry offset, index of the first symbol}
     int32_t *diff;             // [W * H] differences, then the per-row recurrence values
+    int32_t *colsum;           // [16][W] sums of e over segments of rows
     uint16_t *out;             // xres x yres pixels, untiled
     int W, H, bits, pred;      // the JPEG's own dimensions, sample precision, predictor (1 or 6)
     int xres, yres;            // the video frame the decoded values are re-read as (main.c:646-667)
