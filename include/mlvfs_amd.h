@@ -169,6 +169,10 @@ int mlvfs_amd_process_frames_dev(mlvfs_amd_clip_t *clip, const void *d_packed, s
                                  void *d_out, size_t out_stride, int nframes,
                                  int cs_method, int fix_pixels, int apply_stripes, void *stream);
 
+/* The same stages on frames that are already 16-bit pixels in HBM (e.g. decoded LJ92 payloads); d_out != d_frames. */
+int mlvfs_amd_process_unpacked_dev(mlvfs_amd_clip_t *clip, const void *d_frames, size_t stride, void *d_out, size_t out_stride,
+                                   int nframes, int cs_method, int fix_pixels, int apply_stripes, void *stream);
+
 /* The same fused pipeline for frames in HOST memory (a reader that has MLV payloads in RAM): chunks
  * of chunk_frames frames (<= 0: 8) travel H2D -> kernels -> D2H on three streams so that both copy directions and the
  * kernels overlap; returns when h_out is complete.  Strides are bytes between frames.  Full PCIe speed needs page-locked

@@ -13,7 +13,8 @@
 // threads into page-locked memory while the previous batch is on the GPU (mlvfs_amd_mlv_process).
 //
 // The reference opens, indexes and walks the clip again for every frame it serves; results are the same, the cost is not.
-// Compressed payloads (LZMA, LJ92: SURVEY.md 8f N3) are refused.
+// LJ92 payloads (main.c:617-681) are decoded on the GPU (csrc/lj92.cpp) inside mlvfs_amd_mlv_process; LZMA payloads are
+// refused, and so are LJ92 payloads in mlvfs_amd_mlv_read_frames (which hands out packed pixels).
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -67,6 +68,8 @@ struct Reader {
     // page-locked staging of mlvfs_amd_mlv_process, kept between calls (locking pages costs about as much as reading them)
     mutable uint8_t *stage[2] = { nullptr, nullptr };
     mutable size_t stage_bytes = 0;
+    mutable void *d_dec = nullptr, *d_fin = nullptr;   // LJ92 clips: decoded and finished frames of one batch in HBM
+    mutable size_t dev_bytes = 0;
     mutable std::mutex stage_mu;
 
     ~Reader()
@@ -74,6 +77,8 @@ struct Reader {
         for (int fd : fds) if (fd >= 0) close(fd);
         mlvfs_amd_host_free(stage[0]);
         mlvfs_amd_host_free(stage[1]);
+        if (d_dec) (void)hipFree(d_dec);
+        if (d_fin) (void)hipFree(d_fin);
     }
 };
 
@@ -261,12 +266,22 @@ int frame_headers_of(const Reader &r, int index, frame_headers *out)
 // ---- payloads ---------------------------------------------------------------------------------------------------------
 struct Span { int fd; uint64_t off; size_t bytes; };
 
-bool payload_span(const Reader &r, int index, Span *s)
+bool payload_span(const Reader &r, int index, Span *s, bool lj92 = false)
 {
     frame_headers fh;
     if (!frame_headers_of(r, index, &fh)) { set_error("mlv: frame %d has no usable headers", index); return false; }
+    const uint64_t room = fh.vidf_hdr.blockSize > sizeof(mlv_vidf_hdr_t) + fh.vidf_hdr.frameSpace
+                              ? fh.vidf_hdr.blockSize - sizeof(mlv_vidf_hdr_t) - fh.vidf_hdr.frameSpace : 0;
+    if (lj92 && (fh.file_hdr.videoClass & CLASS_LJ92) && !(fh.file_hdr.videoClass & CLASS_LZMA)) {
+        // main.c:587-589: everything behind the VIDF header and its frameSpace is the compressed frame (size word + JPEG)
+        if (room <= 4) { set_error("mlv: frame %d: empty LJ92 payload", index); return false; }
+        s->fd = r.fds[fh.fileNumber];
+        s->off = fh.position + sizeof(mlv_vidf_hdr_t) + fh.vidf_hdr.frameSpace;
+        s->bytes = (size_t)room;
+        return true;
+    }
     if (fh.file_hdr.videoClass & (CLASS_LZMA | CLASS_LJ92)) {
-        set_error("mlv: compressed video class 0x%x (LZMA / LJ92 payloads are not decoded here)", fh.file_hdr.videoClass);
+        set_error("mlv: compressed video class 0x%x (LZMA payloads are not decoded; LJ92 ones only by mlvfs_amd_mlv_process)", fh.file_hdr.videoClass);
         return false;
     }
     const uint64_t bits = (uint64_t)fh.rawi_hdr.xRes * fh.rawi_hdr.yRes * (uint64_t)fh.rawi_hdr.raw_info.bits_per_pixel;
@@ -280,12 +295,14 @@ bool payload_span(const Reader &r, int index, Span *s)
     return true;
 }
 
-int read_frames(const Reader &r, int first, int count, uint8_t *dst, size_t stride, int threads)
+int read_frames(const Reader &r, int first, int count, uint8_t *dst, size_t stride, int threads, bool lj92 = false,
+                size_t *sizes = nullptr)
 {
     if (count <= 0) return MLVFS_AMD_OK;
     std::vector<Span> spans(count);
     for (int k = 0; k < count; k++) {
-        if (!payload_span(r, first + k, &spans[k])) return MLVFS_AMD_ERR_ARG;
+        if (!payload_span(r, first + k, &spans[k], lj92)) return MLVFS_AMD_ERR_ARG;
+        if (sizes) sizes[k] = spans[k].bytes;
         if (spans[k].bytes > stride) { set_error("mlv: stride %zu smaller than a frame payload (%zu)", stride, spans[k].bytes); return MLVFS_AMD_ERR_ARG; }
     }
     threads = std::max(1, std::min(threads <= 0 ? 8 : threads, count));
@@ -356,11 +373,24 @@ int mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first,
     const Reader &r = *(const Reader *)reader;
     if (count <= 0) return MLVFS_AMD_OK;
     if (first < 0 || (size_t)first + (size_t)count > r.vidf.size()) { set_error("mlv: frames %d..%d outside the clip (%zu frames)", first, first + count - 1, r.vidf.size()); return MLVFS_AMD_ERR_ARG; }
-    Span s0;
-    if (!payload_span(r, first, &s0)) return MLVFS_AMD_ERR_ARG;
-    const size_t stride = (s0.bytes + 2 + 15) / 16 * 16;
+    frame_headers fh0;
+    if (!frame_headers_of(r, first, &fh0)) { set_error("mlv: frame %d has no usable headers", first); return MLVFS_AMD_ERR_ARG; }
+    const bool lj92 = (fh0.file_hdr.videoClass & CLASS_LJ92) && !(fh0.file_hdr.videoClass & CLASS_LZMA);
     if (batch_frames <= 0) batch_frames = 32;
     batch_frames = std::min(batch_frames, count);
+    size_t stride = 0;
+    if (lj92) {                                                     // payload sizes vary: the largest one sets the staging pitch
+        for (int k = 0; k < count; k++) {
+            Span sp;
+            if (!payload_span(r, first + k, &sp, true)) return MLVFS_AMD_ERR_ARG;
+            stride = std::max(stride, sp.bytes);
+        }
+        stride = (stride + 15) / 16 * 16;
+    } else {
+        Span s0;
+        if (!payload_span(r, first, &s0)) return MLVFS_AMD_ERR_ARG;
+        stride = (s0.bytes + 2 + 15) / 16 * 16;
+    }
     std::lock_guard<std::mutex> lk(r.stage_mu);                     // one streaming call per reader at a time
     if (r.stage_bytes < stride * batch_frames) {
         mlvfs_amd_host_free(r.stage[0]);
@@ -371,12 +401,35 @@ int mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first,
     }
     uint8_t *const *stage = r.stage;
     int rc = r.stage_bytes ? MLVFS_AMD_OK : MLVFS_AMD_ERR_NOMEM;
-    if (rc == MLVFS_AMD_OK) rc = read_frames(r, first, batch_frames, stage[0], stride, io_threads);
+    std::vector<size_t> sizes[2] = { std::vector<size_t>(batch_frames), std::vector<size_t>(batch_frames) };
+    const size_t px_bytes = (size_t)fh0.rawi_hdr.xRes * fh0.rawi_hdr.yRes * 2, dstride = (px_bytes + 255) / 256 * 256;
+    if (rc == MLVFS_AMD_OK && lj92 && r.dev_bytes < dstride * batch_frames) {
+        if (!mlv::thread_ctx()) return MLVFS_AMD_ERR_HIP;
+        if (r.d_dec) (void)hipFree(r.d_dec);
+        if (r.d_fin) (void)hipFree(r.d_fin);
+        r.d_dec = r.d_fin = nullptr; r.dev_bytes = 0;
+        MLV_HIP(hipMalloc(&r.d_dec, dstride * batch_frames));
+        MLV_HIP(hipMalloc(&r.d_fin, dstride * batch_frames));
+        r.dev_bytes = dstride * batch_frames;
+    }
+    if (rc == MLVFS_AMD_OK) rc = read_frames(r, first, batch_frames, stage[0], stride, io_threads, lj92, sizes[0].data());
     for (int f0 = 0, k = 0; rc == MLVFS_AMD_OK && f0 < count; f0 += batch_frames, k++) {
         const int n = std::min(batch_frames, count - f0), n_next = std::min(batch_frames, count - f0 - n);
         int rc_io = MLVFS_AMD_OK;
         std::thread io;                                             // the next batch is read while this one is on the GPU
-        if (n_next > 0) io = std::thread([&, k, f0, n, n_next]() { rc_io = read_frames(r, first + f0 + n, n_next, stage[(k + 1) & 1], stride, io_threads); });
+        if (n_next > 0) io = std::thread([&, k, f0, n, n_next]() { rc_io = read_frames(r, first + f0 + n, n_next, stage[(k + 1) & 1], stride, io_threads, lj92, sizes[(k + 1) & 1].data()); });
+        if (lj92) {
+            // payload = 32-bit decoded size, then the JPEG stream (main.c:628-633); decode, run the stages in HBM, copy out
+            std::vector<const void *> ptr(n);
+            std::vector<size_t> len(n);
+            for (int i = 0; i < n; i++) { ptr[i] = stage[k & 1] + (size_t)i * stride + 4; len[i] = sizes[k & 1][i] - 4; }
+            rc = mlvfs_amd_lj92_decode_dev(ptr.data(), len.data(), n, fh0.rawi_hdr.xRes, fh0.rawi_hdr.yRes, r.d_dec, dstride, nullptr);
+            if (rc == MLVFS_AMD_OK) rc = mlvfs_amd_process_unpacked_dev(clip, r.d_dec, dstride, r.d_fin, dstride, n, cs_method, fix_pixels, apply_stripes, nullptr);
+            if (rc == MLVFS_AMD_OK && hipMemcpy2D((uint8_t *)h_out + (size_t)f0 * out_stride, out_stride, r.d_fin, dstride, px_bytes, n, hipMemcpyDeviceToHost) != hipSuccess) {
+                set_error("mlv: copying finished frames to the host failed");
+                rc = MLVFS_AMD_ERR_HIP;
+            }
+        } else
         rc = mlvfs_amd_process_frames_host(clip, stage[k & 1], stride, (uint8_t *)h_out + (size_t)f0 * out_stride, out_stride, n,
                                            cs_method, fix_pixels, apply_stripes, 0);
         if (io.joinable()) io.join();

@@ -48,6 +48,39 @@ def test_oracle_equals_reference(oracle, reference, w, h):
         assert st_r == st_o == 0 and np.array_equal(dr, do) and np.array_equal(do, wide), p
 
 
+GOLD = None
+
+
+def gold():
+    global GOLD
+    if GOLD is None:
+        import os
+        GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lj92_vectors.npz"))
+    return GOLD
+
+
+def test_oracle_reproduces_reference_vectors(oracle):
+    """tests/golden/lj92_vectors.npz: streams and the images the reference's decoder made of them."""
+    g = gold()
+    keys = sorted(k[:-7] for k in g.files if k.endswith("_stream"))
+    assert len(keys) >= 40
+    for k in keys:
+        st, img = oracle.lj92_decode(g[k + "_stream"].tobytes())
+        assert st == 0 and np.array_equal(img, g[k + "_image"]), k
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_reference_vectors(gpu, oracle):
+    g = gold()
+    keys = sorted(k[:-7] for k in g.files if k.endswith("_stream") and (k.endswith("refenc_stream") or "pred1_" in k or "pred6_" in k))
+    assert len(keys) >= 16
+    for k in keys:
+        img = g[k + "_image"]
+        h, w = img.shape
+        got = gpu_decode([g[k + "_stream"].tobytes()], w, h)[0]
+        assert np.array_equal(got, oracle.lj92_untile(img, w, h)), k
+
+
 def test_untile_restatement(oracle):
     w, h = 64, 48
     f = synth.normal_frame(w, h, seed=2)

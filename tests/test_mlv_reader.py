@@ -150,12 +150,20 @@ def test_compressed_clips_are_refused(tmp_path):
 
 
 @pytest.mark.gpu
-def test_file_to_gpu_pipeline_equals_oracle(gpu, oracle, tmp_path):
+@pytest.mark.parametrize("kind", ["packed14", "lj92"])
+def test_file_to_gpu_pipeline_equals_oracle(gpu, oracle, tmp_path, kind):
     from mlvfs_amd.stream import ClipStream, to_numpy_u16
     w, h, n = 256, 130, 23
     frames = [synth.normal_frame(w, h, seed=5, frame=k) for k in range(n)]
-    pl = [synth.pack_bits(f).tobytes() for f in frames]
-    names = mlvfile.write_clip(str(tmp_path / "G.MLV"), pl, w, h, chunks=2, frame_space=64, shuffle=True)
+    if kind == "packed14":
+        pl = [synth.pack_bits(f).tobytes() for f in frames]
+        names = mlvfile.write_clip(str(tmp_path / "G.MLV"), pl, w, h, chunks=2, frame_space=64, shuffle=True)
+    else:                                                                      # main.c:617-681: size word + lossless JPEG of the tiled frame
+        import struct
+        from oracle import lj92_testenc as enc
+        from test_lj92 import quadrants
+        pl = [struct.pack("<I", w * h * 2) + enc.encode(quadrants(f), 6, 14) for f in frames]
+        names = mlvfile.write_clip(str(tmp_path / "G.MLV"), pl, w, h, chunks=2, frame_space=64, shuffle=True, video_class=1 | 0x20)
     s = ClipStream(w, h, 14, synth.BLACK, synth.WHITE, device=0)
     packed0 = s.upload_packed([synth.pack_bits(frames[0])])
     s.analyse_first_frame(packed0, cs=5, bad_pix=1, stripes=True, rand_mode=1)
