@@ -126,13 +126,16 @@ __global__ __launch_bounds__(256) void k_lj_unstuff_scatter(const LjFrame *frame
 }
 
 // ---------------------------------------------------------------- symbol walk
-// big-endian words of a workgroup's 8 KiB (+ look-ahead) in LDS; the 32 stream bits starting at bit `p` of the workgroup
+// big-endian words of a workgroup's 8 KiB (+ look-ahead) in LDS; the 32 stream bits starting at bit `p` of the workgroup.
+// Thread t works on words 8t .. 8t+8: one spare word after every 32 spreads the threads of a wave over the banks (without
+// it the 64 lanes of a read hit 4 banks).
+__device__ __forceinline__ uint32_t pad_word(uint32_t i) { return i + (i >> 5); }
 struct Window {
     const uint32_t *w;
     __device__ __forceinline__ uint32_t at(uint32_t p) const
     {
         const uint32_t i = p >> 5, s = p & 31;
-        const uint64_t two = ((uint64_t)w[i] << 32) | w[i + 1];
+        const uint64_t two = ((uint64_t)w[pad_word(i)] << 32) | w[pad_word(i + 1)];
         return (uint32_t)(two >> (32 - s));
     }
 };
@@ -157,9 +160,11 @@ __device__ __forceinline__ uint32_t symbol(const Window &win, const Lut lut, int
 constexpr int WG_WORDS = WG_CHUNKS * CHUNK_BYTES / 4;   // 2048
 constexpr int LUT_LDS_BITS = 13;                        // tables up to 2^13 entries (16 KiB) are copied to LDS
 
+constexpr int CMAP_PITCH = ENTRIES + 2;                 // 17 words per row: the threads' rows start in different banks
+
 struct WalkSmem {
-    uint32_t words[WG_WORDS + 4];
-    uint16_t cmap[WG_CHUNKS][ENTRIES];                  // exit offset | symbols << 5
+    uint32_t words[WG_WORDS + 4 + (WG_WORDS + 4) / 32 + 1];
+    uint16_t cmap[WG_CHUNKS][CMAP_PITCH];               // exit offset | symbols << 5
     uint16_t lut[1 << LUT_LDS_BITS];
     union {
         uint32_t cstart[WG_CHUNKS][2];                  // true entry offset, index of the first symbol (k_lj_decode)
@@ -170,10 +175,21 @@ struct WalkSmem {
 __device__ __forceinline__ void load_window(const LjFrame &f, uint32_t wg, WalkSmem &sm)
 {
     const uint32_t *src = (const uint32_t *)(f.ust + (size_t)wg * WG_CHUNKS * CHUNK_BYTES);      // ust is 16-byte aligned
-    for (int i = threadIdx.x; i < WG_WORDS + 4; i += blockDim.x) sm.words[i] = bswap(src[i]);
+    for (int i = threadIdx.x; i < WG_WORDS + 4; i += blockDim.x) sm.words[pad_word(i)] = bswap(src[i]);
     if (f.huffbits <= LUT_LDS_BITS)
         for (int i = threadIdx.x; i < (1 << f.huffbits); i += blockDim.x) sm.lut[i] = f.lut[i];
 }
+
+// length only (k_lj_chunk_maps)
+template <typename Lut>
+__device__ __forceinline__ uint32_t symbol_len(const Window &win, const Lut lut, int huffbits, uint32_t p)
+{
+    const uint32_t e = lut[win.at(p) >> (32 - huffbits)];
+    const uint32_t used = e & 0xFFu, t = e >> 8;
+    return (used == 0 || t > 16) ? 1u : used + t;
+}
+
+constexpr int SEGS = 16, SEG_CHUNKS = WG_CHUNKS / SEGS;     // the decode kernel walks 16 + 16 maps instead of 256
 
 // chunk maps of one workgroup + their composition
 __global__ __launch_bounds__(256) void k_lj_chunk_maps(const LjFrame *frames)
@@ -190,25 +206,47 @@ __global__ __launch_bounds__(256) void k_lj_chunk_maps(const LjFrame *frames)
     // bits ahead, so {exit offset, symbols} of the 32 positions ahead (a ring in LDS) are all that is needed.  256 symbol
     // look-ups per chunk instead of one walk per entry offset (~30 symbols each, 32 of them).
     for (int q = 0; q < 32; q++) sm.ring[q][threadIdx.x] = (uint16_t)q;              // positions 256..287: already outside
-    for (int q = CHUNK_BITS - 1; q >= 0; q--) {
-        int d;
-        bool bad = false;
-        const uint32_t len = f.huffbits <= LUT_LDS_BITS ? symbol(win, (const uint16_t *)sm.lut, f.huffbits, c0 + q, &d, &bad)
-                                                        : symbol(win, f.lut, f.huffbits, c0 + q, &d, &bad);
-        const uint16_t v = (uint16_t)(sm.ring[(q + len) & 31][threadIdx.x] + 32);    // one more symbol on that walk
-        sm.ring[q & 31][threadIdx.x] = v;            // (q + 32) & 31 == q & 31: read above before it is overwritten here
-        if (q < ENTRIES) sm.cmap[threadIdx.x][q] = v;
+    // The symbol lengths of different positions do not depend on each other: 16 look-ups are issued together (their LDS
+    // latencies overlap), then the 16 dependent ring steps follow.
+    const bool lds_lut = f.huffbits <= LUT_LDS_BITS;
+    for (int q0 = CHUNK_BITS - 16; q0 >= 0; q0 -= 16) {
+        uint32_t len[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            len[i] = lds_lut ? symbol_len(win, (const uint16_t *)sm.lut, f.huffbits, c0 + q0 + i) : symbol_len(win, f.lut, f.huffbits, c0 + q0 + i);
+#pragma unroll
+        for (int i = 15; i >= 0; i--) {
+            const int q = q0 + i;
+            const uint16_t v = (uint16_t)(sm.ring[(q + len[i]) & 31][threadIdx.x] + 32);  // one more symbol on that walk
+            sm.ring[q & 31][threadIdx.x] = v;        // (q + 32) & 31 == q & 31: read above before it is overwritten here
+            if (q0 < ENTRIES) sm.cmap[threadIdx.x][q] = v;
+        }
     }
     __syncthreads();
     uint32_t *dst = (uint32_t *)(f.cmap + (size_t)wg * WG_CHUNKS * ENTRIES);
-    const uint32_t *srcm = (const uint32_t *)&sm.cmap[0][0];
-    for (int i = threadIdx.x; i < WG_CHUNKS * ENTRIES / 2; i += blockDim.x) dst[i] = srcm[i];
-    if (threadIdx.x < ENTRIES) {                         // 32 lanes walk the 256 chunk maps
-        uint32_t e = threadIdx.x, n = 0;
-        for (int c = 0; c < WG_CHUNKS; c++) {
+    for (int i = threadIdx.x; i < WG_CHUNKS * ENTRIES / 2; i += blockDim.x)
+        dst[i] = *(const uint32_t *)&sm.cmap[i / (ENTRIES / 2)][2 * (i % (ENTRIES / 2))];
+    // maps of the 16 segments of 16 chunks (32 lanes each, two rounds), then 32 lanes compose those into the workgroup's map
+    uint2 *smap = f.smap + (size_t)wg * SEGS * ENTRIES;
+    __shared__ uint2 segm[SEGS][ENTRIES];
+    for (int round = 0; round < 2; round++) {
+        const int seg = round * 8 + (threadIdx.x >> 5);
+        uint32_t e = threadIdx.x & 31, n = 0;
+        for (int c = seg * SEG_CHUNKS; c < (seg + 1) * SEG_CHUNKS; c++) {
             const uint32_t m = sm.cmap[c][e];
             e = m & 31u;
             n += m >> 5;
+        }
+        segm[seg][threadIdx.x & 31] = make_uint2(e, n);
+        smap[seg * ENTRIES + (threadIdx.x & 31)] = make_uint2(e, n);
+    }
+    __syncthreads();
+    if (threadIdx.x < ENTRIES) {
+        uint32_t e = threadIdx.x, n = 0;
+        for (int sgi = 0; sgi < SEGS; sgi++) {
+            const uint2 m = segm[sgi][e];
+            e = m.x;
+            n += m.y;
         }
         f.wmap[(size_t)wg * ENTRIES + threadIdx.x] = make_uint2(e, n);
     }
@@ -273,12 +311,25 @@ __global__ __launch_bounds__(256) void k_lj_decode(const LjFrame *frames)
     __shared__ WalkSmem sm;
     load_window(f, wg, sm);
     const uint32_t *srcm = (const uint32_t *)(f.cmap + (size_t)wg * WG_CHUNKS * ENTRIES);
-    uint32_t *dstm = (uint32_t *)&sm.cmap[0][0];
-    for (int i = threadIdx.x; i < WG_CHUNKS * ENTRIES / 2; i += blockDim.x) dstm[i] = srcm[i];
+    for (int i = threadIdx.x; i < WG_CHUNKS * ENTRIES / 2; i += blockDim.x)
+        *(uint32_t *)&sm.cmap[i / (ENTRIES / 2)][2 * (i % (ENTRIES / 2))] = srcm[i];
+    __shared__ uint2 segm[SEGS][ENTRIES];
+    for (int i = threadIdx.x; i < SEGS * ENTRIES; i += blockDim.x) (&segm[0][0])[i] = f.smap[(size_t)wg * SEGS * ENTRIES + i];
     __syncthreads();
-    if (threadIdx.x == 0) {
+    __shared__ uint2 segstart[SEGS];
+    if (threadIdx.x == 0) {                              // 16 segment maps from the workgroup's true start ...
         uint32_t e = start.x, n = start.y;
-        for (int c = 0; c < WG_CHUNKS; c++) {
+        for (int sgi = 0; sgi < SEGS; sgi++) {
+            segstart[sgi] = make_uint2(e, n);
+            const uint2 m = segm[sgi][e];
+            e = m.x;
+            n += m.y;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < SEGS) {                            // ... then 16 lanes walk the 16 chunk maps of their segment
+        uint32_t e = segstart[threadIdx.x].x, n = segstart[threadIdx.x].y;
+        for (int c = threadIdx.x * SEG_CHUNKS; c < (threadIdx.x + 1) * SEG_CHUNKS; c++) {
             sm.cstart[c][0] = e;
             sm.cstart[c][1] = n;
             const uint32_t m = sm.cmap[c][e];
@@ -292,6 +343,8 @@ __global__ __launch_bounds__(256) void k_lj_decode(const LjFrame *frames)
     uint32_t p = c0 + sm.cstart[threadIdx.x][0], idx = sm.cstart[threadIdx.x][1];
     const uint64_t end_bit = (uint64_t)*f.ust_len * 8, wg_bit0 = (uint64_t)wg * WG_CHUNKS * CHUNK_BITS;
     bool bad_any = false;
+    int4 q4 = make_int4(0, 0, 0, 0);
+    uint32_t held = 0;
     while (p < c0 + CHUNK_BITS && idx < npx) {
         int d;
         bool bad = false;
@@ -299,13 +352,38 @@ __global__ __launch_bounds__(256) void k_lj_decode(const LjFrame *frames)
                                                         : symbol(win, f.lut, f.huffbits, p, &d, &bad);
         if (wg_bit0 + p + len > end_bit) bad = true;      // a pixel decoded from bits behind the end of the data
         bad_any |= bad;
-        f.diff[idx++] = d;
+        // a thread's ~30 differences are consecutive in memory but 64 lanes write 64 different lines: groups of four
+        // aligned values leave as one 16-byte store
+        const uint32_t slot = idx & 3u;
+        q4.x = slot == 0 ? d : q4.x; q4.y = slot == 1 ? d : q4.y; q4.z = slot == 2 ? d : q4.z; q4.w = slot == 3 ? d : q4.w;
+        held++;
+        if (slot == 3) {
+            if (held >= 4) *(int4 *)(f.diff + (idx - 3)) = q4;
+            else {                                         // the thread's first values did not start on a multiple of four
+                if (held >= 3) f.diff[idx - 2] = q4.y;
+                if (held >= 2) f.diff[idx - 1] = q4.z;
+                f.diff[idx] = q4.w;
+            }
+            held = 0;
+        }
+        idx++;
         p += len;
+    }
+    if (held) {                                            // an unfinished group: `held` values ending at idx - 1
+        const uint32_t first = idx - held;                 // same group of four: slots first & 3 .. (idx - 1) & 3
+        for (uint32_t i = first; i < idx; i++) f.diff[i] = (i & 3u) == 0 ? q4.x : (i & 3u) == 1 ? q4.y : (i & 3u) == 2 ? q4.z : q4.w;
     }
     if (bad_any) atomicOr(f.err, LJ_ERR_CODE);
 }
 
 // ---------------------------------------------------------------- prediction
+constexpr int ROW_LDS = 8192;
+struct RowView {
+    int *p;
+    bool padded;
+    __device__ __forceinline__ int &operator[](int i) const { return p[padded ? i + (i >> 5) : i]; }
+};
+
 // one workgroup per row.  HALVING rows (predictor 6, r >= 1): e[c] = (e[c-1] >> 1) + d[c] in blocks of 32 columns.
 // SCAN rows (row 0 always, every row of predictor 1): inclusive prefix sum; row 0 also carries the base 2^(bits-1).
 // The row is rewritten in place (diff -> e).
@@ -314,9 +392,18 @@ __global__ __launch_bounds__(256) void k_lj_rows(const LjFrame *frames)
     const LjFrame &f = frames[blockIdx.y];
     const int r = blockIdx.x;
     if (r >= f.H) return;
-    int *row = f.diff + (size_t)r * f.W;
+    int *grow = f.diff + (size_t)r * f.W;
     const int W = f.W;
     __shared__ long long carry[2048 + 1];               // W <= 65535: at most 2048 blocks of 32 columns
+    // rows up to ROW_LDS values are staged in LDS (coalesced in, coalesced out; one spare word per 32 keeps the threads,
+    // which each work on 32 consecutive values, in different banks); longer rows are worked on in place
+    __shared__ int stage[ROW_LDS + ROW_LDS / 32 + 2];
+    const bool staged = W <= ROW_LDS;
+    if (staged) {
+        for (int i = threadIdx.x; i < W; i += blockDim.x) stage[i + (i >> 5)] = grow[i];
+        __syncthreads();
+    }
+    RowView row{ staged ? stage : grow, staged };
     if (r == 0 || f.pred == 1) {
         // predictor 1, r >= 1: e[0] = d[0] stays, e[c] = d[1] + .. + d[c];  row 0: x[c] = base + d[0] + .. + d[c]
         const int first = r == 0 ? 0 : 1;
@@ -337,6 +424,10 @@ __global__ __launch_bounds__(256) void k_lj_rows(const LjFrame *frames)
             long long s = carry[b];
             const int c0 = first + b * 32;
             for (int i = 0; i < 32 && c0 + i < W; i++) { s += row[c0 + i]; row[c0 + i] = (int)s; }
+        }
+        if (staged) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < W; i += blockDim.x) grow[i] = stage[i + (i >> 5)];
         }
         return;
     }
@@ -367,6 +458,10 @@ __global__ __launch_bounds__(256) void k_lj_rows(const LjFrame *frames)
             s += (long long)row[c0 + i] << i;
             row[c0 + i] = (int)((e0 + s) >> i);
         }
+    }
+    if (staged) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < W; i += blockDim.x) grow[i] = stage[i + (i >> 5)];
     }
 }
 

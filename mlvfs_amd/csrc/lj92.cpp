@@ -89,8 +89,17 @@ void build_lut(const Parsed &h, uint16_t *lut)
 struct Work {                              // per host thread and device, grow-only
     uint8_t *d_arena = nullptr, *h_stage = nullptr;
     size_t cap_arena = 0, cap_stage = 0;
+    hipStream_t sub[2] = { nullptr, nullptr };          // sub-batches alternate between two streams: uploads overlap kernels
+    hipEvent_t ready = nullptr, done[2] = { nullptr, nullptr };
     int ensure(size_t arena, size_t stage)
     {
+        if (!ready) {
+            for (int k = 0; k < 2; k++) {
+                MLV_HIP(hipStreamCreateWithFlags(&sub[k], hipStreamNonBlocking));
+                MLV_HIP(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+            }
+            MLV_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+        }
         if (arena > cap_arena) {
             if (d_arena) (void)hipFree(d_arena);
             d_arena = nullptr; cap_arena = 0;
@@ -135,7 +144,7 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
     std::vector<Parsed> hdr(nframes);
     // ---- layout: one staging block (raw scans, tables, frame records) and one device arena
     size_t stage = 0, arena = 0;
-    struct Off { size_t raw, lut, ust, ust_len, blk, cmap, wmap, gmap, wstart, gstart, diff, colsum, err; uint32_t raw_len, nwg, ngrp; };
+    struct Off { size_t raw, lut, ust, ust_len, blk, cmap, smap, wmap, gmap, wstart, gstart, diff, colsum, err; uint32_t raw_len, nwg, ngrp; };
     std::vector<Off> off(nframes);
     uint32_t max_raw = 0, max_nwg = 0, max_ngrp = 0;
     int max_w = 0, max_h = 0;
@@ -168,6 +177,7 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
         o.ust_len = arena; arena += 256;
         o.blk = arena; arena += up(((size_t)o.raw_len / 4096 + 2) * 4, 256);
         o.cmap = arena; arena += (size_t)o.nwg * 256 * 32 * 2;
+        o.smap = arena; arena += (size_t)o.nwg * 16 * 32 * 8;
         o.wmap = arena; arena += up((size_t)o.nwg * 32 * 8, 256);
         o.gmap = arena; arena += up((size_t)o.ngrp * 32 * 8, 256);
         o.wstart = arena; arena += up((size_t)o.nwg * 8, 256);
@@ -189,7 +199,7 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
         f.raw = A + o.raw; f.raw_len = o.raw_len;
         f.ust = A + o.ust; f.ust_len = (uint32_t *)(A + o.ust_len); f.blk_drop = (uint32_t *)(A + o.blk);
         f.lut = (const uint16_t *)(A + o.lut); f.huffbits = h.huffbits;
-        f.cmap = (uint16_t *)(A + o.cmap); f.wmap = (uint2 *)(A + o.wmap); f.gmap = (uint2 *)(A + o.gmap);
+        f.cmap = (uint16_t *)(A + o.cmap); f.smap = (uint2 *)(A + o.smap); f.wmap = (uint2 *)(A + o.wmap); f.gmap = (uint2 *)(A + o.gmap);
         f.wstart = (uint2 *)(A + o.wstart); f.gstart = (uint2 *)(A + o.gstart);
         f.diff = (int32_t *)(A + o.diff);
         f.colsum = (int32_t *)(A + o.colsum);
@@ -199,12 +209,24 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
         f.err = (int *)(A + o.err);
     }
     MLV_HIP(hipMemcpyAsync(w.d_arena, w.h_stage, stage, hipMemcpyHostToDevice, s));
-    // the entropy-coded bytes go straight from the caller's memory (page-locked when they come from the reader's staging)
-    for (int i = 0; i < nframes; i++)
-        MLV_HIP(hipMemcpyAsync(w.d_arena + off[i].raw, (const uint8_t *)streams[i] + hdr[i].scan, off[i].raw_len, hipMemcpyHostToDevice, s));
     for (int i = 0; i < nframes; i++) MLV_HIP(hipMemsetAsync(w.d_arena + off[i].err, 0, sizeof(int), s));
-    rc = lj92_launch((const LjFrame *)(w.d_arena + frames_at), nframes, max_raw, max_nwg, max_ngrp, max_w, max_h, s);
-    if (rc) return rc;
+    MLV_HIP(hipEventRecord(w.ready, s));
+    // Sub-batches of frames alternate between two streams, so that the upload of one overlaps the kernels of the other.  The
+    // entropy-coded bytes go straight from the caller's memory (page-locked when they come from the reader's staging).
+    const int SUB = nframes >= 8 ? 4 : (nframes + 1) / 2;
+    for (int j0 = 0, j = 0; j0 < nframes; j0 += SUB, j++) {
+        const int n = std::min(SUB, nframes - j0);
+        hipStream_t sj = w.sub[j & 1];
+        if (j < 2) MLV_HIP(hipStreamWaitEvent(sj, w.ready, 0));
+        for (int i = j0; i < j0 + n; i++)
+            MLV_HIP(hipMemcpyAsync(w.d_arena + off[i].raw, (const uint8_t *)streams[i] + hdr[i].scan, off[i].raw_len, hipMemcpyHostToDevice, sj));
+        rc = lj92_launch((const LjFrame *)(w.d_arena + frames_at) + j0, n, max_raw, max_nwg, max_ngrp, max_w, max_h, sj);
+        if (rc) return rc;
+    }
+    for (int k = 0; k < 2; k++) {
+        MLV_HIP(hipEventRecord(w.done[k], w.sub[k]));
+        MLV_HIP(hipStreamWaitEvent(s, w.done[k], 0));
+    }
     int *errs = (int *)(w.h_stage + stage);
     for (int i = 0; i < nframes; i++) MLV_HIP(hipMemcpyAsync(&errs[i], w.d_arena + off[i].err, sizeof(int), hipMemcpyDeviceToHost, s));
     MLV_HIP(hipStreamSynchronize(s));                        // the staging block is reused by the next call

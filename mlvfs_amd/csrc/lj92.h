@@ -19,6 +19,7 @@ struct LjFrame {
     int huffbits;
     uint16_t *cmap;            // [nwg * 256][32] chunk maps: exit offset | symbols << 5
     uint2 *wmap, *gmap;        // [nwg][32], [ngrp][32]: {exit offset, symbols}
+    uint2 *smap;               // [nwg][16][32]: the same for the 16 segments of 16 chunks inside each workgroup
     uint2 *wstart, *gstart;    // [nwg], [ngrp]: {true entry offset, index of the first symbol}
     int32_t *diff;             // [W * H] differences, then the per-row recurrence values
     int32_t *colsum;           // [16][W] sums of e over segments of rows

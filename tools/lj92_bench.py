@@ -25,7 +25,7 @@ out = torch.empty((N, H, W), dtype=torch.int16, device="cuda")
 pinned = [torch.from_numpy(np.frombuffer(s, np.uint8).copy()).pin_memory() for s in streams4]     # what the reader's staging is
 for kind, src in (("pageable", streams), ("page-locked", [pinned[k % 4].numpy() for k in range(N)])):
   print("compressed bytes in", kind, "host memory")
-  for batch in (1, 4, 16, N):
+  for batch in ([int(b) for b in os.environ['LJ_BATCHES'].split(',')] if os.environ.get('LJ_BATCHES') else (1, 4, 16, N)):
     lj92.decode_frames(src[:batch], W, H, out=out[:batch]); torch.cuda.synchronize()
     reps = max(1, 64 // batch)
     t0 = time.perf_counter()
