@@ -185,11 +185,19 @@ def main():
     total_px = world * K * F * npx
     kern_ms = float(ms[:n_timed].mean()) if n_timed else float("nan")
     achieved = F * npx * BYTES_PER_PX / (kern_ms * 1e-3) / 1e9 if n_timed else None
-    traffic = None
+    traffic, valu = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = int(json.load(open(tpath)).get("k_frame_bytes_per_frame") * F)     # per launch, like `achieved`
+            tj = json.load(open(tpath))
+            traffic = int(tj.get("k_frame_bytes_per_frame") * F)     # per launch, like `achieved`
+            # what actually bounds the kernel: vector-ALU issue.  Wave-instructions per frame from the
+            # SQ_INSTS_VALU counter, the chip's issue rate for them from tools/valu_rate2.hip, measured time from this run.
+            if tj.get("valu_insts_per_frame") and n_timed:
+                floor_us = tj["valu_insts_per_frame"] / (tj["simds"] * tj["valu_issue_per_clk_per_simd"] * tj["clock_ghz"] * 1e3)
+                valu = {"wave_insts_per_frame": int(tj["valu_insts_per_frame"]), "issue_per_clk_per_simd": tj["valu_issue_per_clk_per_simd"],
+                        "floor_us_per_frame": round(floor_us, 2), "measured_us_per_frame": round(kern_ms * 1e3 / F, 2),
+                        "frac_of_valu_floor": round(floor_us / (kern_ms * 1e3 / F), 3)}
         except Exception:
             traffic = None
 
@@ -211,6 +219,8 @@ def main():
                      "traffic": traffic, "kernel": "k_frame<5,packed,patch,stripes>",
                      "kernel_ms_per_launch": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(F * npx * BYTES_PER_PX)},
     }
+    if valu:
+        result["valu"] = valu
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -378,21 +378,29 @@ __device__ __forceinline__ void apply_patches(Smem &sm, const FrameArgs &a, cons
 template <int METHOD, bool PACKED>
 __device__ __forceinline__ void apply_patches_staged(Smem &sm, const FrameArgs &a, const uint8_t *frame, int cnt, int tx0, int ty0)
 {
+    // staged form (stage_entry): x = cell column | cell row << 16 (or -1), y = pixel within the cell | value << 16
     const int k = threadIdx.x;
     if (k >= cnt) return;
     const int2 e = sm.ent[k];
     if (e.x < 0) return;
-    const int cx = (e.x % a.w) >> 1, cy = (e.x / a.w) >> 1;
+    const int cx = e.x & 0xFFFF, cy = e.x >> 16;
     const int i = cx - (tx0 / 2 - HC), j = cy - (ty0 / 2 - HC);
     if (i < 0 || i >= PW || j < 0 || j >= PH) return;
     int px[4];                                                  // r, g1, g2, b of that cell
+    const int ii0 = i - HC, jj0 = j - HC;
+    if (ii0 >= 0 && ii0 < TCW && jj0 >= 0 && jj0 < TCH) {       // interior cell: its pixels are in LDS already
+        const uint32_t t0 = *(const uint32_t *)&sm.raw[2 * jj0][2 * ii0], t1 = *(const uint32_t *)&sm.raw[2 * jj0 + 1][2 * ii0];
+        px[0] = (int)(t0 & 0xFFFFu); px[1] = (int)(t0 >> 16); px[2] = (int)(t1 & 0xFFFFu); px[3] = (int)(t1 >> 16);
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; q++) px[q] = (int)fetch_clamped<PACKED>(frame, a.w, a.h, 2 * cx + (q & 1), 2 * cy + (q >> 1));
+        for (int q = 0; q < 4; q++) px[q] = (int)fetch_clamped<PACKED>(frame, a.w, a.h, 2 * cx + (q & 1), 2 * cy + (q >> 1));
+    }
     for (int k2 = 0; k2 < cnt; k2++) {                          // all repaired pixels of this cell
         const int2 e2 = sm.ent[k2];
-        if (e2.x < 0) continue;
-        const int x2 = e2.x % a.w, y2 = e2.x / a.w;
-        if ((x2 >> 1) == cx && (y2 >> 1) == cy) px[(x2 & 1) + 2 * (y2 & 1)] = e2.y & 0xFFFF;
+        if (e2.x == e.x) {
+            const int sub_ = e2.y & 3, v = (int)((uint32_t)e2.y >> 16);
+            px[0] = sub_ == 0 ? v : px[0]; px[1] = sub_ == 1 ? v : px[1]; px[2] = sub_ == 2 ? v : px[2]; px[3] = sub_ == 3 ? v : px[3];
+        }
     }
     int ge = 0, dr = 0, db = 0;
     if (METHOD != 0) {
@@ -678,7 +686,15 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             const bool slow = __any(odd);
             emit_item<METHOD>(sm, a.black, slow, item_row, item_g, edge, p0, p1);
         }
-        if (tile_patched && pend - pbeg <= ENT_CAP && tid < pend - pbeg) sm.ent[tid] = my_ent;
+        if (tile_patched && pend - pbeg <= ENT_CAP && tid < pend - pbeg) {
+            // one division per entry, here, instead of two per entry pair in apply_patches_staged
+            int2 st = make_int2(-1, 0);
+            if (my_ent.x >= 0) {
+                const int ey = my_ent.x / a.w, ex = my_ent.x - ey * a.w;
+                st = make_int2((ex >> 1) | ((ey >> 1) << 16), ((ex & 1) + 2 * (ey & 1)) | (int)((uint32_t)(my_ent.y & 0xFFFF) << 16));
+            }
+            sm.ent[tid] = st;
+        }
         lds_barrier();
         if (tile_patched) {
             if (pend - pbeg <= ENT_CAP) apply_patches_staged<METHOD, PACKED>(sm, a, frame, pend - pbeg, tx0, ty0);
