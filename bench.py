@@ -110,9 +110,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal on a one-GPU box (never what the driver runs): MLVFS_BENCH_REHEARSAL=1 puts every rank on device 0 and uses
+    # gloo, so that the multi-rank control flow of this file can be exercised where only one card exists.
+    rehearsal = world > 1 and os.environ.get("MLVFS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     dev = torch.device(f"cuda:{local}")
     F, K, Wm = args.frames_per_step, args.steps, args.warmup
 
