@@ -187,8 +187,8 @@ void mlvfs_amd_host_free(void *p);
 /* Lossless-JPEG frames of a compressed clip (MLV_VIDEO_CLASS_FLAG_LJ92; main.c:617-681: lj92_open + lj92_decode + the
  * untiling loop) decoded on the GPU.  streams[i] / sizes[i]: frame i's JPEG stream in HOST memory (the VIDF payload
  * behind its 4-byte size word); output: xres x yres 16-bit pixels per frame at d_out + i * out_stride, in the layout
- * dng_get_image_data produces, ready for the stages above.  Predictor 6 (what MLV writers use) and 1; one component,
- * one Huffman table, like the reference's decoder.  Synchronises `stream` before returning.  dims of mlvfs_amd_lj92_info:
+ * dng_get_image_data produces, ready for the stages above.  One component, one Huffman table, predictors 0..7, like the
+ * reference's decoder (6, what MLV writers use, and 1 are the fast ones).  Synchronises `stream` before returning.  dims of mlvfs_amd_lj92_info:
  * {width, height, bits, predictor} of the JPEG itself.                                                             */
 int mlvfs_amd_lj92_info(const void *stream, size_t size, int dims[4]);
 int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_t *sizes, int nframes, int xres, int yres,

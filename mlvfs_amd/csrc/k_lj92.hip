@@ -23,7 +23,10 @@
 //    so a row is 32-column blocks with one carried value between them (k_lj_rows), rows are independent of each other,
 //    and x is the running sum of e down each column (k_lj_columns), which also writes the pixel to its untiled position.
 //    Predictor 1 (left) is a prefix sum along each row plus one down the first column.  The first row is always a prefix
-//    sum (lj92.c:533-537), the first pixel is predicted by 2^(bits-1).
+//    sum (lj92.c:533-537), the first pixel is predicted by 2^(bits-1).  The other predictors of lj92.c:546-563 reduce to
+//    the same pieces: 2 and 4 are column sums (4 after a prefix sum of each row), 0 needs the first column only, 5 is the
+//    halving recurrence DOWN the columns followed by predictor 1's sums, 3 sums along diagonals, and 7 -- the one that is
+//    not a composition of one-dimensional recurrences -- walks the anti-diagonals (k_lj_wavefront).
 // No MFMA: bit-stream and integer work.
 #include "lj92.h"
 
@@ -392,6 +395,10 @@ __global__ __launch_bounds__(256) void k_lj_rows(const LjFrame *frames)
     const LjFrame &f = frames[blockIdx.y];
     const int r = blockIdx.x;
     if (r >= f.H) return;
+    // what a row needs below the first one: 1, 5: prefix sums behind the first column; 4: prefix sums of the whole row;
+    // 6: the halving recurrence; 0, 2, 3, 7: nothing (their columns / diagonals are summed elsewhere)
+    const bool scan_row = r == 0 || f.pred == 1 || f.pred == 5 || f.pred == 4;
+    if (!scan_row && f.pred != 6) return;
     int *grow = f.diff + (size_t)r * f.W;
     const int W = f.W;
     __shared__ long long carry[2048 + 1];               // W <= 65535: at most 2048 blocks of 32 columns
@@ -404,9 +411,10 @@ __global__ __launch_bounds__(256) void k_lj_rows(const LjFrame *frames)
         __syncthreads();
     }
     RowView row{ staged ? stage : grow, staged };
-    if (r == 0 || f.pred == 1) {
-        // predictor 1, r >= 1: e[0] = d[0] stays, e[c] = d[1] + .. + d[c];  row 0: x[c] = base + d[0] + .. + d[c]
-        const int first = r == 0 ? 0 : 1;
+    if (scan_row) {
+        // predictors 1 and 5, r >= 1: e[0] = d[0] stays, e[c] = d[1] + .. + d[c];  predictor 4: e[c] = d[0] + .. + d[c];
+        // row 0: x[c] = base + d[0] + .. + d[c]
+        const int first = (r == 0 || f.pred == 4) ? 0 : 1;
         const int nblk = (W - first + 31) / 32;
         for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
             long long s = 0;
@@ -469,6 +477,82 @@ __global__ __launch_bounds__(256) void k_lj_rows(const LjFrame *frames)
 // each column, k_lj_columns starts every segment from the sum of the segments above it and writes the pixels (as 16 bits)
 // to their untiled positions.  Predictor 6 sums e down every column; predictor 1 only down the first one.
 constexpr int COL_SEGS = 16;
+// predictors whose rows hang off the first column (0: nothing else is predicted; 1, 5: prefix sums along the row), as opposed
+// to 2, 4, 6, whose values are sums down every column
+__device__ __forceinline__ bool first_column_only(int pred) { return pred == 0 || pred == 1 || pred == 5 || pred == 3; }
+
+// main.c:646-667: the decoded values, read as yres rows of xres, hold the even rows / columns first
+__device__ __forceinline__ void emit_untiled(const LjFrame &f, int r, int c, int px)
+{
+    const uint32_t xres = (uint32_t)f.xres, yres = (uint32_t)f.yres;
+    const uint32_t i = (uint32_t)r * (uint32_t)f.W + (uint32_t)c, sy = i / xres, sx = i - sy * xres;
+    const uint32_t dy = 2 * sy < yres ? 2 * sy : 2 * sy - yres + 1, dx = 2 * sx < xres ? 2 * sx : 2 * sx - xres + 1;
+    f.out[(size_t)dy * xres + dx] = (uint16_t)px;
+}
+
+// predictor 5: x = left + ((above - above_left) >> 1) + d.  With h = x - left: h[r][c] = (h[r-1][c] >> 1) + d[r][c] down every
+// column c >= 1 (row 0: h = d), after which the rows are prefix sums of h like predictor 1.  One thread per column.
+__global__ __launch_bounds__(256) void k_lj_vhalve(const LjFrame *frames)
+{
+    const LjFrame &f = frames[blockIdx.y];
+    const int c = 1 + blockIdx.x * 256 + threadIdx.x;
+    if (f.pred != 5 || c >= f.W) return;
+    int h = f.diff[c];
+    for (int r = 1; r < f.H; r++) {
+        h = (h >> 1) + f.diff[(size_t)r * f.W + c];
+        f.diff[(size_t)r * f.W + c] = h;
+    }
+}
+
+// predictor 3: x = above_left + d: sums along the diagonals, which start in row 0 (already pixel values) or in column 0
+// (pixel (0,0) plus the differences down to that row).  One thread per diagonal.
+__global__ __launch_bounds__(256) void k_lj_diagonals(const LjFrame *frames)
+{
+    const LjFrame &f = frames[blockIdx.y];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (f.pred != 3 || t >= f.W + f.H - 1) return;
+    int r = t < f.W ? 0 : t - f.W + 1, c = t < f.W ? t : 0;
+    int x = f.diff[c];                                    // row 0 holds pixel values (k_lj_rows)
+    if (r > 0) {
+        x = f.diff[0];
+        for (int k = 1; k <= r; k++) x += f.diff[(size_t)k * f.W];
+    }
+    emit_untiled(f, r, c, x);
+    for (r++, c++; r < f.H && c < f.W; r++, c++) {
+        x += f.diff[(size_t)r * f.W + c];
+        emit_untiled(f, r, c, x);
+    }
+}
+
+// predictor 7: x = ((left + above) >> 1) + d depends on two neighbours non-linearly: anti-diagonals in order, one workgroup
+// per frame, the previous anti-diagonal in LDS (indexed by row).  Slow and only there for completeness; H <= LJ_WAVE_MAX_H.
+__global__ __launch_bounds__(1024) void k_lj_wavefront(const LjFrame *frames)
+{
+    const LjFrame &f = frames[blockIdx.x];
+    if (f.pred != 7) return;
+    __shared__ int diag[2][LJ_WAVE_MAX_H];
+    const int W = f.W, H = f.H;
+    for (int c = threadIdx.x; c < W; c += blockDim.x) emit_untiled(f, 0, c, f.diff[c]);       // row 0: pixel values already
+    if (threadIdx.x == 0) diag[0][0] = f.diff[0];
+    __syncthreads();
+    for (int k = 1; k <= W + H - 2; k++) {
+        const int *prev = diag[(k - 1) & 1];
+        int *cur = diag[k & 1];
+        const int r_lo = max(0, k - W + 1), r_hi = min(H - 1, k);
+        for (int r = r_lo + threadIdx.x; r <= r_hi; r += blockDim.x) {
+            const int c = k - r;
+            int x;
+            if (r == 0) x = f.diff[c];                                                       // first row
+            else {
+                const int d = f.diff[(size_t)r * W + c];
+                x = c == 0 ? prev[r - 1] + d : ((prev[r] + prev[r - 1]) >> 1) + d;            // left is on the previous anti-diagonal in row r, above in row r-1
+                emit_untiled(f, r, c, x);
+            }
+            cur[r] = x;
+        }
+        __syncthreads();
+    }
+}
 
 __device__ __forceinline__ void seg_rows(const LjFrame &f, int seg, int *r0, int *r1)
 {
@@ -481,7 +565,7 @@ __global__ __launch_bounds__(256) void k_lj_column_sums(const LjFrame *frames)
 {
     const LjFrame &f = frames[blockIdx.y];
     const int seg = blockIdx.x % COL_SEGS, c = (blockIdx.x / COL_SEGS) * 256 + threadIdx.x;
-    if (c >= f.W || (f.pred == 1 && c != 0)) return;
+    if (c >= f.W || (first_column_only(f.pred) && c != 0)) return;
     int r0, r1, s = 0;
     seg_rows(f, seg, &r0, &r1);
     for (int r = r0; r < r1; r++) s += f.diff[(size_t)r * f.W + c];
@@ -497,8 +581,10 @@ __global__ __launch_bounds__(256) void k_lj_columns(const LjFrame *frames)
     int r0, r1;
     seg_rows(f, seg, &r0, &r1);
     if (seg == 0) r0 = 0;                                   // the first segment also emits row 0
+    if (f.pred == 3 || f.pred == 7) return;                 // written by k_lj_diagonals / k_lj_wavefront
+    const bool fco = first_column_only(f.pred);
     // value carried into this segment: row 0's pixel plus the sums of the segments above
-    const int cc = f.pred == 1 ? 0 : c;
+    const int cc = fco ? 0 : c;
     int x = f.diff[cc];
     for (int k = 0; k < seg; k++) x += f.colsum[(size_t)k * W + cc];
     // main.c:646-667 reads the decoded values as yres rows of xres, whatever the JPEG's own dimensions are: position of
@@ -510,8 +596,10 @@ __global__ __launch_bounds__(256) void k_lj_columns(const LjFrame *frames)
         if (r == 0) px = f.diff[c];
         else {
             const int e = f.diff[(size_t)r * W + c];
-            if (f.pred == 1) { x += c ? f.diff[(size_t)r * W] : e; px = c ? x + e : x; }      // first column carries, the row sum rides on it
-            else { x += e; px = x; }
+            if (fco) {                                          // the first column carries; 1, 5: the row's prefix sum rides on it,
+                x += c ? f.diff[(size_t)r * W] : e;             // 0: the difference is the pixel
+                px = c ? (f.pred == 0 ? e : x + e) : x;
+            } else { x += e; px = x; }                          // 2, 4, 6: sums down every column
         }
         const uint32_t dy = 2 * sy < yres ? 2 * sy : 2 * sy - yres + 1, dx = 2 * sx < xres ? 2 * sx : 2 * sx - xres + 1;
         f.out[(size_t)dy * xres + dx] = (uint16_t)px;
@@ -523,7 +611,7 @@ __global__ __launch_bounds__(256) void k_lj_columns(const LjFrame *frames)
 }  // namespace
 
 int lj92_launch(const LjFrame *d_frames, int nframes, uint32_t max_raw, uint32_t max_nwg, uint32_t max_ngrp, int max_w, int max_h,
-                hipStream_t s)
+                unsigned preds, hipStream_t s)
 {
     if (nframes <= 0) return MLVFS_AMD_OK;
     const uint32_t ublk = (max_raw + 256u * UNSTUFF_BYTES - 1) / (256u * UNSTUFF_BYTES);
@@ -535,7 +623,10 @@ int lj92_launch(const LjFrame *d_frames, int nframes, uint32_t max_raw, uint32_t
     hipLaunchKernelGGL(k_lj_top, dim3((nframes + 63) / 64), dim3(64), 0, s, d_frames, nframes);
     hipLaunchKernelGGL(k_lj_group_starts, dim3((max_ngrp + 63) / 64, nframes), dim3(64), 0, s, d_frames);
     hipLaunchKernelGGL(k_lj_decode, dim3(max_nwg, nframes), dim3(256), 0, s, d_frames);
+    if (preds & (1u << 5)) hipLaunchKernelGGL(k_lj_vhalve, dim3((max_w + 255) / 256, nframes), dim3(256), 0, s, d_frames);
     hipLaunchKernelGGL(k_lj_rows, dim3(max_h, nframes), dim3(256), 0, s, d_frames);
+    if (preds & (1u << 3)) hipLaunchKernelGGL(k_lj_diagonals, dim3((max_w + max_h + 255) / 256, nframes), dim3(256), 0, s, d_frames);
+    if (preds & (1u << 7)) hipLaunchKernelGGL(k_lj_wavefront, dim3(nframes), dim3(1024), 0, s, d_frames);
     hipLaunchKernelGGL(k_lj_column_sums, dim3((max_w + 255) / 256 * COL_SEGS, nframes), dim3(256), 0, s, d_frames);
     hipLaunchKernelGGL(k_lj_columns, dim3((max_w + 255) / 256 * COL_SEGS, nframes), dim3(256), 0, s, d_frames);
     MLV_HIP(hipGetLastError());

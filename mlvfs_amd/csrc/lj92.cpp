@@ -3,8 +3,8 @@
 //   stream structure   mlvfs/lj92.c:82-94 (marker search), 276-290 (SOF3, skipped blocks), 595-626 (marker loop), 512-520 (SOS)
 //   look-up table      mlvfs/lj92.c:222-270 (direct table indexed by the longest code's worth of bits)
 //   kernels            csrc/k_lj92.hip
-// Supported: what the reference's decoder supports (one component, one table, 16-bit look-ups) with predictor 6 -- the only
-// one the reference's own encoder writes (lj92.c:951) -- or predictor 1.  Other predictors are refused with an error.
+// Supported: what the reference's decoder supports: one component, one table, predictors 0..7.  Predictor 6 -- the only one
+// the reference's own encoder writes (lj92.c:951) -- and 1 have the fast kernels; 7 is limited to 8192 rows.
 #include <cstring>
 #include <map>
 #include <vector>
@@ -152,7 +152,8 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
         const char *why = "";
         Parsed &h = hdr[i];
         if (!streams[i] || sizes[i] > 0x7FFFFFFF || !parse((const uint8_t *)streams[i], (int)sizes[i], &h, &why)) { set_error("lj92: frame %d: %s", i, why); return MLVFS_AMD_ERR_ARG; }
-        if (h.pred != 6 && h.pred != 1) { set_error("lj92: frame %d: predictor %d is not supported (1 and 6 are)", i, h.pred); return MLVFS_AMD_ERR_ARG; }
+        if (h.pred < 0 || h.pred > 7) { set_error("lj92: frame %d: predictor %d does not exist", i, h.pred); return MLVFS_AMD_ERR_ARG; }
+        if (h.pred == 7 && h.height > LJ_WAVE_MAX_H) { set_error("lj92: frame %d: predictor 7 is limited to %d rows", i, LJ_WAVE_MAX_H); return MLVFS_AMD_ERR_ARG; }
         if ((long long)h.width * h.height != (long long)xres * yres) {
             set_error("lj92: frame %d: %dx%d values decoded, the video frame is %dx%d", i, h.width, h.height, xres, yres);
             return MLVFS_AMD_ERR_ARG;
@@ -220,7 +221,9 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
         if (j < 2) MLV_HIP(hipStreamWaitEvent(sj, w.ready, 0));
         for (int i = j0; i < j0 + n; i++)
             MLV_HIP(hipMemcpyAsync(w.d_arena + off[i].raw, (const uint8_t *)streams[i] + hdr[i].scan, off[i].raw_len, hipMemcpyHostToDevice, sj));
-        rc = lj92_launch((const LjFrame *)(w.d_arena + frames_at) + j0, n, max_raw, max_nwg, max_ngrp, max_w, max_h, sj);
+        unsigned preds = 0;
+        for (int i = j0; i < j0 + n; i++) preds |= 1u << hdr[i].pred;
+        rc = lj92_launch((const LjFrame *)(w.d_arena + frames_at) + j0, n, max_raw, max_nwg, max_ngrp, max_w, max_h, preds, sj);
         if (rc) return rc;
     }
     for (int k = 0; k < 2; k++) {

@@ -24,13 +24,16 @@ struct LjFrame {
     int32_t *diff;             // [W * H] differences, then the per-row recurrence values
     int32_t *colsum;           // [16][W] sums of e over segments of rows
     uint16_t *out;             // xres x yres pixels, untiled
-    int W, H, bits, pred;      // the JPEG's own dimensions, sample precision, predictor (1 or 6)
+    int W, H, bits, pred;      // the JPEG's own dimensions, sample precision, predictor (0..7)
     int xres, yres;            // the video frame the decoded values are re-read as (main.c:646-667)
     uint32_t nwg, ngrp;        // 8 KiB workgroup windows over raw_len bytes, groups of 32 of them
     int *err;
 };
 
+constexpr int LJ_WAVE_MAX_H = 8192;        // predictor 7 keeps two anti-diagonals (indexed by row) in LDS
+
+// preds: bit p set when some frame of the batch uses predictor p (the rarely used ones have kernels of their own)
 int lj92_launch(const LjFrame *d_frames, int nframes, uint32_t max_raw, uint32_t max_nwg, uint32_t max_ngrp, int max_w, int max_h,
-                hipStream_t s);
+                unsigned preds, hipStream_t s);
 
 }  // namespace mlv
