@@ -48,11 +48,14 @@ struct Clip {
     size_t patch_bytes = 0;
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    void *d_unpacked = nullptr;      // 10 / 12-bit clips: frames unpacked to 16 bits before the fused kernel
+    size_t unpacked_bytes = 0;
 
     ~Clip();
     int set_pixel_map(const int32_t *xy, size_t count, int rules, int dual_iso);
     int ensure_patches(int nframes);
     int ensure_scratch(size_t bytes);
+    int ensure_unpacked(size_t bytes);
     int detect_bad_pixels(const void *d_frame, int aggressive, int dual_iso, hipStream_t stream);
     int fix_pixels(void *d_frames, size_t stride, int nframes, hipStream_t stream);
     int stripes_compute(const void *d_frame, int frame_size, int rand_mode, hipStream_t stream);

@@ -233,3 +233,40 @@ def test_host_pipeline_matches_device_pipeline(gpu, pinned):
     got = s.process_host(host_in, None, cs=0, fix_pixels=False, stripes=False, chunk=3)       # unpack only
     assert torch.equal(got, as_bytes(s.process(packed)))
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bpp", [12, 10])
+def test_other_bit_depths_through_the_fused_entry_points(gpu, oracle, tmp_path, bpp):
+    """10- and 12-bit clips (dng.c:813-843 unpacks any depth): device, host and file entry points equal the oracle's
+    process_frame; the frames are unpacked to 16 bits first and then take the fused kernel's 16-bit input path."""
+    from mlvfs_amd import mlvfile
+    from mlvfs_amd.stream import ClipStream, to_numpy_u16
+    w, h, n = 256, 130, 5
+    shift = 14 - bpp
+    black, white = synth.BLACK >> shift, synth.WHITE >> shift
+    frames = [(synth.normal_frame(w, h, seed=4, frame=k) >> shift).astype(np.uint16) for k in range(n)]
+    packed = [synth.pack_bits(f, bpp) for f in frames]
+    s = ClipStream(w, h, bpp, black, white, device=0)
+    dev_packed = s.upload_packed(packed)
+    s.analyse_first_frame(dev_packed, cs=5, bad_pix=1, stripes=True, rand_mode=1)
+    pixels = oracle.detect_bad_pixels(frames[0], black, 0)
+    want, corr = [], None
+    for f in frames:
+        img = oracle.chroma_smooth(oracle.apply_bad_pixels(f, black, pixels), black, 5)
+        if corr is None:
+            corr = oracle.stripes_compute(img, black, white, frame_size=w * h * bpp // 8)
+        want.append(oracle.stripes_apply(img, black, white, *corr))
+    got = to_numpy_u16(s.process(dev_packed, cs=5, fix_pixels=True, stripes=True))
+    for k in range(n):
+        assert np.array_equal(got[k], want[k]), ("device", k)
+    host_out = to_numpy_u16(s.process_host(dev_packed.cpu(), cs=5, fix_pixels=True, stripes=True, chunk=2))
+    for k in range(n):
+        assert np.array_equal(host_out[k].reshape(h, w), want[k]), ("host", k)
+    names = mlvfile.write_clip(str(tmp_path / "B.MLV"), [p.tobytes() for p in packed], w, h, bpp=bpp, black=black, white=white)
+    with mlvfile.MlvReader(names[0]) as r:
+        out = np.zeros((n, h, w), np.uint16)
+        r.process(s.clip, 0, n, out, cs=5, fix_pixels=True, stripes=True, batch=2)
+        for k in range(n):
+            assert np.array_equal(out[k], want[k]), ("file", k)
+    s.close()
