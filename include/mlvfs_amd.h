@@ -164,7 +164,9 @@ void mlvfs_amd_rand_stream(uint16_t *out, size_t n, uint64_t skip, unsigned seed
 /* -- fused steady-state pipeline (process_frame order, main.c:942-997) ------ */
 /* packed 14-bit stream -> [pixel map repair] -> [chroma smooth] -> [stripes
  * apply] -> 16-bit frames, one pass over HBM (3.75 B/px).  Stages are enabled
- * by cs_method (0,2,3,5), fix_pixels and apply_stripes (uses the clip state). */
+ * by cs_method (0,2,3,5), fix_pixels and apply_stripes (uses the clip state).
+ * Clips of another bit depth (10, 12, ... bits: geom.bpp) are unpacked to 16 bits first and then take the kernel's
+ * 16-bit input path (one more pass over HBM).                                */
 int mlvfs_amd_process_frames_dev(mlvfs_amd_clip_t *clip, const void *d_packed, size_t packed_stride,
                                  void *d_out, size_t out_stride, int nframes,
                                  int cs_method, int fix_pixels, int apply_stripes, void *stream);
