@@ -73,6 +73,7 @@ bool parse(const uint8_t *d, int len, Parsed *h, const char **why)
         }
     }
     if (!table || h->huffbits < 1 || h->width <= 0 || h->height <= 0 || h->bits < 1 || h->bits > 16 || h->scan >= len) return false;
+    if (h->pred > 7) { *why = "predictor does not exist"; return false; }                   // lj92.c:517
     return true;
 }
 

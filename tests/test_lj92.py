@@ -168,3 +168,53 @@ def test_gpu_rejects_damage_and_unsupported(gpu, oracle):
         assert np.array_equal(gpu_decode([s], w, h)[0], want(oracle, s, w, h)), p
     with pytest.raises(Exception, match="video frame"):
         gpu_decode([good], w + 2, h)
+
+
+def test_host_parser_survives_mutations(amd):
+    """Random damage to a valid stream's first bytes: the host parser answers or refuses, it never reads out of bounds
+    (run under the normal allocator: a crash here is the failure)."""
+    from mlvfs_amd import lj92
+    rng = np.random.default_rng(7)
+    good = np.frombuffer(enc.encode(images(64, 48)["smooth"], 6, 14, comment=b"x"), np.uint8)
+    answered = 0
+    for _ in range(3000):
+        s = good.copy()
+        for _ in range(int(rng.integers(1, 6))):
+            s[int(rng.integers(0, 120))] = int(rng.integers(0, 256))
+        cut = int(rng.integers(0, 4))
+        s = s[: len(s) - [0, 1, len(s) - 40, len(s) - 70][cut]] if cut else s
+        try:
+            d = lj92.info(s.tobytes())
+            answered += 1
+            assert 0 < d["width"] <= 65535 and 0 < d["height"] <= 65535 and 0 <= d["predictor"] <= 7
+        except lib_error():
+            pass
+    assert answered > 100
+
+
+def lib_error():
+    from mlvfs_amd import lib
+    return lib.MlvfsAmdError
+
+
+@pytest.mark.gpu
+def test_gpu_survives_damaged_streams(gpu, oracle):
+    """Damaged entropy-coded data and Huffman tables: the call fails or returns pixels, the GPU neither hangs nor faults,
+    and an undamaged stream decodes correctly afterwards."""
+    from mlvfs_amd import lib
+    w, h = 136, 72
+    img = images(w, h)["smooth"]
+    good = np.frombuffer(enc.encode(img, 6, 14), np.uint8)
+    rng = np.random.default_rng(11)
+    failed = 0
+    for trial in range(60):
+        s = good.copy()
+        lo = 20 if trial % 2 else 70                                           # with / without hits in the table and frame header
+        for _ in range(int(rng.integers(1, 20))):
+            s[int(rng.integers(lo, len(s)))] = int(rng.integers(0, 256))
+        try:
+            gpu_decode([s.tobytes()], w, h)
+        except lib.MlvfsAmdError:
+            failed += 1
+    assert failed > 0
+    assert np.array_equal(gpu_decode([good.tobytes()], w, h)[0], want(oracle, good.tobytes(), w, h))

@@ -182,3 +182,34 @@ def test_file_to_gpu_pipeline_equals_oracle(gpu, oracle, tmp_path, kind):
             for k in range(count):
                 assert np.array_equal(out[k], want[first + k]), (batch, first + k)
     s.close()
+
+
+def test_reader_survives_mutated_files(tmp_path):
+    """Random damage to block headers: opening, indexing, header gathering and payload reads answer or refuse."""
+    pl = payloads(6)
+    names = mlvfile.write_clip(str(tmp_path / "F.MLV"), pl, W, H, chunks=2, frame_space=16)
+    good = [open(n, "rb").read() for n in names]
+    rng = np.random.default_rng(3)
+    stride = (len(pl[0]) + 2 + 15) // 16 * 16
+    opened = 0
+    for _ in range(150):
+        for n, g in zip(names, good):
+            b = bytearray(g)
+            for _ in range(int(rng.integers(1, 8))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            if rng.integers(0, 4) == 0:
+                b = b[: int(rng.integers(16, len(b)))]
+            open(n, "wb").write(bytes(b))
+        try:
+            with mlvfile.MlvReader(names[0]) as r:
+                opened += 1
+                assert r.xref() == orc.make_index(names)                          # whatever the damage, the same index
+                for k in range(r.frame_count + 1):
+                    r.frame_headers(k)
+                try:
+                    r.read_frames(0, r.frame_count, stride)
+                except Exception:
+                    pass
+        except Exception:
+            pass
+    assert opened > 100
