@@ -68,8 +68,12 @@ struct Reader {
     // page-locked staging of mlvfs_amd_mlv_process, kept between calls (locking pages costs about as much as reading them)
     mutable uint8_t *stage[2] = { nullptr, nullptr };
     mutable size_t stage_bytes = 0;
-    mutable void *d_dec = nullptr, *d_fin = nullptr;   // LJ92 clips: decoded and finished frames of one batch in HBM
+    // LJ92 clips: decoded frames of one batch and two buffers of finished frames in HBM; the download of one batch runs on
+    // its own stream while the next batch is decoded
+    mutable void *d_dec = nullptr, *d_fin[2] = { nullptr, nullptr };
     mutable size_t dev_bytes = 0;
+    mutable hipStream_t s_run = nullptr, s_down = nullptr;
+    mutable hipEvent_t fin_done[2] = { nullptr, nullptr }, down_done[2] = { nullptr, nullptr };
     mutable std::mutex stage_mu;
 
     ~Reader()
@@ -78,7 +82,13 @@ struct Reader {
         mlvfs_amd_host_free(stage[0]);
         mlvfs_amd_host_free(stage[1]);
         if (d_dec) (void)hipFree(d_dec);
-        if (d_fin) (void)hipFree(d_fin);
+        for (int k = 0; k < 2; k++) {
+            if (d_fin[k]) (void)hipFree(d_fin[k]);
+            if (fin_done[k]) (void)hipEventDestroy(fin_done[k]);
+            if (down_done[k]) (void)hipEventDestroy(down_done[k]);
+        }
+        if (s_run) (void)hipStreamDestroy(s_run);
+        if (s_down) (void)hipStreamDestroy(s_down);
     }
 };
 
@@ -406,11 +416,22 @@ int mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first,
     if (rc == MLVFS_AMD_OK && lj92 && r.dev_bytes < dstride * batch_frames) {
         if (!mlv::thread_ctx()) return MLVFS_AMD_ERR_HIP;
         if (r.d_dec) (void)hipFree(r.d_dec);
-        if (r.d_fin) (void)hipFree(r.d_fin);
-        r.d_dec = r.d_fin = nullptr; r.dev_bytes = 0;
+        r.d_dec = nullptr; r.dev_bytes = 0;
         MLV_HIP(hipMalloc(&r.d_dec, dstride * batch_frames));
-        MLV_HIP(hipMalloc(&r.d_fin, dstride * batch_frames));
+        for (int k = 0; k < 2; k++) {
+            if (r.d_fin[k]) (void)hipFree(r.d_fin[k]);
+            r.d_fin[k] = nullptr;
+            MLV_HIP(hipMalloc(&r.d_fin[k], dstride * batch_frames));
+        }
         r.dev_bytes = dstride * batch_frames;
+    }
+    if (rc == MLVFS_AMD_OK && lj92 && !r.s_run) {
+        MLV_HIP(hipStreamCreateWithFlags(&r.s_run, hipStreamNonBlocking));
+        MLV_HIP(hipStreamCreateWithFlags(&r.s_down, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            MLV_HIP(hipEventCreateWithFlags(&r.fin_done[k], hipEventDisableTiming));
+            MLV_HIP(hipEventCreateWithFlags(&r.down_done[k], hipEventDisableTiming));
+        }
     }
     if (rc == MLVFS_AMD_OK) rc = read_frames(r, first, batch_frames, stage[0], stride, io_threads, lj92, sizes[0].data());
     for (int f0 = 0, k = 0; rc == MLVFS_AMD_OK && f0 < count; f0 += batch_frames, k++) {
@@ -423,11 +444,17 @@ int mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first,
             std::vector<const void *> ptr(n);
             std::vector<size_t> len(n);
             for (int i = 0; i < n; i++) { ptr[i] = stage[k & 1] + (size_t)i * stride + 4; len[i] = sizes[k & 1][i] - 4; }
-            rc = mlvfs_amd_lj92_decode_dev(ptr.data(), len.data(), n, fh0.rawi_hdr.xRes, fh0.rawi_hdr.yRes, r.d_dec, dstride, nullptr);
-            if (rc == MLVFS_AMD_OK) rc = mlvfs_amd_process_unpacked_dev(clip, r.d_dec, dstride, r.d_fin, dstride, n, cs_method, fix_pixels, apply_stripes, nullptr);
-            if (rc == MLVFS_AMD_OK && hipMemcpy2D((uint8_t *)h_out + (size_t)f0 * out_stride, out_stride, r.d_fin, dstride, px_bytes, n, hipMemcpyDeviceToHost) != hipSuccess) {
-                set_error("mlv: copying finished frames to the host failed");
-                rc = MLVFS_AMD_ERR_HIP;
+            const int slot = k & 1;
+            rc = mlvfs_amd_lj92_decode_dev(ptr.data(), len.data(), n, fh0.rawi_hdr.xRes, fh0.rawi_hdr.yRes, r.d_dec, dstride, r.s_run);
+            // (no early returns in here: the reader thread of the next batch is running)
+            auto ok = [&](hipError_t e) { if (e != hipSuccess && rc == MLVFS_AMD_OK) { set_error("mlv: %s", hipGetErrorString(e)); rc = MLVFS_AMD_ERR_HIP; } };
+            if (rc == MLVFS_AMD_OK && k >= 2) ok(hipStreamWaitEvent(r.s_run, r.down_done[slot], 0));        // d_fin[slot] has been downloaded
+            if (rc == MLVFS_AMD_OK) rc = mlvfs_amd_process_unpacked_dev(clip, r.d_dec, dstride, r.d_fin[slot], dstride, n, cs_method, fix_pixels, apply_stripes, r.s_run);
+            if (rc == MLVFS_AMD_OK) {
+                ok(hipEventRecord(r.fin_done[slot], r.s_run));
+                ok(hipStreamWaitEvent(r.s_down, r.fin_done[slot], 0));
+                ok(hipMemcpy2DAsync((uint8_t *)h_out + (size_t)f0 * out_stride, out_stride, r.d_fin[slot], dstride, px_bytes, n, hipMemcpyDeviceToHost, r.s_down));
+                ok(hipEventRecord(r.down_done[slot], r.s_down));
             }
         } else
         rc = mlvfs_amd_process_frames_host(clip, stage[k & 1], stride, (uint8_t *)h_out + (size_t)f0 * out_stride, out_stride, n,
@@ -436,6 +463,12 @@ int mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first,
         if (rc == MLVFS_AMD_OK && rc_io != MLVFS_AMD_OK) {          // the reader thread's message lives in its own thread
             set_error("mlv: prefetch of frames %d..%d failed", first + f0 + n, first + f0 + n + n_next - 1);
             rc = rc_io;
+        }
+    }
+    if (lj92 && r.s_down) {                                         // the last downloads
+        if (hipStreamSynchronize(r.s_down) != hipSuccess || hipStreamSynchronize(r.s_run) != hipSuccess) {
+            set_error("mlv: copying finished frames to the host failed");
+            if (rc == MLVFS_AMD_OK) rc = MLVFS_AMD_ERR_HIP;
         }
     }
     return rc;
