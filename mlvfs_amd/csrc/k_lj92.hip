@@ -12,10 +12,11 @@
 //    so whatever came before, the first symbol that starts inside a chunk starts at one of its first 32 bits.  For each of
 //    those 32 entry offsets a thread decodes to the end of its chunk and records {offset at which the next chunk is
 //    entered, symbols decoded}: a 32-entry map per chunk (k_lj_chunk_maps).  Maps compose (entry -> exit of one chunk is
-//    the entry of the next), so 32 lanes walking 256 chunk maps give the map of a workgroup's 8 KiB, 32 lanes walking 32 of
-//    those the map of a group (k_lj_group_maps), and a single walk over the few dozen groups from offset 0 (the scan
-//    starts on a symbol) gives every group's true entry offset and first symbol index (k_lj_top); two more walks hand
-//    these down to workgroups and chunks (k_lj_group_starts, k_lj_decode).  Every chunk then decodes only its true symbols
+//    the entry of the next), so 32 lanes walking 16 chunk maps give the map of a segment, 32 lanes walking the 16 segment
+//    maps the map of a workgroup's 8 KiB, 32 lanes walking 32 of those the map of a group (k_lj_group_maps), and a single
+//    walk over the few dozen groups from offset 0 (the scan starts on a symbol) gives every group's true entry offset and
+//    first symbol index (k_lj_top); three more walks hand these down to workgroups, segments and chunks (k_lj_group_starts,
+//    k_lj_decode).  Every chunk then decodes only its true symbols
 //    and stores each difference at its index.
 // 2. THE PREDICTOR.  Predictor 6, the one MLV files use (lj92.c:951), is  x = above + ((left - above_left) >> 1) + d.
 //    With e = x - above it reads  e[c] = (e[c-1] >> 1) + d[c]  along a row, and nested floor divisions collapse:
