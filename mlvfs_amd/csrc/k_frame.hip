@@ -578,6 +578,14 @@ __device__ __forceinline__ void stripe_strip_pk(uint32_t (&top)[STRIP], uint32_t
 #pragma unroll
     for (int c = 0; c < STRIP; c++) {
         const int d0 = coef[(2 * c) & 7] - 65536, d1 = coef[(2 * c + 1) & 7] - 65536;
+        if ((d0 | d1) == 0) {
+            // Unit gain on both columns -- always the case for column phases 0 and 1, which stripes.c:236-237 pins to 1.0 --
+            // leaves min(p, white) (for p <= black + 64 < white that is p itself): one packed op instead of nine
+            typedef unsigned short upk16 __attribute__((ext_vector_type(2)));
+            top[c] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(upk16, top[c]), __builtin_bit_cast(upk16, white_pk)));
+            bot[c] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(upk16, bot[c]), __builtin_bit_cast(upk16, white_pk)));
+            continue;
+        }
         top[c] = stripe_pair(top[c], d0, d1, black_pk, white_pk);
         bot[c] = stripe_pair(bot[c], d0, d1, black_pk, white_pk);
     }
