@@ -144,12 +144,22 @@ struct Window {
     }
 };
 
+// Two-level Huffman look-up (built by lj92.cpp): the first LJ_L1_BITS bits of a code index the first level; codes longer
+// than that share an entry with bit 15 set that points to a second-level table indexed by the remaining bits.  Entries are
+// (ssss << 8) | code length, 0 = no such code.  The whole table is at most LJ_LUT_MAX entries and lives in LDS.
+__device__ __forceinline__ uint32_t lut_entry(const uint16_t *lut, int huffbits, uint32_t bits)
+{
+    const int b1 = huffbits < LJ_L1_BITS ? huffbits : LJ_L1_BITS;
+    uint32_t e = lut[bits >> (32 - b1)];
+    if (e & 0x8000u) e = lut[(e & 0x7FFFu) + ((bits << b1) >> (32 - (huffbits - b1)))];
+    return e;
+}
+
 // one symbol at bit p: returns its length in bits (code + ssss raw bits) and the decoded difference
-template <typename Lut>
-__device__ __forceinline__ uint32_t symbol(const Window &win, const Lut lut, int huffbits, uint32_t p, int *diff, bool *bad)
+__device__ __forceinline__ uint32_t symbol(const Window &win, const uint16_t *lut, int huffbits, uint32_t p, int *diff, bool *bad)
 {
     const uint32_t bits = win.at(p);
-    const uint32_t e = lut[bits >> (32 - huffbits)];
+    const uint32_t e = lut_entry(lut, huffbits, bits);
     const uint32_t used = e & 0xFFu, t = e >> 8;
     if (used == 0 || t > 16) { *bad = true; *diff = 0; return 1; }           // no such code: step on, the frame is reported corrupt
     int d = 0;
@@ -162,14 +172,13 @@ __device__ __forceinline__ uint32_t symbol(const Window &win, const Lut lut, int
 }
 
 constexpr int WG_WORDS = WG_CHUNKS * CHUNK_BYTES / 4;   // 2048
-constexpr int LUT_LDS_BITS = 13;                        // tables up to 2^13 entries (16 KiB) are copied to LDS
 
 constexpr int CMAP_PITCH = ENTRIES + 2;                 // 17 words per row: the threads' rows start in different banks
 
 struct WalkSmem {
     uint32_t words[WG_WORDS + 4 + (WG_WORDS + 4) / 32 + 1];
     uint16_t cmap[WG_CHUNKS][CMAP_PITCH];               // exit offset | symbols << 5
-    uint16_t lut[1 << LUT_LDS_BITS];
+    uint16_t lut[LJ_LUT_MAX];
     union {
         uint32_t cstart[WG_CHUNKS][2];                  // true entry offset, index of the first symbol (k_lj_decode)
         uint16_t ring[32][WG_CHUNKS];                   // k_lj_chunk_maps: {exit, symbols} of the 32 positions ahead, per thread
@@ -180,15 +189,13 @@ __device__ __forceinline__ void load_window(const LjFrame &f, uint32_t wg, WalkS
 {
     const uint32_t *src = (const uint32_t *)(f.ust + (size_t)wg * WG_CHUNKS * CHUNK_BYTES);      // ust is 16-byte aligned
     for (int i = threadIdx.x; i < WG_WORDS + 4; i += blockDim.x) sm.words[pad_word(i)] = bswap(src[i]);
-    if (f.huffbits <= LUT_LDS_BITS)
-        for (int i = threadIdx.x; i < (1 << f.huffbits); i += blockDim.x) sm.lut[i] = f.lut[i];
+    for (int i = threadIdx.x; i < f.lut_entries; i += blockDim.x) sm.lut[i] = f.lut[i];
 }
 
 // length only (k_lj_chunk_maps)
-template <typename Lut>
-__device__ __forceinline__ uint32_t symbol_len(const Window &win, const Lut lut, int huffbits, uint32_t p)
+__device__ __forceinline__ uint32_t symbol_len(const Window &win, const uint16_t *lut, int huffbits, uint32_t p)
 {
-    const uint32_t e = lut[win.at(p) >> (32 - huffbits)];
+    const uint32_t e = lut_entry(lut, huffbits, win.at(p));
     const uint32_t used = e & 0xFFu, t = e >> 8;
     return (used == 0 || t > 16) ? 1u : used + t;
 }
@@ -212,12 +219,11 @@ __global__ __launch_bounds__(256) void k_lj_chunk_maps(const LjFrame *frames)
     for (int q = 0; q < 32; q++) sm.ring[q][threadIdx.x] = (uint16_t)q;              // positions 256..287: already outside
     // The symbol lengths of different positions do not depend on each other: 16 look-ups are issued together (their LDS
     // latencies overlap), then the 16 dependent ring steps follow.
-    const bool lds_lut = f.huffbits <= LUT_LDS_BITS;
     for (int q0 = CHUNK_BITS - 16; q0 >= 0; q0 -= 16) {
         uint32_t len[16];
 #pragma unroll
         for (int i = 0; i < 16; i++)
-            len[i] = lds_lut ? symbol_len(win, (const uint16_t *)sm.lut, f.huffbits, c0 + q0 + i) : symbol_len(win, f.lut, f.huffbits, c0 + q0 + i);
+            len[i] = symbol_len(win, sm.lut, f.huffbits, c0 + q0 + i);
 #pragma unroll
         for (int i = 15; i >= 0; i--) {
             const int q = q0 + i;
@@ -352,8 +358,7 @@ __global__ __launch_bounds__(256) void k_lj_decode(const LjFrame *frames)
     while (p < c0 + CHUNK_BITS && idx < npx) {
         int d;
         bool bad = false;
-        const uint32_t len = f.huffbits <= LUT_LDS_BITS ? symbol(win, (const uint16_t *)sm.lut, f.huffbits, p, &d, &bad)
-                                                        : symbol(win, f.lut, f.huffbits, p, &d, &bad);
+        const uint32_t len = symbol(win, sm.lut, f.huffbits, p, &d, &bad);
         if (wg_bit0 + p + len > end_bit) bad = true;      // a pixel decoded from bits behind the end of the data
         bad_any |= bad;
         // a thread's ~30 differences are consecutive in memory but 64 lanes write 64 different lines: groups of four

@@ -77,14 +77,36 @@ bool parse(const uint8_t *d, int len, Parsed *h, const char **why)
     return true;
 }
 
-void build_lut(const Parsed &h, uint16_t *lut)
+// Canonical codes in order (lj92.c:222-270 fills one flat table of 2^huffbits entries the same way); here the first
+// LJ_L1_BITS bits index the first level and longer codes go through a second-level table per distinct prefix.
+// Returns the number of entries used, or -1 when the table needs more second-level tables than fit.
+int build_lut(const Parsed &h, uint16_t *lut)
 {
-    const int n = 1 << h.huffbits;
-    memset(lut, 0, sizeof(uint16_t) * n);
-    int i = 0, v = 0;
+    const int b1 = std::min(h.huffbits, LJ_L1_BITS), sub_bits = h.huffbits - b1, sub_n = 1 << sub_bits;
+    int used = 1 << b1;
+    memset(lut, 0, sizeof(uint16_t) * LJ_LUT_MAX);
+    uint32_t code = 0;                                          // next canonical code, left-aligned to huffbits
+    int v = 0;
     for (int len = 1; len <= h.huffbits; len++)
-        for (int k = 0; k < h.count[len] && v < h.nvals; k++, v++)
-            for (int r = 0; r < (1 << (h.huffbits - len)) && i < n; r++) lut[i++] = (uint16_t)((h.vals[v] << 8) | len);
+        for (int k = 0; k < h.count[len] && v < h.nvals; k++, v++) {
+            const uint32_t span = 1u << (h.huffbits - len);
+            if (code + span > (1u << h.huffbits)) return used;  // over-subscribed table: the remaining codes do not exist
+            const uint16_t e = h.vals[v] <= 16 ? (uint16_t)((h.vals[v] << 8) | len) : 0;      // ssss > 16 cannot be decoded
+            if (len <= b1) {
+                for (uint32_t i = code >> sub_bits; i < (code + span) >> sub_bits; i++) lut[i] = e;
+            } else {
+                const uint32_t prefix = code >> sub_bits;
+                if (!(lut[prefix] & 0x8000u)) {
+                    if (used + sub_n > LJ_LUT_MAX) return -1;
+                    lut[prefix] = (uint16_t)(0x8000u | used);
+                    used += sub_n;
+                }
+                const int base = lut[prefix] & 0x7FFF;
+                for (uint32_t i = code & (sub_n - 1); i < (code & (sub_n - 1)) + span; i++) lut[base + i] = e;
+            }
+            code += span;
+        }
+    return used;
 }
 
 struct Work {                              // per host thread and device, grow-only
@@ -164,7 +186,7 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
         o.nwg = (o.raw_len + 8191) / 8192;
         if (o.nwg == 0) o.nwg = 1;
         o.ngrp = (o.nwg + 31) / 32;
-        o.lut = stage; stage += up(sizeof(uint16_t) << h.huffbits, 256);
+        o.lut = stage; stage += up(sizeof(uint16_t) * LJ_LUT_MAX, 256);
         max_raw = std::max(max_raw, o.raw_len); max_nwg = std::max(max_nwg, o.nwg); max_ngrp = std::max(max_ngrp, o.ngrp);
         max_w = std::max(max_w, h.width); max_h = std::max(max_h, h.height);
     }
@@ -195,12 +217,13 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
     for (int i = 0; i < nframes; i++) {
         const Off &o = off[i];
         const Parsed &h = hdr[i];
-        build_lut(h, (uint16_t *)(w.h_stage + o.lut));
+        const int lut_n = build_lut(h, (uint16_t *)(w.h_stage + o.lut));
+        if (lut_n < 0) { set_error("lj92: frame %d: Huffman table with more than %d long-code prefixes", i, (LJ_LUT_MAX - (1 << LJ_L1_BITS)) / 32); return MLVFS_AMD_ERR_ARG; }
         LjFrame &f = fr[i];
         uint8_t *A = w.d_arena;
         f.raw = A + o.raw; f.raw_len = o.raw_len;
         f.ust = A + o.ust; f.ust_len = (uint32_t *)(A + o.ust_len); f.blk_drop = (uint32_t *)(A + o.blk);
-        f.lut = (const uint16_t *)(A + o.lut); f.huffbits = h.huffbits;
+        f.lut = (const uint16_t *)(A + o.lut); f.huffbits = h.huffbits; f.lut_entries = lut_n;
         f.cmap = (uint16_t *)(A + o.cmap); f.smap = (uint2 *)(A + o.smap); f.wmap = (uint2 *)(A + o.wmap); f.gmap = (uint2 *)(A + o.gmap);
         f.wstart = (uint2 *)(A + o.wstart); f.gstart = (uint2 *)(A + o.gstart);
         f.diff = (int32_t *)(A + o.diff);

@@ -7,6 +7,8 @@ namespace mlv {
 constexpr uint32_t LJ_TAIL = 128;          // zero bytes kept behind the unstuffed data (look-ahead of the last symbols)
 constexpr int LJ_ERR_CODE = 1;             // a bit pattern that is no Huffman code / a pixel decoded from bits behind the data
 constexpr int LJ_ERR_SHORT = 2;            // fewer symbols than pixels
+constexpr int LJ_L1_BITS = 11;             // first-level Huffman look-up: 2048 entries
+constexpr int LJ_LUT_MAX = 3584;           // both levels together (7 KiB of LDS): 48 second-level tables of 32 entries
 
 // one frame's view of the work buffers (all pointers are device memory)
 struct LjFrame {
@@ -15,8 +17,8 @@ struct LjFrame {
     uint8_t *ust;              // unstuffed bytes, 16-byte aligned, followed by LJ_TAIL zero bytes
     uint32_t *ust_len;
     uint32_t *blk_drop;        // stuffed zeros per 4 KiB block, then their exclusive prefix sums
-    const uint16_t *lut;       // (ssss << 8) | code length, indexed by the next `huffbits` bits; 0 = no such code
-    int huffbits;
+    const uint16_t *lut;       // two-level table, see lut_entry() in k_lj92.hip
+    int huffbits, lut_entries;
     uint16_t *cmap;            // [nwg * 256][32] chunk maps: exit offset | symbols << 5
     uint2 *wmap, *gmap;        // [nwg][32], [ngrp][32]: {exit offset, symbols}
     uint2 *smap;               // [nwg][16][32]: the same for the 16 segments of 16 chunks inside each workgroup
