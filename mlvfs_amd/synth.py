@@ -87,7 +87,7 @@ def normal_frame(w: int, h: int, seed: int = 1, frame: int = 0, hot: int = 64, c
     # defects: positions drawn from the hash, kept >= 8 px from the borders; every
     # 4th defect gets a twin two pixels to the right (same colour plane)
     n_def = hot + cold
-    if n_def:
+    if n_def and w > 16 and h > 16:          # frames too small to keep defects 8 px from the borders get none
         k = np.arange(n_def, dtype=np.int64)
         r = _mix32((k * 2654435761 + seed * 97 + frame * 7919 + 12345) & _M32)
         dx = 8 + (r % (w - 16))
