@@ -403,14 +403,15 @@ class Reference:
         d = np.ascontiguousarray(data, np.uint16)
         return int(self.L.ref_hist_median_of(d, d.size, skip, white))
 
-    def process_frame(self, packed, w, h, black, white, cs=0, bad_pix=0, stripes=0, bpp=14, correction=None):
+    def process_frame(self, packed, w, h, black, white, cs=0, bad_pix=0, stripes=0, bpp=14, correction=None, guid=0):
+        """guid 0: the bad-pixel map is detected anew on every frame (cs.c:235); any other value: once per clip."""
         img = np.zeros((h, w), np.uint16)
         co = np.zeros(8, np.int32) if correction is None else np.array(correction[1], np.int32)
         needed = C.c_int(0 if correction is None else int(correction[0]))
         if correction is None:
             self._libc.srand(1)
         self.L.ref_process_frame(np.ascontiguousarray(packed, np.uint16), img, w, h, bpp, black, white,
-                                 cs, bad_pix, stripes, 0, co, C.byref(needed), int(correction is None))
+                                 cs, bad_pix, stripes, C.c_uint64(guid), co, C.byref(needed), int(correction is None))
         return img, ((needed.value, co) if stripes else None)
 
 

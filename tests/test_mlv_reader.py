@@ -213,3 +213,41 @@ def test_reader_survives_mutated_files(tmp_path):
         except Exception:
             pass
     assert opened > 100
+
+
+@pytest.mark.gpu
+def test_virtual_dng_files_equal_the_reference(gpu, oracle, reference, tmp_path):
+    """What MLVFS serves for <clip>/<frame>.dng is 65536 header bytes + the processed pixels (main.c:908-1005, 1444-1500).
+    Here: container walk (reader) -> per-frame headers -> DNG header writer, and payloads -> fused GPU pipeline; against the
+    reference's dng_get_header_data on the restated frame headers + the reference's own process_frame stages."""
+    import ctypes as C
+    from mlvfs_amd import lib
+    from mlvfs_amd.stream import ClipStream
+    w, h, n = 256, 130, 6
+    frames = [synth.normal_frame(w, h, seed=8, frame=k) for k in range(n)]
+    pl = [synth.pack_bits(f).tobytes() for f in frames]
+    names = mlvfile.write_clip(str(tmp_path / "M11-0815.MLV"), pl, w, h, chunks=2, frame_space=32)
+    L = lib.load()
+    s = ClipStream(w, h, 14, synth.BLACK, synth.WHITE, device=0)
+    s.analyse_first_frame(s.upload_packed([synth.pack_bits(frames[0])]), cs=5, bad_pix=1, stripes=True, rand_mode=1)
+    corr = None
+    with mlvfile.MlvReader(names[0]) as r:
+        out = np.zeros((n, h, w), np.uint16)
+        r.process(s.clip, 0, n, out, cs=5, fix_pixels=True, stripes=True, batch=4)
+        for k in range(n):
+            ok, fh = r.frame_headers(k)
+            assert ok == 1
+            hdr = np.zeros(65536, np.uint8)
+            assert L.dng_get_header_data(C.byref(fh), lib.ptr(hdr), 0, 65536, 0.0, b"M11-0815") == 65536
+            ours = hdr.tobytes() + out[k].tobytes()
+            # the reference: headers as main.c:429-558 gathers them (restated), its header writer, its pixel stages
+            want_ok, blob = orc.frame_headers(names, k)
+            assert want_ok == 1
+            _, ref_hdr, _ = reference.header_data(np.frombuffer(blob, np.uint8), 0, 65536, 0.0, b"M11-0815")
+            packed = np.concatenate([np.frombuffer(pl[k], "<u2"), np.zeros(4, "<u2")])
+            img, corr = reference.process_frame(packed, w, h, synth.BLACK, synth.WHITE, cs=5, bad_pix=1, stripes=1, correction=corr,
+                                                guid=0x5EED0815)
+            theirs = ref_hdr.tobytes() + img.tobytes()
+            assert len(ours) == L.dng_get_size(C.byref(fh)) == len(theirs)
+            assert ours == theirs, k
+    s.close()
