@@ -219,6 +219,13 @@ int    mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int fir
 /* dual-ISO preview on one device frame (hdr.c:40-227); returns 1 / 0 / <0    */
 int mlvfs_amd_hdr_preview_dev(const mlvfs_amd_geom_t *geom, void *d_frame, size_t max_size, void *stream);
 
+/* deflicker of main.c:895-906 on one device frame: the median of every second pixel (the reference's
+ * 16-bit histogram counters included) against `target` -> raw_info.exposure_bias = {(int)(log2(...) * 10000), 10000}, which
+ * dng_get_header_data writes as BaselineExposure.  size_bytes: the frame's size in bytes, as main.c:943 passes it.
+ * Synchronises the stream.                                                                                        */
+int mlvfs_amd_deflicker_dev(const mlvfs_amd_geom_t *geom, const void *d_frame, size_t size_bytes, int target,
+                            int32_t exposure_bias[2], void *stream);
+
 /* full dual-ISO conversion of one device frame, in place (hdr.c:1774-1957 without the
  * pixel-map repairs); returns 1 converted / 0 not dual ISO or not convertible / <0 error.
  * mlvfs_amd_dualiso_reset forgets the per-black-level table caches (a fresh process).  */

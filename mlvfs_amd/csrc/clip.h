@@ -103,6 +103,7 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
 int launch_pixfix(bool packed, const void *frames, size_t stride, int w, int black, const void *entries,
                   const int *level_off, int n_levels, int n_entries, void *patches, void *scatter, size_t scatter_stride,
                   int nframes, const DeviceLuts &luts, hipStream_t stream);
+int launch_deflicker_hist(const void *d_frame, uint32_t samples, uint32_t white, unsigned *d_hist, hipStream_t s);
 int launch_badpix_detect(const void *d_frame, int w, int h, int black, int aggressive, int crop_x, int crop_y,
                          void *d_mask, int words_per_row, int *d_row_count, void *d_list, int cap,
                          const DeviceLuts &luts, hipStream_t stream);

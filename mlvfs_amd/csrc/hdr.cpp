@@ -3,6 +3,7 @@
 // and its device-resident form.
 #include "clip.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -173,6 +174,40 @@ int mlvfs_amd_hdr_preview_dev(const mlvfs_amd_geom_t *geom, void *d_frame, size_
     const size_t hist_bytes = 4 * (size_t)((uint16_t)g.white + 1) * sizeof(unsigned);
     if (c->ensure(0, hist_bytes)) return MLVFS_AMD_ERR_HIP;
     return hdr_preview_device(g, d_frame, max_size, (unsigned *)c->d_b, pick_stream(stream, c), nullptr, nullptr);
+}
+
+// deflicker of main.c:895-906 on a device frame: exposure_bias as the reference stores it in raw_info (numerator = (int)
+// (correction * 10000), denominator 10000).  `size_bytes` is what main.c:943 passes: the frame's size in BYTES.
+int mlvfs_amd_deflicker_dev(const mlvfs_amd_geom_t *geom, const void *d_frame, size_t size_bytes, int target, int32_t exposure_bias[2],
+                            void *stream)
+{
+    ThreadCtx *c = thread_ctx();
+    if (!c) return MLVFS_AMD_ERR_HIP;
+    if (geom->bpp < 1 || geom->bpp > 15 || size_bytes < 2) { set_error("deflicker: unsupported bit depth / size"); return MLVFS_AMD_ERR_ARG; }
+    const uint32_t white = (1u << geom->bpp) + 1;                     // (uint16_t)((1 << bpp) + 1)
+    const uint32_t size = (uint32_t)((size_bytes - 1) / 2);            // elements handed to hist_add behind data + 1
+    const uint32_t samples = (size + 1) / 2;                           // i = 0, 2, 4, ... < size
+    const size_t hist_bytes = sizeof(unsigned) * ((size_t)white + 1);
+    if (c->ensure(0, hist_bytes)) return MLVFS_AMD_ERR_HIP;
+    hipStream_t s = pick_stream(stream, c);
+    int rc = launch_deflicker_hist(d_frame, samples, white, (unsigned *)c->d_b, s);
+    if (rc) return rc;
+    std::vector<unsigned> h(white + 1);
+    MLV_HIP(hipMemcpyAsync(h.data(), c->d_b, hist_bytes, hipMemcpyDeviceToHost, s));
+    MLV_HIP(hipStreamSynchronize(s));
+    // hist_median with the reference's 16-bit counters and its count = size / 2 (histogram.c:57,63-76)
+    const uint32_t middle = (size / 2) / 2;
+    uint32_t cur = 0;
+    uint16_t median = 0;
+    for (uint32_t i = 0; i <= white; i++) {
+        cur += (uint16_t)h[i];
+        if (cur > middle) { median = (uint16_t)i; break; }
+    }
+    const uint16_t black = (uint16_t)geom->black;
+    const double correction = log2((double)(target - black) / (median - black));
+    exposure_bias[0] = (int32_t)(correction * 10000);
+    exposure_bias[1] = 10000;
+    return MLVFS_AMD_OK;
 }
 
 }  // extern "C"

@@ -270,3 +270,28 @@ def test_other_bit_depths_through_the_fused_entry_points(gpu, oracle, tmp_path, 
         for k in range(n):
             assert np.array_equal(out[k], want[k]), ("file", k)
     s.close()
+
+
+@pytest.mark.gpu
+def test_deflicker_equals_reference_histogram_and_formula(gpu, reference):
+    """main.c:895-906 (static in main.c, restated here) on the reference's own histogram helpers (oracle/_ref): every second
+    pixel from pixel 1, 16-bit counters that wrap, median, BaselineExposure numerator."""
+    import torch
+    w, h = 3584, 1320                                     # large enough for the 16-bit counters to wrap
+    for kind, seed in (("normal", 3), ("adversarial", 5)):
+        f = getattr(synth, kind + "_frame")(w, h, seed=seed)
+        flat = np.ascontiguousarray(f.reshape(-1))
+        size_bytes = flat.size * 2
+        n = (size_bytes - 1) // 2
+        white = (1 << 14) + 1
+        median = reference.L.ref_hist_median_of(np.ascontiguousarray(flat[1:]), n, 1, white)
+        d = torch.from_numpy(flat.view(np.int16)).cuda()
+        geom = lib.Geom(w, h, 14, synth.BLACK, synth.WHITE, 0, 0)
+        for target in (3072, 5000, synth.BLACK):
+            want = np.float64(target - synth.BLACK) / np.float64(int(median) - synth.BLACK)
+            with np.errstate(divide="ignore"):
+                corr = np.log2(want) * 10000
+            want0 = int(np.trunc(corr)) if np.isfinite(corr) else -2 ** 31
+            eb = np.zeros(2, np.int32)
+            lib.check(gpu.mlvfs_amd_deflicker_dev(C.byref(geom), C.c_void_p(d.data_ptr()), size_bytes, target, lib.ptr(eb), None))
+            assert (int(eb[0]), int(eb[1])) == (want0, 10000), (kind, target, median)
