@@ -67,7 +67,7 @@ struct StripesWork {
     Clip *owner = nullptr;
     Geom g{};
     int row0 = 0, row1 = 0, gpr = 0, n_groups = 0, nblk = 0;
-    size_t o_counts = 0, o_bsum = 0, o_boff = 0, o_total = 0, o_hist = 0, o_num = 0, o_nre = 0, o_re = 0, bytes = 0;
+    size_t o_counts = 0, o_bsum = 0, o_boff = 0, o_total = 0, o_hist = 0, o_num = 0, o_nre = 0, o_re = 0, o_copies = 0, bytes = 0;
     uint8_t *base = nullptr;
     int init(Clip *owner, const Geom &g, int row0, int row1);
     int count(const void *d_frame, long long *accepted, hipStream_t stream);
@@ -110,9 +110,11 @@ int launch_badpix_detect(const void *d_frame, int w, int h, int black, int aggre
 int stripes_groups_per_row(int w);
 int launch_stripes_count(const void *d_frame, int w, int row0, int row1, int black, int white, unsigned char *d_counts,
                          int *d_block_sum, long long *d_block_off, long long *d_total, hipStream_t stream);
+size_t stripes_hist_copies_bytes();
+int launch_hist_bump(int *d_hist, const int *d_idx, int n, hipStream_t stream);
 int launch_stripes_hist(const void *d_frame, int w, int row0, int row1, int black, int white, const unsigned char *d_counts,
                         const long long *d_block_off, const void *d_rand, long long n_rand, int *d_hist, int *d_num,
-                        void *d_recheck, int recheck_cap, int *d_n_recheck, hipStream_t stream);
+                        void *d_recheck, int recheck_cap, int *d_n_recheck, void *d_copies, hipStream_t stream);
 int launch_stripes_apply(void *d_frames, size_t stride, size_t npix, int w, int black, int white, const int32_t *coef,
                          int nframes, hipStream_t stream);
 

@@ -21,7 +21,8 @@ namespace mlv {
 
 // the 24 add_pixel calls of a group (stripes.c:175-203): histogram, reference px, corrected px
 // pixel slots 0..9 = pa..ph, pa2, pb2
-__constant__ unsigned char k_call[24][3] = {
+// (constexpr: the loops over it are unrolled, so the pixel slots are register names, not indices into a spilled array)
+constexpr unsigned char k_call[24][3] = {
     {2,0,2},{2,0,2},{2,0,2},{2,8,2},  {3,1,3},{3,1,3},{3,1,3},{3,9,3},
     {4,0,4},{4,0,4},{4,8,4},{4,8,4},  {5,1,5},{5,1,5},{5,9,5},{5,9,5},
     {6,0,6},{6,8,6},{6,8,6},{6,8,6},  {7,1,7},{7,9,7},{7,9,7},{7,9,7},
@@ -94,6 +95,36 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const int *__restrict__ bl
     if (threadIdx.x == 0) *total = carry;
 }
 
+// The bins that matter sit within a few hundred of 32768 (ratios of neighbouring pixels): millions of atomic adds on a few
+// hundred addresses.  The workgroups therefore add into HIST_COPIES private copies (block index modulo), which
+// k_stripes_hist_fold then adds into the caller's histogram.
+constexpr int HIST_COPIES = 16;
+
+__global__ __launch_bounds__(256) void k_stripes_hist_fold(const int *__restrict__ copies, int *__restrict__ hist)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;              // 8 * 65536 bins
+    int s = 0;
+#pragma unroll
+    for (int c = 0; c < HIST_COPIES; c++) s += copies[(size_t)c * (8 * 65536) + i];
+    if (s) hist[i] += s;
+}
+
+__global__ void k_hist_bump(int *__restrict__ hist, const int *__restrict__ idx, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&hist[idx[i]], 1);
+}
+
+int launch_hist_bump(int *d_hist, const int *d_idx, int n, hipStream_t stream)
+{
+    if (n <= 0) return MLVFS_AMD_OK;
+    hipLaunchKernelGGL(k_hist_bump, dim3((n + 255) / 256), dim3(256), 0, stream, d_hist, d_idx, n);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+size_t stripes_hist_copies_bytes() { return (size_t)HIST_COPIES * 8 * 65536 * sizeof(int); }
+
 // pass 2: histogram
 __global__ __launch_bounds__(256) void k_stripes_hist(const uint16_t *__restrict__ img, int w, int row0, int groups_per_row,
                                                       int n_groups, int black, double too_bright,
@@ -123,7 +154,7 @@ __global__ __launch_bounds__(256) void k_stripes_hist(const uint16_t *__restrict
         const int y = row0 + g / groups_per_row, x = (g % groups_per_row) * 8;
         int px[10];
         load_group(img + (size_t)y * w, x, black, px);
-#pragma unroll 1
+#pragma unroll
         for (int i = 0; i < 24; i++) {
             const int j = k_call[i][0], a = px[k_call[i][1]], b = px[k_call[i][2]];
             if (!accepted(a, b, too_bright)) continue;
@@ -142,7 +173,7 @@ __global__ __launch_bounds__(256) void k_stripes_hist(const uint16_t *__restrict
             } else {
                 int bin = (int)pos;
                 bin = bin < 0 ? 0 : (bin > 65535 ? 65535 : bin);
-                atomicAdd(&hist[j * 65536 + bin], 1);
+                atomicAdd(&hist[(size_t)(blockIdx.x % HIST_COPIES) * (8 * 65536) + j * 65536 + bin], 1);
             }
             atomicAdd(&lnum[j], 1);
         }
@@ -202,14 +233,16 @@ int launch_stripes_count(const void *d_frame, int w, int row0, int row1, int bla
 
 int launch_stripes_hist(const void *d_frame, int w, int row0, int row1, int black, int white, const unsigned char *d_counts,
                         const long long *d_block_off, const void *d_rand, long long n_rand, int *d_hist, int *d_num,
-                        void *d_recheck, int recheck_cap, int *d_n_recheck, hipStream_t stream)
+                        void *d_recheck, int recheck_cap, int *d_n_recheck, void *d_copies, hipStream_t stream)
 {
     const int gpr = stripes_groups_per_row(w), n_groups = gpr * (row1 - row0);
     if (n_groups <= 0) return MLVFS_AMD_OK;
     const int nblk = (n_groups + 255) / 256;
+    MLV_HIP(hipMemsetAsync(d_copies, 0, stripes_hist_copies_bytes(), stream));
     hipLaunchKernelGGL(k_stripes_hist, dim3(nblk), dim3(256), 0, stream, (const uint16_t *)d_frame, w, row0, gpr, n_groups,
-                       black, white / 1.5, d_counts, d_block_off, (const uint16_t *)d_rand, n_rand, d_hist, d_num,
+                       black, white / 1.5, d_counts, d_block_off, (const uint16_t *)d_rand, n_rand, (int *)d_copies, d_num,
                        (Recheck *)d_recheck, recheck_cap, d_n_recheck);
+    hipLaunchKernelGGL(k_stripes_hist_fold, dim3(8 * 65536 / 256), dim3(256), 0, stream, (const int *)d_copies, d_hist);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
