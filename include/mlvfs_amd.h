@@ -160,6 +160,8 @@ int mlvfs_amd_stripes_apply_dev(const mlvfs_amd_clip_t *clip, void *d_frames, si
 /* glibc TYPE_3 rand() restatement: out[i] = rand()%1024 for calls skip..skip+n-1
  * after srand(seed)                                                            */
 void mlvfs_amd_rand_stream(uint16_t *out, size_t n, uint64_t skip, unsigned seed);
+/* the same values generated on the device into d_out (16-byte aligned device memory); synchronises the stream */
+int mlvfs_amd_rand_stream_dev(void *d_out, size_t n, uint64_t skip, unsigned seed, void *stream);
 
 /* -- fused steady-state pipeline (process_frame order, main.c:942-997) ------ */
 /* packed 14-bit stream -> [pixel map repair] -> [chroma smooth] -> [stripes

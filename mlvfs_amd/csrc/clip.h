@@ -110,6 +110,10 @@ int launch_badpix_detect(const void *d_frame, int w, int h, int black, int aggre
 int stripes_groups_per_row(int w);
 int launch_stripes_count(const void *d_frame, int w, int row0, int row1, int black, int white, unsigned char *d_counts,
                          int *d_block_sum, long long *d_block_off, long long *d_total, hipStream_t stream);
+constexpr int RAND_CHUNK = 31 * 32;      // values per thread of the device generator of the rand() % 1024 stream
+int launch_rand_stream(const uint32_t *d_start, const uint32_t *d_pow2, int npow, uint32_t nchunks, uint32_t *d_states, uint16_t *d_out,
+                       size_t n, hipStream_t stream);
+int rand_stream_device(uint16_t *d_out, size_t n, uint64_t skip, unsigned seed, hipStream_t stream);
 size_t stripes_hist_copies_bytes();
 int launch_hist_bump(int *d_hist, const int *d_idx, int n, hipStream_t stream);
 int launch_stripes_hist(const void *d_frame, int w, int row0, int row1, int black, int white, const unsigned char *d_counts,

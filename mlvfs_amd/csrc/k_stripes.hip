@@ -266,3 +266,79 @@ int launch_stripes_apply(void *d_frames, size_t stride, size_t npix, int w, int 
 }
 
 }  // namespace mlv
+
+// ---------------------------------------------------------------- glibc rand() % 1024 stream on the device
+// x[i] = x[i-31] + x[i-3] (mod 2^32), output (x >> 1) % 1024 (see clip.cpp).  The recurrence is linear, so the state at the
+// start of chunk c is (A^RAND_CHUNK)^c times the state at the start of the stream: k_rand_states applies the host-built
+// powers (A^RAND_CHUNK)^(2^j) for the set bits of c, k_rand_fill then lets one thread per chunk run its 992 = 31 * 32 values
+// with the 31-word ring in registers (31 unrolled steps per round), eight values per 16-byte store.
+namespace mlv {
+
+__global__ __launch_bounds__(32) void k_rand_states(const uint32_t *__restrict__ start, const uint32_t *__restrict__ pow2 /* [j][31][31] */,
+                                                    int npow, uint32_t nchunks, uint32_t *__restrict__ states)
+{
+    const uint32_t c = blockIdx.x;
+    if (c >= nchunks) return;
+    __shared__ uint32_t v[2][32];
+    const int i = threadIdx.x;
+    if (i < 31) v[0][i] = start[i];
+    __syncthreads();
+    int cur = 0;
+    for (int j = 0; j < npow; j++) {
+        if (!((c >> j) & 1u)) continue;                     // uniform
+        if (i < 31) {
+            const uint32_t *row = pow2 + ((size_t)j * 31 + i) * 31;
+            uint32_t acc = 0;
+            for (int k = 0; k < 31; k++) acc += row[k] * v[cur][k];
+            v[cur ^ 1][i] = acc;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (i < 31) states[(size_t)c * 31 + i] = v[cur][i];
+}
+
+__global__ __launch_bounds__(256) void k_rand_fill(const uint32_t *__restrict__ states, uint32_t nchunks, uint16_t *__restrict__ out, size_t n)
+{
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunks) return;
+    uint32_t x[31];
+#pragma unroll
+    for (int k = 0; k < 31; k++) x[k] = states[(size_t)c * 31 + k];
+    const size_t base = (size_t)c * RAND_CHUNK;
+    // the last eight values travel in a 128-bit shift register (31 steps per round do not line up with groups of eight)
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    int held = 0, done = 0;
+    for (int round = 0; round < RAND_CHUNK / 31; round++) {
+#pragma unroll
+        for (int k = 0; k < 31; k++) {
+            const uint32_t v = x[k] + x[(k + 28) % 31];     // oldest + the value three steps back
+            x[k] = v;
+            const uint32_t o = (v >> 1) & 1023u;
+            w0 = (w0 >> 16) | (w1 << 16); w1 = (w1 >> 16) | (w2 << 16); w2 = (w2 >> 16) | (w3 << 16); w3 = (w3 >> 16) | (o << 16);
+            if (++held == 8) {                               // the same step in every thread
+                const size_t at = base + (size_t)done;
+                if (at + 8 <= n) *(uint4 *)(out + at) = make_uint4(w0, w1, w2, w3);
+                else {
+                    const uint32_t ws[4] = { w0, w1, w2, w3 };
+                    for (int q = 0; q < 8; q++)
+                        if (at + q < n) out[at + q] = (uint16_t)(q & 1 ? ws[q >> 1] >> 16 : ws[q >> 1] & 0xFFFFu);
+                }
+                held = 0;
+                done += 8;
+            }
+        }
+    }
+}
+
+int launch_rand_stream(const uint32_t *d_start, const uint32_t *d_pow2, int npow, uint32_t nchunks, uint32_t *d_states, uint16_t *d_out,
+                       size_t n, hipStream_t stream)
+{
+    if (!nchunks) return MLVFS_AMD_OK;
+    hipLaunchKernelGGL(k_rand_states, dim3(nchunks), dim3(32), 0, stream, d_start, d_pow2, npow, nchunks, d_states);
+    hipLaunchKernelGGL(k_rand_fill, dim3((nchunks + 255) / 256), dim3(256), 0, stream, (const uint32_t *)d_states, nchunks, d_out, n);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+}  // namespace mlv

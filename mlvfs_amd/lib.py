@@ -40,7 +40,7 @@ DEVICE_SYMBOLS = [
     "mlvfs_amd_unpack_dev", "mlvfs_amd_chroma_smooth_dev", "mlvfs_amd_detect_bad_pixels_dev",
     "mlvfs_amd_fix_pixels_dev", "mlvfs_amd_stripes_count_dev", "mlvfs_amd_stripes_hist_dev",
     "mlvfs_amd_stripes_solve", "mlvfs_amd_stripes_compute_dev", "mlvfs_amd_stripes_apply_dev",
-    "mlvfs_amd_rand_stream", "mlvfs_amd_process_frames_dev", "mlvfs_amd_process_frames_host",
+    "mlvfs_amd_rand_stream", "mlvfs_amd_rand_stream_dev", "mlvfs_amd_process_frames_dev", "mlvfs_amd_process_frames_host",
     "mlvfs_amd_host_alloc", "mlvfs_amd_host_free", "mlvfs_amd_hdr_preview_dev",
     "mlvfs_amd_cr2hdr20_dev", "mlvfs_amd_dualiso_reset", "mlvfs_amd_amaze_demosaic_dev",
     "mlvfs_amd_timer_begin", "mlvfs_amd_timer_end", "mlvfs_amd_selftest_host",
@@ -133,6 +133,7 @@ def load() -> C.CDLL:
     sig("mlvfs_amd_stripes_compute_dev", i, [vp, vp, i, i, vp])
     sig("mlvfs_amd_stripes_apply_dev", i, [vp, vp, sz, i, vp])
     sig("mlvfs_amd_rand_stream", None, [vp, sz, C.c_uint64, C.c_uint])
+    sig("mlvfs_amd_rand_stream_dev", i, [vp, sz, C.c_uint64, C.c_uint, vp])
     sig("mlvfs_amd_process_frames_dev", i, [vp, vp, sz, vp, sz, i, i, i, i, vp])
     sig("mlvfs_amd_process_frames_host", i, [vp, vp, sz, vp, sz, i, i, i, i, i])
     sig("mlvfs_amd_host_alloc", vp, [sz])

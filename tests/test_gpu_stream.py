@@ -295,3 +295,18 @@ def test_deflicker_equals_reference_histogram_and_formula(gpu, reference):
             eb = np.zeros(2, np.int32)
             lib.check(gpu.mlvfs_amd_deflicker_dev(C.byref(geom), C.c_void_p(d.data_ptr()), size_bytes, target, lib.ptr(eb), None))
             assert (int(eb[0]), int(eb[1])) == (want0, 10000), (kind, target, median)
+
+
+@pytest.mark.gpu
+def test_device_rand_stream_equals_host_stream(gpu):
+    """The rand() % 1024 dither stream generated on the device (jump-ahead per 992-value chunk) is the host stream, which
+    tests/test_cabi.py pins against libc's rand()."""
+    import torch
+    for n, skip in ((1, 0), (7, 0), (992, 0), (993, 5), (100_003, 0), (5_000_000, 12_345_678), (28_000_010, 0), (4096, 2 ** 33 + 17)):
+        want = np.zeros(n, np.uint16)
+        gpu.mlvfs_amd_rand_stream(lib.ptr(want), n, skip, 1)
+        d = torch.full((n + 16,), -1, dtype=torch.int16, device="cuda")
+        lib.check(gpu.mlvfs_amd_rand_stream_dev(C.c_void_p(d.data_ptr()), n, skip, 1, None))
+        got = d.cpu().numpy().view(np.uint16)
+        assert np.array_equal(got[:n], want), (n, skip)
+        assert (got[n:] == 0xFFFF).all(), "wrote past n"
