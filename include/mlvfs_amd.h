@@ -214,7 +214,9 @@ int    mlvfs_amd_mlv_frame_headers(const void *reader, int index, struct frame_h
 /* payloads of `count` frames (uncompressed clips) into dst, `stride` bytes apart, read by io_threads threads (<= 0: 8) */
 int    mlvfs_amd_mlv_read_frames(const void *reader, int first, int count, void *dst, size_t stride, int io_threads);
 /* file -> fused pipeline -> h_out: batches of batch_frames frames (<= 0: 32) are read into page-locked staging by
- * io_threads threads while the previous batch goes through mlvfs_amd_process_frames_host                            */
+ * io_threads threads while the previous batch goes through mlvfs_amd_process_frames_host (LJ92 clips: through the GPU
+ * decoder and mlvfs_amd_process_unpacked_dev).  `clip` must have the frames' geometry; a reader's staging and device buffers
+ * belong to the device of the thread that first streams from it.                                                     */
 int    mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first, int count, void *h_out, size_t out_stride,
                              int cs_method, int fix_pixels, int apply_stripes, int batch_frames, int io_threads);
 

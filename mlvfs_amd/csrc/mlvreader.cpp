@@ -27,7 +27,7 @@
 #include <thread>
 #include <vector>
 
-#include "common.h"
+#include "clip.h"
 
 namespace {
 
@@ -386,6 +386,15 @@ int mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first,
     frame_headers fh0;
     if (!frame_headers_of(r, first, &fh0)) { set_error("mlv: frame %d has no usable headers", first); return MLVFS_AMD_ERR_ARG; }
     const bool lj92 = (fh0.file_hdr.videoClass & CLASS_LJ92) && !(fh0.file_hdr.videoClass & CLASS_LZMA);
+    {
+        // the clip state must describe these frames: the kernels take their geometry from it
+        const mlv::Geom &g = reinterpret_cast<const mlv::Clip *>(clip)->g;
+        if (g.w != fh0.rawi_hdr.xRes || g.h != fh0.rawi_hdr.yRes || (!lj92 && g.bpp != fh0.rawi_hdr.raw_info.bits_per_pixel)) {
+            set_error("mlv: the clip state is %dx%d at %d bits, the file's frames are %dx%d at %d bits", g.w, g.h, g.bpp,
+                      fh0.rawi_hdr.xRes, fh0.rawi_hdr.yRes, fh0.rawi_hdr.raw_info.bits_per_pixel);
+            return MLVFS_AMD_ERR_ARG;
+        }
+    }
     if (batch_frames <= 0) batch_frames = 32;
     batch_frames = std::min(batch_frames, count);
     size_t stride = 0;

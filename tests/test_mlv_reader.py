@@ -251,3 +251,14 @@ def test_virtual_dng_files_equal_the_reference(gpu, oracle, reference, tmp_path)
             assert len(ours) == L.dng_get_size(C.byref(fh)) == len(theirs)
             assert ours == theirs, k
     s.close()
+
+
+@pytest.mark.gpu
+def test_process_refuses_a_clip_state_of_another_geometry(gpu, tmp_path):
+    from mlvfs_amd.stream import ClipStream
+    names = mlvfile.write_clip(str(tmp_path / "Q.MLV"), payloads(3), W, H)
+    s = ClipStream(W + 16, H, 14, synth.BLACK, synth.WHITE, device=0)
+    with mlvfile.MlvReader(names[0]) as r:
+        with pytest.raises(Exception, match="clip state"):
+            r.process(s.clip, 0, 3, np.zeros((3, H, W + 16), np.uint16), cs=0, fix_pixels=False, stripes=False)
+    s.close()
