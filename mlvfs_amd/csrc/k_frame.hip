@@ -190,29 +190,34 @@ __device__ __forceinline__ void cell_pair_ev(const uint32_t *p0, const uint32_t 
     }
 }
 
-// the common path of cell_pair_ev for FOUR adjacent cells: sixteen table reads in flight instead of eight, half as many waits
-__device__ __forceinline__ void cell_quad_ev_fast(const uint32_t *p0, const uint32_t *p1, int black, const uint16_t *t,
-                                                  int (&ge)[4], int (&dr)[4], int (&db)[4])
+// the common path of cell_pair_ev for NC adjacent cells at once: 4 NC table reads in flight, one wait
+template <int NC>
+__device__ __forceinline__ void cell_multi_ev_fast(const uint32_t *p0, const uint32_t *p1, int black, const uint16_t *t,
+                                                   int (&ge)[NC], int (&dr)[NC], int (&db)[NC])
 {
-    uint32_t fb[16], tv[16], ex[16], eb[16];
+    uint32_t fb[4 * NC], tv[4 * NC], ex[4 * NC], eb[4 * NC];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < NC; c++) {
         const int px[4] = { (int)p0[2 * c], (int)p0[2 * c + 1], (int)p1[2 * c], (int)p1[2 * c + 1] };
 #pragma unroll
         for (int i = 0; i < 4; i++) fb[4 * c + i] = __float_as_uint((float)(unsigned)(px[i] - black));
     }
 #pragma unroll
-    for (int i = 0; i < 16; i++) tv[i] = *(const uint16_t *)((const char *)t + bfe_asm<9, 14>(fb[i]));
+    for (int i = 0; i < 4 * NC; i++) tv[i] = *(const uint16_t *)((const char *)t + bfe_asm<9, 14>(fb[i]));
 #pragma unroll
-    for (int i = 0; i < 16; i++) ex[i] = bfe_asm<23, 8>(fb[i]);
-    asm volatile("" :: "v"(ex[0]), "v"(ex[1]), "v"(ex[2]), "v"(ex[3]), "v"(ex[4]), "v"(ex[5]), "v"(ex[6]), "v"(ex[7]));
-    asm volatile("" :: "v"(ex[8]), "v"(ex[9]), "v"(ex[10]), "v"(ex[11]), "v"(ex[12]), "v"(ex[13]), "v"(ex[14]), "v"(ex[15]));
-    asm volatile("" :: "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]), "v"(tv[4]), "v"(tv[5]), "v"(tv[6]), "v"(tv[7]));
-    asm volatile("" :: "v"(tv[8]), "v"(tv[9]), "v"(tv[10]), "v"(tv[11]), "v"(tv[12]), "v"(tv[13]), "v"(tv[14]), "v"(tv[15]));
+    for (int i = 0; i < 4 * NC; i++) ex[i] = bfe_asm<23, 8>(fb[i]);
 #pragma unroll
-    for (int i = 0; i < 16; i++) eb[i] = (ex[i] << 15) + tv[i];
+    for (int i = 0; i < 4 * NC; i += 8) {                // opaque uses: the reads stay unconditional and back to back
+        asm volatile("" :: "v"(ex[i]), "v"(ex[i + 1]), "v"(ex[i + 2]), "v"(ex[i + 3]), "v"(ex[i + 4]), "v"(ex[i + 5]), "v"(ex[i + 6]), "v"(ex[i + 7]));
+    }
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int i = 0; i < 4 * NC; i += 8) {
+        asm volatile("" :: "v"(tv[i]), "v"(tv[i + 1]), "v"(tv[i + 2]), "v"(tv[i + 3]), "v"(tv[i + 4]), "v"(tv[i + 5]), "v"(tv[i + 6]), "v"(tv[i + 7]));
+    }
+#pragma unroll
+    for (int i = 0; i < 4 * NC; i++) eb[i] = (ex[i] << 15) + tv[i];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
         const uint32_t gb = (eb[4 * c + 1] + eb[4 * c + 2]) >> 1;
         ge[c] = (int)(gb - (127u << 15));
         dr[c] = (int)(eb[4 * c + 0] - gb);
@@ -333,11 +338,11 @@ template <int NCELL>
 __device__ __forceinline__ void store_cells(Smem &sm, int black, bool slow, int r, int col0, const uint32_t *p0, const uint32_t *p1)
 {
     const bool row_in = r >= HC && r < HC + TCH;
-    if (NCELL == 8 && !slow) {                           // wave-uniform; measured against pairs: cs2x2 -2.5 %, cs5x5 -2 %
+    if (NCELL == 8 && !slow) {                           // wave-uniform; against pairs: cs2x2 -2.5 %, cs5x5 -2 %; all eight at once: no better
 #pragma unroll
         for (int c = 0; c < 8; c += 4) {
             int ge[4], dr[4], db[4];
-            cell_quad_ev_fast(p0 + 2 * c, p1 + 2 * c, black, sm.t16, ge, dr, db);
+            cell_multi_ev_fast<4>(p0 + 2 * c, p1 + 2 * c, black, sm.t16, ge, dr, db);
             *(int4 *)&sm.dr[r][col0 + c] = make_int4(dr[0], dr[1], dr[2], dr[3]);
             *(int4 *)&sm.db[r][col0 + c] = make_int4(db[0], db[1], db[2], db[3]);
             if (row_in) *(int4 *)&sm.ge[r - HC][col0 + c - HC] = make_int4(ge[0], ge[1], ge[2], ge[3]);
