@@ -32,6 +32,11 @@
 // No MFMA: this is a stencil / gather / selection path.
 #include "clip.h"
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
+#include <algorithm>
+#include <cstdio>
 
 // two 16-bit lanes per register: v_pk_min_i16 / v_pk_max_i16 issue at the rate of v_min_i32 (tools/valu_rate.hip)
 typedef short mlv_pk16 __attribute__((ext_vector_type(2)));
@@ -77,6 +82,11 @@ struct FrameArgs {
     int coef_fast;           // all |coef - 65536| < 32768: 32-bit epilogue
     int coef_pk;             // additionally 14-bit input, white > black + 64, black <= 16384: packed 16-bit epilogue
     int patch, stripes;      // wave-uniform stage switches
+    int *tickets;            // [groups] next tile of each group's range + [1] workgroups done (the last one zeroes them all)
+    int groups;              // workgroups b, b + groups, b + 2 groups, ... form a group (one CU's residents) and share a tile range
+#ifdef KF_DIAG_TIMES
+    unsigned long long *times;
+#endif
 };
 
 struct __align__(16) Smem {
@@ -87,6 +97,7 @@ struct __align__(16) Smem {
     uint16_t t16[MLV_T16_N];            // mantissa-normalised raw2ev (common.h), 16 KiB
     uint32_t has_patch[PMAP_WORDS];     // one bit per tile of a frame: some pixel-map entry touches it (1 KiB)
     int2 ent[ENT_CAP];                  // {pos, value} of the entries that touch the current tile (staged by the loader phase)
+    int next_ticket;
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
@@ -658,14 +669,22 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             if (a.tile_off[i + 1] != a.tile_off[i]) atomicOr(&sm.has_patch[i >> 5], 1u << (i & 31));
     }
 
-    // XCD-aware persistent tile walk: blocks b, b+8, b+16, ... share an XCD; give
-    // every XCD a contiguous band of the tile list
+    // Persistent tile walk.  Group g = blockIdx % groups: with 4 x CUs workgroups in the grid the dispatcher puts blocks
+    // b, b + CUs, b + 2 CUs, b + 3 CUs on one CU (tools/hwid_probe.hip), so a group is one CU's four residents.  Each group
+    // owns a contiguous range of the tile list -- the groups of an XCD (blocks b, b + 8, ... share one) next to each other,
+    // so halo re-reads hit that XCD's L2 -- and its members draw tiles from it by ticket: the four workgroups of a CU do not
+    // progress at the same pace (the oldest waves issue first), and with a fixed share each the slowest one ended up alone
+    // on its CU (measured with s_memrealtime stamps: the first-dispatched quarter of the grid finished at 70 % of the kernel
+    // time).  Whatever the placement, every tile is drawn exactly once.
     const int tiles_per_frame = a.tiles_x * a.tiles_y;
     const int total = tiles_per_frame * a.nframes;          // < 2^30 (checked by the launcher)
     const int nx = 8;
-    const int band = (total + nx - 1) / nx;
-    const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx, slots = (gridDim.x + nx - 1) / nx;
-    const int band_end = min(total, (xcd + 1) * band);
+    const int grp = blockIdx.x % a.groups;
+    const int gpx = (a.groups + nx - 1) / nx;                                    // groups per XCD
+    const int grank = (a.groups % nx == 0) ? (grp % nx) * gpx + grp / nx : grp;  // position of the group's range in the tile list
+    const int gq = total / a.groups, grem = total - gq * a.groups;
+    const int band_start = grank * gq + min(grank, grem);
+    const int band_end = band_start + gq + (grank < grem ? 1 : 0);
     const int black16 = (int)(uint16_t)a.black, white16 = (int)(uint16_t)a.white;
     constexpr bool vec = VEC;                            // w % 16 == 0: dword/vector loads and stores
 
@@ -684,7 +703,9 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     const int k = (la << 3) | (lb << 2) | (lane & 3);
     const int j = (tid >> 6) * 4 + ((lane >> 5) << 1) + (la ^ lb ^ lc);
 
-    int t = xcd * band + slot;
+    if (threadIdx.x == 0) sm.next_ticket = atomicAdd(&a.tickets[grp], 1);
+    __syncthreads();
+    int t = band_start + sm.next_ticket;
     auto tile_coords = [&](int tt, int &f, int &tr, int &tx0, int &ty0) {
         f = tt / tiles_per_frame;
         tr = tt - f * tiles_per_frame;
@@ -705,7 +726,12 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     if (vec) issue_tile(min(t, max(total - 1, 0)));
     __syncthreads();                           // T16 copy complete
 
-    for (; t < band_end; t += slots) {
+#ifdef KF_DIAG_TIMES
+    const uint64_t rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    while (t < band_end) {
+        int my_ticket = 0;
+        if (threadIdx.x == 0) my_ticket = atomicAdd(&a.tickets[grp], 1);       // the tile after this one: back long before it is needed
         int f, tr, tx0, ty0;
         tile_coords(t, f, tr, tx0, ty0);
         const uint8_t *frame = a.src + (size_t)f * a.src_stride;
@@ -750,7 +776,9 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             }
             sm.ent[tid] = st;
         }
+        if (threadIdx.x == 0) sm.next_ticket = my_ticket;
         lds_barrier();
+        const int t_next = band_start + __builtin_amdgcn_readfirstlane(sm.next_ticket);
         if (tile_patched) {
             if (pend - pbeg <= ENT_CAP) apply_patches_staged<METHOD, PACKED>(sm, a, frame, pend - pbeg, tx0, ty0);
             else apply_patches<METHOD, PACKED>(sm, a, frame, f, pbeg, pend, tx0, ty0);
@@ -762,7 +790,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         // levels 1..3 is used, and a third level for the output stage, make no difference.
         if (METHOD != 0) __builtin_amdgcn_s_setprio(1);       // (without chroma smoothing the kernel is load-bound and this costs 8 %)
         // ---- prefetch the next tile while the medians run
-        if (vec) issue_tile(min(t + slots, band_end - 1));
+        if (vec) issue_tile(min(t_next, band_end - 1));
 
         // ---- medians + output: one thread = 4 cells = 8 px on two rows
         const int y = ty0 + 2 * j, x = tx0 + 2 * STRIP * k;
@@ -842,25 +870,83 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             }
         }
         lds_barrier();                       // all strips done with the planes before the next tile's loader
+        t = t_next;
     }
+    if (threadIdx.x == 0 && atomicAdd(&a.tickets[a.groups], 1) == (int)gridDim.x - 1) {
+        for (int i = 0; i <= a.groups; i++) a.tickets[i] = 0;       // last workgroup out: ready for the next launch on this stream
+    }
+#ifdef KF_DIAG_TIMES
+    if (threadIdx.x == 0 && a.times) { a.times[2 * blockIdx.x] = rt0; a.times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 // ---------------------------------------------------------------- host launcher
-template <int METHOD, bool PACKED, bool VEC>
-static int launch_frame_t(const FrameArgs &a, int num_cu, hipStream_t stream)
+// zeroed counters per stream (launches on one stream run one after the other and leave the counters zeroed)
+constexpr int MAX_GROUPS = 1024;
+static int *ticket_counters(hipStream_t stream)
 {
-    const long long total = (long long)a.tiles_x * a.tiles_y * a.nframes;
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, int *> per_stream;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    int *&p = per_stream[{ dev, stream }];
+    if (!p) {
+        if (hipMalloc(&p, (MAX_GROUPS + 1) * sizeof(int)) != hipSuccess || hipMemset(p, 0, (MAX_GROUPS + 1) * sizeof(int)) != hipSuccess) {
+            set_error("ticket counters: allocation failed");
+            p = nullptr;
+        }
+    }
+    return p;
+}
+template <int METHOD, bool PACKED, bool VEC>
+static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
+{
+    const long long total = (long long)a_in.tiles_x * a_in.tiles_y * a_in.nframes;
     int grid = num_cu > 0 ? num_cu * 4 : 1024;          // 4 workgroups per CU (39 KiB LDS, <= 128 VGPRs)
     grid = (grid + 7) / 8 * 8;
     if (grid > total) grid = (int)((total + 7) / 8 * 8);
     static_assert(sizeof(Smem) <= 40 * 1024 + 192, "four workgroups per CU need <= 40 KiB of LDS each");
     auto kern = k_frame<METHOD, PACKED, VEC>;
+    FrameArgs a = a_in;
+    a.tickets = ticket_counters(stream);
+    if (!a.tickets) return MLVFS_AMD_ERR_HIP;
+    a.groups = std::min(std::max(grid / 4, 1), MAX_GROUPS);
+#ifdef KF_DIAG_TIMES
+    static unsigned long long *d_times = nullptr;
+    if (!d_times) hipMalloc(&d_times, 2048 * 2 * sizeof(unsigned long long));
+    const_cast<FrameArgs &>(a).times = d_times;
+#endif
     KernelTimer &tm = kernel_timer();
     const bool timed = tm.on && tm.used + 2 <= (int)tm.ev.size();
     if (timed) MLV_HIP(hipEventRecord(tm.ev[tm.used], stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, stream, a);
     if (timed) { MLV_HIP(hipEventRecord(tm.ev[tm.used + 1], stream)); tm.used += 2; }
     MLV_HIP(hipGetLastError());
+#ifdef KF_DIAG_TIMES
+    if (METHOD == 5 && a.nframes >= 50) {
+        static int shown = 0;
+        if (shown++ % 8 == 3) {
+            hipStreamSynchronize(stream);
+            std::vector<unsigned long long> h(2 * grid);
+            hipMemcpy(h.data(), d_times, h.size() * 8, hipMemcpyDeviceToHost);
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int b = 0; b < grid; b++) { t0 = std::min(t0, h[2 * b]); t1 = std::max(t1, h[2 * b + 1]); }
+            double end_q[4] = { 0, 0, 0, 0 }, start_q[4] = { 0, 0, 0, 0 };
+            for (int b = 0; b < grid; b++) { end_q[b * 4 / grid] += (double)(h[2 * b + 1] - t0); start_q[b * 4 / grid] += (double)(h[2 * b] - t0); }
+            fprintf(stderr, "KF_TIMES grid %d: kernel %.1f us; mean start / end of the workgroups of each quarter of the grid (us):", grid, (t1 - t0) * 0.01);
+            for (int q = 0; q < 4; q++) fprintf(stderr, "  %.1f / %.1f", start_q[q] / (grid / 4) * 0.01, end_q[q] / (grid / 4) * 0.01);
+            fprintf(stderr, "\n");
+            double xe[8] = { 0 }, xm[8] = { 0 };
+            for (int b = 0; b < grid; b++) { const double e = (double)(h[2 * b + 1] - t0) * 0.01; xe[b % 8] += e / (grid / 8); xm[b % 8] = std::max(xm[b % 8], e); }
+            fprintf(stderr, "KF_TIMES per XCD mean/max end:");
+            for (int x = 0; x < 8; x++) fprintf(stderr, "  %.0f/%.0f", xe[x], xm[x]);
+            fprintf(stderr, "\nKF_TIMES end of blocks 0..255 step 8 (XCD 0's groups):");
+            for (int b = 0; b < 256 && b < grid; b += 8) fprintf(stderr, " %.0f", (double)(h[2 * b + 1] - t0) * 0.01);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     return MLVFS_AMD_OK;
 }
 
