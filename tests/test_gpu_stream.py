@@ -208,6 +208,29 @@ def test_full_size_properties(torch_cuda):
     s.close()
 
 
+@pytest.mark.parametrize("w,h", [(48, 20), (144, 40), (1296, 520)])
+def test_tile_tickets_across_launch_sizes(torch_cuda, oracle, w, h):
+    """k_frame hands out tiles by per-stream ticket counters that the last workgroup of a launch zeroes (DESIGN.md 3.1,
+    Placement).  Launches of very different sizes back to back on one stream -- fewer tiles than workgroups, one tile per
+    group, thousands of tiles -- must all process every tile exactly once: each launch is compared with the oracle and the
+    output buffer is poisoned before it, so a tile that nobody drew (or a counter left over from the previous launch) shows."""
+    import torch
+    from mlvfs_amd.stream import to_numpy_u16
+    nf = 37
+    frames = [synth.normal_frame(w, h, seed=5, frame=k % 5) for k in range(nf)]
+    want = [oracle.chroma_smooth(f.copy(), BLACK, 5) for f in frames[:5]]
+    s = make_stream(w, h)
+    packed = s.upload_packed([synth.pack_bits(f) for f in frames])
+    out = s.alloc_out(nf)
+    for lo, hi in [(0, 1), (0, 37), (3, 4), (1, 20), (36, 37), (0, 2), (5, 37), (0, 37)]:
+        out.fill_(0x5A5A)
+        s.process(packed[lo:hi], out[lo:hi], cs=5)
+        got = to_numpy_u16(out[lo:hi])
+        for k in range(lo, hi):
+            assert np.array_equal(got[k - lo], want[k % 5]), f"launch [{lo},{hi}) frame {k}"
+    s.close()
+
+
 @pytest.mark.parametrize("pinned", [True, False])
 def test_host_pipeline_matches_device_pipeline(gpu, pinned):
     """mlvfs_amd_process_frames_host (frames in host memory, chunked H2D / kernels / D2H on three streams) must give
