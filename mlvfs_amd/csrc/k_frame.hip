@@ -27,8 +27,8 @@
 //     ev2raw's 64 KiB table is gathered from L2 (all gathers of a strip in flight at once)
 //   * pixel-map patches: per-tile entry lists (built once per clip on the host)
 //     recompute just the cells they touch
-//   * persistent workgroups, XCD-aware tile walk (each XCD owns a contiguous band of
-//     tiles so halo re-reads hit its own L2)
+//   * persistent workgroups; the four residents of a CU draw tiles by ticket from that CU's contiguous
+//     range of the tile list (the ranges of an XCD's CUs adjacent, so halo re-reads hit its own L2)
 // No MFMA: this is a stencil / gather / selection path.
 #include "clip.h"
 #include <cstdlib>
