@@ -504,7 +504,7 @@ __device__ __forceinline__ void strip_median25(const int (*plane)[PW], int row_t
     }
 }
 
-// 5x5 on both colour-difference planes at once: (dr, db) of a cell, taken relative to the strip's own centre cell
+// 5x5 on both colour-difference planes at once: (dr, db) of a cell, taken relative to a reference from the strip's own centre row
 // (saturating subtract) and saturated to a pair of 16-bit lanes (v_cvt_pk_i16_i32); the same sorted-column / merge /
 // rank-window networks then run on packed min/max.  Both saturations are monotone, so the packed median is the
 // saturated, shifted true median: exact unless it sits ON a 16-bit bound, which the caller treats as "unknown"
@@ -513,7 +513,11 @@ __device__ __forceinline__ void strip_median25(const int (*plane)[PW], int row_t
 __device__ __forceinline__ bool strip_median25_packed(const int (*pr_)[PW], const int (*pb_)[PW], int row_top, int col_left,
                                                       int (&mr)[STRIP], int (&mb)[STRIP])
 {
-    const int ref_r = pr_[row_top + 2][col_left + 2], ref_b = pb_[row_top + 2][col_left + 2];
+    // reference = median of three cells of the centre row (columns 2, 4, 5): in noisy shadows a single cell is often more than
+    // 1 EV away from the median of its neighbourhood (EVs of small integers), which sent the whole wave to the 32-bit networks
+    const int4 cr0 = *(const int4 *)&pr_[row_top + 2][col_left], cr1 = *(const int4 *)&pr_[row_top + 2][col_left + 4];
+    const int4 cb0 = *(const int4 *)&pb_[row_top + 2][col_left], cb1 = *(const int4 *)&pb_[row_top + 2][col_left + 4];
+    const int ref_r = med3i(cr0.z, cr1.x, cr1.y), ref_b = med3i(cb0.z, cb1.x, cb1.y);
     auto pack = [&](int r, int b) {
         return __builtin_amdgcn_cvt_pk_i16(__builtin_elementwise_sub_sat(r, ref_r), __builtin_elementwise_sub_sat(b, ref_b));
     };

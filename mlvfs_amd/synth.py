@@ -210,6 +210,18 @@ def colour_cast_frame(w: int, h: int, seed: int = 11, black: int = BLACK) -> np.
     return np.clip(v, 0, 16383).astype(np.uint16)
 
 
+def low_light_frame(w: int, h: int, seed: int = 21, black: int = BLACK) -> np.ndarray:
+    """Underexposed footage: a smooth scene 0..400 above black (R and B at 0.45 / 0.3 of G), Gaussian read noise of 7 DN, so a
+    few per cent of the pixels of the dark half sit at or below the black level (ev = 0 / INT_MIN in raw2ev: the loader's
+    out-of-table path), but no hard colour edges."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    lum = 8 + 400 * (xx / w) ** 2 + 60 * np.sin(yy * 0.02) ** 2
+    gains = np.array([[0.45, 1.0], [1.0, 0.30]])
+    v = lum * gains[yy % 2, xx % 2] + rng.normal(0.0, 7.0, (h, w)) + black
+    return np.clip(np.rint(v), 0, 16383).astype(np.uint16)
+
+
 def amaze_plane(w: int, h: int, seed: int = 1) -> np.ndarray:
     """Float RGGB plane in the scale the dual-ISO path hands to AMaZE (20-bit values, i.e. 0..16 after the
     tile loader's /65535): smooth gradients, a checker, clipped patches (> 0.8 * 65535 takes the

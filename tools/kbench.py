@@ -15,6 +15,10 @@ base = s.synth_packed(8, seed=1)
 if os.environ.get("KB_KIND") == "colour_cast":          # footage-like colour balance with hard colour edges
     fr = [synth.colour_cast_frame(W, H, seed=11 + i) for i in range(8)]
     base = s.upload_packed([synth.pack_bits(f) for f in fr])
+if os.environ.get("KB_KIND") == "low_light":            # underexposed footage: pixels at / below black, no colour edges
+    fr = [synth.low_light_frame(W, H, seed=21 + i) for i in range(8)]
+    print("low_light: %.2f %% of the pixels at or below black" % (100.0 * np.mean([(f <= synth.BLACK).mean() for f in fr])))
+    base = s.upload_packed([synth.pack_bits(f) for f in fr])
 packed = s.alloc_packed(F)
 for i in range(0, F, 8):
     packed[i:i + 8] = base[:min(8, F - i)]
