@@ -117,7 +117,10 @@ int         mlvfs_amd_init(int device);              /* binds the calling thread
 const char *mlvfs_amd_last_error(void);
 const char *mlvfs_amd_version(void);
 
-/* per-clip artefacts: stripe coefficients + ordered pixel map */
+/* per-clip artefacts: stripe coefficients + ordered pixel map.
+ * A handle also owns scratch that its calls reuse (the per-frame patch lists of the pixel repair): calls on ONE handle must
+ * be ordered -- issue them on one stream, or serialise them --; to process one clip on several streams at once create a
+ * handle per stream and give each the same stripes / pixel map.                                                        */
 typedef struct mlvfs_amd_clip mlvfs_amd_clip_t;
 mlvfs_amd_clip_t *mlvfs_amd_clip_create(const mlvfs_amd_geom_t *geom);
 void   mlvfs_amd_clip_destroy(mlvfs_amd_clip_t *clip);
