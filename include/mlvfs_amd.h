@@ -126,6 +126,10 @@ mlvfs_amd_clip_t *mlvfs_amd_clip_create(const mlvfs_amd_geom_t *geom);
 void   mlvfs_amd_clip_destroy(mlvfs_amd_clip_t *clip);
 int    mlvfs_amd_clip_set_stripes(mlvfs_amd_clip_t *clip, int needed, const int32_t coeffs[8]);
 int    mlvfs_amd_clip_get_stripes(const mlvfs_amd_clip_t *clip, int *needed, int32_t coeffs[8]);
+/* Layout of the raw2ev table inside the fused kernel: 0 = decide from the first frame this clip processes with
+ * chroma smoothing (default; one stream synchronisation), 1 = plain, 2 = spread (dark footage).  Results are identical.   */
+int    mlvfs_amd_clip_set_t16_layout(mlvfs_amd_clip_t *clip, int layout);
+int    mlvfs_amd_clip_get_t16_layout(const mlvfs_amd_clip_t *clip);
 /* xy = count (x,y) pairs in sensor coordinates (crop offsets included), list order
  * is application order.  kind: 0 = bad-pixel rules (cs.c:314-330), 1 = focus-pixel
  * rules incl. edges (cs.c:463-500).                                            */

@@ -48,6 +48,8 @@ struct Clip {
     size_t patch_bytes = 0;
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    // T16 layout of the fused kernel: 0 = not decided yet (from the first frame the clip processes), 1 = plain, 2 = spread
+    int t16_layout = 0;
     void *d_unpacked = nullptr;      // 10 / 12-bit clips: frames unpacked to 16 bits before the fused kernel
     size_t unpacked_bytes = 0;
 
@@ -99,7 +101,9 @@ int launch_unpack(const void *d_packed, size_t packed_stride, void *d_out, size_
                   uint32_t npix, int bpp, int nframes, hipStream_t stream);
 int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src, size_t src_stride, void *dst,
                  size_t dst_stride, int nframes, int method, const PatchView *pv, bool stripes,
-                 const int32_t *coef, hipStream_t stream);
+                 const int32_t *coef, hipStream_t stream, bool spread = false);       // spread: T16 layout for dark clips (k_frame.hip)
+// share of sampled pixels of one frame that lie 1 .. 511 above black, in 1/1024 (synchronises the stream)
+int dark_share(bool packed, const void *d_frame, int w, int h, int black, hipStream_t stream, int *share_1024);
 int launch_pixfix(bool packed, const void *frames, size_t stride, int w, int black, const void *entries,
                   const int *level_off, int n_levels, int n_entries, void *patches, void *scatter, size_t scatter_stride,
                   int nframes, const DeviceLuts &luts, hipStream_t stream);

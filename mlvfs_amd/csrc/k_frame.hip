@@ -61,7 +61,6 @@ constexpr int GROUPS = TCW / 8;         // full items per plane row (8)
 constexpr int N_FULL = PH * GROUPS;     // 160 full items per tile  (threads 0..159)
 constexpr int N_ITEMS = N_FULL + PH;    // + 20 edge items = 180    (threads 160..179)
 constexpr int PMAP_WORDS = 256;         // tiles per frame covered by the LDS patch bitmap: 8192 (3584x1320 has 1176)
-constexpr int ENT_CAP = 32;             // pixel-map entries of one tile staged in LDS (more: the unstaged path)
 static_assert(N_ITEMS <= 256 && TCH * (TCW / STRIP) == 256, "one item and one strip per thread");
 
 struct FrameArgs {
@@ -89,12 +88,18 @@ struct FrameArgs {
 #endif
 };
 
-struct __align__(16) Smem {
+// SPREAD: the T16 table with entry i at i + (i >> 7).  A pixel below 2^e above black uses only every 2^(13-e)-th entry, so
+// the look-ups of dark footage crowd into a few LDS banks (below 128 DN: one); the spread form puts those entries into
+// different banks for two more operations per pixel.  Chosen per clip from its first frame (launch_frame's `spread`).
+template <bool SPREAD_>
+struct __align__(16) SmemT {
+    static constexpr bool SPREAD = SPREAD_;
+    static constexpr int ENT_CAP = SPREAD_ ? 24 : 32;   // pixel-map entries of one tile staged in LDS (more: the unstaged path)
     uint16_t raw[2 * TCH][2 * TCW];     // interior pixels (post patch), 8 KiB
     int dr[PH][PW];                     // 5.3 KiB
     int db[PH][PW];
     int ge[TCH][TCW];                   // 4 KiB
-    uint16_t t16[MLV_T16_N];            // mantissa-normalised raw2ev (common.h), 16 KiB
+    uint16_t t16[MLV_T16_N + (SPREAD_ ? 64 : 0)];   // mantissa-normalised raw2ev (common.h), 16 KiB
     uint32_t has_patch[PMAP_WORDS];     // one bit per tile of a frame: some pixel-map entry touches it (1 KiB)
     int2 ent[ENT_CAP];                  // {pos, value} of the entries that touch the current tile (staged by the loader phase)
     int next_ticket;
@@ -146,6 +151,15 @@ __device__ __forceinline__ uint32_t bfe_asm(uint32_t v)
 }
 
 // EV triples of two adjacent Bayer cells (8 pixels): r/g1 on the top row, g2/b below
+// byte offset of the table entry of a pixel whose float is fb
+template <bool SPREAD>
+__device__ __forceinline__ uint32_t t16_offset(uint32_t fb)
+{
+    if (SPREAD) return (bfe_asm<17, 6>(fb) << 1) + bfe_asm<9, 14>(fb);       // v_bfe + v_lshl_add
+    return bfe_asm<9, 14>(fb);
+}
+
+template <bool SPREAD>
 __device__ __forceinline__ void cell_pair_ev(const uint32_t *p0, const uint32_t *p1, int black, const uint16_t *t, bool slow,
                                              int (&ge)[2], int (&dr)[2], int (&db)[2])
 {
@@ -161,7 +175,7 @@ __device__ __forceinline__ void cell_pair_ev(const uint32_t *p0, const uint32_t 
 #pragma unroll
         for (int i = 0; i < 8; i++) fb[i] = __float_as_uint((float)(unsigned)lin[i]);
 #pragma unroll
-        for (int i = 0; i < 8; i++) tv[i] = *(const uint16_t *)((const char *)t + bfe_asm<9, 14>(fb[i]));
+        for (int i = 0; i < 8; i++) tv[i] = *(const uint16_t *)((const char *)t + t16_offset<SPREAD>(fb[i]));
         // opaque use: keeps the eight LDS reads unconditional and back to back (the compiler
         // otherwise sinks each read next to its use and waits for it there)
         uint32_t ex[8], eb[8];
@@ -185,7 +199,7 @@ __device__ __forceinline__ void cell_pair_ev(const uint32_t *p0, const uint32_t 
 #pragma unroll
         for (int i = 0; i < 8; i++) l[i] = min(max(lin[i], 1), 16383);
 #pragma unroll
-        for (int i = 0; i < 8; i++) tv[i] = t[ev_index(l[i])];
+        for (int i = 0; i < 8; i++) tv[i] = t[SPREAD ? ev_index(l[i]) + (ev_index(l[i]) >> 7) : ev_index(l[i])];
         asm volatile("" :: "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]), "v"(tv[4]), "v"(tv[5]), "v"(tv[6]), "v"(tv[7]));
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -202,7 +216,7 @@ __device__ __forceinline__ void cell_pair_ev(const uint32_t *p0, const uint32_t 
 }
 
 // the common path of cell_pair_ev for NC adjacent cells at once: 4 NC table reads in flight, one wait
-template <int NC>
+template <int NC, bool SPREAD>
 __device__ __forceinline__ void cell_multi_ev_fast(const uint32_t *p0, const uint32_t *p1, int black, const uint16_t *t,
                                                    int (&ge)[NC], int (&dr)[NC], int (&db)[NC])
 {
@@ -214,7 +228,7 @@ __device__ __forceinline__ void cell_multi_ev_fast(const uint32_t *p0, const uin
         for (int i = 0; i < 4; i++) fb[4 * c + i] = __float_as_uint((float)(unsigned)(px[i] - black));
     }
 #pragma unroll
-    for (int i = 0; i < 4 * NC; i++) tv[i] = *(const uint16_t *)((const char *)t + bfe_asm<9, 14>(fb[i]));
+    for (int i = 0; i < 4 * NC; i++) tv[i] = *(const uint16_t *)((const char *)t + t16_offset<SPREAD>(fb[i]));
 #pragma unroll
     for (int i = 0; i < 4 * NC; i++) ex[i] = bfe_asm<23, 8>(fb[i]);
 #pragma unroll
@@ -237,11 +251,12 @@ __device__ __forceinline__ void cell_multi_ev_fast(const uint32_t *p0, const uin
 }
 
 // single cell (patch path)
+template <bool SPREAD>
 __device__ __forceinline__ void cell_ev(int r, int g1, int g2, int b, int black, const uint16_t *t, int &ge, int &dr, int &db)
 {
     const uint32_t p0[4] = { (uint32_t)r, (uint32_t)g1, (uint32_t)r, (uint32_t)g1 }, p1[4] = { (uint32_t)g2, (uint32_t)b, (uint32_t)g2, (uint32_t)b };
     int g[2], a[2], c[2];
-    cell_pair_ev(p0, p1, black, t, true, g, a, c);          // rare path: always with the out-of-table fix-ups
+    cell_pair_ev<SPREAD>(p0, p1, black, t, true, g, a, c);          // rare path: always with the out-of-table fix-ups
     ge = g[0]; dr = a[0]; db = c[0];
 }
 
@@ -345,15 +360,15 @@ __device__ __forceinline__ void fetch_rows(const uint8_t *frame, int w, int h, i
 }
 
 // EV triples of NCELL (even) cells into the planes: plane row r, first plane column col0
-template <int NCELL>
-__device__ __forceinline__ void store_cells(Smem &sm, int black, bool slow, int r, int col0, const uint32_t *p0, const uint32_t *p1)
+template <int NCELL, class SM>
+__device__ __forceinline__ void store_cells(SM &sm, int black, bool slow, int r, int col0, const uint32_t *p0, const uint32_t *p1)
 {
     const bool row_in = r >= HC && r < HC + TCH;
     if (NCELL == 8 && !slow) {                           // wave-uniform; against pairs: cs2x2 -2.5 %, cs5x5 -2 %; all eight at once: no better
 #pragma unroll
         for (int c = 0; c < 8; c += 4) {
             int ge[4], dr[4], db[4];
-            cell_multi_ev_fast<4>(p0 + 2 * c, p1 + 2 * c, black, sm.t16, ge, dr, db);
+            cell_multi_ev_fast<4, SM::SPREAD>(p0 + 2 * c, p1 + 2 * c, black, sm.t16, ge, dr, db);
             *(int4 *)&sm.dr[r][col0 + c] = make_int4(dr[0], dr[1], dr[2], dr[3]);
             *(int4 *)&sm.db[r][col0 + c] = make_int4(db[0], db[1], db[2], db[3]);
             if (row_in) *(int4 *)&sm.ge[r - HC][col0 + c - HC] = make_int4(ge[0], ge[1], ge[2], ge[3]);
@@ -363,7 +378,7 @@ __device__ __forceinline__ void store_cells(Smem &sm, int black, bool slow, int 
 #pragma unroll
     for (int c = 0; c < NCELL; c += 2) {
         int ge[2], dr[2], db[2];
-        cell_pair_ev(p0 + 2 * c, p1 + 2 * c, black, sm.t16, slow, ge, dr, db);
+        cell_pair_ev<SM::SPREAD>(p0 + 2 * c, p1 + 2 * c, black, sm.t16, slow, ge, dr, db);
         *(int2 *)&sm.dr[r][col0 + c] = make_int2(dr[0], dr[1]);
         *(int2 *)&sm.db[r][col0 + c] = make_int2(db[0], db[1]);
         const int ci = col0 + c - HC;
@@ -371,7 +386,8 @@ __device__ __forceinline__ void store_cells(Smem &sm, int black, bool slow, int 
     }
 }
 
-__device__ __forceinline__ void store_raw(Smem &sm, int row, int g, const uint32_t (&p)[16])
+template <class SM>
+__device__ __forceinline__ void store_raw(SM &sm, int row, int g, const uint32_t (&p)[16])
 {
     uint4 *o = (uint4 *)&sm.raw[row][16 * g];
     o[0] = make_uint4(p[0] | (p[1] << 16), p[2] | (p[3] << 16), p[4] | (p[5] << 16), p[6] | (p[7] << 16));
@@ -379,26 +395,26 @@ __device__ __forceinline__ void store_raw(Smem &sm, int row, int g, const uint32
 }
 
 // pixels of one item -> planes (+ interior raw)
-template <int METHOD>
-__device__ __forceinline__ void emit_item(Smem &sm, int black, bool slow, int pr, int g, bool edge, const uint32_t (&p0)[16],
+template <int METHOD, class SM>
+__device__ __forceinline__ void emit_item(SM &sm, int black, bool slow, int pr, int g, bool edge, const uint32_t (&p0)[16],
                                           const uint32_t (&p1)[16])
 {
     if (!edge) {
-        if (METHOD != 0) store_cells<8>(sm, black, slow, pr, HC + 8 * g, p0, p1);
+        if (METHOD != 0) store_cells<8, SM>(sm, black, slow, pr, HC + 8 * g, p0, p1);
         if (pr >= HC && pr < HC + TCH) {
             store_raw(sm, 2 * (pr - HC), g, p0);
             store_raw(sm, 2 * (pr - HC) + 1, g, p1);
         }
     } else if (METHOD != 0) {
-        store_cells<2>(sm, black, slow, pr, 0, p0 + 12, p1 + 12);    // left halo  (px 12..15)
-        store_cells<2>(sm, black, slow, pr, HC + TCW, p0, p1);       // right halo (px 0..3)
+        store_cells<2, SM>(sm, black, slow, pr, 0, p0 + 12, p1 + 12);    // left halo  (px 12..15)
+        store_cells<2, SM>(sm, black, slow, pr, HC + TCW, p0, p1);       // right halo (px 0..3)
     }
 }
 
 // ---------------------------------------------------------------- patches
 // recompute every cell of this tile that a pixel-map entry touches
-template <int METHOD, bool PACKED>
-__device__ __forceinline__ void apply_patches(Smem &sm, const FrameArgs &a, const uint8_t *frame, int f, int beg, int end, int tx0, int ty0)
+template <int METHOD, bool PACKED, class SM>
+__device__ __forceinline__ void apply_patches(SM &sm, const FrameArgs &a, const uint8_t *frame, int f, int beg, int end, int tx0, int ty0)
 {
     const int2 *pl = a.patches + (size_t)f * a.n_patch;
     for (int k = beg + (int)threadIdx.x; k < end; k += blockDim.x) {
@@ -418,7 +434,7 @@ __device__ __forceinline__ void apply_patches(Smem &sm, const FrameArgs &a, cons
         }
         int ge = 0, dr = 0, db = 0;
         if (METHOD != 0) {
-            cell_ev(px[0], px[1], px[2], px[3], a.black, sm.t16, ge, dr, db);
+            cell_ev<SM::SPREAD>(px[0], px[1], px[2], px[3], a.black, sm.t16, ge, dr, db);
             sm.dr[j][i] = dr;
             sm.db[j][i] = db;
         }
@@ -432,8 +448,8 @@ __device__ __forceinline__ void apply_patches(Smem &sm, const FrameArgs &a, cons
 }
 
 // the same with the tile's `cnt` entries already staged in sm.ent (fetched while the loader phase ran)
-template <int METHOD, bool PACKED>
-__device__ __forceinline__ void apply_patches_staged(Smem &sm, const FrameArgs &a, const uint8_t *frame, int cnt, int tx0, int ty0)
+template <int METHOD, bool PACKED, class SM>
+__device__ __forceinline__ void apply_patches_staged(SM &sm, const FrameArgs &a, const uint8_t *frame, int cnt, int tx0, int ty0)
 {
     // staged form (stage_entry): x = cell column | cell row << 16 (or -1), y = pixel within the cell | value << 16
     const int k = threadIdx.x;
@@ -461,7 +477,7 @@ __device__ __forceinline__ void apply_patches_staged(Smem &sm, const FrameArgs &
     }
     int ge = 0, dr = 0, db = 0;
     if (METHOD != 0) {
-        cell_ev(px[0], px[1], px[2], px[3], a.black, sm.t16, ge, dr, db);
+        cell_ev<SM::SPREAD>(px[0], px[1], px[2], px[3], a.black, sm.t16, ge, dr, db);
         sm.dr[j][i] = dr;
         sm.db[j][i] = db;
     }
@@ -652,15 +668,21 @@ __device__ __forceinline__ void stripe_strip_pk(uint32_t (&top)[STRIP], uint32_t
     }
 }
 
-template <int METHOD, bool PACKED, bool VEC>
+template <int METHOD, bool PACKED, bool VEC, bool SPREAD>
 __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 {
+    using Smem = SmemT<SPREAD>;
+    constexpr int ENT_CAP = Smem::ENT_CAP;
     __shared__ Smem sm;                                  // static: a compile-time LDS base (a dynamic one costs an add per access)
 
     if (METHOD != 0) {
-        const uint4 *src = (const uint4 *)a.t16;
-        uint4 *dstl = (uint4 *)sm.t16;
-        for (int i = threadIdx.x; i < MLV_T16_N * 2 / 16; i += blockDim.x) dstl[i] = src[i];
+        if (SPREAD) {
+            for (int i = threadIdx.x; i < MLV_T16_N; i += blockDim.x) sm.t16[i + (i >> 7)] = a.t16[i];
+        } else {
+            const uint4 *src = (const uint4 *)a.t16;
+            uint4 *dstl = (uint4 *)sm.t16;
+            for (int i = threadIdx.x; i < MLV_T16_N * 2 / 16; i += blockDim.x) dstl[i] = src[i];
+        }
     }
     // Which tiles of a frame have pixel-map entries: one bit per tile in LDS.  Reading the tile's list bounds from HBM in
     // every iteration made each wave wait for ALL its outstanding loads (the prefetch of the next tile included) before the
@@ -769,7 +791,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 odd = (int)lo <= a.black || (!PACKED && (int)hi - a.black > 16383) || (PACKED && a.black < 0);
             }
             const bool slow = __any(odd);
-            emit_item<METHOD>(sm, a.black, slow, item_row, item_g, edge, p0, p1);
+            emit_item<METHOD, Smem>(sm, a.black, slow, item_row, item_g, edge, p0, p1);
         }
         if (tile_patched && pend - pbeg <= ENT_CAP && tid < pend - pbeg) {
             // one division per entry, here, instead of two per entry pair in apply_patches_staged
@@ -784,8 +806,8 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         lds_barrier();
         const int t_next = band_start + __builtin_amdgcn_readfirstlane(sm.next_ticket);
         if (tile_patched) {
-            if (pend - pbeg <= ENT_CAP) apply_patches_staged<METHOD, PACKED>(sm, a, frame, pend - pbeg, tx0, ty0);
-            else apply_patches<METHOD, PACKED>(sm, a, frame, f, pbeg, pend, tx0, ty0);
+            if (pend - pbeg <= ENT_CAP) apply_patches_staged<METHOD, PACKED, Smem>(sm, a, frame, pend - pbeg, tx0, ty0);
+            else apply_patches<METHOD, PACKED, Smem>(sm, a, frame, f, pbeg, pend, tx0, ty0);
             lds_barrier();
         }
         // Waves that are past the loader issue ahead of waves (of the CU's other workgroups) that are still in it: a tile that
@@ -903,15 +925,15 @@ static int *ticket_counters(hipStream_t stream)
     }
     return p;
 }
-template <int METHOD, bool PACKED, bool VEC>
+template <int METHOD, bool PACKED, bool VEC, bool SPREAD>
 static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
 {
     const long long total = (long long)a_in.tiles_x * a_in.tiles_y * a_in.nframes;
     int grid = num_cu > 0 ? num_cu * 4 : 1024;          // 4 workgroups per CU (39 KiB LDS, <= 128 VGPRs)
     grid = (grid + 7) / 8 * 8;
     if (grid > total) grid = (int)((total + 7) / 8 * 8);
-    static_assert(sizeof(Smem) <= 40 * 1024 + 192, "four workgroups per CU need <= 40 KiB of LDS each");
-    auto kern = k_frame<METHOD, PACKED, VEC>;
+    static_assert(sizeof(SmemT<SPREAD>) <= 40 * 1024, "four workgroups per CU need <= 40 KiB of LDS each");
+    auto kern = k_frame<METHOD, PACKED, VEC, SPREAD>;
     FrameArgs a = a_in;
     a.tickets = ticket_counters(stream);
     if (!a.tickets) return MLVFS_AMD_ERR_HIP;
@@ -956,7 +978,7 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
 
 int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src, size_t src_stride, void *dst,
                  size_t dst_stride, int nframes, int method, const PatchView *pv, bool stripes,
-                 const int32_t *coef, hipStream_t stream)
+                 const int32_t *coef, hipStream_t stream, bool spread)
 {
     if (nframes <= 0) return MLVFS_AMD_OK;
     if ((long long)frame_tiles_x(g.w) * frame_tiles_y(g.h) * nframes >= (1ll << 30)) {
@@ -988,11 +1010,14 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
     // vector path: rows are whole 16-pixel groups and every row starts 16-byte aligned
     const bool vec = (g.w % 16) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 &&
                      (nframes == 1 || (src_stride % 16 == 0 && dst_stride % 16 == 0));
+#define MLV_DISPATCH_S(M, S)                                                                              \
+    return packed ? (vec ? launch_frame_t<M, true, true, S>(a, dev->num_cu, stream)                       \
+                         : launch_frame_t<M, true, false, S>(a, dev->num_cu, stream))                     \
+                  : (vec ? launch_frame_t<M, false, true, S>(a, dev->num_cu, stream)                      \
+                         : launch_frame_t<M, false, false, S>(a, dev->num_cu, stream))
 #define MLV_DISPATCH(M)                                                                                   \
-    return packed ? (vec ? launch_frame_t<M, true, true>(a, dev->num_cu, stream)                          \
-                         : launch_frame_t<M, true, false>(a, dev->num_cu, stream))                        \
-                  : (vec ? launch_frame_t<M, false, true>(a, dev->num_cu, stream)                         \
-                         : launch_frame_t<M, false, false>(a, dev->num_cu, stream))
+    if (spread && M != 0) { MLV_DISPATCH_S(M, true); }                                                    \
+    MLV_DISPATCH_S(M, false)
     switch (method) {
         case 0: MLV_DISPATCH(0);
         case 2: MLV_DISPATCH(2);
@@ -1001,6 +1026,42 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
         default: set_error("Unsupported chroma smooth method %d", method); return MLVFS_AMD_ERR_ARG;
     }
 #undef MLV_DISPATCH
+#undef MLV_DISPATCH_S
+}
+
+// ---------------------------------------------------------------- which T16 layout suits a clip
+// every 7th pixel of every 5th row of one frame: how many lie 1 .. 511 above black (the range whose look-ups collide in the plain layout)
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_dark_share(const uint8_t *frame, int w, int h, int black, int *counts)
+{
+    const int nx = (w + 6) / 7, ny = (h + 4) / 5;
+    int dark = 0, all = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nx * ny; i += gridDim.x * blockDim.x) {
+        const int y = (i / nx) * 5, x = (i % nx) * 7;
+        const int lin = (int)fetch_clamped<PACKED>(frame, w, h, x, y) - black;
+        dark += lin >= 1 && lin < 512;
+        all++;
+    }
+    for (int o = 32; o > 0; o >>= 1) { dark += __shfl_xor(dark, o); all += __shfl_xor(all, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[0], dark); atomicAdd(&counts[1], all); }
+}
+
+int dark_share(bool packed, const void *d_frame, int w, int h, int black, hipStream_t stream, int *share_1024)
+{
+    int *d_counts = nullptr, hc[2] = { 0, 0 };
+    MLV_HIP(hipMalloc(&d_counts, 2 * sizeof(int)));
+    hipError_t e = hipMemsetAsync(d_counts, 0, 2 * sizeof(int), stream);
+    if (e == hipSuccess) {
+        if (packed) hipLaunchKernelGGL(k_dark_share<true>, dim3(64), dim3(256), 0, stream, (const uint8_t *)d_frame, w, h, black, d_counts);
+        else hipLaunchKernelGGL(k_dark_share<false>, dim3(64), dim3(256), 0, stream, (const uint8_t *)d_frame, w, h, black, d_counts);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hc, d_counts, sizeof(hc), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_counts);
+    if (e != hipSuccess) { set_error("dark_share: %s", hipGetErrorString(e)); return MLVFS_AMD_ERR_HIP; }
+    *share_1024 = hc[1] > 0 ? (int)((long long)hc[0] * 1024 / hc[1]) : 0;
+    return MLVFS_AMD_OK;
 }
 
 }  // namespace mlv

@@ -36,7 +36,7 @@ DROPIN_SYMBOLS = [
 DEVICE_SYMBOLS = [
     "mlvfs_amd_device_count", "mlvfs_amd_init", "mlvfs_amd_last_error", "mlvfs_amd_version",
     "mlvfs_amd_clip_create", "mlvfs_amd_clip_destroy", "mlvfs_amd_clip_set_stripes", "mlvfs_amd_clip_get_stripes",
-    "mlvfs_amd_clip_set_pixel_map", "mlvfs_amd_clip_get_pixel_map",
+    "mlvfs_amd_clip_set_pixel_map", "mlvfs_amd_clip_get_pixel_map", "mlvfs_amd_clip_set_t16_layout", "mlvfs_amd_clip_get_t16_layout",
     "mlvfs_amd_unpack_dev", "mlvfs_amd_chroma_smooth_dev", "mlvfs_amd_detect_bad_pixels_dev",
     "mlvfs_amd_fix_pixels_dev", "mlvfs_amd_stripes_count_dev", "mlvfs_amd_stripes_hist_dev",
     "mlvfs_amd_stripes_solve", "mlvfs_amd_stripes_compute_dev", "mlvfs_amd_stripes_apply_dev",
@@ -121,6 +121,8 @@ def load() -> C.CDLL:
     sig("mlvfs_amd_clip_destroy", None, [vp])
     sig("mlvfs_amd_clip_set_stripes", i, [vp, i, vp])
     sig("mlvfs_amd_clip_get_stripes", i, [vp, C.POINTER(i), vp])
+    sig("mlvfs_amd_clip_set_t16_layout", i, [vp, i])
+    sig("mlvfs_amd_clip_get_t16_layout", i, [vp])
     sig("mlvfs_amd_clip_set_pixel_map", i, [vp, vp, sz, i, i])
     sig("mlvfs_amd_clip_get_pixel_map", sz, [vp, vp, sz])
     sig("mlvfs_amd_unpack_dev", i, [gp, vp, sz, vp, sz, i, vp])

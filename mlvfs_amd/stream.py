@@ -95,6 +95,13 @@ class ClipStream:
         co = np.ascontiguousarray(coeffs, np.int32)
         lib.check(self.L.mlvfs_amd_clip_set_stripes(self.clip, int(needed), lib.ptr(co)))
 
+    def set_t16_layout(self, layout: int) -> None:
+        """0 = auto (from the first processed frame), 1 = plain, 2 = spread (dark footage); results are identical."""
+        lib.check(self.L.mlvfs_amd_clip_set_t16_layout(self.clip, layout), "clip_set_t16_layout")
+
+    def get_t16_layout(self) -> int:
+        return int(self.L.mlvfs_amd_clip_get_t16_layout(self.clip))
+
     def get_stripes(self):
         co = np.zeros(8, np.int32)
         needed = C.c_int(0)
@@ -154,6 +161,16 @@ class ClipStream:
         lib.check(self.L.mlvfs_amd_process_frames_dev(self.clip, _dptr(packed), self.packed_stride, _dptr(out),
                                                       self.out_stride, n, cs, int(fix_pixels), int(stripes),
                                                       _stream_ptr()), "process_frames_dev")
+        return out
+
+    def process_unpacked(self, frames: torch.Tensor, out: torch.Tensor | None = None, cs: int = 0, fix_pixels: bool = False,
+                         stripes: bool = False) -> torch.Tensor:
+        """The same pass for frames that are already 16-bit in HBM (decoded LJ92 payloads)."""
+        n = frames.shape[0]
+        out = self.alloc_out(n) if out is None else out
+        lib.check(self.L.mlvfs_amd_process_unpacked_dev(self.clip, _dptr(frames), self.out_stride, _dptr(out), self.out_stride,
+                                                        n, cs, int(fix_pixels), int(stripes), _stream_ptr()),
+                  "process_unpacked_dev")
         return out
 
     def process_host(self, packed: torch.Tensor, out: torch.Tensor | None = None, cs: int = 0, fix_pixels: bool = False,

@@ -208,6 +208,43 @@ def test_full_size_properties(torch_cuda):
     s.close()
 
 
+@pytest.mark.parametrize("kind", ["normal", "adversarial", "low_light", "colour_cast"])
+@pytest.mark.parametrize("cs", [2, 3, 5])
+def test_t16_layouts_give_identical_results(torch_cuda, oracle, kind, cs):
+    """The fused kernel keeps its raw2ev table in one of two LDS layouts (plain / spread for dark footage, DESIGN.md 3.1);
+    either must reproduce the oracle, whatever the footage, and the automatic choice must pick the spread form for underexposed
+    frames and the plain one for the benchmark's."""
+    from mlvfs_amd.stream import to_numpy_u16
+    w, h = 272, 136
+    if kind == "low_light":
+        frames = [synth.low_light_frame(w, h, seed=3 + k) for k in range(2)]
+    elif kind == "colour_cast":
+        frames = [synth.colour_cast_frame(w, h, seed=3 + k) for k in range(2)]
+    else:
+        frames = [getattr(synth, kind + "_frame")(w, h, seed=3, frame=k) for k in range(2)]
+    want = [oracle.chroma_smooth(f.copy(), BLACK, cs) for f in frames]
+    s = make_stream(w, h)
+    packed = s.upload_packed([synth.pack_bits(f) for f in frames])
+    for layout in (1, 2, 0):
+        s.set_t16_layout(layout)
+        got = to_numpy_u16(s.process(packed, cs=cs))
+        for k in range(2):
+            assert np.array_equal(got[k], want[k]), f"layout {layout} frame {k}: {(got[k] != want[k]).sum()} px differ"
+    chosen = s.get_t16_layout()
+    if kind == "low_light":
+        assert chosen == 2
+    if kind == "normal":
+        assert chosen == 1
+    # 16-bit input path
+    unp = s.unpack(packed)
+    for layout in (1, 2):
+        s.set_t16_layout(layout)
+        got = to_numpy_u16(s.process_unpacked(unp, cs=cs))
+        for k in range(2):
+            assert np.array_equal(got[k], want[k]), f"16-bit input, layout {layout} frame {k}"
+    s.close()
+
+
 @pytest.mark.parametrize("w,h", [(48, 20), (144, 40), (1296, 520)])
 def test_tile_tickets_across_launch_sizes(torch_cuda, oracle, w, h):
     """k_frame hands out tiles by per-stream ticket counters that the last workgroup of a launch zeroes (DESIGN.md 3.1,
