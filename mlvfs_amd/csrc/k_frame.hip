@@ -60,6 +60,7 @@ constexpr int STRIP = 4;                // cells per thread in the median phase
 constexpr int GROUPS = TCW / 8;         // full items per plane row (8)
 constexpr int N_FULL = PH * GROUPS;     // 160 full items per tile  (threads 0..159)
 constexpr int N_ITEMS = N_FULL + PH;    // + 20 edge items = 180    (threads 160..179)
+constexpr int DARK_ITEMS_MIN = 16;        // of 180 loader items
 constexpr int PMAP_WORDS = 256;         // tiles per frame covered by the LDS patch bitmap: 8192 (3584x1320 has 1176)
 static_assert(N_ITEMS <= 256 && TCH * (TCW / STRIP) == 256, "one item and one strip per thread");
 
@@ -103,6 +104,7 @@ struct __align__(16) SmemT {
     uint32_t has_patch[PMAP_WORDS];     // one bit per tile of a frame: some pixel-map entry touches it (1 KiB)
     int2 ent[ENT_CAP];                  // {pos, value} of the entries that touch the current tile (staged by the loader phase)
     int next_ticket;
+    int dark_items[2];                  // loader items of the current / next tile that hold pixels at or below black (5x5 only)
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     const int k = (la << 3) | (lb << 2) | (lane & 3);
     const int j = (tid >> 6) * 4 + ((lane >> 5) << 1) + (la ^ lb ^ lc);
 
-    if (threadIdx.x == 0) sm.next_ticket = atomicAdd(&a.tickets[grp], 1);
+    if (threadIdx.x == 0) { sm.next_ticket = atomicAdd(&a.tickets[grp], 1); sm.dark_items[0] = 0; sm.dark_items[1] = 0; }
     __syncthreads();
     int t = band_start + sm.next_ticket;
     auto tile_coords = [&](int tt, int &f, int &tr, int &tx0, int &ty0) {
@@ -755,6 +757,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 #ifdef KF_DIAG_TIMES
     const uint64_t rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    int par = 0;                               // tile parity: which of the two dark_items counters this tile uses
     while (t < band_end) {
         int my_ticket = 0;
         if (threadIdx.x == 0) my_ticket = atomicAdd(&a.tickets[grp], 1);       // the tile after this one: back long before it is needed
@@ -791,6 +794,10 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 odd = (int)lo <= a.black || (!PACKED && (int)hi - a.black > 16383) || (PACKED && a.black < 0);
             }
             const bool slow = __any(odd);
+            if (METHOD == 5 && SPREAD && slow) {
+                const unsigned long long who = __ballot(odd);
+                if (lane == 0) atomicAdd(&sm.dark_items[par], __popcll(who));
+            }
             emit_item<METHOD, Smem>(sm, a.black, slow, item_row, item_g, edge, p0, p1);
         }
         if (tile_patched && pend - pbeg <= ENT_CAP && tid < pend - pbeg) {
@@ -830,7 +837,12 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         if (METHOD != 0 && y >= 4 && y < a.h - 5) {
             int mr[STRIP], mb[STRIP];
             if (METHOD == 5) {
-                if (__any(strip_median25_packed(sm.dr, sm.db, j, STRIP * k, mr, mb))) {      // wave-uniform, rare
+                // Deep shadows (EVs of neighbouring small integers are more than the packed window apart) would fail the packed
+                // attempt in nearly every wave: tiles with many items at or below black go to the 32-bit networks directly
+                // (dark clips only, i.e. the SPREAD instantiation: the plain one stays as it is)
+                const bool direct32 = SPREAD && __builtin_amdgcn_readfirstlane(sm.dark_items[par]) >= DARK_ITEMS_MIN;
+                if (SPREAD && tid == 0) sm.dark_items[par ^ 1] = 0;
+                if (direct32 || __any(strip_median25_packed(sm.dr, sm.db, j, STRIP * k, mr, mb))) {      // wave-uniform, rare
                     // opaque zero: without it the compiler shares the plane loads of both paths and keeps all 80
                     // 32-bit values alive across the packed networks (spills)
                     int z = 0;
@@ -897,6 +909,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         }
         lds_barrier();                       // all strips done with the planes before the next tile's loader
         t = t_next;
+        if (SPREAD) par ^= 1;
     }
     if (threadIdx.x == 0 && atomicAdd(&a.tickets[a.groups], 1) == (int)gridDim.x - 1) {
         for (int i = 0; i <= a.groups; i++) a.tickets[i] = 0;       // last workgroup out: ready for the next launch on this stream
