@@ -931,7 +931,11 @@ static int *ticket_counters(hipStream_t stream)
     std::lock_guard<std::mutex> lk(mu);
     int *&p = per_stream[{ dev, stream }];
     if (!p) {
-        if (hipMalloc(&p, (MAX_GROUPS + 1) * sizeof(int)) != hipSuccess || hipMemset(p, 0, (MAX_GROUPS + 1) * sizeof(int)) != hipSuccess) {
+        // zeroed ON THE LAUNCHING STREAM: the streams are non-blocking, a null-stream hipMemset is not ordered before their
+        // kernels (it once landed in the middle of the first launch, the "done" count never completed and the next launch
+        // on that stream started from stale tickets)
+        if (hipMalloc(&p, (MAX_GROUPS + 1) * sizeof(int)) != hipSuccess ||
+            hipMemsetAsync(p, 0, (MAX_GROUPS + 1) * sizeof(int), stream) != hipSuccess) {
             set_error("ticket counters: allocation failed");
             p = nullptr;
         }

@@ -1,6 +1,6 @@
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/v17
+O=$R/gpurun_out/v18
 mkdir -p $O
 cd $R
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1
