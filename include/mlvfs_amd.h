@@ -73,8 +73,12 @@ void stripes_apply_correction(struct frame_headers *frame_headers, struct stripe
 int hdr_convert_data(struct frame_headers *frame_headers, uint16_t *image_data, off_t offset, size_t max_size);
 
 /* replaces mlvfs/hdr.h:28 (hdr.c:1932-1957): full dual-ISO conversion (cr2hdr 20-bit).
- * Built so far: interp_method 1 (mean23), fullres / alias map on or off, chroma_smooth 0.
- * Other configurations report an error and return 0 (frame not converted).        */
+ * Every configuration main.c can ask for is built: interp_method 0 (AMaZE + edge-directed interpolation, --amaze-edge) and
+ * 1 (mean23), fullres / alias map on or off, chroma_smooth 0 / 2 / 3 / 5 (any other value only logs, like hdr.c:1915-1927),
+ * fix_bad_pixels_mode 0 / 1 / 2 (focus + bad pixel repair in dual-ISO mode first, hdr.c:1784-1790).  Returns 1 when the
+ * frame was converted (levels in frame_headers are then multiplied by 4, hdr.c:1949-1950), 0 when the frame is not dual ISO
+ * or cannot be converted -- a width that is not a multiple of 4 with interp_method 0 has no defined result in the
+ * reference's SSE2 AMaZE and is refused --; the frame is then left untouched.                          */
 int cr2hdr20_convert_data(struct frame_headers *frame_headers, uint16_t *image_data, int interp_method, int fullres,
                           int use_alias_map, int chroma_smooth, int fix_bad_pixels_mode);
 
@@ -120,7 +124,8 @@ const char *mlvfs_amd_version(void);
 /* per-clip artefacts: stripe coefficients + ordered pixel map.
  * A handle also owns scratch that its calls reuse (the per-frame patch lists of the pixel repair): calls on ONE handle must
  * be ordered -- issue them on one stream, or serialise them --; to process one clip on several streams at once create a
- * handle per stream and give each the same stripes / pixel map.                                                        */
+ * handle per stream and give each the same stripes / pixel map.  (The drop-in symbols of PART 1 do that themselves: the
+ * maps they cache per clip are shared read-only between libfuse's worker threads, each thread repairs into its own buffers.) */
 typedef struct mlvfs_amd_clip mlvfs_amd_clip_t;
 mlvfs_amd_clip_t *mlvfs_amd_clip_create(const mlvfs_amd_geom_t *geom);
 void   mlvfs_amd_clip_destroy(mlvfs_amd_clip_t *clip);

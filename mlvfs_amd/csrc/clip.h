@@ -29,6 +29,7 @@ struct PixEntry {
     int dep[12];    // per tap: index of the entry whose repaired value must be read, or -1
 };
 
+struct ThreadCtx;
 struct Clip {
     Geom g{};
     int pan_x = 0, pan_y = 0;
@@ -60,6 +61,9 @@ struct Clip {
     int ensure_unpacked(size_t bytes);
     int detect_bad_pixels(const void *d_frame, int aggressive, int dual_iso, hipStream_t stream);
     int fix_pixels(void *d_frames, size_t stride, int nframes, hipStream_t stream);
+    // one frame, for callers that SHARE this clip between host threads (drop-in path): nothing of the clip is written --
+    // the patch list lives in the calling thread's context, the black level is the frame's
+    int fix_pixels_shared(void *d_frame, size_t stride, int black, ThreadCtx *c) const;
     int stripes_compute(const void *d_frame, int frame_size, int rand_mode, hipStream_t stream);
 };
 
@@ -81,7 +85,7 @@ struct StripesWork {
 
 // device-level pixel repair shared by the drop-in symbols and the dual-ISO path (dropin.cpp)
 struct ThreadCtx;
-Clip *focus_clip_for(struct frame_headers *fh, ThreadCtx *c, int dual_iso);
+bool focus_map_applies(struct frame_headers *fh, ThreadCtx *c, int dual_iso);      // a map file exists and has entries for this frame
 int focus_pixels_device(struct frame_headers *fh, ThreadCtx *c, void *d_frame, int dual_iso, bool *changed);
 int bad_pixels_device(struct frame_headers *fh, ThreadCtx *c, void *d_frame, int aggressive, int dual_iso, bool *changed);
 

@@ -73,8 +73,16 @@ struct ThreadCtx {         // one per (host thread, device)
     size_t cap_a = 0, cap_b = 0;
     void *h_pin = nullptr;
     size_t cap_pin = 0;
+    void *d_patch = nullptr;             // this thread's patch list for pixel maps shared between threads (Clip::fix_pixels_shared)
+    size_t cap_patch = 0;
     int ensure(size_t need_a, size_t need_b);
+    int ensure_patch(size_t need);
+    ~ThreadCtx();
 };
+
+// what the library keeps per (device, stream) -- the fused kernel's ticket counters -- is dropped with the stream
+// (k_frame.hip); call before destroying a stream the library created
+void release_stream_state(int device, hipStream_t stream);
 
 // returns nullptr (and sets the error string) on failure
 ThreadCtx *thread_ctx();

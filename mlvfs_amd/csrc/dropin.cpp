@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -68,11 +69,26 @@ int download(ThreadCtx *c, void *host, const void *dev, size_t bytes)
 }
 
 // ---- per-clip caches of the reference (cs.c:215-217, 333-334) ---------------
+// A map is the list of sensor coordinates; what the kernels need (dependency levels, per-tile lists: a Clip) is DERIVED from it
+// per (device, crop, dual-ISO mode) and never changed afterwards, so that the worker threads that serve frames of one clip
+// can share it: each thread launches on its own stream with its own patch buffer (ThreadCtx), the derived Clip is read-only.
+// shared_ptr: a slot recycled (or free_focus_pixel_maps) while another thread still holds the Clip must not free it.
+using ClipRef = std::shared_ptr<Clip>;
+
+std::string derived_key(const FrameView &v, const ThreadCtx *c, int dual_iso)
+{
+    char key[128];
+    snprintf(key, sizeof key, "%d:%dx%d:%d,%d:%d", c->dev->id, v.w, v.h, v.pan_x, v.pan_y, dual_iso);
+    return key;
+}
+
 struct BadMap {
     uint64_t guid = 0;
     int aggressive = 0;
-    int w = 0, h = 0, dual_iso = -1;
-    Clip *clip = nullptr;
+    int w = 0, h = 0;
+    bool valid = false;
+    std::vector<int32_t> xy;                 // sensor coordinates (crop offsets included), list order = application order
+    std::map<std::string, ClipRef> clips;
 };
 constexpr int BAD_PIXEL_MAP_COUNT = 8;
 BadMap g_bad_maps[BAD_PIXEL_MAP_COUNT];
@@ -83,7 +99,7 @@ struct FocusMap {
     uint32_t camera;
     int raw_w, raw_h;
     std::vector<int32_t> xy;             // as read from the .fpm file
-    std::map<std::string, Clip *> clips; // per frame geometry / crop / mode
+    std::map<std::string, ClipRef> clips; // per device / frame geometry / crop / mode
 };
 std::vector<FocusMap *> g_focus_maps;
 std::mutex g_focus_mutex;
@@ -161,35 +177,44 @@ int bad_pixels_device(struct frame_headers *fh, ThreadCtx *c, void *d_frame, int
     if (changed) *changed = false;
     if (v.black > 16384) { fprintf(stderr, "Black level too large for processing\n"); return MLVFS_AMD_OK; }
     const size_t bytes = (size_t)v.w * v.h * 2;
-    std::lock_guard<std::mutex> lk(g_bad_mutex);
-
-    BadMap *map = nullptr;
-    for (int i = 0; i < BAD_PIXEL_MAP_COUNT; i++)                                    // cs.c:233-239
-        if (v.guid && v.guid == g_bad_maps[i].guid && aggressive == g_bad_maps[i].aggressive && g_bad_maps[i].clip &&
-            g_bad_maps[i].w == v.w && g_bad_maps[i].h == v.h && g_bad_maps[i].clip->device == c->dev->id)
-            map = &g_bad_maps[i];
-    if (!map) {
-        map = &g_bad_maps[g_bad_next];
-        g_bad_next = (g_bad_next + 1) % BAD_PIXEL_MAP_COUNT;
-        delete map->clip;
-        map->clip = make_clip(v, c);
-        map->guid = v.guid; map->aggressive = aggressive; map->w = v.w; map->h = v.h; map->dual_iso = dual_iso;
-        int rc = map->clip->detect_bad_pixels(d_frame, aggressive, dual_iso, c->stream);
-        if (rc) return rc;
-        const int crop_x = (v.pan_x + 7) & ~7, crop_y = v.pan_y & ~1;
-        const size_t n = map->clip->xy.size() / 2;
-        printf("%zu bad pixels found for %llx (crop: %d, %d):\n", n, (unsigned long long)v.guid, crop_x, crop_y);   // cs.c:307-311
-        for (size_t m = 0; m < n; m++) printf("%d %d\n", map->clip->xy[2 * m], map->clip->xy[2 * m + 1]);
-    } else if (map->dual_iso != dual_iso) {
-        std::vector<int32_t> xy = map->clip->xy;
-        map->clip->pan_x = v.pan_x; map->clip->pan_y = v.pan_y;
-        int rc = map->clip->set_pixel_map(xy.data(), xy.size() / 2, 0, dual_iso);
-        if (rc) return rc;
-        map->dual_iso = dual_iso;
+    ClipRef clip;
+    {
+        // held over the detection: the other workers of this clip wait for the map instead of detecting it again
+        std::lock_guard<std::mutex> lk(g_bad_mutex);
+        BadMap *map = nullptr;
+        for (int i = 0; i < BAD_PIXEL_MAP_COUNT; i++)                                // cs.c:233-239
+            if (g_bad_maps[i].valid && v.guid && v.guid == g_bad_maps[i].guid && aggressive == g_bad_maps[i].aggressive &&
+                g_bad_maps[i].w == v.w && g_bad_maps[i].h == v.h)
+                map = &g_bad_maps[i];
+        const std::string key = derived_key(v, c, dual_iso);
+        if (!map) {
+            map = &g_bad_maps[g_bad_next];
+            g_bad_next = (g_bad_next + 1) % BAD_PIXEL_MAP_COUNT;
+            *map = BadMap();
+            clip.reset(make_clip(v, c));
+            int rc = clip->detect_bad_pixels(d_frame, aggressive, dual_iso, c->stream);
+            if (rc) return rc;
+            map->guid = v.guid; map->aggressive = aggressive; map->w = v.w; map->h = v.h;
+            map->xy = clip->xy;
+            map->clips[key] = clip;
+            map->valid = true;
+            const int crop_x = (v.pan_x + 7) & ~7, crop_y = v.pan_y & ~1;
+            const size_t n = map->xy.size() / 2;
+            printf("%zu bad pixels found for %llx (crop: %d, %d):\n", n, (unsigned long long)v.guid, crop_x, crop_y);   // cs.c:307-311
+            for (size_t m = 0; m < n; m++) printf("%d %d\n", map->xy[2 * m], map->xy[2 * m + 1]);
+        } else {
+            ClipRef &slot = map->clips[key];
+            if (!slot) {                            // this crop / mode / device for the first time: derive, then never change
+                ClipRef fresh(make_clip(v, c));
+                int rc = fresh->set_pixel_map(map->xy.data(), map->xy.size() / 2, 0, dual_iso);
+                if (rc) { map->clips.erase(key); return rc; }
+                slot = fresh;
+            }
+            clip = slot;
+        }
     }
-    if (map->clip->n_entries == 0) return MLVFS_AMD_OK;                              // nothing to repair
-    map->clip->g.black = v.black;
-    int rc = map->clip->fix_pixels(d_frame, bytes, 1, c->stream);
+    if (clip->n_entries == 0) return MLVFS_AMD_OK;                                   // nothing to repair
+    int rc = clip->fix_pixels_shared(d_frame, bytes, v.black, c);
     if (rc == MLVFS_AMD_OK && changed) *changed = true;
     return rc;
 }
@@ -215,21 +240,8 @@ static FocusMap *load_focus_map(uint32_t camera, int raw_w, int raw_h)          
     return m;
 }
 
-// returns OK with *have_map = false when there is no map for this camera (nothing to do, nothing staged)
-int focus_pixels_device(struct frame_headers *fh, ThreadCtx *c, void *d_frame, int dual_iso, bool *changed)
-{
-    const FrameView v = view_of(fh);
-    if (changed) *changed = false;
-    Clip *clip = focus_clip_for(fh, c, dual_iso);
-    if (!clip || clip->n_entries == 0) return MLVFS_AMD_OK;
-    clip->g.black = v.black;
-    int rc = clip->fix_pixels(d_frame, (size_t)v.w * v.h * 2, 1, c->stream);
-    if (rc == MLVFS_AMD_OK && changed) *changed = true;
-    return rc;
-}
-
-// the clip (pixel map) for this frame's camera / geometry, or nullptr when no .fpm file exists
-Clip *focus_clip_for(struct frame_headers *fh, ThreadCtx *c, int dual_iso)
+// the clip (pixel map) for this frame's camera / geometry, or null when no .fpm file exists
+static ClipRef focus_clip_ref(struct frame_headers *fh, ThreadCtx *c, int dual_iso)
 {
     const FrameView v = view_of(fh);
     const uint32_t camera = fh->idnt_hdr.cameraModel;
@@ -241,14 +253,31 @@ Clip *focus_clip_for(struct frame_headers *fh, ThreadCtx *c, int dual_iso)
     if (!fm) fm = load_focus_map(camera, raw_w, raw_h);
     if (fm->xy.empty()) return nullptr;                                              // no map for this camera: no-op
     if (v.black > 16384) { fprintf(stderr, "raw2ev LUT error\n"); return nullptr; }
-    char key[128];
-    snprintf(key, sizeof key, "%d:%dx%d:%d,%d:%d", c->dev->id, v.w, v.h, v.pan_x, v.pan_y, dual_iso);
-    Clip *&clip = fm->clips[key];
-    if (!clip) {
-        clip = make_clip(v, c);
-        if (clip->set_pixel_map(fm->xy.data(), fm->xy.size() / 2, 1, dual_iso)) return nullptr;
+    const std::string key = derived_key(v, c, dual_iso);
+    ClipRef &slot = fm->clips[key];
+    if (!slot) {
+        ClipRef fresh(make_clip(v, c));
+        if (fresh->set_pixel_map(fm->xy.data(), fm->xy.size() / 2, 1, dual_iso)) { fm->clips.erase(key); return nullptr; }
+        slot = fresh;
     }
-    return clip;
+    return slot;
+}
+
+bool focus_map_applies(struct frame_headers *fh, ThreadCtx *c, int dual_iso)
+{
+    ClipRef clip = focus_clip_ref(fh, c, dual_iso);
+    return clip && clip->n_entries != 0;
+}
+
+int focus_pixels_device(struct frame_headers *fh, ThreadCtx *c, void *d_frame, int dual_iso, bool *changed)
+{
+    const FrameView v = view_of(fh);
+    if (changed) *changed = false;
+    ClipRef clip = focus_clip_ref(fh, c, dual_iso);
+    if (!clip || clip->n_entries == 0) return MLVFS_AMD_OK;
+    int rc = clip->fix_pixels_shared(d_frame, (size_t)v.w * v.h * 2, v.black, c);
+    if (rc == MLVFS_AMD_OK && changed) *changed = true;
+    return rc;
 }
 
 }  // namespace mlv
@@ -278,8 +307,7 @@ void fix_focus_pixels(struct frame_headers *fh, uint16_t *image_data, int dual_i
         if (!probe) return;
         c = probe;
     }
-    Clip *clip = focus_clip_for(fh, c, dual_iso);
-    if (!clip || clip->n_entries == 0) return;
+    if (!focus_map_applies(fh, c, dual_iso)) return;
     const size_t bytes = (size_t)fh->rawi_hdr.xRes * fh->rawi_hdr.yRes * 2;
     if (upload(c, image_data, bytes)) return;
     bool changed = false;
@@ -292,14 +320,11 @@ void free_focus_pixel_maps(void)                                                
     LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     {
         std::lock_guard<std::mutex> lk(g_focus_mutex);
-        for (FocusMap *m : g_focus_maps) {
-            for (auto &kv : m->clips) delete kv.second;
-            delete m;
-        }
+        for (FocusMap *m : g_focus_maps) delete m;               // derived clips: freed with their last user
         g_focus_maps.clear();
     }
     std::lock_guard<std::mutex> lk(g_bad_mutex);
-    for (auto &bm : g_bad_maps) { delete bm.clip; bm = BadMap(); }
+    for (auto &bm : g_bad_maps) bm = BadMap();
 }
 
 // ============================================================== stripes.h

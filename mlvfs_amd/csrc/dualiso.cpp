@@ -68,21 +68,36 @@ static HostLut g_lut_interp, g_lut_mix, g_lut_blend, g_lut_amaze;
 static HostCurves g_curves;
 static std::vector<double> g_evf;        // raw2evf_base: log2(i) * 32768, i = 0 gives -inf (main.c:136-148)
 
+// Device copies are IMMUTABLE once uploaded: conversions of other threads that took the pointers (and released the lock) may
+// still have kernels queued on their own streams, so a table whose host version changed (another clip's black level) goes to
+// a fresh allocation and the old one is retired; retired sets are freed, after a device-wide synchronisation, once more than
+// a handful have piled up (two clips with different black levels served alternately) or on mlvfs_amd_dualiso_reset().
 struct DeviceTables {            // per device copies + the host version they mirror
     int *raw2ev[4] = { nullptr, nullptr, nullptr, nullptr }, *ev2raw[4] = { nullptr, nullptr, nullptr, nullptr };
     unsigned ver[4] = { 0, 0, 0, 0 };
     double *fullres = nullptr, *log2sig = nullptr, *evf = nullptr;
     unsigned curves_ver = 0;
+    std::vector<void *> retired;
+    void retire(void *p)
+    {
+        if (!p) return;
+        retired.push_back(p);
+        if (retired.size() > 16) {
+            (void)hipDeviceSynchronize();
+            for (void *q : retired) (void)hipFree(q);
+            retired.clear();
+        }
+    }
 };
 static std::map<int, DeviceTables> g_dev_tables;
 
 static int upload_lut(DeviceTables &T, int k, const HostLut &H)
 {
     if (T.ver[k] == H.version && T.raw2ev[k]) return MLVFS_AMD_OK;
-    if (!T.raw2ev[k]) {
-        MLV_HIP(hipMalloc(&T.raw2ev[k], sizeof(int) * N20));
-        MLV_HIP(hipMalloc(&T.ev2raw[k], sizeof(int) * 24 * EVR));
-    }
+    T.retire(T.raw2ev[k]); T.retire(T.ev2raw[k]);
+    T.raw2ev[k] = T.ev2raw[k] = nullptr;
+    MLV_HIP(hipMalloc(&T.raw2ev[k], sizeof(int) * N20));
+    MLV_HIP(hipMalloc(&T.ev2raw[k], sizeof(int) * 24 * EVR));
     MLV_HIP(hipMemcpy(T.raw2ev[k], H.raw2ev.data(), sizeof(int) * N20, hipMemcpyHostToDevice));
     MLV_HIP(hipMemcpy(T.ev2raw[k], H.ev2raw.data(), sizeof(int) * 24 * EVR, hipMemcpyHostToDevice));
     T.ver[k] = H.version;
@@ -128,10 +143,10 @@ static int prepare_tables(int device, int black, int white, int interp_method, D
         g_curves.version++;
     }
     if (T.curves_ver != g_curves.version || !T.fullres) {
-        if (!T.fullres) {
-            MLV_HIP(hipMalloc(&T.fullres, sizeof(double) * N20));
-            MLV_HIP(hipMalloc(&T.log2sig, sizeof(double) * N20));
-        }
+        T.retire(T.fullres); T.retire(T.log2sig);
+        T.fullres = T.log2sig = nullptr;
+        MLV_HIP(hipMalloc(&T.fullres, sizeof(double) * N20));
+        MLV_HIP(hipMalloc(&T.log2sig, sizeof(double) * N20));
         MLV_HIP(hipMemcpy(T.fullres, g_curves.fullres.data(), sizeof(double) * N20, hipMemcpyHostToDevice));
         MLV_HIP(hipMemcpy(T.log2sig, g_curves.log2sig.data(), sizeof(double) * N20, hipMemcpyHostToDevice));
         T.curves_ver = g_curves.version;
@@ -148,6 +163,9 @@ static int prepare_tables(int device, int black, int white, int interp_method, D
 struct DiWork {
     void *base = nullptr;
     size_t cap = 0;
+    DiWork() = default;
+    DiWork(const DiWork &) = delete;
+    ~DiWork() { if (base) (void)hipFree(base); }             // with the host thread that owned it
     int ensure(size_t bytes)
     {
         if (bytes <= cap) return MLVFS_AMD_OK;
@@ -162,6 +180,9 @@ static thread_local std::map<int, DiWork> t_work;
 struct PinnedWork {              // page-locked host landing zone for the summaries the host decisions read
     void *base = nullptr;
     size_t cap = 0;
+    PinnedWork() = default;
+    PinnedWork(const PinnedWork &) = delete;
+    ~PinnedWork() { if (base) (void)hipHostFree(base); }
     int ensure(size_t bytes)
     {
         if (bytes <= cap) return MLVFS_AMD_OK;

@@ -922,14 +922,16 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 // ---------------------------------------------------------------- host launcher
 // zeroed counters per stream (launches on one stream run one after the other and leave the counters zeroed)
 constexpr int MAX_GROUPS = 1024;
+namespace {
+std::mutex g_ticket_mu;
+std::map<std::pair<int, hipStream_t>, int *> g_tickets;
+}
 static int *ticket_counters(hipStream_t stream)
 {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, int *> per_stream;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    int *&p = per_stream[{ dev, stream }];
+    std::lock_guard<std::mutex> lk(g_ticket_mu);
+    int *&p = g_tickets[{ dev, stream }];
     if (!p) {
         // zeroed ON THE LAUNCHING STREAM: the streams are non-blocking, a null-stream hipMemset is not ordered before their
         // kernels (it once landed in the middle of the first launch, the "done" count never completed and the next launch
@@ -937,10 +939,23 @@ static int *ticket_counters(hipStream_t stream)
         if (hipMalloc(&p, (MAX_GROUPS + 1) * sizeof(int)) != hipSuccess ||
             hipMemsetAsync(p, 0, (MAX_GROUPS + 1) * sizeof(int), stream) != hipSuccess) {
             set_error("ticket counters: allocation failed");
-            p = nullptr;
+            if (p) (void)hipFree(p);
+            g_tickets.erase({ dev, stream });
+            return nullptr;
         }
     }
     return p;
+}
+// The streams this library creates (per host thread, per host pipeline) give their counters back when they are destroyed: a
+// recycled stream handle then starts from freshly zeroed counters instead of whatever an aborted launch left behind, and
+// retired worker threads leak nothing.  Streams the caller owns keep their 4 KiB until the process ends.
+void release_stream_state(int device, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(g_ticket_mu);
+    auto it = g_tickets.find({ device, stream });
+    if (it == g_tickets.end()) return;
+    if (it->second) (void)hipFree(it->second);
+    g_tickets.erase(it);
 }
 template <int METHOD, bool PACKED, bool VEC, bool SPREAD>
 static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)

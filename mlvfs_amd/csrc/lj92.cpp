@@ -32,7 +32,7 @@ bool parse(const uint8_t *d, int len, Parsed *h, const char **why)
         int i = ix;
         while (i < len - 1 && d[i] != 0xFF) i++;
         i += 2;
-        if (i >= len) return -1;
+        if (i + 1 >= len) return -1;                     // every segment that is looked at starts with a 2-byte length: d[ix], d[ix + 1]
         ix = i;
         return d[i - 1];
     };
@@ -114,6 +114,18 @@ struct Work {                              // per host thread and device, grow-o
     size_t cap_arena = 0, cap_stage = 0;
     hipStream_t sub[2] = { nullptr, nullptr };          // sub-batches alternate between two streams: uploads overlap kernels
     hipEvent_t ready = nullptr, done[2] = { nullptr, nullptr };
+    Work() = default;
+    Work(const Work &) = delete;
+    ~Work()                                             // with the host thread that owned it
+    {
+        for (int k = 0; k < 2; k++) {
+            if (sub[k]) { (void)hipStreamSynchronize(sub[k]); (void)hipStreamDestroy(sub[k]); }
+            if (done[k]) (void)hipEventDestroy(done[k]);
+        }
+        if (ready) (void)hipEventDestroy(ready);
+        if (d_arena) (void)hipFree(d_arena);
+        if (h_stage) (void)hipHostFree(h_stage);
+    }
     int ensure(size_t arena, size_t stage)
     {
         if (!ready) {

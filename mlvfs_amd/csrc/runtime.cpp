@@ -170,7 +170,26 @@ static Device *get_device(int id)
 // ------------------------------------------------------------------ thread contexts
 static std::atomic<int> g_thread_counter{0};
 static thread_local int t_device = -1;
-static thread_local std::map<int, ThreadCtx *> *t_ctxs = nullptr;
+// a host thread's contexts live as long as the thread: libfuse's loop creates and retires workers, and what a retired worker
+// held (stream, staging buffers, ticket counters of that stream) goes back when its thread_local storage is destroyed
+struct ThreadCtxs {
+    std::map<int, ThreadCtx *> m;
+    ~ThreadCtxs() { for (auto &kv : m) delete kv.second; }
+};
+static thread_local ThreadCtxs t_ctxs;
+
+ThreadCtx::~ThreadCtx()
+{
+    if (stream) {
+        (void)hipStreamSynchronize(stream);
+        release_stream_state(dev ? dev->id : 0, stream);
+        (void)hipStreamDestroy(stream);
+    }
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
+    if (d_patch) (void)hipFree(d_patch);
+    if (h_pin) (void)hipHostFree(h_pin);
+}
 
 static int visible_devices()
 {
@@ -196,9 +215,8 @@ ThreadCtx *thread_ctx()
         const char *env = getenv("MLVFS_AMD_DEVICE");
         t_device = env ? atoi(env) % n : (g_thread_counter.fetch_add(1) % n);
     }
-    if (!t_ctxs) t_ctxs = new std::map<int, ThreadCtx *>;
-    auto it = t_ctxs->find(t_device);
-    if (it != t_ctxs->end()) {
+    auto it = t_ctxs.m.find(t_device);
+    if (it != t_ctxs.m.end()) {
         if (hipSetDevice(t_device) != hipSuccess) return nullptr;
         return it->second;
     }
@@ -212,7 +230,7 @@ ThreadCtx *thread_ctx()
         delete c;
         return nullptr;
     }
-    (*t_ctxs)[t_device] = c;
+    t_ctxs.m[t_device] = c;
     return c;
 }
 
@@ -229,6 +247,17 @@ int ThreadCtx::ensure(size_t need_a, size_t need_b)
         d_b = nullptr; cap_b = 0;
         MLV_HIP(hipMalloc(&d_b, need_b));
         cap_b = need_b;
+    }
+    return MLVFS_AMD_OK;
+}
+
+int ThreadCtx::ensure_patch(size_t need)
+{
+    if (need > cap_patch) {
+        if (d_patch) { (void)hipStreamSynchronize(stream); (void)hipFree(d_patch); }
+        d_patch = nullptr; cap_patch = 0;
+        MLV_HIP(hipMalloc(&d_patch, need));
+        cap_patch = need;
     }
     return MLVFS_AMD_OK;
 }

@@ -292,3 +292,28 @@ def header_case(k: int):
     fps_override = [0.0, 0.0, 24.0, 23.976, 0.5][r(5)]
     base = [b"M27-1337", b"a", b"abc", b"/Volumes/CARD/DCIM/100EOS5D/M27-1337.MLV", b""][r(5)]
     return fh, fps_override, base
+
+
+def fnv1a(a: np.ndarray) -> str:
+    """64-bit FNV-1a over 64-bit words, 4096 lanes folded in parallel and then combined (fast enough for full-size
+    frames): the hash of tests/golden/golden.json, shared by the tests and bench.py's output check."""
+    b = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
+    pad = (-b.size) % 8
+    if pad:
+        b = np.concatenate([b, np.zeros(pad, np.uint8)])
+    w = b.view(np.uint64)
+    h = np.uint64(0xCBF29CE484222325)
+    prime = np.uint64(0x100000001B3)
+    lanes = 4096
+    n = (w.size + lanes - 1) // lanes * lanes
+    ww = np.zeros(n, np.uint64)
+    ww[: w.size] = w
+    ww = ww.reshape(-1, lanes)
+    acc = np.full(lanes, h, np.uint64)
+    with np.errstate(over="ignore"):
+        for row in ww:
+            acc = (acc ^ row) * prime
+        out = h
+        for v in acc:
+            out = (out ^ v) * prime
+    return f"{int(out):016x}"

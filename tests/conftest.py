@@ -53,26 +53,4 @@ def gpu(amd):
     return amd
 
 
-def fnv1a(a: np.ndarray) -> str:
-    """64-bit FNV-1a over 64-bit words (fast enough for full-size frames)."""
-    b = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
-    pad = (-b.size) % 8
-    if pad:
-        b = np.concatenate([b, np.zeros(pad, np.uint8)])
-    w = b.view(np.uint64)
-    h = np.uint64(0xCBF29CE484222325)
-    prime = np.uint64(0x100000001B3)
-    # fold 4096 lanes in parallel, then combine: deterministic and vectorised
-    lanes = 4096
-    n = (w.size + lanes - 1) // lanes * lanes
-    ww = np.zeros(n, np.uint64)
-    ww[: w.size] = w
-    ww = ww.reshape(-1, lanes)
-    acc = np.full(lanes, h, np.uint64)
-    with np.errstate(over="ignore"):
-        for row in ww:
-            acc = (acc ^ row) * prime
-        out = h
-        for v in acc:
-            out = (out ^ v) * prime
-    return f"{int(out):016x}"
+from mlvfs_amd.synth import fnv1a  # noqa: E402,F401  (kept importable from conftest: tests/golden/make_golden.py)

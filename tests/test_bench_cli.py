@@ -1,0 +1,99 @@
+"""bench.py's command line: `--gpus N` starts its own ranks (BASELINE.json configs[4]).
+
+CPU part: the argument / environment logic that runs before anything touches the GPU.
+GPU part: (a) on any box, a two-rank REHEARSAL of the whole multi-rank control flow (gloo, both ranks on
+device 0: the one-GPU box has one card) started by `python bench.py --gpus 2` itself; (b) where two devices
+exist, the row-sharded first-frame stripes histogram over RCCL (backend "nccl") with world size 2 against the
+oracle's coefficients (stripes.c:143-248)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def test_gpus_must_agree_with_world_size():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "disagrees with WORLD_SIZE" in r.stderr and r.stdout == ""
+
+
+def test_parent_spawns_ranks_and_relays_their_failure():
+    """Without a GPU the ranks cannot run: the parent must still be the one that started them (torchrun's own
+    failure report names bench.py), print no result line and return a failure code -- never a silent n_gpus: 1."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--frames-per-step", "2",
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert '"metric"' not in r.stdout
+    assert "bench.py" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_starts_two_ranks_rehearsal(gpu):
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["full_size"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MLVFS_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames-per-step", "4",
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "frames x2"
+    # the row-sharded histogram over two ranks gives the single-process coefficients (= the reference's)
+    assert res["config"]["stripe_coeffs"] == golden["B_cs5_badpix_stripes_coeffs"]
+    assert res["parity"]["ok"] is True and res["parity"]["hashes"] == res["parity"]["reference"]
+    assert res["roofline"]["frac"] and res["value"] > 0
+
+
+def _nccl_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
+    from mlvfs_amd import dist as mdist, synth
+    from mlvfs_amd.stream import ClipStream
+    w, h = 640, 402
+    s = ClipStream(w, h, 14, synth.BLACK, synth.WHITE, device=rank)
+    f = synth.normal_frame(w, h)
+    frame = torch.from_numpy(f.view(np.int16)).to(f"cuda:{rank}")
+    count_rows, hist_rows = mdist.gpu_callbacks(s, frame)
+    hist, num, calls = mdist.sharded_stripes_histogram(count_rows, hist_rows, h, torch.device(f"cuda:{rank}"))
+    needed, co = mdist.solve_coefficients(hist, num, s.frame_size)
+    q.put((rank, int(needed), [int(c) for c in co], int(calls), int(num.sum().item())))
+    dist.barrier()
+    dist.destroy_process_group()
+    s.close()
+
+
+@pytest.mark.gpu
+def test_row_sharded_stripes_over_rccl_world2(gpu, oracle):
+    if gpu.mlvfs_amd_device_count() < 2:
+        pytest.skip("needs two HIP devices (the multi-GPU node); the control flow is covered by the rehearsal test "
+                    "above and by tests/test_dist.py over gloo")
+    import torch.multiprocessing as mp
+    from mlvfs_amd import synth
+    w, h = 640, 402
+    want_needed, want_co, hist, num = oracle.stripes_compute(synth.normal_frame(w, h), synth.BLACK, synth.WHITE, want_hist=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, needed, co, calls, nsum in res:
+        assert needed == want_needed and co == [int(c) for c in want_co]
+        assert calls == int(num.sum()) == nsum
