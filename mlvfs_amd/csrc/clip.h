@@ -11,15 +11,19 @@ namespace mlv {
 
 // tile geometry of the fused kernel (k_frame.hip); the per-tile patch lists are built
 // on the host with the same numbers
-constexpr int FRAME_TCW = 64, FRAME_TCH = 16, FRAME_HC = 2;
+// Two tile heights: 16 cell rows, and 15 for chroma smoothing 5x5 (its medians use one lane per row for the halo group: k_frame.hip)
+constexpr int FRAME_TCW = 64, FRAME_TCH = 16, FRAME_TCH5 = 15, FRAME_HC = 2;
+constexpr int FRAME_GEOS = 2;                                   // tile geometries: 0 = FRAME_TCH rows, 1 = FRAME_TCH5 rows
+inline int frame_tile_rows(int geo) { return geo == 1 ? FRAME_TCH5 : FRAME_TCH; }
+inline int frame_geo_of(int method) { return method == 5 ? 1 : 0; }
 inline int frame_tiles_x(int w) { return (w + 2 * FRAME_TCW - 1) / (2 * FRAME_TCW); }
-inline int frame_tiles_y(int h) { return (h + 2 * FRAME_TCH - 1) / (2 * FRAME_TCH); }
+inline int frame_tiles_y(int h, int geo) { return (h + 2 * frame_tile_rows(geo) - 1) / (2 * frame_tile_rows(geo)); }
 
 struct PatchView {            // what the fused kernel needs to apply a clip's pixel map
     const void *patches;      // int2[nframes][n_patch] {pos, value}
     int n_patch;
-    const int *tile_off;      // CSR over tiles of one frame: entries whose cell lies in the tile + halo
-    const int *tile_ent;
+    const int *tile_off[FRAME_GEOS];      // CSR over tiles of one frame, per tile geometry: entries whose cell lies in the tile + halo
+    const int *tile_ent[FRAME_GEOS];
 };
 
 struct PixEntry {
@@ -44,7 +48,11 @@ struct Clip {
     int n_entries = 0, n_levels = 0;
     PixEntry *d_entries = nullptr;
     int *d_level_off = nullptr;
-    int *d_tile_off = nullptr, *d_tile_ent = nullptr;
+    int *d_tile_off[FRAME_GEOS] = { nullptr, nullptr }, *d_tile_ent[FRAME_GEOS] = { nullptr, nullptr };
+    PatchView patch_view(const void *patches) const
+    {
+        return PatchView{ patches, n_entries, { d_tile_off[0], d_tile_off[1] }, { d_tile_ent[0], d_tile_ent[1] } };
+    }
     void *d_patches = nullptr;
     size_t patch_bytes = 0;
     void *d_scratch = nullptr;

@@ -52,17 +52,15 @@ __device__ __forceinline__ mlv_pk16 mlv_max_(mlv_pk16 a, mlv_pk16 b) { return __
 namespace mlv {
 
 constexpr int TCW = FRAME_TCW;          // tile width  in cells (64)
-constexpr int TCH = FRAME_TCH;          // tile height in cells (16)
 constexpr int HC = FRAME_HC;            // halo in cells (2)
 constexpr int PW = TCW + 2 * HC;        // plane width  (68)
-constexpr int PH = TCH + 2 * HC;        // plane height (20)
 constexpr int STRIP = 4;                // cells per thread in the median phase
 constexpr int GROUPS = TCW / 8;         // full items per plane row (8)
-constexpr int N_FULL = PH * GROUPS;     // 160 full items per tile  (threads 0..159)
-constexpr int N_ITEMS = N_FULL + PH;    // + 20 edge items = 180    (threads 160..179)
-constexpr int DARK_ITEMS_MIN = 16;        // of 180 loader items
-constexpr int PMAP_WORDS = 256;         // tiles per frame covered by the LDS patch bitmap: 8192 (3584x1320 has 1176)
-static_assert(N_ITEMS <= 256 && TCH * (TCW / STRIP) == 256, "one item and one strip per thread");
+constexpr int DARK_ITEMS_MIN = 16;      // of the loader items of a tile
+constexpr int PMAP_WORDS = 64;          // tiles per frame covered by the LDS patch bitmap: 2048 (3584x1320 has 1176 / 1232)
+// Tile height in cells: 16 rows of 16 strips fill the 256 threads; 5x5 tiles have 15 rows, the 16 lanes that this frees
+// compute the right-hand halo group of every row for the neighbour-sharing medians (strip_chain_*, below).
+constexpr int tile_rows_of(int method) { return method == 5 ? FRAME_TCH5 : FRAME_TCH; }
 
 struct FrameArgs {
     const uint8_t *src;      // packed stream or u16 frames
@@ -72,7 +70,8 @@ struct FrameArgs {
     int w, h, black, white;
     int nframes;
     int tiles_x, tiles_y;
-    const uint16_t *t16, *u16;
+    const uint16_t *t16;
+    const uint16_t *e2r;     // (uint16)(ev2raw[ev] + black), ev in [0, 14 * 32768): the output pixel by EV, one buffer look-up
     // patches: per frame `n_patch` entries {pos, value}; per-tile entry lists (CSR)
     const int2 *patches;
     int n_patch;
@@ -89,23 +88,51 @@ struct FrameArgs {
 #endif
 };
 
+// Table look-ups as buffer loads with idxen: the address unit scales the index by the descriptor's stride, no VALU address arithmetic
+// (tools/gather_probe.hip checks the semantics on gfx950).  The LLVM intrinsics are bound by name: hipcc has no builtin for
+// the struct forms, and unlike inline asm the compiler counts these loads in its s_waitcnt bookkeeping.
+typedef int mlv_i32x4 __attribute__((ext_vector_type(4)));
+__device__ unsigned short mlv_sbl_u16(mlv_i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.i16");
+__device__ __forceinline__ mlv_i32x4 table_rsrc(const void *p, unsigned stride, unsigned entries)
+{
+    const unsigned long long a = (unsigned long long)p;
+    mlv_i32x4 r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)(((unsigned)(a >> 32) & 0xFFFFu) | (stride << 16));
+    r.z = (int)entries;
+    r.w = 0x00020000;
+    return r;
+}
+constexpr int E2R_ENTRIES = 14 * MLV_EV_RES;
+
 // SPREAD: the T16 table with entry i at i + (i >> 7).  A pixel below 2^e above black uses only every 2^(13-e)-th entry, so
 // the look-ups of dark footage crowd into a few LDS banks (below 128 DN: one); the spread form puts those entries into
 // different banks for two more operations per pixel.  Chosen per clip from its first frame (launch_frame's `spread`).
-template <bool SPREAD_>
+constexpr int XCHG_WORDS = 28;          // per tile row: what the halo group lane hands to the last strip of the row (7 x 16 bytes)
+template <bool SPREAD_, int TCH_>
 struct __align__(16) SmemT {
     static constexpr bool SPREAD = SPREAD_;
+    static constexpr int TCH = TCH_;                    // tile height in cells
+    static constexpr int PH = TCH_ + 2 * HC;            // plane height
+    static constexpr int N_FULL = PH * GROUPS;          // full loader items per tile (threads 0 .. N_FULL-1)
+    static constexpr int N_ITEMS = N_FULL + PH;         // + one edge item per plane row
+    static constexpr bool CHAIN = TCH_ == FRAME_TCH5;   // the 5x5 geometry
     static constexpr int ENT_CAP = SPREAD_ ? 24 : 32;   // pixel-map entries of one tile staged in LDS (more: the unstaged path)
     uint16_t raw[2 * TCH][2 * TCW];     // interior pixels (post patch), 8 KiB
     int dr[PH][PW];                     // 5.3 KiB
     int db[PH][PW];
     int ge[TCH][TCW];                   // 4 KiB
     uint16_t t16[MLV_T16_N + (SPREAD_ ? 64 : 0)];   // mantissa-normalised raw2ev (common.h), 16 KiB
-    uint32_t has_patch[PMAP_WORDS];     // one bit per tile of a frame: some pixel-map entry touches it (1 KiB)
+    uint32_t has_patch[PMAP_WORDS];     // one bit per tile of a frame: some pixel-map entry touches it
     int2 ent[ENT_CAP];                  // {pos, value} of the entries that touch the current tile (staged by the loader phase)
+    uint32_t xchg[CHAIN ? TCH_ : 1][XCHG_WORDS];     // 5x5: sorted columns / pair list / rank window of each row's halo group
+    uint8_t fb_queue[CHAIN ? 256 : 4];  // 5x5: strips whose packed medians are not certain (row * 16 + strip), settled densely
+    int fb_count;
     int next_ticket;
     int dark_items[2];                  // loader items of the current / next tile that hold pixels at or below black (5x5 only)
 };
+static_assert(SmemT<false, FRAME_TCH>::N_ITEMS <= 256 && FRAME_TCH * (TCW / STRIP) == 256, "one item and one strip per thread");
+static_assert(SmemT<false, FRAME_TCH5>::N_ITEMS <= 256 && FRAME_TCH5 * (TCW / STRIP) + FRAME_TCH5 <= 256, "strips + one halo-group lane per row");
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
 // vector-memory counter, which would stall every wave on its own global stores (and
@@ -223,11 +250,14 @@ __device__ __forceinline__ void cell_multi_ev_fast(const uint32_t *p0, const uin
                                                    int (&ge)[NC], int (&dr)[NC], int (&db)[NC])
 {
     uint32_t fb[4 * NC], tv[4 * NC], ex[4 * NC], eb[4 * NC];
+    // float(px) - float(black) == float(px - black), exactly (integers below 2^24): v_sub_f32 issues at twice the rate of
+    // v_sub_u32 on gfx950 (tools/valu_rate2.hip: 0.45 against 0.29 per clock and SIMD)
+    const float fblack = (float)black;
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        const int px[4] = { (int)p0[2 * c], (int)p0[2 * c + 1], (int)p1[2 * c], (int)p1[2 * c + 1] };
+        const uint32_t px[4] = { p0[2 * c], p0[2 * c + 1], p1[2 * c], p1[2 * c + 1] };
 #pragma unroll
-        for (int i = 0; i < 4; i++) fb[4 * c + i] = __float_as_uint((float)(unsigned)(px[i] - black));
+        for (int i = 0; i < 4; i++) fb[4 * c + i] = __float_as_uint((float)px[i] - fblack);
     }
 #pragma unroll
     for (int i = 0; i < 4 * NC; i++) tv[i] = *(const uint16_t *)((const char *)t + t16_offset<SPREAD>(fb[i]));
@@ -282,7 +312,7 @@ __device__ __forceinline__ uint32_t group_offset(int w, int x, int y)
     return PACKED ? (px >> 4) * 28u : px * 2u;
 }
 
-template <bool PACKED>
+template <bool PACKED, int N_FULL>
 __device__ __forceinline__ void issue_item(uint32_t (&r0)[Words<PACKED>::N], uint32_t (&r1)[Words<PACKED>::N],
                                            const uint8_t *frame, int w, int h, int tx0, int ty0, int tid)
 {
@@ -365,7 +395,7 @@ __device__ __forceinline__ void fetch_rows(const uint8_t *frame, int w, int h, i
 template <int NCELL, class SM>
 __device__ __forceinline__ void store_cells(SM &sm, int black, bool slow, int r, int col0, const uint32_t *p0, const uint32_t *p1)
 {
-    const bool row_in = r >= HC && r < HC + TCH;
+    const bool row_in = r >= HC && r < HC + SM::TCH;
     if (NCELL == 8 && !slow) {                           // wave-uniform; against pairs: cs2x2 -2.5 %, cs5x5 -2 %; all eight at once: no better
 #pragma unroll
         for (int c = 0; c < 8; c += 4) {
@@ -403,7 +433,7 @@ __device__ __forceinline__ void emit_item(SM &sm, int black, bool slow, int pr, 
 {
     if (!edge) {
         if (METHOD != 0) store_cells<8, SM>(sm, black, slow, pr, HC + 8 * g, p0, p1);
-        if (pr >= HC && pr < HC + TCH) {
+        if (pr >= HC && pr < HC + SM::TCH) {
             store_raw(sm, 2 * (pr - HC), g, p0);
             store_raw(sm, 2 * (pr - HC) + 1, g, p1);
         }
@@ -424,7 +454,7 @@ __device__ __forceinline__ void apply_patches(SM &sm, const FrameArgs &a, const 
         if (e.x < 0) continue;
         const int cx = (e.x % a.w) >> 1, cy = (e.x / a.w) >> 1;
         const int i = cx - (tx0 / 2 - HC), j = cy - (ty0 / 2 - HC);
-        if (i < 0 || i >= PW || j < 0 || j >= PH) continue;
+        if (i < 0 || i >= PW || j < 0 || j >= SM::PH) continue;
         int px[4];                                              // r, g1, g2, b of that cell
 #pragma unroll
         for (int q = 0; q < 4; q++) px[q] = (int)fetch_clamped<PACKED>(frame, a.w, a.h, 2 * cx + (q & 1), 2 * cy + (q >> 1));
@@ -441,7 +471,7 @@ __device__ __forceinline__ void apply_patches(SM &sm, const FrameArgs &a, const 
             sm.db[j][i] = db;
         }
         const int ii = i - HC, jj = j - HC;
-        if (ii >= 0 && ii < TCW && jj >= 0 && jj < TCH) {
+        if (ii >= 0 && ii < TCW && jj >= 0 && jj < SM::TCH) {
             if (METHOD != 0) sm.ge[jj][ii] = ge;
             *(uint32_t *)&sm.raw[2 * jj][2 * ii] = (uint32_t)px[0] | ((uint32_t)px[1] << 16);
             *(uint32_t *)&sm.raw[2 * jj + 1][2 * ii] = (uint32_t)px[2] | ((uint32_t)px[3] << 16);
@@ -460,10 +490,10 @@ __device__ __forceinline__ void apply_patches_staged(SM &sm, const FrameArgs &a,
     if (e.x < 0) return;
     const int cx = e.x & 0xFFFF, cy = e.x >> 16;
     const int i = cx - (tx0 / 2 - HC), j = cy - (ty0 / 2 - HC);
-    if (i < 0 || i >= PW || j < 0 || j >= PH) return;
+    if (i < 0 || i >= PW || j < 0 || j >= SM::PH) return;
     int px[4];                                                  // r, g1, g2, b of that cell
     const int ii0 = i - HC, jj0 = j - HC;
-    if (ii0 >= 0 && ii0 < TCW && jj0 >= 0 && jj0 < TCH) {       // interior cell: its pixels are in LDS already
+    if (ii0 >= 0 && ii0 < TCW && jj0 >= 0 && jj0 < SM::TCH) {       // interior cell: its pixels are in LDS already
         const uint32_t t0 = *(const uint32_t *)&sm.raw[2 * jj0][2 * ii0], t1 = *(const uint32_t *)&sm.raw[2 * jj0 + 1][2 * ii0];
         px[0] = (int)(t0 & 0xFFFFu); px[1] = (int)(t0 >> 16); px[2] = (int)(t1 & 0xFFFFu); px[3] = (int)(t1 >> 16);
     } else {
@@ -484,7 +514,7 @@ __device__ __forceinline__ void apply_patches_staged(SM &sm, const FrameArgs &a,
         sm.db[j][i] = db;
     }
     const int ii = i - HC, jj = j - HC;
-    if (ii >= 0 && ii < TCW && jj >= 0 && jj < TCH) {
+    if (ii >= 0 && ii < TCW && jj >= 0 && jj < SM::TCH) {
         if (METHOD != 0) sm.ge[jj][ii] = ge;
         *(uint32_t *)&sm.raw[2 * jj][2 * ii] = (uint32_t)px[0] | ((uint32_t)px[1] << 16);
         *(uint32_t *)&sm.raw[2 * jj + 1][2 * ii] = (uint32_t)px[2] | ((uint32_t)px[3] << 16);
@@ -575,6 +605,147 @@ __device__ __forceinline__ bool strip_median25_packed(const int (*pr_)[PW], cons
     }
     return unknown;
 }
+
+// ---------------------------------------------------------------- 5x5 with neighbour sharing
+// A strip's window is 8 columns: its own group of four and the four of the strip to its right.  Two neighbouring strips
+// would each sort, merge and rank the same four columns; instead every lane does that for ONE group (mlv::ChainGroup: four
+// sorted columns, two pair lists, one rank window) and takes, from the lane to its right (v_mov_b32 wave_shl:1: the 16 strips of a
+// tile row sit in 16 consecutive lanes), the two sorted columns, the pair list and the rank window it needs of that lane's group
+// -- 26 values instead of 4 column sorts, 2 merges and a rank window, and half of the packing.  The group to the right of a
+// row's last strip (plane columns 64..67, the halo) is computed by a lane that has no strip (the 5x5 tile has 15 rows: lanes
+// 48..62 of the fourth wave) and handed over through LDS.
+//
+// Exactness.  Lanes pack relative to their OWN reference r (as before: saturating subtract, saturating 16-bit pack), the
+// neighbour's values arrive relative to ITS reference r' and are rebased with a saturating add of D = sat16(r' - r).  For a
+// neighbour cell x that saturated at the first stage the rebased value is not sat16(x - r), but it lies in the band of width |D|
+// at the same end of the 16-bit range as sat16(x - r) does (x - r >= 32767 + D and sat(32767 + D) >= 32767 - |D|; mirrored at
+// the low end).  So for every threshold c in [-32768 + |D|, 32766 - |D|] each window value is <= c exactly when its true
+// relative value is: the 13th smallest of the 25 is exact whenever it comes out strictly inside (-32768 + |D|, 32767 - |D|).
+// Anything else (that includes a saturated D) is "unknown" and settled by the 32-bit networks.  |D| = 0 gives the old rule.
+struct ChainGroup {
+    mlv_pk16 s[4][5];        // sorted columns
+    mlv_pk16 p0[10], p1[10]; // columns 0+1 and 2+3 merged
+    mlv_pk16 q[6];           // ranks 8..13 of the 20
+    int ref_r, ref_b;
+};
+
+__device__ __forceinline__ void chain_group(const int (*pr_)[PW], const int (*pb_)[PW], int row_top, int col_left, ChainGroup &g)
+{
+    // reference = median of three cells of the group's centre row (a single cell is, in noisy shadows, often more than 1 EV
+    // away from the median of its neighbourhood)
+    const int4 cr = *(const int4 *)&pr_[row_top + 2][col_left], cb = *(const int4 *)&pb_[row_top + 2][col_left];
+    g.ref_r = med3i(cr.y, cr.z, cr.w);
+    g.ref_b = med3i(cb.y, cb.z, cb.w);
+    auto pack = [&](int r, int b) {
+        return __builtin_amdgcn_cvt_pk_i16(__builtin_elementwise_sub_sat(r, g.ref_r), __builtin_elementwise_sub_sat(b, g.ref_b));
+    };
+    mlv_pk16 col[4][5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const int4 a = r == 2 ? cr : *(const int4 *)&pr_[row_top + r][col_left];
+        const int4 b = r == 2 ? cb : *(const int4 *)&pb_[row_top + r][col_left];
+        col[0][r] = pack(a.x, b.x); col[1][r] = pack(a.y, b.y); col[2][r] = pack(a.z, b.z); col[3][r] = pack(a.w, b.w);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) mlv_sort5(col[c], g.s[c]);
+    mlv_merge55(g.s[0], g.s[1], g.p0);
+    mlv_merge55(g.s[2], g.s[3], g.p1);
+}
+__device__ __forceinline__ void chain_group_window(ChainGroup &g) { mlv_quad_mid6(g.p0, g.p1, g.q); }
+
+// what a strip needs of the group to its right
+struct ChainNext {
+    mlv_pk16 s0[5], s2[5], p0[10], q[6];
+    int ref_r, ref_b;
+};
+// wave_shl:1 with bound_ctrl: lane i reads lane i + 1, the wave's last lane reads 0; no "old" operand, so no move to set one up
+__device__ __forceinline__ int dpp_next_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ mlv_pk16 dpp_next(mlv_pk16 v) { return __builtin_bit_cast(mlv_pk16, dpp_next_i(__builtin_bit_cast(int, v))); }
+
+// in two parts, so that the LDS reads of a row's last strip (chain_collect_*) have arithmetic to hide behind: the sorted
+// columns, the pair list and the references first, then -- after the lane's own rank window -- the neighbour's rank window
+__device__ __forceinline__ void chain_fetch_lists(const ChainGroup &g, ChainNext &n)
+{
+#pragma unroll
+    for (int i = 0; i < 5; i++) { n.s0[i] = dpp_next(g.s[0][i]); n.s2[i] = dpp_next(g.s[2][i]); }
+#pragma unroll
+    for (int i = 0; i < 10; i++) n.p0[i] = dpp_next(g.p0[i]);
+    n.ref_r = dpp_next_i(g.ref_r);
+    n.ref_b = dpp_next_i(g.ref_b);
+}
+__device__ __forceinline__ void chain_fetch_window(const ChainGroup &g, ChainNext &n)
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++) n.q[i] = dpp_next(g.q[i]);
+}
+
+// the halo group's lane -> LDS -> the row's last strip
+__device__ __forceinline__ void chain_publish(const ChainGroup &g, uint32_t *x)
+{
+    uint4 *o = (uint4 *)x;
+    auto u = [](mlv_pk16 v) { return __builtin_bit_cast(uint32_t, v); };
+    o[0] = make_uint4((uint32_t)g.ref_r, (uint32_t)g.ref_b, u(g.s[0][0]), u(g.s[0][1]));
+    o[1] = make_uint4(u(g.s[0][2]), u(g.s[0][3]), u(g.s[0][4]), u(g.s[2][0]));
+    o[2] = make_uint4(u(g.s[2][1]), u(g.s[2][2]), u(g.s[2][3]), u(g.s[2][4]));
+    o[3] = make_uint4(u(g.p0[0]), u(g.p0[1]), u(g.p0[2]), u(g.p0[3]));
+    o[4] = make_uint4(u(g.p0[4]), u(g.p0[5]), u(g.p0[6]), u(g.p0[7]));
+    o[5] = make_uint4(u(g.p0[8]), u(g.p0[9]), u(g.q[0]), u(g.q[1]));
+    o[6] = make_uint4(u(g.q[2]), u(g.q[3]), u(g.q[4]), u(g.q[5]));
+}
+__device__ __forceinline__ void chain_collect_lists(const uint32_t *x, ChainNext &n)
+{
+    const uint4 *o = (const uint4 *)x;
+    auto k = [](uint32_t v) { return __builtin_bit_cast(mlv_pk16, v); };
+    const uint4 a0 = o[0], a1 = o[1], a2 = o[2], a3 = o[3], a4 = o[4];
+    const uint2 a5 = *(const uint2 *)&o[5];
+    n.ref_r = (int)a0.x; n.ref_b = (int)a0.y;
+    n.s0[0] = k(a0.z); n.s0[1] = k(a0.w); n.s0[2] = k(a1.x); n.s0[3] = k(a1.y); n.s0[4] = k(a1.z);
+    n.s2[0] = k(a1.w); n.s2[1] = k(a2.x); n.s2[2] = k(a2.y); n.s2[3] = k(a2.z); n.s2[4] = k(a2.w);
+    n.p0[0] = k(a3.x); n.p0[1] = k(a3.y); n.p0[2] = k(a3.z); n.p0[3] = k(a3.w);
+    n.p0[4] = k(a4.x); n.p0[5] = k(a4.y); n.p0[6] = k(a4.z); n.p0[7] = k(a4.w);
+    n.p0[8] = k(a5.x); n.p0[9] = k(a5.y);
+}
+__device__ __forceinline__ void chain_collect_window(const uint32_t *x, ChainNext &n)
+{
+    auto k = [](uint32_t v) { return __builtin_bit_cast(mlv_pk16, v); };
+    const uint2 a5 = *(const uint2 *)(x + 22);
+    const uint4 a6 = *(const uint4 *)(x + 24);
+    n.q[0] = k(a5.x); n.q[1] = k(a5.y); n.q[2] = k(a6.x); n.q[3] = k(a6.y); n.q[4] = k(a6.z); n.q[5] = k(a6.w);
+}
+
+// medians of the strip's four cells from its own group and the neighbour's; true = not certain (see above)
+__device__ __forceinline__ bool chain_finish(const ChainGroup &g, ChainNext &n, int (&mr)[STRIP], int (&mb)[STRIP])
+{
+    const int dr_ = __builtin_elementwise_sub_sat(n.ref_r, g.ref_r), db_ = __builtin_elementwise_sub_sat(n.ref_b, g.ref_b);
+    const mlv_pk16 D = __builtin_amdgcn_cvt_pk_i16(dr_, db_);
+#pragma unroll
+    for (int i = 0; i < 5; i++) { n.s0[i] = __builtin_elementwise_add_sat(n.s0[i], D); n.s2[i] = __builtin_elementwise_add_sat(n.s2[i], D); }
+#pragma unroll
+    for (int i = 0; i < 10; i++) n.p0[i] = __builtin_elementwise_add_sat(n.p0[i], D);
+    mlv_pk16 q1[6];
+    mlv_quad_mid6(g.p1, n.p0, q1);
+    mlv_pk16 o[STRIP][1];
+    mlv_final6of11(g.q, n.s0, o[0]);          // window columns 0..3 | 4
+    mlv_final6of11(q1, g.s[1], o[1]);         // 2..5 | 1
+    mlv_final6of11(q1, n.s2, o[2]);           // 2..5 | 6
+#pragma unroll
+    for (int i = 0; i < 6; i++) n.q[i] = __builtin_elementwise_add_sat(n.q[i], D);     // (the neighbour's rank window is the last to arrive)
+    mlv_final6of11(n.q, g.s[3], o[3]);        // 4..7 | 3
+    // certain when strictly inside (-32768 + |D|, 32767 - |D|): v - lo <= hi - lo as unsigned, lo = -32767 + |D|, hi = 32766 - |D|
+    const int ar = (int)min((unsigned)wabs(dr_), 32767u), ab = (int)min((unsigned)wabs(db_), 32767u);
+    const int lo_r = ar - 32767, span_r = 65533 - 2 * ar, lo_b = ab - 32767, span_b = 65533 - 2 * ab;
+    bool unknown = ar >= 32767 || ab >= 32767;           // the references themselves are more than the 16-bit range apart
+#pragma unroll
+    for (int c = 0; c < STRIP; c++) {
+        const int vr = (int)o[c][0].x, vb = (int)o[c][0].y;
+        unknown |= (unsigned)(vr - lo_r) > (unsigned)span_r;
+        unknown |= (unsigned)(vb - lo_b) > (unsigned)span_b;
+        mr[c] = vr + g.ref_r;
+        mb[c] = vb + g.ref_b;
+    }
+    return unknown;
+}
+
 
 // 3x3: sorted columns of 3, classic max-of-mins / med-of-meds / min-of-maxes
 __device__ __forceinline__ void strip_median9(const int (*plane)[PW], int row_top, int col_left, int (&med)[STRIP])
@@ -673,8 +844,10 @@ __device__ __forceinline__ void stripe_strip_pk(uint32_t (&top)[STRIP], uint32_t
 template <int METHOD, bool PACKED, bool VEC, bool SPREAD>
 __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 {
-    using Smem = SmemT<SPREAD>;
+    using Smem = SmemT<SPREAD, tile_rows_of(METHOD)>;
     constexpr int ENT_CAP = Smem::ENT_CAP;
+    constexpr int TCH = Smem::TCH, N_FULL = Smem::N_FULL, N_ITEMS = Smem::N_ITEMS;
+    constexpr bool CHAIN = Smem::CHAIN;
     __shared__ Smem sm;                                  // static: a compile-time LDS base (a dynamic one costs an add per access)
 
     if (METHOD != 0) {
@@ -716,22 +889,24 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     const int black16 = (int)(uint16_t)a.black, white16 = (int)(uint16_t)a.white;
     constexpr bool vec = VEC;                            // w % 16 == 0: dword/vector loads and stores
 
+    const mlv_i32x4 rs_e2r = table_rsrc(a.e2r, 2, E2R_ENTRIES);
     constexpr int NW = Words<PACKED>::N;
     uint32_t r0[NW], r1[NW];                             // prefetch registers of this thread's item
     const int tid = threadIdx.x;
-    const bool has_item = tid < N_ITEMS;
-    const bool edge = tid >= N_FULL;
-    const int item_row = edge ? tid - N_FULL : tid >> 3, item_g = tid & 7;
+    const int item_row = tid >= N_FULL ? tid - N_FULL : tid >> 3, item_g = tid & 7;
 
     // median phase: lane -> (row, strip).  The 16 lanes that one ds_read_b128 pass serves
     // together ({0-3,12-15,20-27} / {4-11,16-19,28-31} of each half wave) share one row and
     // take its 16 strips, so their 16-byte accesses fall into 16 different bank groups.
     const int lane = tid & 63;
     const int la = (lane >> 4) & 1, lb = (lane >> 3) & 1, lc = (lane >> 2) & 1;
-    const int k = (la << 3) | (lb << 2) | (lane & 3);
-    const int j = (tid >> 6) * 4 + ((lane >> 5) << 1) + (la ^ lb ^ lc);
+    // 5x5 (neighbour sharing): the 16 strips of a row in 16 consecutive lanes, four rows per wave; the fourth wave holds rows
+    // 12..14 and, in lanes 48..62, the halo groups of rows 0..14 (lane 63 repeats row 14's).  Other methods: the conflict-free map.
+    const bool is_strip = !CHAIN || tid < TCH * 16;
+    const int k = CHAIN ? (lane & 15) : ((la << 3) | (lb << 2) | (lane & 3));
+    const int j = CHAIN ? (is_strip ? (tid >> 4) : min(tid - TCH * 16, TCH - 1)) : (tid >> 6) * 4 + ((lane >> 5) << 1) + (la ^ lb ^ lc);
 
-    if (threadIdx.x == 0) { sm.next_ticket = atomicAdd(&a.tickets[grp], 1); sm.dark_items[0] = 0; sm.dark_items[1] = 0; }
+    if (threadIdx.x == 0) { sm.next_ticket = atomicAdd(&a.tickets[grp], 1); sm.dark_items[0] = 0; sm.dark_items[1] = 0; sm.fb_count = 0; }
     __syncthreads();
     int t = band_start + sm.next_ticket;
     auto tile_coords = [&](int tt, int &f, int &tr, int &tx0, int &ty0) {
@@ -749,7 +924,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     auto issue_tile = [&](int tt) {
         int f, tr, tx0, ty0;
         tile_coords(tt, f, tr, tx0, ty0);
-        issue_item<PACKED>(r0, r1, a.src + (size_t)f * a.src_stride, a.w, a.h, tx0, ty0, load_tid);
+        issue_item<PACKED, N_FULL>(r0, r1, a.src + (size_t)f * a.src_stride, a.w, a.h, tx0, ty0, load_tid);
     };
     if (vec) issue_tile(min(t, max(total - 1, 0)));
     __syncthreads();                           // T16 copy complete
@@ -777,6 +952,13 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         }
         // ---- loader: prefetched registers -> EV planes + interior raw pixels
         __builtin_amdgcn_s_setprio(0);
+        // Lane predicates and wave-uniform switches are re-derived per tile from opaque copies: hoisted out of the loop they
+        // became 64-bit SGPR masks, two scalar registers each, of which the kernel kept more than it has -- they were spilt
+        // to VGPR lanes and came back through v_readlane, VECTOR instructions (about 40 per tile and wave).
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        const bool has_item = tid_o < N_ITEMS;
+        const bool edge = tid_o >= N_FULL;
         if (has_item) {
             uint32_t p0[16], p1[16];
             if (vec) { unpack16<PACKED>(r0, p0); unpack16<PACKED>(r1, p1); }
@@ -826,87 +1008,142 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         if (vec) issue_tile(min(t_next, band_end - 1));
 
         // ---- medians + output: one thread = 4 cells = 8 px on two rows
-        const int y = ty0 + 2 * j, x = tx0 + 2 * STRIP * k;
-        uint32_t top[STRIP], bot[STRIP];        // (R | G1<<16), (G2 | B<<16)
-        {
-            const uint4 v0 = *(const uint4 *)&sm.raw[2 * j][2 * STRIP * k];
-            const uint4 v1 = *(const uint4 *)&sm.raw[2 * j + 1][2 * STRIP * k];
-            top[0] = v0.x; top[1] = v0.y; top[2] = v0.z; top[3] = v0.w;
-            bot[0] = v1.x; bot[1] = v1.y; bot[2] = v1.z; bot[3] = v1.w;
-        }
-        if (METHOD != 0 && y >= 4 && y < a.h - 5) {
-            int mr[STRIP], mb[STRIP];
-            if (METHOD == 5) {
-                // Deep shadows (EVs of neighbouring small integers are more than the packed window apart) would fail the packed
-                // attempt in nearly every wave: tiles with many items at or below black go to the 32-bit networks directly
-                // (dark clips only, i.e. the SPREAD instantiation: the plain one stays as it is)
-                const bool direct32 = SPREAD && __builtin_amdgcn_readfirstlane(sm.dark_items[par]) >= DARK_ITEMS_MIN;
-                if (SPREAD && tid == 0) sm.dark_items[par ^ 1] = 0;
-                if (direct32 || __any(strip_median25_packed(sm.dr, sm.db, j, STRIP * k, mr, mb))) {      // wave-uniform, rare
-                    // opaque zero: without it the compiler shares the plane loads of both paths and keeps all 80
-                    // 32-bit values alive across the packed networks (spills)
-                    int z = 0;
-                    asm volatile("" : "+s"(z));
-                    strip_median25(sm.dr, j + z, STRIP * k, mr);
-                    strip_median25(sm.db, j + z, STRIP * k, mb);
-                }
-            } else if (METHOD == 3) {
-                strip_median9(sm.dr, j + 1, STRIP * k + 1, mr);
-                strip_median9(sm.db, j + 1, STRIP * k + 1, mb);
-            } else {
-                strip_median5(sm.dr, j + 1, STRIP * k + 1, mr);
-                strip_median5(sm.db, j + 1, STRIP * k + 1, mb);
+        int stripe_mode = a.stripes ? ((PACKED && a.coef_pk) ? 1 : (a.coef_fast ? 2 : 3)) : 0;      // scalar, re-read per tile (see above)
+        asm volatile("" : "+s"(stripe_mode));
+        // the rest of a strip once its medians are known: R / B replacement, stripes, store
+        auto finish_strip = [&](int jj, int kk, bool smooth, const int (&mr)[STRIP], const int (&mb)[STRIP], bool store) {
+            const int y = ty0 + 2 * jj, x = tx0 + 2 * STRIP * kk;
+            uint32_t top[STRIP], bot[STRIP];        // (R | G1<<16), (G2 | B<<16)
+            {
+                const uint4 v0 = *(const uint4 *)&sm.raw[2 * jj][2 * STRIP * kk];
+                const uint4 v1 = *(const uint4 *)&sm.raw[2 * jj + 1][2 * STRIP * kk];
+                top[0] = v0.x; top[1] = v0.y; top[2] = v0.z; top[3] = v0.w;
+                bot[0] = v1.x; bot[1] = v1.y; bot[2] = v1.z; bot[3] = v1.w;
             }
-            const int4 g4 = *(const int4 *)&sm.ge[j][STRIP * k];
-            const int gev[STRIP] = { g4.x, g4.y, g4.z, g4.w };
-            // ev2raw gathers (64 KiB table in L2): all 8 issued before the first use
-            int er[STRIP], eb[STRIP], ur[STRIP], ub[STRIP];
+            if (METHOD != 0) {
+                const int4 g4 = *(const int4 *)&sm.ge[jj][STRIP * kk];
+                const int gev[STRIP] = { g4.x, g4.y, g4.z, g4.w };
+                // the output pixel by EV (896 KiB table in L2): all 8 look-ups issued before the first use
+                int er[STRIP], eb[STRIP], ur[STRIP], ub[STRIP];
 #pragma unroll
-            for (int c = 0; c < STRIP; c++) {
-                er[c] = wadd(gev[c], mr[c]);
-                eb[c] = wadd(gev[c], mb[c]);
-                ur[c] = a.u16[min(max(er[c], 0), MLV_EV_MAX) & 32767];
-                ub[c] = a.u16[min(max(eb[c], 0), MLV_EV_MAX) & 32767];
-            }
-            asm volatile("" :: "v"(ur[0]), "v"(ur[1]), "v"(ur[2]), "v"(ur[3]), "v"(ub[0]), "v"(ub[1]), "v"(ub[2]), "v"(ub[3]));
-#pragma unroll
-            for (int c = 0; c < STRIP; c++) {
-                const int xc = x + 2 * c;
-                // chroma_smooth.c:28, 35, 64-65
-                const bool ok = xc >= 4 && xc < a.w - 4 && gev[c] >= 2 * MLV_EV_RES && er[c] > MLV_EV_RES && eb[c] > MLV_EV_RES;
-                const int qr = min(max(er[c], 0), MLV_EV_MAX) >> 15, qb = min(max(eb[c], 0), MLV_EV_MAX) >> 15;
-                const uint32_t pr_ = (uint32_t)((ur[c] >> (13 - qr)) + a.black) & 0xFFFFu;
-                const uint32_t pb_ = (uint32_t)((ub[c] >> (13 - qb)) + a.black) & 0xFFFFu;
-                top[c] = ok ? ((top[c] & 0xFFFF0000u) | pr_) : top[c];
-                bot[c] = ok ? ((bot[c] & 0x0000FFFFu) | (pb_ << 16)) : bot[c];
-            }
-        }
-        if (a.stripes) {
-            // a strip starts at an x that is a multiple of 8, so pixel n of the strip has column phase n
-            if (PACKED && a.coef_pk) stripe_strip_pk(top, bot, a.coef, black16, white16);
-            else if (a.coef_fast) stripe_strip<true>(top, bot, a.coef, black16, white16);
-            else stripe_strip<false>(top, bot, a.coef, black16, white16);
-        }
-        if (y < a.h) {
-            if (vec) {
-                if (x < a.w) {
-                    const uint32_t o = (uint32_t)y * (uint32_t)a.w + (uint32_t)x;           // < 2^28 pixels per frame
-                    *(uint4 *)(out + o) = make_uint4(top[0], top[1], top[2], top[3]);
-                    if (y + 1 < a.h) *(uint4 *)(out + o + (uint32_t)a.w) = make_uint4(bot[0], bot[1], bot[2], bot[3]);
+                for (int c = 0; c < STRIP; c++) {
+                    er[c] = wadd(gev[c], mr[c]);
+                    eb[c] = wadd(gev[c], mb[c]);
+                    ur[c] = mlv_sbl_u16(rs_e2r, min(max(er[c], 0), MLV_EV_MAX), 0, 0, 0);
+                    ub[c] = mlv_sbl_u16(rs_e2r, min(max(eb[c], 0), MLV_EV_MAX), 0, 0, 0);
                 }
-            } else {
-#pragma unroll 1
+                asm volatile("" :: "v"(ur[0]), "v"(ur[1]), "v"(ur[2]), "v"(ur[3]), "v"(ub[0]), "v"(ub[1]), "v"(ub[2]), "v"(ub[3]));
+                // chroma_smooth.c:27 leaves columns 0..3 and w-4.. alone: only the tiles at the frame's left and right margin test for that
+                const bool x_margin = tx0 < 4 || tx0 + 2 * TCW > a.w - 4;                   // scalar
+#pragma unroll
                 for (int c = 0; c < STRIP; c++) {
                     const int xc = x + 2 * c;
-                    if (xc < a.w) out[(size_t)y * a.w + xc] = (uint16_t)top[c];
-                    if (xc + 1 < a.w) out[(size_t)y * a.w + xc + 1] = (uint16_t)(top[c] >> 16);
-                    if (y + 1 < a.h) {
-                        if (xc < a.w) out[(size_t)(y + 1) * a.w + xc] = (uint16_t)bot[c];
-                        if (xc + 1 < a.w) out[(size_t)(y + 1) * a.w + xc + 1] = (uint16_t)(bot[c] >> 16);
+                    // chroma_smooth.c:28, 35, 64-65
+                    bool ok = smooth && gev[c] >= 2 * MLV_EV_RES && er[c] > MLV_EV_RES && eb[c] > MLV_EV_RES;
+                    if (x_margin) ok = ok && xc >= 4 && xc < a.w - 4;
+                    const uint32_t pr_ = (uint32_t)ur[c], pb_ = (uint32_t)ub[c];
+                    top[c] = ok ? ((top[c] & 0xFFFF0000u) | pr_) : top[c];
+                    bot[c] = ok ? ((bot[c] & 0x0000FFFFu) | (pb_ << 16)) : bot[c];
+                }
+            }
+            if (stripe_mode != 0) {
+                // a strip starts at an x that is a multiple of 8, so pixel n of the strip has column phase n
+                int co[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) { co[i] = a.coef[i]; asm volatile("" : "+s"(co[i])); }
+                if (stripe_mode == 1) stripe_strip_pk(top, bot, co, black16, white16);
+                else if (stripe_mode == 2) stripe_strip<true>(top, bot, co, black16, white16);
+                else stripe_strip<false>(top, bot, co, black16, white16);
+            }
+            if (store && y < a.h) {
+                if (vec) {
+                    if (x < a.w) {
+                        const uint32_t o = (uint32_t)y * (uint32_t)a.w + (uint32_t)x;           // < 2^28 pixels per frame
+                        *(uint4 *)(out + o) = make_uint4(top[0], top[1], top[2], top[3]);
+                        if (y + 1 < a.h) *(uint4 *)(out + o + (uint32_t)a.w) = make_uint4(bot[0], bot[1], bot[2], bot[3]);
+                    }
+                } else {
+#pragma unroll 1
+                    for (int c = 0; c < STRIP; c++) {
+                        const int xc = x + 2 * c;
+                        if (xc < a.w) out[(size_t)y * a.w + xc] = (uint16_t)top[c];
+                        if (xc + 1 < a.w) out[(size_t)y * a.w + xc + 1] = (uint16_t)(top[c] >> 16);
+                        if (y + 1 < a.h) {
+                            if (xc < a.w) out[(size_t)(y + 1) * a.w + xc] = (uint16_t)bot[c];
+                            if (xc + 1 < a.w) out[(size_t)(y + 1) * a.w + xc + 1] = (uint16_t)(bot[c] >> 16);
+                        }
                     }
                 }
             }
+        };
+        const int y = ty0 + 2 * j;
+        const bool smooth_row = METHOD != 0 && y >= 4 && y < a.h - 5;                       // chroma_smooth.c:25
+        int mr[STRIP] = { 0, 0, 0, 0 }, mb[STRIP] = { 0, 0, 0, 0 };
+        if (CHAIN) {
+            // Deep shadows (EVs of neighbouring small integers are more than the packed window apart) would fail the packed
+            // attempt almost everywhere: tiles with many items at or below black go to the 32-bit networks directly
+            // (dark clips only, i.e. the SPREAD instantiation)
+            const bool direct32 = SPREAD && __builtin_amdgcn_readfirstlane(sm.dark_items[par]) >= DARK_ITEMS_MIN;
+            if (SPREAD && tid == 0) sm.dark_items[par ^ 1] = 0;
+            if (direct32) {                                            // the same for every wave of the workgroup
+                if (is_strip) {
+                    if (smooth_row) {
+                        strip_median25(sm.dr, j, STRIP * k, mr);
+                        strip_median25(sm.db, j, STRIP * k, mb);
+                    }
+                    finish_strip(j, k, smooth_row, mr, mb, true);
+                }
+            } else {
+                ChainGroup g;
+                chain_group(sm.dr, sm.db, j, is_strip ? STRIP * k : TCW, g);          // a strip's own group, or a row's halo group
+                const bool halo_wave = tid >= 192;                     // the wave that holds the halo groups' lanes (uniform)
+                if (halo_wave) {
+                    chain_group_window(g);
+                    if (!is_strip) chain_publish(g, sm.xchg[j]);
+                }
+                lds_barrier();                                         // the halo groups are in LDS
+                ChainNext n;
+                chain_fetch_lists(g, n);
+                if (k == 15) chain_collect_lists(sm.xchg[j], n);       // (lanes without a strip read a row's record too: harmless)
+                if (!halo_wave) chain_group_window(g);                 // the lane's own rank window, while those reads are under way
+                chain_fetch_window(g, n);
+                if (k == 15) chain_collect_window(sm.xchg[j], n);
+                bool unknown = chain_finish(g, n, mr, mb);
+                unknown = unknown && is_strip && smooth_row;
+                if (unknown) sm.fb_queue[atomicAdd(&sm.fb_count, 1)] = (uint8_t)(j * 16 + k);      // settled below, densely
+                if (is_strip) finish_strip(j, k, smooth_row, mr, mb, !unknown);
+            }
+        } else {
+            if (smooth_row) {
+                if (METHOD == 3) {
+                    strip_median9(sm.dr, j + 1, STRIP * k + 1, mr);
+                    strip_median9(sm.db, j + 1, STRIP * k + 1, mb);
+                } else if (METHOD == 2) {
+                    strip_median5(sm.dr, j + 1, STRIP * k + 1, mr);
+                    strip_median5(sm.db, j + 1, STRIP * k + 1, mb);
+                }
+            }
+            finish_strip(j, k, smooth_row, mr, mb, true);
         }
+        if (CHAIN) {
+            // Strips whose packed medians were not certain: all of the tile's, gathered in LDS, go through the 32-bit networks
+            // one per lane -- as many waves as ceil(count / 64) run them, instead of every wave that had one such strip.
+            lds_barrier();
+            const int nfb = __builtin_amdgcn_readfirstlane(sm.fb_count);
+            if (nfb > 0) {
+                if ((tid & ~63) < nfb) {                               // this wave has entries
+                    const int e = sm.fb_queue[min(tid, nfb - 1)];
+                    const int j2 = e >> 4, k2 = e & 15;
+                    int z = 0;
+                    asm volatile("" : "+s"(z));                        // (keeps these plane loads apart from the packed path's)
+                    strip_median25(sm.dr, j2 + z, STRIP * k2, mr);
+                    strip_median25(sm.db, j2 + z, STRIP * k2, mb);
+                    finish_strip(j2, k2, true, mr, mb, tid < nfb);
+                }
+                lds_barrier();
+                if (tid == 0) sm.fb_count = 0;
+            }
+        } else
         lds_barrier();                       // all strips done with the planes before the next tile's loader
         t = t_next;
         if (SPREAD) par ^= 1;
@@ -957,6 +1194,37 @@ void release_stream_state(int device, hipStream_t stream)
     if (it->second) (void)hipFree(it->second);
     g_tickets.erase(it);
 }
+// ---------------------------------------------------------------- per-black output table in HBM
+// E2R[ev] = (uint16)(ev2raw[ev] + black) for ev in [0, 14 * 32768): exactly what chroma_smooth.c:67-68 stores for a clamped EV.
+// One 16-bit look-up by index replaces mask, address, quotient, two shifts, add and mask per output pixel (cs5x5 -2.5 %, A/B in
+// profiles/r02/ab_table_gathers_kbench.log: "e1").  Built on the device from the exact 16-bit re-encoding U16 (common.h) the
+// first time a black level is seen on a device; 896 KiB per black level, served from L2.
+// (The same trick for the loader -- raw2ev by pixel value from a 256 KiB table, no conversion arithmetic at all, results
+// identical -- makes the kernel wait for the texture addresser instead: cs5x5 +11 %, cs2x2 +27 %, "e2" in the same log.)
+__global__ __launch_bounds__(256) void k_build_e2r(const uint16_t *u16, int black, uint16_t *e2r)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < E2R_ENTRIES) e2r[i] = (uint16_t)((((int)u16[i & 32767]) >> (13 - (i >> 15))) + black);
+}
+namespace {
+std::mutex g_tables_mu;
+std::map<std::pair<int, int>, uint16_t *> g_e2r;               // (device, black)
+}
+static int e2r_table(const Device *dev, int black, const uint16_t **out, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(g_tables_mu);
+    auto it = g_e2r.find({ dev->id, black });
+    if (it != g_e2r.end()) { *out = it->second; return MLVFS_AMD_OK; }
+    uint16_t *t = nullptr;
+    MLV_HIP(hipMalloc(&t, sizeof(uint16_t) * E2R_ENTRIES));
+    hipLaunchKernelGGL(k_build_e2r, dim3((E2R_ENTRIES + 255) / 256), dim3(256), 0, stream, dev->luts.u16, black, t);
+    MLV_HIP(hipGetLastError());
+    MLV_HIP(hipStreamSynchronize(stream));                     // other streams use the table from now on
+    g_e2r[{ dev->id, black }] = t;
+    *out = t;
+    return MLVFS_AMD_OK;
+}
+
 template <int METHOD, bool PACKED, bool VEC, bool SPREAD>
 static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
 {
@@ -964,7 +1232,7 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
     int grid = num_cu > 0 ? num_cu * 4 : 1024;          // 4 workgroups per CU (39 KiB LDS, <= 128 VGPRs)
     grid = (grid + 7) / 8 * 8;
     if (grid > total) grid = (int)((total + 7) / 8 * 8);
-    static_assert(sizeof(SmemT<SPREAD>) <= 40 * 1024, "four workgroups per CU need <= 40 KiB of LDS each");
+    static_assert(sizeof(SmemT<SPREAD, tile_rows_of(METHOD)>) <= 40 * 1024, "four workgroups per CU need <= 40 KiB of LDS each");
     auto kern = k_frame<METHOD, PACKED, VEC, SPREAD>;
     FrameArgs a = a_in;
     a.tickets = ticket_counters(stream);
@@ -1013,7 +1281,8 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
                  const int32_t *coef, hipStream_t stream, bool spread)
 {
     if (nframes <= 0) return MLVFS_AMD_OK;
-    if ((long long)frame_tiles_x(g.w) * frame_tiles_y(g.h) * nframes >= (1ll << 30)) {
+    const int geo = frame_geo_of(method);
+    if ((long long)frame_tiles_x(g.w) * frame_tiles_y(g.h, geo) * nframes >= (1ll << 30)) {
         set_error("too many tiles in one launch (%d frames): split the batch", nframes);
         return MLVFS_AMD_ERR_ARG;
     }
@@ -1028,10 +1297,14 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
     a.w = g.w; a.h = g.h; a.black = g.black; a.white = g.white;
     a.nframes = nframes;
     a.tiles_x = frame_tiles_x(g.w);
-    a.tiles_y = frame_tiles_y(g.h);
-    a.t16 = dev->luts.t16; a.u16 = dev->luts.u16;
+    a.tiles_y = frame_tiles_y(g.h, geo);
+    a.t16 = dev->luts.t16;
+    if (method != 0) {
+        int rc = e2r_table(dev, g.black, &a.e2r, stream);
+        if (rc) return rc;
+    }
     a.patch = pv && pv->n_patch > 0;
-    if (a.patch) { a.patches = (const int2 *)pv->patches; a.n_patch = pv->n_patch; a.tile_off = pv->tile_off; a.tile_ent = pv->tile_ent; }
+    if (a.patch) { a.patches = (const int2 *)pv->patches; a.n_patch = pv->n_patch; a.tile_off = pv->tile_off[geo]; a.tile_ent = pv->tile_ent[geo]; }
     a.stripes = stripes ? 1 : 0;
     a.coef_fast = 1;
     for (int i = 0; i < 8; i++) {
