@@ -57,6 +57,7 @@ constexpr int PW = TCW + 2 * HC;        // plane width  (68)
 constexpr int STRIP = 4;                // cells per thread in the median phase
 constexpr int GROUPS = TCW / 8;         // full items per plane row (8)
 constexpr int DARK_ITEMS_MIN = 16;      // of the loader items of a tile
+constexpr int FB_DIRECT = 100;          // 5x5: more uncertain strips than this (of 240): the next tiles go to the 32-bit networks directly
 constexpr int PMAP_WORDS = 64;          // tiles per frame covered by the LDS patch bitmap: 2048 (3584x1320 has 1176 / 1232)
 // Tile height in cells: 16 rows of 16 strips fill the 256 threads; 5x5 tiles have 15 rows, the 16 lanes that this frees
 // compute the right-hand halo group of every row for the neighbour-sharing medians (strip_chain_*, below).
@@ -933,6 +934,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     const uint64_t rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     int par = 0;                               // tile parity: which of the two dark_items counters this tile uses
+    int fb_prev = 0, fb_run = 0;               // 5x5: uncertain strips of the last tile that tried the packed networks; tiles since
     while (t < band_end) {
         int my_ticket = 0;
         if (threadIdx.x == 0) my_ticket = atomicAdd(&a.tickets[grp], 1);       // the tile after this one: back long before it is needed
@@ -1079,21 +1081,17 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         const int y = ty0 + 2 * j;
         const bool smooth_row = METHOD != 0 && y >= 4 && y < a.h - 5;                       // chroma_smooth.c:25
         int mr[STRIP] = { 0, 0, 0, 0 }, mb[STRIP] = { 0, 0, 0, 0 };
+        bool skip_packed = false;
         if (CHAIN) {
             // Deep shadows (EVs of neighbouring small integers are more than the packed window apart) would fail the packed
-            // attempt almost everywhere: tiles with many items at or below black go to the 32-bit networks directly
-            // (dark clips only, i.e. the SPREAD instantiation)
-            const bool direct32 = SPREAD && __builtin_amdgcn_readfirstlane(sm.dark_items[par]) >= DARK_ITEMS_MIN;
+            // attempt almost everywhere: tiles with many items at or below black skip it (dark clips only, i.e. the SPREAD
+            // instantiation), and so do tiles that follow a tile most of whose strips were uncertain (hard colour edges
+            // everywhere; every fourth such tile tries the packed networks again).  Skipping = every strip goes to the queue.
+            skip_packed = (SPREAD && __builtin_amdgcn_readfirstlane(sm.dark_items[par]) >= DARK_ITEMS_MIN) ||
+                          (fb_prev > FB_DIRECT && (++fb_run & 3) != 0);          // the same for every wave of the workgroup
             if (SPREAD && tid == 0) sm.dark_items[par ^ 1] = 0;
-            if (direct32) {                                            // the same for every wave of the workgroup
-                if (is_strip) {
-                    if (smooth_row) {
-                        strip_median25(sm.dr, j, STRIP * k, mr);
-                        strip_median25(sm.db, j, STRIP * k, mb);
-                    }
-                    finish_strip(j, k, smooth_row, mr, mb, true);
-                }
-            } else {
+            bool unknown = true;
+            if (!skip_packed) {
                 ChainGroup g;
                 chain_group(sm.dr, sm.db, j, is_strip ? STRIP * k : TCW, g);          // a strip's own group, or a row's halo group
                 const bool halo_wave = tid >= 192;                     // the wave that holds the halo groups' lanes (uniform)
@@ -1108,11 +1106,11 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 if (!halo_wave) chain_group_window(g);                 // the lane's own rank window, while those reads are under way
                 chain_fetch_window(g, n);
                 if (k == 15) chain_collect_window(sm.xchg[j], n);
-                bool unknown = chain_finish(g, n, mr, mb);
-                unknown = unknown && is_strip && smooth_row;
-                if (unknown) sm.fb_queue[atomicAdd(&sm.fb_count, 1)] = (uint8_t)(j * 16 + k);      // settled below, densely
-                if (is_strip) finish_strip(j, k, smooth_row, mr, mb, !unknown);
+                unknown = chain_finish(g, n, mr, mb);
             }
+            unknown = unknown && is_strip && smooth_row;
+            if (unknown) sm.fb_queue[atomicAdd(&sm.fb_count, 1)] = (uint8_t)(j * 16 + k);      // settled below, densely
+            if (is_strip && !unknown) finish_strip(j, k, smooth_row && !skip_packed, mr, mb, true);
         } else {
             if (smooth_row) {
                 if (METHOD == 3) {
@@ -1130,6 +1128,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             // one per lane -- as many waves as ceil(count / 64) run them, instead of every wave that had one such strip.
             lds_barrier();
             const int nfb = __builtin_amdgcn_readfirstlane(sm.fb_count);
+            if (!skip_packed) fb_prev = nfb;
             if (nfb > 0) {
                 if ((tid & ~63) < nfb) {                               // this wave has entries
                     const int e = sm.fb_queue[min(tid, nfb - 1)];
