@@ -94,8 +94,9 @@ struct StripesWork {
 // device-level pixel repair shared by the drop-in symbols and the dual-ISO path (dropin.cpp)
 struct ThreadCtx;
 bool focus_map_applies(struct frame_headers *fh, ThreadCtx *c, int dual_iso);      // a map file exists and has entries for this frame
-int focus_pixels_device(struct frame_headers *fh, ThreadCtx *c, void *d_frame, int dual_iso, bool *changed);
-int bad_pixels_device(struct frame_headers *fh, ThreadCtx *c, void *d_frame, int aggressive, int dual_iso, bool *changed);
+// n_patched (optional): entries of the patch list the repair left in c->d_patch ({position or -1, value} each)
+int focus_pixels_device(struct frame_headers *fh, ThreadCtx *c, void *d_frame, int dual_iso, bool *changed, int *n_patched = nullptr);
+int bad_pixels_device(struct frame_headers *fh, ThreadCtx *c, void *d_frame, int aggressive, int dual_iso, bool *changed, int *n_patched = nullptr);
 
 void glibc_rand_stream(uint16_t *out, size_t n, uint64_t skip, unsigned seed);
 int stripes_solve(const int32_t *hist, const int32_t num[8], int frame_size, int32_t coeffs[8]);

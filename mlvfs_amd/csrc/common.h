@@ -75,6 +75,18 @@ struct ThreadCtx {         // one per (host thread, device)
     size_t cap_pin = 0;
     void *d_patch = nullptr;             // this thread's patch list for pixel maps shared between threads (Clip::fix_pixels_shared)
     size_t cap_patch = 0;
+    // The 16-bit frame the drop-in stages work on: two buffers (a stage reads one and writes the other, or works in place), and --
+    // MLVFS_AMD_RESIDENT=1 -- which host buffer the current one mirrors, so that the next stage called on the same host pointer
+    // need not upload it again (dropin.cpp)
+    static constexpr int RES_SAMPLES = 64;
+    void *d_res[2] = { nullptr, nullptr };
+    size_t cap_res = 0;
+    const void *res_host = nullptr;
+    size_t res_bytes = 0;
+    int res_cur = 0;
+    int res_rank = 0;                    // which stage left the resident copy (dropin.cpp: stages only continue in process_frame's order)
+    uint64_t res_sig[RES_SAMPLES];
+    int ensure_res(size_t bytes);
     int ensure(size_t need_a, size_t need_b);
     int ensure_patch(size_t need);
     ~ThreadCtx();

@@ -188,6 +188,8 @@ ThreadCtx::~ThreadCtx()
     if (d_a) (void)hipFree(d_a);
     if (d_b) (void)hipFree(d_b);
     if (d_patch) (void)hipFree(d_patch);
+    if (d_res[0]) (void)hipFree(d_res[0]);
+    if (d_res[1]) (void)hipFree(d_res[1]);
     if (h_pin) (void)hipHostFree(h_pin);
 }
 
@@ -248,6 +250,21 @@ int ThreadCtx::ensure(size_t need_a, size_t need_b)
         MLV_HIP(hipMalloc(&d_b, need_b));
         cap_b = need_b;
     }
+    return MLVFS_AMD_OK;
+}
+
+int ThreadCtx::ensure_res(size_t bytes)
+{
+    if (bytes <= cap_res) return MLVFS_AMD_OK;
+    (void)hipStreamSynchronize(stream);
+    res_host = nullptr;
+    for (int k = 0; k < 2; k++) {
+        if (d_res[k]) (void)hipFree(d_res[k]);
+        d_res[k] = nullptr;
+    }
+    cap_res = 0;
+    for (int k = 0; k < 2; k++) MLV_HIP(hipMalloc(&d_res[k], bytes));
+    cap_res = bytes;
     return MLVFS_AMD_OK;
 }
 
