@@ -248,6 +248,9 @@ int mlvfs_amd_deflicker_dev(const mlvfs_amd_geom_t *geom, const void *d_frame, s
 int mlvfs_amd_cr2hdr20_dev(const mlvfs_amd_geom_t *geom, void *d_frame, int interp_method, int fullres, int use_alias_map,
                            int chroma_smooth, void *stream);
 void mlvfs_amd_dualiso_reset(void);
+/* the global decisions of the calling thread's last conversion: {RGGB?, is_bright[0..3] as bits 3..0, white, white of the bright
+ * rows (20 bit), a, b of the exposure fit (hdr.c:638-823), ISO difference in EV, darkened white} */
+void mlvfs_amd_dualiso_last_scalars(double out[8]);
 
 /* AMaZE demosaic of a float RGGB plane in HBM (amaze_demosaic_RT.c:113, as called from hdr.c:1034 with
  * winx = winy = 0): d_raw and the three outputs are height rows of width floats (no row padding), values in
@@ -264,6 +267,9 @@ int mlvfs_amd_timer_end(float *ms, int cap);
 
 /* self tests that need no GPU (selection networks, LUT identities): 0 = pass */
 int mlvfs_amd_selftest_host(void);
+/* the library's host EV tables against raw2ev_lin[16384] (index = pixel - black) and ev2raw[24 * 32768] (index 0 = EV -10 * 32768):
+ * 0 = identical (main.c:128-196; no GPU needed) */
+int mlvfs_amd_selftest_tables(const int32_t *raw2ev_lin, const int32_t *ev2raw);
 
 #ifdef __cplusplus
 }

@@ -159,6 +159,8 @@ static int prepare_tables(int device, int black, int white, int interp_method, D
     return MLVFS_AMD_OK;
 }
 
+static thread_local double t_last_scalars[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+
 // ------------------------------------------------------------------ per-thread work buffers
 struct DiWork {
     void *base = nullptr;
@@ -553,6 +555,11 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     printf("Half-res blending...\n");
     p.corr_ev = corr_ev; p.overlap = overlap;
     p.max_ev = log2(white / 64 - black / 64);
+    {   // the host decisions of this conversion, for mlvfs_amd_dualiso_last_scalars
+        double *sc = t_last_scalars;
+        sc[0] = rggb; sc[1] = is_bright[0] * 8 + is_bright[1] * 4 + is_bright[2] * 2 + is_bright[3];
+        sc[2] = white; sc[3] = white_bright; sc[4] = a; sc[5] = b; sc[6] = corr_ev; sc[7] = p.white_darkened;
+    }
 
     DiLuts L{};
     pt.mark("score candidates");
@@ -670,6 +677,12 @@ int mlvfs_amd_amaze_demosaic_dev(const float *d_raw, int width, int height, floa
     if (rc) return rc;
     return amaze_launch(d_raw, width, height, d_red, d_green, d_blue, scratch, s);
 }
+
+// Debug getter: the global decisions of the calling thread's last full dual-ISO conversion that got as far as the exposure
+// match -- {pattern is RGGB, is_bright[0..3] as bits 3..0, white (20 bit), white of the bright rows, a, b of the exposure fit
+// (hdr.c:638-823), ISO difference in EV, darkened white} -- so that tests can compare them one by one with the checker's
+// instead of only through the pixels they shape.
+void mlvfs_amd_dualiso_last_scalars(double out[8]) { for (int i = 0; i < 8; i++) out[i] = t_last_scalars[i]; }
 
 // test hook: forget the per-black table caches, as a fresh process would
 void mlvfs_amd_dualiso_reset(void)

@@ -80,3 +80,15 @@ extern "C" int mlvfs_amd_selftest_host(void)
     if (!mlv::luts_ok()) fails += 1000000;
     return fails;
 }
+
+// The library's host EV tables (its own formulas, or the caller's get_raw2ev / get_ev2raw when the caller exports them) against
+// tables handed in: raw2ev_lin[16384] (index = pixel - black; [0] = INT_MIN) and ev2raw[24 * 32768] (index 0 = EV -10 * 32768).
+// 0 = identical.  Needs no GPU.  (The CPU test suite passes the tables of the reference's own main.c.)
+extern "C" int mlvfs_amd_selftest_tables(const int32_t *raw2ev_lin, const int32_t *ev2raw)
+{
+    if (!mlv::luts_ok()) return 1;
+    const int32_t *a = mlv::host_raw2ev_lin(), *b = mlv::host_ev2raw();
+    for (int i = 0; i < 16384; i++) if (a[i] != raw2ev_lin[i]) return 2;
+    for (int i = 0; i < 24 * MLV_EV_RES; i++) if (b[i] != ev2raw[i]) return 3;
+    return 0;
+}

@@ -33,6 +33,26 @@ def have_ref() -> bool:
     return os.path.exists(REF_SO)
 
 
+REF_LUTS_SO = os.path.join(HERE, "_ref", "libref_luts.so")
+
+
+def restated_ev_tables(black: int):
+    """The same three tables from oracle/ref_luts.c (the repo's restatement of main.c:128-196, built alone into
+    _ref/libref_luts.so): what the C-host test and the GPU library's stand-alone mode assume the caller provides."""
+    L = C.CDLL(REF_LUTS_SO)
+    L.get_raw2ev.restype = C.POINTER(C.c_int)
+    L.get_raw2ev.argtypes = [C.c_int]
+    L.get_raw2evf.restype = C.POINTER(C.c_double)
+    L.get_raw2evf.argtypes = [C.c_int]
+    L.get_ev2raw.restype = C.POINTER(C.c_int)
+    n = 16384 + black
+    r = np.ctypeslib.as_array(L.get_raw2ev(black), shape=(n,)).copy()
+    rf = np.ctypeslib.as_array(L.get_raw2evf(black), shape=(n,)).copy()
+    base = C.cast(L.get_ev2raw(), C.c_void_p).value - 10 * 32768 * 4
+    e = np.ctypeslib.as_array(C.cast(base, C.POINTER(C.c_int)), shape=(24 * 32768,)).copy()
+    return r, rf, e
+
+
 class PixelList(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32)]
 
@@ -252,6 +272,22 @@ class Reference:
     """_ref/libmlvfs_ref.so -- the reference's own code behind oracle/ref_adapter.c."""
     kind = "reference"
 
+    def mlv_frame_headers(self, path: str, index: int):
+        """mlv_get_frame_headers (main.c:429-558, the reference's text sliced into the build by oracle/Makefile) ->
+        (return value, the frame_headers struct as bytes)"""
+        out = np.zeros(int(self.L.ref_sizeof_frame_headers()), np.uint8)
+        ok = self.L.ref_mlv_frame_headers(path.encode(), index, out)
+        return ok, out.tobytes()
+
+    def ev_tables(self, black: int):
+        """get_raw2ev(black)[0..16383+black], get_raw2evf likewise, get_ev2raw()[-10*32768 .. 14*32768-1] (main.c:128-196)"""
+        n = 16384 + black
+        r = np.ctypeslib.as_array(self.L.get_raw2ev(black), shape=(n,)).copy()
+        rf = np.ctypeslib.as_array(self.L.get_raw2evf(black), shape=(n,)).copy()
+        base = C.cast(self.L.get_ev2raw(), C.c_void_p).value - 10 * 32768 * 4
+        e = np.ctypeslib.as_array(C.cast(base, C.POINTER(C.c_int)), shape=(24 * 32768,)).copy()
+        return r, rf, e
+
     def __init__(self):
         if not have_ref():
             build()
@@ -286,6 +322,9 @@ class Reference:
             f.restype = C.c_size_t
             f.argtypes = [C.c_char_p, u8p, C.c_size_t]
         L.ref_mlv_frame_count.argtypes = [C.c_char_p]
+        L.ref_mlv_frame_headers.argtypes = [C.c_char_p, C.c_int, u8p]
+        L.get_raw2evf.restype = C.POINTER(C.c_double)
+        L.get_raw2evf.argtypes = [C.c_int]
         L.ref_lj92_decode.argtypes = [u8p, C.c_int, u16p, C.c_int, i32p]
         L.ref_lj92_encode.argtypes = [u16p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
         L.ref_header_data.restype = C.c_size_t

