@@ -210,6 +210,14 @@ int mlvfs_amd_lj92_info(const void *stream, size_t size, int dims[4]);
 int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_t *sizes, int nframes, int xres, int yres,
                               void *d_out, size_t out_stride, void *stream);
 
+/* -- LZMA payloads ----------------------------------------- */
+/* One VIDF payload of an LZMA-compressed clip (MLV_VIDEO_CLASS_FLAG_LZMA; main.c:598-616): [u32 size of the packed frame][5 LZMA
+ * property bytes][LZMA stream] -> the packed frame, exactly what LzmaUncompress leaves in lzma_out for dng_get_image_data.  Host
+ * code (the entropy decoding of a frame is one serial chain; the reader decodes one frame per thread): no HIP device needed.
+ * Returns 0 and the decoded size, or LzmaDecode's error code (1 data, 4 unsupported properties, 6 input ends early), or
+ * MLVFS_AMD_ERR_ARG when the buffer is smaller than the size word says.                                             */
+int mlvfs_amd_lzma_uncompress(const void *payload, size_t size, void *dst, size_t dst_cap, size_t *out_size);
+
 /* -- MLV container reader and prefetcher (host code) -------- */
 /* Opens <name>.MLV and its chunks .M00, .M01, ... (index.c:367-424) and builds, once, what MLVFS rebuilds for every
  * frame it serves: the XREF index (index.c:216-341; use_idx_file != 0: taken from <name>.IDX when that exists, written
@@ -231,6 +239,17 @@ int    mlvfs_amd_mlv_read_frames(const void *reader, int first, int count, void 
  * belong to the device of the thread that first streams from it.                                                     */
 int    mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first, int count, void *h_out, size_t out_stride,
                              int cs_method, int fix_pixels, int apply_stripes, int batch_frames, int io_threads);
+
+/* -- animated GIF preview (gif.c:82-244) ---------------------- */
+/* = gif_get_size: size of the preview file of a clip with these frame headers                                        */
+size_t mlvfs_amd_gif_size(const struct frame_headers *frame_headers);
+/* The preview of 10 frames (host memory, `stride` bytes apart: packed payloads of geom->bpp bits with one word of slack behind
+ * each when packed != 0, else 16-bit frames): the pixel picking and the gamma map run on the GPU, the file's framing on the host;
+ * file receives mlvfs_amd_gif_size bytes, byte for byte what gif_get_data builds.                                   */
+int mlvfs_amd_gif_render(const mlvfs_amd_geom_t *geom, const void *h_frames, size_t stride, int packed, int nframes, uint8_t *file);
+/* = gif_get_data on an opened clip (frames k * count / 10, k = 0..9; uncompressed, LZMA and LJ92 clips): copies
+ * min(max_size, size - offset) bytes from `offset` on, returns max_size (0 on failure).                              */
+size_t mlvfs_amd_mlv_gif_data(const void *reader, uint8_t *output_buffer, off_t offset, size_t max_size);
 
 /* dual-ISO preview on one device frame (hdr.c:40-227); returns 1 / 0 / <0    */
 int mlvfs_amd_hdr_preview_dev(const mlvfs_amd_geom_t *geom, void *d_frame, size_t max_size, void *stream);

@@ -112,6 +112,9 @@ struct Geom {
     int w, h, bpp, black, white;
 };
 
+// LZMA payloads (lzma.cpp): 0 = ok, else LzmaDecode's error code
+int lzma_decode(const uint8_t props[5], const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, size_t *dst_len);
+
 // device API: the caller's stream; NULL is HIP's default (null) stream, which orders
 // against everything else the caller enqueued
 inline hipStream_t pick_stream(void *s, ThreadCtx *) { return (hipStream_t)s; }

@@ -13,8 +13,10 @@
 // threads into page-locked memory while the previous batch is on the GPU (mlvfs_amd_mlv_process).
 //
 // The reference opens, indexes and walks the clip again for every frame it serves; results are the same, the cost is not.
-// LJ92 payloads (main.c:617-681) are decoded on the GPU (csrc/lj92.cpp) inside mlvfs_amd_mlv_process; LZMA payloads are
-// refused, and so are LJ92 payloads in mlvfs_amd_mlv_read_frames (which hands out packed pixels).
+// LJ92 payloads (main.c:617-681) are decoded on the GPU (csrc/lj92.cpp) inside mlvfs_amd_mlv_process; LZMA payloads
+// (main.c:598-616) by the reader threads that fetch them (csrc/lzma.cpp: one frame per thread), so that an LZMA clip looks like
+// an uncompressed one to everything behind read_frames.  LJ92 payloads are refused in mlvfs_amd_mlv_read_frames (which hands
+// out packed pixels).
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -41,7 +43,7 @@ struct XrefEntry { uint16_t file; uint8_t empty, kind; uint64_t offset; };      
 static_assert(sizeof(BlockHead) == 16 && sizeof(XrefHead) == 24 && sizeof(XrefEntry) == 12, "MLV v2.0 layouts");
 
 enum : uint8_t { KIND_OTHER = 0, KIND_VIDF = 1, KIND_AUDF = 2 };
-constexpr uint16_t CLASS_LZMA = 0x80, CLASS_LJ92 = 0x20;                                          // mlv.h:30-33
+constexpr uint16_t CLASS_LZMA = 0x80, CLASS_LJ92 = 0x100;                                         // mlv.h:30-31 (the reference's values: LJ92 is 0x100 there)
 
 bool read_at(int fd, void *dst, size_t n, uint64_t off)
 {
@@ -274,7 +276,7 @@ int frame_headers_of(const Reader &r, int index, frame_headers *out)
 }
 
 // ---- payloads ---------------------------------------------------------------------------------------------------------
-struct Span { int fd; uint64_t off; size_t bytes; };
+struct Span { int fd; uint64_t off; size_t bytes; size_t lzma_bytes = 0; };      // lzma_bytes != 0: the block's compressed payload
 
 bool payload_span(const Reader &r, int index, Span *s, bool lj92 = false)
 {
@@ -290,14 +292,19 @@ bool payload_span(const Reader &r, int index, Span *s, bool lj92 = false)
         s->bytes = (size_t)room;
         return true;
     }
-    if (fh.file_hdr.videoClass & (CLASS_LZMA | CLASS_LJ92)) {
-        set_error("mlv: compressed video class 0x%x (LZMA payloads are not decoded; LJ92 ones only by mlvfs_amd_mlv_process)", fh.file_hdr.videoClass);
+    if ((fh.file_hdr.videoClass & CLASS_LJ92) && !(fh.file_hdr.videoClass & CLASS_LZMA)) {
+        set_error("mlv: LJ92 payloads (video class 0x%x) are decoded only by mlvfs_amd_mlv_process", fh.file_hdr.videoClass);
         return false;
     }
     const uint64_t bits = (uint64_t)fh.rawi_hdr.xRes * fh.rawi_hdr.yRes * (uint64_t)fh.rawi_hdr.raw_info.bits_per_pixel;
     s->fd = r.fds[fh.fileNumber];
     s->off = fh.position + sizeof(mlv_vidf_hdr_t) + fh.vidf_hdr.frameSpace;
     s->bytes = (size_t)((bits + 7) / 8);
+    if (fh.file_hdr.videoClass & CLASS_LZMA) {           // main.c:573 tests this flag first
+        if (room < 4 + 5 + 5) { set_error("mlv: frame %d: empty LZMA payload", index); return false; }
+        s->lzma_bytes = (size_t)room;                     // [size][properties][stream], decoded by the thread that reads it
+        return true;
+    }
     const uint64_t in_block = fh.vidf_hdr.blockSize > sizeof(mlv_vidf_hdr_t) + fh.vidf_hdr.frameSpace
                                   ? fh.vidf_hdr.blockSize - sizeof(mlv_vidf_hdr_t) - fh.vidf_hdr.frameSpace : 0;
     if (in_block < s->bytes) { set_error("mlv: frame %d: VIDF block holds %llu payload bytes, geometry needs %zu", index,
@@ -316,11 +323,24 @@ int read_frames(const Reader &r, int first, int count, uint8_t *dst, size_t stri
         if (spans[k].bytes > stride) { set_error("mlv: stride %zu smaller than a frame payload (%zu)", stride, spans[k].bytes); return MLVFS_AMD_ERR_ARG; }
     }
     threads = std::max(1, std::min(threads <= 0 ? 8 : threads, count));
-    std::atomic<int> next{ 0 }, failed{ -1 };
+    std::atomic<int> next{ 0 }, failed{ -1 }, failed_lzma{ -1 };
     auto work = [&]() {
         for (int k; (k = next.fetch_add(1)) < count;) {
             uint8_t *d = dst + (size_t)k * stride;
-            if (!read_at(spans[k].fd, d, spans[k].bytes, spans[k].off)) { failed = first + k; continue; }
+            if (spans[k].lzma_bytes) {
+                // main.c:598-616: the size word says how much LzmaUncompress may produce; what dng_get_image_data then reads
+                // is the frame's packed size (a shorter result leaves the rest of the reference's buffer undefined: zeros here)
+                std::vector<uint8_t> comp(spans[k].lzma_bytes);
+                size_t got = 0;
+                if (!read_at(spans[k].fd, comp.data(), comp.size(), spans[k].off)) { failed = first + k; continue; }
+                const size_t want = (size_t)comp[0] | ((size_t)comp[1] << 8) | ((size_t)comp[2] << 16) | ((size_t)comp[3] << 24);
+                std::vector<uint8_t> big;
+                uint8_t *out = d;
+                if (want > stride) { big.resize(want); out = big.data(); }      // a size word larger than the frame: decode all, keep the frame
+                if (mlv::lzma_decode(comp.data() + 4, comp.data() + 9, comp.size() - 9, out, want, &got) != 0) { failed_lzma = first + k; continue; }
+                if (out != d) memcpy(d, out, std::min(got, spans[k].bytes));
+                if (got < spans[k].bytes) memset(d + got, 0, spans[k].bytes - got);
+            } else if (!read_at(spans[k].fd, d, spans[k].bytes, spans[k].off)) { failed = first + k; continue; }
             if (stride > spans[k].bytes) memset(d + spans[k].bytes, 0, std::min<size_t>(stride - spans[k].bytes, 64));   // the 2-pixel over-read of main.c:579 sees zeros
         }
     };
@@ -329,6 +349,7 @@ int read_frames(const Reader &r, int first, int count, uint8_t *dst, size_t stri
     work();
     for (auto &t : pool) t.join();
     if (failed >= 0) { set_error("mlv: short read in the payload of frame %d", (int)failed); return MLVFS_AMD_ERR_ARG; }
+    if (failed_lzma >= 0) { set_error("mlv: the LZMA payload of frame %d cannot be decoded", (int)failed_lzma); return MLVFS_AMD_ERR_ARG; }   // main.c:614: "LZMA Failed!"
     return MLVFS_AMD_OK;
 }
 
@@ -481,6 +502,59 @@ int mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first,
         }
     }
     return rc;
+}
+
+// = gif_get_data (gif.c:82-221) on an opened clip: the animated preview of 10 frames spread over the clip, 1/4 x 1/4 size; copies
+// min(max_size, size - offset) bytes of the file from `offset` on and returns max_size like the reference, 0 on failure.
+size_t mlvfs_amd_mlv_gif_data(const void *reader, uint8_t *output_buffer, off_t offset, size_t max_size)
+{
+    if (!reader || !output_buffer || offset < 0) { set_error("mlv: null argument"); return 0; }
+    const Reader &r = *(const Reader *)reader;
+    frame_headers fh0;
+    if (!frame_headers_of(r, 0, &fh0)) return 0;                                                  // gif.c:85
+    const int frame_count = (int)r.vidf.size();
+    const int xres = fh0.rawi_hdr.xRes, yres = fh0.rawi_hdr.yRes, bpp = fh0.rawi_hdr.raw_info.bits_per_pixel;
+    const bool lj92 = (fh0.file_hdr.videoClass & CLASS_LJ92) && !(fh0.file_hdr.videoClass & CLASS_LZMA);
+    const mlvfs_amd_geom_t geom{ xres, yres, lj92 ? 16 : bpp, (int32_t)fh0.rawi_hdr.raw_info.black_level, (int32_t)fh0.rawi_hdr.raw_info.white_level, 0, 0 };
+    const size_t total = mlvfs_amd_gif_size(&fh0);
+    std::vector<uint8_t> file(total);
+    constexpr int NF = 10;                                                                        // gif.c:37
+    int rc = MLVFS_AMD_OK;
+    if (lj92) {
+        // the frames' JPEG streams -> 16-bit frames in HBM (the GPU decoder) -> back to the host for the renderer's upload: ten frames
+        std::vector<std::vector<uint8_t>> comp(NF);
+        std::vector<const void *> ptr(NF);
+        std::vector<size_t> len(NF);
+        for (int k = 0; k < NF && rc == MLVFS_AMD_OK; k++) {
+            Span sp;
+            if (!payload_span(r, k * frame_count / NF, &sp, true)) return 0;
+            comp[k].resize(sp.bytes);
+            if (!read_at(sp.fd, comp[k].data(), sp.bytes, sp.off)) { set_error("mlv: short read"); return 0; }
+            ptr[k] = comp[k].data() + 4; len[k] = sp.bytes - 4;
+        }
+        mlv::ThreadCtx *c = mlv::thread_ctx();
+        if (!c) return 0;
+        const size_t fbytes = (size_t)xres * yres * 2, dstride = (fbytes + 255) / 256 * 256;
+        void *d = nullptr;
+        if (hipMalloc(&d, dstride * NF) != hipSuccess) { set_error("mlv: out of device memory"); return 0; }
+        std::vector<uint8_t> frames(dstride * NF);
+        rc = mlvfs_amd_lj92_decode_dev(ptr.data(), len.data(), NF, xres, yres, d, dstride, c->stream);
+        if (rc == MLVFS_AMD_OK && (hipMemcpyAsync(frames.data(), d, dstride * NF, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                                   hipStreamSynchronize(c->stream) != hipSuccess)) rc = MLVFS_AMD_ERR_HIP;
+        (void)hipFree(d);
+        if (rc == MLVFS_AMD_OK) rc = mlvfs_amd_gif_render(&geom, frames.data(), dstride, 0, NF, file.data());
+    } else {
+        Span s0;
+        if (!payload_span(r, 0, &s0)) return 0;
+        const size_t stride = (s0.bytes + 2 + 15) / 16 * 16;
+        std::vector<uint8_t> frames(stride * NF, 0);
+        for (int k = 0; k < NF && rc == MLVFS_AMD_OK; k++)                                         // gif.c:160: frame k * count / 10
+            rc = read_frames(r, k * frame_count / NF, 1, frames.data() + (size_t)k * stride, stride, 1);
+        if (rc == MLVFS_AMD_OK) rc = mlvfs_amd_gif_render(&geom, frames.data(), stride, 1, NF, file.data());
+    }
+    if (rc != MLVFS_AMD_OK) return 0;
+    if ((size_t)offset < total) memcpy(output_buffer, file.data() + offset, std::min(max_size, total - (size_t)offset));   // gif.c:215
+    return max_size;
 }
 
 }  // extern "C"

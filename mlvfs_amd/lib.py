@@ -46,7 +46,8 @@ DEVICE_SYMBOLS = [
     "mlvfs_amd_timer_begin", "mlvfs_amd_timer_end", "mlvfs_amd_selftest_host", "mlvfs_amd_selftest_tables",
     "mlvfs_amd_mlv_open", "mlvfs_amd_mlv_close", "mlvfs_amd_mlv_frame_count", "mlvfs_amd_mlv_chunk_count",
     "mlvfs_amd_mlv_xref", "mlvfs_amd_mlv_frame_headers", "mlvfs_amd_mlv_read_frames", "mlvfs_amd_mlv_process",
-    "mlvfs_amd_lj92_info", "mlvfs_amd_lj92_decode_dev", "mlvfs_amd_process_unpacked_dev", "mlvfs_amd_deflicker_dev",
+    "mlvfs_amd_lj92_info", "mlvfs_amd_lj92_decode_dev", "mlvfs_amd_lzma_uncompress",
+    "mlvfs_amd_gif_size", "mlvfs_amd_gif_render", "mlvfs_amd_mlv_gif_data", "mlvfs_amd_process_unpacked_dev", "mlvfs_amd_deflicker_dev",
 ]
 
 
@@ -151,6 +152,10 @@ def load() -> C.CDLL:
     sig("mlvfs_amd_selftest_tables", i, [vp, vp])
     sig("mlvfs_amd_process_unpacked_dev", i, [vp, vp, sz, vp, sz, i, i, i, i, vp])
     sig("mlvfs_amd_deflicker_dev", i, [gp, vp, sz, i, vp, vp])
+    sig("mlvfs_amd_lzma_uncompress", i, [vp, sz, vp, sz, C.POINTER(sz)])
+    sig("mlvfs_amd_gif_size", sz, [fhp])
+    sig("mlvfs_amd_gif_render", i, [gp, vp, sz, i, i, vp])
+    sig("mlvfs_amd_mlv_gif_data", sz, [vp, vp, C.c_long, sz])
     sig("mlvfs_amd_lj92_info", i, [vp, sz, vp])
     sig("mlvfs_amd_lj92_decode_dev", i, [vp, vp, i, i, i, vp, sz, vp])
     sig("mlvfs_amd_mlv_open", vp, [C.c_char_p, i])

@@ -279,6 +279,35 @@ class Reference:
         ok = self.L.ref_mlv_frame_headers(path.encode(), index, out)
         return ok, out.tobytes()
 
+    def lzma_payload(self, data: bytes, level=5, dict_size=1 << 20, lc=3, lp=0, pb=2) -> bytes:
+        """[u32 size][5 properties][LZMA stream] of `data` by the reference's encoder (test streams)"""
+        src = np.frombuffer(data, np.uint8)
+        out = np.zeros(len(data) + len(data) // 3 + 1024, np.uint8)
+        self.L.ref_lzma_make_payload.restype = C.c_long
+        self.L.ref_lzma_make_payload.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int]
+        n = self.L.ref_lzma_make_payload(np.ascontiguousarray(src), src.size, out, out.size, level, dict_size, lc, lp, pb)
+        assert n > 0, n
+        return out[:n].tobytes()
+
+    def lzma_uncompress(self, payload: bytes):
+        """LzmaUncompress as main.c:598-616 calls it -> (return code, decoded bytes)"""
+        p = np.frombuffer(payload, np.uint8)
+        want = int.from_bytes(payload[:4], "little")
+        out = np.zeros(max(want, 1), np.uint8)
+        n = C.c_size_t(0)
+        self.L.ref_lzma_uncompress.argtypes = [u8p, C.c_size_t, u8p, C.POINTER(C.c_size_t)]
+        r = self.L.ref_lzma_uncompress(np.ascontiguousarray(p), p.size, out, C.byref(n))
+        return r, out[:n.value].tobytes()
+
+    def gif(self, path: str) -> bytes:
+        """gif_get_data (gif.c:82-221) of a clip on disk: the whole preview file"""
+        self.L.ref_gif.restype = C.c_size_t
+        self.L.ref_gif.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
+        n = self.L.ref_gif(path.encode(), None, 0)
+        out = np.zeros(max(n, 1), np.uint8)
+        got = self.L.ref_gif(path.encode(), out.ctypes.data, n)
+        return out[:got].tobytes()
+
     def ev_tables(self, black: int):
         """get_raw2ev(black)[0..16383+black], get_raw2evf likewise, get_ev2raw()[-10*32768 .. 14*32768-1] (main.c:128-196)"""
         n = 16384 + black

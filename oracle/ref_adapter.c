@@ -242,3 +242,34 @@ int ref_mlv_frame_headers(const char *path, int index, uint8_t *out)
     memcpy(out, &fh, sizeof fh);
     return ok;
 }
+
+/* LZMA payloads: the reference's vendored decoder / encoder (LZMA/LzmaLib.c) behind the layout main.c:598-616 reads:
+ * [u32 decoded size][5 property bytes][stream].  The encoder only makes test streams. */
+#include "LZMA/LzmaLib.h"
+long ref_lzma_make_payload(const uint8_t *src, size_t n, uint8_t *out, size_t cap, int level, unsigned dict, int lc, int lp, int pb)
+{
+    if (cap < 9) return -1;
+    size_t dest_len = cap - 9, props_len = 5;
+    const int r = LzmaCompress(out + 9, &dest_len, src, n, out + 4, &props_len, level, dict, lc, lp, pb, 32, 1);
+    if (r != SZ_OK || props_len != 5) return -1 - r;
+    out[0] = (uint8_t)n; out[1] = (uint8_t)(n >> 8); out[2] = (uint8_t)(n >> 16); out[3] = (uint8_t)(n >> 24);
+    return (long)(dest_len + 9);
+}
+int ref_lzma_uncompress(const uint8_t *payload, size_t size, uint8_t *out, size_t *out_len)
+{
+    size_t lzma_out_size = *(const uint32_t *)payload, lzma_in_size = size - LZMA_PROPS_SIZE - 4;      /* main.c:600-602 */
+    const int r = LzmaUncompress(out, &lzma_out_size, payload + 4 + LZMA_PROPS_SIZE, &lzma_in_size, payload + 4, LZMA_PROPS_SIZE);
+    *out_len = lzma_out_size;
+    return r;
+}
+
+/* the animated preview, gif.c:82-244 (its frame fetch is the sliced get_image_data) */
+#include "gif.h"
+size_t ref_gif(const char *path, uint8_t *out, size_t cap)
+{
+    struct frame_headers fh;
+    if (!mlv_get_frame_headers(path, 0, &fh)) return 0;
+    const size_t n = gif_get_size(&fh);
+    if (!out || cap < n) return n;
+    return gif_get_data(path, out, 0, n) ? n : 0;
+}

@@ -28,7 +28,7 @@ if LJ:
     quad = lambda f: np.ascontiguousarray(np.block([[f[0::2, 0::2], f[0::2, 1::2]], [f[1::2, 0::2], f[1::2, 1::2]]]))
     pl = [struct.pack("<I", W * H * 2) + ref.lj92_encode(quad(frames8[k]), 14) for k in range(8)]
 t0 = time.perf_counter()
-names = mlvfile.write_clip(os.path.join(d, "BENCH.MLV"), [pl[k % 8] for k in range(N)], W, H, chunks=2, extras=True, video_class=1 | (0x20 if LJ else 0))
+names = mlvfile.write_clip(os.path.join(d, "BENCH.MLV"), [pl[k % 8] for k in range(N)], W, H, chunks=2, extras=True, video_class=1 | (0x100 if LJ else 0))
 print(f"wrote {N} frames ({sum(os.path.getsize(n) for n in names) / 1e9:.2f} GB, {len(names)} chunks) in {time.perf_counter() - t0:.1f} s", flush=True)
 t0 = time.perf_counter()
 r = mlvfile.MlvReader(names[0])
