@@ -4,6 +4,7 @@
 
 #include "common.h"
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -19,11 +20,17 @@ inline int frame_geo_of(int method) { return method == 5 ? 1 : 0; }
 inline int frame_tiles_x(int w) { return (w + 2 * FRAME_TCW - 1) / (2 * FRAME_TCW); }
 inline int frame_tiles_y(int h, int geo) { return (h + 2 * frame_tile_rows(geo) - 1) / (2 * frame_tile_rows(geo)); }
 
-struct PatchView {            // what the fused kernel needs to apply a clip's pixel map
-    const void *patches;      // int2[nframes][n_patch] {pos, value}
-    int n_patch;
-    const int *tile_off[FRAME_GEOS];      // CSR over tiles of one frame, per tile geometry: entries whose cell lies in the tile + halo
-    const int *tile_ent[FRAME_GEOS];
+// A Bayer cell that holds repaired pixels, as the fused kernel's tile lists name it: the pixel-map entry of each of its four
+// pixels (index into the clip's ordered entry list; -1: the pixel keeps the frame's value)
+struct CellRec {
+    int cell;       // cell column | cell row << 16
+    int e[4];       // pixel (x & 1) + 2 * (y & 1)
+};
+
+struct PatchView {            // what the fused kernel needs to apply a clip's pixel map (one tile geometry)
+    const void *cells;        // int4[nframes][n_rec] {cell, R | G1 << 16, G2 | B << 16, -}: k_pixfix_cells
+    int n_rec;
+    const int *tile_off;      // CSR over the tiles of one frame: records of the cells that lie in the tile + halo
 };
 
 struct PixEntry {
@@ -45,13 +52,27 @@ struct Clip {
     // pixel map
     std::vector<int32_t> xy;
     int rules = 0, dual_iso = 0;
-    int n_entries = 0, n_levels = 0;
+    int n_entries = 0, n_levels = 0, n_level0 = 0;       // n_level0: entries without a dependency (they come first)
     PixEntry *d_entries = nullptr;
     int *d_level_off = nullptr;
-    int *d_tile_off[FRAME_GEOS] = { nullptr, nullptr }, *d_tile_ent[FRAME_GEOS] = { nullptr, nullptr };
-    PatchView patch_view(const void *patches) const
+    // per tile geometry: the cells with repaired pixels, listed tile by tile (a cell in the halo of a neighbouring tile is
+    // listed there too)
+    int *d_tile_off[FRAME_GEOS] = { nullptr, nullptr };
+    CellRec *d_tile_rec[FRAME_GEOS] = { nullptr, nullptr };
+    int n_rec[FRAME_GEOS] = { 0, 0 };
+    // One buffer per call holds the patch list {position, value} of every frame and, behind it, the cell values of every
+    // frame for the tile geometry in use
+    size_t patch_buffer_bytes(int nframes) const
     {
-        return PatchView{ patches, n_entries, { d_tile_off[0], d_tile_off[1] }, { d_tile_ent[0], d_tile_ent[1] } };
+        return (size_t)nframes * ((size_t)n_entries * 8 + (size_t)std::max(n_rec[0], n_rec[1]) * 16) + 16;
+    }
+    static void *cells_of(void *patches, int n_entries, int nframes)
+    {
+        return (uint8_t *)patches + ((size_t)nframes * (size_t)n_entries * 8 + 15) / 16 * 16;
+    }
+    PatchView patch_view(void *patches, int nframes, int geo) const
+    {
+        return PatchView{ cells_of(patches, n_entries, nframes), n_rec[geo], d_tile_off[geo] };
     }
     void *d_patches = nullptr;
     size_t patch_bytes = 0;
@@ -118,8 +139,11 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
 // share of sampled pixels of one frame that lie 1 .. 511 above black, in 1/1024 (synchronises the stream)
 int dark_share(bool packed, const void *d_frame, int w, int h, int black, hipStream_t stream, int *share_1024);
 int launch_pixfix(bool packed, const void *frames, size_t stride, int w, int black, const void *entries,
-                  const int *level_off, int n_levels, int n_entries, void *patches, void *scatter, size_t scatter_stride,
-                  int nframes, const DeviceLuts &luts, hipStream_t stream);
+                  const int *level_off, int n_levels, int n_level0, int n_entries, void *patches, void *scatter,
+                  size_t scatter_stride, int nframes, const DeviceLuts &luts, hipStream_t stream);
+// the four pixels of every listed cell after the repair (for the fused kernel): after launch_pixfix, on the same stream
+int launch_pixfix_cells(bool packed, const void *frames, size_t stride, int w, int h, const CellRec *recs, int n_rec,
+                        const void *patches, int n_entries, void *cells, int nframes, hipStream_t stream);
 int launch_deflicker_hist(const void *d_frame, uint32_t samples, uint32_t white, unsigned *d_hist, hipStream_t s);
 int launch_badpix_detect(const void *d_frame, int w, int h, int black, int aggressive, int crop_x, int crop_y,
                          void *d_mask, int words_per_row, int *d_row_count, void *d_list, int cap,

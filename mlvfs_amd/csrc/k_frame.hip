@@ -25,7 +25,7 @@
 //     per plane, conflict-free lane -> (row, strip) map.
 //   * raw2ev lives in LDS as the 8192-entry mantissa-normalised 16-bit table (common.h),
 //     ev2raw's 64 KiB table is gathered from L2 (all gathers of a strip in flight at once)
-//   * pixel-map patches: per-tile entry lists (built once per clip on the host)
+//   * pixel-map patches: per-tile lists of repaired cells (built once per clip on the host; values per frame: k_pixfix_cells)
 //     recompute just the cells they touch
 //   * persistent workgroups; the four residents of a CU draw tiles by ticket from that CU's contiguous
 //     range of the tile list (the ranges of an XCD's CUs adjacent, so halo re-reads hit its own L2)
@@ -73,10 +73,10 @@ struct FrameArgs {
     int tiles_x, tiles_y;
     const uint16_t *t16;
     const uint16_t *e2r;     // (uint16)(ev2raw[ev] + black), ev in [0, 14 * 32768): the output pixel by EV, one buffer look-up
-    // patches: per frame `n_patch` entries {pos, value}; per-tile entry lists (CSR)
-    const int2 *patches;
-    int n_patch;
-    const int *tile_off, *tile_ent;
+    // pixel map: per frame `n_rec` cell records {cell, R | G1 << 16, G2 | B << 16, -} (k_pixfix_cells), listed tile by tile (CSR)
+    const int4 *cells;
+    int n_rec;
+    const int *tile_off;
     // stripes
     int coef[8];
     int coef_fast;           // all |coef - 65536| < 32768: 32-bit epilogue
@@ -118,14 +118,12 @@ struct __align__(16) SmemT {
     static constexpr int N_FULL = PH * GROUPS;          // full loader items per tile (threads 0 .. N_FULL-1)
     static constexpr int N_ITEMS = N_FULL + PH;         // + one edge item per plane row
     static constexpr bool CHAIN = TCH_ == FRAME_TCH5;   // the 5x5 geometry
-    static constexpr int ENT_CAP = SPREAD_ ? 24 : 32;   // pixel-map entries of one tile staged in LDS (more: the unstaged path)
     uint16_t raw[2 * TCH][2 * TCW];     // interior pixels (post patch), 8 KiB
     int dr[PH][PW];                     // 5.3 KiB
     int db[PH][PW];
     int ge[TCH][TCW];                   // 4 KiB
     uint16_t t16[MLV_T16_N + (SPREAD_ ? 64 : 0)];   // mantissa-normalised raw2ev (common.h), 16 KiB
     uint32_t has_patch[PMAP_WORDS];     // one bit per tile of a frame: some pixel-map entry touches it
-    int2 ent[ENT_CAP];                  // {pos, value} of the entries that touch the current tile (staged by the loader phase)
     uint32_t xchg[CHAIN ? TCH_ : 1][XCHG_WORDS];     // 5x5: sorted columns / pair list / rank window of each row's halo group
     uint8_t fb_queue[CHAIN ? 256 : 4];  // 5x5: strips whose packed medians are not certain (row * 16 + strip), settled densely
     int fb_count;
@@ -283,13 +281,13 @@ __device__ __forceinline__ void cell_multi_ev_fast(const uint32_t *p0, const uin
     }
 }
 
-// single cell (patch path)
+// single cell (pixel-map path); slow (wave-uniform): with the out-of-table fix-ups
 template <bool SPREAD>
-__device__ __forceinline__ void cell_ev(int r, int g1, int g2, int b, int black, const uint16_t *t, int &ge, int &dr, int &db)
+__device__ __forceinline__ void cell_ev(int r, int g1, int g2, int b, int black, const uint16_t *t, bool slow, int &ge, int &dr, int &db)
 {
     const uint32_t p0[4] = { (uint32_t)r, (uint32_t)g1, (uint32_t)r, (uint32_t)g1 }, p1[4] = { (uint32_t)g2, (uint32_t)b, (uint32_t)g2, (uint32_t)b };
     int g[2], a[2], c[2];
-    cell_pair_ev<SPREAD>(p0, p1, black, t, true, g, a, c);          // rare path: always with the out-of-table fix-ups
+    cell_pair_ev<SPREAD>(p0, p1, black, t, slow, g, a, c);
     ge = g[0]; dr = a[0]; db = c[0];
 }
 
@@ -444,81 +442,47 @@ __device__ __forceinline__ void emit_item(SM &sm, int black, bool slow, int pr, 
     }
 }
 
-// ---------------------------------------------------------------- patches
-// recompute every cell of this tile that a pixel-map entry touches
+// ---------------------------------------------------------------- pixel map
+// A tile's repaired cells arrive as records {cell, R | G1 << 16, G2 | B << 16} (k_pixfix_cells): the EV triple of a record is
+// computed by a lane that has no loader item (the fourth wave, while the other three convert the tile), and goes into the
+// planes -- with the four pixels into the interior raw tile -- once the loader's stores are behind a barrier.
+struct PatchCell { int i, j, ge, dr, db; uint32_t top, bot; };      // i < 0: nothing to store
+
 template <int METHOD, bool PACKED, class SM>
-__device__ __forceinline__ void apply_patches(SM &sm, const FrameArgs &a, const uint8_t *frame, int f, int beg, int end, int tx0, int ty0)
+__device__ __forceinline__ PatchCell patch_cell(const SM &sm, const FrameArgs &a, int4 rec, int tx0, int ty0)
 {
-    const int2 *pl = a.patches + (size_t)f * a.n_patch;
-    for (int k = beg + (int)threadIdx.x; k < end; k += blockDim.x) {
-        const int2 e = pl[a.tile_ent[k]];
-        if (e.x < 0) continue;
-        const int cx = (e.x % a.w) >> 1, cy = (e.x / a.w) >> 1;
-        const int i = cx - (tx0 / 2 - HC), j = cy - (ty0 / 2 - HC);
-        if (i < 0 || i >= PW || j < 0 || j >= SM::PH) continue;
-        int px[4];                                              // r, g1, g2, b of that cell
+    PatchCell c;
+    c.i = -1; c.j = 0; c.ge = c.dr = c.db = 0;
+    c.top = (uint32_t)rec.y; c.bot = (uint32_t)rec.z;
+    const bool have = rec.x >= 0;
+    const int cx = rec.x & 0xFFFF, cy = rec.x >> 16;
+    const int i = cx - (tx0 / 2 - HC), j = cy - (ty0 / 2 - HC);
+    if (have && i >= 0 && i < PW && j >= 0 && j < SM::PH) { c.i = i; c.j = j; }
+    if (METHOD != 0) {
+        const int px[4] = { (int)(c.top & 0xFFFFu), (int)(c.top >> 16), (int)(c.bot & 0xFFFFu), (int)(c.bot >> 16) };
+        bool odd = false;
+        if (c.i >= 0) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) px[q] = (int)fetch_clamped<PACKED>(frame, a.w, a.h, 2 * cx + (q & 1), 2 * cy + (q >> 1));
-        for (int k2 = beg; k2 < end; k2++) {                    // all repaired pixels of this cell
-            const int2 e2 = pl[a.tile_ent[k2]];
-            if (e2.x < 0) continue;
-            const int x2 = e2.x % a.w, y2 = e2.x / a.w;
-            if ((x2 >> 1) == cx && (y2 >> 1) == cy) px[(x2 & 1) + 2 * (y2 & 1)] = e2.y & 0xFFFF;
+            for (int q = 0; q < 4; q++) odd = odd || (unsigned)(px[q] - a.black - 1) >= 16383u;
         }
-        int ge = 0, dr = 0, db = 0;
-        if (METHOD != 0) {
-            cell_ev<SM::SPREAD>(px[0], px[1], px[2], px[3], a.black, sm.t16, ge, dr, db);
-            sm.dr[j][i] = dr;
-            sm.db[j][i] = db;
-        }
-        const int ii = i - HC, jj = j - HC;
-        if (ii >= 0 && ii < TCW && jj >= 0 && jj < SM::TCH) {
-            if (METHOD != 0) sm.ge[jj][ii] = ge;
-            *(uint32_t *)&sm.raw[2 * jj][2 * ii] = (uint32_t)px[0] | ((uint32_t)px[1] << 16);
-            *(uint32_t *)&sm.raw[2 * jj + 1][2 * ii] = (uint32_t)px[2] | ((uint32_t)px[3] << 16);
-        }
+        cell_ev<SM::SPREAD>(px[0], px[1], px[2], px[3], a.black, sm.t16, __any(odd), c.ge, c.dr, c.db);
     }
+    return c;
 }
 
-// the same with the tile's `cnt` entries already staged in sm.ent (fetched while the loader phase ran)
-template <int METHOD, bool PACKED, class SM>
-__device__ __forceinline__ void apply_patches_staged(SM &sm, const FrameArgs &a, const uint8_t *frame, int cnt, int tx0, int ty0)
+template <int METHOD, class SM>
+__device__ __forceinline__ void patch_store(SM &sm, const PatchCell &c)
 {
-    // staged form (stage_entry): x = cell column | cell row << 16 (or -1), y = pixel within the cell | value << 16
-    const int k = threadIdx.x;
-    if (k >= cnt) return;
-    const int2 e = sm.ent[k];
-    if (e.x < 0) return;
-    const int cx = e.x & 0xFFFF, cy = e.x >> 16;
-    const int i = cx - (tx0 / 2 - HC), j = cy - (ty0 / 2 - HC);
-    if (i < 0 || i >= PW || j < 0 || j >= SM::PH) return;
-    int px[4];                                                  // r, g1, g2, b of that cell
-    const int ii0 = i - HC, jj0 = j - HC;
-    if (ii0 >= 0 && ii0 < TCW && jj0 >= 0 && jj0 < SM::TCH) {       // interior cell: its pixels are in LDS already
-        const uint32_t t0 = *(const uint32_t *)&sm.raw[2 * jj0][2 * ii0], t1 = *(const uint32_t *)&sm.raw[2 * jj0 + 1][2 * ii0];
-        px[0] = (int)(t0 & 0xFFFFu); px[1] = (int)(t0 >> 16); px[2] = (int)(t1 & 0xFFFFu); px[3] = (int)(t1 >> 16);
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; q++) px[q] = (int)fetch_clamped<PACKED>(frame, a.w, a.h, 2 * cx + (q & 1), 2 * cy + (q >> 1));
-    }
-    for (int k2 = 0; k2 < cnt; k2++) {                          // all repaired pixels of this cell
-        const int2 e2 = sm.ent[k2];
-        if (e2.x == e.x) {
-            const int sub_ = e2.y & 3, v = (int)((uint32_t)e2.y >> 16);
-            px[0] = sub_ == 0 ? v : px[0]; px[1] = sub_ == 1 ? v : px[1]; px[2] = sub_ == 2 ? v : px[2]; px[3] = sub_ == 3 ? v : px[3];
-        }
-    }
-    int ge = 0, dr = 0, db = 0;
+    if (c.i < 0) return;
     if (METHOD != 0) {
-        cell_ev<SM::SPREAD>(px[0], px[1], px[2], px[3], a.black, sm.t16, ge, dr, db);
-        sm.dr[j][i] = dr;
-        sm.db[j][i] = db;
+        sm.dr[c.j][c.i] = c.dr;
+        sm.db[c.j][c.i] = c.db;
     }
-    const int ii = i - HC, jj = j - HC;
+    const int ii = c.i - HC, jj = c.j - HC;
     if (ii >= 0 && ii < TCW && jj >= 0 && jj < SM::TCH) {
-        if (METHOD != 0) sm.ge[jj][ii] = ge;
-        *(uint32_t *)&sm.raw[2 * jj][2 * ii] = (uint32_t)px[0] | ((uint32_t)px[1] << 16);
-        *(uint32_t *)&sm.raw[2 * jj + 1][2 * ii] = (uint32_t)px[2] | ((uint32_t)px[3] << 16);
+        if (METHOD != 0) sm.ge[jj][ii] = c.ge;
+        *(uint32_t *)&sm.raw[2 * jj][2 * ii] = c.top;
+        *(uint32_t *)&sm.raw[2 * jj + 1][2 * ii] = c.bot;
     }
 }
 
@@ -846,7 +810,6 @@ template <int METHOD, bool PACKED, bool VEC, bool SPREAD>
 __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 {
     using Smem = SmemT<SPREAD, tile_rows_of(METHOD)>;
-    constexpr int ENT_CAP = Smem::ENT_CAP;
     constexpr int TCH = Smem::TCH, N_FULL = Smem::N_FULL, N_ITEMS = Smem::N_ITEMS;
     constexpr bool CHAIN = Smem::CHAIN;
     __shared__ Smem sm;                                  // static: a compile-time LDS base (a dynamic one costs an add per access)
@@ -946,11 +909,14 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         // for data the loader needs anyway --, the entries themselves in flight while the loader phase runs
         const bool tile_patched = a.patch && (!pmap_ok || ((sm.has_patch[tr >> 5] >> (tr & 31)) & 1u));      // wave-uniform
         int pbeg = 0, pend = 0;
-        int2 my_ent = make_int2(-1, 0);
+        int4 my_rec = make_int4(-1, 0, 0, 0);
+        static_assert(N_ITEMS <= 192, "the fourth wave has no loader item: it takes the pixel-map cells");
+        const bool patch_wave = tid >= 192;                    // wave-uniform
+        const int4 *cells = a.cells + (size_t)f * a.n_rec;
         if (tile_patched) {
             pbeg = a.tile_off[tr];
             pend = a.tile_off[tr + 1];
-            if (pend - pbeg <= ENT_CAP && pbeg + tid < pend) my_ent = (a.patches + (size_t)f * a.n_patch)[a.tile_ent[pbeg + tid]];
+            if (patch_wave && pbeg + (tid - 192) < pend) my_rec = cells[pbeg + (tid - 192)];
         }
         // ---- loader: prefetched registers -> EV planes + interior raw pixels
         __builtin_amdgcn_s_setprio(0);
@@ -984,21 +950,19 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             }
             emit_item<METHOD, Smem>(sm, a.black, slow, item_row, item_g, edge, p0, p1);
         }
-        if (tile_patched && pend - pbeg <= ENT_CAP && tid < pend - pbeg) {
-            // one division per entry, here, instead of two per entry pair in apply_patches_staged
-            int2 st = make_int2(-1, 0);
-            if (my_ent.x >= 0) {
-                const int ey = my_ent.x / a.w, ex = my_ent.x - ey * a.w;
-                st = make_int2((ex >> 1) | ((ey >> 1) << 16), ((ex & 1) + 2 * (ey & 1)) | (int)((uint32_t)(my_ent.y & 0xFFFF) << 16));
-            }
-            sm.ent[tid] = st;
-        }
+        PatchCell my_cell;
+        my_cell.i = -1;
+        if (tile_patched && patch_wave) my_cell = patch_cell<METHOD, PACKED, Smem>(sm, a, my_rec, tx0, ty0);      // the first 64 cells of the tile
         if (threadIdx.x == 0) sm.next_ticket = my_ticket;
         lds_barrier();
         const int t_next = band_start + __builtin_amdgcn_readfirstlane(sm.next_ticket);
         if (tile_patched) {
-            if (pend - pbeg <= ENT_CAP) apply_patches_staged<METHOD, PACKED, Smem>(sm, a, frame, pend - pbeg, tx0, ty0);
-            else apply_patches<METHOD, PACKED, Smem>(sm, a, frame, f, pbeg, pend, tx0, ty0);
+            if (patch_wave) patch_store<METHOD, Smem>(sm, my_cell);
+            for (int base = pbeg + 64; base < pend; base += 256) {          // a dense map (focus pixels): the rest, all lanes
+                const int4 rec = base + tid < pend ? cells[base + tid] : make_int4(-1, 0, 0, 0);
+                const PatchCell c = patch_cell<METHOD, PACKED, Smem>(sm, a, rec, tx0, ty0);
+                patch_store<METHOD, Smem>(sm, c);
+            }
             lds_barrier();
         }
         // Waves that are past the loader issue ahead of waves (of the CU's other workgroups) that are still in it: a tile that
@@ -1302,8 +1266,8 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
         int rc = e2r_table(dev, g.black, &a.e2r, stream);
         if (rc) return rc;
     }
-    a.patch = pv && pv->n_patch > 0;
-    if (a.patch) { a.patches = (const int2 *)pv->patches; a.n_patch = pv->n_patch; a.tile_off = pv->tile_off[geo]; a.tile_ent = pv->tile_ent[geo]; }
+    a.patch = pv && pv->n_rec > 0;
+    if (a.patch) { a.cells = (const int4 *)pv->cells; a.n_rec = pv->n_rec; a.tile_off = pv->tile_off; }
     a.stripes = stripes ? 1 : 0;
     a.coef_fast = 1;
     for (int i = 0; i < 8; i++) {

@@ -12,7 +12,9 @@
 // then processes level after level in parallel; a tap with a dependency reads the
 // dependency's repaired value, every other tap reads the ORIGINAL frame (nothing
 // is written back until all levels are done), which is exactly the sequential
-// semantics.  The result is a per-frame patch list {position, value}; it is
+// semantics.  Level 0 (no dependencies: nearly every entry of a real map) runs
+// as a flat grid over entries x frames, the few entries of the levels above in
+// one workgroup per frame.  The result is a per-frame patch list {position, value}; it is
 // either scattered into the 16-bit frame (in-place entry points) or consumed by
 // the fused kernel's tile loader (k_frame.hip), which never materialises the
 // intermediate frame.
@@ -75,17 +77,38 @@ __device__ __forceinline__ int repair_value(int kind, int black, const uint16_t 
     return pixel_of_ev(e, black, u16);
 }
 
-// one workgroup per frame; levels are separated by workgroup barriers
+// Level 0 -- entries none of whose taps was rewritten by an earlier entry; on a real map (isolated hot pixels, the regular grid
+// of a focus-pixel map) that is all of them, tens of thousands per frame for some cameras -- has no order to keep: one lane per
+// entry and frame over the whole grid.
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_pixfix_flat(const uint8_t *__restrict__ frames, size_t stride, int w, int black,
+                                                     const PixEntry *__restrict__ entries, int n_level0, int n_entries,
+                                                     int2 *__restrict__ patches, const uint16_t *__restrict__ t16,
+                                                     const uint16_t *__restrict__ u16)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_level0) return;
+    const uint8_t *frame = frames + (size_t)blockIdx.y * stride;
+    const int pos = entries[m].pos, kind = entries[m].kind, emit = entries[m].emit;
+    int val = 0;
+    if (kind != 0) {
+        auto tap = [&](int t) { return fetch_px<PACKED>(frame, pos + tap_offset(t, w)); };
+        val = repair_value(kind, black, t16, u16, tap) & 0xFFFF;
+    }
+    patches[(size_t)blockIdx.y * n_entries + m] = make_int2((kind != 0 && emit) ? pos : -1, val);
+}
+
+// The levels above: one workgroup per frame, levels separated by workgroup barriers (few entries: pairs of bad pixels within
+// three pixels of each other)
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_pixfix(const uint8_t *__restrict__ frames, size_t stride, int w, int black,
                                                 const PixEntry *__restrict__ entries, const int *__restrict__ level_off,
                                                 int n_levels, int n_entries, int2 *__restrict__ patches,
-                                                uint16_t *scatter_base, size_t scatter_stride,
                                                 const uint16_t *__restrict__ t16, const uint16_t *__restrict__ u16)
 {
     const uint8_t *frame = frames + (size_t)blockIdx.x * stride;
     int2 *out = patches + (size_t)blockIdx.x * n_entries;
-    for (int lv = 0; lv < n_levels; lv++) {
+    for (int lv = 1; lv < n_levels; lv++) {
         const int beg = level_off[lv], end = level_off[lv + 1];
         for (int m = beg + threadIdx.x; m < end; m += blockDim.x) {
             const PixEntry e = entries[m];
@@ -102,28 +125,80 @@ __global__ __launch_bounds__(256) void k_pixfix(const uint8_t *__restrict__ fram
         __threadfence_block();
         __syncthreads();
     }
-    if (scatter_base) {
-        uint16_t *img = (uint16_t *)((uint8_t *)scatter_base + (size_t)blockIdx.x * scatter_stride);
-        for (int m = threadIdx.x; m < n_entries; m += blockDim.x) {
-            const int2 p = out[m];
-            if (p.x >= 0) img[p.x] = (uint16_t)p.y;
-        }
-    }
+}
+
+// in-place entry points: the finished list into the 16-bit frames (after every level: a tap never sees a value of this call
+// unless the list order says so)
+__global__ __launch_bounds__(256) void k_pixfix_scatter(const int2 *__restrict__ patches, int n_entries, uint16_t *scatter_base,
+                                                        size_t scatter_stride)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_entries) return;
+    const int2 p = patches[(size_t)blockIdx.y * n_entries + m];
+    if (p.x >= 0) ((uint16_t *)((uint8_t *)scatter_base + (size_t)blockIdx.y * scatter_stride))[p.x] = (uint16_t)p.y;
 }
 
 int launch_pixfix(bool packed, const void *frames, size_t stride, int w, int black, const void *entries,
-                  const int *level_off, int n_levels, int n_entries, void *patches, void *scatter, size_t scatter_stride,
-                  int nframes, const DeviceLuts &luts, hipStream_t stream)
+                  const int *level_off, int n_levels, int n_level0, int n_entries, void *patches, void *scatter,
+                  size_t scatter_stride, int nframes, const DeviceLuts &luts, hipStream_t stream)
 {
     if (n_entries <= 0 || nframes <= 0) return MLVFS_AMD_OK;
+    const dim3 flat((n_level0 + 255) / 256, nframes), all((n_entries + 255) / 256, nframes);
+    if (packed) {
+        if (n_level0 > 0)
+            hipLaunchKernelGGL(k_pixfix_flat<true>, flat, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
+                               (const PixEntry *)entries, n_level0, n_entries, (int2 *)patches, luts.t16, luts.u16);
+        if (n_levels > 1)
+            hipLaunchKernelGGL(k_pixfix<true>, dim3(nframes), dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
+                               (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches, luts.t16, luts.u16);
+    } else {
+        if (n_level0 > 0)
+            hipLaunchKernelGGL(k_pixfix_flat<false>, flat, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
+                               (const PixEntry *)entries, n_level0, n_entries, (int2 *)patches, luts.t16, luts.u16);
+        if (n_levels > 1)
+            hipLaunchKernelGGL(k_pixfix<false>, dim3(nframes), dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
+                               (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches, luts.t16, luts.u16);
+    }
+    if (scatter)
+        hipLaunchKernelGGL(k_pixfix_scatter, all, dim3(256), 0, stream, (const int2 *)patches, n_entries, (uint16_t *)scatter,
+                           scatter_stride);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+// The fused kernel (k_frame.hip) takes the repair cell by cell: the four pixels of every Bayer cell that holds a repaired pixel
+// -- the repaired ones from the patch list, the others from the frame --, in the order of its per-tile lists.  One lane per
+// listed cell and frame; the kernel then reads one 16-byte record per cell and never looks at the patch list.
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_pixfix_cells(const uint8_t *__restrict__ frames, size_t stride, int w, int h,
+                                                      const CellRec *__restrict__ recs, int n_rec,
+                                                      const int2 *__restrict__ patches, int n_entries, int4 *__restrict__ cells)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rec) return;
+    const uint8_t *frame = frames + (size_t)blockIdx.y * stride;
+    const CellRec rec = recs[r];
+    const int cx = rec.cell & 0xFFFF, cy = rec.cell >> 16;
+    int v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int x = min(2 * cx + (q & 1), w - 1), y = min(2 * cy + (q >> 1), h - 1);
+        v[q] = rec.e[q] >= 0 ? (patches[(size_t)blockIdx.y * n_entries + rec.e[q]].y & 0xFFFF) : fetch_px<PACKED>(frame, y * w + x);
+    }
+    cells[(size_t)blockIdx.y * n_rec + r] = make_int4(rec.cell, v[0] | (v[1] << 16), v[2] | (v[3] << 16), 0);
+}
+
+int launch_pixfix_cells(bool packed, const void *frames, size_t stride, int w, int h, const CellRec *recs, int n_rec,
+                        const void *patches, int n_entries, void *cells, int nframes, hipStream_t stream)
+{
+    if (n_rec <= 0 || nframes <= 0) return MLVFS_AMD_OK;
+    const dim3 grid((n_rec + 255) / 256, nframes);
     if (packed)
-        hipLaunchKernelGGL(k_pixfix<true>, dim3(nframes), dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
-                           (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches,
-                           (uint16_t *)scatter, scatter_stride, luts.t16, luts.u16);
+        hipLaunchKernelGGL(k_pixfix_cells<true>, grid, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, h, recs, n_rec,
+                           (const int2 *)patches, n_entries, (int4 *)cells);
     else
-        hipLaunchKernelGGL(k_pixfix<false>, dim3(nframes), dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
-                           (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches,
-                           (uint16_t *)scatter, scatter_stride, luts.t16, luts.u16);
+        hipLaunchKernelGGL(k_pixfix_cells<false>, grid, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, h, recs, n_rec,
+                           (const int2 *)patches, n_entries, (int4 *)cells);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }

@@ -85,6 +85,39 @@ def test_fused_adversarial(torch_cuda, oracle):
     s.close()
 
 
+@pytest.mark.parametrize("cs", [0, 2, 3, 5])
+@pytest.mark.parametrize("unpacked", [False, True])
+def test_dense_focus_pixel_map(torch_cuda, oracle, cs, unpacked):
+    """A focus-pixel map as some cameras have it: a regular grid, far more than 64 repaired cells per tile (the fused kernel
+    takes the first 64 in its fourth wave during the loader phase, the rest afterwards), neighbours inside one cell and
+    across tile borders, k_pixfix's flat grid over entries x frames."""
+    from mlvfs_amd.stream import to_numpy_u16
+    w, h = 416, 264
+    frames = [synth.normal_frame(w, h, frame=k) for k in range(3)]
+    ys, xs = np.mgrid[6:h - 6:3, 7:w - 8:5]
+    pts = np.stack([xs.reshape(-1), ys.reshape(-1)], 1).astype(np.int32)
+    edge = [[1, 50], [w - 2, 60], [100, 1], [120, h - 2], [2, 2], [w - 1, h - 1], [0, 100]]       # the edge rules of cs.c:479-497
+    pts = np.concatenate([pts, pts[::7] + [1, 0], edge]).astype(np.int32)   # some cells with two repaired pixels
+    assert len(pts) > 7000
+    want = [oracle.apply_focus_pixels(f, BLACK, pts, (0, 0), 0) for f in frames]
+    if cs:
+        want = [oracle.chroma_smooth(f, BLACK, cs) for f in want]
+    s = make_stream(w, h)
+    s.set_pixel_map(pts, kind=1)
+    packed = s.upload_packed([synth.pack_bits(f) for f in frames])
+    if unpacked:
+        got = to_numpy_u16(s.process_unpacked(s.unpack(packed), cs=cs, fix_pixels=True, stripes=False))
+    else:
+        got = to_numpy_u16(s.process(packed, cs=cs, fix_pixels=True, stripes=False))
+    for k in range(3):
+        assert np.array_equal(got[k], want[k]), f"frame {k}: {(got[k] != want[k]).sum()} px differ"
+    # the in-place stage (scatter kernel) agrees
+    staged = to_numpy_u16(s.fix_pixels(s.unpack(packed)))
+    for k in range(3):
+        assert np.array_equal(staged[k], oracle.apply_focus_pixels(frames[k], BLACK, pts, (0, 0), 0))
+    s.close()
+
+
 def test_stage_api_matches_fused(torch_cuda, oracle):
     """unpack_dev -> fix_pixels_dev -> chroma_smooth_dev -> stripes_apply_dev == fused launch."""
     from mlvfs_amd.stream import to_numpy_u16

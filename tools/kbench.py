@@ -23,6 +23,8 @@ packed = s.alloc_packed(F)
 for i in range(0, F, 8):
     packed[i:i + 8] = base[:min(8, F - i)]
 out = s.alloc_out(F)
+if os.environ.get("KB_LAYOUT"):                         # 1 = plain, 2 = spread raw2ev table in LDS (default: decided from the first frame)
+    s.set_t16_layout(int(os.environ["KB_LAYOUT"]))
 frame0 = s.unpack(packed[:1])
 s.detect_bad_pixels(frame0[0], 0)
 s.set_stripes(1, [65536, 65536, 65354, 65738, 65241, 65868, 65450, 65640])
