@@ -57,6 +57,7 @@ constexpr int PW = TCW + 2 * HC;        // plane width  (68)
 constexpr int STRIP = 4;                // cells per thread in the median phase
 constexpr int GROUPS = TCW / 8;         // full items per plane row (8)
 constexpr int DARK_ITEMS_MIN = 16;      // of the loader items of a tile
+constexpr int FB_ROBUST = 12;           // 5x5: more uncertain strips than this: the next tiles' lanes share their references row by row
 constexpr int FB_DIRECT = 100;          // 5x5: more uncertain strips than this (of 240): the next tiles go to the 32-bit networks directly
 constexpr int PMAP_WORDS = 64;          // tiles per frame covered by the LDS patch bitmap: 2048 (3584x1320 has 1176 / 1232)
 // Tile height in cells: 16 rows of 16 strips fill the 256 threads; 5x5 tiles have 15 rows, the 16 lanes that this frees
@@ -594,13 +595,43 @@ struct ChainGroup {
     int ref_r, ref_b;
 };
 
-__device__ __forceinline__ void chain_group(const int (*pr_)[PW], const int (*pb_)[PW], int row_top, int col_left, ChainGroup &g)
+// Noisy shadows: the colour difference of a cell is, at a signal of a few DN, an EV or more away from the median of its
+// neighbourhood, and so are many of the lanes' references -- from the window's median (first reason to be uncertain) and from
+// each other (|D| eats the window: second reason).  A row's 16 lanes then agree on ONE reference, the median of five of
+// theirs (lanes 1, 4, 8, 11, 14 of the row: v_mov_b32 row_share), provided at least ten of the sixteen lie within 1 EV of it;
+// rows across a colour edge do not and keep their own.  Any reference gives exact medians (the criterion of chain_finish holds
+// for whatever the lanes subtracted); this only decides how many strips are certain: underexposed footage 19 % -> 5 % uncertain.
+// Costs 16 instructions per plane, so it runs only after a tile that had uncertain strips (k_frame: `robust`).
+template <int N>
+__device__ __forceinline__ int dpp_row_share(int v) { return __builtin_amdgcn_mov_dpp(v, 0x150 + N, 0xf, 0xf, true); }
+
+__device__ __forceinline__ int robust_ref(int own)
+{
+    const int a = dpp_row_share<1>(own), b = dpp_row_share<4>(own), c = dpp_row_share<8>(own), d = dpp_row_share<11>(own),
+              e = dpp_row_share<14>(own);
+    const int shared = med3i(e, max(min(a, b), min(c, d)), min(max(a, b), max(c, d)));       // median of five
+    const unsigned long long agree = __ballot((unsigned)(own - shared + 32767) < 65535u);
+    unsigned long long use = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        if (__builtin_popcount((unsigned)(agree >> (16 * r)) & 0xFFFFu) >= 10) use |= 0xFFFFull << (16 * r);
+    int ref;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(ref) : "v"(own), "v"(shared), "s"(use));
+    return ref;
+}
+
+__device__ __forceinline__ void chain_group(const int (*pr_)[PW], const int (*pb_)[PW], int row_top, int col_left, bool robust,
+                                            ChainGroup &g)
 {
     // reference = median of three cells of the group's centre row (a single cell is, in noisy shadows, often more than 1 EV
     // away from the median of its neighbourhood)
     const int4 cr = *(const int4 *)&pr_[row_top + 2][col_left], cb = *(const int4 *)&pb_[row_top + 2][col_left];
     g.ref_r = med3i(cr.y, cr.z, cr.w);
     g.ref_b = med3i(cb.y, cb.z, cb.w);
+    if (robust) {                                          // wave-uniform
+        g.ref_r = robust_ref(g.ref_r);
+        g.ref_b = robust_ref(g.ref_b);
+    }
     auto pack = [&](int r, int b) {
         return __builtin_amdgcn_cvt_pk_i16(__builtin_elementwise_sub_sat(r, g.ref_r), __builtin_elementwise_sub_sat(b, g.ref_b));
     };
@@ -898,6 +929,8 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 #endif
     int par = 0;                               // tile parity: which of the two dark_items counters this tile uses
     int fb_prev = 0, fb_run = 0;               // 5x5: uncertain strips of the last tile that tried the packed networks; tiles since
+    bool robust = false;                       // 5x5: rows of lanes agree on their references (robust_ref)
+    int calm = 0;                              //      tiles in a row without an uncertain strip
     while (t < band_end) {
         int my_ticket = 0;
         if (threadIdx.x == 0) my_ticket = atomicAdd(&a.tickets[grp], 1);       // the tile after this one: back long before it is needed
@@ -1057,7 +1090,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             bool unknown = true;
             if (!skip_packed) {
                 ChainGroup g;
-                chain_group(sm.dr, sm.db, j, is_strip ? STRIP * k : TCW, g);          // a strip's own group, or a row's halo group
+                chain_group(sm.dr, sm.db, j, is_strip ? STRIP * k : TCW, robust, g);  // a strip's own group, or a row's halo group
                 const bool halo_wave = tid >= 192;                     // the wave that holds the halo groups' lanes (uniform)
                 if (halo_wave) {
                     chain_group_window(g);
@@ -1092,7 +1125,19 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             // one per lane -- as many waves as ceil(count / 64) run them, instead of every wave that had one such strip.
             lds_barrier();
             const int nfb = __builtin_amdgcn_readfirstlane(sm.fb_count);
-            if (!skip_packed) fb_prev = nfb;
+            if (!skip_packed) {
+                fb_prev = nfb;
+                // shared references (robust_ref) from the tile after one with uncertain strips until four tiles in a row had none
+                calm = nfb == 0 ? calm + 1 : 0;
+                robust = nfb > FB_ROBUST || (robust && calm < 4);
+            }
+#ifdef KF_DIAG_TIMES
+            if (tid == 0 && a.times) {                         // tiles, tiles that skipped the packed networks, strips settled densely
+                atomicAdd(&a.times[4096], 1ull);
+                if (skip_packed) atomicAdd(&a.times[4097], 1ull);
+                atomicAdd(&a.times[4098], (unsigned long long)nfb);
+            }
+#endif
             if (nfb > 0) {
                 if ((tid & ~63) < nfb) {                               // this wave has entries
                     const int e = sm.fb_queue[min(tid, nfb - 1)];
@@ -1203,7 +1248,8 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
     a.groups = std::min(std::max(grid / 4, 1), MAX_GROUPS);
 #ifdef KF_DIAG_TIMES
     static unsigned long long *d_times = nullptr;
-    if (!d_times) hipMalloc(&d_times, 2048 * 2 * sizeof(unsigned long long));
+    if (!d_times) hipMalloc(&d_times, (2048 * 2 + 8) * sizeof(unsigned long long));
+    hipMemsetAsync(d_times + 4096, 0, 8 * sizeof(unsigned long long), stream);
     const_cast<FrameArgs &>(a).times = d_times;
 #endif
     KernelTimer &tm = kernel_timer();
@@ -1223,6 +1269,10 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
             for (int b = 0; b < grid; b++) { t0 = std::min(t0, h[2 * b]); t1 = std::max(t1, h[2 * b + 1]); }
             double end_q[4] = { 0, 0, 0, 0 }, start_q[4] = { 0, 0, 0, 0 };
             for (int b = 0; b < grid; b++) { end_q[b * 4 / grid] += (double)(h[2 * b + 1] - t0); start_q[b * 4 / grid] += (double)(h[2 * b] - t0); }
+            unsigned long long fbc[3];
+            hipMemcpy(fbc, d_times + 4096, sizeof(fbc), hipMemcpyDeviceToHost);
+            fprintf(stderr, "KF_TIMES tiles %llu, of which %llu skipped the packed networks; strips settled densely %llu (%.1f %% of all)\n", fbc[0], fbc[1],
+                    fbc[2], fbc[0] ? 100.0 * fbc[2] / (240.0 * fbc[0]) : 0.0);
             fprintf(stderr, "KF_TIMES grid %d: kernel %.1f us; mean start / end of the workgroups of each quarter of the grid (us):", grid, (t1 - t0) * 0.01);
             for (int q = 0; q < 4; q++) fprintf(stderr, "  %.1f / %.1f", start_q[q] / (grid / 4) * 0.01, end_q[q] / (grid / 4) * 0.01);
             fprintf(stderr, "\n");
