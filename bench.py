@@ -304,7 +304,7 @@ def extra_pcie(N=128, threads=16):
 
     want1 = synth.fnv1a(want[1].numpy().view(np.uint16))
     # (b) the drop-in symbols, in a child process per mode (the library reads MLVFS_AMD_RESIDENT once per process)
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         env = dict(os.environ, MLVFS_AMD_RESIDENT=mode)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dropin_bench.py"), str(threads), "12"], env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
@@ -314,10 +314,12 @@ def extra_pcie(N=128, threads=16):
             continue
         d = json.loads(line[-1])
         res[f"dropin_symbols_resident{mode}"] = {"fps_1_thread": d["fps_1_threads"], f"fps_{threads}_threads": d[f"fps_{threads}_threads"],
-                                                 "calls_per_frame": 5, "equals_batch_api": d["frame1_hash"] == want1,
+                                                 "calls_per_frame": 5 + (mode == "2"), "equals_batch_api": d["frame1_hash"] == want1,
                                                  "identical_between_threads": d["identical_between_threads"]}
     res["note"] = "resident1: MLVFS_AMD_RESIDENT=1, a stage takes up the device copy the previous stage left for the same host buffer " \
-                  "(upload skipped; every call still downloads what it changed before it returns)"
+                  "(upload skipped; every call still downloads what it changed before it returns).  resident2: no stage downloads, " \
+                  "the host calls mlvfs_amd_frame_sync(buffer) after the last one (one line in process_frame, INTEGRATION.md); " \
+                  "a C host with pthreads: tools/dropin_bench_c.sh"
     return res
 
 

@@ -196,6 +196,9 @@ int mlvfs_amd_process_unpacked_dev(mlvfs_amd_clip_t *clip, const void *d_frames,
 int mlvfs_amd_process_frames_host(mlvfs_amd_clip_t *clip, const void *h_packed, size_t packed_stride, void *h_out,
                                   size_t out_stride, int nframes, int cs_method, int fix_pixels, int apply_stripes,
                                   int chunk_frames);
+/* Page-locked buffers, pooled: a freed buffer is kept (up to 2 GiB in all) and handed out again for the next request of its
+ * size, so a host may allocate and free one per frame like process_frame does with malloc (main.c:931).  With frame buffers
+ * from here the drop-in symbols of PART 1 copy at the link's speed instead of the pageable path's. */
 void *mlvfs_amd_host_alloc(size_t bytes);
 void mlvfs_amd_host_free(void *p);
 
@@ -283,6 +286,12 @@ int mlvfs_amd_amaze_demosaic_dev(const float *d_raw, int width, int height, floa
  * the events, writes one duration in milliseconds per launch, returns the count. */
 int mlvfs_amd_timer_begin(int max_launches);
 int mlvfs_amd_timer_end(float *ms, int cap);
+
+/* MLVFS_AMD_RESIDENT=2 in the environment: the drop-in stages of PART 1 leave their result for `image_data` on the GPU and do
+ * not write the host buffer; this call, by the same thread after the last stage, fetches it (one download per frame instead of
+ * one per stage).  What main.c:996 would be followed by in process_frame -- see INTEGRATION.md.  In every other mode, and for a
+ * buffer nothing is pending for, it does nothing.  0 = the host buffer is current. */
+int mlvfs_amd_frame_sync(void *image_data);
 
 /* self tests that need no GPU (selection networks, LUT identities): 0 = pass */
 int mlvfs_amd_selftest_host(void);

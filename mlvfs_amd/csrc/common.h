@@ -85,6 +85,8 @@ struct ThreadCtx {         // one per (host thread, device)
     size_t res_bytes = 0;
     int res_cur = 0;
     int res_rank = 0;                    // which stage left the resident copy (dropin.cpp: stages only continue in process_frame's order)
+    bool res_dirty = false;              // MLVFS_AMD_RESIDENT=2: the resident copy is newer than the host buffer (mlvfs_amd_frame_sync)
+    hipEvent_t ev_up = nullptr;          // end of the upload of dng_get_image_data's input (dropin.cpp, MLVFS_AMD_RESIDENT=2)
     uint64_t res_sig[RES_SAMPLES];
     int ensure_res(size_t bytes);
     int ensure(size_t need_a, size_t need_b);
@@ -98,6 +100,10 @@ void release_stream_state(int device, hipStream_t stream);
 
 // returns nullptr (and sets the error string) on failure
 ThreadCtx *thread_ctx();
+// a symbol that reads or rewrites the host frame itself: bring the host copy up to date if a deferred result of this thread is
+// pending for it (MLVFS_AMD_RESIDENT=2), then forget the resident copy (dropin.cpp)
+int drop_resident(ThreadCtx *c, void *host);
+
 int bind_device(int device);
 
 // host copies of the reference tables (built once; luts.cpp)

@@ -9,6 +9,8 @@
 // the reference's failure value.  There is deliberately no CPU fallback.
 #include "clip.h"
 
+#include <atomic>
+
 #include <cerrno>
 #include <cstdlib>
 #include <cstring>
@@ -66,13 +68,20 @@ Clip *make_clip(const FrameView &v, ThreadCtx *c)
 // (Copies to and from the caller's pageable memory are the runtime's: staging them through a page-locked buffer of the thread's
 // own, chunk by chunk with the copying done by the calling thread, was measured and is slower -- 795 against 1093 frames/s
 // from 16 threads.)
+// MLVFS_AMD_RESIDENT=2 goes one step further for a host that calls mlvfs_amd_frame_sync(buffer) after the last stage (one line
+// in process_frame): the stages do not download at all, the frame crosses the link once in each direction --
+// 17.7 MB instead of 37-75 -- and the host buffer is NOT current until that call returns.
 enum { RANK_UNPACK = 0, RANK_FOCUS = 1, RANK_BAD = 2, RANK_CS = 3, RANK_STRIPES_READ = 4, RANK_STRIPES = 5 };
 
-bool resident_mode()
+int resident_level()
 {
-    static const bool on = [] { const char *e = getenv("MLVFS_AMD_RESIDENT"); return e && e[0] == '1'; }();
-    return on;
+    static const int level = [] {
+        const char *e = getenv("MLVFS_AMD_RESIDENT");
+        return e && e[0] == '2' ? 2 : (e && e[0] == '1' ? 1 : 0);
+    }();
+    return level;
 }
+bool resident_mode() { return resident_level() >= 1; }
 
 void sample_host(const void *host, size_t bytes, uint64_t (&sig)[ThreadCtx::RES_SAMPLES])
 {
@@ -86,6 +95,25 @@ void sample_host(const void *host, size_t bytes, uint64_t (&sig)[ThreadCtx::RES_
     }
 }
 
+void warn_unsynced(const void *host)
+{
+    static std::atomic<bool> said{ false };
+    if (!said.exchange(true))
+        fprintf(stderr, "mlvfs_amd: MLVFS_AMD_RESIDENT=2, but the frame at %p was never fetched with mlvfs_amd_frame_sync(): "
+                        "its host buffer holds stale pixels\n", host);
+}
+
+int download(ThreadCtx *c, void *host, const void *dev, size_t bytes);
+
+// host -> device on the thread's stream.  (Copies of the sixteen threads through ONE upload and ONE download stream per device,
+// for page-locked buffers, were tried: no faster at 16 threads -- 1 200 frames/s, the level a bare copy loop of 16 threads
+// reaches 1 840 at, tools/zerocopy_probe.hip -- and slower without MLVFS_AMD_RESIDENT.)
+int upload(ThreadCtx *c, void *dev, const void *host, size_t bytes)
+{
+    MLV_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return MLVFS_AMD_OK;
+}
+
 // device buffer that holds the frame at `host`: the resident copy, or a fresh upload
 int stage_frame(ThreadCtx *c, const void *host, size_t bytes, int rank, void **d_cur, void **d_other)
 {
@@ -93,14 +121,25 @@ int stage_frame(ThreadCtx *c, const void *host, size_t bytes, int rank, void **d
     if (rc) return rc;
     bool have = false;
     if (resident_mode() && c->res_host == host && c->res_bytes == bytes && rank > c->res_rank) {
-        uint64_t now[ThreadCtx::RES_SAMPLES];
-        sample_host(host, bytes, now);
-        have = memcmp(now, c->res_sig, sizeof now) == 0;
+        if (c->res_dirty) have = true;             // the host buffer is behind by design: nothing to compare
+        else {
+            uint64_t now[ThreadCtx::RES_SAMPLES];
+            sample_host(host, bytes, now);
+            have = memcmp(now, c->res_sig, sizeof now) == 0;
+        }
     }
     if (!have) {
+        if (c->res_dirty) {                        // a deferred result is pending and this call does not continue it
+            if (c->res_host == host) {             // (waits: the upload below reads the host buffer when it is queued)
+                rc = download(c, const_cast<void *>(host), c->d_res[c->res_cur], c->res_bytes);
+                if (rc) return rc;
+            } else warn_unsynced(c->res_host);
+        }
+        c->res_dirty = false;
         c->res_host = nullptr;
         c->res_cur = 0;
-        MLV_HIP(hipMemcpyAsync(c->d_res[0], host, bytes, hipMemcpyHostToDevice, c->stream));
+        rc = upload(c, c->d_res[0], host, bytes);
+        if (rc) return rc;
     }
     *d_cur = c->d_res[c->res_cur];
     if (d_other) *d_other = c->d_res[c->res_cur ^ 1];
@@ -112,6 +151,7 @@ void commit_frame(ThreadCtx *c, const void *host, size_t bytes, int rank, int wh
 {
     c->res_cur = which;
     c->res_rank = rank;
+    c->res_dirty = false;
     if (!resident_mode()) { c->res_host = nullptr; return; }
     c->res_host = host;
     c->res_bytes = bytes;
@@ -122,6 +162,28 @@ int download(ThreadCtx *c, void *host, const void *dev, size_t bytes)
 {
     MLV_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
     MLV_HIP(hipStreamSynchronize(c->stream));
+    return MLVFS_AMD_OK;
+}
+
+// A stage is done with the frame in device buffer `which`: download it (all of it, or -- pixel repairs -- the n_patched
+// entries of the thread's patch list) and remember the copy; MLVFS_AMD_RESIDENT=2: remember it as newer than the host buffer
+int download_patches(ThreadCtx *c, uint16_t *image, size_t npix, int n_entries);
+int finish_frame(ThreadCtx *c, void *host, size_t bytes, int rank, int which, int n_patched = -1)
+{
+    if (resident_level() == 2) {
+        c->res_cur = which;
+        c->res_rank = rank;
+        c->res_host = host;
+        c->res_bytes = bytes;
+        c->res_dirty = true;
+        return MLVFS_AMD_OK;
+    }
+    int rc = MLVFS_AMD_OK;
+    if (n_patched < 0) rc = download(c, host, c->d_res[which], bytes);
+    else if (n_patched > 0) rc = download_patches(c, (uint16_t *)host, bytes / 2, n_patched);
+    else if (hipStreamSynchronize(c->stream) != hipSuccess) rc = MLVFS_AMD_ERR_HIP;
+    if (rc) return rc;
+    commit_frame(c, host, bytes, rank, which);
     return MLVFS_AMD_OK;
 }
 
@@ -178,7 +240,33 @@ std::mutex g_focus_mutex;
 
 }  // namespace
 
+int mlv::drop_resident(ThreadCtx *c, void *host)
+{
+    int rc = MLVFS_AMD_OK;
+    if (c->res_dirty) {
+        if (c->res_host == host) rc = download(c, host, c->d_res[c->res_cur], c->res_bytes);
+        else warn_unsynced(c->res_host);
+    }
+    c->res_dirty = false;
+    c->res_host = nullptr;
+    return rc;
+}
+
 extern "C" {
+
+// MLVFS_AMD_RESIDENT=2: the stages called on `image_data` by this thread left their result on the GPU; fetch it.  A no-op in
+// the other modes and for a buffer nothing is pending for.  0 = the host buffer is current.
+int mlvfs_amd_frame_sync(void *image_data)
+{
+    ThreadCtx *c = thread_ctx();
+    if (!c) return MLVFS_AMD_ERR_HIP;
+    if (!c->res_dirty || c->res_host != image_data) return MLVFS_AMD_OK;
+    LibcRandGuard rand_guard;
+    if (download(c, image_data, c->d_res[c->res_cur], c->res_bytes)) return MLVFS_AMD_ERR_HIP;
+    c->res_dirty = false;
+    sample_host(image_data, c->res_bytes, c->res_sig);          // later stages may still take the copy up (as with RESIDENT=1)
+    return MLVFS_AMD_OK;
+}
 
 // ============================================================== dng.h
 size_t dng_get_header_size(void) { return 65536; }                                   // dng.c:797-800 (HEADER_SIZE)
@@ -213,14 +301,30 @@ size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8
     const size_t in_bytes = words * 2, out_b = (size_t)npix * 2;
     if (c->ensure((in_bytes + 15) / 16 * 16, 0) || c->ensure_res((out_b + 15) / 16 * 16)) return 0;
     c->res_host = nullptr;
-    if (hipMemcpyAsync(c->d_a, packed_bits, in_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+    if (c->res_dirty) warn_unsynced(c->res_host);
+    c->res_dirty = false;
+    if (upload(c, c->d_a, packed_bits, in_bytes)) {
         set_error("dng_get_image_data: upload failed");
         return 0;
     }
+    // MLVFS_AMD_RESIDENT=2 returns without waiting for the stream, but packed_bits is the caller's again on return: if it is
+    // page-locked memory the copy above is still under way then (from pageable memory it is not), so its end gets an event
+    const bool deferred = resident_level() == 2 && offset == 0 && out_b == dng_get_image_size(fh);
+    if (deferred) {
+        if (!c->ev_up && hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming) != hipSuccess) return 0;
+        if (hipEventRecord(c->ev_up, c->stream) != hipSuccess) return 0;
+    }
     if (launch_unpack(c->d_a, 0, c->d_res[0], 0, first_px, npix, bpp, 1, c->stream)) return 0;
     uint8_t *dst = output_buffer + lead + offset % 2;
-    if (download(c, dst, c->d_res[0], out_b)) return 0;
-    commit_frame(c, dst, out_b, RANK_UNPACK, 0);   // the next stage on this buffer finds it on the device (MLVFS_AMD_RESIDENT=1)
+    // process_frame's call -- the whole frame (main.c:942) --: the next stage on this buffer finds it on the device
+    // (MLVFS_AMD_RESIDENT=1, 2); a window of the frame is delivered at once in every mode
+    if (offset == 0 && out_b == dng_get_image_size(fh)) {
+        if (finish_frame(c, dst, out_b, RANK_UNPACK, 0)) return 0;
+        if (deferred && hipEventSynchronize(c->ev_up) != hipSuccess) return 0;
+    } else {
+        if (download(c, dst, c->d_res[0], out_b)) return 0;
+        commit_frame(c, dst, out_b, RANK_UNPACK, 0);
+    }
     return max_size;
 }
 
@@ -240,8 +344,7 @@ void chroma_smooth(struct frame_headers *fh, uint16_t *image_data, int method)
     if (launch_frame(c->dev, Geom{ v.w, v.h, v.bpp, v.black, v.white }, false, d_in, bytes, d_out, bytes, 1, method,
                      nullptr, false, nullptr, c->stream))
         return;
-    if (download(c, image_data, d_out, bytes)) return;
-    commit_frame(c, image_data, bytes, RANK_CS, d_out == c->d_res[1]);
+    (void)finish_frame(c, image_data, bytes, RANK_CS, d_out == c->d_res[1]);
 }
 
 // device-level forms (frame already in HBM at d_frame): shared with the dual-ISO path
@@ -378,9 +481,7 @@ void fix_bad_pixels(struct frame_headers *fh, uint16_t *image_data, int aggressi
     c->res_host = nullptr;
     int n_patched = 0;
     if (bad_pixels_device(fh, c, d_in, aggressive, dual_iso, nullptr, &n_patched)) return;
-    if (n_patched > 0) { if (download_patches(c, image_data, npix, n_patched)) return; }
-    else if (hipStreamSynchronize(c->stream) != hipSuccess) return;
-    commit_frame(c, image_data, bytes, RANK_BAD, which);
+    (void)finish_frame(c, image_data, bytes, RANK_BAD, which, n_patched);
 }
 
 void fix_focus_pixels(struct frame_headers *fh, uint16_t *image_data, int dual_iso)
@@ -401,9 +502,7 @@ void fix_focus_pixels(struct frame_headers *fh, uint16_t *image_data, int dual_i
     c->res_host = nullptr;
     int n_patched = 0;
     if (focus_pixels_device(fh, c, d_in, dual_iso, nullptr, &n_patched)) return;
-    if (n_patched > 0) { if (download_patches(c, image_data, npix, n_patched)) return; }
-    else if (hipStreamSynchronize(c->stream) != hipSuccess) return;
-    commit_frame(c, image_data, bytes, RANK_FOCUS, which);
+    (void)finish_frame(c, image_data, bytes, RANK_FOCUS, which, n_patched);
 }
 
 void free_focus_pixel_maps(void)                                                     // cs.c:403-418
@@ -502,8 +601,7 @@ void stripes_apply_correction(struct frame_headers *fh, struct stripes_correctio
     if (padded == size) {
         if (stage_frame(c, image_data, bytes, RANK_STRIPES, &d_in, nullptr)) return;
     } else {                                        // a window that is not a whole number of 8-pixel groups: zero-padded copy
-        if (c->ensure_res(bytes)) return;
-        c->res_host = nullptr;
+        if (drop_resident(c, image_data) || c->ensure_res(bytes)) return;
         c->res_cur = 0;
         d_in = c->d_res[0];
         if (hipMemsetAsync(d_in, 0, bytes, c->stream) != hipSuccess) return;
@@ -515,8 +613,8 @@ void stripes_apply_correction(struct frame_headers *fh, struct stripes_correctio
     const int which = c->res_cur;
     c->res_host = nullptr;
     if (launch_stripes_apply(d_in, bytes, padded, v.w, v.black, v.white, coef, 1, c->stream)) return;
-    if (download(c, image_data, d_in, size * 2)) return;
-    if (padded == size) commit_frame(c, image_data, bytes, RANK_STRIPES, which);
+    if (padded == size) (void)finish_frame(c, image_data, bytes, RANK_STRIPES, which);
+    else (void)download(c, image_data, d_in, size * 2);
 }
 
 // ============================================================== histogram.h (host only)

@@ -637,7 +637,7 @@ int cr2hdr20_convert_data(struct frame_headers *fh, uint16_t *image_data, int in
     const int w = fh->rawi_hdr.xRes, h = fh->rawi_hdr.yRes;
     ThreadCtx *c = thread_ctx();
     if (!c) return 0;
-    c->res_host = nullptr;                         // this call rewrites the host frame: no resident copy of it (dropin.cpp)
+    if (drop_resident(c, image_data)) return 0;             // this call rewrites the host frame: no resident copy of it (dropin.cpp)
     const size_t bytes = (size_t)w * h * 2;
     if (c->ensure(bytes, 0)) return 0;
     if (hipMemcpyAsync(c->d_a, image_data, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { set_error("cr2hdr20: upload failed"); return 0; }

@@ -138,7 +138,7 @@ int hdr_convert_data(struct frame_headers *fh, uint16_t *image_data, off_t offse
                   fh->rawi_hdr.raw_info.white_level };
     ThreadCtx *c = thread_ctx();
     if (!c) return 0;
-    c->res_host = nullptr;                         // this call rewrites the host frame: no resident copy of it (dropin.cpp)
+    if (drop_resident(c, image_data)) return 0;             // this call rewrites the host frame: no resident copy of it (dropin.cpp)
     const size_t bytes = (size_t)w * h * 2;
     const size_t hist_bytes = 4 * (size_t)((uint16_t)g.white + 1) * sizeof(unsigned);
     if (c->ensure(bytes, hist_bytes)) return 0;

@@ -19,7 +19,7 @@ extern "C" void fix_pattern_noise(int16_t *raw, int w, int h, int white, int deb
     if (w < 2 || h < 2 || (w & 1) || (h & 1)) { set_error("fix_pattern_noise: %dx%d frame not supported", w, h); return; }
     ThreadCtx *c = thread_ctx();
     if (!c) return;
-    c->res_host = nullptr;                         // this call rewrites the host frame: no resident copy of it (dropin.cpp)
+    if (drop_resident(c, raw)) return;             // this call rewrites the host frame: no resident copy of it (dropin.cpp)
     const size_t bytes = (size_t)w * h * 2;
     if (c->ensure(bytes, pattern_noise_scratch_bytes(w, h))) return;
     if (hipMemcpyAsync(c->d_a, raw, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { set_error("fix_pattern_noise: upload failed"); return; }

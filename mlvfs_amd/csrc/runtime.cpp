@@ -191,6 +191,7 @@ ThreadCtx::~ThreadCtx()
     if (d_res[0]) (void)hipFree(d_res[0]);
     if (d_res[1]) (void)hipFree(d_res[1]);
     if (h_pin) (void)hipHostFree(h_pin);
+    if (ev_up) (void)hipEventDestroy(ev_up);
 }
 
 static int visible_devices()

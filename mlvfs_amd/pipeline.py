@@ -80,4 +80,6 @@ def process_frame(packed: np.ndarray, fh: abi.FrameHeaders, opt: MlvfsOptions, m
             if corr:
                 L.stripes_compute_correction(C.byref(fh), corr, p, 0, img.size)
         L.stripes_apply_correction(C.byref(fh), corr, p, 0, img.size)
+    # the one line a host adds to run with MLVFS_AMD_RESIDENT=2; does nothing in the other modes
+    lib.check(L.mlvfs_amd_frame_sync(p), "frame_sync")
     return img

@@ -49,6 +49,7 @@ int main(int argc, char **argv)
         }
         stripes_apply_correction(&fh, c, img, 0, npix);
     }
+    if (mlvfs_amd_frame_sync(img) != 0) { fprintf(stderr, "frame sync failed\n"); return 6; }     /* the line MLVFS_AMD_RESIDENT=2 asks of main.c:996 */
     f = fopen(argv[2], "wb");
     if (!f) return 5;
     fwrite(img, 2, npix, f);

@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BLACK, WHITE = synth.BLACK, synth.WHITE
 RESIDENT = os.environ.get("MLVFS_AMD_RESIDENT") == "1"
+DEFERRED = os.environ.get("MLVFS_AMD_RESIDENT") == "2"
 
 
-@pytest.mark.skipif(RESIDENT, reason="this is the child")
+@pytest.mark.skipif(RESIDENT or DEFERRED, reason="this is the child")
 def test_dropin_suite_in_resident_mode(gpu):
     env = dict(os.environ, MLVFS_AMD_RESIDENT="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_resident.py", "tests/test_gpu_threads.py",
@@ -61,3 +62,90 @@ def test_resident_frames_equal_the_oracle_and_notice_host_changes(gpu, oracle):
     gpu.stripes_apply_correction(C.byref(fh), corr, lib.ptr(other), 0, other.size)
     assert np.array_equal(other, want)
     gpu.stripes_free_corrections()
+
+
+# ---------------------------------------------------------------------------------------------- MLVFS_AMD_RESIDENT=2
+@pytest.mark.skipif(RESIDENT or DEFERRED, reason="this is the child")
+def test_deferred_mode_in_a_child_process(gpu):
+    """MLVFS_AMD_RESIDENT=2: no stage downloads, mlvfs_amd_frame_sync() does.  The C host (tests/c_host.c) and the Python mirror
+    of process_frame call it after the last stage; the tests below (child only) check the mode itself."""
+    env = dict(os.environ, MLVFS_AMD_RESIDENT="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_resident.py", "tests/test_gpu_c_host.py",
+                        "-k", "deferred or c_program"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def _unpack_into(gpu, fh, f, img):
+    packed = np.ascontiguousarray(synth.pack_bits(f), np.uint16)
+    assert gpu.dng_get_image_data(C.byref(fh), lib.ptr(packed), lib.ptr(img), 0, img.nbytes) == img.nbytes
+
+
+@pytest.mark.skipif(not DEFERRED, reason="needs MLVFS_AMD_RESIDENT=2 (run by test_deferred_mode_in_a_child_process)")
+def test_deferred_stages_leave_the_host_buffer_alone_until_the_sync(gpu, oracle):
+    w, h = 416, 264
+    f = synth.normal_frame(w, h, hot=100, cold=100)
+    fh = abi.make_frame_headers(w, h, black=BLACK, white=WHITE)
+    img = np.full((h, w), 0xABCD, np.uint16)
+    _unpack_into(gpu, fh, f, img)
+    gpu.fix_focus_pixels(C.byref(fh), lib.ptr(img), 0)
+    gpu.fix_bad_pixels(C.byref(fh), lib.ptr(img), 0, 0)
+    gpu.chroma_smooth(C.byref(fh), lib.ptr(img), 5)
+    corr = gpu.stripes_new_correction(b"deferred.MLV")
+    corr.contents.correction_needed = 1
+    co = [65536, 65536, 65354, 65738, 65241, 65868, 65450, 65640]
+    for k2 in range(8):
+        corr.contents.coeffficients[k2] = co[k2]
+    gpu.stripes_apply_correction(C.byref(fh), corr, lib.ptr(img), 0, img.size)
+    assert (img == 0xABCD).all(), "a stage wrote the host buffer"
+    assert gpu.mlvfs_amd_frame_sync(lib.ptr(img)) == 0
+    want = oracle.stripes_apply(oracle.chroma_smooth(oracle.fix_bad_pixels(f, BLACK, 0, 0), BLACK, 5), BLACK, WHITE, 1, np.array(co, np.int32))
+    assert np.array_equal(img, want)
+    assert gpu.mlvfs_amd_frame_sync(lib.ptr(img)) == 0 and np.array_equal(img, want)        # nothing pending: a no-op
+    gpu.stripes_free_corrections()
+
+
+@pytest.mark.skipif(not DEFERRED, reason="needs MLVFS_AMD_RESIDENT=2 (run by test_deferred_mode_in_a_child_process)")
+def test_deferred_result_is_fetched_by_symbols_that_read_the_host_frame(gpu, oracle):
+    """A stage called out of process_frame's order, and the symbols that stage the host frame themselves (pattern noise here),
+    first bring the host buffer up to date."""
+    w, h = 416, 264
+    f = synth.normal_frame(w, h)
+    fh = abi.make_frame_headers(w, h, black=BLACK, white=WHITE)
+    img = np.full((h, w), 0xABCD, np.uint16)
+    _unpack_into(gpu, fh, f, img)
+    gpu.fix_pattern_noise(lib.ptr(img), w, h, WHITE, 0)                  # main.c:946-949: right after the unpack
+    want = oracle.fix_pattern_noise(f, WHITE)
+    assert np.array_equal(img, want)
+    gpu.chroma_smooth(C.byref(fh), lib.ptr(img), 3)                      # uploads (nothing resident), result deferred
+    gpu.chroma_smooth(C.byref(fh), lib.ptr(img), 2)                      # not "the next stage": fetched, uploaded again
+    assert gpu.mlvfs_amd_frame_sync(lib.ptr(img)) == 0
+    assert np.array_equal(img, oracle.chroma_smooth(oracle.chroma_smooth(want, BLACK, 3), BLACK, 2))
+    # a window that is not the whole frame is written at once (dng.c:815-826 arithmetic), whatever the mode
+    part = pipeline.get_image_data(fh, synth.pack_bits(f)[512 * 14 // 16:], offset=1024, max_size=4096)      # from the first pixel's word on
+    assert np.array_equal(part, f.reshape(-1)[512:512 + 2048])
+
+
+@pytest.mark.skipif(not DEFERRED, reason="needs MLVFS_AMD_RESIDENT=2 (run by test_deferred_mode_in_a_child_process)")
+def test_deferred_process_frame_mirror_and_threads(gpu, oracle):
+    """pipeline.process_frame (the mirror of main.c's, with the sync as its last line) from several threads at once."""
+    import threading
+    w, h = 416, 264
+    frames = [synth.normal_frame(w, h, frame=k, hot=50, cold=50) for k in range(4)]
+    opt = pipeline.MlvfsOptions(chroma_smooth=5, fix_bad_pixels=1, fix_stripes=0)
+    want = [oracle.chroma_smooth(oracle.fix_bad_pixels(f, BLACK, 0, 0), BLACK, 5) for f in frames]
+    got = {}
+
+    def worker(i):
+        for rep in range(3):
+            fh = abi.make_frame_headers(w, h, black=BLACK, white=WHITE)
+            fh.file_hdr.fileGuid = 0x7000 + i
+            got[i] = pipeline.process_frame(synth.pack_bits(frames[i]), fh, opt, mlv_filename=f"t{i}.MLV")
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for i in range(4):
+        assert np.array_equal(got[i], want[i]), i
+    gpu.free_focus_pixel_maps()

@@ -19,20 +19,31 @@ name = b"dropin_bench.MLV"
 last = {}
 
 
-PINNED = os.environ.get("DROPIN_PINNED") == "1"     # frame buffers from mlvfs_amd_host_alloc (page-locked), one per thread, reused
+PINNED = os.environ.get("DROPIN_PINNED") == "1"     # frame buffers from mlvfs_amd_host_alloc (page-locked, pooled), one per frame
+REUSE = os.environ.get("DROPIN_REUSE") == "1"       # one pageable frame buffer per thread, reused (no fresh pages per frame)
 
 
 def worker(nf, idx, counts):
     fh = abi.make_frame_headers(W, H, black=synth.BLACK, white=synth.WHITE)
     fh.file_hdr.fileGuid = 0x1234
-    pin = None
-    if PINNED:
+    keep = np.empty(W * H, np.uint16) if REUSE else None
+    srcs = packed_np
+    if PINNED:                                          # the packed frames where a reader would have put them: page-locked too
         L.mlvfs_amd_init(0)
-        pin = L.mlvfs_amd_host_alloc(W * H * 2)
-        pin_img = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint16)), shape=(W * H,))
+        srcs, src_ptrs = [], []
+        for a in packed_np:
+            p = L.mlvfs_amd_host_alloc(a.nbytes)
+            v = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint16)), shape=(a.size,))
+            v[:] = a
+            srcs.append(v); src_ptrs.append(p)
     for k in range(nf):
-        img = pin_img if PINNED else np.empty(W * H, np.uint16)      # a fresh buffer per frame, like process_frame's malloc
-        src = packed_np[(idx + k) % 2]
+        pin = None
+        if PINNED:                                      # a buffer per frame from the library's pool, given back after the frame
+            pin = L.mlvfs_amd_host_alloc(W * H * 2)
+            img = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint16)), shape=(W * H,))
+        else:
+            img = keep if REUSE else np.empty(W * H, np.uint16)      # a fresh buffer per frame, like process_frame's malloc
+        src = srcs[(idx + k) % 2]
         L.dng_get_image_data(C.byref(fh), lib.ptr(src), lib.ptr(img), 0, img.nbytes)
         L.fix_focus_pixels(C.byref(fh), lib.ptr(img), 0)
         L.fix_bad_pixels(C.byref(fh), lib.ptr(img), 0, 0)
@@ -42,16 +53,20 @@ def worker(nf, idx, counts):
             corr = L.stripes_new_correction(name)
             L.stripes_compute_correction(C.byref(fh), corr, lib.ptr(img), 0, img.size)
         L.stripes_apply_correction(C.byref(fh), corr, lib.ptr(img), 0, img.size)     # sizes in pixels (main.c:996)
-        if (idx + k) % 2 == 1:
-            last[idx] = img.copy() if PINNED else img
+        L.mlvfs_amd_frame_sync(lib.ptr(img))            # MLVFS_AMD_RESIDENT=2: the one download of the frame (a no-op otherwise)
+        if (idx + k) % 2 == 1 and k >= nf - 2:
+            last[idx] = img.copy() if (PINNED or REUSE) else img
+        if pin:
+            L.mlvfs_amd_host_free(pin)
     counts[idx] = nf
-    if pin:
-        L.mlvfs_amd_host_free(pin)
+    if PINNED:
+        for p in src_ptrs:
+            L.mlvfs_amd_host_free(p)
 
 
 C.CDLL(None).srand(1)
 worker(1, 0, [0])                                       # clip state (map, coefficients) from frame 0
-res = {"resident": os.environ.get("MLVFS_AMD_RESIDENT", "0"), "frames_per_thread": NF, "pinned_frame_buffers": PINNED}
+res = {"resident": os.environ.get("MLVFS_AMD_RESIDENT", "0"), "frames_per_thread": NF, "pinned_frame_buffers": PINNED, "reused_frame_buffers": REUSE}
 for t in (1, T):
     counts = [0] * t
     th = [threading.Thread(target=worker, args=(NF, i, counts)) for i in range(t)]
