@@ -23,7 +23,7 @@ PINNED = os.environ.get("DROPIN_PINNED") == "1"     # frame buffers from mlvfs_a
 REUSE = os.environ.get("DROPIN_REUSE") == "1"       # one pageable frame buffer per thread, reused (no fresh pages per frame)
 
 
-def worker(nf, idx, counts):
+def worker(nf, idx, counts, start, t_begin):
     fh = abi.make_frame_headers(W, H, black=synth.BLACK, white=synth.WHITE)
     fh.file_hdr.fileGuid = 0x1234
     keep = np.empty(W * H, np.uint16) if REUSE else None
@@ -36,7 +36,11 @@ def worker(nf, idx, counts):
             v = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint16)), shape=(a.size,))
             v[:] = a
             srcs.append(v); src_ptrs.append(p)
-    for k in range(nf):
+    for k in range(-2, nf):                             # two frames of warm-up per thread (its stream and buffers), then the clock
+        if k == 0:
+            if start.wait() == 0:
+                t_begin[0] = time.perf_counter()
+            start.wait()
         pin = None
         if PINNED:                                      # a buffer per frame from the library's pool, given back after the frame
             pin = L.mlvfs_amd_host_alloc(W * H * 2)
@@ -65,15 +69,15 @@ def worker(nf, idx, counts):
 
 
 C.CDLL(None).srand(1)
-worker(1, 0, [0])                                       # clip state (map, coefficients) from frame 0
+worker(1, 0, [0], threading.Barrier(1), [0.0])         # clip state (map, coefficients) from frame 0
 res = {"resident": os.environ.get("MLVFS_AMD_RESIDENT", "0"), "frames_per_thread": NF, "pinned_frame_buffers": PINNED, "reused_frame_buffers": REUSE}
 for t in (1, T):
     counts = [0] * t
-    th = [threading.Thread(target=worker, args=(NF, i, counts)) for i in range(t)]
-    t0 = time.perf_counter()
+    start, t_begin = threading.Barrier(t), [0.0]
+    th = [threading.Thread(target=worker, args=(NF, i, counts, start, t_begin)) for i in range(t)]
     for x in th: x.start()
     for x in th: x.join()
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t_begin[0]
     res[f"fps_{t}_threads"] = round(sum(counts) / dt, 1)
 ref = None
 same = True
