@@ -1,7 +1,7 @@
 """debug: GPU AMaZE planes vs oracle over a sweep of sizes with strong textures"""
 import ctypes as C, sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from mlvfs_amd import lib, synth
 from oracle.bindings import Oracle
 import torch

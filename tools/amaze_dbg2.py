@@ -1,6 +1,6 @@
 import ctypes as C, sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from mlvfs_amd import lib, synth
 from oracle.bindings import Oracle
 import torch

@@ -2,7 +2,7 @@
 usage: python tools/dualiso_bench.py [interp_method] [reps]"""
 import ctypes as C, sys, time, os
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from mlvfs_amd import lib, synth
 import torch
 interp = int(sys.argv[1]) if len(sys.argv) > 1 else 0

@@ -4,7 +4,7 @@ AMaZE launch on 256 CUs, both of which overlap across frames.
 usage: python tools/dualiso_mt_bench.py [interp_method] [frames_per_thread]"""
 import ctypes as C, os, sys, threading, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from mlvfs_amd import lib, synth
 import torch
 interp = int(sys.argv[1]) if len(sys.argv) > 1 else 0

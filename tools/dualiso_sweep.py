@@ -1,7 +1,7 @@
 """GPU vs oracle over random geometries / switches of the full dual-ISO conversion (debug aid)."""
 import ctypes as C, os, sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from mlvfs_amd import abi, lib, synth
 from oracle.bindings import Oracle
 gpu = lib.load(); gpu.mlvfs_amd_init(0)

@@ -1,7 +1,7 @@
 """Fused pipeline (k_frame + k_pixfix) vs oracle over random geometries / switches (debug aid)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from mlvfs_amd import lib, synth
 from mlvfs_amd.stream import ClipStream, to_numpy_u16

@@ -1,7 +1,7 @@
 """Time the dual-ISO preview (hdr_convert_data drop-in, host buffers; and the device-resident form) on 3584x1320."""
 import ctypes as C, sys, time, os
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from mlvfs_amd import abi, lib, synth
 import torch
 gpu = lib.load(); gpu.mlvfs_amd_init(0)

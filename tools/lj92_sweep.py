@@ -2,7 +2,7 @@
 usage: python tools/lj92_sweep.py [seed] [cases]"""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from mlvfs_amd import lib, lj92, synth
 from oracle import lj92_testenc as enc
 from oracle.bindings import Oracle

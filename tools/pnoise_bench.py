@@ -1,7 +1,7 @@
 """Time fix_pattern_noise (drop-in symbol, host buffers) on 3584x1320."""
 import ctypes as C, sys, time, os
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from mlvfs_amd import lib, synth
 gpu = lib.load(); gpu.mlvfs_amd_init(0)
 w, h = 3584, 1320
