@@ -213,6 +213,26 @@ def test_full_size_against_oracle(torch_cuda, oracle, cs):
     s.close()
 
 
+def test_full_size_focus_pixel_map(torch_cuda, oracle):
+    """3584x1320 with a focus-pixel map of the size some cameras have (every 8th column of every 12th row, 48 000 entries, plus
+    neighbours three pixels apart that depend on each other), low-light footage (the spread table layout, shared references)."""
+    from mlvfs_amd.stream import to_numpy_u16
+    w, h = FULL_W, FULL_H
+    frames = [synth.low_light_frame(w, h, seed=21 + k) for k in range(2)]
+    ys, xs = np.mgrid[6:h - 6:12, 7:w - 8:8]
+    pts = np.stack([xs.reshape(-1), ys.reshape(-1)], 1).astype(np.int32)
+    pts = np.concatenate([pts, pts[::5] + [3, 0], pts[::9] + [0, 2]]).astype(np.int32)
+    want = [oracle.chroma_smooth(oracle.apply_focus_pixels(f, BLACK, pts, (0, 0), 0), BLACK, 5) for f in frames]
+    s = make_stream(w, h)
+    s.set_pixel_map(pts, kind=1)
+    packed = s.upload_packed([synth.pack14(f).astype("<u2") for f in frames])
+    got = to_numpy_u16(s.process(packed, cs=5, fix_pixels=True, stripes=False))
+    for k in range(2):
+        assert np.array_equal(got[k], want[k]), f"frame {k}: {(got[k] != want[k]).sum()} px differ"
+    assert s.get_t16_layout() == 2
+    s.close()
+
+
 def test_full_size_properties(torch_cuda):
     """Size-independent checks on a 16-frame 3584x1320 stream built in HBM:
       * unpack(pack(x)) == x for every frame (round trip),

@@ -1,5 +1,6 @@
 """libfuse calls process_frame from a pool of worker threads (SURVEY.md 8b "Threading"): different frames of different
 clips go through the drop-in symbols concurrently.  Every thread must get exactly the single-threaded result."""
+import ctypes as C
 import threading
 
 import numpy as np
@@ -189,3 +190,28 @@ def test_retired_worker_threads_give_their_buffers_back(gpu):
     # 48 retired threads held 2 x 1 MiB of staging each (plus stream and counters); what the HIP runtime itself keeps per
     # destroyed stream (about 0.2 MiB here) is not ours to free
     assert free1 - free2 < (24 << 20), f"{(free1 - free2) >> 20} MiB of device memory lost over 48 retired threads"
+
+
+def test_host_buffer_pool(gpu):
+    """mlvfs_amd_host_alloc / _free: a freed buffer comes back for the next request of its size (a host may allocate one per frame),
+    other sizes get other buffers, foreign pointers are ignored, and the buffers work with the host entry point."""
+    gpu.mlvfs_amd_init(0)
+    a = gpu.mlvfs_amd_host_alloc(9461760)
+    b = gpu.mlvfs_amd_host_alloc(9461760)
+    assert a and b and a != b
+    gpu.mlvfs_amd_host_free(a)
+    c = gpu.mlvfs_amd_host_alloc(9461760 - 100)            # same 64 KiB class
+    assert c == a
+    d = gpu.mlvfs_amd_host_alloc(1 << 20)
+    assert d and d not in (a, b)
+    gpu.mlvfs_amd_host_free(C.c_void_p(12345))             # not ours: ignored
+    gpu.mlvfs_amd_host_free(None)
+    view = np.ctypeslib.as_array(C.cast(c, C.POINTER(C.c_uint16)), shape=(1000,))
+    view[:] = 7
+    assert int(view.sum()) == 7000
+    for p in (b, c, d):
+        gpu.mlvfs_amd_host_free(p)
+    again = [gpu.mlvfs_amd_host_alloc(9461760) for _ in range(2)]
+    assert set(again) == {a, b}
+    for p in again:
+        gpu.mlvfs_amd_host_free(p)
