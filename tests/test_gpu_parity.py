@@ -209,6 +209,28 @@ def test_hdr_preview_dropin(gpu, oracle, w, h):
     assert np.array_equal(got, n) and fh.rawi_hdr.raw_info.black_level == BLACK
 
 
+def test_hdr_preview_with_focus_map(gpu, oracle, tmp_path, monkeypatch):
+    """hdr.c:104: the preview repairs the camera's focus pixels (dual-ISO rule) on the host frame before it matches the
+    exposures -- a drop-in symbol calling another one, in every MLVFS_AMD_RESIDENT mode."""
+    w, h = 416, 264
+    ys, xs = np.mgrid[8:h - 8:6, 9:w - 9:8]
+    pts = np.stack([xs.reshape(-1), ys.reshape(-1)], 1).astype(np.int32)
+    camera = 0x80000331
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / f"{camera:x}_{w}x{h}.fpm").write_text("".join(f"{x} \t {y}\n" for x, y in pts))
+    gpu.free_focus_pixel_maps()
+    f = synth.dual_iso_frame(w, h)
+    fixed = oracle.apply_focus_pixels(f, BLACK, pts, (0, 0), 1)
+    assert (fixed != f).any()
+    ok, want, levels = oracle.hdr_preview(fixed, BLACK, WHITE)
+    assert ok == 1
+    fh = fh_for(w, h, camera=camera)
+    got = f.copy()
+    assert gpu.hdr_convert_data(C.byref(fh), lib.ptr(got), 0, got.nbytes) == 1
+    assert np.array_equal(got, want), f"{(got != want).sum()} px differ"
+    gpu.free_focus_pixel_maps()
+
+
 # ------------------------------------------------------------------ process_frame order through the drop-in symbols
 @pytest.mark.parametrize("cs,bad,stripes", [(0, 0, 0), (2, 0, 0), (5, 1, 1), (3, 2, 1), (5, 0, 1)])
 def test_process_frame_dropin(gpu, oracle, cs, bad, stripes):

@@ -71,7 +71,7 @@ def test_deferred_mode_in_a_child_process(gpu):
     of process_frame call it after the last stage; the tests below (child only) check the mode itself."""
     env = dict(os.environ, MLVFS_AMD_RESIDENT="2")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_resident.py", "tests/test_gpu_c_host.py",
-                        "-k", "deferred or c_program"],
+                        "tests/test_gpu_parity.py", "-k", "deferred or c_program or hdr_preview or pattern_noise"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
