@@ -630,6 +630,14 @@ struct histogram *hist_create(uint16_t white)                                   
 
 void hist_add(struct histogram *h, uint16_t *data, uint32_t size, uint16_t skip)     // histogram.c:52-59
 {
+    // main.c:943 runs deflicker() -- hist_add on the frame buffer -- right after the unpack: with MLVFS_AMD_RESIDENT=2 the pixels
+    // are still on the GPU then
+    if (resident_level() == 2) {
+        ThreadCtx *c = thread_ctx();
+        if (c && c->res_dirty && (const uint8_t *)data >= (const uint8_t *)c->res_host &&
+            (const uint8_t *)data < (const uint8_t *)c->res_host + c->res_bytes)
+            (void)mlvfs_amd_frame_sync(const_cast<void *>(c->res_host));
+    }
     const uint32_t step = (uint32_t)skip + 1;
     for (uint32_t i = 0; i < size; i += step) h->data[data[i] < h->white ? data[i] : h->white]++;   // 16-bit counters wrap
     h->count += size / step;

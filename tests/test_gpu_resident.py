@@ -122,6 +122,14 @@ def test_deferred_result_is_fetched_by_symbols_that_read_the_host_frame(gpu, ora
     gpu.chroma_smooth(C.byref(fh), lib.ptr(img), 2)                      # not "the next stage": fetched, uploaded again
     assert gpu.mlvfs_amd_frame_sync(lib.ptr(img)) == 0
     assert np.array_equal(img, oracle.chroma_smooth(oracle.chroma_smooth(want, BLACK, 3), BLACK, 2))
+    # deflicker (main.c:895-906) reads the frame through hist_add right after the unpack
+    img2 = np.full((h, w), 0xABCD, np.uint16)
+    _unpack_into(gpu, fh, f, img2)
+    assert (img2 == 0xABCD).all()
+    hist = gpu.hist_create(1 << 14)
+    gpu.hist_add(hist, C.c_void_p(img2.ctypes.data + 2), (img2.size - 1) // 2, 1)
+    assert np.array_equal(img2, f)
+    gpu.hist_destroy(hist)
     # a window that is not the whole frame is written at once (dng.c:815-826 arithmetic), whatever the mode
     part = pipeline.get_image_data(fh, synth.pack_bits(f)[512 * 14 // 16:], offset=1024, max_size=4096)      # from the first pixel's word on
     assert np.array_equal(part, f.reshape(-1)[512:512 + 2048])
