@@ -56,9 +56,18 @@ constexpr int HC = FRAME_HC;            // halo in cells (2)
 constexpr int PW = TCW + 2 * HC;        // plane width  (68)
 constexpr int STRIP = 4;                // cells per thread in the median phase
 constexpr int GROUPS = TCW / 8;         // full items per plane row (8)
-constexpr int DARK_ITEMS_MIN = 16;      // of the loader items of a tile
-constexpr int FB_ROBUST = 12;           // 5x5: more uncertain strips than this: the next tiles' lanes share their references row by row
-constexpr int FB_DIRECT = 100;          // 5x5: more uncertain strips than this (of 240): the next tiles go to the 32-bit networks directly
+#ifndef KF_DARK_ITEMS_MIN
+#define KF_DARK_ITEMS_MIN 16
+#endif
+constexpr int DARK_ITEMS_MIN = KF_DARK_ITEMS_MIN;      // of the loader items of a tile
+#ifndef KF_FB_ROBUST
+#define KF_FB_ROBUST 12
+#endif
+constexpr int FB_ROBUST = KF_FB_ROBUST;           // 5x5: more uncertain strips than this: the next tiles' lanes share their references row by row
+#ifndef KF_FB_DIRECT
+#define KF_FB_DIRECT 100
+#endif
+constexpr int FB_DIRECT = KF_FB_DIRECT;          // 5x5: more uncertain strips than this (of 240): the next tiles go to the 32-bit networks directly
 constexpr int PMAP_WORDS = 64;          // tiles per frame covered by the LDS patch bitmap: 2048 (3584x1320 has 1176 / 1232)
 // Tile height in cells: 16 rows of 16 strips fill the 256 threads; 5x5 tiles have 15 rows, the 16 lanes that this frees
 // compute the right-hand halo group of every row for the neighbour-sharing medians (strip_chain_*, below).
@@ -743,6 +752,73 @@ __device__ __forceinline__ bool chain_finish(const ChainGroup &g, ChainNext &n, 
 }
 
 
+// ---------------------------------------------------------------- 5x5 with neighbour sharing, 32-bit
+// The same chain on one plane of plain int32 values: no reference, no rebasing, nothing uncertain.  For the tiles
+// that skip the packed attempt (every strip would go through the stand-alone 32-bit networks at 348 operations per strip and
+// plane; here a lane does 4 column sorts, 2 merges, 2 rank windows and 4 selections = 212, plus 26 moves): underexposed footage
+// 11.8 -> 11.3 us per frame, colour patches 15.6 -> 14.6, the benchmark's frames unchanged (A/B in one run).
+struct Chain32 {
+    int s[4][5];
+    int p0[10], p1[10];
+    int q[6];
+};
+struct Next32 { int s0[5], s2[5], p0[10], q[6]; };
+
+__device__ __forceinline__ void chain32_group(const int (*pl)[PW], int row_top, int col_left, Chain32 &g)
+{
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const int4 a = *(const int4 *)&pl[row_top + r][col_left];
+        g.s[0][r] = a.x; g.s[1][r] = a.y; g.s[2][r] = a.z; g.s[3][r] = a.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) sort5(g.s[c]);
+    mlv_merge55(g.s[0], g.s[1], g.p0);
+    mlv_merge55(g.s[2], g.s[3], g.p1);
+    mlv_quad_mid6(g.p0, g.p1, g.q);
+}
+__device__ __forceinline__ void chain32_publish(const Chain32 &g, uint32_t *x)
+{
+    uint4 *o = (uint4 *)x;
+    auto u = [](int v) { return (uint32_t)v; };
+    o[0] = make_uint4(u(g.s[0][0]), u(g.s[0][1]), u(g.s[0][2]), u(g.s[0][3]));
+    o[1] = make_uint4(u(g.s[0][4]), u(g.s[2][0]), u(g.s[2][1]), u(g.s[2][2]));
+    o[2] = make_uint4(u(g.s[2][3]), u(g.s[2][4]), u(g.p0[0]), u(g.p0[1]));
+    o[3] = make_uint4(u(g.p0[2]), u(g.p0[3]), u(g.p0[4]), u(g.p0[5]));
+    o[4] = make_uint4(u(g.p0[6]), u(g.p0[7]), u(g.p0[8]), u(g.p0[9]));
+    o[5] = make_uint4(u(g.q[0]), u(g.q[1]), u(g.q[2]), u(g.q[3]));
+    *(uint2 *)&o[6] = make_uint2(u(g.q[4]), u(g.q[5]));
+}
+__device__ __forceinline__ void chain32_collect(const uint32_t *x, Next32 &n)
+{
+    const uint4 *o = (const uint4 *)x;
+    const uint4 a0 = o[0], a1 = o[1], a2 = o[2], a3 = o[3], a4 = o[4], a5 = o[5];
+    const uint2 a6 = *(const uint2 *)&o[6];
+    n.s0[0] = (int)a0.x; n.s0[1] = (int)a0.y; n.s0[2] = (int)a0.z; n.s0[3] = (int)a0.w; n.s0[4] = (int)a1.x;
+    n.s2[0] = (int)a1.y; n.s2[1] = (int)a1.z; n.s2[2] = (int)a1.w; n.s2[3] = (int)a2.x; n.s2[4] = (int)a2.y;
+    n.p0[0] = (int)a2.z; n.p0[1] = (int)a2.w; n.p0[2] = (int)a3.x; n.p0[3] = (int)a3.y; n.p0[4] = (int)a3.z; n.p0[5] = (int)a3.w;
+    n.p0[6] = (int)a4.x; n.p0[7] = (int)a4.y; n.p0[8] = (int)a4.z; n.p0[9] = (int)a4.w;
+    n.q[0] = (int)a5.x; n.q[1] = (int)a5.y; n.q[2] = (int)a5.z; n.q[3] = (int)a5.w; n.q[4] = (int)a6.x; n.q[5] = (int)a6.y;
+}
+__device__ __forceinline__ void chain32_fetch(const Chain32 &g, Next32 &n)
+{
+#pragma unroll
+    for (int i = 0; i < 5; i++) { n.s0[i] = dpp_next_i(g.s[0][i]); n.s2[i] = dpp_next_i(g.s[2][i]); }
+#pragma unroll
+    for (int i = 0; i < 10; i++) n.p0[i] = dpp_next_i(g.p0[i]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) n.q[i] = dpp_next_i(g.q[i]);
+}
+__device__ __forceinline__ void chain32_finish(const Chain32 &g, const Next32 &n, int (&med)[STRIP])
+{
+    int q1[6], o[1];
+    mlv_quad_mid6(g.p1, n.p0, q1);
+    mlv_final6of11(g.q, n.s0, o);  med[0] = o[0];      // window columns 0..3 | 4
+    mlv_final6of11(q1, g.s[1], o); med[1] = o[0];      // 2..5 | 1
+    mlv_final6of11(q1, n.s2, o);   med[2] = o[0];      // 2..5 | 6
+    mlv_final6of11(n.q, g.s[3], o); med[3] = o[0];     // 4..7 | 3
+}
+
 // 3x3: sorted columns of 3, classic max-of-mins / med-of-meds / min-of-maxes
 __device__ __forceinline__ void strip_median9(const int (*plane)[PW], int row_top, int col_left, int (&med)[STRIP])
 {
@@ -1088,6 +1164,27 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                           (fb_prev > FB_DIRECT && (++fb_run & 3) != 0);          // the same for every wave of the workgroup
             if (SPREAD && tid == 0) sm.dark_items[par ^ 1] = 0;
             bool unknown = true;
+            const bool chain32 = skip_packed;                  // the same for every wave of the workgroup
+            if (chain32) {
+                // a tile that skips the packed attempt: both planes through the 32-bit chain, one after the other (the rows'
+                // exchange records are reused)
+#pragma unroll 1
+                for (int pln = 0; pln < 2; pln++) {
+                    Chain32 g;
+                    chain32_group(pln ? sm.db : sm.dr, j, is_strip ? STRIP * k : TCW, g);
+                    if (!is_strip) chain32_publish(g, sm.xchg[j]);
+                    lds_barrier();
+                    Next32 n;
+                    chain32_fetch(g, n);
+                    if (k == 15) chain32_collect(sm.xchg[j], n);
+                    if (pln) chain32_finish(g, n, mb);
+                    else {
+                        chain32_finish(g, n, mr);
+                        lds_barrier();                         // every row's record has been read: the second plane may overwrite it
+                    }
+                }
+                unknown = false;
+            } else
             if (!skip_packed) {
                 ChainGroup g;
                 chain_group(sm.dr, sm.db, j, is_strip ? STRIP * k : TCW, robust, g);  // a strip's own group, or a row's halo group
@@ -1107,7 +1204,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             }
             unknown = unknown && is_strip && smooth_row;
             if (unknown) sm.fb_queue[atomicAdd(&sm.fb_count, 1)] = (uint8_t)(j * 16 + k);      // settled below, densely
-            if (is_strip && !unknown) finish_strip(j, k, smooth_row && !skip_packed, mr, mb, true);
+            if (is_strip && !unknown) finish_strip(j, k, smooth_row && (!skip_packed || chain32), mr, mb, true);
         } else {
             if (smooth_row) {
                 if (METHOD == 3) {
