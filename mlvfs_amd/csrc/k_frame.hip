@@ -64,8 +64,15 @@ constexpr int DARK_ITEMS_MIN = KF_DARK_ITEMS_MIN;      // of the loader items of
 #define KF_FB_ROBUST 12
 #endif
 constexpr int FB_ROBUST = KF_FB_ROBUST;           // 5x5: more uncertain strips than this: the next tiles' lanes share their references row by row
+#ifndef KF_FB_WAIT_MIN
+#define KF_FB_WAIT_MIN 1
+#endif
+#ifndef KF_FB_WAIT_MAX
+#define KF_FB_WAIT_MAX 15
+#endif
+constexpr int FB_WAIT_MIN = KF_FB_WAIT_MIN, FB_WAIT_MAX = KF_FB_WAIT_MAX;     // 5x5: tiles that skip the packed networks after a busy one
 #ifndef KF_FB_DIRECT
-#define KF_FB_DIRECT 100
+#define KF_FB_DIRECT 60
 #endif
 constexpr int FB_DIRECT = KF_FB_DIRECT;          // 5x5: more uncertain strips than this (of 240): the next tiles go to the 32-bit networks directly
 constexpr int PMAP_WORDS = 64;          // tiles per frame covered by the LDS patch bitmap: 2048 (3584x1320 has 1176 / 1232)
@@ -1004,7 +1011,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     const uint64_t rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     int par = 0;                               // tile parity: which of the two dark_items counters this tile uses
-    int fb_prev = 0, fb_run = 0;               // 5x5: uncertain strips of the last tile that tried the packed networks; tiles since
+    int fb_skip = 0, fb_wait = FB_WAIT_MIN;    // 5x5: tiles still to go straight to the 32-bit chain; how many after the next busy tile
     bool robust = false;                       // 5x5: rows of lanes agree on their references (robust_ref)
     int calm = 0;                              //      tiles in a row without an uncertain strip
     while (t < band_end) {
@@ -1158,10 +1165,11 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         if (CHAIN) {
             // Deep shadows (EVs of neighbouring small integers are more than the packed window apart) would fail the packed
             // attempt almost everywhere: tiles with many items at or below black skip it (dark clips only, i.e. the SPREAD
-            // instantiation), and so do tiles that follow a tile most of whose strips were uncertain (hard colour edges
-            // everywhere; every fourth such tile tries the packed networks again).  Skipping = every strip goes to the queue.
-            skip_packed = (SPREAD && __builtin_amdgcn_readfirstlane(sm.dark_items[par]) >= DARK_ITEMS_MIN) ||
-                          (fb_prev > FB_DIRECT && (++fb_run & 3) != 0);          // the same for every wave of the workgroup
+            // instantiation), and so do tiles that follow a tile a quarter of whose strips were uncertain (hard colour edges
+            // everywhere: that is where the packed attempt plus the dense pass cost more than the 32-bit chain).
+            const bool dark_tile = SPREAD && __builtin_amdgcn_readfirstlane(sm.dark_items[par]) >= DARK_ITEMS_MIN;
+            skip_packed = dark_tile || fb_skip > 0;            // the same for every wave of the workgroup
+            if (fb_skip > 0) fb_skip--;
             if (SPREAD && tid == 0) sm.dark_items[par ^ 1] = 0;
             bool unknown = true;
             const bool chain32 = skip_packed;                  // the same for every wave of the workgroup
@@ -1223,7 +1231,11 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             lds_barrier();
             const int nfb = __builtin_amdgcn_readfirstlane(sm.fb_count);
             if (!skip_packed) {
-                fb_prev = nfb;
+                // more than FB_DIRECT uncertain strips: the next fb_wait tiles go to the 32-bit chain directly, and the wait doubles
+                // (up to FB_WAIT_MAX) each time the tile after it is no better -- a stray busy tile costs its few successors a
+                // fifth more, a clip full of hard colour edges tries the packed networks once in sixteen tiles
+                if (nfb > FB_DIRECT) { fb_skip = fb_wait; fb_wait = min(2 * fb_wait + 1, FB_WAIT_MAX); }
+                else fb_wait = FB_WAIT_MIN;
                 // shared references (robust_ref) from the tile after one with uncertain strips until four tiles in a row had none
                 calm = nfb == 0 ? calm + 1 : 0;
                 robust = nfb > FB_ROBUST || (robust && calm < 4);
