@@ -141,6 +141,10 @@ int dark_share(bool packed, const void *d_frame, int w, int h, int black, hipStr
 int launch_pixfix(bool packed, const void *frames, size_t stride, int w, int black, const void *entries,
                   const int *level_off, int n_levels, int n_level0, int n_entries, void *patches, void *scatter,
                   size_t scatter_stride, int nframes, const DeviceLuts &luts, hipStream_t stream);
+// both of the above for the fused kernel (one launch when the map is small)
+int launch_pixfix_for_frame_kernel(bool packed, const void *frames, size_t stride, int w, int h, int black, const void *entries,
+                                   const int *level_off, int n_levels, int n_level0, int n_entries, void *patches,
+                                   const CellRec *recs, int n_rec, void *cells, int nframes, const DeviceLuts &luts, hipStream_t stream);
 // the four pixels of every listed cell after the repair (for the fused kernel): after launch_pixfix, on the same stream
 int launch_pixfix_cells(bool packed, const void *frames, size_t stride, int w, int h, const CellRec *recs, int n_rec,
                         const void *patches, int n_entries, void *cells, int nframes, hipStream_t stream);

@@ -203,6 +203,71 @@ int launch_pixfix_cells(bool packed, const void *frames, size_t stride, int w, i
     return MLVFS_AMD_OK;
 }
 
+// A small map (a clip's hot and cold pixels: a hundred entries) for the fused kernel in ONE launch: every level and the cell
+// records, one workgroup per frame.  The three launches above cost a batch of 100 frames 2 % of its time in launch gaps.
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_pixfix_small(const uint8_t *__restrict__ frames, size_t stride, int w, int h, int black,
+                                                      const PixEntry *__restrict__ entries, const int *__restrict__ level_off,
+                                                      int n_levels, int n_entries, int2 *__restrict__ patches,
+                                                      const CellRec *__restrict__ recs, int n_rec, int4 *__restrict__ cells,
+                                                      const uint16_t *__restrict__ t16, const uint16_t *__restrict__ u16)
+{
+    const uint8_t *frame = frames + (size_t)blockIdx.x * stride;
+    int2 *out = patches + (size_t)blockIdx.x * n_entries;
+    for (int lv = 0; lv < n_levels; lv++) {
+        const int beg = level_off[lv], end = level_off[lv + 1];
+        for (int m = beg + threadIdx.x; m < end; m += blockDim.x) {
+            const PixEntry e = entries[m];
+            int val = 0;
+            if (e.kind != 0) {
+                auto tap = [&](int t) {
+                    const int d = e.dep[t];
+                    return d >= 0 ? out[d].y : fetch_px<PACKED>(frame, e.pos + tap_offset(t, w));
+                };
+                val = repair_value(e.kind, black, t16, u16, tap) & 0xFFFF;
+            }
+            out[m] = make_int2((e.kind != 0 && e.emit) ? e.pos : -1, val);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int r = threadIdx.x; r < n_rec; r += blockDim.x) {
+        const CellRec rec = recs[r];
+        const int cx = rec.cell & 0xFFFF, cy = rec.cell >> 16;
+        int v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int x = min(2 * cx + (q & 1), w - 1), y = min(2 * cy + (q >> 1), h - 1);
+            v[q] = rec.e[q] >= 0 ? (out[rec.e[q]].y & 0xFFFF) : fetch_px<PACKED>(frame, y * w + x);
+        }
+        cells[(size_t)blockIdx.x * n_rec + r] = make_int4(rec.cell, v[0] | (v[1] << 16), v[2] | (v[3] << 16), 0);
+    }
+}
+
+// patch list + cell records for the fused kernel: one launch for a small map, the flat grid + levels + cells for a large one
+int launch_pixfix_for_frame_kernel(bool packed, const void *frames, size_t stride, int w, int h, int black, const void *entries,
+                                   const int *level_off, int n_levels, int n_level0, int n_entries, void *patches,
+                                   const CellRec *recs, int n_rec, void *cells, int nframes, const DeviceLuts &luts, hipStream_t stream)
+{
+    if (n_entries <= 0 || nframes <= 0) return MLVFS_AMD_OK;
+    if (n_entries > 1024 || n_rec > 2048) {
+        int rc = launch_pixfix(packed, frames, stride, w, black, entries, level_off, n_levels, n_level0, n_entries, patches, nullptr, 0,
+                               nframes, luts, stream);
+        if (rc) return rc;
+        return launch_pixfix_cells(packed, frames, stride, w, h, recs, n_rec, patches, n_entries, cells, nframes, stream);
+    }
+    if (packed)
+        hipLaunchKernelGGL(k_pixfix_small<true>, dim3(nframes), dim3(256), 0, stream, (const uint8_t *)frames, stride, w, h, black,
+                           (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches, recs, n_rec, (int4 *)cells,
+                           luts.t16, luts.u16);
+    else
+        hipLaunchKernelGGL(k_pixfix_small<false>, dim3(nframes), dim3(256), 0, stream, (const uint8_t *)frames, stride, w, h, black,
+                           (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches, recs, n_rec, (int4 *)cells,
+                           luts.t16, luts.u16);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
 // ------------------------------------------------------------------ detection
 // pass 1: one lane per pixel; per 64-pixel span a ballot word, per row a count
 __global__ __launch_bounds__(256) void k_badpix_flags(const uint16_t *__restrict__ img, int w, int h, int black,
