@@ -1114,15 +1114,23 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                     ur[c] = mlv_sbl_u16(rs_e2r, min(max(er[c], 0), MLV_EV_MAX), 0, 0, 0);
                     ub[c] = mlv_sbl_u16(rs_e2r, min(max(eb[c], 0), MLV_EV_MAX), 0, 0, 0);
                 }
-                asm volatile("" :: "v"(ur[0]), "v"(ur[1]), "v"(ur[2]), "v"(ur[3]), "v"(ub[0]), "v"(ub[1]), "v"(ub[2]), "v"(ub[3]));
                 // chroma_smooth.c:27 leaves columns 0..3 and w-4.. alone: only the tiles at the frame's left and right margin test for that
                 const bool x_margin = tx0 < 4 || tx0 + 2 * TCW > a.w - 4;                   // scalar
+                // which cells take the smoothed values (chroma_smooth.c:28, 35, 64-65): decided while the look-ups are under way
+                bool okc[STRIP];
+                unsigned long long okm[STRIP];
 #pragma unroll
                 for (int c = 0; c < STRIP; c++) {
                     const int xc = x + 2 * c;
-                    // chroma_smooth.c:28, 35, 64-65
-                    bool ok = smooth && gev[c] >= 2 * MLV_EV_RES && er[c] > MLV_EV_RES && eb[c] > MLV_EV_RES;
-                    if (x_margin) ok = ok && xc >= 4 && xc < a.w - 4;
+                    okc[c] = smooth && gev[c] >= 2 * MLV_EV_RES && er[c] > MLV_EV_RES && eb[c] > MLV_EV_RES;
+                    if (x_margin) okc[c] = okc[c] && xc >= 4 && xc < a.w - 4;
+                    okm[c] = __ballot(okc[c]);
+                }
+                asm volatile("" :: "v"(ur[0]), "v"(ur[1]), "v"(ur[2]), "v"(ur[3]), "v"(ub[0]), "v"(ub[1]), "v"(ub[2]), "v"(ub[3]),
+                             "s"(okm[0]), "s"(okm[1]), "s"(okm[2]), "s"(okm[3]));
+#pragma unroll
+                for (int c = 0; c < STRIP; c++) {
+                    const bool ok = okc[c];
                     const uint32_t pr_ = (uint32_t)ur[c], pb_ = (uint32_t)ub[c];
                     top[c] = ok ? ((top[c] & 0xFFFF0000u) | pr_) : top[c];
                     bot[c] = ok ? ((bot[c] & 0x0000FFFFu) | (pb_ << 16)) : bot[c];
