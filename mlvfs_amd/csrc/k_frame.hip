@@ -1096,13 +1096,15 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         auto finish_strip = [&](int jj, int kk, bool smooth, const int (&mr)[STRIP], const int (&mb)[STRIP], bool store) {
             const int y = ty0 + 2 * jj, x = tx0 + 2 * STRIP * kk;
             uint32_t top[STRIP], bot[STRIP];        // (R | G1<<16), (G2 | B<<16)
-            {
+            auto read_raw = [&]() {
                 const uint4 v0 = *(const uint4 *)&sm.raw[2 * jj][2 * STRIP * kk];
                 const uint4 v1 = *(const uint4 *)&sm.raw[2 * jj + 1][2 * STRIP * kk];
                 top[0] = v0.x; top[1] = v0.y; top[2] = v0.z; top[3] = v0.w;
                 bot[0] = v1.x; bot[1] = v1.y; bot[2] = v1.z; bot[3] = v1.w;
-            }
+            };
+            if (METHOD == 0) read_raw();
             if (METHOD != 0) {
+                // (the green EVs first: the look-ups' indices wait for them; the raw pixels are read once the look-ups are under way)
                 const int4 g4 = *(const int4 *)&sm.ge[jj][STRIP * kk];
                 const int gev[STRIP] = { g4.x, g4.y, g4.z, g4.w };
                 // the output pixel by EV (896 KiB table in L2): all 8 look-ups issued before the first use
@@ -1114,6 +1116,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                     ur[c] = mlv_sbl_u16(rs_e2r, min(max(er[c], 0), MLV_EV_MAX), 0, 0, 0);
                     ub[c] = mlv_sbl_u16(rs_e2r, min(max(eb[c], 0), MLV_EV_MAX), 0, 0, 0);
                 }
+                read_raw();
                 // chroma_smooth.c:27 leaves columns 0..3 and w-4.. alone: only the tiles at the frame's left and right margin test for that
                 const bool x_margin = tx0 < 4 || tx0 + 2 * TCW > a.w - 4;                   // scalar
                 // which cells take the smoothed values (chroma_smooth.c:28, 35, 64-65): decided while the look-ups are under way
