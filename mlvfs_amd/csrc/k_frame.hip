@@ -1121,16 +1121,15 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 const bool x_margin = tx0 < 4 || tx0 + 2 * TCW > a.w - 4;                   // scalar
                 // which cells take the smoothed values (chroma_smooth.c:28, 35, 64-65): decided while the look-ups are under way
                 bool okc[STRIP];
-                unsigned long long okm[STRIP];
 #pragma unroll
                 for (int c = 0; c < STRIP; c++) {
                     const int xc = x + 2 * c;
                     okc[c] = smooth && gev[c] >= 2 * MLV_EV_RES && er[c] > MLV_EV_RES && eb[c] > MLV_EV_RES;
                     if (x_margin) okc[c] = okc[c] && xc >= 4 && xc < a.w - 4;
-                    okm[c] = __ballot(okc[c]);
                 }
-                asm volatile("" :: "v"(ur[0]), "v"(ur[1]), "v"(ur[2]), "v"(ur[3]), "v"(ub[0]), "v"(ub[1]), "v"(ub[2]), "v"(ub[3]),
-                             "s"(okm[0]), "s"(okm[1]), "s"(okm[2]), "s"(okm[3]));
+                // (the fence keeps the eight look-ups together and comes after the decisions in program order: the compiler
+                // schedules them under the look-ups' latency; with the masks as operands of the fence it also copied them)
+                asm volatile("" :: "v"(ur[0]), "v"(ur[1]), "v"(ur[2]), "v"(ur[3]), "v"(ub[0]), "v"(ub[1]), "v"(ub[2]), "v"(ub[3]));
 #pragma unroll
                 for (int c = 0; c < STRIP; c++) {
                     const bool ok = okc[c];
