@@ -17,15 +17,19 @@ try:
         h = int(rng.integers(8, 300))
         cs = int(rng.choice([0, 2, 3, 5, 5]))
         badpix = int(rng.integers(0, 3)); st = int(rng.integers(0, 2)) if w % 8 == 0 else 0
-        kind = str(rng.choice(["normal", "adversarial", "colour_cast"]))
-        nf = 3
-        if kind == "colour_cast":
-            frames = [synth.colour_cast_frame(w, h, seed=int(rng.integers(1, 999)) + k) for k in range(nf)]
+        kind = str(rng.choice(["normal", "adversarial", "colour_cast", "low_light"]))
+        if rng.random() < 0.25:                                # now and then a frame of many tiles (the 5x5 kernel's per-tile state machines)
+            w, h = int(rng.integers(30, 70)) * 16, int(rng.integers(200, 420))
+        nf = int(rng.integers(2, 5))
+        if kind in ("colour_cast", "low_light"):
+            gen = getattr(synth, kind + "_frame")
+            frames = [gen(w, h, seed=int(rng.integers(1, 999)) + k) for k in range(nf)]
         else:
             gen = getattr(synth, kind + "_frame")
             sd = int(rng.integers(1, 999))
             frames = [gen(w, h, seed=sd, frame=k) for k in range(nf)]
         s = ClipStream(w, h, 14, synth.BLACK, synth.WHITE, device=0)
+        if rng.random() < 0.4: s.set_t16_layout(int(rng.integers(1, 3)))        # else decided from the first frame
         packed = s.upload_packed([synth.pack_bits(f) for f in frames])
         s.analyse_first_frame(packed, cs=cs, bad_pix=badpix, stripes=bool(st), rand_mode=1)
         got = to_numpy_u16(s.process(packed, cs=cs, fix_pixels=bool(badpix), stripes=bool(st)))
