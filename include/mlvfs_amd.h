@@ -292,6 +292,10 @@ int mlvfs_amd_timer_end(float *ms, int cap);
  * one per stage).  What main.c:996 would be followed by in process_frame -- see INTEGRATION.md.  In every other mode, and for a
  * buffer nothing is pending for, it does nothing.  0 = the host buffer is current. */
 int mlvfs_amd_frame_sync(void *image_data);
+/* MLVFS_AMD_RESIDENT=2 records the stages process_frame asks for and runs them as ONE launch of the fused kernel when the frame is
+ * fetched.  out[0]: frames of this process that went that way; out[1]: frames whose recorded stages had to run earlier (a call
+ * outside process_frame's order, the first frame of a clip, a focus-pixel map, pattern noise, dual ISO). */
+void mlvfs_amd_dropin_stats(long long out[2]);
 
 /* self tests that need no GPU (selection networks, LUT identities): 0 = pass */
 int mlvfs_amd_selftest_host(void);

@@ -18,6 +18,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <memory>
+
 #include "../../include/mlvfs_amd.h"
 
 #define MLV_EV_RES 32768
@@ -65,6 +67,22 @@ struct LibcRandGuard {
     static void draw_mod1024(uint16_t *out, long long n);      // n values of rand() % 1024 from the APPLICATION's stream
 };
 
+struct Clip;
+// MLVFS_AMD_RESIDENT=2: the stages process_frame has asked for so far on the frame whose packed payload sits in d_a.  They run as
+// ONE launch of the fused kernel -- the batch path's -- when the frame is fetched (mlvfs_amd_frame_sync) or when a call comes
+// that cannot be recorded (dropin.cpp)
+struct LazyFrame {
+    bool active = false;
+    void *host = nullptr;
+    size_t bytes = 0;
+    int w = 0, h = 0, black = 0, white = 0;
+    int rank = 0;                        // last stage recorded (process_frame's order only)
+    std::shared_ptr<Clip> pix;           // bad-pixel map to apply (shared, read-only)
+    int cs = 0;
+    bool stripes = false;
+    int32_t coef[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+};
+
 struct ThreadCtx {         // one per (host thread, device)
     Device *dev = nullptr;
     hipStream_t stream = nullptr;
@@ -86,6 +104,7 @@ struct ThreadCtx {         // one per (host thread, device)
     int res_cur = 0;
     int res_rank = 0;                    // which stage left the resident copy (dropin.cpp: stages only continue in process_frame's order)
     bool res_dirty = false;              // MLVFS_AMD_RESIDENT=2: the resident copy is newer than the host buffer (mlvfs_amd_frame_sync)
+    LazyFrame lazy;
     hipEvent_t ev_up = nullptr;          // end of the upload of dng_get_image_data's input (dropin.cpp, MLVFS_AMD_RESIDENT=2)
     uint64_t res_sig[RES_SAMPLES];
     int ensure_res(size_t bytes);

@@ -105,6 +105,59 @@ void warn_unsynced(const void *host)
 
 int download(ThreadCtx *c, void *host, const void *dev, size_t bytes);
 
+// ---- MLVFS_AMD_RESIDENT=2: recorded stages, one fused launch ---------------------------------------------------------------
+// In this mode nothing has to be in host memory before mlvfs_amd_frame_sync, so nothing has to RUN before it either: the unpack,
+// the bad-pixel repair (once the clip's map is cached), the chroma smoothing and the stripe correction that process_frame asks
+// for are recorded, and run as ONE launch of the fused kernel on the packed payload (what mlvfs_amd_process_frames_dev does for a
+// batch) when the frame is fetched -- or earlier, when a call arrives that is not the next stage of process_frame's order or
+// needs the pixels (first frame of a clip: bad-pixel detection, stripe histogram; focus-pixel maps; pattern noise; dual ISO).
+std::atomic<long long> g_lazy_fused{ 0 }, g_lazy_early{ 0 };
+
+int lazy_run(ThreadCtx *c, bool at_sync)
+{
+    LazyFrame &z = c->lazy;
+    if (!z.active) return MLVFS_AMD_OK;
+    z.active = false;
+    (at_sync ? g_lazy_fused : g_lazy_early)++;
+    std::shared_ptr<Clip> pix;
+    pix.swap(z.pix);
+    const Geom g{ z.w, z.h, 14, z.black, z.white };
+    const bool patch = pix && pix->n_entries > 0;
+    int rc = c->ensure_res((z.bytes + 15) / 16 * 16);
+    if (!rc) {
+        if (!patch && z.cs == 0 && !z.stripes)
+            rc = launch_unpack(c->d_a, 0, c->d_res[0], 0, 0, (uint32_t)(z.bytes / 2), 14, 1, c->stream);
+        else {
+            PatchView pv{};
+            if (patch) {
+                const int geo = frame_geo_of(z.cs);
+                rc = c->ensure_patch(pix->patch_buffer_bytes(1));
+                if (!rc)
+                    rc = launch_pixfix_for_frame_kernel(true, c->d_a, 0, z.w, z.h, z.black, pix->d_entries, pix->d_level_off, pix->n_levels,
+                                                        pix->n_level0, pix->n_entries, c->d_patch, pix->d_tile_rec[geo], pix->n_rec[geo],
+                                                        Clip::cells_of(c->d_patch, pix->n_entries, 1), 1, c->dev->luts, c->stream);
+                pv = pix->patch_view(c->d_patch, 1, geo);
+            }
+            if (!rc)
+                rc = launch_frame(c->dev, g, true, c->d_a, 0, c->d_res[0], 0, 1, z.cs, patch ? &pv : nullptr, z.stripes, z.coef, c->stream);
+        }
+    }
+    if (rc) { c->res_host = nullptr; c->res_dirty = false; return rc; }
+    c->res_cur = 0;
+    c->res_rank = z.rank;
+    c->res_host = z.host;
+    c->res_bytes = z.bytes;
+    c->res_dirty = true;                           // a resident copy newer than the host buffer, like any deferred stage's
+    return MLVFS_AMD_OK;
+}
+
+// may this call be recorded instead of run?  (the next stage, in process_frame's order, of the frame whose payload is waiting)
+bool lazy_next(ThreadCtx *c, const void *host, size_t bytes, int rank)
+{
+    const LazyFrame &z = c->lazy;
+    return z.active && z.host == host && z.bytes == bytes && rank > z.rank;
+}
+
 // host -> device on the thread's stream.  (Copies of the sixteen threads through ONE upload and ONE download stream per device,
 // for page-locked buffers, were tried: no faster at 16 threads -- 1 200 frames/s, the level a bare copy loop of 16 threads
 // reaches 1 840 at, tools/zerocopy_probe.hip -- and slower without MLVFS_AMD_RESIDENT.)
@@ -117,7 +170,9 @@ int upload(ThreadCtx *c, void *dev, const void *host, size_t bytes)
 // device buffer that holds the frame at `host`: the resident copy, or a fresh upload
 int stage_frame(ThreadCtx *c, const void *host, size_t bytes, int rank, void **d_cur, void **d_other)
 {
-    int rc = c->ensure_res((bytes + 15) / 16 * 16);
+    int rc = lazy_run(c, false);                   // recorded stages this call cannot join: run them now
+    if (rc) return rc;
+    rc = c->ensure_res((bytes + 15) / 16 * 16);
     if (rc) return rc;
     bool have = false;
     if (resident_mode() && c->res_host == host && c->res_bytes == bytes && rank > c->res_rank) {
@@ -242,7 +297,8 @@ std::mutex g_focus_mutex;
 
 int mlv::drop_resident(ThreadCtx *c, void *host)
 {
-    int rc = MLVFS_AMD_OK;
+    int rc = lazy_run(c, false);
+    if (rc) return rc;
     if (c->res_dirty) {
         if (c->res_host == host) rc = download(c, host, c->d_res[c->res_cur], c->res_bytes);
         else warn_unsynced(c->res_host);
@@ -260,12 +316,21 @@ int mlvfs_amd_frame_sync(void *image_data)
 {
     ThreadCtx *c = thread_ctx();
     if (!c) return MLVFS_AMD_ERR_HIP;
-    if (!c->res_dirty || c->res_host != image_data) return MLVFS_AMD_OK;
     LibcRandGuard rand_guard;
+    if (c->lazy.active && c->lazy.host == image_data && lazy_run(c, true)) return MLVFS_AMD_ERR_HIP;
+    if (!c->res_dirty || c->res_host != image_data) return MLVFS_AMD_OK;
     if (download(c, image_data, c->d_res[c->res_cur], c->res_bytes)) return MLVFS_AMD_ERR_HIP;
     c->res_dirty = false;
     sample_host(image_data, c->res_bytes, c->res_sig);          // later stages may still take the copy up (as with RESIDENT=1)
     return MLVFS_AMD_OK;
+}
+
+// how often this process ran recorded stages as one fused launch at mlvfs_amd_frame_sync [0], and how often earlier because a
+// call could not be recorded [1] (MLVFS_AMD_RESIDENT=2; for tests and tuning)
+void mlvfs_amd_dropin_stats(long long out[2])
+{
+    out[0] = g_lazy_fused.load();
+    out[1] = g_lazy_early.load();
 }
 
 // ============================================================== dng.h
@@ -300,8 +365,9 @@ size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8
     const size_t words = (size_t)(last_bit / 16 - first_word) + 2;
     const size_t in_bytes = words * 2, out_b = (size_t)npix * 2;
     if (c->ensure((in_bytes + 15) / 16 * 16, 0) || c->ensure_res((out_b + 15) / 16 * 16)) return 0;
-    c->res_host = nullptr;
     if (c->res_dirty) warn_unsynced(c->res_host);
+    if (c->lazy.active) { warn_unsynced(c->lazy.host); c->lazy.active = false; c->lazy.pix.reset(); }
+    c->res_host = nullptr;
     c->res_dirty = false;
     if (upload(c, c->d_a, packed_bits, in_bytes)) {
         set_error("dng_get_image_data: upload failed");
@@ -314,8 +380,18 @@ size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8
         if (!c->ev_up && hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming) != hipSuccess) return 0;
         if (hipEventRecord(c->ev_up, c->stream) != hipSuccess) return 0;
     }
-    if (launch_unpack(c->d_a, 0, c->d_res[0], 0, first_px, npix, bpp, 1, c->stream)) return 0;
     uint8_t *dst = output_buffer + lead + offset % 2;
+    if (deferred && bpp == 14 && fh->rawi_hdr.raw_info.black_level >= 0) {
+        // recorded, not run: the payload waits in d_a for the stages that follow (lazy_run)
+        LazyFrame &z = c->lazy;
+        z.active = true; z.host = dst; z.bytes = out_b;
+        z.w = fh->rawi_hdr.xRes; z.h = fh->rawi_hdr.yRes;
+        z.black = fh->rawi_hdr.raw_info.black_level; z.white = fh->rawi_hdr.raw_info.white_level;
+        z.rank = RANK_UNPACK; z.pix.reset(); z.cs = 0; z.stripes = false;
+        if (hipEventSynchronize(c->ev_up) != hipSuccess) return 0;
+        return max_size;
+    }
+    if (launch_unpack(c->d_a, 0, c->d_res[0], 0, first_px, npix, bpp, 1, c->stream)) return 0;
     // process_frame's call -- the whole frame (main.c:942) --: the next stage on this buffer finds it on the device
     // (MLVFS_AMD_RESIDENT=1, 2); a window of the frame is delivered at once in every mode
     if (offset == 0 && out_b == dng_get_image_size(fh)) {
@@ -338,6 +414,11 @@ void chroma_smooth(struct frame_headers *fh, uint16_t *image_data, int method)
     ThreadCtx *c = thread_ctx();
     if (!c) return;
     const size_t bytes = (size_t)v.w * v.h * 2;
+    if (lazy_next(c, image_data, bytes, RANK_CS) && v.black == c->lazy.black) {
+        c->lazy.cs = method;
+        c->lazy.rank = RANK_CS;
+        return;
+    }
     void *d_in = nullptr, *d_out = nullptr;
     if (stage_frame(c, image_data, bytes, RANK_CS, &d_in, &d_out)) return;
     c->res_host = nullptr;
@@ -351,6 +432,27 @@ void chroma_smooth(struct frame_headers *fh, uint16_t *image_data, int method)
 }  // extern "C"
 
 namespace mlv {
+
+// the clip's bad-pixel map if it has been detected already (derived for this device / crop on first use); no GPU work on a frame
+bool cached_bad_clip(struct frame_headers *fh, ThreadCtx *c, int aggressive, std::shared_ptr<Clip> *out)
+{
+    const FrameView v = view_of(fh);
+    if (v.black > 16384 || !v.guid) return false;
+    std::lock_guard<std::mutex> lk(g_bad_mutex);
+    for (int i = 0; i < BAD_PIXEL_MAP_COUNT; i++) {
+        BadMap &m = g_bad_maps[i];
+        if (!(m.valid && v.guid == m.guid && aggressive == m.aggressive && m.w == v.w && m.h == v.h)) continue;
+        ClipRef &slot = m.clips[derived_key(v, c, 0)];
+        if (!slot) {
+            ClipRef fresh(make_clip(v, c));
+            if (fresh->set_pixel_map(m.xy.data(), m.xy.size() / 2, 0, 0)) { m.clips.erase(derived_key(v, c, 0)); return false; }
+            slot = fresh;
+        }
+        *out = slot;
+        return true;
+    }
+    return false;
+}
 
 int bad_pixels_device(struct frame_headers *fh, ThreadCtx *c, void *d_frame, int aggressive, int dual_iso, bool *changed, int *n_patched)
 {
@@ -475,6 +577,14 @@ void fix_bad_pixels(struct frame_headers *fh, uint16_t *image_data, int aggressi
     ThreadCtx *c = thread_ctx();
     if (!c) return;
     const size_t npix = (size_t)fh->rawi_hdr.xRes * fh->rawi_hdr.yRes, bytes = npix * 2;
+    if (lazy_next(c, image_data, bytes, RANK_BAD) && dual_iso == 0) {
+        ClipRef clip;
+        if (cached_bad_clip(fh, c, aggressive, &clip)) {      // (the first frame of a clip detects: that needs the pixels)
+            c->lazy.pix = clip;
+            c->lazy.rank = RANK_BAD;
+            return;
+        }
+    }
     void *d_in = nullptr;
     if (stage_frame(c, image_data, bytes, RANK_BAD, &d_in, nullptr)) return;
     const int which = c->res_cur;
@@ -597,6 +707,12 @@ void stripes_apply_correction(struct frame_headers *fh, struct stripes_correctio
     const int start = (int)(((offset % 8) + 8) % 8);
     for (int k = 0; k < 8; k++) coef[k] = correction->coeffficients[(k + start) % 8];
     const size_t padded = (size + 7) / 8 * 8, bytes = padded * 2;
+    if (padded == size && start == 0 && lazy_next(c, image_data, bytes, RANK_STRIPES) && v.black == c->lazy.black && v.white == c->lazy.white) {
+        memcpy(c->lazy.coef, coef, sizeof coef);
+        c->lazy.stripes = true;
+        c->lazy.rank = RANK_STRIPES;
+        return;
+    }
     void *d_in = nullptr;
     if (padded == size) {
         if (stage_frame(c, image_data, bytes, RANK_STRIPES, &d_in, nullptr)) return;
@@ -634,7 +750,10 @@ void hist_add(struct histogram *h, uint16_t *data, uint32_t size, uint16_t skip)
     // are still on the GPU then
     if (resident_level() == 2) {
         ThreadCtx *c = thread_ctx();
-        if (c && c->res_dirty && (const uint8_t *)data >= (const uint8_t *)c->res_host &&
+        if (c && c->lazy.active && (const uint8_t *)data >= (const uint8_t *)c->lazy.host &&
+            (const uint8_t *)data < (const uint8_t *)c->lazy.host + c->lazy.bytes)
+            (void)mlvfs_amd_frame_sync(c->lazy.host);
+        else if (c && c->res_dirty && (const uint8_t *)data >= (const uint8_t *)c->res_host &&
             (const uint8_t *)data < (const uint8_t *)c->res_host + c->res_bytes)
             (void)mlvfs_amd_frame_sync(const_cast<void *>(c->res_host));
     }

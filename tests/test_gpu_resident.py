@@ -151,9 +151,16 @@ def test_deferred_process_frame_mirror_and_threads(gpu, oracle):
             fh.file_hdr.fileGuid = 0x7000 + i
             got[i] = pipeline.process_frame(synth.pack_bits(frames[i]), fh, opt, mlv_filename=f"t{i}.MLV")
 
+    stats0 = (C.c_longlong * 2)()
+    gpu.mlvfs_amd_dropin_stats(stats0)
     th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
     for t in th: t.start()
     for t in th: t.join()
     for i in range(4):
         assert np.array_equal(got[i], want[i]), i
+    # every thread's first frame detects its clip's bad pixels (that needs the pixels: the recorded unpack runs early); the two
+    # that follow are recorded from the unpack to the chroma smoothing and run as one launch of the fused kernel at the sync
+    stats = (C.c_longlong * 2)()
+    gpu.mlvfs_amd_dropin_stats(stats)
+    assert stats[0] - stats0[0] == 8 and stats[1] - stats0[1] == 4, (list(stats0), list(stats))
     gpu.free_focus_pixel_maps()
