@@ -103,6 +103,12 @@ __device__ __forceinline__ float diag_bound(float rb, float centre, float lo, fl
 //     walked by ONE workgroup in the reference's order (`rows_per_wg`, chain_len = tiles_x).
 // Not reproduced: what equal-size neighbours leave INSIDE each other's written range; the only reads of that kind
 // are the overrun lanes of the pmwt sweep, which are 0 and provably stay 0 unless the garbage case above applies.
+#ifdef AMAZE_DIAG
+__device__ unsigned long long g_amaze_stamps[16];
+#define AMZ_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && tk == 0) g_amaze_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AMZ_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, int w, int h, float *__restrict__ red,
                                                  float *__restrict__ green_out, float *__restrict__ blue, float *__restrict__ scratch,
                                                  int tiles_x, int row0, int wgs_per_row, int chain_len, int rows_per_wg, int copy_from)
@@ -138,6 +144,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
     const float *c = t.cfa;
     auto RAW = [&](int y, int x) -> float { return x < w ? raw[(size_t)y * w + x] : 0.0f; };   // the reference's rows are zero padded
 
+    AMZ_STAMP(0);
     // ---- tile load + mirrored apron (:361-469; w % 4 == 0, so the vector groups of the loader never straddle a region).
     // The fills address the tile by FLAT index and run in the reference's order, because they overlap: a right-edge
     // fill that starts less than 16 columns before the end of a tile row (ccmax + 16 > 160) runs on into the first
@@ -204,6 +211,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
     for (int n = tid; n < HALF; n += nt) { s_nyq[n] = 0; t.rbint[n] = 0.0f; }
     __syncthreads();
 
+    AMZ_STAMP(1);
     // ---- gradients (:537-613)
     {
         const int cw = (cc1 + 3) & ~3, rows = rr1 - 4;
@@ -227,6 +235,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
     }
     __syncthreads();
 
+    AMZ_STAMP(2);
     // ---- directional colour differences (:622-675)
     {
         const float *d0 = t.dw0, *d1 = t.dw1;
@@ -257,6 +266,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
     }
     __syncthreads();
 
+    AMZ_STAMP(3);
     // ---- refinement of the colour differences (:766-801)
     {
         const int lanes = 4 * iters(4, cc1 - 4, 4), rows = rr1 - 8;
@@ -278,26 +288,52 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
         }
         __syncthreads();
         // vertical: one thread per (column, row parity) walks down; also the squared difference of the two
+        // The walk carries ONE value from row to row (the refined difference two rows up); everything else it reads is unrefined
+        // data of rows it has not reached.  The operands of the rows ahead are in flight while a row is computed and stored: a
+        // ring of VCD_AHEAD rows (the in-place store made the compiler wait for each row's loads in turn: 1 200 cycles per row, a
+        // quarter of the tile's time).
+        constexpr int VCD_AHEAD = 4;
         for (int n = tid; n < 2 * lanes; n += nt) {
             const int cc = 4 + n / 2;
-            float up = 0.0f;
-            bool have = false;
-            for (int rr = 4 + (n & 1); rr < rr1 - 4; rr += 2) {
-                const int i = rr * T + cc;
-                const float sgn = ((rr + cc) & 1) ? -1.0f : 1.0f;
-                if (!have) up = t.vcd[i - V2];               // rows 2,3 are never written: zero like the reference's block
-                const float vv = var3(up, t.vcd[i], t.vcd[i + V2]), vav = var3(t.vcdalt[i - V2], t.vcdalt[i], t.vcdalt[i + V2]);
-                const float v = bound_difference(vav < vv ? t.vcdalt[i] : t.vcd[i], sgn, c[i], c[i - V1], c[i + V1]);
-                t.vcd[i] = v;
-                t.cdsq[i] = sq(v - t.hcd2[i]);
-                up = v;
-                have = true;
+            const int r0 = 4 + (n & 1), r_end = rr1 - 4;
+            if (r0 >= r_end) continue;
+            const int i0 = r0 * T + cc;
+            const int last = i0 + ((r_end - 1 - r0) / 2) * V2;           // index of the walk's last row (loads beyond it are clamped to it)
+            float up = t.vcd[i0 - V2];                       // rows 2,3 are never written: zero like the reference's block
+            // per row: vcd two rows below, vcdalt two rows below, cfa above / at / below, hcd2
+            float q_v[VCD_AHEAD], q_a[VCD_AHEAD], q_cm[VCD_AHEAD], q_c0[VCD_AHEAD], q_cp[VCD_AHEAD], q_h[VCD_AHEAD];
+#pragma unroll
+            for (int d = 0; d < VCD_AHEAD; d++) {
+                const int j = min(i0 + d * V2, last);
+                q_v[d] = t.vcd[j + V2]; q_a[d] = t.vcdalt[j + V2]; q_cm[d] = c[j - V1]; q_c0[d] = c[j]; q_cp[d] = c[j + V1]; q_h[d] = t.hcd2[j];
+            }
+            float v0 = t.vcd[i0], a_1 = t.vcdalt[i0 - V2], a0 = t.vcdalt[i0];
+            int i = i0;
+            for (int rr = r0; rr < r_end; rr += 2 * VCD_AHEAD) {
+#pragma unroll
+                for (int d = 0; d < VCD_AHEAD; d++) {
+                    if (rr + 2 * d < r_end) {
+                        const float sgn = ((rr + cc) & 1) ? -1.0f : 1.0f;            // (rows of one walk have one parity)
+                        const float v1 = q_v[d], a1 = q_a[d], cm = q_cm[d], c0 = q_c0[d], cp = q_cp[d], h2 = q_h[d];
+                        // refill this slot with the row VCD_AHEAD steps ahead
+                        const int j = min(i + VCD_AHEAD * V2, last);
+                        q_v[d] = t.vcd[j + V2]; q_a[d] = t.vcdalt[j + V2]; q_cm[d] = c[j - V1]; q_c0[d] = c[j]; q_cp[d] = c[j + V1]; q_h[d] = t.hcd2[j];
+                        const float vv = var3(up, v0, v1), vav = var3(a_1, a0, a1);
+                        const float v = bound_difference(vav < vv ? a0 : v0, sgn, c0, cm, cp);
+                        t.vcd[i] = v;
+                        t.cdsq[i] = sq(v - h2);
+                        up = v;
+                        v0 = v1; a_1 = a0; a0 = a1;
+                        i += V2;
+                    }
+                }
             }
         }
     }
     __syncthreads();
     const float *hc = t.hcd2, *vc = t.vcd;
 
+    AMZ_STAMP(4);
     // ---- horizontal/vertical weight (:881-925) and the Nyquist texture test (:969-996)
     int flagged = 0;
     {
@@ -346,6 +382,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
     flagged = __syncthreads_or(flagged);
 
     if (flagged) {
+        AMZ_STAMP(5);
         // ---- majority vote in raster order (:998-1010) as wavefronts of constant 2*row + col
         const int tau_lo = 2 * 8 + 8, tau_hi = 2 * (rr1 - 9) + (cc1 - 9);
         for (int tau = tau_lo; tau <= tau_hi; tau++) {
@@ -362,6 +399,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
             }
             __syncthreads();
         }
+        AMZ_STAMP(6);
         // ---- area interpolation in Nyquist regions (:1016-1044)
         const int rows = rr1 - 16, sites_max = iters(8, cc1 - 8, 2);
         for (int n = tid; n < rows * sites_max; n += nt) {
@@ -386,6 +424,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
         __syncthreads();
     }
 
+    AMZ_STAMP(7);
     // ---- G at R/B sites (:1046-1073): the weight update reads the updated row above -> one row per barrier in LDS
     for (int n = tid; n < HALF; n += nt) s_w[n] = t.hvwt[n];
     __syncthreads();
@@ -441,6 +480,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
         }
     }
 
+    AMZ_STAMP(8);
     // ---- diagonal interpolation (:1112-1276)
     {
         const float G_EVEN[2] = { 0.13719494435797422f, 0.05640252782101291f };
@@ -476,11 +516,21 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
                 const int b0 = rr * T + cc0, j = b0 / 2 + tid;
                 const float alt = 0.25f * (s_w[(b0 - M1) / 2 + tid] + s_w[(b0 + P1) / 2 + tid] + s_w[(b0 - P1) / 2 + tid] + s_w[(b0 + M1) / 2 + tid]);
                 const float cur = s_w[j];
-                const float nw = fabsf(0.5f - cur) < fabsf(0.5f - alt) ? alt : cur;
-                s_w[j] = nw;
-                t.rbint[j] = 0.5f * (c[b0 + 2 * tid] + t.rbm[j] * (1.0f - nw) + t.rbp[j] * nw);
+                s_w[j] = fabsf(0.5f - cur) < fabsf(0.5f - alt) ? alt : cur;
             }
             __syncthreads();
+        }
+        // rbint from the row's final weight (a site's weight is written once, in its own row's step): all rows at once, instead of
+        // three global loads inside every step of the walk above (that was a quarter of the tile's time)
+        {
+            const int rows_w = rr1 - 20, lanes_w = 4 * iters(10, cc1 - 10, 8);
+            for (int n = tid; n < rows_w * lanes_w; n += nt) {
+                const int rr = 10 + n / lanes_w, m = n % lanes_w, cc0 = 10 + (rr & 1);
+                if (m >= 4 * iters(cc0, cc1 - 10, 8)) continue;
+                const int b0 = rr * T + cc0, j = b0 / 2 + m;
+                const float nw = s_w[j];
+                t.rbint[j] = 0.5f * (c[b0 + 2 * m] + t.rbm[j] * (1.0f - nw) + t.rbp[j] * nw);
+            }
         }
         for (int n = tid; n < HALF; n += nt) t.pmwt[n] = s_w[n];
         // (s_w keeps pmwt for the next sweep; rbint was written through to HBM: make it visible)
@@ -519,6 +569,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
     }
     __syncthreads();
 
+    AMZ_STAMP(9);
     // ---- chrominance (:1345-1395)
     {
         const int rows = iters(13, rr1 - 12, 2), sites = iters(13, cc1 - 12, 2);
@@ -548,6 +599,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
     }
     __syncthreads();
 
+    AMZ_STAMP(10);
     // ---- the three planes of the tile interior (:1397-1470)
     {
         const float *hw = t.hvwt, *g = t.green;
@@ -572,6 +624,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
         }
     }
     __syncthreads();
+    AMZ_STAMP(11);
     }   // tiles of this workgroup
 }
 
@@ -605,6 +658,22 @@ int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green,
         }
     }
     MLV_HIP(hipGetLastError());
+#ifdef AMAZE_DIAG
+    {
+        static int shown = 0;
+        if (shown++ == 3) {
+            unsigned long long st[16];
+            hipStreamSynchronize(s);
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(g_amaze_stamps), sizeof st);
+            const char *names[12] = { "load + apron", "gradients", "directional differences", "refinement (vcd walk)", "hv weight + nyquist test",
+                                      "majority vote", "area interpolation", "G at R/B (row by row)", "diagonal interpolation (row by row)",
+                                      "chrominance", "output planes", "" };
+            fprintf(stderr, "AMAZE_DIAG cycles of workgroup 0, first tile (s_memtime):");
+            for (int k = 0; k + 1 < 12; k++) fprintf(stderr, "\n  %-36s %8lld", names[k], (long long)(st[k + 1] - st[k]));
+            fprintf(stderr, "\n  total %lld\n", (long long)(st[11] - st[0]));
+        }
+    }
+#endif
     return MLVFS_AMD_OK;
 }
 
