@@ -17,28 +17,35 @@ geom = lib.Geom(w, h, 14, synth.BLACK, synth.WHITE, 0, 0)
 devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(1); os.dup2(devnull, 1)      # the reference's progress printf()s
 
 
-def worker(n, bufs, stream, out):
+def worker(n, bufs, warm, stream, out, start, t_begin, t_end, idx):
+    # steady state: one conversion of warm-up per thread (its stream and work buffers), barrier, clock; the thread's end (buffers
+    # released, a device-wide synchronisation) is outside the clock
+    gpu.mlvfs_amd_cr2hdr20_dev(C.byref(geom), C.c_void_p(warm.data_ptr()), interp, 1, 1, 0, C.c_void_p(stream.cuda_stream))
+    stream.synchronize()
+    if start.wait() == 0:
+        t_begin[0] = time.perf_counter()
+    start.wait()
     ok = 0
     for k in range(n):
         ok += gpu.mlvfs_amd_cr2hdr20_dev(C.byref(geom), C.c_void_p(bufs[k].data_ptr()), interp, 1, 1, 0, C.c_void_p(stream.cuda_stream))
     stream.synchronize()
+    t_end[idx] = time.perf_counter()
     out.append(ok)
 
 
 try:
     ref = None
-    for threads in (1, 2, 4, 8, 16):
+    for threads in [int(x) for x in os.environ.get("DI_THREADS", "1,2,4,8,16").split(",")]:
         streams = [torch.cuda.Stream() for _ in range(threads)]
-        for rep in range(2):                                   # first repetition warms every thread's scratch buffers
-            bufs = [[src.clone() for _ in range(per_thread)] for _ in range(threads)]
-            torch.cuda.synchronize()
-            res = []
-            ths = [threading.Thread(target=worker, args=(per_thread, bufs[i], streams[i], res)) for i in range(threads)]
-            t0 = time.perf_counter()
-            for t in ths: t.start()
-            for t in ths: t.join()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+        bufs = [[src.clone() for _ in range(per_thread)] for _ in range(threads)]
+        warm = [src.clone() for _ in range(threads)]
+        torch.cuda.synchronize()
+        res, start, t_begin, t_end = [], threading.Barrier(threads), [0.0], [0.0] * threads
+        ths = [threading.Thread(target=worker, args=(per_thread, bufs[i], warm[i], streams[i], res, start, t_begin, t_end, i)) for i in range(threads)]
+        for t in ths: t.start()
+        for t in ths: t.join()
+        torch.cuda.synchronize()
+        dt = max(t_end) - t_begin[0]
         assert sum(res) == threads * per_thread
         if ref is None: ref = bufs[0][0].clone()
         assert all(torch.equal(b, ref) for bb in bufs for b in bb), "results differ between threads"
