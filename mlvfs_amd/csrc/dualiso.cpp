@@ -369,7 +369,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     // ---- hdr_check + all histograms in one pass
     const size_t ph_hist = 0, ph_ds = ph_hist + sizeof(unsigned) * DI_HIST_WORDS, ph_bs = ph_ds + ns * 4, ph_hb = ph_bs + ns * 4,
                  ph_hd = ph_hb + sizeof(unsigned) * DI_HIST_N, ph_tail = ph_hd + sizeof(unsigned) * DI_HIST_N,
-                 ph_dev = ph_tail + (size_t)32 * w * 2, ph_edge = ph_dev + sizeof(unsigned) * DI_D_WORDS,
+                 ph_dev = ph_tail + (size_t)32 * w * 2, ph_edge = ph_dev + (o_check - o_hist) + 256,       // (the check sums travel behind the block)
                  ph_rows = ph_edge + (size_t)13 * w * 2, ph_end = ph_rows + (size_t)nsy_max * 12;
     PinnedWork &pw = t_pinned[c->dev->id];
     rc = pw.ensure(ph_end);
@@ -386,12 +386,12 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
         if (r) return r;
         unsigned *dev = (unsigned *)(PH + ph_dev);
         uint16_t *edge = (uint16_t *)(PH + ph_edge);
-        MLV_HIP(hipMemcpyAsync(dev, B + o_hist, sizeof(unsigned) * DI_D_WORDS, hipMemcpyDeviceToHost, stream));
+        MLV_HIP(hipMemcpyAsync(dev, B + o_hist, (o_check - o_hist) + 16, hipMemcpyDeviceToHost, stream));      // block + check sums: one copy
         MLV_HIP(hipMemcpyAsync(edge, d_frame, (size_t)top_rows * w * 2, hipMemcpyDeviceToHost, stream));
         MLV_HIP(hipMemcpyAsync(edge + (size_t)top_rows * w, (const uint16_t *)d_frame + (size_t)(H - bot_rows) * w, (size_t)bot_rows * w * 2,
                                hipMemcpyDeviceToHost, stream));
-        MLV_HIP(hipMemcpyAsync(check, B + o_check, 16, hipMemcpyDeviceToHost, stream));
         MLV_HIP(hipStreamSynchronize(stream));
+        memcpy(check, (const uint8_t *)dev + (o_check - o_hist), 16);
         unsigned *hb = hist.data() + DI_H_BAYER, *g0 = hist.data() + DI_H_GREEN0, *g1 = hist.data() + DI_H_GREEN1;
         memset(hb, 0, sizeof(unsigned) * 4 * 16384);
         for (int q = 0; q < 4; q++)
@@ -481,8 +481,8 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     if (rc) return rc;
     struct UintSpan { unsigned *p; size_t n; unsigned *data() const { return p; } const unsigned *begin() const { return p; } const unsigned *end() const { return p + n; } };
     const UintSpan hb{ (unsigned *)(PH + ph_hb), (size_t)DI_HIST_N }, hd{ (unsigned *)(PH + ph_hd), (size_t)DI_HIST_N };
-    MLV_HIP(hipMemcpyAsync(hb.data(), B + o_hb, sizeof(unsigned) * DI_HIST_N, hipMemcpyDeviceToHost, stream));
-    MLV_HIP(hipMemcpyAsync(hd.data(), B + o_hd, sizeof(unsigned) * DI_HIST_N, hipMemcpyDeviceToHost, stream));
+    static_assert(sizeof(unsigned) * DI_HIST_N % 256 == 0, "the two histograms lie back to back on the device and in the pinned block");
+    MLV_HIP(hipMemcpyAsync(hb.data(), B + o_hb, 2 * sizeof(unsigned) * DI_HIST_N, hipMemcpyDeviceToHost, stream));      // hb and hd in one copy
     MLV_HIP(hipStreamSynchronize(stream));
     long long n = 0;
     for (unsigned v : hb) n += v;

@@ -567,8 +567,13 @@ static inline dim3 flat_grid(size_t n) { size_t b = (n + 255) / 256; if (b > 819
 int di_launch_analyse(const void *d_img, int w, int H, int black, int white, const double *d_evf, unsigned *d_hist,
                       double *d_check, hipStream_t s)
 {
-    MLV_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * DI_D_WORDS, s));
-    MLV_HIP(hipMemsetAsync(d_check, 0, 2 * sizeof(double), s));
+    const ptrdiff_t gap = (const uint8_t *)d_check - (const uint8_t *)d_hist;
+    if (gap >= (ptrdiff_t)(sizeof(unsigned) * DI_D_WORDS) && gap < (ptrdiff_t)(sizeof(unsigned) * DI_D_WORDS) + 4096)
+        MLV_HIP(hipMemsetAsync(d_hist, 0, (size_t)gap + 2 * sizeof(double), s));                   // the check sums lie right behind: one call
+    else {
+        MLV_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * DI_D_WORDS, s));
+        MLV_HIP(hipMemsetAsync(d_check, 0, 2 * sizeof(double), s));
+    }
     hipLaunchKernelGGL(k_di_analyse, dim3((H + DI_BAND - 1) / DI_BAND, 4), dim3(256), 0, s, (const uint16_t *)d_img, w, H, black, white,
                        d_evf, d_hist, d_check);
     MLV_HIP(hipGetLastError());
@@ -578,8 +583,11 @@ int di_launch_analyse(const void *d_img, int w, int H, int black, int white, con
 int di_launch_subsample(const void *d_img, const DiParams &p, int nsx, int nsy, int *d_dark_s, int *d_bright_s,
                         unsigned *d_hist_b, unsigned *d_hist_d, hipStream_t s)
 {
-    MLV_HIP(hipMemsetAsync(d_hist_b, 0, sizeof(unsigned) * DI_HIST_N, s));
-    MLV_HIP(hipMemsetAsync(d_hist_d, 0, sizeof(unsigned) * DI_HIST_N, s));
+    if (d_hist_d == d_hist_b + DI_HIST_N) MLV_HIP(hipMemsetAsync(d_hist_b, 0, 2 * sizeof(unsigned) * DI_HIST_N, s));      // back to back: one call
+    else {
+        MLV_HIP(hipMemsetAsync(d_hist_b, 0, sizeof(unsigned) * DI_HIST_N, s));
+        MLV_HIP(hipMemsetAsync(d_hist_d, 0, sizeof(unsigned) * DI_HIST_N, s));
+    }
     if (nsx * nsy > 0)
         hipLaunchKernelGGL(k_di_subsample, dim3((nsx * nsy + 255) / 256), dim3(256), 0, s, (const uint16_t *)d_img, p, nsx, nsy,
                            d_dark_s, d_bright_s, d_hist_b, d_hist_d);
