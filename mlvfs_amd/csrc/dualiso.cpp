@@ -370,7 +370,11 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     const size_t ph_hist = 0, ph_ds = ph_hist + sizeof(unsigned) * DI_HIST_WORDS, ph_bs = ph_ds + ns * 4, ph_hb = ph_bs + ns * 4,
                  ph_hd = ph_hb + sizeof(unsigned) * DI_HIST_N, ph_tail = ph_hd + sizeof(unsigned) * DI_HIST_N,
                  ph_dev = ph_tail + (size_t)32 * w * 2, ph_edge = ph_dev + (o_check - o_hist) + 256,       // (the check sums travel behind the block)
-                 ph_rows = ph_edge + (size_t)13 * w * 2, ph_end = ph_rows + (size_t)nsy_max * 12;
+                 ph_rows = ph_edge + (size_t)13 * w * 2,
+                 // (every copy of this path starts or ends in this page-locked block: a copy from or to pageable memory waits inside
+                 // the runtime for the stream to reach it, and the calls of the other host threads wait with it)
+                 ph_cand = (ph_rows + (size_t)nsy_max * 12 + 63) / 64 * 64, ph_score = ph_cand + 8 * 2 * 3100, ph_sq = ph_score + 4 * 3100,
+                 ph_st = ph_sq + (size_t)H * 8, ph_end = ph_st + 64;
     PinnedWork &pw = t_pinned[c->dev->id];
     rc = pw.ensure(ph_end);
     if (rc) return rc;
@@ -513,21 +517,23 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
                               (const int *)(B + o_rows) + 2 * nsy, (int *)(B + o_hi_d), (int *)(B + o_hi_b), stream);
     if (rc) return rc;
     pt.mark("subsample + D2H + quantiles");
-    std::vector<double> cand;
+    double *cand = (double *)(PH + ph_cand);
+    int ncand = 0;
     for (double ev = 0; ev < 6; ev += 0.002) {
         const double ta = pow(2, -ev);
-        cand.push_back(ta);
-        cand.push_back(dmed - bmed * ta);
+        if (ncand >= 3100) break;                             // (3000 candidates: 6 / 0.002)
+        cand[2 * ncand] = ta;
+        cand[2 * ncand + 1] = dmed - bmed * ta;
+        ncand++;
     }
-    const int ncand = (int)cand.size() / 2;
     double a = 0, b = 0;
     if (hi_n > 0) {
-        MLV_HIP(hipMemcpyAsync(B + o_cand, cand.data(), cand.size() * 8, hipMemcpyHostToDevice, stream));
+        MLV_HIP(hipMemcpyAsync(B + o_cand, cand, (size_t)ncand * 16, hipMemcpyHostToDevice, stream));
         rc = di_launch_score((const int *)(B + o_hi_d), (const int *)(B + o_hi_b), hi_n, (const double *)(B + o_cand), ncand,
                              (int *)(B + o_score), stream);
         if (rc) return rc;
-        std::vector<int> score(ncand);
-        MLV_HIP(hipMemcpyAsync(score.data(), B + o_score, (size_t)ncand * 4, hipMemcpyDeviceToHost, stream));
+        int *score = (int *)(PH + ph_score);
+        MLV_HIP(hipMemcpyAsync(score, B + o_score, (size_t)ncand * 4, hipMemcpyDeviceToHost, stream));
         MLV_HIP(hipStreamSynchronize(stream));
         int best = 0;
         for (int k = 0; k < ncand; k++)
@@ -577,7 +583,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     if (rc) return rc;
     if (amaze) {
         // squeezed row map (hdr.c:977-1026): dark rows from the top, bright rows from h/4*2; rows that do not fit are dropped
-        std::vector<int> sq(2 * (size_t)h);
+        int *sq = (int *)(PH + ph_sq);                         // 2 h entries
         for (int y = 0; y < h; y++) { sq[y] = -1; sq[h + y] = 0; }
         for (int pass = 0; pass < 2; pass++) {
             int yh = -1;
@@ -597,7 +603,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
             for (int y = 0; y < h; y++)
                 if (sq[y] >= 0 && owner[sq[y]] != y) sq[y] = -1;
         }
-        MLV_HIP(hipMemcpyAsync(B + o_sq, sq.data(), sq.size() * 4, hipMemcpyHostToDevice, stream));
+        MLV_HIP(hipMemcpyAsync(B + o_sq, sq, (size_t)2 * h * 4, hipMemcpyHostToDevice, stream));
         float *amaze_scratch = nullptr;
         rc = amaze_scratch_for(c->dev->id, w, h, stream, &amaze_scratch);
         if (rc) return rc;
@@ -608,8 +614,8 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
         printf("AMaZE interpolation ...\n");
         rc = di_launch_amaze_interp(p, L, P, stream);
         if (rc) return rc;
-        unsigned st[4];
-        MLV_HIP(hipMemcpyAsync(st, P.stats, sizeof st, hipMemcpyDeviceToHost, stream));
+        unsigned *st = (unsigned *)(PH + ph_st);
+        MLV_HIP(hipMemcpyAsync(st, P.stats, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         MLV_HIP(hipStreamSynchronize(stream));               // also keeps `sq` alive until the upload has happened
         printf("Edge-directed interpolation...\n");
         printf("Semi-overexposed: %.02f%%\n", st[0] * 100.0 / (st[0] + st[1]));
