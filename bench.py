@@ -331,6 +331,33 @@ def extra_pcie(N=128, threads=16):
         res[f"dropin_symbols_resident{mode}"] = {"fps_1_thread": d["fps_1_threads"], f"fps_{threads}_threads": d[f"fps_{threads}_threads"],
                                                  "calls_per_frame": 5 + (mode == "2"), "equals_batch_api": d["frame1_hash"] == want1,
                                                  "identical_between_threads": d["identical_between_threads"]}
+    # (c) the same from a C host with pthreads (what MLVFS is): tools/dropin_bench_c.c, malloc'ed buffers, a memcpy per frame for the file read
+    try:
+        exe = os.path.join(ROOT, "build", "dropin_bench_c")
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        so_dir = os.path.join(ROOT, "mlvfs_amd")
+        subprocess.run(["gcc", "-std=gnu99", "-O2", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "dropin_bench_c.c"),
+                        "-o", exe, "-L", so_dir, "-lmlvfs_amd", "-Wl,-rpath," + so_dir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib",
+                        "-lamdhip64", "-lm"], check=True, capture_output=True, timeout=120)
+        frames = []
+        for k in range(2):
+            fn = os.path.join(ROOT, "build", f"dropin_frame{k}.bin")
+            synth.pack14(synth.normal_frame(W, H, seed=1, frame=k)).astype("<u2").tofile(fn)
+            frames.append(fn)
+        chost = {}
+        for mode in ("0", "1", "2"):
+            r = subprocess.run([exe, frames[0], frames[1], str(threads), "24", "0"], env=dict(os.environ, MLVFS_AMD_RESIDENT=mode),
+                               capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stderr.splitlines() if ln.startswith("{")]
+            if line:
+                d = json.loads(line[-1])
+                chost[f"resident{mode}"] = {"fps_1_thread": d["fps_1_threads"], f"fps_{threads}_threads": d[f"fps_{threads}_threads"],
+                                            "identical_between_threads": d["identical_between_threads"]}
+            else:
+                chost[f"resident{mode}"] = {"failed": f"rc {r.returncode}"}
+        res["dropin_symbols_c_host"] = chost
+    except Exception as e:                                   # no compiler on the box: the Python harness above stands
+        res["dropin_symbols_c_host"] = {"skipped": str(e)[:200]}
     res["note"] = "resident1: MLVFS_AMD_RESIDENT=1, a stage takes up the device copy the previous stage left for the same host buffer " \
                   "(upload skipped; every call still downloads what it changed before it returns).  resident2: no stage downloads, " \
                   "the host calls mlvfs_amd_frame_sync(buffer) after the last one (one line in process_frame, INTEGRATION.md); " \
