@@ -318,50 +318,63 @@ def extra_pcie(N=128, threads=16):
     s.close()
 
     want1 = synth.fnv1a(want[1].numpy().view(np.uint16))
-    # (b) the drop-in symbols, in a child process per mode (the library reads MLVFS_AMD_RESIDENT once per process)
-    for mode in ("0", "1", "2"):
-        env = dict(os.environ, MLVFS_AMD_RESIDENT=mode)
+    # (b) the drop-in symbols, in a child process per mode (the library reads MLVFS_AMD_RESIDENT once per process); "wrap": the
+    # frame bracket where process_frame calls mlvfs_load_chunks / mlvfs_close_chunks (integration/mlvfs_amd_wrap.c)
+    for mode in ("0", "1", "wrap"):
+        env = dict(os.environ, MLVFS_AMD_RESIDENT=mode) if mode != "wrap" else dict(os.environ, DROPIN_BRACKET="1")
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dropin_bench.py"), str(threads), "12"], env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not line:
-            res[f"dropin_symbols_resident{mode}"] = {"failed": f"rc {r.returncode}"}
+            res["dropin_symbols_" + ("wrap" if mode == "wrap" else f"resident{mode}")] = {"failed": f"rc {r.returncode}"}
             continue
         d = json.loads(line[-1])
-        res[f"dropin_symbols_resident{mode}"] = {"fps_1_thread": d["fps_1_threads"], f"fps_{threads}_threads": d[f"fps_{threads}_threads"],
-                                                 "calls_per_frame": 5 + (mode == "2"), "equals_batch_api": d["frame1_hash"] == want1,
+        res["dropin_symbols_" + ("wrap" if mode == "wrap" else f"resident{mode}")] = {"fps_1_thread": d["fps_1_threads"], f"fps_{threads}_threads": d[f"fps_{threads}_threads"],
+                                                 "equals_batch_api": d["frame1_hash"] == want1,
                                                  "identical_between_threads": d["identical_between_threads"]}
-    # (c) the same from a C host with pthreads (what MLVFS is): tools/dropin_bench_c.c, malloc'ed buffers, a memcpy per frame for the file read
+    # (c) the same from a C host with pthreads (what MLVFS is): tools/dropin_bench_c.c, malloc'ed buffers, a memcpy per frame for the
+    # file read.  ONE source, which calls the reference's symbols only, linked twice: plainly, and with integration/mlvfs_amd_wrap.c
+    # + --wrap of mlvfs_load_chunks / mlvfs_close_chunks (the link-only route: no line of the host changes)
     try:
         exe = os.path.join(ROOT, "build", "dropin_bench_c")
         os.makedirs(os.path.dirname(exe), exist_ok=True)
         so_dir = os.path.join(ROOT, "mlvfs_amd")
-        subprocess.run(["gcc", "-std=gnu99", "-O2", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "dropin_bench_c.c"),
-                        "-o", exe, "-L", so_dir, "-lmlvfs_amd", "-Wl,-rpath," + so_dir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib",
-                        "-lamdhip64", "-lm"], check=True, capture_output=True, timeout=120)
+        srcs = [os.path.join(ROOT, "tools", "dropin_bench_c.c"), os.path.join(ROOT, "tests", "c_host_chunks.c")]
+        link = ["-L", so_dir, "-lmlvfs_amd", "-Wl,-rpath," + so_dir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-lm"]
+        cc = ["gcc", "-std=gnu99", "-O2", "-pthread", "-I", os.path.join(ROOT, "include")]
+        subprocess.run(cc + srcs + ["-o", exe] + link, check=True, capture_output=True, timeout=120)
+        subprocess.run(cc + srcs + [os.path.join(ROOT, "integration", "mlvfs_amd_wrap.c"), "-Wl,--wrap=mlvfs_load_chunks",
+                                    "-Wl,--wrap=mlvfs_close_chunks", "-o", exe + "_wrap"] + link, check=True, capture_output=True, timeout=120)
         frames = []
         for k in range(2):
             fn = os.path.join(ROOT, "build", f"dropin_frame{k}.bin")
             synth.pack14(synth.normal_frame(W, H, seed=1, frame=k)).astype("<u2").tofile(fn)
             frames.append(fn)
         chost = {}
-        for mode in ("0", "1", "2"):
-            r = subprocess.run([exe, frames[0], frames[1], str(threads), "24", "0"], env=dict(os.environ, MLVFS_AMD_RESIDENT=mode),
+        for mode in ("0", "1", "wrap"):
+            key = "wrap" if mode == "wrap" else f"resident{mode}"
+            dump = os.path.join(ROOT, "build", "dropin_frame1_out.bin")
+            if os.path.exists(dump):
+                os.remove(dump)
+            r = subprocess.run([exe + "_wrap" if mode == "wrap" else exe, frames[0], frames[1], str(threads), "24", "0"],
+                               env=dict(os.environ, MLVFS_AMD_RESIDENT="0" if mode == "wrap" else mode, DROPIN_DUMP=dump),
                                capture_output=True, text=True, timeout=300)
             line = [ln for ln in r.stderr.splitlines() if ln.startswith("{")]
             if line:
                 d = json.loads(line[-1])
-                chost[f"resident{mode}"] = {"fps_1_thread": d["fps_1_threads"], f"fps_{threads}_threads": d[f"fps_{threads}_threads"],
-                                            "identical_between_threads": d["identical_between_threads"]}
+                chost[key] = {"fps_1_thread": d["fps_1_threads"], f"fps_{threads}_threads": d[f"fps_{threads}_threads"],
+                              "identical_between_threads": d["identical_between_threads"], "equals_batch_api": os.path.exists(dump) and bool(np.array_equal(np.fromfile(dump, "<u2"), want[1].numpy().view(np.uint16))),
+                              "fused_at_fetch": d.get("fused_at_fetch")}
             else:
-                chost[f"resident{mode}"] = {"failed": f"rc {r.returncode}"}
+                chost[key] = {"failed": f"rc {r.returncode}"}
         res["dropin_symbols_c_host"] = chost
     except Exception as e:                                   # no compiler on the box: the Python harness above stands
         res["dropin_symbols_c_host"] = {"skipped": str(e)[:200]}
     res["note"] = "resident1: MLVFS_AMD_RESIDENT=1, a stage takes up the device copy the previous stage left for the same host buffer " \
-                  "(upload skipped; every call still downloads what it changed before it returns).  resident2: no stage downloads, " \
-                  "the host calls mlvfs_amd_frame_sync(buffer) after the last one (one line in process_frame, INTEGRATION.md); " \
-                  "a C host with pthreads: tools/dropin_bench_c.sh"
+                  "(upload skipped; every call still downloads what it changed before it returns).  wrap: the host is linked with " \
+                  "integration/mlvfs_amd_wrap.c and -Wl,--wrap=mlvfs_load_chunks -Wl,--wrap=mlvfs_close_chunks -- no source line of the " \
+                  "host changes --: the stages between the two calls are recorded and run as one fused launch, the frame crosses " \
+                  "PCIe once each way (INTEGRATION.md section 1); a C host with pthreads: tools/dropin_bench_c.sh"
     return res
 
 

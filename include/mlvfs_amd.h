@@ -287,14 +287,25 @@ int mlvfs_amd_amaze_demosaic_dev(const float *d_raw, int width, int height, floa
 int mlvfs_amd_timer_begin(int max_launches);
 int mlvfs_amd_timer_end(float *ms, int cap);
 
-/* MLVFS_AMD_RESIDENT=2 in the environment: the drop-in stages of PART 1 leave their result for `image_data` on the GPU and do
- * not write the host buffer; this call, by the same thread after the last stage, fetches it (one download per frame instead of
- * one per stage).  What main.c:996 would be followed by in process_frame -- see INTEGRATION.md.  In every other mode, and for a
- * buffer nothing is pending for, it does nothing.  0 = the host buffer is current. */
+/* FRAME BRACKET.  process_frame (mlvfs/main.c:908-1005) brackets its stages with mlvfs_load_chunks (main.c:923) and
+ * mlvfs_close_chunks (main.c:998, resource_manager.c:285-317) on the calling thread and nothing of MLVFS reads image_buffer->data
+ * in between (deflicker's hist_add is served, see below).  Between mlvfs_amd_frame_begin() and mlvfs_amd_frame_end() on one thread
+ * the drop-in stages of PART 1 therefore do not write the host buffer: unpack, bad-pixel repair (once the clip's map is known),
+ * chroma smoothing and stripes are RECORDED and run as one launch of the fused kernel on the packed payload, and the frame is
+ * downloaded once, inside mlvfs_amd_frame_end().  integration/mlvfs_amd_wrap.c + `-Wl,--wrap=mlvfs_load_chunks
+ * -Wl,--wrap=mlvfs_close_chunks` make those two calls of the UNCHANGED main.c the bracket.
+ * Outside a bracket every call completes before it returns -- gif_get_data (gif.c:90-221) uses load_chunks / close_chunks
+ * directly and reads the frame right after get_image_data.  Both calls are cheap no-ops for a thread that does no pixel work in
+ * between (mlv_get_frame_headers, main.c:434-555, brackets a header walk the same way); MLVFS_AMD_DEFER=0 in the environment
+ * disables the deferral.  0 = ok / the host buffer is current. */
+int mlvfs_amd_frame_begin(void);
+int mlvfs_amd_frame_end(void);
+/* inside a bracket: fetch the frame at `image_data` NOW (a host that wants the pixels before the bracket ends).  Does nothing
+ * outside a bracket and for a buffer nothing is pending for.  0 = the host buffer is current. */
 int mlvfs_amd_frame_sync(void *image_data);
-/* MLVFS_AMD_RESIDENT=2 records the stages process_frame asks for and runs them as ONE launch of the fused kernel when the frame is
- * fetched.  out[0]: frames of this process that went that way; out[1]: frames whose recorded stages had to run earlier (a call
- * outside process_frame's order, the first frame of a clip, a focus-pixel map, pattern noise, dual ISO). */
+/* out[0]: frames of this process whose recorded stages ran as ONE fused launch at the fetch; out[1]: frames whose recorded stages
+ * had to run earlier (a call outside process_frame's order, the first frame of a clip, a focus-pixel map, pattern noise, dual ISO,
+ * hist_add on the frame). */
 void mlvfs_amd_dropin_stats(long long out[2]);
 
 /* self tests that need no GPU (selection networks, LUT identities): 0 = pass */

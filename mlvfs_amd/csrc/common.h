@@ -68,8 +68,8 @@ struct LibcRandGuard {
 };
 
 struct Clip;
-// MLVFS_AMD_RESIDENT=2: the stages process_frame has asked for so far on the frame whose packed payload sits in d_a.  They run as
-// ONE launch of the fused kernel -- the batch path's -- when the frame is fetched (mlvfs_amd_frame_sync) or when a call comes
+// Frame bracket (dropin.cpp): the stages process_frame has asked for so far on the frame whose packed payload sits in d_a.  They run as
+// ONE launch of the fused kernel -- the batch path's -- when the frame is fetched (mlvfs_amd_frame_end / _sync) or when a call comes
 // that cannot be recorded (dropin.cpp)
 struct LazyFrame {
     bool active = false;
@@ -103,9 +103,9 @@ struct ThreadCtx {         // one per (host thread, device)
     size_t res_bytes = 0;
     int res_cur = 0;
     int res_rank = 0;                    // which stage left the resident copy (dropin.cpp: stages only continue in process_frame's order)
-    bool res_dirty = false;              // MLVFS_AMD_RESIDENT=2: the resident copy is newer than the host buffer (mlvfs_amd_frame_sync)
+    bool res_dirty = false;              // frame bracket: the resident copy is newer than the host buffer (mlvfs_amd_frame_end / _sync)
     LazyFrame lazy;
-    hipEvent_t ev_up = nullptr;          // end of the upload of dng_get_image_data's input (dropin.cpp, MLVFS_AMD_RESIDENT=2)
+    hipEvent_t ev_up = nullptr;          // end of the upload of dng_get_image_data's input (dropin.cpp, frame bracket)
     uint64_t res_sig[RES_SAMPLES];
     int ensure_res(size_t bytes);
     int ensure(size_t need_a, size_t need_b);
@@ -119,8 +119,12 @@ void release_stream_state(int device, hipStream_t stream);
 
 // returns nullptr (and sets the error string) on failure
 ThreadCtx *thread_ctx();
+// the calling thread's context if it has one already (never creates a stream, never touches the GPU)
+ThreadCtx *thread_ctx_if_any();
+// everything the thread has deferred inside a frame bracket reaches its host buffer (dropin.cpp)
+int flush_pending(ThreadCtx *c);
 // a symbol that reads or rewrites the host frame itself: bring the host copy up to date if a deferred result of this thread is
-// pending for it (MLVFS_AMD_RESIDENT=2), then forget the resident copy (dropin.cpp)
+// pending for it (frame bracket), then forget the resident copy (dropin.cpp)
 int drop_resident(ThreadCtx *c, void *host);
 
 int bind_device(int device);

@@ -68,18 +68,39 @@ Clip *make_clip(const FrameView &v, ThreadCtx *c)
 // (Copies to and from the caller's pageable memory are the runtime's: staging them through a page-locked buffer of the thread's
 // own, chunk by chunk with the copying done by the calling thread, was measured and is slower -- 795 against 1093 frames/s
 // from 16 threads.)
-// MLVFS_AMD_RESIDENT=2 goes one step further for a host that calls mlvfs_amd_frame_sync(buffer) after the last stage (one line
-// in process_frame): the stages do not download at all, the frame crosses the link once in each direction --
-// 17.7 MB instead of 37-75 -- and the host buffer is NOT current until that call returns.
+// FRAME BRACKET ("level 2"): between mlvfs_amd_frame_begin() and mlvfs_amd_frame_end() on one thread the stages do not download
+// at all -- the frame crosses the link once in each direction, 17.7 MB instead of 37-75 -- and the host buffer is NOT current
+// until mlvfs_amd_frame_end() (or mlvfs_amd_frame_sync(buffer)) returns.  process_frame brackets its stages with
+// mlvfs_load_chunks (main.c:923) ... mlvfs_close_chunks (main.c:998) on the calling thread, and nothing of MLVFS reads the frame
+// buffer in between except deflicker's hist_add (handled below): integration/mlvfs_amd_wrap.c, linked with
+// -Wl,--wrap=mlvfs_load_chunks -Wl,--wrap=mlvfs_close_chunks, turns those two calls into the bracket with main.c byte for byte
+// unchanged.  OUTSIDE a bracket every call completes before it returns: gif_get_data (gif.c:90-221) opens its chunks with
+// load_chunks / close_chunks directly and reads the frame right after get_image_data (gif.c:164) -- it never sees a deferred unpack.
+// (Round 2 selected this behaviour process-wide with MLVFS_AMD_RESIDENT=2, which was wrong for exactly that caller; the value is
+// now read as 1.)  MLVFS_AMD_DEFER=0 in the environment makes the bracket calls do nothing.
 enum { RANK_UNPACK = 0, RANK_FOCUS = 1, RANK_BAD = 2, RANK_CS = 3, RANK_STRIPES_READ = 4, RANK_STRIPES = 5 };
+
+thread_local bool t_bracket = false;               // this thread is between mlvfs_amd_frame_begin and mlvfs_amd_frame_end
+
+bool defer_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("MLVFS_AMD_DEFER");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
 
 int resident_level()
 {
     static const int level = [] {
         const char *e = getenv("MLVFS_AMD_RESIDENT");
-        return e && e[0] == '2' ? 2 : (e && e[0] == '1' ? 1 : 0);
+        if (e && e[0] == '2')
+            fprintf(stderr, "mlvfs_amd: MLVFS_AMD_RESIDENT=2 is read as 1: deferred stages now need the frame bracket "
+                            "(integration/mlvfs_amd_wrap.c, or mlvfs_amd_frame_begin / mlvfs_amd_frame_end)\n");
+        return e && (e[0] == '1' || e[0] == '2') ? 1 : 0;
     }();
-    return level;
+    return t_bracket ? 2 : level;
 }
 bool resident_mode() { return resident_level() >= 1; }
 
@@ -99,14 +120,14 @@ void warn_unsynced(const void *host)
 {
     static std::atomic<bool> said{ false };
     if (!said.exchange(true))
-        fprintf(stderr, "mlvfs_amd: MLVFS_AMD_RESIDENT=2, but the frame at %p was never fetched with mlvfs_amd_frame_sync(): "
-                        "its host buffer holds stale pixels\n", host);
+        fprintf(stderr, "mlvfs_amd: the frame at %p, processed inside a frame bracket, was never fetched (mlvfs_amd_frame_end / "
+                        "mlvfs_amd_frame_sync): its host buffer holds stale pixels\n", host);
 }
 
 int download(ThreadCtx *c, void *host, const void *dev, size_t bytes);
 
-// ---- MLVFS_AMD_RESIDENT=2: recorded stages, one fused launch ---------------------------------------------------------------
-// In this mode nothing has to be in host memory before mlvfs_amd_frame_sync, so nothing has to RUN before it either: the unpack,
+// ---- frame bracket: recorded stages, one fused launch ------------------------------------------------------------------------
+// Inside a bracket nothing has to be in host memory before mlvfs_amd_frame_end, so nothing has to RUN before it either: the unpack,
 // the bad-pixel repair (once the clip's map is cached), the chroma smoothing and the stripe correction that process_frame asks
 // for are recorded, and run as ONE launch of the fused kernel on the packed payload (what mlvfs_amd_process_frames_dev does for a
 // batch) when the frame is fetched -- or earlier, when a call arrives that is not the next stage of process_frame's order or
@@ -221,7 +242,7 @@ int download(ThreadCtx *c, void *host, const void *dev, size_t bytes)
 }
 
 // A stage is done with the frame in device buffer `which`: download it (all of it, or -- pixel repairs -- the n_patched
-// entries of the thread's patch list) and remember the copy; MLVFS_AMD_RESIDENT=2: remember it as newer than the host buffer
+// entries of the thread's patch list) and remember the copy; inside a frame bracket: remember it as newer than the host buffer
 int download_patches(ThreadCtx *c, uint16_t *image, size_t npix, int n_entries);
 int finish_frame(ThreadCtx *c, void *host, size_t bytes, int rank, int which, int n_patched = -1)
 {
@@ -240,6 +261,16 @@ int finish_frame(ThreadCtx *c, void *host, size_t bytes, int rank, int which, in
     if (rc) return rc;
     commit_frame(c, host, bytes, rank, which);
     return MLVFS_AMD_OK;
+}
+
+// A stage failed after stage_frame handed it device buffer `which`: that buffer still holds what the previous stage left.  Inside
+// a frame bracket it may be the only up-to-date copy of the frame (`was_dirty`): the host buffer gets it before the copy is
+// forgotten, so the failed stage is skipped and nothing earlier is lost.
+void abandon_stage(ThreadCtx *c, void *host, size_t bytes, int which, bool was_dirty)
+{
+    if (was_dirty) (void)download(c, host, c->d_res[which], bytes);
+    c->res_dirty = false;
+    c->res_host = nullptr;
 }
 
 // pixel repairs: the kernel has left {position, value} per map entry in the thread's patch list (position -1: not the final
@@ -308,25 +339,59 @@ int mlv::drop_resident(ThreadCtx *c, void *host)
     return rc;
 }
 
-extern "C" {
-
-// MLVFS_AMD_RESIDENT=2: the stages called on `image_data` by this thread left their result on the GPU; fetch it.  A no-op in
-// the other modes and for a buffer nothing is pending for.  0 = the host buffer is current.
-int mlvfs_amd_frame_sync(void *image_data)
+// everything this thread has deferred reaches its host buffer: recorded stages run (one fused launch), a device copy newer than
+// the host buffer is downloaded.  The copy stays known as the buffer's mirror, so later stages may still take it up.
+int mlv::flush_pending(ThreadCtx *c)
 {
-    ThreadCtx *c = thread_ctx();
-    if (!c) return MLVFS_AMD_ERR_HIP;
-    LibcRandGuard rand_guard;
-    if (c->lazy.active && c->lazy.host == image_data && lazy_run(c, true)) return MLVFS_AMD_ERR_HIP;
-    if (!c->res_dirty || c->res_host != image_data) return MLVFS_AMD_OK;
-    if (download(c, image_data, c->d_res[c->res_cur], c->res_bytes)) return MLVFS_AMD_ERR_HIP;
+    if (c->lazy.active) {
+        int rc = lazy_run(c, true);
+        if (rc) return rc;
+    }
+    if (!c->res_dirty) return MLVFS_AMD_OK;
+    void *host = const_cast<void *>(c->res_host);
+    const int rc = download(c, host, c->d_res[c->res_cur], c->res_bytes);
     c->res_dirty = false;
-    sample_host(image_data, c->res_bytes, c->res_sig);          // later stages may still take the copy up (as with RESIDENT=1)
+    if (rc) { c->res_host = nullptr; return rc; }
+    sample_host(host, c->res_bytes, c->res_sig);
     return MLVFS_AMD_OK;
 }
 
-// how often this process ran recorded stages as one fused launch at mlvfs_amd_frame_sync [0], and how often earlier because a
-// call could not be recorded [1] (MLVFS_AMD_RESIDENT=2; for tests and tuning)
+extern "C" {
+
+// Frame bracket (see the top of this file).  mlvfs_amd_frame_begin: from here on this thread's drop-in stages are recorded or
+// leave their result on the GPU.  Costs nothing and touches no GPU: mlv_get_frame_headers (main.c:434,555) brackets a mere header
+// walk with the same two calls.  mlvfs_amd_frame_end: everything this thread deferred reaches its host buffer (recorded stages
+// run as one fused launch, one download), then calls complete at once again.  0 = the host buffer is current.
+int mlvfs_amd_frame_begin(void)
+{
+    if (defer_enabled()) t_bracket = true;
+    return MLVFS_AMD_OK;
+}
+
+int mlvfs_amd_frame_end(void)
+{
+    if (!t_bracket) return MLVFS_AMD_OK;
+    t_bracket = false;
+    ThreadCtx *c = thread_ctx_if_any();             // a bracket without pixel work never creates a stream
+    if (!c || (!c->lazy.active && !c->res_dirty)) return MLVFS_AMD_OK;
+    LibcRandGuard rand_guard;
+    return flush_pending(c);
+}
+
+// Inside a bracket: fetch the frame at `image_data` now (what mlvfs_amd_frame_end does for whatever is pending).  A no-op outside
+// a bracket and for a buffer nothing is pending for.  0 = the host buffer is current.
+int mlvfs_amd_frame_sync(void *image_data)
+{
+    ThreadCtx *c = thread_ctx_if_any();
+    if (!c) return MLVFS_AMD_OK;
+    const bool mine = (c->lazy.active && c->lazy.host == image_data) || (c->res_dirty && c->res_host == image_data);
+    if (!mine) return MLVFS_AMD_OK;
+    LibcRandGuard rand_guard;
+    return flush_pending(c);
+}
+
+// how often this process ran recorded stages as one fused launch at the fetch [0], and how often earlier because a call could not
+// be recorded [1] (for tests and tuning)
 void mlvfs_amd_dropin_stats(long long out[2])
 {
     out[0] = g_lazy_fused.load();
@@ -364,16 +429,18 @@ size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8
     const uint64_t last_bit = (uint64_t)(first_px + npix - 1) * bpp;
     const size_t words = (size_t)(last_bit / 16 - first_word) + 2;
     const size_t in_bytes = words * 2, out_b = (size_t)npix * 2;
-    if (c->ensure((in_bytes + 15) / 16 * 16, 0) || c->ensure_res((out_b + 15) / 16 * 16)) return 0;
+    // a new frame starts: whatever this thread still holds for an earlier one was never fetched (a bracket that was not closed);
+    // its host buffer may be gone by now, so it is dropped, not written
     if (c->res_dirty) warn_unsynced(c->res_host);
     if (c->lazy.active) { warn_unsynced(c->lazy.host); c->lazy.active = false; c->lazy.pix.reset(); }
     c->res_host = nullptr;
     c->res_dirty = false;
+    if (c->ensure((in_bytes + 15) / 16 * 16, 0) || c->ensure_res((out_b + 15) / 16 * 16)) return 0;
     if (upload(c, c->d_a, packed_bits, in_bytes)) {
         set_error("dng_get_image_data: upload failed");
         return 0;
     }
-    // MLVFS_AMD_RESIDENT=2 returns without waiting for the stream, but packed_bits is the caller's again on return: if it is
+    // inside a frame bracket the call returns without waiting for the stream, but packed_bits is the caller's again on return: if it is
     // page-locked memory the copy above is still under way then (from pageable memory it is not), so its end gets an event
     const bool deferred = resident_level() == 2 && offset == 0 && out_b == dng_get_image_size(fh);
     if (deferred) {
@@ -393,7 +460,7 @@ size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8
     }
     if (launch_unpack(c->d_a, 0, c->d_res[0], 0, first_px, npix, bpp, 1, c->stream)) return 0;
     // process_frame's call -- the whole frame (main.c:942) --: the next stage on this buffer finds it on the device
-    // (MLVFS_AMD_RESIDENT=1, 2); a window of the frame is delivered at once in every mode
+    // (MLVFS_AMD_RESIDENT=1, frame bracket); a window of the frame is delivered at once in every mode
     if (offset == 0 && out_b == dng_get_image_size(fh)) {
         if (finish_frame(c, dst, out_b, RANK_UNPACK, 0)) return 0;
         if (deferred && hipEventSynchronize(c->ev_up) != hipSuccess) return 0;
@@ -421,11 +488,14 @@ void chroma_smooth(struct frame_headers *fh, uint16_t *image_data, int method)
     }
     void *d_in = nullptr, *d_out = nullptr;
     if (stage_frame(c, image_data, bytes, RANK_CS, &d_in, &d_out)) return;
-    c->res_host = nullptr;
+    const int which = c->res_cur;
+    const bool was_dirty = c->res_dirty;
     if (launch_frame(c->dev, Geom{ v.w, v.h, v.bpp, v.black, v.white }, false, d_in, bytes, d_out, bytes, 1, method,
-                     nullptr, false, nullptr, c->stream))
+                     nullptr, false, nullptr, c->stream)) {
+        abandon_stage(c, image_data, bytes, which, was_dirty);
         return;
-    (void)finish_frame(c, image_data, bytes, RANK_CS, d_out == c->d_res[1]);
+    }
+    if (finish_frame(c, image_data, bytes, RANK_CS, which ^ 1)) abandon_stage(c, image_data, bytes, which, false);
 }
 
 // device-level forms (frame already in HBM at d_frame): shared with the dual-ISO path
@@ -588,10 +658,12 @@ void fix_bad_pixels(struct frame_headers *fh, uint16_t *image_data, int aggressi
     void *d_in = nullptr;
     if (stage_frame(c, image_data, bytes, RANK_BAD, &d_in, nullptr)) return;
     const int which = c->res_cur;
-    c->res_host = nullptr;
+    const bool was_dirty = c->res_dirty;
     int n_patched = 0;
-    if (bad_pixels_device(fh, c, d_in, aggressive, dual_iso, nullptr, &n_patched)) return;
-    (void)finish_frame(c, image_data, bytes, RANK_BAD, which, n_patched);
+    // (a repair that fails half way may have rewritten part of the device copy: the frame is then as good as the reference's
+    // after a failed malloc in the middle of cs.c:220-331 -- partly repaired)
+    if (bad_pixels_device(fh, c, d_in, aggressive, dual_iso, nullptr, &n_patched)) { abandon_stage(c, image_data, bytes, which, was_dirty); return; }
+    if (finish_frame(c, image_data, bytes, RANK_BAD, which, n_patched)) abandon_stage(c, image_data, bytes, which, false);
 }
 
 void fix_focus_pixels(struct frame_headers *fh, uint16_t *image_data, int dual_iso)
@@ -609,10 +681,10 @@ void fix_focus_pixels(struct frame_headers *fh, uint16_t *image_data, int dual_i
     void *d_in = nullptr;
     if (stage_frame(c, image_data, bytes, RANK_FOCUS, &d_in, nullptr)) return;
     const int which = c->res_cur;
-    c->res_host = nullptr;
+    const bool was_dirty = c->res_dirty;
     int n_patched = 0;
-    if (focus_pixels_device(fh, c, d_in, dual_iso, nullptr, &n_patched)) return;
-    (void)finish_frame(c, image_data, bytes, RANK_FOCUS, which, n_patched);
+    if (focus_pixels_device(fh, c, d_in, dual_iso, nullptr, &n_patched)) { abandon_stage(c, image_data, bytes, which, was_dirty); return; }
+    if (finish_frame(c, image_data, bytes, RANK_FOCUS, which, n_patched)) abandon_stage(c, image_data, bytes, which, false);
 }
 
 void free_focus_pixel_maps(void)                                                     // cs.c:403-418
@@ -727,10 +799,13 @@ void stripes_apply_correction(struct frame_headers *fh, struct stripes_correctio
         }
     }
     const int which = c->res_cur;
-    c->res_host = nullptr;
-    if (launch_stripes_apply(d_in, bytes, padded, v.w, v.black, v.white, coef, 1, c->stream)) return;
-    if (padded == size) (void)finish_frame(c, image_data, bytes, RANK_STRIPES, which);
-    else (void)download(c, image_data, d_in, size * 2);
+    const bool was_dirty = c->res_dirty;
+    if (launch_stripes_apply(d_in, bytes, padded, v.w, v.black, v.white, coef, 1, c->stream)) {
+        abandon_stage(c, image_data, padded == size ? bytes : 0, which, padded == size && was_dirty);
+        return;
+    }
+    if (padded == size) { if (finish_frame(c, image_data, bytes, RANK_STRIPES, which)) abandon_stage(c, image_data, bytes, which, false); }
+    else { (void)download(c, image_data, d_in, size * 2); c->res_host = nullptr; c->res_dirty = false; }
 }
 
 // ============================================================== histogram.h (host only)
@@ -746,10 +821,10 @@ struct histogram *hist_create(uint16_t white)                                   
 
 void hist_add(struct histogram *h, uint16_t *data, uint32_t size, uint16_t skip)     // histogram.c:52-59
 {
-    // main.c:943 runs deflicker() -- hist_add on the frame buffer -- right after the unpack: with MLVFS_AMD_RESIDENT=2 the pixels
+    // main.c:943 runs deflicker() -- hist_add on the frame buffer -- right after the unpack: inside a frame bracket the pixels
     // are still on the GPU then
     if (resident_level() == 2) {
-        ThreadCtx *c = thread_ctx();
+        ThreadCtx *c = thread_ctx_if_any();
         if (c && c->lazy.active && (const uint8_t *)data >= (const uint8_t *)c->lazy.host &&
             (const uint8_t *)data < (const uint8_t *)c->lazy.host + c->lazy.bytes)
             (void)mlvfs_amd_frame_sync(c->lazy.host);

@@ -151,7 +151,7 @@ int hdr_convert_data(struct frame_headers *fh, uint16_t *image_data, off_t offse
         // before the exposure matching; re-stage the frame only if something changed it
         std::vector<uint16_t> before(q->img, q->img + q->bytes / 2);
         fix_focus_pixels(q->fh, q->img, 1);
-        if (mlvfs_amd_frame_sync(q->img)) return MLVFS_AMD_ERR_HIP;       // (MLVFS_AMD_RESIDENT=2: the repair is wanted on the host now)
+        if (mlvfs_amd_frame_sync(q->img)) return MLVFS_AMD_ERR_HIP;       // (frame bracket: the repair is wanted on the host now)
         if (memcmp(before.data(), q->img, q->bytes) != 0)
             MLV_HIP(hipMemcpyAsync(q->c->d_a, q->img, q->bytes, hipMemcpyHostToDevice, q->c->stream));
         return MLVFS_AMD_OK;

@@ -237,8 +237,21 @@ ThreadCtx *thread_ctx()
     return c;
 }
 
+ThreadCtx *thread_ctx_if_any()
+{
+    if (t_device < 0) return nullptr;
+    auto it = t_ctxs.m.find(t_device);
+    return it == t_ctxs.m.end() ? nullptr : it->second;
+}
+
 int ThreadCtx::ensure(size_t need_a, size_t need_b)
 {
+    // d_a may hold the packed payload of a frame whose stages are recorded (frame bracket): whoever wants the scratch buffers
+    // now is not one of those stages, so they run first
+    if (lazy.active) {
+        const int rc = flush_pending(this);
+        if (rc) return rc;
+    }
     if (need_a > cap_a) {
         if (d_a) (void)hipFree(d_a);
         d_a = nullptr; cap_a = 0;
@@ -257,8 +270,13 @@ int ThreadCtx::ensure(size_t need_a, size_t need_b)
 int ThreadCtx::ensure_res(size_t bytes)
 {
     if (bytes <= cap_res) return MLVFS_AMD_OK;
+    if (lazy.active || res_dirty) {                  // the buffers about to be freed hold a frame the host has not got yet
+        const int rc = flush_pending(this);
+        if (rc) return rc;
+    }
     (void)hipStreamSynchronize(stream);
     res_host = nullptr;
+    res_dirty = false;
     for (int k = 0; k < 2; k++) {
         if (d_res[k]) (void)hipFree(d_res[k]);
         d_res[k] = nullptr;

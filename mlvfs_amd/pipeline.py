@@ -5,12 +5,18 @@ reference's process_frame (mlvfs/main.c:908-1005) on top of the DROP-IN symbols
 of libmlvfs_amd.so -- i.e. it calls exactly what MLVFS's unchanged main.c would
 call, with the same arguments, on host buffers:
 
+    mlvfs_load_chunks                               main.c:923
     get_image_data -> dng_get_image_data            main.c:942 (687-700)
     [fix_pattern_noise]                             main.c:946-949
     [hdr_convert_data | cr2hdr20_convert_data]      main.c:951-959
     fix_focus_pixels; [fix_bad_pixels]              main.c:968-972
     [chroma_smooth]                                 main.c:975-978
     [stripes get/new/compute (first frame) + apply] main.c:980-997
+    mlvfs_close_chunks                              main.c:998
+
+The two chunk calls belong to MLVFS (resource_manager.c:285-317).  A MLVFS linked with integration/mlvfs_amd_wrap.c and
+`-Wl,--wrap=mlvfs_load_chunks -Wl,--wrap=mlvfs_close_chunks` runs the library's frame bracket inside them; `WRAPPED = True`
+makes this mirror do the same (MLVFS_AMD_PIPELINE_WRAPPED=1 in the environment, or set by a test; default: the plain link).
 
 `MlvfsOptions` mirrors the flags of `struct mlvfs` (mlvfs/mlvfs.h:32-48) that reach
 the hot path.  The reference's container IO / FUSE plumbing is out of scope: the
@@ -19,11 +25,27 @@ packed payload and the frame_headers are handed in by the caller.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
 
 from . import abi, lib
+
+
+WRAPPED = os.environ.get("MLVFS_AMD_PIPELINE_WRAPPED") == "1"
+
+
+def mlvfs_load_chunks() -> None:
+    """main.c:923 as the wrap shim extends it (integration/mlvfs_amd_wrap.c): arms the frame bracket after the real call."""
+    if WRAPPED:
+        lib.load().mlvfs_amd_frame_begin()
+
+
+def mlvfs_close_chunks() -> None:
+    """main.c:998 as the wrap shim extends it: ends the bracket (the frame is fetched here) before the real call."""
+    if WRAPPED:
+        lib.check(lib.load().mlvfs_amd_frame_end(), "frame_end")
 
 
 @dataclass
@@ -56,6 +78,7 @@ def process_frame(packed: np.ndarray, fh: abi.FrameHeaders, opt: MlvfsOptions, m
     `fh` is mutated like the reference mutates its frame_headers (dual-ISO levels)."""
     L = lib.load()
     w, h = fh.rawi_hdr.xRes, fh.rawi_hdr.yRes
+    mlvfs_load_chunks()
     img = get_image_data(fh, packed).reshape(h, w)
     p = lib.ptr(img)
     if opt.fix_pattern_noise:
@@ -80,6 +103,5 @@ def process_frame(packed: np.ndarray, fh: abi.FrameHeaders, opt: MlvfsOptions, m
             if corr:
                 L.stripes_compute_correction(C.byref(fh), corr, p, 0, img.size)
         L.stripes_apply_correction(C.byref(fh), corr, p, 0, img.size)
-    # the one line a host adds to run with MLVFS_AMD_RESIDENT=2; does nothing in the other modes
-    lib.check(L.mlvfs_amd_frame_sync(p), "frame_sync")
+    mlvfs_close_chunks()
     return img

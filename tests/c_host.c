@@ -1,5 +1,8 @@
 /* A plain C host -- no Python, no torch -- that links libmlvfs_amd.so the way MLVFS would
- * and runs process_frame's call sequence (mlvfs/main.c:942-997) on one frame read from a file.
+ * and runs process_frame's call sequence (mlvfs/main.c:923-998) on one frame read from a file -- including the
+ * mlvfs_load_chunks / mlvfs_close_chunks pair around it (tests/c_host_chunks.c plays resource_manager.c:285-317).  Built twice
+ * by tests/test_gpu_c_host.py: as it is, and with integration/mlvfs_amd_wrap.c + -Wl,--wrap=... (the frame bracket); this file
+ * is the same in both and calls nothing of the library beyond the reference's symbols.
  *   c_host <in: packed 14-bit words> <out: u16 pixels> w h black white cs bad_pixels stripes [dual_iso: 1 preview, 2 full]
  * The caller's table accessors (get_raw2ev / get_ev2raw, mlvfs/main.c:128-196) are deliberately NOT provided: the
  * library then builds the tables itself, as it does under Python.  tests/test_gpu_c_host.py compares the output with
@@ -10,6 +13,9 @@
 #include <string.h>
 #include "mlvfs_abi.h"
 #include "mlvfs_amd.h"
+
+FILE **mlvfs_load_chunks(const char *path, uint32_t *chunk_count);        /* resource_manager.h */
+void mlvfs_close_chunks(FILE **chunk_files, uint32_t chunk_count);
 
 int main(int argc, char **argv)
 {
@@ -27,10 +33,10 @@ int main(int argc, char **argv)
     fh.rawi_hdr.raw_info.black_level = black; fh.rawi_hdr.raw_info.white_level = white;
     const size_t npix = (size_t)w * h, nwords = (npix * 14 + 15) / 16 + 4;
     uint16_t *packed = calloc(nwords, 2), *img = malloc(npix * 2);
-    FILE *f = fopen(argv[1], "rb");
-    if (!f || !packed || !img) return 3;
-    const size_t got = fread(packed, 2, nwords, f);
-    fclose(f);
+    uint32_t chunk_count = 0;
+    FILE **chunk_files = mlvfs_load_chunks(argv[1], &chunk_count);           /* main.c:923 */
+    if (!chunk_files || !chunk_count || !packed || !img) return 3;
+    const size_t got = fread(packed, 2, nwords, chunk_files[0]);             /* get_image_data, main.c:696 */
     (void)got;
     if (dng_get_image_data(&fh, packed, (uint8_t *)img, 0, npix * 2) != npix * 2) { fprintf(stderr, "unpack failed\n"); return 4; }
     int is_dual_iso = 0;                                       /* main.c:951-973 */
@@ -49,8 +55,8 @@ int main(int argc, char **argv)
         }
         stripes_apply_correction(&fh, c, img, 0, npix);
     }
-    if (mlvfs_amd_frame_sync(img) != 0) { fprintf(stderr, "frame sync failed\n"); return 6; }     /* the line MLVFS_AMD_RESIDENT=2 asks of main.c:996 */
-    f = fopen(argv[2], "wb");
+    mlvfs_close_chunks(chunk_files, chunk_count);                            /* main.c:998 */
+    FILE *f = fopen(argv[2], "wb");
     if (!f) return 5;
     fwrite(img, 2, npix, f);
     fprintf(stderr, "levels %d %d dual_iso %d\n", fh.rawi_hdr.raw_info.black_level, fh.rawi_hdr.raw_info.white_level, is_dual_iso);

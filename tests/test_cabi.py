@@ -126,3 +126,41 @@ def test_library_covers_what_the_callers_import_from_the_replaced_objects(amd, t
     out = subprocess.run(["nm", "-D", "--defined-only", lib.SO_PATH], capture_output=True, text=True, check=True).stdout
     exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
     assert needed <= exported, sorted(needed - exported)
+
+
+def test_wrap_shim_links_and_brackets_process_frame_only(amd, tmp_path):
+    """integration/mlvfs_amd_wrap.c: a host that calls mlvfs_load_chunks / mlvfs_close_chunks from one
+    object and defines them in another (like main.o / resource_manager.o) links with the two --wrap flags, its calls then go
+    through the shim and the shim's through to the host's definitions.  No compute: the bracket calls do not touch a GPU.  And
+    where the reference tree is present: the pixel stages of process_frame sit between the two wrapped calls (main.c:923-998),
+    gif.c's do not (it uses index.c's load_chunks / close_chunks)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = tmp_path / "host.c"
+    host.write_text('#include <stdint.h>\n#include <stdio.h>\n'
+                    'FILE **mlvfs_load_chunks(const char *path, uint32_t *chunk_count);\n'
+                    'void mlvfs_close_chunks(FILE **chunk_files, uint32_t chunk_count);\n'
+                    'int main(int argc, char **argv) { uint32_t n = 0; FILE **c = mlvfs_load_chunks(argv[0], &n);\n'
+                    '  if (!c || n != 1) return 1; mlvfs_close_chunks(c, n); puts("closed"); return 0; }\n')
+    exe = tmp_path / "host"
+    so_dir = os.path.dirname(lib.SO_PATH)
+    subprocess.run(["gcc", "-std=gnu99", "-I", os.path.join(root, "include"), str(host), os.path.join(root, "tests", "c_host_chunks.c"),
+                    os.path.join(root, "integration", "mlvfs_amd_wrap.c"), "-Wl,--wrap=mlvfs_load_chunks", "-Wl,--wrap=mlvfs_close_chunks",
+                    "-o", str(exe), "-L", so_dir, "-lmlvfs_amd", "-Wl,-rpath," + so_dir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib",
+                    "-lamdhip64"], check=True)
+    syms = subprocess.run(["nm", str(exe)], capture_output=True, text=True, check=True).stdout
+    assert " T __wrap_mlvfs_load_chunks" in syms and " T __wrap_mlvfs_close_chunks" in syms and " U mlvfs_amd_frame_begin" in syms
+    dis = subprocess.run(["objdump", "-d", "--no-show-raw-insn", str(exe)], capture_output=True, text=True, check=True).stdout
+    main_body = dis[dis.index("<main>:"):].split("\n\n")[0]
+    assert "<__wrap_mlvfs_load_chunks>" in main_body and "<__wrap_mlvfs_close_chunks>" in main_body
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)          # no GPU here: the bracket must not need one
+    assert r.returncode == 0 and "closed" in r.stdout, r.stderr[-1000:]
+    assert amd.mlvfs_amd_frame_begin() == 0 and amd.mlvfs_amd_frame_end() == 0 and amd.mlvfs_amd_frame_sync(None) == 0
+    ref = "/root/reference/mlvfs"
+    if os.path.isdir(ref):
+        main_c = open(os.path.join(ref, "main.c"), errors="replace").read()
+        body = main_c[main_c.index("static int process_frame("):main_c.index("int create_preview(")]
+        a, b = body.index("mlvfs_load_chunks("), body.index("mlvfs_close_chunks(")
+        for stage in ("get_image_data(", "fix_pattern_noise(", "cr2hdr20_convert_data(", "fix_bad_pixels(", "chroma_smooth(", "stripes_apply_correction("):
+            assert a < body.index(stage) < b, stage
+        gif_c = open(os.path.join(ref, "gif.c"), errors="replace").read()
+        assert "mlvfs_load_chunks" not in gif_c and "mlvfs_close_chunks" not in gif_c and "load_chunks(path" in gif_c

@@ -15,19 +15,30 @@ ROOT = os.path.dirname(HERE)
 BLACK, WHITE = synth.BLACK, synth.WHITE
 
 
-@pytest.fixture(scope="module", params=["library builds the tables", "caller provides get_raw2ev / get_ev2raw"])
-def c_host(request, tmp_path_factory, gpu):
-    """Two hosts: a bare one, and one that -- like MLVFS's main.c (mlvfs.h:90-92) -- exports the table accessors the library
-    imports weakly (their definitions come from oracle/ref_luts.c, the caller's part of the reference build)."""
-    exe = tmp_path_factory.mktemp("c_host") / "c_host"
+def build_c_host(exe, variant):
     so_dir = os.path.dirname(lib.SO_PATH)
-    srcs = [os.path.join(HERE, "c_host.c")]
-    if request.param.startswith("caller"):
+    srcs = [os.path.join(HERE, "c_host.c"), os.path.join(HERE, "c_host_chunks.c")]
+    flags = []
+    if "caller" in variant:
         srcs.append(os.path.join(ROOT, "oracle", "ref_luts.c"))
-    cmd = ["gcc", "-std=gnu99", "-O1", "-rdynamic", "-I", os.path.join(ROOT, "include"), *srcs, "-o", str(exe),
+    if "wrap" in variant:                                           # one more object, two linker flags
+        srcs.append(os.path.join(ROOT, "integration", "mlvfs_amd_wrap.c"))
+        flags = ["-Wl,--wrap=mlvfs_load_chunks", "-Wl,--wrap=mlvfs_close_chunks"]
+    cmd = ["gcc", "-std=gnu99", "-O1", "-rdynamic", "-I", os.path.join(ROOT, "include"), *srcs, *flags, "-o", str(exe),
            "-L", so_dir, "-lmlvfs_amd", "-Wl,-rpath," + so_dir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-lm"]
     subprocess.run(cmd, check=True)
     return str(exe)
+
+
+@pytest.fixture(scope="module", params=["library builds the tables", "caller provides get_raw2ev / get_ev2raw",
+                                        "wrap: mlvfs_load_chunks / mlvfs_close_chunks are the frame bracket",
+                                        "wrap + caller provides the tables"])
+def c_host(request, tmp_path_factory, gpu):
+    """Four links of ONE source (tests/c_host.c, which calls the reference's symbols and nothing else): a bare one; one that --
+    like MLVFS's main.c (mlvfs.h:90-92) -- exports the table accessors the library imports weakly (their definitions come from
+    oracle/ref_luts.c, the caller's part of the reference build); and both again with integration/mlvfs_amd_wrap.c and
+    -Wl,--wrap=..., where the stages between the two chunk calls are recorded and the frame is fetched inside mlvfs_close_chunks."""
+    return build_c_host(tmp_path_factory.mktemp("c_host") / "c_host", request.param)
 
 
 @pytest.mark.parametrize("cs,bad,stripes", [(5, 1, 1), (2, 0, 0), (3, 2, 1)])

@@ -2,7 +2,9 @@
 """PCIe-inclusive rate of the five drop-in symbols called per frame in process_frame's order (main.c:942-997), 3584x1320, from
 1 and N host threads (libfuse's worker pool), every thread on its own malloc'ed frame buffer.  Prints one JSON line.
 MLVFS_AMD_RESIDENT=1 in the environment selects the mode in which a stage takes up the device copy the previous stage left
-(DESIGN.md 7); the results are checked against each other by the caller (bench.py) through the hash printed here.
+(DESIGN.md 7); DROPIN_BRACKET=1 puts mlvfs_amd_frame_begin / mlvfs_amd_frame_end where process_frame calls mlvfs_load_chunks /
+mlvfs_close_chunks (what integration/mlvfs_amd_wrap.c does at link level for the C host, tools/dropin_bench_c.sh); the results
+are checked against each other by the caller (bench.py) through the hash printed here.
 usage: python tools/dropin_bench.py [threads] [frames_per_thread]"""
 import ctypes as C, json, os, sys, threading, time
 import numpy as np
@@ -20,6 +22,7 @@ last = {}
 
 
 PINNED = os.environ.get("DROPIN_PINNED") == "1"     # frame buffers from mlvfs_amd_host_alloc (page-locked, pooled), one per frame
+BRACKET = os.environ.get("DROPIN_BRACKET") == "1"   # the frame bracket around the stages (main.c:923 / 998 through the wrap shim)
 REUSE = os.environ.get("DROPIN_REUSE") == "1"       # one pageable frame buffer per thread, reused (no fresh pages per frame)
 
 
@@ -48,6 +51,8 @@ def worker(nf, idx, counts, start, t_begin):
         else:
             img = keep if REUSE else np.empty(W * H, np.uint16)      # a fresh buffer per frame, like process_frame's malloc
         src = srcs[(idx + k) % 2]
+        if BRACKET:
+            L.mlvfs_amd_frame_begin()
         L.dng_get_image_data(C.byref(fh), lib.ptr(src), lib.ptr(img), 0, img.nbytes)
         L.fix_focus_pixels(C.byref(fh), lib.ptr(img), 0)
         L.fix_bad_pixels(C.byref(fh), lib.ptr(img), 0, 0)
@@ -57,7 +62,8 @@ def worker(nf, idx, counts, start, t_begin):
             corr = L.stripes_new_correction(name)
             L.stripes_compute_correction(C.byref(fh), corr, lib.ptr(img), 0, img.size)
         L.stripes_apply_correction(C.byref(fh), corr, lib.ptr(img), 0, img.size)     # sizes in pixels (main.c:996)
-        L.mlvfs_amd_frame_sync(lib.ptr(img))            # MLVFS_AMD_RESIDENT=2: the one download of the frame (a no-op otherwise)
+        if BRACKET:
+            L.mlvfs_amd_frame_end()                     # the one download of the frame
         if (idx + k) % 2 == 1 and k >= nf - 2:
             last[idx] = img.copy() if (PINNED or REUSE) else img
         if pin:
@@ -70,7 +76,7 @@ def worker(nf, idx, counts, start, t_begin):
 
 C.CDLL(None).srand(1)
 worker(1, 0, [0], threading.Barrier(1), [0.0])         # clip state (map, coefficients) from frame 0
-res = {"resident": os.environ.get("MLVFS_AMD_RESIDENT", "0"), "frames_per_thread": NF, "pinned_frame_buffers": PINNED, "reused_frame_buffers": REUSE}
+res = {"resident": "bracket" if BRACKET else os.environ.get("MLVFS_AMD_RESIDENT", "0"), "frames_per_thread": NF, "pinned_frame_buffers": PINNED, "reused_frame_buffers": REUSE}
 for t in (1, T):
     counts = [0] * t
     start, t_begin = threading.Barrier(t), [0.0]

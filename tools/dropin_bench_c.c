@@ -1,9 +1,12 @@
 /* tools/dropin_bench_c.c -- what tools/dropin_bench.py measures, from a C host with pthreads (libfuse's worker pool in MLVFS):
- * process_frame's call sequence (mlvfs/main.c:942-997: unpack, focus pixels, bad pixels, cs5x5, stripes) on 3584x1320 frames,
- * every frame in a freshly allocated buffer, T threads x N frames.  Prints one JSON line.
+ * process_frame's call sequence (mlvfs/main.c:923-998: mlvfs_load_chunks, unpack, focus pixels, bad pixels, cs5x5, stripes,
+ * mlvfs_close_chunks) on 3584x1320 frames, every frame in a freshly allocated buffer, T threads x N frames.  Prints one JSON line.
  *   dropin_bench_c <packed frame 0> <packed frame 1> T N pinned
  * pinned = 1: frame and input buffers from mlvfs_amd_host_alloc / _free (page-locked, pooled) instead of malloc / free.
- * MLVFS_AMD_RESIDENT=0/1/2 in the environment selects the mode; mlvfs_amd_frame_sync is called after the last stage. */
+ * The file calls NOTHING of the library beyond the reference's symbols (mlvfs_amd_host_alloc for pinned = 1 aside).  Modes:
+ * MLVFS_AMD_RESIDENT=0/1 in the environment; and the same source linked with integration/mlvfs_amd_wrap.c and
+ * -Wl,--wrap=mlvfs_load_chunks -Wl,--wrap=mlvfs_close_chunks (tools/dropin_bench_c.sh: "wrap"), which makes the chunk calls the
+ * library's frame bracket: one upload, one fused launch, one download per frame. */
 #define _GNU_SOURCE
 #include <pthread.h>
 #include <stdint.h>
@@ -15,6 +18,10 @@
 #include "mlvfs_amd.h"
 
 enum { W = 3584, H = 1320, BLACK = 2048, WHITE = 15000 };
+FILE **mlvfs_load_chunks(const char *path, uint32_t *chunk_count);        /* resource_manager.h; here: tests/c_host_chunks.c */
+void mlvfs_close_chunks(FILE **chunk_files, uint32_t chunk_count);
+
+static const char *g_path[2];
 static uint16_t *g_packed[2];
 static size_t g_words;
 static int g_pinned, g_frames;
@@ -42,6 +49,9 @@ static void one_frame(int idx, int k, int keep_hash)
     fh.rawi_hdr.raw_info.frame_size = W * H * 14 / 8;
     fh.rawi_hdr.raw_info.black_level = BLACK; fh.rawi_hdr.raw_info.white_level = WHITE;
     const size_t npix = (size_t)W * H;
+    uint32_t chunk_count = 0;
+    FILE **chunk_files = mlvfs_load_chunks(g_path[(idx + k) & 1], &chunk_count);      /* main.c:923: fopen of every chunk */
+    if (!chunk_files || !chunk_count) return;
     /* get_image_data (main.c:684-703): a buffer for the payload, read from the file (here: copied from memory), unpacked, freed */
     uint16_t *packed = buf_alloc(g_words * 2);
     memcpy(packed, g_packed[(idx + k) & 1], g_words * 2);
@@ -57,8 +67,12 @@ static void one_frame(int idx, int k, int keep_hash)
         if (c) stripes_compute_correction(&fh, c, img, 0, npix);
     }
     stripes_apply_correction(&fh, c, img, 0, npix);
-    mlvfs_amd_frame_sync(img);
-    if (keep_hash && ((idx + k) & 1)) g_hash[idx] = fnv1a(img, npix * 2);
+    mlvfs_close_chunks(chunk_files, chunk_count);                                     /* main.c:998 */
+    if (keep_hash && ((idx + k) & 1)) {
+        g_hash[idx] = fnv1a(img, npix * 2);
+        const char *dump = getenv("DROPIN_DUMP");                                     /* frame 1 as thread 0 got it, for the caller to compare */
+        if (dump && idx == 0) { FILE *d = fopen(dump, "wb"); if (d) { fwrite(img, 2, npix, d); fclose(d); } }
+    }
     buf_free(img);
 }
 
@@ -90,6 +104,7 @@ int main(int argc, char **argv)
     if (T < 1 || T > 256) return 2;
     g_words = ((size_t)W * H * 14 + 15) / 16 + 4;
     for (int i = 0; i < 2; i++) {
+        g_path[i] = argv[1 + i];
         g_packed[i] = calloc(g_words, 2);
         FILE *f = fopen(argv[1 + i], "rb");
         if (!f || fread(g_packed[i], 2, g_words - 4, f) == 0) { fprintf(stderr, "cannot read %s\n", argv[1 + i]); return 3; }
@@ -114,8 +129,10 @@ int main(int argc, char **argv)
     uint64_t ref = 0;
     for (int i = 0; i < T; i++) if (g_hash[i]) { if (!ref) ref = g_hash[i]; same = same && g_hash[i] == ref; }
     const char *mode = getenv("MLVFS_AMD_RESIDENT");
-    fprintf(stderr, "{\"host\": \"C, pthreads\", \"resident\": \"%s\", \"pinned_frame_buffers\": %s, \"frames_per_thread\": %d, \"fps_1_threads\": %.1f, "
-            "\"fps_%d_threads\": %.1f, \"frame1_hash\": \"%016llx\", \"identical_between_threads\": %s}\n", mode ? mode : "0",
+    long long st[2];
+    mlvfs_amd_dropin_stats(st);
+    fprintf(stderr, "{\"host\": \"C, pthreads\", \"resident\": \"%s\", \"fused_at_fetch\": %lld, \"run_early\": %lld, \"pinned_frame_buffers\": %s, \"frames_per_thread\": %d, \"fps_1_threads\": %.1f, "
+            "\"fps_%d_threads\": %.1f, \"frame1_hash\": \"%016llx\", \"identical_between_threads\": %s}\n", mode ? mode : "0", st[0], st[1],
             g_pinned ? "true" : "false", g_frames, fps[0], T, fps[1], (unsigned long long)ref, same ? "true" : "false");
     stripes_free_corrections();
     free_focus_pixel_maps();
