@@ -200,7 +200,11 @@ int mlvfs_amd_process_frames_host(mlvfs_amd_clip_t *clip, const void *h_packed, 
  * size, so a host may allocate and free one per frame like process_frame does with malloc (main.c:931).  With frame buffers
  * from here the drop-in symbols of PART 1 copy at the link's speed instead of the pageable path's. */
 void *mlvfs_amd_host_alloc(size_t bytes);
+/* Gives the buffer back to the pool.  A pointer that did not come from mlvfs_amd_host_alloc, and a buffer freed a second time,
+ * are reported on stderr and otherwise ignored (the library frees nothing it does not own). */
 void mlvfs_amd_host_free(void *p);
+/* Returns the pool's cached (free) buffers to the runtime; result: bytes released. */
+size_t mlvfs_amd_host_trim(void);
 
 /* -- LJ92 payloads ---------------------------------------- */
 /* Lossless-JPEG frames of a compressed clip (MLV_VIDEO_CLASS_FLAG_LJ92; main.c:617-681: lj92_open + lj92_decode + the

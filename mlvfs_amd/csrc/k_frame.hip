@@ -1333,22 +1333,63 @@ __global__ __launch_bounds__(256) void k_build_e2r(const uint16_t *u16, int blac
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < E2R_ENTRIES) e2r[i] = (uint16_t)((((int)u16[i & 32767]) >> (13 - (i >> 15))) + black);
 }
+// The black level comes from file headers (and dual ISO multiplies it by 4): a long-running host that serves many clips would
+// otherwise collect one table per level it has ever seen.  At most E2R_CACHE tables per device stay; the least recently used one
+// goes -- not at once: a thread that fetched its pointer a moment ago may not have launched yet, so an evicted table is parked and
+// freed at the NEXT eviction on that device, after the device has drained (the same rule as DeviceTables::retire in dualiso.cpp).  The table of a new level is built OUTSIDE the lock, so first launches of
+// different clips do not queue behind each other's synchronisation.
 namespace {
+constexpr size_t E2R_CACHE = 8;
+struct E2rEntry { uint16_t *table; unsigned long long used; };
 std::mutex g_tables_mu;
-std::map<std::pair<int, int>, uint16_t *> g_e2r;               // (device, black)
+std::map<std::pair<int, int>, E2rEntry> g_e2r;               // (device, black)
+std::map<int, uint16_t *> g_e2r_parked;                       // per device: the table evicted last
+unsigned long long g_e2r_clock = 0;
 }
 static int e2r_table(const Device *dev, int black, const uint16_t **out, hipStream_t stream)
 {
-    std::lock_guard<std::mutex> lk(g_tables_mu);
-    auto it = g_e2r.find({ dev->id, black });
-    if (it != g_e2r.end()) { *out = it->second; return MLVFS_AMD_OK; }
+    {
+        std::lock_guard<std::mutex> lk(g_tables_mu);
+        auto it = g_e2r.find({ dev->id, black });
+        if (it != g_e2r.end()) { it->second.used = ++g_e2r_clock; *out = it->second.table; return MLVFS_AMD_OK; }
+    }
     uint16_t *t = nullptr;
     MLV_HIP(hipMalloc(&t, sizeof(uint16_t) * E2R_ENTRIES));
     hipLaunchKernelGGL(k_build_e2r, dim3((E2R_ENTRIES + 255) / 256), dim3(256), 0, stream, dev->luts.u16, black, t);
-    MLV_HIP(hipGetLastError());
-    MLV_HIP(hipStreamSynchronize(stream));                     // other streams use the table from now on
-    g_e2r[{ dev->id, black }] = t;
-    *out = t;
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {       // other streams use the table from now on
+        (void)hipFree(t);
+        set_error("building the output table for black level %d failed", black);
+        return MLVFS_AMD_ERR_HIP;
+    }
+    uint16_t *victim = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_tables_mu);
+        auto it = g_e2r.find({ dev->id, black });
+        if (it != g_e2r.end()) {                              // another thread built the same level meanwhile: keep theirs
+            it->second.used = ++g_e2r_clock;
+            *out = it->second.table;
+            victim = t;
+        } else {
+            size_t mine = 0;
+            auto oldest = g_e2r.end();
+            for (auto e = g_e2r.begin(); e != g_e2r.end(); ++e)
+                if (e->first.first == dev->id) {
+                    mine++;
+                    if (oldest == g_e2r.end() || e->second.used < oldest->second.used) oldest = e;
+                }
+            if (mine >= E2R_CACHE) {                           // (rare: a ninth black level on this device)
+                victim = g_e2r_parked[dev->id];                // evicted one eviction ago: long out of every thread's hands
+                g_e2r_parked[dev->id] = oldest->second.table;
+                g_e2r.erase(oldest);
+            }
+            g_e2r[{ dev->id, black }] = E2rEntry{ t, ++g_e2r_clock };
+            *out = t;
+        }
+    }
+    if (victim) {
+        if (victim != t) (void)hipDeviceSynchronize();         // launches that still read it have finished
+        (void)hipFree(victim);
+    }
     return MLVFS_AMD_OK;
 }
 

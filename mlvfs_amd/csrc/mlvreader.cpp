@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -282,8 +283,16 @@ bool payload_span(const Reader &r, int index, Span *s, bool lj92 = false)
 {
     frame_headers fh;
     if (!frame_headers_of(r, index, &fh)) { set_error("mlv: frame %d has no usable headers", index); return false; }
-    const uint64_t room = fh.vidf_hdr.blockSize > sizeof(mlv_vidf_hdr_t) + fh.vidf_hdr.frameSpace
-                              ? fh.vidf_hdr.blockSize - sizeof(mlv_vidf_hdr_t) - fh.vidf_hdr.frameSpace : 0;
+    uint64_t room = fh.vidf_hdr.blockSize > sizeof(mlv_vidf_hdr_t) + fh.vidf_hdr.frameSpace
+                        ? fh.vidf_hdr.blockSize - sizeof(mlv_vidf_hdr_t) - fh.vidf_hdr.frameSpace : 0;
+    {
+        // blockSize is a field of the file: a payload cannot be longer than what the chunk holds behind its start (buffers
+        // are sized from it)
+        struct stat st;
+        const uint64_t start = fh.position + sizeof(mlv_vidf_hdr_t) + fh.vidf_hdr.frameSpace;
+        const uint64_t left = fstat(r.fds[fh.fileNumber], &st) == 0 && (uint64_t)st.st_size > start ? (uint64_t)st.st_size - start : 0;
+        room = std::min(room, left);
+    }
     if (lj92 && (fh.file_hdr.videoClass & CLASS_LJ92) && !(fh.file_hdr.videoClass & CLASS_LZMA)) {
         // main.c:587-589: everything behind the VIDF header and its frameSpace is the compressed frame (size word + JPEG)
         if (room <= 4) { set_error("mlv: frame %d: empty LJ92 payload", index); return false; }
@@ -325,7 +334,7 @@ int read_frames(const Reader &r, int first, int count, uint8_t *dst, size_t stri
     threads = std::max(1, std::min(threads <= 0 ? 8 : threads, count));
     std::atomic<int> next{ 0 }, failed{ -1 }, failed_lzma{ -1 };
     auto work = [&]() {
-        for (int k; (k = next.fetch_add(1)) < count;) {
+        for (int k; (k = next.fetch_add(1)) < count;) try {
             uint8_t *d = dst + (size_t)k * stride;
             if (spans[k].lzma_bytes) {
                 // main.c:598-616: the size word says how much LzmaUncompress may produce; what dng_get_image_data then reads
@@ -334,6 +343,9 @@ int read_frames(const Reader &r, int first, int count, uint8_t *dst, size_t stri
                 size_t got = 0;
                 if (!read_at(spans[k].fd, comp.data(), comp.size(), spans[k].off)) { failed = first + k; continue; }
                 const size_t want = (size_t)comp[0] | ((size_t)comp[1] << 8) | ((size_t)comp[2] << 16) | ((size_t)comp[3] << 24);
+                // the size word is a field of the file too: a frame cannot decode to much more than its packed size (the
+                // reference would malloc up to 4 GiB per worker here)
+                if (want > 8 * spans[k].bytes + (1u << 20)) { failed_lzma = first + k; continue; }
                 std::vector<uint8_t> big;
                 uint8_t *out = d;
                 if (want > stride) { big.resize(want); out = big.data(); }      // a size word larger than the frame: decode all, keep the frame
@@ -342,6 +354,8 @@ int read_frames(const Reader &r, int first, int count, uint8_t *dst, size_t stri
                 if (got < spans[k].bytes) memset(d + got, 0, spans[k].bytes - got);
             } else if (!read_at(spans[k].fd, d, spans[k].bytes, spans[k].off)) { failed = first + k; continue; }
             if (stride > spans[k].bytes) memset(d + spans[k].bytes, 0, std::min<size_t>(stride - spans[k].bytes, 64));   // the 2-pixel over-read of main.c:579 sees zeros
+        } catch (const std::exception &) {               // out of memory in a reader thread: the frame fails, the host lives
+            if (spans[k].lzma_bytes) failed_lzma = first + k; else failed = first + k;
         }
     };
     std::vector<std::thread> pool;
@@ -506,7 +520,14 @@ int mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first,
 
 // = gif_get_data (gif.c:82-221) on an opened clip: the animated preview of 10 frames spread over the clip, 1/4 x 1/4 size; copies
 // min(max_size, size - offset) bytes of the file from `offset` on and returns max_size like the reference, 0 on failure.
+static size_t gif_data(const void *reader, uint8_t *output_buffer, off_t offset, size_t max_size);
 size_t mlvfs_amd_mlv_gif_data(const void *reader, uint8_t *output_buffer, off_t offset, size_t max_size)
+{
+    try { return gif_data(reader, output_buffer, offset, max_size); }
+    catch (const std::exception &e) { set_error("mlv: preview: %s", e.what()); return 0; }       // (allocation sized from the file)
+}
+
+static size_t gif_data(const void *reader, uint8_t *output_buffer, off_t offset, size_t max_size)
 {
     if (!reader || !output_buffer || offset < 0) { set_error("mlv: null argument"); return 0; }
     const Reader &r = *(const Reader *)reader;

@@ -11,9 +11,14 @@
  *
  * The reference objects import three caller-side symbols (get_raw2ev,
  * get_raw2evf, get_ev2raw: mlvfs/mlvfs.h:90-92).  Their definitions live in the
- * reference's main.c (lines 128-196), which cannot be compiled here because it
- * needs <fuse.h> (absent from this image; no stand-in header is written).  The
- * adapter therefore plays the caller's part and supplies them from ref_luts.c.
+ * reference's main.c (lines 128-196), which cannot be compiled as a whole here
+ * because it needs <fuse.h> (absent from this image; no stand-in header is
+ * written).  oracle/Makefile therefore slices those functions -- with
+ * mlv_get_frame_headers and get_image_data -- out of main.c BY NAME at build
+ * time into a translation unit of this library (_ref/main_slices.c, deleted
+ * after the build): the table builders here are the reference's own text.
+ * ref_luts.c, the repo's restatement of them, is a separate library
+ * (_ref/libref_luts.so) that tests/test_oracle_vs_ref.py checks against that text.
  */
 #include <stdint.h>
 #include <stdlib.h>

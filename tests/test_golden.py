@@ -56,6 +56,9 @@ def test_oracle_reproduces_full_size_hashes(oracle):
     assert fnv1a(oracle.unpack(p, 1920, 1080, 14)) == full["A_1920x1080_unpack"]
     f = synth.normal_frame(3584, 1320, seed=1, frame=0)
     assert fnv1a(oracle.chroma_smooth(f, BLACK, 2)) == full["B_cs2_frame0"]
+    assert fnv1a(oracle.chroma_smooth(f, BLACK, 3)) == full["B_cs3_frame0"]
+    ok, img, lv = oracle.hdr_preview(synth.dual_iso_frame(3584, 1320), BLACK, WHITE)
+    assert ok == 1 and fnv1a(img) == full["B_3584x1320_hdr_preview"] and list(lv) == full["B_3584x1320_hdr_preview_levels"]
 
 
 # ------------------------------------------------------------------ GPU side

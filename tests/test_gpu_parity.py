@@ -292,3 +292,41 @@ def test_fix_pattern_noise_full_size_hash(gpu):
     got = f.copy()
     gpu.fix_pattern_noise(lib.ptr(got), 1920, 1080, WHITE, 0)
     assert fnv1a(got) == meta["A_1920x1080_pattern_noise"]
+
+
+# ------------------------------------------------------------------ full size (3584x1320) against the reference's hashes
+def _golden_full():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))["full_size"]
+
+
+def test_fix_pattern_noise_benchmark_size_hash(gpu):
+    """P1 at 3584x1320 (BASELINE configs' geometry) against the hash of the reference's output."""
+    from conftest import fnv1a
+    w, h = 3584, 1320
+    got = synth.normal_frame(w, h, seed=1)
+    gpu.fix_pattern_noise(lib.ptr(got), w, h, WHITE, 0)
+    assert fnv1a(got) == _golden_full()["B_3584x1320_pattern_noise"]
+
+
+def test_hdr_preview_benchmark_size_hash(gpu):
+    """H1 hdr_convert_data at 3584x1320: pixels and the levels it writes back (hdr.c:223-224) against the reference's."""
+    from conftest import fnv1a
+    w, h = 3584, 1320
+    got = synth.dual_iso_frame(w, h)
+    fh = fh_for(w, h)
+    assert gpu.hdr_convert_data(C.byref(fh), lib.ptr(got), 0, got.nbytes) == 1
+    full = _golden_full()
+    assert fnv1a(got) == full["B_3584x1320_hdr_preview"]
+    assert [fh.rawi_hdr.raw_info.black_level, fh.rawi_hdr.raw_info.white_level] == full["B_3584x1320_hdr_preview_levels"]
+
+
+def test_chroma_smooth_3x3_benchmark_frames_hash(gpu):
+    """cs3x3 on the benchmark's frames 0 and 1 through the drop-in symbol against the reference's hashes."""
+    from conftest import fnv1a
+    w, h = 3584, 1320
+    full = _golden_full()
+    for k in range(2):
+        got = synth.normal_frame(w, h, seed=1, frame=k)
+        gpu.chroma_smooth(C.byref(fh_for(w, h)), lib.ptr(got), 3)
+        assert fnv1a(got) == full[f"B_cs3_frame{k}"], k

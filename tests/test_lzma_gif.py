@@ -113,6 +113,40 @@ def test_lzma_clip_reads_like_an_uncompressed_one(reference, tmp_path):
             assert bytes(got[k][:W * H * 14 // 8]) == synth.pack_bits(f).tobytes()[:W * H * 14 // 8]
 
 
+def test_lzma_clip_with_hostile_size_fields_is_refused_not_allocated(reference, tmp_path):
+    """The VIDF blockSize and the payload's 32-bit size word come from the file: buffers sized from them are bounded by what the
+    chunk really holds and by the frame's packed size (the reference mallocs both as they stand, main.c:587-602)."""
+    import resource
+    import struct
+    names, frames = lzma_clip(reference, tmp_path, n=3)
+    raw = bytearray(open(names[0], "rb").read())
+    stride = (W * H * 14 // 8 + 2 + 15) // 16 * 16
+    last = raw.rfind(b"VIDF")
+    # (1) the last frame's block claims 3.7 GiB
+    bad = bytearray(raw)
+    bad[last + 4:last + 8] = struct.pack("<I", 0xF0000000)
+    open(names[0], "wb").write(bytes(bad))
+    peak0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    with mlvfile.MlvReader(names[0]) as r:
+        if r.frame_count == len(frames):                                  # (an index that drops the over-long block is fine as well)
+            try:
+                got = r.read_frames(len(frames) - 1, 1, stride)
+            except lib.MlvfsAmdError as e:                                # refusing is fine too
+                assert "mlv" in str(e)
+            else:
+                assert bytes(got[0][:W * H * 14 // 8]) == synth.pack_bits(frames[-1]).tobytes()[:W * H * 14 // 8]
+    # (2) its payload's size word claims 4 GiB
+    bad = bytearray(raw)
+    vidf_hdr = 32                                                         # mlv_vidf_hdr_t (mlv.h:69-81)
+    bad[last + vidf_hdr:last + vidf_hdr + 4] = struct.pack("<I", 0xFFFFFFF0)
+    open(names[0], "wb").write(bytes(bad))
+    with mlvfile.MlvReader(names[0]) as r:
+        with pytest.raises(Exception, match="LZMA"):
+            r.read_frames(r.frame_count - 1, 1, stride)
+        assert bytes(r.read_frames(0, 1, stride)[0][:64]) == synth.pack_bits(frames[0]).tobytes()[:64]   # the others still read
+    assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - peak0 < 512 * 1024, "a buffer was sized from a hostile field (KiB)"
+
+
 @pytest.mark.gpu
 def test_lzma_clip_through_the_fused_pipeline(gpu, oracle, reference, tmp_path):
     from mlvfs_amd.stream import ClipStream

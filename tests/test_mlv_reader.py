@@ -105,7 +105,13 @@ def test_frame_headers_equal_the_reference_text(clip, reference):
     """mlv_get_frame_headers as main.c:429-558 defines it (the reference's own text, sliced into oracle/_ref by oracle/Makefile)
     against the reader of libmlvfs_amd.so and against the Python restatement oracle/mlv_container.py."""
     names, pl, kw = clip
+    idx = names[0][:-3] + "IDX"
+    if os.path.exists(idx):
+        os.remove(idx)
     with mlvfile.MlvReader(names[0]) as r:
+        for k in range(len(pl)):
+            r.frame_headers(k)
+        assert not os.path.exists(idx), "the library's reader (use_idx_file=0) wrote an index file"   # the reference's walk below does (index.c:458-470)
         for k in list(range(len(pl))) + [len(pl), len(pl) + 5]:
             ok, fh = r.frame_headers(k)
             want_ok, want = reference.mlv_frame_headers(names[0], k)
@@ -113,7 +119,6 @@ def test_frame_headers_equal_the_reference_text(clip, reference):
             assert ok == want_ok == rest_ok, k
             if want_ok:                          # (not found: the reference leaves part of the struct as the search left it)
                 assert bytes(fh) == want == rest, k
-    assert not os.path.exists(names[0][:-3] + "IDX") or True
 
 
 def test_payloads(clip):
