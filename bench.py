@@ -539,10 +539,19 @@ def main():
             # what actually bounds the kernel: vector-ALU issue.  Wave-instructions per frame from the
             # SQ_INSTS_VALU counter, the chip's issue rate for them from tools/valu_rate2.hip, measured time from this run.
             if tj.get("valu_insts_per_frame") and n_timed:
-                floor_us = tj["valu_insts_per_frame"] / (tj["simds"] * tj["valu_issue_per_clk_per_simd"] * tj["clock_ghz"] * 1e3)
-                valu = {"wave_insts_per_frame": int(tj["valu_insts_per_frame"]), "issue_per_clk_per_simd": tj["valu_issue_per_clk_per_simd"],
-                        "floor_us_per_frame": round(floor_us, 2), "measured_us_per_frame": round(kern_ms * 1e3 / F, 2),
-                        "frac_of_valu_floor": round(floor_us / (kern_ms * 1e3 / F), 3), "source": "profiles/traffic.json (SQ_INSTS_VALU pass)"}
+                per_frame_us = kern_ms * 1e3 / F
+                flat_us = tj["valu_insts_per_frame"] / (tj["simds"] * tj["valu_issue_per_clk_per_simd"] * tj["clock_ghz"] * 1e3)
+                valu = {"wave_insts_per_frame": int(tj["valu_insts_per_frame"]), "measured_us_per_frame": round(per_frame_us, 2),
+                        "flat_floor_us_per_frame": round(flat_us, 2), "flat_issue_per_clk_per_simd": tj["valu_issue_per_clk_per_simd"],
+                        "source": "profiles/traffic.json (SQ_INSTS_VALU pass)"}
+                # class-weighted floor: every instruction of the kernel's common path priced at the measured
+                # issue rate of ITS class -- tools/isa_classes.py on the compiler's assembly, rates from tools/valu_rate*.hip
+                if tj.get("class_weighted_clk_per_wave_inst"):
+                    cw_us = tj["valu_insts_per_frame"] * tj["class_weighted_clk_per_wave_inst"] / (tj["simds"] * tj["clock_ghz"] * 1e3)
+                    valu.update({"floor_us_per_frame": round(cw_us, 2), "frac_of_valu_floor": round(cw_us / per_frame_us, 3),
+                                 "floor": "class-weighted: " + str(tj.get("class_source", "")), "class_shares": tj.get("class_shares")})
+                else:
+                    valu.update({"floor_us_per_frame": round(flat_us, 2), "frac_of_valu_floor": round(flat_us / per_frame_us, 3), "floor": "flat"})
         except Exception:
             traffic = None
 
@@ -562,7 +571,9 @@ def main():
                    "collective": None if world == 1 else ("gloo (rehearsal)" if rehearsal else "RCCL all_gather + all_reduce int32[8][65536], once per clip")},
         "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_frame<5,packed,patch,stripes>",
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "void mlv::k_frame<5, true, true, false>(mlv::FrameArgs)" if args.cs == 5 else f"void mlv::k_frame<{args.cs}, true, true, false>(mlv::FrameArgs)",
+                     "kernel_template_arguments": "METHOD (chroma smoothing 2 / 3 / 5), PACKED (14-bit stream in), VEC (width % 16 == 0), SPREAD (dark-clip table layout)",
                      "kernel_ms_per_launch": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(F * npx * BYTES_PER_PX)},
         "parity": parity,
     }

@@ -1,0 +1,331 @@
+#!/usr/bin/env python3
+"""tools/isa_classes.py -- where the vector instructions of the headline kernel go, by ISSUE-RATE CLASS and weighted by how often
+each instruction runs per tile, from the compiler's own assembly of k_frame<5, true, true, false> (METHOD, PACKED, VEC, SPREAD).
+
+VERDICT r2 weak #2: the flat "VALU floor" of round 2 priced every vector instruction at the 0.24 wave-instructions per clock and
+SIMD of v_min/max_i32, although tools/valu_rate*.hip measured v_mov_b32 / v_*_f32 / unpacked 16-bit min/max at ~0.45 and plain
+adds, logic and constant shifts at ~0.31.  This tool produces the class-weighted floor bench.py reports instead.
+
+How (no GPU needed):
+ 1. compiles mlvfs_amd/csrc/k_frame.hip twice with the production flags -- once plainly, once with -gline-tables-only -- and checks
+    that the kernel's instruction stream is the same in both (line tables must not change code generation);
+ 2. walks the annotated assembly: every instruction carries its source location INCLUDING the inlined-at chain
+    (".loc ... ; k_frame.hip:L @[ k_frame.hip:L' @[ ... ] ]");
+ 3. gives every instruction a weight = wave-executions per tile on the benchmark's frames (common path), from WHERE in the source
+    it sits -- found by searching the source for the statements that delimit each region, so the table below survives edits:
+        loader, full items        3   (waves 0..2 hold full items: 152 of them in the 5x5 geometry)
+        loader, edge items        1   (wave 2 only)
+        cell_pair_ev, slow path   0   (pixels at / below black: not on these frames)   ... and so on, see REGIONS
+ 4. classes every instruction by mnemonic and prices the class with the measured rates (profiles/r01/valu_rate2.log,
+    profiles/r03/valu_rate3.log; unknown mnemonics at the quarter rate);
+ 5. checks the weighted total against SQ_INSTS_VALU of the same build (profiles/r03/*pmc*: per frame / tiles per frame) when given.
+
+usage: python tools/isa_classes.py [--pmc-valu-per-frame N] [--clock-ghz 2.35] [--json out.json]
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "mlvfs_amd", "csrc", "k_frame.hip")
+KERNEL = "_ZN3mlv7k_frameILi5ELb1ELb1ELb0EEEvNS_9FrameArgsE"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"),
+         "-mllvm", "--amdgpu-sched-strategy=max-ilp", "-fno-slp-vectorize"]
+W, H, TCW, TCH5 = 3584, 1320, 64, 15
+TILES_PER_FRAME = ((W // 2 + TCW - 1) // TCW) * ((H // 2 + TCH5 - 1) // TCH5)
+
+
+def compile_asm(out_dir, debug):
+    tag = "g" if debug else "prod"
+    d = os.path.join(out_dir, tag)
+    os.makedirs(d, exist_ok=True)
+    cmd = ["/opt/rocm/bin/hipcc", *FLAGS, *(["-gline-tables-only"] if debug else []), "--save-temps=obj", "-c", SRC, "-o", os.path.join(d, "k_frame.o")]
+    subprocess.run(cmd, check=True, capture_output=True, cwd=os.path.dirname(SRC))
+    text = open(os.path.join(d, "k_frame-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    start = text.index("\n" + KERNEL + ":")
+    end = text.index("s_endpgm", start)
+    return text[start:end].splitlines()
+
+
+INSTR = re.compile(r"^\t([a-z][a-z0-9_]+)\b(.*)$")
+
+
+def instruction_stream(lines):
+    out = []
+    for ln in lines:
+        m = INSTR.match(ln)
+        if m and not ln.startswith("\t."):
+            ops = re.sub(r"\.L[A-Za-z0-9_]+", "L", m.group(2).split(";")[0]).strip()
+            out.append((m.group(1), ops))
+    return out
+
+
+# ---------------------------------------------------------------- source regions
+def source_index():
+    src = open(SRC).read().splitlines()
+
+    def find(text, after=0, nth=1):
+        for i in range(after, len(src)):
+            if text in src[i]:
+                nth -= 1
+                if nth == 0:
+                    return i + 1
+        raise SystemExit(f"isa_classes: marker not found in k_frame.hip: {text!r}")
+
+    def block_end(line):                      # the closing brace that matches the first '{' at or after `line`
+        depth, seen = 0, False
+        for i in range(line - 1, len(src)):
+            code = src[i].split("//")[0]
+            for ch in code:
+                if ch == "{":
+                    depth += 1
+                    seen = True
+                elif ch == "}":
+                    depth -= 1
+                    if seen and depth == 0:
+                        return i + 1
+        raise SystemExit("isa_classes: unbalanced braces")
+
+    def func(name):
+        a = find(name)
+        return a, block_end(a)
+
+    idx = {"find": find, "block_end": block_end, "func": func, "src": src}
+    return idx
+
+
+def build_regions():
+    ix = source_index()
+    find, block_end, func = ix["find"], ix["block_end"], ix["func"]
+    R = {}
+    R["kernel"] = func("__global__ __launch_bounds__(256, 4) void k_frame(")
+    k0 = R["kernel"][0]
+    R["loop"] = (find("while (t < band_end) {", k0), None)
+    R["loop"] = (R["loop"][0], block_end(R["loop"][0]))
+    R["loader"] = (find("if (has_item) {", k0), None)
+    R["loader"] = (R["loader"][0], block_end(R["loader"][0]))
+    R["chain32"] = (find("if (chain32) {", k0), None)
+    R["chain32"] = (R["chain32"][0], block_end(R["chain32"][0]))
+    R["packed"] = (find("if (!skip_packed) {", k0), None)
+    R["packed"] = (R["packed"][0], block_end(R["packed"][0]))
+    R["halo_wave"] = (find("if (halo_wave) {", k0), None)
+    R["halo_wave"] = (R["halo_wave"][0], block_end(R["halo_wave"][0]))
+    R["own_window"] = (find("if (!halo_wave) chain_group_window(g);", k0),) * 2
+    R["queue_push"] = (find("if (unknown) sm.fb_queue[", k0),) * 2
+    R["fallback"] = (find("if (nfb > 0) {", k0), None)
+    R["fallback"] = (R["fallback"][0], block_end(R["fallback"][0]))
+    R["patch_fetch"] = (find("if (tile_patched) {", k0), None)
+    R["patch_fetch"] = (R["patch_fetch"][0], block_end(R["patch_fetch"][0]))
+    R["patch_cell"] = (find("if (tile_patched && patch_wave) my_cell = patch_cell", k0),) * 2
+    R["patch_store"] = (find("if (tile_patched) {", R["patch_fetch"][1]), None)
+    R["patch_store"] = (R["patch_store"][0], block_end(R["patch_store"][0]))
+    R["novec_store"] = (find("} else {", find("if (store && y < a.h) {", k0)), None)
+    R["novec_store"] = (R["novec_store"][0], block_end(R["novec_store"][0]))
+    R["stripe_slow"] = (find("else if (stripe_mode == 2)", k0), find("else stripe_strip<false>", k0))
+    for name, sig in {"cell_pair_ev": "__device__ __forceinline__ void cell_pair_ev(", "cell_multi_ev_fast": "__device__ __forceinline__ void cell_multi_ev_fast(",
+                      "fetch_rows": "__device__ __forceinline__ void fetch_rows(", "fetch_clamped": "__device__ __forceinline__ uint32_t fetch_clamped(",
+                      "emit_item": "__device__ __forceinline__ void emit_item(", "store_cells": "__device__ __forceinline__ void store_cells(",
+                      "strip_median25": "__device__ __forceinline__ void strip_median25(", "robust_ref": "__device__ __forceinline__ int robust_ref(",
+                      "chain_publish": "__device__ __forceinline__ void chain_publish(", "patch_cell_fn": "__device__ __forceinline__ PatchCell patch_cell(",
+                      "patch_store_fn": "__device__ __forceinline__ void patch_store(", "stripe_px": "__device__ __forceinline__ uint32_t stripe_px(",
+                      "stripe_strip": "__device__ __forceinline__ void stripe_strip("}.items():
+        R[name] = func(sig)
+    R["chain32_fns"] = (find("struct Chain32 {"), func("__device__ __forceinline__ void chain32_finish(")[1])
+    R["sort5_32"] = func("__device__ __forceinline__ void sort5(int (&v)[5])")
+    cp = R["cell_pair_ev"][0]
+    R["cell_pair_slow"] = (find("int l[8];", cp) - 1, R["cell_pair_ev"][1])        # the block after `if (!slow) { ... return; }`
+    em = R["emit_item"][0]
+    R["emit_edge"] = (find("} else if (METHOD != 0) {", em), R["emit_item"][1])
+    sc = R["store_cells"][0]
+    R["store_pairs"] = (find("for (int c = 0; c < NCELL; c += 2) {", sc), R["store_cells"][1])
+    return R
+
+
+def inside(line, rng):
+    return rng[0] <= line <= rng[1]
+
+
+def weight_of(chain, R, tiles_per_workgroup):
+    """chain: k_frame.hip lines from the innermost frame to the outermost (the line in k_frame's own body is last)."""
+    if not chain:
+        return 4.0, "unattributed"
+    if any(inside(l, R["chain32_fns"]) or inside(l, R["sort5_32"]) for l in chain):
+        return 0.0, "32-bit chain (tiles that skip the packed attempt)"
+    outer = chain[-1]
+    if not inside(outer, R["kernel"]):
+        return 4.0, "unattributed"
+    if not inside(outer, R["loop"]):
+        return 4.0 / tiles_per_workgroup, "prologue / epilogue (per workgroup)"
+    inner = set(chain)
+
+    def any_in(name):
+        return any(inside(l, R[name]) for l in inner)
+
+    # paths the benchmark's frames do not take
+    if any_in("cell_pair_slow"):
+        return 0.0, "loader: out-of-table pixels (slow path)"
+    if any_in("fetch_rows") or any_in("fetch_clamped") or any_in("novec_store"):
+        return 0.0, "widths that are no multiple of 16"
+    if inside(outer, R["chain32"]):
+        return 0.0, "32-bit chain (tiles that skip the packed attempt)"
+    if inside(outer, R["fallback"]) or inside(outer, R["queue_push"]) or any_in("strip_median25"):
+        return 0.0, "uncertain strips (32-bit networks, dense pass)"
+    if any_in("robust_ref"):
+        return 0.0, "shared references (noisy shadows)"
+    if any_in("stripe_px") or any_in("stripe_strip") or inside(outer, R["stripe_slow"]):
+        return 0.0, "stripes, 32-bit / generic epilogue"
+    if inside(outer, R["patch_fetch"]) or inside(outer, R["patch_cell"]) or inside(outer, R["patch_store"]) or any_in("patch_cell_fn") or any_in("patch_store_fn"):
+        return 0.1, "pixel-map cells (one tile in ten has any)"
+    if inside(outer, R["loader"]):
+        if any_in("emit_edge") or (any_in("cell_pair_ev") and not any_in("cell_multi_ev_fast")) or any_in("store_pairs"):
+            return 1.0, "loader: edge items (wave 2)"
+        return 3.0, "loader: full items (waves 0-2)"
+    if inside(outer, R["packed"]):
+        if inside(outer, R["halo_wave"]) or any_in("chain_publish"):
+            return 1.0, "medians: halo groups' window + publish (wave 3)"
+        if inside(outer, R["own_window"]):
+            return 3.0, "medians: own rank window (waves 0-2)"
+        return 4.0, "medians: packed neighbour-sharing chain"
+    return 4.0, "output stage, loop control (all waves)"
+
+
+# ---------------------------------------------------------------- instruction classes
+def load_rates():
+    rates = {}
+    for rel in ("profiles/r01/valu_rate2.log", "profiles/r03/valu_rate3.log"):
+        p = os.path.join(ROOT, rel)
+        if not os.path.exists(p):
+            continue
+        for ln in open(p):
+            m = re.match(r"(v_[a-z0-9_]+)(.*?)thr=\s*(\d+)\s+([0-9.]+) wave-instr", ln)
+            if m and int(m.group(3)) == 1024:
+                key = m.group(1) + ("_dpp" if "row_" in m.group(2) or "wave_" in m.group(2) else "")
+                if m.group(1) == "v_cndmask_b32":
+                    if rel.endswith("valu_rate2.log"):
+                        continue                               # superseded by valu_rate3 (see its header)
+                    key = "v_cndmask_b32:vcc" if "vcc" in m.group(2) else "v_cndmask_b32:sgpr"
+                rates.setdefault(key, float(m.group(4)))
+    return rates
+
+
+def class_of(mn, ops, rates):
+    """-> (class name, rate in wave-instructions per clock and SIMD) for vector-ALU instructions; None for the rest"""
+    if not mn.startswith("v_"):
+        return None
+    base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", mn)
+    if base == "v_cndmask_b32":                          # the VCC form and the SGPR-pair form were timed separately (valu_rate3)
+        r = rates.get("v_cndmask_b32:vcc" if mn.endswith("_e32") or mn == base and "vcc" in ops else "v_cndmask_b32:sgpr")
+        if r is not None:
+            return ("slow (v_cndmask_b32 on VCC: measured 0.044)" if r < 0.15 else "quarter-rate (min/max/med3, packed, bfe, cvt, mul, cmp, 3-operand)"), r
+    if mn.endswith("_dpp") or " row_" in ops or "wave_sh" in ops or "quad_perm" in ops:
+        key = base + "_dpp"
+        r = rates.get(key, rates.get("v_mov_b32_dpp", 0.245))
+        return "quarter-rate (DPP operand)", min(r, 0.25)
+    r = rates.get(base)
+    if r is None:
+        return "quarter-rate (not timed: assumed)", 0.245
+    if r >= 0.40:
+        return "half-rate (v_mov_b32, f32 add/sub/mul, unpacked 16-bit min/max)", r
+    if r >= 0.28:
+        return "third-rate (add/sub, logic, constant shifts)", r
+    if r < 0.15:
+        return "slow (measured below 0.15)", r
+    return "quarter-rate (min/max/med3, packed, bfe, cvt, mul, cmp, 3-operand)", r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pmc-valu-per-frame", type=float, default=None, help="SQ_INSTS_VALU per frame of the same build (cross-check)")
+    ap.add_argument("--clock-ghz", type=float, default=2.35, help="in-kernel clock measured on the box (DESIGN.md 3.1)")
+    ap.add_argument("--frames-per-launch", type=int, default=100)
+    ap.add_argument("--workgroups", type=int, default=1024)
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--out-dir", default=os.path.join(ROOT, "build", "isa"))
+    a = ap.parse_args()
+
+    prod = instruction_stream(compile_asm(a.out_dir, False))
+    dbg_lines = compile_asm(a.out_dir, True)
+    dbg = instruction_stream(dbg_lines)
+    same = prod == dbg
+    R = build_regions()
+    rates = load_rates()
+    tiles_per_wg = TILES_PER_FRAME * a.frames_per_launch / a.workgroups
+
+    loc_re = re.compile(r"k_frame\.hip:(\d+):\d+")
+    chain = []
+    per_region, per_class, unknown = {}, {}, {}
+    counts = {"valu": 0.0, "salu": 0.0, "lds": 0.0, "vmem": 0.0, "static_valu": 0, "static_all": 0}
+    for ln in dbg_lines:
+        if ln.startswith("\t.loc"):
+            found = [int(x) for x in loc_re.findall(ln.split(";", 1)[1] if ";" in ln else "") if int(x) > 0]
+            if found:                                          # (a location without a line in k_frame.hip is compiler-made, "line 0":
+                chain = found                                  #  such instructions stay with the code around them)
+            continue
+        m = INSTR.match(ln)
+        if not m or ln.startswith("\t."):
+            continue
+        mn, ops = m.group(1), m.group(2)
+        w, region = weight_of(chain, R, tiles_per_wg)
+        counts["static_all"] += 1
+        c = class_of(mn, ops, rates)
+        if c is None:
+            if mn.startswith("ds_"):
+                counts["lds"] += w
+            elif mn.startswith(("buffer_", "global_", "flat_", "scratch_")):
+                counts["vmem"] += w
+            elif mn.startswith("s_"):
+                counts["salu"] += w
+            continue
+        counts["static_valu"] += 1
+        counts["valu"] += w
+        name, rate = c
+        reg = per_region.setdefault(region, {"weight": w, "valu": 0.0, "clk": 0.0, "static": 0})
+        reg["valu"] += w
+        reg["clk"] += w / rate
+        reg["static"] += 1
+        cl = per_class.setdefault(name, {"valu": 0.0, "clk": 0.0, "mnemonics": {}})
+        cl["valu"] += w
+        cl["clk"] += w / rate
+        cl["mnemonics"][mn] = cl["mnemonics"].get(mn, 0.0) + w
+        if "not timed" in name:
+            unknown[mn] = unknown.get(mn, 0.0) + w
+
+    simds = 1024
+    tiles = TILES_PER_FRAME
+    flat_clk = counts["valu"] / 0.24
+    weighted_clk = sum(c["clk"] for c in per_class.values())
+    us = lambda clk_per_tile: clk_per_tile * tiles / simds / (a.clock_ghz * 1e3)
+    res = {
+        "kernel": "k_frame<5, true, true, false>", "same_instruction_stream_with_line_tables": same,
+        "static_instructions": counts["static_all"], "static_valu": counts["static_valu"],
+        "tiles_per_frame": tiles, "valu_wave_instructions_per_tile": round(counts["valu"], 1),
+        "valu_wave_instructions_per_frame": round(counts["valu"] * tiles),
+        "lds_instructions_per_tile": round(counts["lds"], 1), "vmem_instructions_per_tile": round(counts["vmem"], 1),
+        "salu_instructions_per_tile": round(counts["salu"], 1),
+        "clock_ghz": a.clock_ghz,
+        "flat_floor_us_per_frame_at_0.24": round(us(flat_clk), 2),
+        "class_weighted_floor_us_per_frame": round(us(weighted_clk), 2),
+        "classes": {k: {"valu_per_tile": round(v["valu"], 1), "share": round(v["valu"] / counts["valu"], 3),
+                        "clk_per_tile": round(v["clk"]), "top": dict(sorted(((m, round(x, 1)) for m, x in v["mnemonics"].items()), key=lambda t: -t[1])[:8])}
+                    for k, v in sorted(per_class.items(), key=lambda t: -t[1]["valu"])},
+        "regions": {k: {"wave_executions_per_tile": v["weight"] if v["weight"] >= 0.1 else round(v["weight"], 4), "static_valu": v["static"],
+                        "valu_per_tile": round(v["valu"], 1), "share": round(v["valu"] / counts["valu"], 3)}
+                    for k, v in sorted(per_region.items(), key=lambda t: -t[1]["valu"])},
+        "not_timed_mnemonics": dict(sorted(((m, round(x, 1)) for m, x in unknown.items()), key=lambda t: -t[1])),
+    }
+    if a.pmc_valu_per_frame:
+        res["pmc_SQ_INSTS_VALU_per_frame"] = a.pmc_valu_per_frame
+        res["static_model_over_pmc"] = round(counts["valu"] * tiles / a.pmc_valu_per_frame, 3)
+    text = json.dumps(res, indent=1)
+    if a.json:
+        open(a.json, "w").write(text + "\n")
+    print(text)
+    if not same:
+        print("isa_classes: WARNING: the instruction stream differs between the production build and the -gline-tables-only build", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
