@@ -273,6 +273,17 @@ int mlvfs_amd_deflicker_dev(const mlvfs_amd_geom_t *geom, const void *d_frame, s
  * mlvfs_amd_dualiso_reset forgets the per-black-level table caches (a fresh process).  */
 int mlvfs_amd_cr2hdr20_dev(const mlvfs_amd_geom_t *geom, void *d_frame, int interp_method, int fullres, int use_alias_map,
                            int chroma_smooth, void *stream);
+/* The same for `nframes` frames of one clip geometry, `stride` bytes apart, in ONE submission: every stage is launched once for the
+ * whole batch (the frame index is a grid dimension; AMaZE runs nframes x 319 tiles at 3584x1320 instead of 319 with a two-tile
+ * tail), the integer decisions of hdr.c:441-636, 250-300 and 638-772 (pattern, bright / dark fields, white levels, order
+ * statistics, highlight rows, slope fit) are made by single-workgroup kernels, and ONE host round trip per batch remains -- the
+ * libm scalars (log2 of the fitted slope and of the levels) and the reference's progress lines -- plus the final wait.
+ * results[f] (host memory) = 1 converted / 0 left alone (not dual ISO, detection failed), like the reference's return value
+ * frame by frame; the function returns 0, or < 0 on an error of the library.  Frames are processed as if in order: the table caches
+ * take the white level of the first frame that converts (hdr.c:1080,1240,1575,1672).  Work memory: ~0.93 GB per 3584x1320 frame
+ * of the batch with the AMaZE interpolation, kept by the calling thread. */
+int mlvfs_amd_cr2hdr20_batch_dev(const mlvfs_amd_geom_t *geom, void *d_frames, size_t stride, int nframes, int interp_method,
+                                 int fullres, int use_alias_map, int chroma_smooth, int *results, void *stream);
 void mlvfs_amd_dualiso_reset(void);
 /* the global decisions of the calling thread's last conversion: {RGGB?, is_bright[0..3] as bits 3..0, white, white of the bright
  * rows (20 bit), a, b of the exposure fit (hdr.c:638-823), ISO difference in EV, darkened white} */

@@ -214,103 +214,26 @@ static int amaze_scratch_for(int device, int w, int h, hipStream_t s, float **ou
     return MLVFS_AMD_OK;
 }
 
-// ------------------------------------------------------------------ host analysis helpers
-static int kth_from_hist(const unsigned *hist, int bins, long long k)      // k-th smallest (0-based) bin index
+// ------------------------------------------------------------------ candidate slopes of match_exposures
+// test_a = pow(2, -ev) for ev = 0, 0.002, ... < 6 with ev ACCUMULATED like the reference's loop (hdr.c:752-755): the same for
+// every frame, so built once with the node's libm and kept on each device
+static std::vector<double> g_ta;
+static std::map<int, double *> g_dev_ta;
+static int candidate_slopes(int device, const double **d_ta, const double **h_ta, int *ncand)
 {
-    long long acc = 0;
-    for (int i = 0; i < bins; i++) { acc += hist[i]; if (acc > k) return i; }
-    return bins - 1;
-}
-
-static bool is_rggb_from_hist(const unsigned *hb)                             // hdr.c:463-494
-{
-    double d_rggb = 0, d_gbrg = 0;
-    long long acc[4] = { 0, 0, 0, 0 };
-    for (int i = 0; i < 16384; i++) {
-        for (int k = 0; k < 4; k++) acc[k] += hb[k * 16384 + i];
-        d_rggb += (double)std::llabs(acc[1] - acc[2]);
-        d_gbrg += (double)std::llabs(acc[0] - acc[3]);
-    }
-    return d_rggb < d_gbrg;
-}
-
-static int bright_dark_from_hist(const unsigned *hg, int black, int is_bright[4])   // hdr.c:540-636
-{
-    const int white = 10000;
-    long long total = 0;
-    for (int i = 0; i < 16384; i++) total += hg[i];
-    long long acc[4] = { 0, 0, 0, 0 };
-    int raw[4] = { 0, 0, 0, 0 }, off[4] = { 0, 0, 0, 0 };
-    const int ref_max = (int)(total * 0.998), ref_off = (int)(total * 0.05);
-    // The reference walks ref = 0, 1, 2, ... (hdr.c:563-589); between two values of ref at which some class advances
-    // nothing changes, so only those values are visited: same assignments, same exit.
-    for (long long ref = 0; ref < ref_max;) {
-        for (int i = 0; i < 4; i++)
-            while (acc[i] < ref && raw[i] < 16384) { acc[i] += hg[i * 16384 + raw[i]]; raw[i]++; }
-        if (ref < ref_off && std::max(std::max(raw[0], raw[1]), std::max(raw[2], raw[3])) < black + (white - black) / 4)
-            memcpy(off, raw, sizeof off);
-        if (raw[0] >= white || raw[1] >= white || raw[2] >= white || raw[3] >= white) break;
-        long long next = ref_max;
-        for (int i = 0; i < 4; i++)
-            if (raw[i] < 16384) next = std::min(next, acc[i] + 1);     // first ref at which class i moves again
-        ref = std::max(next, ref + 1);
-    }
-    for (int i = 0; i < 4; i++) raw[i] -= off[i];
-    int s[4];
-    memcpy(s, raw, sizeof s);
-    std::sort(s, s + 4);
-    const double med = (s[1] + s[2]) / 2;
-    for (int i = 0; i < 4; i++) is_bright[i] = raw[i] > med;
-    printf("ISO pattern     : %c%c%c%c %s\n", is_bright[0] ? 'B' : 'd', is_bright[1] ? 'B' : 'd', is_bright[2] ? 'B' : 'd',
-           is_bright[3] ? 'B' : 'd', "RGGB");
-    if (is_bright[0] + is_bright[1] + is_bright[2] + is_bright[3] != 2) { printf("Bright/dark detection error\n"); return 0; }
-    if (is_bright[0] == is_bright[2] || is_bright[1] == is_bright[3]) { printf("Interlacing method not supported\n"); return 0; }
-    return 1;
-}
-
-// white_detect (hdr.c:250-300) from the per-row-phase histograms of every 3rd pixel.  The
-// reference caps each class list at max_pix entries by overwriting its last slot; `tail`
-// holds the last `tail_rows` image rows so the overwritten samples can be taken out again.
-static void whites_from_hist(const unsigned *hw, const int is_bright[4], int w, int h, int ay1, const uint16_t *tail,
-                             int tail_rows, int *white_dark, int *white_bright)
-{
-    const int spr = (w + 2) / 3;
-    const long long max_pix = (long long)w * h / 2 / 9;
-    std::vector<unsigned> hist[2] = { std::vector<unsigned>(32768, 0), std::vector<unsigned>(32768, 0) };
-    for (int ph = 0; ph < 4; ph++)
-        for (int i = 0; i < 32768; i++) hist[is_bright[ph]][i] += hw[ph * 32768 + i];
-    long long total[2] = { 0, 0 };
-    for (int y = ay1; y < h; y += 3) total[is_bright[y % 4]] += spr;
-    long long kept[2] = { total[0], total[1] };
-    // remove the samples the cap overwrote: class indices max_pix-1 .. total-2
-    long long idx[2] = { 0, 0 };
-    for (int y = ay1; y < h; y += 3) {
-        const int c = is_bright[y % 4];
-        if (total[c] > max_pix && idx[c] + spr > max_pix - 1 && y >= h - tail_rows) {
-            const uint16_t *row = tail + (size_t)(y - (h - tail_rows)) * w;
-            for (int sx = 0; sx < spr; sx++) {
-                const long long k = idx[c] + sx;
-                if (k >= max_pix - 1 && k <= total[c] - 2) {
-                    const int v = row[3 * sx] < 32767 ? row[3 * sx] : 32767;
-                    hist[c][v]--;
-                    kept[c]--;
-                }
-            }
+    std::lock_guard<std::mutex> lk(g_di_mutex);
+    if (g_ta.empty())
+        for (double ev = 0; ev < 6; ev += 0.002) {
+            if (g_ta.size() >= 3100) break;
+            g_ta.push_back(pow(2, -ev));
         }
-        idx[c] += spr;
+    double *&d = g_dev_ta[device];
+    if (!d) {
+        MLV_HIP(hipMalloc(&d, sizeof(double) * g_ta.size()));
+        MLV_HIP(hipMemcpy(d, g_ta.data(), sizeof(double) * g_ta.size(), hipMemcpyHostToDevice));
     }
-    // k-th smallest of the negated values = (k+1)-th largest value
-    auto kth_largest = [&](int c, long long k) {
-        if (kept[c] <= 0) return 0;
-        if (k > kept[c] - 1) k = kept[c] - 1;
-        long long acc = 0;
-        for (int i = 32767; i >= 0; i--) { acc += hist[c][i]; if (acc > k) return i; }
-        return 0;
-    };
-    const int w0 = kth_largest(0, 10) - 100, w1 = kth_largest(1, 50) - 1500;
-    *white_dark = w0 < 10000 ? 10000 : (w0 > 16383 ? 16383 : w0);
-    *white_bright = w1 < 5000 ? 5000 : (w1 > 16383 ? 16383 : w1);
-    printf("White levels    : %d %d\n", *white_dark, *white_bright);
+    *d_ta = d; *h_ta = g_ta.data(); *ncand = (int)g_ta.size();
+    return MLVFS_AMD_OK;
 }
 
 // MLVFS_AMD_DI_TIMING=1: wall-clock of the host-visible phases of one conversion on stderr (tuning aid)
@@ -327,218 +250,41 @@ struct PhaseTimer {
     }
 };
 
-// ------------------------------------------------------------------ the conversion on a device frame
-// d_frame: w x H uint16 frame in HBM, converted in place.  Returns 1 converted, 0 not dual ISO / failed
-// like the reference, < 0 on an error of the library.
-int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w, int H, int black14, int white14,
-                    int interp_method, int use_fullres, int use_alias_map, int chroma_smooth_method, int bad_pixels_mode,
-                    hipStream_t stream, bool *frame_touched)
+// ------------------------------------------------------------------ from a frame's integer decisions to its parameters
+// What the reference decides after its analysis passes, in its order, with its progress lines: the checks that make it give up
+// (return 0: the frame is left alone), the exposure fit's scalars and the libm values derived from them.  `d` comes from the
+// device (k_di_decide_*), `ta` are the candidate slopes.
+struct DiOptions { int interp_method, use_fullres, use_alias_map, chroma_smooth_method; };
+
+static int finish_decisions(const DiDecide &d, const double *ta, int w, int H, int black14, const DiOptions &o, DiParams *out, double scalars[8])
 {
-    if (frame_touched) *frame_touched = false;
-    PhaseTimer pt;
-    if (w <= 0 || H <= 8) return 0;
-    const size_t N = (size_t)w * H;
-    const double *d_evf = nullptr;
-    int rc = prepare_tables(c->dev->id, 0, 0, 1, nullptr, &d_evf);
-    if (rc) return rc;
-
-    // ---- work buffer layout
-    const int nsx = (w + 2) / 3, nsy_max = H / 3 + 2;
-    const size_t ns = (size_t)nsx * nsy_max;
-    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += up(bytes); return o; };
-    const size_t o_hist = take(sizeof(unsigned) * DI_D_WORDS), o_check = take(16), o_ds = take(ns * 4), o_bs = take(ns * 4),
-                 o_hb = take(sizeof(unsigned) * DI_HIST_N), o_hd = take(sizeof(unsigned) * DI_HIST_N), o_hi_d = take(ns / 25 * 4 + 65536),
-                 o_hi_b = take(ns / 25 * 4 + 65536), o_cand = take(8 * 2 * 3100), o_score = take(4 * 3100),
-                 o_rows = take((size_t)nsy_max * 12);
-    const size_t o_raw = take(N * 4), o_dark = take(N * 4), o_bright = take(N * 4), o_full = take(N * 4), o_half = take(N * 4),
-                 o_over = take(N * 2), o_amap = take(N * 2), o_aux = take(N * 2), o_amap2 = take(N * 2);
-    // an unknown method only logs in the reference (hdr.c:1518) and leaves the "smoothed" copies unsmoothed
-    const bool cs = chroma_smooth_method == 2 || chroma_smooth_method == 3 || chroma_smooth_method == 5;
-    const size_t o_full_s = take(cs ? N * 4 : 0), o_half_s = take(cs ? N * 4 : 0), o_cells = take(cs ? N * 3 : 0);
-    const bool amaze = interp_method == 0;
-    const size_t o_cfa = take(amaze ? N * 4 : 0), o_red = take(amaze ? N * 4 : 0), o_green = take(amaze ? N * 4 : 0),
-                 o_blue = take(amaze ? N * 4 : 0), o_gray = take(amaze ? N * 4 : 0), o_dir = take(amaze ? N : 0),
-                 o_sq = take(amaze ? (size_t)H * 8 : 0), o_stats = take(16);
-    DiWork &wk = t_work[c->dev->id];
-    rc = wk.ensure(off);
-    if (rc) return rc;
-    uint8_t *B = (uint8_t *)wk.base;
-
-    // ---- hdr_check + all histograms in one pass
-    const size_t ph_hist = 0, ph_ds = ph_hist + sizeof(unsigned) * DI_HIST_WORDS, ph_bs = ph_ds + ns * 4, ph_hb = ph_bs + ns * 4,
-                 ph_hd = ph_hb + sizeof(unsigned) * DI_HIST_N, ph_tail = ph_hd + sizeof(unsigned) * DI_HIST_N,
-                 ph_dev = ph_tail + (size_t)32 * w * 2, ph_edge = ph_dev + (o_check - o_hist) + 256,       // (the check sums travel behind the block)
-                 ph_rows = ph_edge + (size_t)13 * w * 2,
-                 // (every copy of this path starts or ends in this page-locked block: a copy from or to pageable memory waits inside
-                 // the runtime for the stream to reach it, and the calls of the other host threads wait with it)
-                 ph_cand = (ph_rows + (size_t)nsy_max * 12 + 63) / 64 * 64, ph_score = ph_cand + 8 * 2 * 3100, ph_sq = ph_score + 4 * 3100,
-                 ph_st = ph_sq + (size_t)H * 8, ph_end = ph_st + 64;
-    PinnedWork &pw = t_pinned[c->dev->id];
-    rc = pw.ensure(ph_end);
-    if (rc) return rc;
-    uint8_t *PH = (uint8_t *)pw.base;
-    unsigned *hist_p = (unsigned *)(PH + ph_hist);
-    struct { unsigned *p; unsigned *data() const { return p; } } hist{ hist_p };
-    double check[2];
-    // device block + the first 5 and last 8 rows of the frame (the row ranges of the three derived histograms differ
-    // from "all rows" only there: hdr.c:453 / :519 stop at a multiple of 4, the GBRG variant starts at row 5)
-    const int top_rows = std::min(5, H), bot_rows = std::min(8, H - top_rows);
-    auto analyse = [&]() -> int {
-        int r = di_launch_analyse(d_frame, w, H, black14, white14, d_evf, (unsigned *)(B + o_hist), (double *)(B + o_check), stream);
-        if (r) return r;
-        unsigned *dev = (unsigned *)(PH + ph_dev);
-        uint16_t *edge = (uint16_t *)(PH + ph_edge);
-        MLV_HIP(hipMemcpyAsync(dev, B + o_hist, (o_check - o_hist) + 16, hipMemcpyDeviceToHost, stream));      // block + check sums: one copy
-        MLV_HIP(hipMemcpyAsync(edge, d_frame, (size_t)top_rows * w * 2, hipMemcpyDeviceToHost, stream));
-        MLV_HIP(hipMemcpyAsync(edge + (size_t)top_rows * w, (const uint16_t *)d_frame + (size_t)(H - bot_rows) * w, (size_t)bot_rows * w * 2,
-                               hipMemcpyDeviceToHost, stream));
-        MLV_HIP(hipStreamSynchronize(stream));
-        memcpy(check, (const uint8_t *)dev + (o_check - o_hist), 16);
-        unsigned *hb = hist.data() + DI_H_BAYER, *g0 = hist.data() + DI_H_GREEN0, *g1 = hist.data() + DI_H_GREEN1;
-        memset(hb, 0, sizeof(unsigned) * 4 * 16384);
-        for (int q = 0; q < 4; q++)
-            for (int px = 0; px < 2; px++) {
-                const unsigned *cl = dev + DI_D_CLASS + (size_t)(q * 2 + px) * 16384;
-                unsigned *bay = hb + (size_t)((q & 1) * 2 + px) * 16384;
-                for (int v = 0; v < 16384; v++) bay[v] += cl[v];
-                if (px == 1 - (q & 1)) memcpy(g0 + (size_t)q * 16384, cl, sizeof(unsigned) * 16384);              // greens: x & 1 != y & 1
-                if (px == (q & 1)) memcpy(g1 + (size_t)((q + 3) & 3) * 16384, cl, sizeof(unsigned) * 16384);     // greens of the frame one row lower
-            }
-        const int R0 = H / 4 * 4, h1 = H - 1, R1 = h1 / 4 * 4;
-        auto take_out = [&](int y, const uint16_t *row) {
-            const int y1 = y - 1;
-            const bool in0 = y < R0, in1 = y1 >= 4 && y1 < R1;
-            if (in0 && in1) return;
-            for (int x = 0; x < w; x++) {
-                const int v = row[x] & 16383;
-                if (!in0) { hb[(size_t)((y & 1) * 2 + (x & 1)) * 16384 + v]--; if ((x & 1) != (y & 1)) g0[(size_t)(y & 3) * 16384 + v]--; }
-                if (!in1 && (x & 1) == (y & 1)) g1[(size_t)(y1 & 3) * 16384 + v]--;
-            }
-        };
-        for (int y = 0; y < top_rows; y++) take_out(y, edge + (size_t)y * w);
-        for (int k = 0; k < bot_rows; k++) take_out(H - bot_rows + k, edge + (size_t)(top_rows + k) * w);
-        memcpy(hist.data() + DI_H_WHITE0, dev + DI_D_WHITE0, sizeof(unsigned) * 8 * 32768);
-        return MLVFS_AMD_OK;
-    };
-    rc = analyse();
-    if (rc) return rc;
-    pt.mark("analyse (kernel + D2H)");
-    if (!(check[0] / check[1] > 0.5)) return 0;                         // hdr_check, hdr.c:432-438
-
-    // ---- focus / bad pixels are repaired between the check and the analysis (hdr.c:1943-1947)
-    if (fh) {
-        bool ch1 = false, ch2 = false;
-        rc = focus_pixels_device(fh, c, d_frame, 1, &ch1);
-        if (rc) return rc;
-        if (bad_pixels_mode) {
-            rc = bad_pixels_device(fh, c, d_frame, bad_pixels_mode == 2, 1, &ch2);
-            if (rc) return rc;
-        }
-        if (ch1 || ch2) {
-            if (frame_touched) *frame_touched = true;       // the reference repairs in place before it can still bail out
-            rc = analyse();
-            if (rc) return rc;
-        }
-    }
-    if (interp_method != 0 && interp_method != 1) { set_error("cr2hdr20_convert_data: unknown interpolation method"); return 0; }
-    if (amaze && ((w & 3) || w < 36 || H < 37)) {
-        // the reference's SSE2 AMaZE leaves green columns unwritten when w % 4 != 0 and mirrors from row/column 35
-        set_error("cr2hdr20_convert_data: the AMaZE interpolation needs a width that is a multiple of 4 and a frame of at least 36x37; frame not converted");
-        return 0;
-    }
-
-    // ---- pattern (hdr.c:1783-1795)
-    const bool rggb = is_rggb_from_hist(hist.data() + DI_H_BAYER);
-    const int ay1 = rggb ? 0 : 1;
-    const int h = rggb ? H : H - 1;
-    uint16_t *img = (uint16_t *)d_frame + (rggb ? 0 : w);
-    int is_bright[4];
-    if (!bright_dark_from_hist(hist.data() + (rggb ? DI_H_GREEN0 : DI_H_GREEN1), black14, is_bright)) return 0;
-
-    // ---- white levels (hdr.c:1806-1810)
-    const int tail_rows = std::min(h, 32);
-    struct { uint16_t *p; size_t n; uint16_t *data() const { return p; } size_t size() const { return n; } } tail{ (uint16_t *)(PH + ph_tail), (size_t)tail_rows * w };
-    MLV_HIP(hipMemcpyAsync(tail.data(), img + (size_t)(h - tail_rows) * w, tail.size() * 2, hipMemcpyDeviceToHost, stream));
-    MLV_HIP(hipStreamSynchronize(stream));
-    int wd, wb;
-    whites_from_hist(hist.data() + (rggb ? DI_H_WHITE0 : DI_H_WHITE1), is_bright, w, h, ay1, tail.data(), tail_rows, &wd, &wb);
-    const int black = black14 * 64, white = wd * 64, white_bright = wb * 64;
+    DiParams p{};
+    *out = p;                                                             // h = 0: leave the frame alone
+    if (!d.check_ok) return 0;                                          // hdr_check, hdr.c:432-438
+    const bool amaze = o.interp_method == 0;
+    const bool rggb = d.rggb != 0;
+    const int ay1 = rggb ? 0 : 1, h = rggb ? H : H - 1;
+    const int *is_bright = d.is_bright;
+    printf("ISO pattern     : %c%c%c%c %s\n", is_bright[0] ? 'B' : 'd', is_bright[1] ? 'B' : 'd', is_bright[2] ? 'B' : 'd',
+           is_bright[3] ? 'B' : 'd', "RGGB");
+    if (is_bright[0] + is_bright[1] + is_bright[2] + is_bright[3] != 2) { printf("Bright/dark detection error\n"); return 0; }
+    if (is_bright[0] == is_bright[2] || is_bright[1] == is_bright[3]) { printf("Interlacing method not supported\n"); return 0; }
+    printf("White levels    : %d %d\n", d.white_dark, d.white_bright);
+    const int black = black14 * 64, white = d.white_dark * 64, white_bright = d.white_bright * 64;
     printf("Noise levels    : %.02f %.02f %.02f %.02f (14-bit)\n", 8.0, 8.0, 8.0, 8.0);
     const int dark_noise = 8 * 64;
     const double dark_noise_ev = 3.0 + 6, bright_noise_ev0 = 3.0 + 6;
-
-    DiParams p{};
+    const bool cs = o.chroma_smooth_method == 2 || o.chroma_smooth_method == 3 || o.chroma_smooth_method == 5;
     p.w = w; p.h = h; p.ay1 = ay1;
     p.is_bright_bits = is_bright[0] | (is_bright[1] << 1) | (is_bright[2] << 2) | (is_bright[3] << 3);
     p.black20 = black; p.white20 = white;
     p.match_white20 = std::min(white, white_bright);
     p.dark_noise = dark_noise;
-    p.use_fullres = use_fullres; p.use_alias_map = use_alias_map; p.chroma_smooth = cs ? chroma_smooth_method : 0;
-
+    p.use_fullres = o.use_fullres; p.use_alias_map = o.use_alias_map; p.chroma_smooth = cs ? o.chroma_smooth_method : 0;
     // ---- match_exposures (hdr.c:638-823)
-    const int y0 = ay1 + 2;
-    const int nsy = (h - 2 > y0) ? (h - 2 - y0 + 2) / 3 : 0;
-    pt.mark("pattern + whites (host)");
-    rc = di_launch_subsample(img, p, nsx, nsy, (int *)(B + o_ds), (int *)(B + o_bs), (unsigned *)(B + o_hb), (unsigned *)(B + o_hd), stream);
-    if (rc) return rc;
-    struct UintSpan { unsigned *p; size_t n; unsigned *data() const { return p; } const unsigned *begin() const { return p; } const unsigned *end() const { return p + n; } };
-    const UintSpan hb{ (unsigned *)(PH + ph_hb), (size_t)DI_HIST_N }, hd{ (unsigned *)(PH + ph_hd), (size_t)DI_HIST_N };
-    static_assert(sizeof(unsigned) * DI_HIST_N % 256 == 0, "the two histograms lie back to back on the device and in the pinned block");
-    MLV_HIP(hipMemcpyAsync(hb.data(), B + o_hb, 2 * sizeof(unsigned) * DI_HIST_N, hipMemcpyDeviceToHost, stream));      // hb and hd in one copy
-    MLV_HIP(hipStreamSynchronize(stream));
-    long long n = 0;
-    for (unsigned v : hb) n += v;
-    if (n <= 0) { printf("Doesn't look like interlaced ISO\n"); return 0; }
-    auto med_k = [](long long m) { return (m & 1) ? m / 2 : m / 2 - 1; };
-    const int bmed = kth_from_hist(hb.data(), DI_HIST_N, med_k(n)) - DI_HIST_OFF;
-    const int b_lo = kth_from_hist(hb.data(), DI_HIST_N, n * 98 / 100) - DI_HIST_OFF;
-    const int b_hi = kth_from_hist(hb.data(), DI_HIST_N, (long long)(n * 99.9 / 100)) - DI_HIST_OFF;
-    const int dmed = kth_from_hist(hd.data(), DI_HIST_N, med_k(n)) - DI_HIST_OFF;
-    const int nmax = (w + 2) * (h + 2) / 9, hi_nmax = nmax / 50;
-    // highlight pairs stay on the device: per-row counts -> what each row contributes.  A row appends its qualifying
-    // samples until the list has hi_nmax entries; the reference's `break` only leaves the inner loop (hdr.c:744), so
-    // once the cap is reached every further row still appends its first qualifying sample.
-    int *rowinfo = (int *)(PH + ph_rows);                       // counts | take | offset
-    rc = di_launch_hi_count((const int *)(B + o_bs), nsx, nsy, b_lo, b_hi, (int *)(B + o_rows), stream);
-    if (rc) return rc;
-    MLV_HIP(hipMemcpyAsync(rowinfo, B + o_rows, (size_t)nsy * 4, hipMemcpyDeviceToHost, stream));
-    MLV_HIP(hipStreamSynchronize(stream));
-    int hi_n = 0;
-    for (int sy = 0; sy < nsy; sy++) {
-        const int take = std::min(rowinfo[sy], std::max(hi_nmax - hi_n, 1));
-        rowinfo[nsy + sy] = take;
-        rowinfo[2 * nsy + sy] = hi_n;
-        hi_n += take;
-    }
-    MLV_HIP(hipMemcpyAsync(B + o_rows + (size_t)nsy * 4, rowinfo + nsy, (size_t)nsy * 8, hipMemcpyHostToDevice, stream));
-    rc = di_launch_hi_compact((const int *)(B + o_ds), (const int *)(B + o_bs), nsx, nsy, b_lo, b_hi, (const int *)(B + o_rows) + nsy,
-                              (const int *)(B + o_rows) + 2 * nsy, (int *)(B + o_hi_d), (int *)(B + o_hi_b), stream);
-    if (rc) return rc;
-    pt.mark("subsample + D2H + quantiles");
-    double *cand = (double *)(PH + ph_cand);
-    int ncand = 0;
-    for (double ev = 0; ev < 6; ev += 0.002) {
-        const double ta = pow(2, -ev);
-        if (ncand >= 3100) break;                             // (3000 candidates: 6 / 0.002)
-        cand[2 * ncand] = ta;
-        cand[2 * ncand + 1] = dmed - bmed * ta;
-        ncand++;
-    }
+    if (d.n <= 0) { printf("Doesn't look like interlaced ISO\n"); return 0; }
     double a = 0, b = 0;
-    if (hi_n > 0) {
-        MLV_HIP(hipMemcpyAsync(B + o_cand, cand, (size_t)ncand * 16, hipMemcpyHostToDevice, stream));
-        rc = di_launch_score((const int *)(B + o_hi_d), (const int *)(B + o_hi_b), hi_n, (const double *)(B + o_cand), ncand,
-                             (int *)(B + o_score), stream);
-        if (rc) return rc;
-        int *score = (int *)(PH + ph_score);
-        MLV_HIP(hipMemcpyAsync(score, B + o_score, (size_t)ncand * 4, hipMemcpyDeviceToHost, stream));
-        MLV_HIP(hipStreamSynchronize(stream));
-        int best = 0;
-        for (int k = 0; k < ncand; k++)
-            if (score[k] > best) { best = score[k]; a = cand[2 * k]; b = cand[2 * k + 1]; }
-    }
+    if (d.hi_n > 0 && d.best >= 0) { a = ta[d.best]; b = d.dmed - d.bmed * a; }
     const double b20 = b * 16;
     p.a = a; p.b20 = b20;
     p.white_darkened = (int)((p.match_white20 - black + b20) * a + black);
@@ -550,8 +296,7 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     const double lowiso_dr = log2(white - black) - dark_noise_ev, highiso_dr = log2(white_bright - black) - bright_noise_ev0;
     printf("Dynamic range   : %.02f (+) %.02f => %.02f EV (in theory)\n", lowiso_dr, highiso_dr, highiso_dr + corr_ev);
     printf("Interpolation   : %s\n", amaze ? "amaze-edge" : "mean23");
-    if (use_fullres) printf("Full-res reconstruction...\n");
-
+    if (o.use_fullres) printf("Full-res reconstruction...\n");
     // ---- mix_images preconditions (hdr.c:1539-1556)
     double overlap = lowiso_dr - corr_ev;
     overlap -= std::min(3.0, overlap - 3);
@@ -561,73 +306,264 @@ int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w
     printf("Half-res blending...\n");
     p.corr_ev = corr_ev; p.overlap = overlap;
     p.max_ev = log2(white / 64 - black / 64);
-    {   // the host decisions of this conversion, for mlvfs_amd_dualiso_last_scalars
-        double *sc = t_last_scalars;
-        sc[0] = rggb; sc[1] = is_bright[0] * 8 + is_bright[1] * 4 + is_bright[2] * 2 + is_bright[3];
-        sc[2] = white; sc[3] = white_bright; sc[4] = a; sc[5] = b; sc[6] = corr_ev; sc[7] = p.white_darkened;
+    scalars[0] = rggb; scalars[1] = is_bright[0] * 8 + is_bright[1] * 4 + is_bright[2] * 2 + is_bright[3];
+    scalars[2] = white; scalars[3] = white_bright; scalars[4] = a; scalars[5] = b; scalars[6] = corr_ev; scalars[7] = p.white_darkened;
+    if (o.chroma_smooth_method) printf("Chroma smoothing...\n");
+    if (o.chroma_smooth_method && !cs) fprintf(stderr, "Unsupported chroma smooth method\nUnsupported chroma smooth method\n");
+    if (o.use_alias_map) printf("Building alias map...\nFiltering alias map...\nSmoothing alias map...\n");
+    printf("Final blending...\n");
+    *out = p;
+    return 1;
+}
+
+// squeezed row map of the AMaZE path (hdr.c:977-1026): dark rows from the top, bright rows from h/4*2; rows that do not fit are
+// dropped.  sq[0..h): squeezed row an image row is written to (-1 none); sq[hs..hs+h): the row it is looked up at (0 if none)
+static void squeezed_rows(const DiParams &p, int *sq, int hs)
+{
+    const int h = p.h;
+    auto is_bright = [&](int y) { return (p.is_bright_bits >> (y & 3)) & 1; };
+    for (int y = 0; y < hs; y++) { sq[y] = -1; sq[hs + y] = 0; }
+    for (int pass = 0; pass < 2; pass++) {
+        int yh = -1;
+        for (int y = 0; y < h; y++) {
+            if (is_bright(y) != pass) continue;
+            if (yh < 0) yh = pass ? h / 4 * 2 + y : y;
+            sq[y] = yh; sq[hs + y] = yh;
+            yh++;
+            if (pass && yh >= h) break;
+        }
+    }
+    // the two exposures may claim the same squeezed row (odd geometries): the later writer, a bright row, wins
+    std::vector<int> owner((size_t)h, -1);
+    for (int pass = 0; pass < 2; pass++)
+        for (int y = 0; y < h; y++)
+            if (is_bright(y) == pass && sq[y] >= 0) owner[sq[y]] = y;
+    for (int y = 0; y < h; y++)
+        if (sq[y] >= 0 && owner[sq[y]] != y) sq[y] = -1;
+}
+
+// AMaZE tile planes of a batch: frame f's blocks at f * stride; a slot is zeroed when it is (re)allocated or when the rows of the
+// frame in it change (RGGB and GBRG frames of one clip differ by a row), like the reference's calloc per call
+struct AmazeSlots : DiWork { int w = 0, H = 0; std::vector<int> slot_h; size_t stride = 0; };
+static thread_local std::map<int, AmazeSlots> t_amaze_slots;
+
+// ------------------------------------------------------------------ the conversion of a batch of device frames
+// d_frames: nframes frames of w x H uint16 in HBM, img_stride bytes apart, converted in place.  results[f] = 1 converted, 0 not dual
+// ISO / failed like the reference (the frame is untouched).  Returns 0, or < 0 on an error of the library.
+// Host synchronisations: ONE between the analysis kernels and the conversion kernels (the decisions of all frames come back in
+// one copy: the libm scalars and the reference's progress lines are the host's), one at the end (the interpolation's statistics,
+// which the reference prints).  With `fh` (the drop-in symbol: one frame) one more in front: the focus / bad pixel repairs that
+// hdr.c:1943-1947 makes between the check and the analysis need the check's verdict.
+int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_t img_stride, int nframes, int w, int H, int black14,
+                   int white14, const DiOptions &o, int bad_pixels_mode, hipStream_t stream, int *results, bool *frame_touched)
+{
+    if (frame_touched) *frame_touched = false;
+    for (int f = 0; f < nframes; f++) results[f] = 0;
+    PhaseTimer pt;
+    if (w <= 0 || H <= 8 || nframes <= 0) return 0;
+    if (fh && nframes != 1) { set_error("cr2hdr20: frame headers go with a single frame"); return MLVFS_AMD_ERR_ARG; }
+    const size_t N = (size_t)w * H, S = (N + 63) / 64 * 64, NF = (size_t)nframes;
+    const double *d_evf = nullptr;
+    int rc = prepare_tables(c->dev->id, 0, 0, 1, nullptr, &d_evf);
+    if (rc) return rc;
+    const double *d_ta = nullptr, *h_ta = nullptr;
+    int ncand = 0;
+    rc = candidate_slopes(c->dev->id, &d_ta, &h_ta, &ncand);
+    if (rc) return rc;
+
+    // ---- work buffer layout (per-frame blocks, frame f at f * its stride)
+    const int nsx = (w + 2) / 3, nsy_max = H / 3 + 2;
+    const size_t ns = ((size_t)nsx * nsy_max + 63) / 64 * 64;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o2 = off; off += up(bytes); return o2; };
+    const size_t hist_stride = up(sizeof(unsigned) * DI_D_WORDS) / 4, derived_stride = up(sizeof(unsigned) * di_derived_words()) / 4;
+    const size_t hi_stride = up(ns / 25 * 4 + 65536) / 4;
+    const size_t o_hist = take(NF * hist_stride * 4), o_check = take(NF * 2 * 8), o_derived = take(NF * derived_stride * 4),
+                 o_ds = take(NF * ns * 4), o_bs = take(NF * ns * 4), o_hbd = take(NF * 2 * sizeof(unsigned) * DI_HIST_N),
+                 o_hi = take(NF * 2 * hi_stride * 4), o_score = take(NF * 4 * 3104), o_rows = take(NF * (size_t)nsy_max * 12),
+                 o_dd = take(NF * sizeof(DiDecide)), o_pp = take(NF * sizeof(DiParams));
+    const size_t o_raw = take(NF * S * 4), o_dark = take(NF * S * 4), o_bright = take(NF * S * 4), o_full = take(NF * S * 4),
+                 o_half = take(NF * S * 4), o_over = take(NF * S * 2), o_amap = take(NF * S * 2), o_aux = take(NF * S * 2),
+                 o_amap2 = take(NF * S * 2);
+    // an unknown method only logs in the reference (hdr.c:1518) and leaves the "smoothed" copies unsmoothed
+    const bool cs = o.chroma_smooth_method == 2 || o.chroma_smooth_method == 3 || o.chroma_smooth_method == 5;
+    const size_t cells_stride = ((size_t)3 * (H / 2) * (w / 2) + 63) / 64 * 64;
+    const size_t o_full_s = take(cs ? NF * S * 4 : 0), o_half_s = take(cs ? NF * S * 4 : 0), o_cells = take(cs ? NF * cells_stride * 4 : 0);
+    const bool amaze = o.interp_method == 0;
+    const size_t o_cfa = take(amaze ? NF * S * 4 : 0), o_red = take(amaze ? NF * S * 4 : 0), o_green = take(amaze ? NF * S * 4 : 0),
+                 o_blue = take(amaze ? NF * S * 4 : 0), o_gray = take(amaze ? NF * S * 4 : 0), o_dir = take(amaze ? NF * S : 0),
+                 o_sq = take(amaze ? NF * (size_t)H * 8 : 0), o_stats = take(NF * 16);
+    DiWork &wk = t_work[c->dev->id];
+    rc = wk.ensure(off);
+    if (rc) return rc;
+    uint8_t *B = (uint8_t *)wk.base;
+
+    // page-locked landing zone: every copy of this path starts or ends here (a copy from or to pageable memory waits inside the
+    // runtime for the stream to reach it, and the calls of the other host threads wait with it)
+    const size_t ph_dd = 0, ph_pp = ph_dd + up(NF * sizeof(DiDecide)), ph_sq = ph_pp + up(NF * sizeof(DiParams)),
+                 ph_st = ph_sq + up(NF * (size_t)H * 8), ph_check = ph_st + up(NF * 16), ph_end = ph_check + up(NF * 16);
+    PinnedWork &pw = t_pinned[c->dev->id];
+    rc = pw.ensure(ph_end);
+    if (rc) return rc;
+    uint8_t *PH = (uint8_t *)pw.base;
+    DiDecide *dd = (DiDecide *)(PH + ph_dd);
+    DiParams *pp = (DiParams *)(PH + ph_pp);
+
+    DiBatch bt{};
+    bt.pp = (const DiParams *)(B + o_pp);
+    bt.p0.w = w; bt.p0.h = H;
+    bt.p0.use_fullres = o.use_fullres; bt.p0.use_alias_map = o.use_alias_map; bt.p0.chroma_smooth = cs ? o.chroma_smooth_method : 0;
+    bt.S = S; bt.img_stride = img_stride; bt.nframes = nframes;
+    DiDecideBuffers D{};
+    D.hist = (const unsigned *)(B + o_hist); D.hist_stride = hist_stride;
+    D.check = (const double *)(B + o_check); D.check_stride = 2;
+    D.derived = (unsigned *)(B + o_derived); D.derived_stride = derived_stride;
+    D.hist_bd = (const unsigned *)(B + o_hbd);
+    D.rows = (int *)(B + o_rows); D.nsy_max = nsy_max;
+    D.score = (const int *)(B + o_score); D.score_stride = 3104; D.ncand = ncand;
+    D.dd = (DiDecide *)(B + o_dd); D.pp = (DiParams *)(B + o_pp);
+
+    // ---- hdr_check + all histograms in one pass over every frame
+    auto analyse = [&]() {
+        return di_launch_analyse(d_frames, w, H, black14, white14, d_evf, (unsigned *)(B + o_hist), (double *)(B + o_check), stream, nframes,
+                                 img_stride, hist_stride, 2);
+    };
+    rc = analyse();
+    if (rc) return rc;
+    if (fh) {
+        // the drop-in symbol: focus / bad pixels are repaired between the check and the analysis (hdr.c:1943-1947), only on frames
+        // the check accepts
+        double *check = (double *)(PH + ph_check);
+        MLV_HIP(hipMemcpyAsync(check, B + o_check, 16, hipMemcpyDeviceToHost, stream));
+        MLV_HIP(hipStreamSynchronize(stream));
+        pt.mark("analyse (kernel + D2H)");
+        if (!(check[0] / check[1] > 0.5)) return 0;                     // hdr_check, hdr.c:432-438
+        bool ch1 = false, ch2 = false;
+        rc = focus_pixels_device(fh, c, d_frames, 1, &ch1);
+        if (rc) return rc;
+        if (bad_pixels_mode) {
+            rc = bad_pixels_device(fh, c, d_frames, bad_pixels_mode == 2, 1, &ch2);
+            if (rc) return rc;
+        }
+        if (ch1 || ch2) {
+            if (frame_touched) *frame_touched = true;       // the reference repairs in place before it can still bail out
+            rc = analyse();
+            if (rc) return rc;
+        }
+        D.check_passed = 1;                                 // (the reference checks the frame as it was before the repairs)
+    }
+    if (o.interp_method != 0 && o.interp_method != 1) { set_error("cr2hdr20_convert_data: unknown interpolation method"); return 0; }
+    if (amaze && ((w & 3) || w < 36 || H < 37)) {
+        // the reference's SSE2 AMaZE leaves green columns unwritten when w % 4 != 0 and mirrors from row/column 35
+        set_error("cr2hdr20_convert_data: the AMaZE interpolation needs a width that is a multiple of 4 and a frame of at least 36x37; frame not converted");
+        return 0;
     }
 
-    DiLuts L{};
-    pt.mark("score candidates");
-    rc = prepare_tables(c->dev->id, black, white, interp_method, &L, &d_evf);
+    // ---- the decisions of every frame, on the device: pattern, fields, whites; samples, order statistics; highlight rows; fit
+    rc = di_launch_decide_pattern(d_frames, bt, H, black14, D, stream);
+    if (!rc) rc = di_launch_subsample(d_frames, bt, nsx, nsy_max, ns, (int *)(B + o_ds), (int *)(B + o_bs), (unsigned *)(B + o_hbd), stream);
+    if (!rc) rc = di_launch_decide_quantiles(bt, D, stream);
+    if (!rc) rc = di_launch_hi_count((const int *)(B + o_bs), nsx, nsy_max, ns, 0, 0, D.dd, bt, (int *)(B + o_rows), stream);
+    if (!rc) rc = di_launch_decide_rows(bt, D, stream);
+    if (!rc) rc = di_launch_hi_compact((const int *)(B + o_ds), (const int *)(B + o_bs), nsx, nsy_max, ns, 0, 0, D.dd, bt, (const int *)(B + o_rows),
+                                       (int *)(B + o_hi), hi_stride, stream);
+    if (!rc) rc = di_launch_score((const int *)(B + o_hi), hi_stride, 0, d_ta, ncand, 0, 0, D.dd, nframes, (int *)(B + o_score), 3104, stream);
+    if (!rc) rc = di_launch_decide_fit(bt, D, stream);
     if (rc) return rc;
-    if (chroma_smooth_method) printf("Chroma smoothing...\n");
-    if (chroma_smooth_method && !cs) fprintf(stderr, "Unsupported chroma smooth method\nUnsupported chroma smooth method\n");
-    if (use_alias_map) printf("Building alias map...\nFiltering alias map...\nSmoothing alias map...\n");
-    printf("Final blending...\n");
+    MLV_HIP(hipMemcpyAsync(dd, B + o_dd, NF * sizeof(DiDecide), hipMemcpyDeviceToHost, stream));
+    MLV_HIP(hipStreamSynchronize(stream));                  // <- the round trip of the batch
+    pt.mark("decisions (device) + D2H");
+
+    // ---- host: checks, libm scalars, progress lines; the tables of the first frame that converts
+    int nconv = 0;
+    bt.nheights = 0;
+    DiLuts L{};
+    for (int f = 0; f < nframes; f++) {
+        double sc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        results[f] = finish_decisions(dd[f], h_ta, w, H, black14, o, &pp[f], sc);
+        if (results[f] != 1) continue;
+        memcpy(t_last_scalars, sc, sizeof sc);
+        if (!nconv++) {
+            rc = prepare_tables(c->dev->id, pp[f].black20, pp[f].white20, o.interp_method, &L, &d_evf);
+            if (rc) return rc;
+        }
+        bool seen = false;
+        for (int k = 0; k < bt.nheights; k++) seen = seen || bt.heights[k] == pp[f].h;
+        if (!seen && bt.nheights < 2) bt.heights[bt.nheights++] = pp[f].h;
+    }
+    pt.mark("checks + scalars + tables (host)");
+    if (nconv == 0) return 0;
+    MLV_HIP(hipMemcpyAsync(B + o_pp, pp, NF * sizeof(DiParams), hipMemcpyHostToDevice, stream));
+
     DiPlanes P{ (uint32_t *)(B + o_raw), (uint32_t *)(B + o_dark), (uint32_t *)(B + o_bright), (uint32_t *)(B + o_full),
                 (uint32_t *)(B + o_half), (uint32_t *)(B + o_full_s), (uint32_t *)(B + o_half_s), (uint16_t *)(B + o_over),
                 (uint16_t *)(B + o_amap), (uint16_t *)(B + o_aux), (uint16_t *)(B + o_amap2), (int *)(B + o_cells) };
-    pt.mark("tables");
-    rc = di_launch_match(img, p, P, stream);
+    P.cells_stride = cells_stride;
+    rc = di_launch_match(d_frames, bt, H, P, stream);
     if (rc) return rc;
     if (amaze) {
-        // squeezed row map (hdr.c:977-1026): dark rows from the top, bright rows from h/4*2; rows that do not fit are dropped
-        int *sq = (int *)(PH + ph_sq);                         // 2 h entries
-        for (int y = 0; y < h; y++) { sq[y] = -1; sq[h + y] = 0; }
-        for (int pass = 0; pass < 2; pass++) {
-            int yh = -1;
-            for (int y = 0; y < h; y++) {
-                if (is_bright[y % 4] != pass) continue;
-                if (yh < 0) yh = pass ? h / 4 * 2 + y : y;
-                sq[y] = yh; sq[h + y] = yh;
-                yh++;
-                if (pass && yh >= h) break;
-            }
+        int *sq = (int *)(PH + ph_sq);                         // per frame: sq_dst | sq_row, H entries each
+        for (int f = 0; f < nframes; f++) {
+            if (results[f] == 1) squeezed_rows(pp[f], sq + (size_t)f * 2 * H, H);
+            else memset(sq + (size_t)f * 2 * H, 0, (size_t)2 * H * 4);
         }
-        {   // the two exposures may claim the same squeezed row (odd geometries): the later writer, a bright row, wins
-            std::vector<int> owner((size_t)h, -1);
-            for (int pass = 0; pass < 2; pass++)
-                for (int y = 0; y < h; y++)
-                    if (is_bright[y % 4] == pass && sq[y] >= 0) owner[sq[y]] = y;
-            for (int y = 0; y < h; y++)
-                if (sq[y] >= 0 && owner[sq[y]] != y) sq[y] = -1;
+        MLV_HIP(hipMemcpyAsync(B + o_sq, sq, NF * (size_t)2 * H * 4, hipMemcpyHostToDevice, stream));
+        // AMaZE's tile planes
+        AmazeSlots &as = t_amaze_slots[c->dev->id];
+        const size_t a_stride = amaze_scratch_bytes(w, H) / sizeof(float);
+        if (as.w != w || as.H != H || as.slot_h.size() < NF) {
+            rc = as.ensure(a_stride * sizeof(float) * NF);
+            if (rc) return rc;
+            MLV_HIP(hipMemsetAsync(as.base, 0, a_stride * sizeof(float) * NF, stream));
+            as.w = w; as.H = H; as.stride = a_stride;
+            as.slot_h.assign(NF, 0);
         }
-        MLV_HIP(hipMemcpyAsync(B + o_sq, sq, (size_t)2 * h * 4, hipMemcpyHostToDevice, stream));
-        float *amaze_scratch = nullptr;
-        rc = amaze_scratch_for(c->dev->id, w, h, stream, &amaze_scratch);
-        if (rc) return rc;
+        for (int f = 0; f < nframes; f++) {
+            if (results[f] != 1) continue;
+            if (as.slot_h[f] != 0 && as.slot_h[f] != pp[f].h)
+                MLV_HIP(hipMemsetAsync((float *)as.base + (size_t)f * a_stride, 0, a_stride * sizeof(float), stream));
+            as.slot_h[f] = pp[f].h;
+        }
         P.cfa = (float *)(B + o_cfa); P.red = (float *)(B + o_red); P.green = (float *)(B + o_green); P.blue = (float *)(B + o_blue);
         P.gray_ev = (int *)(B + o_gray); P.dir = (uint8_t *)(B + o_dir);
-        P.sq_dst = (const int *)(B + o_sq); P.sq_row = P.sq_dst + h;
-        P.stats = (unsigned *)(B + o_stats); P.amaze_scratch = amaze_scratch;
-        printf("AMaZE interpolation ...\n");
-        rc = di_launch_amaze_interp(p, L, P, stream);
+        P.sq_dst = (const int *)(B + o_sq); P.sq_row = P.sq_dst + H;
+        P.stats = (unsigned *)(B + o_stats); P.amaze_scratch = (float *)as.base; P.amaze_scratch_stride = a_stride;
+        rc = di_launch_amaze_interp(bt, H, L, P, stream);
         if (rc) return rc;
-        unsigned *st = (unsigned *)(PH + ph_st);
-        MLV_HIP(hipMemcpyAsync(st, P.stats, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-        MLV_HIP(hipStreamSynchronize(stream));               // also keeps `sq` alive until the upload has happened
-        printf("Edge-directed interpolation...\n");
-        printf("Semi-overexposed: %.02f%%\n", st[0] * 100.0 / (st[0] + st[1]));
-        printf("Deep shadows    : %.02f%%\n", st[2] * 100.0 / (st[2] + st[3]));
     }
-    pt.mark("amaze + edge directions");
-    rc = di_launch_convert(p, L, P, amaze, img, stream);
+    rc = di_launch_convert(bt, H, L, P, amaze, d_frames, stream);
     if (rc) return rc;
-    if (pt.on) { (void)hipStreamSynchronize(stream); pt.mark("interp + mix + blend"); }
-    printf("Noise level     : %.02f (20-bit), ideally %.02f\n", 8.0, 8.0);
-    printf("Dynamic range   : %.02f EV (cooked)\n", log2(white - black) - log2(8.0));
-    return 1;
+    if (amaze) {
+        unsigned *st = (unsigned *)(PH + ph_st);
+        MLV_HIP(hipMemcpyAsync(st, B + o_stats, NF * 16, hipMemcpyDeviceToHost, stream));
+        MLV_HIP(hipStreamSynchronize(stream));               // (also keeps the pinned parameter blocks alive until their uploads have happened)
+        for (int f = 0; f < nframes; f++) {
+            if (results[f] != 1) continue;
+            const unsigned *s4 = st + 4 * f;
+            printf("AMaZE interpolation ...\nEdge-directed interpolation...\n");
+            printf("Semi-overexposed: %.02f%%\n", s4[0] * 100.0 / (s4[0] + s4[1]));
+            printf("Deep shadows    : %.02f%%\n", s4[2] * 100.0 / (s4[2] + s4[3]));
+        }
+    } else MLV_HIP(hipStreamSynchronize(stream));
+    pt.mark("match + interpolation + blend");
+    for (int f = 0; f < nframes; f++) {
+        if (results[f] != 1) continue;
+        printf("Noise level     : %.02f (20-bit), ideally %.02f\n", 8.0, 8.0);
+        printf("Dynamic range   : %.02f EV (cooked)\n", log2(pp[f].white20 - pp[f].black20) - log2(8.0));
+    }
+    return 0;
+}
+
+// one frame (the drop-in symbol, mlvfs_amd_cr2hdr20_dev): 1 converted, 0 not dual ISO / failed like the reference, < 0 library error
+int cr2hdr20_device(ThreadCtx *c, struct frame_headers *fh, void *d_frame, int w, int H, int black14, int white14,
+                    int interp_method, int use_fullres, int use_alias_map, int chroma_smooth_method, int bad_pixels_mode,
+                    hipStream_t stream, bool *frame_touched)
+{
+    int result = 0;
+    const DiOptions o{ interp_method, use_fullres, use_alias_map, chroma_smooth_method };
+    const int rc = cr2hdr20_batch(c, fh, d_frame, (size_t)w * H * 2, 1, w, H, black14, white14, o, bad_pixels_mode, stream, &result, frame_touched);
+    return rc < 0 ? rc : result;
 }
 
 }  // namespace mlv
@@ -670,6 +606,18 @@ int mlvfs_amd_cr2hdr20_dev(const mlvfs_amd_geom_t *geom, void *d_frame, int inte
     if (!c) return MLVFS_AMD_ERR_HIP;
     return cr2hdr20_device(c, nullptr, d_frame, geom->width, geom->height, geom->black, geom->white, interp_method, fullres,
                            use_alias_map, chroma_smooth, 0, pick_stream(stream, c), nullptr);
+}
+
+int mlvfs_amd_cr2hdr20_batch_dev(const mlvfs_amd_geom_t *geom, void *d_frames, size_t stride, int nframes, int interp_method,
+                                 int fullres, int use_alias_map, int chroma_smooth, int *results, void *stream)
+{
+    ThreadCtx *c = thread_ctx();
+    if (!c) return MLVFS_AMD_ERR_HIP;
+    if (!geom || !d_frames || !results || nframes < 0) { set_error("cr2hdr20_batch: null argument"); return MLVFS_AMD_ERR_ARG; }
+    if (nframes > 1 && stride < (size_t)geom->width * geom->height * 2) { set_error("cr2hdr20_batch: stride smaller than a frame"); return MLVFS_AMD_ERR_ARG; }
+    const DiOptions o{ interp_method, fullres, use_alias_map, chroma_smooth };
+    return cr2hdr20_batch(c, nullptr, d_frames, stride, nframes, geom->width, geom->height, geom->black, geom->white, o, 0,
+                          pick_stream(stream, c), results, nullptr);
 }
 
 int mlvfs_amd_amaze_demosaic_dev(const float *d_raw, int width, int height, float *d_red, float *d_green, float *d_blue, void *stream)

@@ -31,6 +31,35 @@ struct DiParams {
     double a, b20, corr_ev, max_ev, overlap;
 };
 
+// Batches (mlvfs_amd_cr2hdr20_batch_dev): every kernel of the conversion takes the frame index from its grid (blockIdx.y, or .z
+// for the kernels whose grid is two-dimensional) and its DiParams from a device array; the planes of frame f start f * stride
+// elements behind the batch's base pointers.  A single conversion is a batch of one whose parameters travel by value.
+struct DiBatch {
+    const DiParams *pp;        // device array [nframes], or null: use `p0`
+    DiParams p0;
+    size_t S;                  // plane stride between frames, in pixels (a multiple of 64)
+    size_t img_stride;         // bytes between the 16-bit input / output frames
+    int nframes;
+    int heights[2], nheights;  // the distinct row counts among the frames that are converted (H, and H - 1 for GBRG frames): AMaZE's
+                               // launch plan depends on the rows, one plan per height
+};
+// frames a batch leaves alone (not dual ISO, detection failed) carry h = 0 in their DiParams
+
+// what the device-side decisions of a batch hand to the host, per frame (k_di_decide_*), in ONE copy
+struct DiDecide {
+    double check_sum, check_n;             // hdr_check (hdr.c:407-439)
+    int rggb;                              // identify_rggb_or_gbrg (hdr.c:441-495)
+    int is_bright[4];                      // identify_bright_and_dark_fields (hdr.c:497-636); raw differences in bd_raw
+    int bd_raw[4];
+    int white_dark, white_bright;          // white_detect (hdr.c:250-300), 14-bit
+    long long n;                           // samples of match_exposures' histograms (hdr.c:700-722)
+    int bmed, b_lo, b_hi, dmed;
+    int hi_n;                              // highlight pairs (hdr.c:735-746)
+    int best;                              // index of the winning candidate slope, -1 none (hdr.c:752-772)
+    int best_score;
+    int check_ok;                          // hdr_check passed (or was passed before the drop-in path's pixel repairs)
+};
+
 struct DiLuts {                // device pointers; *_ev2raw are indexable from -10*32768
     const int *interp_raw2ev, *interp_ev2raw;      // the interpolator's cache: mean23's (hdr.c:1240) or AMaZE's (hdr.c:1080)
     const int *mix_raw2ev, *mix_ev2raw;
@@ -48,25 +77,49 @@ struct DiPlanes {
     int *gray_ev;              // raw2ev of the de-squeezed gray image, [h][w]
     uint8_t *dir;              // chosen edge direction, [h][w]
     const int *sq_dst, *sq_row;        // per image row: squeezed row it is written to (-1 none) / looked up at (0 if none)
-    unsigned *stats;           // semi-overexposed, not overexposed, deep shadow, not shadow
+    unsigned *stats;           // semi-overexposed, not overexposed, deep shadow, not shadow (4 per frame)
     float *amaze_scratch;
+    size_t amaze_scratch_stride;   // floats between the frames' scratch blocks
+    size_t cells_stride;           // ints between the frames' chroma-smoothing work planes
 };
 
 constexpr int AMAZE_TS = 160;                                              // tile side, amaze_demosaic_RT.c:136
 constexpr int AMAZE_TILE_FLOATS = 13 * AMAZE_TS * AMAZE_TS + 13 * AMAZE_TS * AMAZE_TS / 2;
-int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, float *d_scratch, hipStream_t s);
+// nframes planes of `plane_stride` floats each; h_of (device, per frame, stride in ints `h_stride`; null: every frame has `h` rows)
+// gives the rows of each frame, 0 = skip the frame
+int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, float *d_scratch, hipStream_t s,
+                 int nframes = 1, size_t plane_stride = 0, size_t scratch_stride = 0, const int *h_of = nullptr, int h_stride = 0);
 size_t amaze_scratch_bytes(int w, int h);
-int di_launch_amaze_interp(const DiParams &p, const DiLuts &L, const DiPlanes &P, hipStream_t s);
+int di_launch_amaze_interp(const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s);
 
 int di_launch_analyse(const void *d_img, int w, int H, int black, int white, const double *d_evf, unsigned *d_hist,
-                      double *d_check, hipStream_t s);
-int di_launch_subsample(const void *d_img, const DiParams &p, int nsx, int nsy, int *d_dark_s, int *d_bright_s,
-                        unsigned *d_hist_b, unsigned *d_hist_d, hipStream_t s);
-int di_launch_hi_count(const int *d_bs, int nsx, int nsy, int b_lo, int b_hi, int *d_counts, hipStream_t s);
-int di_launch_hi_compact(const int *d_ds, const int *d_bs, int nsx, int nsy, int b_lo, int b_hi, const int *d_take, const int *d_offset,
-                         int *d_hd, int *d_hb, hipStream_t s);
-int di_launch_score(const int *d_hd, const int *d_hb, int hi_n, const double *d_cand, int ncand, int *d_score, hipStream_t s);
-int di_launch_match(const void *d_img, const DiParams &p, const DiPlanes &P, hipStream_t s);
-int di_launch_convert(const DiParams &p, const DiLuts &L, const DiPlanes &P, bool interp_done, void *d_out, hipStream_t s);
+                      double *d_check, hipStream_t s, int nframes = 1, size_t img_stride = 0, size_t hist_stride = 0, size_t check_stride = 0);
+int di_launch_subsample(const void *d_img, const DiBatch &b, int nsx, int nsy_max, size_t ns_stride, int *d_dark_s, int *d_bright_s,
+                        unsigned *d_hist_bd, hipStream_t s);
+int di_launch_hi_count(const int *d_bs, int nsx, int nsy_max, size_t ns_stride, int b_lo, int b_hi, const DiDecide *dd, const DiBatch &b,
+                       int *d_rows, hipStream_t s);
+int di_launch_hi_compact(const int *d_ds, const int *d_bs, int nsx, int nsy_max, size_t ns_stride, int b_lo, int b_hi, const DiDecide *dd,
+                         const DiBatch &b, const int *d_rows, int *d_hi, size_t hi_stride, hipStream_t s);
+int di_launch_score(const int *d_hi, size_t hi_stride, int hi_n, const double *d_ta, int ncand, int dmed, int bmed, const DiDecide *dd,
+                    int nframes, int *d_score, int score_stride, hipStream_t s);
+int di_launch_match(const void *d_img, const DiBatch &b, int h_launch, const DiPlanes &P, hipStream_t s);
+int di_launch_convert(const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, bool interp_done, void *d_out, hipStream_t s);
+// device-side decisions of a batch (k_dualiso.hip: k_di_decide_*)
+struct DiDecideBuffers {
+    const unsigned *hist; size_t hist_stride;          // k_di_analyse's block per frame
+    const double *check; size_t check_stride;
+    unsigned *derived; size_t derived_stride;          // work: Bayer / green histograms with their row ranges applied, prefix sums
+    const unsigned *hist_bd;                           // match_exposures' histograms, hist_b | hist_d per frame
+    int *rows; int nsy_max;                            // counts | take | offset per frame
+    const int *score; int score_stride; int ncand;
+    int check_passed;                                  // the caller has evaluated hdr_check already (drop-in path: before its pixel repairs)
+    DiDecide *dd;                                      // [nframes]
+    DiParams *pp;                                      // [nframes]: the geometry part is written by the pattern step
+};
+size_t di_derived_words();
+int di_launch_decide_pattern(const void *d_frames, const DiBatch &b, int H, int black14, const DiDecideBuffers &D, hipStream_t s);
+int di_launch_decide_quantiles(const DiBatch &b, const DiDecideBuffers &D, hipStream_t s);
+int di_launch_decide_rows(const DiBatch &b, const DiDecideBuffers &D, hipStream_t s);
+int di_launch_decide_fit(const DiBatch &b, const DiDecideBuffers &D, hipStream_t s);
 
 }  // namespace mlv

@@ -111,11 +111,18 @@ __device__ unsigned long long g_amaze_stamps[16];
 #endif
 __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, int w, int h, float *__restrict__ red,
                                                  float *__restrict__ green_out, float *__restrict__ blue, float *__restrict__ scratch,
-                                                 int tiles_x, int row0, int wgs_per_row, int chain_len, int rows_per_wg, int copy_from)
+                                                 int tiles_x, int row0, int wgs_per_row, int chain_len, int rows_per_wg, int copy_from,
+                                                 size_t plane_stride, size_t scratch_stride, const int *__restrict__ h_of, int h_stride)
 {
     __shared__ unsigned char s_nyq[HALF];
     __shared__ float s_w[HALF];
     const int tid = threadIdx.x, nt = blockDim.x;
+    {   // frame of a batch (blockIdx.y): its planes, its scratch blocks; only the frames of THIS launch plan's height take part
+        const size_t f = blockIdx.y;
+        if (h_of && h_of[f * (size_t)h_stride] != h) return;
+        raw += f * plane_stride; red += f * plane_stride; green_out += f * plane_stride; blue += f * plane_stride;
+        scratch += f * scratch_stride;
+    }
     const int ty0 = row0 + (int)(blockIdx.x / wgs_per_row), tx0 = (int)(blockIdx.x % wgs_per_row);
     float *const block = scratch + (size_t)(ty0 * tiles_x + tx0) * AMAZE_TILE_FLOATS;
     if (copy_from >= 0) {
@@ -628,14 +635,15 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
     }   // tiles of this workgroup
 }
 
-int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, float *d_scratch, hipStream_t s)
+int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, float *d_scratch, hipStream_t s,
+                 int nframes, size_t plane_stride, size_t scratch_stride, const int *h_of, int h_stride)
 {
     const int step = AMAZE_TS - 32;
     const int tiles_x = (w + 16 + step - 1) / step, tiles_y = (h + 16 + step - 1) / step;
     const int cc1_last = w + 16 - (-16 + (tiles_x - 1) * step), rr1_last = h + 16 - (-16 + (tiles_y - 1) * step);
     auto launch = [&](int row0, int nrows, int wgs_per_row, int chain_len, int rows_per_wg, int copy_from) {
-        hipLaunchKernelGGL(k_amaze, dim3(nrows * wgs_per_row), dim3(1024), 0, s, d_raw, w, h, d_red, d_green, d_blue, d_scratch, tiles_x,
-                           row0, wgs_per_row, chain_len, rows_per_wg, copy_from);
+        hipLaunchKernelGGL(k_amaze, dim3(nrows * wgs_per_row, nframes), dim3(1024), 0, s, d_raw, w, h, d_red, d_green, d_blue, d_scratch, tiles_x,
+                           row0, wgs_per_row, chain_len, rows_per_wg, copy_from, plane_stride, scratch_stride, h_of, h_stride);
     };
     // incomplete tiles at the right end of a row, chained behind the last complete one
     const int incomplete_x = cc1_last >= AMAZE_TS ? 0 : (cc1_last < 32 ? 2 : 1);

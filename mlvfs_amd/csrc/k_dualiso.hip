@@ -33,6 +33,21 @@ namespace mlv {
 
 __device__ __forceinline__ int di_bright(const DiParams &p, int y) { return (p.is_bright_bits >> (y & 3)) & 1; }
 
+// The frame of a batch this workgroup works on -- blockIdx.y, or blockIdx.z for the kernels whose grid is two-dimensional -- and
+// its parameters (dualiso.h: DiBatch); false: the batch leaves this frame alone.
+template <int DIM>
+__device__ __forceinline__ bool di_frame(const DiBatch &b, int &f, DiParams &p)
+{
+    f = DIM == 1 ? (int)blockIdx.y : (int)blockIdx.z;
+    p = b.pp ? b.pp[f] : b.p0;
+    return p.h > 0;
+}
+// the 16-bit frame f of a batch as the conversion sees it: one row further down for GBRG (hdr.c:1790-1795)
+__device__ __forceinline__ const uint16_t *di_img(const uint16_t *base, const DiBatch &b, int f, const DiParams &p)
+{
+    return (const uint16_t *)((const uint8_t *)base + (size_t)f * b.img_stride) + (size_t)p.ay1 * p.w;
+}
+
 // ------------------------------------------------------------------ analysis
 // One workgroup = the rows of one phase (y % 4) of a 16-row band.  The 14-bit values of its pixels are counted per
 // column parity in LDS (two 16-bit counters per word: a band holds at most 4 * w / 2 < 65536 pixels per class), then
@@ -42,11 +57,15 @@ __device__ __forceinline__ int di_bright(const DiParams &p, int y) { return (p.i
 constexpr int DI_BAND = 16;
 __global__ __launch_bounds__(256) void k_di_analyse(const uint16_t *__restrict__ img, int w, int H, int black, int white,
                                                     const double *__restrict__ evf /* [16384] log2(i)*32768 */,
-                                                    unsigned *__restrict__ hist /* device layout, dualiso.h */, double *__restrict__ check /* sum, count */)
+                                                    unsigned *__restrict__ hist /* device layout, dualiso.h */, double *__restrict__ check /* sum, count */,
+                                                    size_t img_stride /* bytes */, size_t hist_stride /* words */, size_t check_stride /* doubles */)
 {
     __shared__ unsigned cnt[16384];                          // slot = (x & 1) * 16384 + value; two slots per word
     for (int i = threadIdx.x; i < 16384; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
+    img = (const uint16_t *)((const uint8_t *)img + (size_t)blockIdx.z * img_stride);        // frame of the batch
+    hist += (size_t)blockIdx.z * hist_stride;
+    check += (size_t)blockIdx.z * check_stride;
     const int q = blockIdx.y, y_base = blockIdx.x * DI_BAND + q;
     unsigned *h_w0 = hist + DI_D_WHITE0, *h_w1 = hist + DI_D_WHITE1;
     double sum = 0, n = 0;
@@ -87,12 +106,21 @@ __global__ __launch_bounds__(256) void k_di_analyse(const uint16_t *__restrict__
 // ------------------------------------------------------------------ exposure matching
 __device__ __forceinline__ int di_p16(const uint16_t *img, size_t i) { return (int)(((unsigned)img[i] << 2) & 0xFFFFu); }   // 14->20->16 bit
 
-__global__ __launch_bounds__(256) void k_di_subsample(const uint16_t *__restrict__ img, DiParams p, int nsx, int nsy,
-                                                      int *__restrict__ dark_s, int *__restrict__ bright_s,
-                                                      unsigned *__restrict__ hist_b, unsigned *__restrict__ hist_d)
+// samples of frame f: rows y = ay1 + 2 + 3 sy while y < h - 2 (hdr.c:664)
+__device__ __forceinline__ int di_nsy(const DiParams &p) { const int y0 = p.ay1 + 2; return (p.h - 2 > y0) ? (p.h - 2 - y0 + 2) / 3 : 0; }
+
+// Layout of the sample arrays of a batch: frame f at f * ns_stride (dark_s, bright_s), its two histograms back to back at
+// f * 2 * DI_HIST_N (hist_b | hist_d).  grid = (blocks over nsx * nsy_max, frames)
+__global__ __launch_bounds__(256) void k_di_subsample(const uint16_t *__restrict__ img_base, DiBatch bt, int nsx, size_t ns_stride,
+                                                      int *__restrict__ dark_s, int *__restrict__ bright_s, unsigned *__restrict__ hist_bd)
 {
+    int f; DiParams p;
+    if (!di_frame<1>(bt, f, p)) return;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nsx * nsy) return;
+    if (idx >= nsx * di_nsy(p)) return;
+    const uint16_t *img = di_img(img_base, bt, f, p);
+    dark_s += (size_t)f * ns_stride; bright_s += (size_t)f * ns_stride;
+    unsigned *hist_b = hist_bd + (size_t)f * 2 * DI_HIST_N, *hist_d = hist_b + DI_HIST_N;
     const int sx = idx % nsx, sy = idx / nsx;
     const int x = 3 * sx, y = p.ay1 + 2 + 3 * sy, w = p.w;
     const int black = p.black20 / 16, white = p.match_white20 / 16;
@@ -113,31 +141,43 @@ __global__ __launch_bounds__(256) void k_di_subsample(const uint16_t *__restrict
 }
 
 // highlight pairs of match_exposures (hdr.c:735-746): the samples with b_lo < bright < b_hi in raster order.  One workgroup
-// per sample row counts them; the host turns the counts into how many each row contributes and where (the reference's
-// cap only leaves the inner loop, dualiso.cpp); the second kernel writes them in order.
+// per sample row counts them; the counts are turned into how many each row contributes and where (the reference's cap only leaves
+// the inner loop: dualiso.cpp for one frame, k_di_decide_rows for a batch); the second kernel writes them in order.
+// grid = (nsy_max, frames); dd != null: the frame's limits come from its decisions on the device
 __device__ __forceinline__ bool di_hi_ok(int b, int b_lo, int b_hi) { return !(b >= b_hi || b <= b_lo); }
 
-__global__ __launch_bounds__(256) void k_di_hi_count(const int *__restrict__ bs, int nsx, int b_lo, int b_hi, int *__restrict__ counts)
+__global__ __launch_bounds__(256) void k_di_hi_count(const int *__restrict__ bs, int nsx, size_t ns_stride, int b_lo, int b_hi,
+                                                     const DiDecide *__restrict__ dd, DiBatch bt, int *__restrict__ counts, int rows_stride)
 {
     __shared__ int red[4];
-    const int *row = bs + (size_t)blockIdx.x * nsx;
+    int f; DiParams p;
+    const bool live = di_frame<1>(bt, f, p);
+    if (dd) { b_lo = dd[f].b_lo; b_hi = dd[f].b_hi; }
+    const int *row = bs + (size_t)f * ns_stride + (size_t)blockIdx.x * nsx;
     int n = 0;
-    for (int x = threadIdx.x; x < nsx; x += blockDim.x) n += di_hi_ok(row[x], b_lo, b_hi);
+    if (live && (int)blockIdx.x < di_nsy(p))
+        for (int x = threadIdx.x; x < nsx; x += blockDim.x) n += di_hi_ok(row[x], b_lo, b_hi);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n;
     __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) counts[(size_t)f * rows_stride + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void k_di_hi_compact(const int *__restrict__ ds, const int *__restrict__ bs, int nsx, int b_lo, int b_hi,
-                                                       const int *__restrict__ take, const int *__restrict__ offset,
-                                                       int *__restrict__ hd, int *__restrict__ hb)
+// rows: [counts | take | offset] of nsy_max ints each per frame (rows_stride = 3 nsy_max); hi: hd | hb of hi_stride ints each per frame
+__global__ __launch_bounds__(256) void k_di_hi_compact(const int *__restrict__ ds, const int *__restrict__ bs, int nsx, size_t ns_stride,
+                                                       int b_lo, int b_hi, const DiDecide *__restrict__ dd, DiBatch bt,
+                                                       const int *__restrict__ rows, int nsy_max, int *__restrict__ hd_base, size_t hi_stride)
 {
     __shared__ int part[256];
+    int f; DiParams p;
+    if (!di_frame<1>(bt, f, p) || (int)blockIdx.x >= di_nsy(p)) return;
+    if (dd) { b_lo = dd[f].b_lo; b_hi = dd[f].b_hi; }
+    const int *take = rows + (size_t)f * 3 * nsy_max + nsy_max, *offset = take + nsy_max;
+    int *hd = hd_base + (size_t)f * 2 * hi_stride, *hb = hd + hi_stride;
     const int lim = take[blockIdx.x];
     if (lim <= 0) return;
-    const size_t base = (size_t)blockIdx.x * nsx;
+    const size_t base = (size_t)f * ns_stride + (size_t)blockIdx.x * nsx;
     const int per = (nsx + 255) / 256, x0 = threadIdx.x * per, x1 = min(x0 + per, nsx);     // consecutive samples per thread: keeps the order
     int n = 0;
     for (int x = x0; x < x1; x++) n += di_hi_ok(bs[base + x], b_lo, b_hi);
@@ -160,11 +200,16 @@ __global__ __launch_bounds__(256) void k_di_hi_compact(const int *__restrict__ d
     }
 }
 
-__global__ __launch_bounds__(256) void k_di_score(const int *__restrict__ hd, const int *__restrict__ hb, int hi_n,
-                                                  const double *__restrict__ cand /* [2*ncand]: a, b */, int *__restrict__ score)
+// score of every candidate slope test_a = ta[k] (hdr.c:752-772); its offset test_b = dmed - bmed * test_a in double, uncontracted,
+// like the reference's.  grid = (ncand, frames)
+__global__ __launch_bounds__(256) void k_di_score(const int *__restrict__ hd_base, size_t hi_stride, int hi_n, const double *__restrict__ ta_tab,
+                                                  int dmed, int bmed, const DiDecide *__restrict__ dd, int *__restrict__ score, int score_stride)
 {
     __shared__ int red[4];
-    const double ta = cand[2 * blockIdx.x], tb = cand[2 * blockIdx.x + 1];
+    const int f = blockIdx.y;
+    if (dd) { hi_n = dd[f].hi_n; dmed = dd[f].dmed; bmed = dd[f].bmed; }
+    const int *hd = hd_base + (size_t)f * 2 * hi_stride, *hb = hd + hi_stride;
+    const double ta = ta_tab[blockIdx.x], tb = dmed - bmed * ta;
     int s = 0;
     for (int i = threadIdx.x; i < hi_n; i += blockDim.x) {
         const int e = (int)(hd[i] - (hb[i] * ta + tb));
@@ -174,11 +219,15 @@ __global__ __launch_bounds__(256) void k_di_score(const int *__restrict__ hd, co
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) score[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) score[(size_t)f * score_stride + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void k_di_match(const uint16_t *__restrict__ img, uint32_t *__restrict__ raw, DiParams p)
+__global__ __launch_bounds__(256) void k_di_match(const uint16_t *__restrict__ img_base, uint32_t *__restrict__ raw, DiBatch bt)
 {
+    int f; DiParams p;
+    if (!di_frame<1>(bt, f, p)) return;
+    const uint16_t *img = di_img(img_base, bt, f, p);
+    raw += (size_t)f * bt.S;
     const size_t n = (size_t)p.w * p.h;
     const double a = p.a, b20 = p.b20;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -247,14 +296,23 @@ struct DiAmazeIn {              // inputs of the edge-directed interpolation (nu
     const float *red, *green, *blue;
     const uint8_t *dir;
     const int *sq_row;
+    size_t sq_stride;           // ints between the frames' squeezed-row maps
 };
 
 template <bool AMAZE>
-__global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ raw, DiParams p, DiLuts L, DiAmazeIn A,
+__global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ raw, DiBatch bt, DiLuts L, DiAmazeIn A,
                                                    uint32_t *__restrict__ dark, uint32_t *__restrict__ bright,
                                                    uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
                                                    uint16_t *__restrict__ over, uint16_t *__restrict__ amap)
 {
+    int f; DiParams p;
+    if (!di_frame<1>(bt, f, p)) return;
+    {
+        const size_t o = (size_t)f * bt.S;
+        raw += o; dark += o; bright += o; fullres += o; halfres += o; over += o;
+        if (amap) amap += o;
+        if (AMAZE) { A.red += o; A.green += o; A.blue += o; A.dir += o; A.sq_row += (size_t)f * A.sq_stride; }
+    }
     const int w = p.w, h = p.h;
     const size_t n = (size_t)w * h;
     const int *ir2e = L.interp_raw2ev, *ie2r = L.interp_ev2raw;
@@ -310,9 +368,12 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
 
 // ------------------------------------------------------------------ AMaZE-based interpolation, hdr.c:954-1229
 // squeeze: rows of one exposure become adjacent, greens halved around black (hdr.c:977-1026)
-__global__ __launch_bounds__(256) void k_di_squeeze(const uint32_t *__restrict__ raw, DiParams p, const int *__restrict__ sq_dst,
-                                                    float *__restrict__ cfa)
+__global__ __launch_bounds__(256) void k_di_squeeze(const uint32_t *__restrict__ raw, DiBatch bt, const int *__restrict__ sq_dst,
+                                                    size_t sq_stride, float *__restrict__ cfa)
 {
+    int f; DiParams p;
+    if (!di_frame<1>(bt, f, p)) return;
+    raw += (size_t)f * bt.S; cfa += (size_t)f * bt.S; sq_dst += (size_t)f * sq_stride;
     const size_t n = (size_t)p.w * p.h;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % p.w), y = (int)(i / p.w);
@@ -326,8 +387,13 @@ __global__ __launch_bounds__(256) void k_di_squeeze(const uint32_t *__restrict__
 
 // undo the green scaling, clamp (hdr.c:1041-1050), in place on the squeezed planes
 __global__ __launch_bounds__(256) void k_di_amaze_clamp(float *__restrict__ red, float *__restrict__ green, float *__restrict__ blue,
-                                                        size_t n, int black)
+                                                        DiBatch bt)
 {
+    int f; DiParams p;
+    if (!di_frame<1>(bt, f, p)) return;
+    red += (size_t)f * bt.S; green += (size_t)f * bt.S; blue += (size_t)f * bt.S;
+    const size_t n = (size_t)p.w * p.h;
+    const int black = p.black20;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float fb = (float)black, hi = 1048575.0f;
         const float g = (green[i] - fb) * 2.0f + fb, r = red[i], b = blue[i];
@@ -339,9 +405,13 @@ __global__ __launch_bounds__(256) void k_di_amaze_clamp(float *__restrict__ red,
 
 // de-squeezed gray image in EV (hdr.c:1055-1059 + the raw2ev lookups of :1157-1168)
 __global__ __launch_bounds__(256) void k_di_gray(const float *__restrict__ red, const float *__restrict__ green,
-                                                 const float *__restrict__ blue, DiParams p, const int *__restrict__ sq_row,
+                                                 const float *__restrict__ blue, DiBatch bt, const int *__restrict__ sq_row, size_t sq_stride,
                                                  const int *__restrict__ r2e, int *__restrict__ gray_ev)
 {
+    int f; DiParams p;
+    if (!di_frame<1>(bt, f, p)) return;
+    red += (size_t)f * bt.S; green += (size_t)f * bt.S; blue += (size_t)f * bt.S; gray_ev += (size_t)f * bt.S;
+    sq_row += (size_t)f * sq_stride;
     const size_t n = (size_t)p.w * p.h;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % p.w), y = (int)(i / p.w);
@@ -352,11 +422,14 @@ __global__ __launch_bounds__(256) void k_di_gray(const float *__restrict__ red, 
 }
 
 // best of 11 edge directions where the interpolation has to be good (hdr.c:1096-1173)
-__global__ __launch_bounds__(256) void k_di_edge_dir(const uint32_t *__restrict__ raw, const int *__restrict__ gray_ev, DiParams p,
+__global__ __launch_bounds__(256) void k_di_edge_dir(const uint32_t *__restrict__ raw, const int *__restrict__ gray_ev, DiBatch bt,
                                                      const double *__restrict__ fullres_curve, uint8_t *__restrict__ dir,
                                                      unsigned *__restrict__ stats)
 {
     __shared__ unsigned s_stats[4];
+    int f; DiParams p;
+    if (!di_frame<1>(bt, f, p)) return;
+    raw += (size_t)f * bt.S; gray_ev += (size_t)f * bt.S; dir += (size_t)f * bt.S; stats += (size_t)f * 4;
     if (threadIdx.x < 4) s_stats[threadIdx.x] = 0;
     __syncthreads();
     const int w = p.w, h = p.h;
@@ -395,9 +468,12 @@ __global__ __launch_bounds__(256) void k_di_edge_dir(const uint32_t *__restrict_
 
 // alias error from the chroma-smoothed planes (hdr.c:1620: build_alias_map gets fullres_smooth / halfres_smooth)
 __global__ __launch_bounds__(256) void k_di_alias_err(const uint32_t *__restrict__ bright, const uint32_t *__restrict__ fullres_s,
-                                                      const uint32_t *__restrict__ halfres_s, DiParams p, DiLuts L,
+                                                      const uint32_t *__restrict__ halfres_s, DiBatch bt, DiLuts L,
                                                       uint16_t *__restrict__ amap)
 {
+    int f; DiParams p;
+    if (!di_frame<1>(bt, f, p)) return;
+    bright += (size_t)f * bt.S; fullres_s += (size_t)f * bt.S; halfres_s += (size_t)f * bt.S; amap += (size_t)f * bt.S;
     const size_t n = (size_t)p.w * p.h;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         amap[i] = (uint16_t)di_alias_err(p, L, (int)bright[i], (int)fullres_s[i], (int)halfres_s[i]);
@@ -407,11 +483,15 @@ __global__ __launch_bounds__(256) void k_di_alias_err(const uint32_t *__restrict
 // hdr.c:1488-1522 = chroma_smooth.c:22-71 for uint32_t pixels, black 0 and the 20-bit tables of mix_images.
 // Pass 1 turns every Bayer cell into (green EV, R - green, B - green); pass 2 takes the medians over the cell
 // neighbourhood and rewrites R and B of the cells the reference visits.  The planes stay L2-resident in between.
-__global__ __launch_bounds__(256) void k_di_cs_cells(const uint32_t *__restrict__ plane, int w, int cw, int ch,
+__global__ __launch_bounds__(256) void k_di_cs_cells(const uint32_t *__restrict__ plane, DiBatch bt, size_t cells_stride,
                                                      const int *__restrict__ r2e, int *__restrict__ cells /* [3][ch][cw] */)
 {
+    int f; DiParams p;
+    if (!di_frame<2>(bt, f, p)) return;
+    const int w = p.w, cw = p.w / 2, ch = p.h / 2;
+    plane += (size_t)f * bt.S; cells += (size_t)f * cells_stride;
     const int cx = blockIdx.x * blockDim.x + threadIdx.x, cy = blockIdx.y;
-    if (cx >= cw) return;
+    if (cx >= cw || cy >= ch) return;
     const uint32_t *c = plane + 2 * cx + (size_t)(2 * cy) * w;
     const int ge = (r2e[c[1]] + r2e[c[w]]) / 2;
     const size_t o = cx + (size_t)cy * cw, pl = (size_t)cw * ch;
@@ -421,9 +501,13 @@ __global__ __launch_bounds__(256) void k_di_cs_cells(const uint32_t *__restrict_
 }
 
 template <int METHOD>
-__global__ __launch_bounds__(256) void k_di_cs_apply(const int *__restrict__ cells, int w, int h, int cw, int ch,
+__global__ __launch_bounds__(256) void k_di_cs_apply(const int *__restrict__ cells, DiBatch bt, size_t cells_stride,
                                                      const int *__restrict__ e2r, uint32_t *__restrict__ out)
 {
+    int f; DiParams p;
+    if (!di_frame<2>(bt, f, p)) return;
+    const int w = p.w, h = p.h, cw = p.w / 2, ch = p.h / 2;
+    out += (size_t)f * bt.S; cells += (size_t)f * cells_stride;
     const int cx = blockIdx.x * blockDim.x + threadIdx.x, cy = blockIdx.y;
     const int x = 2 * cx, y = 2 * cy;
     if (x < 4 || x >= w - 4 || y < 4 || y >= h - 5) return;
@@ -454,11 +538,15 @@ __global__ __launch_bounds__(256) void k_di_cs_apply(const int *__restrict__ cel
 
 // 6th largest of the 37 neighbours (kth_smallest(negated, 37, 5)), hdr.c:1423-1443
 __global__ __launch_bounds__(256) void k_di_alias_rank(const uint16_t *__restrict__ amap, const uint32_t *__restrict__ bright,
-                                                       const double *__restrict__ fullres_curve, int w, int h,
+                                                       const double *__restrict__ fullres_curve, DiBatch bt,
                                                        uint16_t *__restrict__ aux)
 {
+    int f; DiParams p;
+    if (!di_frame<2>(bt, f, p)) return;
+    const int w = p.w, h = p.h;
+    amap += (size_t)f * bt.S; bright += (size_t)f * bt.S; aux += (size_t)f * bt.S;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
+    if (x >= w || y >= h) return;
     const size_t i = x + (size_t)y * w;
     int out = amap[i];
     if (x >= 6 && x < w - 6 && y >= 6 && y < h - 6 && !(fullres_curve[bright[i]] > 0.8)) {
@@ -489,10 +577,14 @@ __global__ __launch_bounds__(256) void k_di_alias_rank(const uint16_t *__restric
 // integer gaussian, hdr.c:1446-1466 (terms exactly as written there, duplicates included)
 __global__ __launch_bounds__(256) void k_di_alias_blur(const uint16_t *__restrict__ aux, const uint16_t *__restrict__ amap_in,
                                                        const uint32_t *__restrict__ bright, const double *__restrict__ fullres_curve,
-                                                       int w, int h, uint16_t *__restrict__ out)
+                                                       DiBatch bt, uint16_t *__restrict__ out)
 {
+    int f; DiParams p;
+    if (!di_frame<2>(bt, f, p)) return;
+    const int w = p.w, h = p.h;
+    aux += (size_t)f * bt.S; amap_in += (size_t)f * bt.S; bright += (size_t)f * bt.S; out += (size_t)f * bt.S;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
+    if (x >= w || y >= h) return;
     const size_t i = x + (size_t)y * w;
     int v = amap_in[i];
     if (x >= 6 && x < w - 6 && y >= 6 && y < h - 6 && !(fullres_curve[bright[i]] > 0.8)) {
@@ -512,9 +604,17 @@ __global__ __launch_bounds__(256) void k_di_alias_blur(const uint16_t *__restric
 __global__ __launch_bounds__(256) void k_di_blend(const uint32_t *__restrict__ dark, const uint32_t *__restrict__ bright,
                                                   const uint32_t *__restrict__ fullres, const uint32_t *__restrict__ fullres_s,
                                                   const uint32_t *__restrict__ halfres_s, const uint16_t *__restrict__ over,
-                                                  const uint16_t *__restrict__ amap, DiParams p, DiLuts L,
-                                                  uint16_t *__restrict__ img_out)
+                                                  const uint16_t *__restrict__ amap, DiBatch bt, DiLuts L,
+                                                  uint16_t *__restrict__ img_base)
 {
+    int f; DiParams p;
+    if (!di_frame<1>(bt, f, p)) return;
+    {
+        const size_t o = (size_t)f * bt.S;
+        dark += o; bright += o; fullres += o; fullres_s += o; halfres_s += o; over += o;
+        if (amap) amap += o;
+    }
+    uint16_t *img_out = const_cast<uint16_t *>(di_img(img_base, bt, f, p));
     const int w = p.w, h = p.h;
     const size_t n = (size_t)w * h;
     const int *r2e = L.blend_raw2ev, *e2r = L.blend_ev2raw;
@@ -561,137 +661,517 @@ __global__ __launch_bounds__(256) void k_di_blend(const uint32_t *__restrict__ d
     }
 }
 
+// ------------------------------------------------------------------ decisions of a batch, on the device
+// The scalar decisions that dualiso.cpp makes on the host between the kernels of ONE conversion -- pattern, bright / dark fields,
+// white levels (hdr.c:441-636, 250-300), the order statistics, the highlight rows' shares and the winning slope of match_exposures
+// (hdr.c:638-772) -- for every frame of a batch at once, one workgroup per frame, so that a batch needs ONE round trip to the
+// host (for the libm scalars log2 / pow and the reference's progress lines) instead of five per frame.  All of it is integer work
+// on histograms; each step restates the host code it replaces (named in its comment), and tests/test_gpu_dualiso.py requires
+// the two to agree value by value.
+namespace {
+
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *sh)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ long long block_min_i64(long long v, long long *sh)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const long long u = __shfl_xor(v, o); v = u < v ? u : v; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const long long a = sh[0] < sh[1] ? sh[0] : sh[1], b = sh[2] < sh[3] ? sh[2] : sh[3];
+    return a < b ? a : b;
+}
+// exclusive prefix of one value per thread (256 threads), total in *total
+__device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long v, unsigned long long *sh, unsigned long long *total)
+{
+    __syncthreads();
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const unsigned long long t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (total) *total = sh[255];
+    const unsigned long long r = sh[threadIdx.x] - v;
+    __syncthreads();
+    return r;
+}
+// in place: hist[0..n) -> C[r] = sum of hist[v], v < r, for r = 0..n (n + 1 words, the array has room); 256 threads, n % 256 == 0
+__device__ void block_prefix_in_place(unsigned *hist, int n, unsigned long long *sh)
+{
+    const int per = n / 256, i0 = threadIdx.x * per;
+    unsigned long long s = 0;
+    for (int i = 0; i < per; i++) s += hist[i0 + i];
+    unsigned long long tot;
+    unsigned long long run = block_excl_scan(s, sh, &tot);
+    for (int i = 0; i < per; i++) { const unsigned v = hist[i0 + i]; hist[i0 + i] = (unsigned)run; run += v; }
+    if (threadIdx.x == 255) hist[n] = (unsigned)run;
+    __syncthreads();
+}
+// smallest r in [0, n] with C[r] >= ref, n if none (C non-decreasing, n + 1 entries)
+__device__ __forceinline__ int quantile_of(const unsigned *C, int n, long long ref)
+{
+    if (ref <= 0) return 0;
+    if ((long long)C[n] < ref) return n;
+    int lo = 0, hi = n;                                   // C[lo] < ref <= C[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((long long)C[mid] >= ref) hi = mid; else lo = mid; }
+    return hi;
+}
+// first index i (ascending) with sum of hist[0..i] > k, bins - 1 if none: kth_from_hist of dualiso.cpp; 256 threads, bins % 256 == 0
+__device__ int block_kth_from_hist(const unsigned *hist, int bins, long long k, unsigned long long *sh, int *sh_i)
+{
+    const int per = bins / 256, i0 = threadIdx.x * per;
+    unsigned long long s = 0;
+    for (int i = 0; i < per; i++) s += hist[i0 + i];
+    unsigned long long tot;
+    unsigned long long run = block_excl_scan(s, sh, &tot);
+    if (threadIdx.x == 0) *sh_i = bins - 1;
+    __syncthreads();
+    if ((long long)run <= k && (long long)(run + s) > k) {          // the crossing lies in this thread's chunk
+        for (int i = 0; i < per; i++) { run += hist[i0 + i]; if ((long long)run > k) { *sh_i = i0 + i; break; } }
+    }
+    __syncthreads();
+    const int r = *sh_i;
+    __syncthreads();
+    return r;
+}
+
+}  // namespace
+
+// derived (per frame, words): hb [4][16384] | g [4][16385] (greens by row phase of the frame's pattern, then their prefix sums) |
+// wh [2][32768] (white histograms by exposure, overwritten samples taken out)
+constexpr size_t DI_DERIVED_WORDS = 4 * 16384 + 4 * 16385 + 3 + 2 * 32768;
+
+// analyse()'s host half, the pattern, the bright / dark fields and the white levels of dualiso.cpp (is_rggb_from_hist,
+// bright_dark_from_hist, whites_from_hist) for frame blockIdx.x; writes dd[f] and the geometry part of pp[f]
+__global__ __launch_bounds__(256) void k_di_decide_pattern(const uint16_t *__restrict__ frames, size_t img_stride, int w, int H, int black14,
+                                                           DiDecideBuffers D)
+{
+    __shared__ unsigned long long sh[256];
+    __shared__ long long shl[4];
+    __shared__ int sh_i, s_rggb, s_bright[4], s_rows[512][2], s_nrows;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const uint16_t *frame = (const uint16_t *)((const uint8_t *)frames + (size_t)f * img_stride);
+    const unsigned *dev = D.hist + (size_t)f * D.hist_stride;
+    unsigned *hb = D.derived + (size_t)f * D.derived_stride, *g = hb + 4 * 16384, *wh = g + 4 * 16385 + 3;
+    DiDecide &dd = D.dd[f];
+    if (tid == 0) {
+        dd.check_sum = D.check[(size_t)f * D.check_stride];
+        dd.check_n = D.check[(size_t)f * D.check_stride + 1];
+        dd.n = 0; dd.bmed = dd.b_lo = dd.b_hi = dd.dmed = 0; dd.hi_n = 0; dd.best = -1; dd.best_score = 0;
+        dd.check_ok = D.check_passed || (dd.check_n > 0 && dd.check_sum / dd.check_n > 0.5);      // hdr.c:432-438
+    }
+    // ---- the four Bayer-phase histograms over rows [0, H / 4 * 4) (hdr.c:453): all rows' classes minus the rows below that range
+    for (int i = tid; i < 4 * 16384; i += 256) {
+        const int k = i >> 14, v = i & 16383, qb = k >> 1, px = k & 1;
+        hb[i] = dev[DI_D_CLASS + (size_t)(qb * 2 + px) * 16384 + v] + dev[DI_D_CLASS + (size_t)((qb + 2) * 2 + px) * 16384 + v];
+    }
+    __syncthreads();
+    const int R0 = H / 4 * 4, R1 = (H - 1) / 4 * 4;
+    for (int y = R0; y < H; y++)
+        for (int x = tid; x < w; x += 256) atomicSub(&hb[(size_t)((y & 1) * 2 + (x & 1)) * 16384 + (frame[(size_t)y * w + x] & 16383)], 1u);
+    __syncthreads();
+    {   // is_rggb_from_hist: sum over v of |acc1 - acc2| against |acc0 - acc3| (integers far below 2^53: the doubles of the host are exact)
+        const int per = 16384 / 256, i0 = tid * per;
+        unsigned long long run[4];
+        for (int k = 0; k < 4; k++) {
+            unsigned long long s = 0;
+            for (int i = 0; i < per; i++) s += hb[(size_t)k * 16384 + i0 + i];
+            run[k] = block_excl_scan(s, sh, nullptr);
+        }
+        unsigned long long d_rggb = 0, d_gbrg = 0;
+        for (int i = 0; i < per; i++) {
+            for (int k = 0; k < 4; k++) run[k] += hb[(size_t)k * 16384 + i0 + i];
+            d_rggb += run[1] > run[2] ? run[1] - run[2] : run[2] - run[1];
+            d_gbrg += run[0] > run[3] ? run[0] - run[3] : run[3] - run[0];
+        }
+        d_rggb = block_sum_u64(d_rggb, sh);
+        d_gbrg = block_sum_u64(d_gbrg, sh);
+        if (tid == 0) s_rggb = d_rggb < d_gbrg;
+        __syncthreads();
+    }
+    const int rggb = s_rggb, ay1 = rggb ? 0 : 1, h = rggb ? H : H - 1;
+    // ---- greens by row phase: the frame as it is (RGGB: x & 1 != y & 1, rows [0, R0)) or one row lower (GBRG: rows 4 <= y - 1 < R1)
+    for (int i = tid; i < 4 * 16384; i += 256) {
+        const int ph = i >> 14, v = i & 16383;
+        const int q = rggb ? ph : ((ph + 1) & 3);                 // GBRG: class q feeds phase (q + 3) & 3
+        const int px = rggb ? 1 - (q & 1) : (q & 1);
+        g[(size_t)ph * 16385 + v] = dev[DI_D_CLASS + (size_t)(q * 2 + px) * 16384 + v];
+    }
+    __syncthreads();
+    // rows outside the range (dualiso.cpp: take_out): RGGB [R0, H); GBRG y - 1 < 4 or y - 1 >= R1, i.e. [0, 5) and [R1 + 1, H)
+    for (int pass = 0; pass < 2; pass++) {
+        const int ya = rggb ? (pass ? H : R0) : (pass ? R1 + 1 : 0), yb = rggb ? H : (pass ? H : min(5, H));
+        for (int y = ya; y < yb; y++) {
+            const int ph = rggb ? (y & 3) : ((y - 1) & 3);
+            for (int x = tid; x < w; x += 256)
+                if (rggb ? ((x & 1) != (y & 1)) : ((x & 1) == (y & 1))) atomicSub(&g[(size_t)ph * 16385 + (frame[(size_t)y * w + x] & 16383)], 1u);
+        }
+    }
+    __syncthreads();
+    // ---- bright_dark_from_hist in closed form.  The host walks ref upwards and moves every class to raw_i(ref) = the smallest r whose
+    // count of values below r reaches ref; it records `off` while ref < ref_off and all classes are below the threshold, and stops at
+    // the first ref that takes a class to 10000 or at ref_max.  The state only depends on ref, so the stops are evaluated directly.
+    for (int k = 0; k < 4; k++) block_prefix_in_place(g + (size_t)k * 16385, 16384, sh);
+    if (tid == 0) {
+        const unsigned *C[4] = { g, g + 16385, g + 2 * 16385, g + 3 * 16385 };
+        const int white = 10000;
+        long long total = 0;
+        for (int k = 0; k < 4; k++) total += C[k][16384];
+        const int ref_max = (int)(total * 0.998), ref_off = (int)(total * 0.05);
+        int raw[4] = { 0, 0, 0, 0 }, off[4] = { 0, 0, 0, 0 };
+        if (ref_max > 0) {
+            long long ref_b = (long long)1 << 62;
+            for (int k = 0; k < 4; k++) ref_b = min(ref_b, (long long)C[k][white - 1] + 1);       // first ref with raw_k >= white
+            const long long ref_end = ref_b < ref_max ? ref_b : (long long)ref_max - 1;
+            for (int k = 0; k < 4; k++) raw[k] = quantile_of(C[k], 16384, ref_end);
+            const int thr = black14 + (white - black14) / 4;
+            if (thr > 0) {
+                const int t1 = min(thr - 1, 16384);
+                long long r_thr = (long long)1 << 62;
+                for (int k = 0; k < 4; k++) r_thr = min(r_thr, (long long)C[k][t1]);           // largest ref with every raw_k < thr
+                const long long ref_o = min(min((long long)ref_off - 1, r_thr), ref_end);
+                if (ref_o >= 0)
+                    for (int k = 0; k < 4; k++) off[k] = quantile_of(C[k], 16384, ref_o);
+            }
+        }
+        int d[4], sv[4];
+        for (int k = 0; k < 4; k++) { d[k] = raw[k] - off[k]; sv[k] = d[k]; }
+        for (int a = 0; a < 4; a++) for (int b = a + 1; b < 4; b++) if (sv[b] < sv[a]) { const int t = sv[a]; sv[a] = sv[b]; sv[b] = t; }
+        const double med = (sv[1] + sv[2]) / 2;
+        for (int k = 0; k < 4; k++) { s_bright[k] = d[k] > med; dd.is_bright[k] = s_bright[k]; dd.bd_raw[k] = d[k]; }
+        dd.rggb = rggb;
+    }
+    __syncthreads();
+    // ---- whites_from_hist: the every-3rd-pixel histograms by exposure; the samples the reference's list cap overwrote (class
+    // indices max_pix - 1 .. total - 2, only ever in the last rows) are taken out; 11th / 51st largest
+    const int isb[4] = { s_bright[0], s_bright[1], s_bright[2], s_bright[3] };
+    const uint16_t *img = frame + (size_t)ay1 * w;
+    const unsigned *hw = dev + (rggb ? DI_D_WHITE0 : DI_D_WHITE1);
+    for (int i = tid; i < 2 * 32768; i += 256) {
+        const int c = i >> 15, v = i & 32767;
+        unsigned s = 0;
+        for (int ph = 0; ph < 4; ph++) if (isb[ph] == c) s += hw[(size_t)ph * 32768 + v];
+        wh[i] = s;
+    }
+    const int spr = (w + 2) / 3, tail_rows = min(h, 32);
+    const long long max_pix = (long long)w * h / 2 / 9;
+    if (tid == 0) {
+        long long total[2] = { 0, 0 }, idx[2] = { 0, 0 };
+        for (int y = ay1; y < h; y += 3) total[isb[y % 4]] += spr;
+        shl[0] = total[0]; shl[1] = total[1];
+        int n = 0;
+        for (int y = ay1; y < h; y += 3) {
+            const int c = isb[y % 4];
+            if (total[c] > max_pix && idx[c] + spr > max_pix - 1 && y >= h - tail_rows && n < 512) { s_rows[n][0] = y; s_rows[n][1] = (int)idx[c]; n++; }
+            idx[c] += spr;
+        }
+        s_nrows = n;
+    }
+    __syncthreads();
+    unsigned long long removed[2] = { 0, 0 };
+    for (int r = 0; r < s_nrows; r++) {
+        const int y = s_rows[r][0], c = isb[y % 4];
+        const long long i0 = s_rows[r][1], tot = shl[c];
+        for (int sx = tid; sx < spr; sx += 256) {
+            const long long k = i0 + sx;
+            if (k >= max_pix - 1 && k <= tot - 2) {
+                const int v0 = img[(size_t)y * w + 3 * sx];
+                atomicSub(&wh[(size_t)c * 32768 + (v0 < 32767 ? v0 : 32767)], 1u);
+                removed[c]++;
+            }
+        }
+    }
+    removed[0] = block_sum_u64(removed[0], sh);
+    removed[1] = block_sum_u64(removed[1], sh);
+    __syncthreads();
+    int wlev[2];
+    for (int c = 0; c < 2; c++) {
+        const long long kept = shl[c] - (long long)removed[c];
+        long long k = c == 0 ? 10 : 50;
+        int val = 0;
+        if (kept > 0) {
+            if (k > kept - 1) k = kept - 1;
+            // (k + 1)-th largest = first index from the top whose running count exceeds k = from the bottom: exceeds kept - 1 - k
+            val = block_kth_from_hist(wh + (size_t)c * 32768, 32768, kept - 1 - k, sh, &sh_i);
+        }
+        wlev[c] = val;
+    }
+    if (tid == 0) {
+        const int w0 = wlev[0] - 100, w1 = wlev[1] - 1500;
+        dd.white_dark = w0 < 10000 ? 10000 : (w0 > 16383 ? 16383 : w0);
+        dd.white_bright = w1 < 5000 ? 5000 : (w1 > 16383 ? 16383 : w1);
+        // the geometry and levels the sampling kernels need (dualiso.cpp fills the rest after the round trip)
+        DiParams &p = D.pp[f];
+        const int nb = isb[0] + isb[1] + isb[2] + isb[3];
+        const bool ok = nb == 2 && isb[0] != isb[2] && isb[1] != isb[3] && dd.check_ok;
+        p.w = w; p.h = ok ? h : 0; p.ay1 = ay1;
+        p.is_bright_bits = isb[0] | (isb[1] << 1) | (isb[2] << 2) | (isb[3] << 3);
+        p.black20 = black14 * 64; p.white20 = dd.white_dark * 64;
+        p.match_white20 = min(dd.white_dark, dd.white_bright) * 64;
+    }
+}
+
+// medians and percentiles of match_exposures from its two histograms (hdr.c:700-733; dualiso.cpp: kth_from_hist)
+__global__ __launch_bounds__(256) void k_di_decide_quantiles(DiDecideBuffers D)
+{
+    __shared__ unsigned long long sh[256];
+    __shared__ int sh_i;
+    const int f = blockIdx.x;
+    const unsigned *hb = D.hist_bd + (size_t)f * 2 * DI_HIST_N, *hd = hb + DI_HIST_N;
+    DiDecide &dd = D.dd[f];
+    if (D.pp[f].h <= 0) return;
+    unsigned long long s = 0;
+    for (int i = threadIdx.x; i < DI_HIST_N; i += 256) s += hb[i];
+    const long long n = (long long)block_sum_u64(s, sh);
+    const long long mk = (n & 1) ? n / 2 : n / 2 - 1;
+    int bmed = 0, b_lo = 0, b_hi = 0, dmed = 0;
+    if (n > 0) {
+        bmed = block_kth_from_hist(hb, DI_HIST_N, mk, sh, &sh_i) - DI_HIST_OFF;
+        b_lo = block_kth_from_hist(hb, DI_HIST_N, n * 98 / 100, sh, &sh_i) - DI_HIST_OFF;
+        b_hi = block_kth_from_hist(hb, DI_HIST_N, (long long)(n * 99.9 / 100), sh, &sh_i) - DI_HIST_OFF;
+        dmed = block_kth_from_hist(hd, DI_HIST_N, mk, sh, &sh_i) - DI_HIST_OFF;
+    }
+    if (threadIdx.x == 0) { dd.n = n; dd.bmed = bmed; dd.b_lo = b_lo; dd.b_hi = b_hi; dd.dmed = dmed; }
+}
+
+// what every sample row contributes to the list of highlight pairs and where (hdr.c:735-746: the cap leaves only the inner loop)
+__global__ __launch_bounds__(64) void k_di_decide_rows(DiDecideBuffers D)
+{
+    const int f = blockIdx.x;
+    const DiParams p = D.pp[f];
+    if (p.h <= 0 || threadIdx.x != 0) return;
+    int *counts = D.rows + (size_t)f * 3 * D.nsy_max, *take = counts + D.nsy_max, *offset = take + D.nsy_max;
+    const int nsy = di_nsy(p), nmax = (p.w + 2) * (p.h + 2) / 9, hi_nmax = nmax / 50;
+    int hi_n = 0;
+    if (D.dd[f].n > 0)
+        for (int sy = 0; sy < nsy; sy++) {
+            const int t = min(counts[sy], max(hi_nmax - hi_n, 1));
+            take[sy] = t;
+            offset[sy] = hi_n;
+            hi_n += t;
+        }
+    else
+        for (int sy = 0; sy < nsy; sy++) { take[sy] = 0; offset[sy] = 0; }
+    D.dd[f].hi_n = hi_n;
+}
+
+// the winning slope: the FIRST candidate with the highest score, if that score is above zero (hdr.c:764-771)
+__global__ __launch_bounds__(256) void k_di_decide_fit(DiDecideBuffers D)
+{
+    __shared__ long long shl[4];
+    const int f = blockIdx.x;
+    if (D.pp[f].h <= 0) return;
+    const int *score = D.score + (size_t)f * D.score_stride;
+    long long best = 0;                                   // (score << 32) | (0x7FFFFFFF - index): maximum = highest score, lowest index
+    if (D.dd[f].hi_n > 0)
+        for (int k = threadIdx.x; k < D.ncand; k += 256) {
+            const long long key = ((long long)score[k] << 32) | (long long)(0x7FFFFFFF - k);
+            best = key > best ? key : best;
+        }
+    const long long top = -block_min_i64(-best, shl);
+    if (threadIdx.x == 0) {
+        const int sc = (int)(top >> 32);
+        D.dd[f].best_score = sc;
+        D.dd[f].best = sc > 0 ? 0x7FFFFFFF - (int)(top & 0x7FFFFFFF) : -1;
+    }
+}
+
 // ------------------------------------------------------------------ launchers
-static inline dim3 flat_grid(size_t n) { size_t b = (n + 255) / 256; if (b > 8192) b = 8192; return dim3((unsigned)b); }
+// grid-stride kernels: x over the pixels of one frame, y = frame of the batch
+static inline dim3 flat_grid(size_t n, int nframes = 1)
+{
+    size_t b = (n + 255) / 256;
+    const size_t cap = nframes > 4 ? 2048 : 8192;       // a batch fills the chip with its frames
+    if (b > cap) b = cap;
+    return dim3((unsigned)b, (unsigned)nframes);
+}
 
 int di_launch_analyse(const void *d_img, int w, int H, int black, int white, const double *d_evf, unsigned *d_hist,
-                      double *d_check, hipStream_t s)
+                      double *d_check, hipStream_t s, int nframes, size_t img_stride, size_t hist_stride, size_t check_stride)
 {
-    const ptrdiff_t gap = (const uint8_t *)d_check - (const uint8_t *)d_hist;
-    if (gap >= (ptrdiff_t)(sizeof(unsigned) * DI_D_WORDS) && gap < (ptrdiff_t)(sizeof(unsigned) * DI_D_WORDS) + 4096)
-        MLV_HIP(hipMemsetAsync(d_hist, 0, (size_t)gap + 2 * sizeof(double), s));                   // the check sums lie right behind: one call
-    else {
-        MLV_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * DI_D_WORDS, s));
-        MLV_HIP(hipMemsetAsync(d_check, 0, 2 * sizeof(double), s));
+    if (nframes > 1) {
+        MLV_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * hist_stride * nframes, s));
+        MLV_HIP(hipMemsetAsync(d_check, 0, sizeof(double) * check_stride * nframes, s));
+    } else {
+        const ptrdiff_t gap = (const uint8_t *)d_check - (const uint8_t *)d_hist;
+        if (gap >= (ptrdiff_t)(sizeof(unsigned) * DI_D_WORDS) && gap < (ptrdiff_t)(sizeof(unsigned) * DI_D_WORDS) + 4096)
+            MLV_HIP(hipMemsetAsync(d_hist, 0, (size_t)gap + 2 * sizeof(double), s));                   // the check sums lie right behind: one call
+        else {
+            MLV_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * DI_D_WORDS, s));
+            MLV_HIP(hipMemsetAsync(d_check, 0, 2 * sizeof(double), s));
+        }
     }
-    hipLaunchKernelGGL(k_di_analyse, dim3((H + DI_BAND - 1) / DI_BAND, 4), dim3(256), 0, s, (const uint16_t *)d_img, w, H, black, white,
-                       d_evf, d_hist, d_check);
+    hipLaunchKernelGGL(k_di_analyse, dim3((H + DI_BAND - 1) / DI_BAND, 4, nframes), dim3(256), 0, s, (const uint16_t *)d_img, w, H, black, white,
+                       d_evf, d_hist, d_check, img_stride, hist_stride, check_stride);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
 
-int di_launch_subsample(const void *d_img, const DiParams &p, int nsx, int nsy, int *d_dark_s, int *d_bright_s,
-                        unsigned *d_hist_b, unsigned *d_hist_d, hipStream_t s)
+// hist_bd: per frame hist_b | hist_d back to back
+int di_launch_subsample(const void *d_img, const DiBatch &b, int nsx, int nsy_max, size_t ns_stride, int *d_dark_s, int *d_bright_s,
+                        unsigned *d_hist_bd, hipStream_t s)
 {
-    if (d_hist_d == d_hist_b + DI_HIST_N) MLV_HIP(hipMemsetAsync(d_hist_b, 0, 2 * sizeof(unsigned) * DI_HIST_N, s));      // back to back: one call
-    else {
-        MLV_HIP(hipMemsetAsync(d_hist_b, 0, sizeof(unsigned) * DI_HIST_N, s));
-        MLV_HIP(hipMemsetAsync(d_hist_d, 0, sizeof(unsigned) * DI_HIST_N, s));
-    }
-    if (nsx * nsy > 0)
-        hipLaunchKernelGGL(k_di_subsample, dim3((nsx * nsy + 255) / 256), dim3(256), 0, s, (const uint16_t *)d_img, p, nsx, nsy,
-                           d_dark_s, d_bright_s, d_hist_b, d_hist_d);
+    MLV_HIP(hipMemsetAsync(d_hist_bd, 0, 2 * sizeof(unsigned) * DI_HIST_N * b.nframes, s));
+    if (nsx * nsy_max > 0)
+        hipLaunchKernelGGL(k_di_subsample, dim3((nsx * nsy_max + 255) / 256, b.nframes), dim3(256), 0, s, (const uint16_t *)d_img, b, nsx,
+                           ns_stride, d_dark_s, d_bright_s, d_hist_bd);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
 
-int di_launch_hi_count(const int *d_bs, int nsx, int nsy, int b_lo, int b_hi, int *d_counts, hipStream_t s)
+int di_launch_hi_count(const int *d_bs, int nsx, int nsy_max, size_t ns_stride, int b_lo, int b_hi, const DiDecide *dd, const DiBatch &b,
+                       int *d_rows, hipStream_t s)
 {
-    if (nsy > 0) hipLaunchKernelGGL(k_di_hi_count, dim3(nsy), dim3(256), 0, s, d_bs, nsx, b_lo, b_hi, d_counts);
+    if (nsy_max > 0)
+        hipLaunchKernelGGL(k_di_hi_count, dim3(nsy_max, b.nframes), dim3(256), 0, s, d_bs, nsx, ns_stride, b_lo, b_hi, dd, b, d_rows, 3 * nsy_max);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
 
-int di_launch_hi_compact(const int *d_ds, const int *d_bs, int nsx, int nsy, int b_lo, int b_hi, const int *d_take, const int *d_offset,
-                         int *d_hd, int *d_hb, hipStream_t s)
+int di_launch_hi_compact(const int *d_ds, const int *d_bs, int nsx, int nsy_max, size_t ns_stride, int b_lo, int b_hi, const DiDecide *dd,
+                         const DiBatch &b, const int *d_rows, int *d_hi, size_t hi_stride, hipStream_t s)
 {
-    if (nsy > 0) hipLaunchKernelGGL(k_di_hi_compact, dim3(nsy), dim3(256), 0, s, d_ds, d_bs, nsx, b_lo, b_hi, d_take, d_offset, d_hd, d_hb);
+    if (nsy_max > 0)
+        hipLaunchKernelGGL(k_di_hi_compact, dim3(nsy_max, b.nframes), dim3(256), 0, s, d_ds, d_bs, nsx, ns_stride, b_lo, b_hi, dd, b, d_rows,
+                           nsy_max, d_hi, hi_stride);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
 
-int di_launch_score(const int *d_hd, const int *d_hb, int hi_n, const double *d_cand, int ncand, int *d_score, hipStream_t s)
+int di_launch_score(const int *d_hi, size_t hi_stride, int hi_n, const double *d_ta, int ncand, int dmed, int bmed, const DiDecide *dd,
+                    int nframes, int *d_score, int score_stride, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_di_score, dim3(ncand), dim3(256), 0, s, d_hd, d_hb, hi_n, d_cand, d_score);
+    hipLaunchKernelGGL(k_di_score, dim3(ncand, nframes), dim3(256), 0, s, d_hi, hi_stride, hi_n, d_ta, dmed, bmed, dd, d_score, score_stride);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
 
-static int di_chroma_smooth(const uint32_t *plane, uint32_t *plane_s, const DiParams &p, const DiLuts &L, int *cells, hipStream_t s)
+static int di_chroma_smooth(const uint32_t *plane, uint32_t *plane_s, const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P,
+                            hipStream_t s)
 {
-    const int w = p.w, h = p.h, cw = w / 2, ch = h / 2;
-    MLV_HIP(hipMemcpyAsync(plane_s, plane, (size_t)w * h * 4, hipMemcpyDeviceToDevice, s));
+    const DiParams &p = b.p0;                            // width and options are the batch's; the rows are each frame's
+    const int w = p.w, cw = w / 2, ch = h_launch / 2;
+    MLV_HIP(hipMemcpyAsync(plane_s, plane, (b.nframes > 1 ? b.S * b.nframes : (size_t)w * h_launch) * 4, hipMemcpyDeviceToDevice, s));
     if (cw <= 0 || ch <= 0) return MLVFS_AMD_OK;
-    dim3 g((cw + 255) / 256, ch);
-    hipLaunchKernelGGL(k_di_cs_cells, g, dim3(256), 0, s, plane, w, cw, ch, L.mix_raw2ev, cells);
+    dim3 g((cw + 255) / 256, ch, b.nframes);
+    hipLaunchKernelGGL(k_di_cs_cells, g, dim3(256), 0, s, plane, b, P.cells_stride, L.mix_raw2ev, P.cells);
     switch (p.chroma_smooth) {
-    case 2: hipLaunchKernelGGL(k_di_cs_apply<2>, g, dim3(256), 0, s, cells, w, h, cw, ch, L.mix_ev2raw, plane_s); break;
-    case 3: hipLaunchKernelGGL(k_di_cs_apply<3>, g, dim3(256), 0, s, cells, w, h, cw, ch, L.mix_ev2raw, plane_s); break;
-    default: hipLaunchKernelGGL(k_di_cs_apply<5>, g, dim3(256), 0, s, cells, w, h, cw, ch, L.mix_ev2raw, plane_s); break;
+    case 2: hipLaunchKernelGGL(k_di_cs_apply<2>, g, dim3(256), 0, s, P.cells, b, P.cells_stride, L.mix_ev2raw, plane_s); break;
+    case 3: hipLaunchKernelGGL(k_di_cs_apply<3>, g, dim3(256), 0, s, P.cells, b, P.cells_stride, L.mix_ev2raw, plane_s); break;
+    default: hipLaunchKernelGGL(k_di_cs_apply<5>, g, dim3(256), 0, s, P.cells, b, P.cells_stride, L.mix_ev2raw, plane_s); break;
     }
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
 
-// raw (exposure-matched 20-bit) -> dark/bright by mean23; returns with fullres/halfres/over (and the alias error) filled in
-int di_launch_match(const void *d_img, const DiParams &p, const DiPlanes &P, hipStream_t s)
+// 14 -> 20 bit with the exposures matched (hdr.c:781-803); d_img: frame 0 of the batch, NOT offset for GBRG (the kernels do that)
+int di_launch_match(const void *d_img, const DiBatch &b, int h_launch, const DiPlanes &P, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_di_match, flat_grid((size_t)p.w * p.h), dim3(256), 0, s, (const uint16_t *)d_img, P.raw, p);
+    hipLaunchKernelGGL(k_di_match, flat_grid((size_t)b.p0.w * h_launch, b.nframes), dim3(256), 0, s, (const uint16_t *)d_img, P.raw, b);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
 
-// squeeze -> AMaZE -> clamp -> gray -> edge directions; the planes feed k_di_interp<true>
-int di_launch_amaze_interp(const DiParams &p, const DiLuts &L, const DiPlanes &P, hipStream_t s)
+// squeeze -> AMaZE -> clamp -> gray -> edge directions; the planes feed k_di_interp<true>.  P.sq_dst: per frame sq_dst | sq_row of
+// h_launch ints each
+int di_launch_amaze_interp(const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s)
 {
-    const size_t n = (size_t)p.w * p.h;
-    MLV_HIP(hipMemsetAsync(P.cfa, 0, n * sizeof(float), s));          // rows no exposure lands on stay zero (hdr.c:971)
-    MLV_HIP(hipMemsetAsync(P.stats, 0, 4 * sizeof(unsigned), s));
-    hipLaunchKernelGGL(k_di_squeeze, flat_grid(n), dim3(256), 0, s, P.raw, p, P.sq_dst, P.cfa);
-    int rc = amaze_launch(P.cfa, p.w, p.h, P.red, P.green, P.blue, P.amaze_scratch, s);
+    const int w = b.p0.w, nf = b.nframes;
+    const size_t n = (size_t)w * h_launch, sq_stride = 2 * (size_t)h_launch;
+    MLV_HIP(hipMemsetAsync(P.cfa, 0, (nf > 1 ? b.S * nf : n) * sizeof(float), s));          // rows no exposure lands on stay zero (hdr.c:971)
+    MLV_HIP(hipMemsetAsync(P.stats, 0, 4 * sizeof(unsigned) * nf, s));
+    hipLaunchKernelGGL(k_di_squeeze, flat_grid(n, nf), dim3(256), 0, s, P.raw, b, P.sq_dst, sq_stride, P.cfa);
+    // a frame's AMaZE geometry follows its own row count (one less for GBRG): the launch plan is made per distinct height
+    int rc = MLVFS_AMD_OK;
+    if (b.pp) {
+        static_assert(sizeof(DiParams) % sizeof(int) == 0, "h of frame f sits f * sizeof(DiParams) / 4 ints behind h of frame 0");
+        for (int k = 0; k < b.nheights && !rc; k++)
+            rc = amaze_launch(P.cfa, w, b.heights[k], P.red, P.green, P.blue, P.amaze_scratch, s, nf, b.S, P.amaze_scratch_stride, &b.pp->h,
+                              (int)(sizeof(DiParams) / sizeof(int)));
+    } else rc = amaze_launch(P.cfa, w, b.p0.h, P.red, P.green, P.blue, P.amaze_scratch, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_di_amaze_clamp, flat_grid(n), dim3(256), 0, s, P.red, P.green, P.blue, n, p.black20);
-    hipLaunchKernelGGL(k_di_gray, flat_grid(n), dim3(256), 0, s, P.red, P.green, P.blue, p, P.sq_row, L.interp_raw2ev, P.gray_ev);
-    hipLaunchKernelGGL(k_di_edge_dir, flat_grid(n), dim3(256), 0, s, P.raw, P.gray_ev, p, L.fullres_curve, P.dir, P.stats);
+    hipLaunchKernelGGL(k_di_amaze_clamp, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b);
+    hipLaunchKernelGGL(k_di_gray, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b, P.sq_row, sq_stride, L.interp_raw2ev, P.gray_ev);
+    hipLaunchKernelGGL(k_di_edge_dir, flat_grid(n, nf), dim3(256), 0, s, P.raw, P.gray_ev, b, L.fullres_curve, P.dir, P.stats);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
 
 // amaze: the planes of di_launch_amaze_interp are ready and the edge-directed interpolation replaces mean23
-int di_launch_convert(const DiParams &p, const DiLuts &L, const DiPlanes &P, bool amaze, void *d_out, hipStream_t s)
+int di_launch_convert(const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, bool amaze, void *d_out, hipStream_t s)
 {
-    const size_t n = (size_t)p.w * p.h;
+    const DiParams &p = b.p0;
+    const int nf = b.nframes;
+    const size_t n = (size_t)p.w * h_launch;
     uint16_t *amap_fused = (p.use_alias_map && !p.chroma_smooth) ? P.amap : nullptr;
-    const DiAmazeIn A{ P.red, P.green, P.blue, P.dir, P.sq_row };
+    const DiAmazeIn A{ P.red, P.green, P.blue, P.dir, P.sq_row, 2 * (size_t)h_launch };
     if (amaze)
-        hipLaunchKernelGGL(k_di_interp<true>, flat_grid(n), dim3(256), 0, s, P.raw, p, L, A, P.dark, P.bright, P.fullres, P.halfres,
+        hipLaunchKernelGGL(k_di_interp<true>, flat_grid(n, nf), dim3(256), 0, s, P.raw, b, L, A, P.dark, P.bright, P.fullres, P.halfres,
                            P.over, amap_fused);
     else
-        hipLaunchKernelGGL(k_di_interp<false>, flat_grid(n), dim3(256), 0, s, P.raw, p, L, A, P.dark, P.bright, P.fullres, P.halfres,
+        hipLaunchKernelGGL(k_di_interp<false>, flat_grid(n, nf), dim3(256), 0, s, P.raw, b, L, A, P.dark, P.bright, P.fullres, P.halfres,
                            P.over, amap_fused);
     MLV_HIP(hipGetLastError());
     const uint32_t *fullres_s = P.fullres, *halfres_s = P.halfres;
     if (p.chroma_smooth) {                                             // hdr.c:1612-1619
-        int rc = di_chroma_smooth(P.halfres, P.halfres_s, p, L, P.cells, s);
+        int rc = di_chroma_smooth(P.halfres, P.halfres_s, b, h_launch, L, P, s);
         if (rc) return rc;
         halfres_s = P.halfres_s;
         if (p.use_fullres) {                                           // otherwise fullres_smooth aliases the all-zero fullres (hdr.c:1822)
-            rc = di_chroma_smooth(P.fullres, P.fullres_s, p, L, P.cells, s);
+            rc = di_chroma_smooth(P.fullres, P.fullres_s, b, h_launch, L, P, s);
             if (rc) return rc;
             fullres_s = P.fullres_s;
         }
         if (p.use_alias_map)
-            hipLaunchKernelGGL(k_di_alias_err, flat_grid(n), dim3(256), 0, s, P.bright, fullres_s, halfres_s, p, L, P.amap);
+            hipLaunchKernelGGL(k_di_alias_err, flat_grid(n, nf), dim3(256), 0, s, P.bright, fullres_s, halfres_s, b, L, P.amap);
     }
     const uint16_t *amap_final = nullptr;
     if (p.use_alias_map) {
-        dim3 g((p.w + 255) / 256, p.h);
-        hipLaunchKernelGGL(k_di_alias_rank, g, dim3(256), 0, s, P.amap, P.bright, L.fullres_curve, p.w, p.h, P.aux);
-        hipLaunchKernelGGL(k_di_alias_blur, g, dim3(256), 0, s, P.aux, P.amap, P.bright, L.fullres_curve, p.w, p.h, P.amap2);
+        dim3 g((p.w + 255) / 256, h_launch, nf);
+        hipLaunchKernelGGL(k_di_alias_rank, g, dim3(256), 0, s, P.amap, P.bright, L.fullres_curve, b, P.aux);
+        hipLaunchKernelGGL(k_di_alias_blur, g, dim3(256), 0, s, P.aux, P.amap, P.bright, L.fullres_curve, b, P.amap2);
         amap_final = P.amap2;
     }
-    hipLaunchKernelGGL(k_di_blend, flat_grid(n), dim3(256), 0, s, P.dark, P.bright, P.fullres, fullres_s, halfres_s, P.over, amap_final,
-                       p, L, (uint16_t *)d_out);
+    hipLaunchKernelGGL(k_di_blend, flat_grid(n, nf), dim3(256), 0, s, P.dark, P.bright, P.fullres, fullres_s, halfres_s, P.over, amap_final,
+                       b, L, (uint16_t *)d_out);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+
+size_t di_derived_words() { return DI_DERIVED_WORDS; }
+
+int di_launch_decide_pattern(const void *d_frames, const DiBatch &b, int H, int black14, const DiDecideBuffers &D, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_di_decide_pattern, dim3(b.nframes), dim3(256), 0, s, (const uint16_t *)d_frames, b.img_stride, b.p0.w, H, black14, D);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+int di_launch_decide_quantiles(const DiBatch &b, const DiDecideBuffers &D, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_di_decide_quantiles, dim3(b.nframes), dim3(256), 0, s, D);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+int di_launch_decide_rows(const DiBatch &b, const DiDecideBuffers &D, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_di_decide_rows, dim3(b.nframes), dim3(64), 0, s, D);
+    MLV_HIP(hipGetLastError());
+    return MLVFS_AMD_OK;
+}
+int di_launch_decide_fit(const DiBatch &b, const DiDecideBuffers &D, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_di_decide_fit, dim3(b.nframes), dim3(256), 0, s, D);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }

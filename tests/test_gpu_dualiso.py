@@ -184,3 +184,79 @@ def test_cr2hdr20_device_api(gpu, oracle):
     assert gpu.mlvfs_amd_cr2hdr20_dev(C.byref(geom), C.c_void_p(t.data_ptr()), 1, 1, 1, 0, None) == 1
     torch.cuda.synchronize()
     check_close(t.cpu().numpy().view(np.uint16), want)
+
+
+# ---------------------------------------------------------------------------------------------- batches
+def batch_convert(gpu, frames, interp, fullres=1, alias=1, cs=0, reset=True, pad_rows=3):
+    """mlvfs_amd_cr2hdr20_batch_dev on frames of one geometry laid out `stride` bytes apart (with a gap, to catch stride errors)."""
+    import torch
+    h, w = frames[0].shape
+    if reset:
+        gpu.mlvfs_amd_dualiso_reset()
+    stride = (h + pad_rows) * w * 2
+    host = np.full((len(frames), h + pad_rows, w), 0x5A5A, np.uint16)
+    for k, f in enumerate(frames):
+        host[k, :h] = f
+    t = torch.from_numpy(host.view(np.int16)).cuda()
+    res = np.full(len(frames), -7, np.int32)
+    geom = lib.Geom(w, h, 14, BLACK, WHITE, 0, 0)
+    rc = gpu.mlvfs_amd_cr2hdr20_batch_dev(C.byref(geom), C.c_void_p(t.data_ptr()), stride, len(frames), interp, fullres, alias, cs, lib.ptr(res), None)
+    assert rc == 0, gpu.mlvfs_amd_last_error()
+    torch.cuda.synchronize()
+    out = t.cpu().numpy().view(np.uint16)
+    assert (out[:, h:] == 0x5A5A).all(), "the batch wrote between the frames"
+    return res, [out[k, :h] for k in range(len(frames))]
+
+
+@pytest.mark.parametrize("interp,cs", [(0, 0), (1, 0), (0, 5), (1, 3)])
+def test_cr2hdr20_batch_equals_the_oracle_frame_by_frame(gpu, oracle, interp, cs):
+    """One submission for a mixed batch: dual-ISO frames of different content and white levels, one that is not dual ISO, one
+    whose pattern starts on a GB row -- results, pixels and the order-dependent table caches (the first frame that converts fixes
+    the tables' white level, hdr.c:1240) as if the frames had been converted one after the other."""
+    w, h = 416, 264
+    frames = [synth.dual_iso_frame(w, h, seed=3), synth.normal_frame(w, h), synth.dual_iso_frame(w, h, seed=5, frame=2),
+              np.minimum(synth.dual_iso_frame(w, h, seed=4), 12000).astype(np.uint16),
+              synth.dual_iso_frame(w, h + 2, seed=6)[1:h + 1].copy(), synth.dual_iso_frame(w, h, seed=3)]
+    oracle.L.orc_dualiso_reset()
+    want = [oracle.cr2hdr20(f, BLACK, WHITE, interp, 1, 1, cs, reset=False) for f in frames]
+    res, got = batch_convert(gpu, frames, interp, 1, 1, cs)
+    assert list(res) == [r for r, _, _ in want] == [1, 0, 1, 1, 1, 1]
+    for k, (r, img, _) in enumerate(want):
+        assert np.array_equal(got[k], img), f"frame {k}: {(got[k] != img).sum()} px differ"
+    assert np.array_equal(got[1], frames[1]) and np.array_equal(got[0], got[5])
+    # the same frames one by one through the single-frame entry give the same bytes (a batch of one is the same code)
+    gpu.mlvfs_amd_dualiso_reset()
+    for k, f in enumerate(frames):
+        r1, one, _ = convert(gpu, f, interp, 1, 1, cs, reset=False)
+        assert r1 == res[k] and np.array_equal(one, got[k]), k
+
+
+def test_cr2hdr20_batch_decisions_equal_the_oracle(gpu, oracle):
+    """The device-side decisions, scalar by scalar, for the last frame of a batch (mlvfs_amd_dualiso_last_scalars) on frames whose
+    white levels, fits and patterns differ."""
+    w, h = 416, 264
+    for frames in ([synth.dual_iso_frame(w, h, seed=9)], [synth.normal_frame(w, h), synth.dual_iso_frame(w, h + 2, seed=2)[1:h + 1].copy()],
+                   [synth.dual_iso_frame(w, h, seed=1), np.minimum(synth.dual_iso_frame(w, h, seed=8), 11000).astype(np.uint16)]):
+        oracle.L.orc_dualiso_reset()
+        sc0 = None
+        for f in frames:
+            r0, _, _, sc = oracle.cr2hdr20(f, BLACK, WHITE, 1, 1, 1, 0, want_scalars=True, reset=False)
+            if r0 == 1:
+                sc0 = sc
+        res, _ = batch_convert(gpu, frames, 1)
+        sc1 = scalars(gpu)
+        for n, x, y in zip(("rggb", "is_bright", "white", "white_bright", "a", "b", "corr_ev", "white_darkened"), sc1, sc0):
+            assert x == y, (n, x, y)
+
+
+def test_cr2hdr20_batch_full_size(gpu):
+    """BASELINE.json config 4 at 3584x1320, --amaze-edge: a batch of three against the hashes of the reference's output."""
+    import json
+    import os
+    from conftest import fnv1a
+    full = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))["full_size"]
+    f = synth.dual_iso_frame(3584, 1320)
+    res, got = batch_convert(gpu, [f, f, f], 0, 1, 1, 0, pad_rows=0)
+    assert list(res) == [1, 1, 1]
+    for g in got:
+        assert fnv1a(g) == full["dualiso_3584x1320_i0_f1_a1_cs0"]

@@ -243,7 +243,7 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=100)
     ap.add_argument("--workgroups", type=int, default=1024)
     ap.add_argument("--json", default=None)
-    ap.add_argument("--out-dir", default=os.path.join(ROOT, "build", "isa"))
+    ap.add_argument("--out-dir", default="/tmp/mlvfs_amd_isa")      # (not under the repository: the temporaries are 100 MB and would travel with gpurun)
     a = ap.parse_args()
 
     prod = instruction_stream(compile_asm(a.out_dir, False))
