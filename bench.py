@@ -241,9 +241,11 @@ def extra_footage(F=48):
     return res
 
 
-def extra_dualiso(golden, fnv1a, per_thread=10):
-    """configs[3]: full dual-ISO conversion (AMaZE + edge-directed interpolation, full-res, alias map) of device-resident
-    3584x1320 frames, 1 and 4 conversions in flight (one host thread + HIP stream each); result hashed against the reference's."""
+def extra_dualiso(golden, fnv1a, batch=8, reps=4, threads=3):
+    """configs[3]: full dual-ISO conversion (AMaZE + edge-directed interpolation, full-res, alias map) of 3584x1320 frames resident
+    in HBM: (a) one conversion at a time (latency), (b) mlvfs_amd_cr2hdr20_batch_dev with `batch` frames per submission from one
+    host thread, (c) the same from `threads` host threads, each with its own stream and batch (the analysis kernels of one batch
+    overlap the AMaZE tiles of another).  Every converted frame is hashed against the reference's output."""
     import torch
     from mlvfs_amd import lib, synth
     L = lib.load()
@@ -251,45 +253,66 @@ def extra_dualiso(golden, fnv1a, per_thread=10):
     src = torch.from_numpy(f.view(np.int16)).cuda()
     geom = lib.Geom(W, H, 14, synth.BLACK, synth.WHITE, 0, 0)
     L.mlvfs_amd_dualiso_reset()
-    res = {"workload": "configs[3]: 3584x1320 cr2hdr20 amaze-edge, fullres, alias map, no chroma smooth; frame resident in HBM"}
+    res = {"workload": "configs[3]: 3584x1320 cr2hdr20 amaze-edge, fullres, alias map, no chroma smooth; frames resident in HBM"}
+    want = golden["dualiso_3584x1320_i0_f1_a1_cs0"]
 
-    def worker(n, bufs, warm, stream, oks, start, t_begin, t_end, idx):
-        # steady state of a worker thread: one conversion of warm-up (the thread's stream and work buffers are created by its first
-        # call and released when it ends: tens of milliseconds, a device-wide synchronisation on release), clock (from the first worker that is ready to the last that is done)
-        lib.check(L.mlvfs_amd_init(0))
-        L.mlvfs_amd_cr2hdr20_dev(C.byref(geom), C.c_void_p(warm.data_ptr()), 0, 1, 1, 0, C.c_void_p(stream.cuda_stream))
-        stream.synchronize()
-        t_begin[idx] = time.perf_counter()                 # (no barrier: the workers of a pool are not in step)
-        ok = 0
-        for k in range(n):
-            ok += L.mlvfs_amd_cr2hdr20_dev(C.byref(geom), C.c_void_p(bufs[k].data_ptr()), 0, 1, 1, 0, C.c_void_p(stream.cuda_stream))
-        stream.synchronize()
-        t_end[idx] = time.perf_counter()
-        oks.append(ok)
-
-    first = None
-    for threads in (1, 4):
-        streams = [torch.cuda.Stream() for _ in range(threads)]
-        bufs = [[src.clone() for _ in range(per_thread)] for _ in range(threads)]
-        warm = [src.clone() for _ in range(threads)]
+    # (a) single conversions, one after the other
+    one = src.clone()
+    L.mlvfs_amd_cr2hdr20_dev(C.byref(geom), C.c_void_p(one.data_ptr()), 0, 1, 1, 0, None)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(6):
+        one.copy_(src); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ok = L.mlvfs_amd_cr2hdr20_dev(C.byref(geom), C.c_void_p(one.data_ptr()), 0, 1, 1, 0, None)
         torch.cuda.synchronize()
-        oks, start, t_begin, t_end = [], None, [0.0] * threads, [0.0] * threads
-        ths = [threading.Thread(target=worker, args=(per_thread, bufs[i], warm[i], streams[i], oks, start, t_begin, t_end, i)) for i in range(threads)]
+        ts.append(time.perf_counter() - t0)
+        if ok != 1:
+            raise RuntimeError("cr2hdr20_dev did not convert the frame")
+    res["single"] = {"ms_per_frame": round(float(np.median(ts)) * 1e3, 3), "conversions_per_s": round(1 / float(np.median(ts)), 1)}
+    hashes = {fnv1a(one.cpu().numpy().view(np.uint16))}
+
+    # (b), (c) batches
+    def batch_worker(i, bufs, streams, n_batches, t_begin, t_end, oks, go):
+        lib.check(L.mlvfs_amd_init(0))
+        r = np.zeros(batch, np.int32)
+        sp = C.c_void_p(streams[i].cuda_stream)
+        def run():
+            with torch.cuda.stream(streams[i]):                # fresh frames: a device copy on the same stream
+                bufs[i].copy_(src.unsqueeze(0).expand(batch, -1, -1))
+            rc = L.mlvfs_amd_cr2hdr20_batch_dev(C.byref(geom), C.c_void_p(bufs[i].data_ptr()), W * H * 2, batch, 0, 1, 1, 0, lib.ptr(r), sp)
+            streams[i].synchronize()
+            return int(rc == 0) * int(r.sum())
+        run()                                                  # the thread's work buffers
+        go.wait()
+        t_begin[i] = time.perf_counter()
+        oks[i] = sum(run() for _ in range(n_batches))
+        t_end[i] = time.perf_counter()
+
+    for T in (1, threads):
+        streams = [torch.cuda.Stream() for _ in range(T)]
+        bufs = [torch.empty((batch, H, W), dtype=torch.int16, device="cuda") for _ in range(T)]
+        t_begin, t_end, oks, go = [0.0] * T, [0.0] * T, [0] * T, threading.Barrier(T)
+        ths = [threading.Thread(target=batch_worker, args=(i, bufs, streams, reps, t_begin, t_end, oks, go)) for i in range(T)]
         for t in ths: t.start()
         for t in ths: t.join()
         torch.cuda.synchronize()
-        dt = max(t_end) - min(t_begin)
-        n = threads * per_thread
+        n = T * batch * reps
         if sum(oks) != n:
-            raise RuntimeError("cr2hdr20_dev did not convert every frame")
-        if first is None:
-            first = bufs[0][0].clone()
-        same = all(torch.equal(b, first) for bb in bufs for b in bb)
-        res[f"in_flight_{threads}"] = {"ms_per_frame": round(dt / n * 1e3, 3), "conversions_per_s": round(n / dt, 1),
-                                       "Mpix/s": round(n * W * H / dt / 1e6, 1), "identical_between_threads": bool(same)}
-    got = fnv1a(first.cpu().numpy().view(np.uint16))
-    want = golden["dualiso_3584x1320_i0_f1_a1_cs0"]
-    res["parity"] = {"hash": got, "reference": want, "ok": got == want}
+            raise RuntimeError("cr2hdr20_batch_dev did not convert every frame")
+        dt = max(t_end) - min(t_begin)
+        for bb in bufs:
+            for k in (0, batch - 1):
+                hashes.add(fnv1a(bb[k].cpu().numpy().view(np.uint16)))
+        res[f"batch_{batch}_threads_{T}"] = {"ms_per_frame": round(dt / n * 1e3, 3), "conversions_per_s": round(n / dt, 1),
+                                             "Mpix/s": round(n * W * H / dt / 1e6, 1)}
+        del bufs
+        torch.cuda.empty_cache()
+    best = max(v["conversions_per_s"] for k, v in res.items() if k.startswith("batch_"))
+    # SURVEY 8(d)'s convention for this path too: packed in + 16-bit out per frame against the HBM peak (the conversion's own
+    # multi-pass traffic is ~15 GB per batch of 8: profiles/r03/dualiso_batch_pmc_summary.txt)
+    res["hbm_frac_compulsory_bytes"] = round(best * W * H * BYTES_PER_PX / 1e9 / HBM_PEAK_GBS, 5)
+    res["parity"] = {"hashes": sorted(hashes), "reference": want, "ok": hashes == {want}}
     return res
 
 
@@ -370,6 +393,35 @@ def extra_pcie(N=128, threads=16):
         res["dropin_symbols_c_host"] = chost
     except Exception as e:                                   # no compiler on the box: the Python harness above stands
         res["dropin_symbols_c_host"] = {"skipped": str(e)[:200]}
+    # (d) the REFERENCE'S OWN process_frame text (main.c:908-1005 with mlv_get_frame_headers, get_image_data, the index walk and the
+    # fopen of every chunk per frame, sliced out of main.c / resource_manager.c by oracle/Makefile) linked against the library:
+    # plainly, and with the wrap shim.  File reads (page cache) included.  oracle/_ref/ref_host_* travel as binaries.
+    try:
+        import shutil
+        import tempfile
+        from mlvfs_amd import mlvfile
+        hosts = {k: os.path.join(ROOT, "oracle", "_ref", "ref_host_" + k) for k in ("amd", "amd_wrap")}
+        if all(os.path.exists(h) for h in hosts.values()):
+            d = tempfile.mkdtemp(prefix="mlvfs_amd_bench_")
+            try:
+                nfr = 32
+                pl = [synth.pack14(synth.normal_frame(W, H, seed=1, frame=k % 2)).astype("<u2").tobytes() + b"\0" * 4 for k in range(nfr)]
+                mlvfile.write_clip(os.path.join(d, "B01-0001.MLV"), pl, W, H, chunks=2)
+                vp = ["/B01-0001.MLV/B01-0001_%06d.dng" % k for k in range(nfr)]
+                rh = {}
+                for k, exe in hosts.items():
+                    r = subprocess.run([exe, d, "-", "cs=5", "badpix=1", "stripes=1", f"threads={threads}", "loops=2", "--", *vp],
+                                       capture_output=True, text=True, timeout=300, env=dict(os.environ, MLVFS_AMD_RESIDENT="0"))
+                    line = [ln for ln in r.stderr.splitlines() if ln.startswith("{")]
+                    rh[k] = json.loads(line[-1])["fps"] if line else f"failed rc {r.returncode}"
+                res["reference_process_frame_text_host"] = {f"fps_{threads}_threads_plain_link": rh["amd"], f"fps_{threads}_threads_wrap_link": rh["amd_wrap"],
+                                                            "includes": "mlv_get_frame_headers + index walk + fopen/fread of a 32-frame two-chunk clip per frame (page cache)"}
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+        else:
+            res["reference_process_frame_text_host"] = {"skipped": "oracle/_ref/ref_host_* not built"}
+    except Exception as e:
+        res["reference_process_frame_text_host"] = {"failed": str(e)[:200]}
     res["note"] = "resident1: MLVFS_AMD_RESIDENT=1, a stage takes up the device copy the previous stage left for the same host buffer " \
                   "(upload skipped; every call still downloads what it changed before it returns).  wrap: the host is linked with " \
                   "integration/mlvfs_amd_wrap.c and -Wl,--wrap=mlvfs_load_chunks -Wl,--wrap=mlvfs_close_chunks -- no source line of the " \

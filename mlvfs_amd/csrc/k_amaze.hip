@@ -641,8 +641,9 @@ int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green,
     const int step = AMAZE_TS - 32;
     const int tiles_x = (w + 16 + step - 1) / step, tiles_y = (h + 16 + step - 1) / step;
     const int cc1_last = w + 16 - (-16 + (tiles_x - 1) * step), rr1_last = h + 16 - (-16 + (tiles_y - 1) * step);
+    static const int threads = [] { const char *e = getenv("MLVFS_AMD_AMAZE_THREADS"); const int v = e ? atoi(e) : 1024; return v >= 64 && v <= 1024 ? v / 64 * 64 : 1024; }();
     auto launch = [&](int row0, int nrows, int wgs_per_row, int chain_len, int rows_per_wg, int copy_from) {
-        hipLaunchKernelGGL(k_amaze, dim3(nrows * wgs_per_row, nframes), dim3(1024), 0, s, d_raw, w, h, d_red, d_green, d_blue, d_scratch, tiles_x,
+        hipLaunchKernelGGL(k_amaze, dim3(nrows * wgs_per_row, nframes), dim3(threads), 0, s, d_raw, w, h, d_red, d_green, d_blue, d_scratch, tiles_x,
                            row0, wgs_per_row, chain_len, rows_per_wg, copy_from, plane_stride, scratch_stride, h_of, h_stride);
     };
     // incomplete tiles at the right end of a row, chained behind the last complete one
