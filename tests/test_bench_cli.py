@@ -53,6 +53,24 @@ def test_bench_gpus2_starts_two_ranks_rehearsal(gpu):
     assert res["roofline"]["frac"] and res["value"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_gpus4_rehearsal_weak_and_strong(gpu):
+    """Four ranks on the one card (gloo; the box allows six processes on its GPU, this pytest process is one of them, so the
+    8-rank run of BASELINE.json configs[4] is rehearsed with 4 here and with 8 CPU-only ranks in tests/test_dist.py): the frame
+    ranges, the row-sharded histogram over four shards, the broadcast of the pixel map, the strong-scaling pass."""
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["full_size"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MLVFS_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--steps", "2", "--warmup", "1", "--frames-per-step", "6", "--preheat-ms", "20",
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert res["n_gpus"] == 4 and res["config"]["parallelism"] == "frames x4" and res["scaling"] == "weak"
+    assert res["config"]["stripe_coeffs"] == golden["B_cs5_badpix_stripes_coeffs"] and res["parity"]["ok"] is True
+    st = res["config"]["strong_scaling"]
+    assert st["frames_total"] == 12 and st["frames_per_rank"] == [3, 3, 3, 3] and st["fps"] > 0
+
+
 def _nccl_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist

@@ -42,7 +42,7 @@ def _worker(rank, world, port, w, h, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])                  # 8: the rank count of BASELINE.json configs[4] (one 8-GPU node)
 def test_row_sharded_stripes_over_gloo(oracle, world):
     from mlvfs_amd import synth
     w, h = 256, 130

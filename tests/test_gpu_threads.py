@@ -6,7 +6,7 @@ import threading
 import numpy as np
 import pytest
 
-from mlvfs_amd import abi, pipeline, synth
+from mlvfs_amd import abi, lib, pipeline, synth
 
 pytestmark = pytest.mark.gpu
 BLACK, WHITE = synth.BLACK, synth.WHITE
@@ -215,3 +215,40 @@ def test_host_buffer_pool(gpu):
     assert set(again) == {a, b}
     for p in again:
         gpu.mlvfs_amd_host_free(p)
+
+
+def test_drop_in_threads_spread_over_all_visible_gpus(gpu, oracle):
+    """host threads that never called mlvfs_amd_init are bound round-robin to the visible GPUs (the
+    frame-parallel multi-GPU mode of the drop-in path: runtime.cpp thread_ctx).  Sixteen workers, each through process_frame's
+    sequence with the frame bracket, must all deliver the oracle's frame whichever card served them.  Needs two devices (the
+    8-GPU node of BASELINE.json configs[4]); on the one-GPU box the same code path is test_process_frame_from_many_threads."""
+    import threading
+    n_dev = gpu.mlvfs_amd_device_count()
+    if n_dev < 2:
+        pytest.skip("needs at least two HIP devices")
+    w, h = 416, 264
+    f = synth.normal_frame(w, h, seed=77, hot=40, cold=40)
+    want = oracle.chroma_smooth(oracle.fix_bad_pixels(f, BLACK, 0, 0), BLACK, 5)
+    packed = synth.pack_bits(f)
+    got, errs = {}, []
+
+    def worker(i):
+        try:
+            fh = abi.make_frame_headers(w, h, black=BLACK, white=WHITE)
+            fh.file_hdr.fileGuid = 0                                   # every frame detects its own bad pixels: no shared state
+            for rep in range(3):
+                gpu.mlvfs_amd_frame_begin()
+                img = pipeline.get_image_data(fh, packed).reshape(h, w)
+                gpu.fix_bad_pixels(C.byref(fh), lib.ptr(img), 0, 0)
+                gpu.chroma_smooth(C.byref(fh), lib.ptr(img), 5)
+                assert gpu.mlvfs_amd_frame_end() == 0
+                got[i] = img
+        except Exception as e:                                         # noqa: BLE001 - reported below
+            errs.append((i, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(16)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for i in range(16):
+        assert np.array_equal(got[i], want), i
