@@ -34,9 +34,14 @@ template <bool PACKED>
 __device__ __forceinline__ int fetch_px(const uint8_t *frame, int pos)
 {
     if (PACKED) {
+        // the two 16-bit words that hold the pixel as ONE 32-bit load (2-byte aligned: global memory takes that), halves swapped
+        // back into stream order: a lane-wide gather costs the texture addresser the same for 2 or 4 bytes, and a dense map
+        // (a focus-pixel map: 150 000 entries x 12 taps) is bound by exactly those gathers
         const uint16_t *s = (const uint16_t *)frame;
         const size_t bit = (size_t)pos * 14;
-        const uint32_t two = ((uint32_t)s[bit >> 4] << 16) | s[(bit >> 4) + 1];
+        uint32_t v;
+        __builtin_memcpy(&v, s + (bit >> 4), 4);
+        const uint32_t two = (v << 16) | (v >> 16);
         return (int)((two >> (32 - 14 - (bit & 15))) & 0x3FFFu);
     }
     return ((const uint16_t *)frame)[pos];
@@ -80,22 +85,33 @@ __device__ __forceinline__ int repair_value(int kind, int black, const uint16_t 
 // Level 0 -- entries none of whose taps was rewritten by an earlier entry; on a real map (isolated hot pixels, the regular grid
 // of a focus-pixel map) that is all of them, tens of thousands per frame for some cameras -- has no order to keep: one lane per
 // entry and frame over the whole grid.
+// The raw2ev table (16 KiB) is staged in LDS -- twelve look-ups per cross-shaped repair that would otherwise be twelve more
+// gathers through the texture path -- and a workgroup takes FLAT_PER_WG entries so that the copy is paid once per 1024 entries.
+constexpr int FLAT_PER_WG = 1024;
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_pixfix_flat(const uint8_t *__restrict__ frames, size_t stride, int w, int black,
                                                      const PixEntry *__restrict__ entries, int n_level0, int n_entries,
                                                      int2 *__restrict__ patches, const uint16_t *__restrict__ t16,
                                                      const uint16_t *__restrict__ u16)
 {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= n_level0) return;
-    const uint8_t *frame = frames + (size_t)blockIdx.y * stride;
-    const int pos = entries[m].pos, kind = entries[m].kind, emit = entries[m].emit;
-    int val = 0;
-    if (kind != 0) {
-        auto tap = [&](int t) { return fetch_px<PACKED>(frame, pos + tap_offset(t, w)); };
-        val = repair_value(kind, black, t16, u16, tap) & 0xFFFF;
+    __shared__ uint16_t s_t16[MLV_T16_N];
+    {
+        const uint4 *src = (const uint4 *)t16;
+        uint4 *dst = (uint4 *)s_t16;
+        for (int i = threadIdx.x; i < MLV_T16_N * 2 / 16; i += blockDim.x) dst[i] = src[i];
     }
-    patches[(size_t)blockIdx.y * n_entries + m] = make_int2((kind != 0 && emit) ? pos : -1, val);
+    __syncthreads();
+    const uint8_t *frame = frames + (size_t)blockIdx.y * stride;
+    const int m_end = min((int)(blockIdx.x + 1) * FLAT_PER_WG, n_level0);
+    for (int m = blockIdx.x * FLAT_PER_WG + threadIdx.x; m < m_end; m += blockDim.x) {
+        const int pos = entries[m].pos, kind = entries[m].kind, emit = entries[m].emit;
+        int val = 0;
+        if (kind != 0) {
+            auto tap = [&](int t) { return fetch_px<PACKED>(frame, pos + tap_offset(t, w)); };
+            val = repair_value(kind, black, (const uint16_t *)s_t16, u16, tap) & 0xFFFF;
+        }
+        patches[(size_t)blockIdx.y * n_entries + m] = make_int2((kind != 0 && emit) ? pos : -1, val);
+    }
 }
 
 // The levels above: one workgroup per frame, levels separated by workgroup barriers (few entries: pairs of bad pixels within
@@ -143,7 +159,7 @@ int launch_pixfix(bool packed, const void *frames, size_t stride, int w, int bla
                   size_t scatter_stride, int nframes, const DeviceLuts &luts, hipStream_t stream)
 {
     if (n_entries <= 0 || nframes <= 0) return MLVFS_AMD_OK;
-    const dim3 flat((n_level0 + 255) / 256, nframes), all((n_entries + 255) / 256, nframes);
+    const dim3 flat((n_level0 + FLAT_PER_WG - 1) / FLAT_PER_WG, nframes), all((n_entries + 255) / 256, nframes);
     if (packed) {
         if (n_level0 > 0)
             hipLaunchKernelGGL(k_pixfix_flat<true>, flat, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
