@@ -47,7 +47,7 @@ if os.environ.get("PS_REAL", "1") == "1":
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
     import focus_maps
     from mlvfs_amd import synth
-    for name in ("80000331_1808x727", "80000346_1808x727", "80000346_1872x1060", "80000346_2592x1108"):
+    for name in (os.environ["PS_ONLY"],) if os.environ.get("PS_ONLY") else ("80000331_1808x727", "80000346_1808x727", "80000346_1872x1060", "80000346_2592x1108"):
         raw_w, raw_h = (int(v) for v in name.split("_")[1].split("x"))
         w, h = (raw_w - 80) // 16 * 16, (raw_h - 30) // 2 * 2
         xy = focus_maps.load(name)
