@@ -670,6 +670,8 @@ __global__ __launch_bounds__(256) void k_di_blend(const uint32_t *__restrict__ d
 // the two to agree value by value.
 namespace {
 
+constexpr int DNT = 1024;                                  // threads of a decision workgroup (one per frame: latency is what it costs)
+
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *sh)
 {
 #pragma unroll
@@ -677,7 +679,10 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
+    unsigned long long r = 0;
+    for (int k = 0; k < DNT / 64; k++) r += sh[k];
+    __syncthreads();
+    return r;
 }
 __device__ __forceinline__ long long block_min_i64(long long v, long long *sh)
 {
@@ -686,36 +691,37 @@ __device__ __forceinline__ long long block_min_i64(long long v, long long *sh)
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    const long long a = sh[0] < sh[1] ? sh[0] : sh[1], b = sh[2] < sh[3] ? sh[2] : sh[3];
-    return a < b ? a : b;
-}
-// exclusive prefix of one value per thread (256 threads), total in *total
-__device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long v, unsigned long long *sh, unsigned long long *total)
-{
-    __syncthreads();
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const unsigned long long t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
-    }
-    if (total) *total = sh[255];
-    const unsigned long long r = sh[threadIdx.x] - v;
+    long long r = sh[0];
+    for (int k = 1; k < (int)blockDim.x / 64; k++) r = sh[k] < r ? sh[k] : r;
     __syncthreads();
     return r;
 }
-// in place: hist[0..n) -> C[r] = sum of hist[v], v < r, for r = 0..n (n + 1 words, the array has room); 256 threads, n % 256 == 0
+// exclusive prefix of one value per thread (DNT threads), total in *total: per wave by shuffles, the waves' sums in LDS
+__device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long v, unsigned long long *sh, unsigned long long *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    __syncthreads();
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+    for (int k = 0; k < DNT / 64; k++) { const unsigned long long t = sh[k]; if (k < wv) base += t; tot += t; }
+    if (total) *total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+// in place: hist[0..n) -> C[r] = sum of hist[v], v < r, for r = 0..n (n + 1 words, the array has room); DNT threads, n % DNT == 0
 __device__ void block_prefix_in_place(unsigned *hist, int n, unsigned long long *sh)
 {
-    const int per = n / 256, i0 = threadIdx.x * per;
+    const int per = n / DNT, i0 = threadIdx.x * per;
     unsigned long long s = 0;
     for (int i = 0; i < per; i++) s += hist[i0 + i];
     unsigned long long tot;
     unsigned long long run = block_excl_scan(s, sh, &tot);
     for (int i = 0; i < per; i++) { const unsigned v = hist[i0 + i]; hist[i0 + i] = (unsigned)run; run += v; }
-    if (threadIdx.x == 255) hist[n] = (unsigned)run;
+    if (threadIdx.x == DNT - 1) hist[n] = (unsigned)run;
     __syncthreads();
 }
 // smallest r in [0, n] with C[r] >= ref, n if none (C non-decreasing, n + 1 entries)
@@ -727,10 +733,10 @@ __device__ __forceinline__ int quantile_of(const unsigned *C, int n, long long r
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((long long)C[mid] >= ref) hi = mid; else lo = mid; }
     return hi;
 }
-// first index i (ascending) with sum of hist[0..i] > k, bins - 1 if none: kth_from_hist of dualiso.cpp; 256 threads, bins % 256 == 0
+// first index i (ascending) with sum of hist[0..i] > k, bins - 1 if none: kth_from_hist of rounds 1-2's host code; DNT threads, bins % DNT == 0
 __device__ int block_kth_from_hist(const unsigned *hist, int bins, long long k, unsigned long long *sh, int *sh_i)
 {
-    const int per = bins / 256, i0 = threadIdx.x * per;
+    const int per = bins / DNT, i0 = threadIdx.x * per;
     unsigned long long s = 0;
     for (int i = 0; i < per; i++) s += hist[i0 + i];
     unsigned long long tot;
@@ -754,11 +760,11 @@ constexpr size_t DI_DERIVED_WORDS = 4 * 16384 + 4 * 16385 + 3 + 2 * 32768;
 
 // analyse()'s host half, the pattern, the bright / dark fields and the white levels of dualiso.cpp (is_rggb_from_hist,
 // bright_dark_from_hist, whites_from_hist) for frame blockIdx.x; writes dd[f] and the geometry part of pp[f]
-__global__ __launch_bounds__(256) void k_di_decide_pattern(const uint16_t *__restrict__ frames, size_t img_stride, int w, int H, int black14,
+__global__ __launch_bounds__(DNT) void k_di_decide_pattern(const uint16_t *__restrict__ frames, size_t img_stride, int w, int H, int black14,
                                                            DiDecideBuffers D)
 {
-    __shared__ unsigned long long sh[256];
-    __shared__ long long shl[4];
+    __shared__ unsigned long long sh[DNT / 64];
+    __shared__ long long shl[DNT / 64];
     __shared__ int sh_i, s_rggb, s_bright[4], s_rows[512][2], s_nrows;
     const int f = blockIdx.x, tid = threadIdx.x;
     const uint16_t *frame = (const uint16_t *)((const uint8_t *)frames + (size_t)f * img_stride);
@@ -772,17 +778,17 @@ __global__ __launch_bounds__(256) void k_di_decide_pattern(const uint16_t *__res
         dd.check_ok = D.check_passed || (dd.check_n > 0 && dd.check_sum / dd.check_n > 0.5);      // hdr.c:432-438
     }
     // ---- the four Bayer-phase histograms over rows [0, H / 4 * 4) (hdr.c:453): all rows' classes minus the rows below that range
-    for (int i = tid; i < 4 * 16384; i += 256) {
+    for (int i = tid; i < 4 * 16384; i += DNT) {
         const int k = i >> 14, v = i & 16383, qb = k >> 1, px = k & 1;
         hb[i] = dev[DI_D_CLASS + (size_t)(qb * 2 + px) * 16384 + v] + dev[DI_D_CLASS + (size_t)((qb + 2) * 2 + px) * 16384 + v];
     }
     __syncthreads();
     const int R0 = H / 4 * 4, R1 = (H - 1) / 4 * 4;
     for (int y = R0; y < H; y++)
-        for (int x = tid; x < w; x += 256) atomicSub(&hb[(size_t)((y & 1) * 2 + (x & 1)) * 16384 + (frame[(size_t)y * w + x] & 16383)], 1u);
+        for (int x = tid; x < w; x += DNT) atomicSub(&hb[(size_t)((y & 1) * 2 + (x & 1)) * 16384 + (frame[(size_t)y * w + x] & 16383)], 1u);
     __syncthreads();
     {   // is_rggb_from_hist: sum over v of |acc1 - acc2| against |acc0 - acc3| (integers far below 2^53: the doubles of the host are exact)
-        const int per = 16384 / 256, i0 = tid * per;
+        const int per = 16384 / DNT, i0 = tid * per;
         unsigned long long run[4];
         for (int k = 0; k < 4; k++) {
             unsigned long long s = 0;
@@ -802,7 +808,7 @@ __global__ __launch_bounds__(256) void k_di_decide_pattern(const uint16_t *__res
     }
     const int rggb = s_rggb, ay1 = rggb ? 0 : 1, h = rggb ? H : H - 1;
     // ---- greens by row phase: the frame as it is (RGGB: x & 1 != y & 1, rows [0, R0)) or one row lower (GBRG: rows 4 <= y - 1 < R1)
-    for (int i = tid; i < 4 * 16384; i += 256) {
+    for (int i = tid; i < 4 * 16384; i += DNT) {
         const int ph = i >> 14, v = i & 16383;
         const int q = rggb ? ph : ((ph + 1) & 3);                 // GBRG: class q feeds phase (q + 3) & 3
         const int px = rggb ? 1 - (q & 1) : (q & 1);
@@ -814,7 +820,7 @@ __global__ __launch_bounds__(256) void k_di_decide_pattern(const uint16_t *__res
         const int ya = rggb ? (pass ? H : R0) : (pass ? R1 + 1 : 0), yb = rggb ? H : (pass ? H : min(5, H));
         for (int y = ya; y < yb; y++) {
             const int ph = rggb ? (y & 3) : ((y - 1) & 3);
-            for (int x = tid; x < w; x += 256)
+            for (int x = tid; x < w; x += DNT)
                 if (rggb ? ((x & 1) != (y & 1)) : ((x & 1) == (y & 1))) atomicSub(&g[(size_t)ph * 16385 + (frame[(size_t)y * w + x] & 16383)], 1u);
         }
     }
@@ -858,7 +864,7 @@ __global__ __launch_bounds__(256) void k_di_decide_pattern(const uint16_t *__res
     const int isb[4] = { s_bright[0], s_bright[1], s_bright[2], s_bright[3] };
     const uint16_t *img = frame + (size_t)ay1 * w;
     const unsigned *hw = dev + (rggb ? DI_D_WHITE0 : DI_D_WHITE1);
-    for (int i = tid; i < 2 * 32768; i += 256) {
+    for (int i = tid; i < 2 * 32768; i += DNT) {
         const int c = i >> 15, v = i & 32767;
         unsigned s = 0;
         for (int ph = 0; ph < 4; ph++) if (isb[ph] == c) s += hw[(size_t)ph * 32768 + v];
@@ -883,7 +889,7 @@ __global__ __launch_bounds__(256) void k_di_decide_pattern(const uint16_t *__res
     for (int r = 0; r < s_nrows; r++) {
         const int y = s_rows[r][0], c = isb[y % 4];
         const long long i0 = s_rows[r][1], tot = shl[c];
-        for (int sx = tid; sx < spr; sx += 256) {
+        for (int sx = tid; sx < spr; sx += DNT) {
             const long long k = i0 + sx;
             if (k >= max_pix - 1 && k <= tot - 2) {
                 const int v0 = img[(size_t)y * w + 3 * sx];
@@ -923,16 +929,16 @@ __global__ __launch_bounds__(256) void k_di_decide_pattern(const uint16_t *__res
 }
 
 // medians and percentiles of match_exposures from its two histograms (hdr.c:700-733; dualiso.cpp: kth_from_hist)
-__global__ __launch_bounds__(256) void k_di_decide_quantiles(DiDecideBuffers D)
+__global__ __launch_bounds__(DNT) void k_di_decide_quantiles(DiDecideBuffers D)
 {
-    __shared__ unsigned long long sh[256];
+    __shared__ unsigned long long sh[DNT / 64];
     __shared__ int sh_i;
     const int f = blockIdx.x;
     const unsigned *hb = D.hist_bd + (size_t)f * 2 * DI_HIST_N, *hd = hb + DI_HIST_N;
     DiDecide &dd = D.dd[f];
     if (D.pp[f].h <= 0) return;
     unsigned long long s = 0;
-    for (int i = threadIdx.x; i < DI_HIST_N; i += 256) s += hb[i];
+    for (int i = threadIdx.x; i < DI_HIST_N; i += DNT) s += hb[i];
     const long long n = (long long)block_sum_u64(s, sh);
     const long long mk = (n & 1) ? n / 2 : n / 2 - 1;
     int bmed = 0, b_lo = 0, b_hi = 0, dmed = 0;
@@ -1153,13 +1159,13 @@ size_t di_derived_words() { return DI_DERIVED_WORDS; }
 
 int di_launch_decide_pattern(const void *d_frames, const DiBatch &b, int H, int black14, const DiDecideBuffers &D, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_di_decide_pattern, dim3(b.nframes), dim3(256), 0, s, (const uint16_t *)d_frames, b.img_stride, b.p0.w, H, black14, D);
+    hipLaunchKernelGGL(k_di_decide_pattern, dim3(b.nframes), dim3(DNT), 0, s, (const uint16_t *)d_frames, b.img_stride, b.p0.w, H, black14, D);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
 int di_launch_decide_quantiles(const DiBatch &b, const DiDecideBuffers &D, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_di_decide_quantiles, dim3(b.nframes), dim3(256), 0, s, D);
+    hipLaunchKernelGGL(k_di_decide_quantiles, dim3(b.nframes), dim3(DNT), 0, s, D);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
