@@ -951,25 +951,56 @@ __global__ __launch_bounds__(DNT) void k_di_decide_quantiles(DiDecideBuffers D)
     if (threadIdx.x == 0) { dd.n = n; dd.bmed = bmed; dd.b_lo = b_lo; dd.b_hi = b_hi; dd.dmed = dmed; }
 }
 
-// what every sample row contributes to the list of highlight pairs and where (hdr.c:735-746: the cap leaves only the inner loop)
-__global__ __launch_bounds__(64) void k_di_decide_rows(DiDecideBuffers D)
+// what every sample row contributes to the list of highlight pairs and where (hdr.c:735-746: the cap leaves only the inner loop).
+// Sequentially: take = min(count, max(hi_nmax - hi_n, 1)); hi_n += take.  In closed form over the exclusive prefix P of the counts:
+// a row takes all of its samples while P + count <= hi_nmax, the row that crosses takes what is left, and every row after the list
+// is full still takes one sample if it has any.
+__global__ __launch_bounds__(256) void k_di_decide_rows(DiDecideBuffers D)
 {
-    const int f = blockIdx.x;
+    __shared__ int s_tot[4];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const DiParams p = D.pp[f];
-    if (p.h <= 0 || threadIdx.x != 0) return;
+    if (p.h <= 0) return;
     int *counts = D.rows + (size_t)f * 3 * D.nsy_max, *take = counts + D.nsy_max, *offset = take + D.nsy_max;
     const int nsy = di_nsy(p), nmax = (p.w + 2) * (p.h + 2) / 9, hi_nmax = nmax / 50;
-    int hi_n = 0;
-    if (D.dd[f].n > 0)
-        for (int sy = 0; sy < nsy; sy++) {
-            const int t = min(counts[sy], max(hi_nmax - hi_n, 1));
+    const bool any = D.dd[f].n > 0;
+    // two scans in one sweep: P = samples before the row; Q = rows before it that have samples AND start at or behind the cap
+    int base_p = 0, base_q = 0;
+    for (int r0 = 0; r0 < nsy; r0 += 256) {
+        const int sy = r0 + tid;
+        const int c = (any && sy < nsy) ? counts[sy] : 0;
+        int incp = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incp, o); if (lane >= o) incp += u; }
+        if (lane == 63) s_tot[wv] = incp;
+        __syncthreads();
+        int wp = 0, tot = 0;
+        for (int k = 0; k < 4; k++) { if (k < wv) wp += s_tot[k]; tot += s_tot[k]; }
+        const int P = base_p + wp + incp - c;                          // exclusive prefix of this row
+        __syncthreads();
+        // rows at or behind the cap: P >= hi_nmax (hi_n has reached the cap exactly when the prefix has)
+        const int late = (P >= hi_nmax && c > 0) ? 1 : 0;
+        int incq = late;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incq, o); if (lane >= o) incq += u; }
+        if (lane == 63) s_tot[wv] = incq;
+        __syncthreads();
+        int wq = 0, totq = 0;
+        for (int k = 0; k < 4; k++) { if (k < wv) wq += s_tot[k]; totq += s_tot[k]; }
+        const int Q = base_q + wq + incq - late;
+        __syncthreads();
+        if (sy < nsy) {
+            int t, o;
+            if (P + c <= hi_nmax) { t = c; o = P; }                      // fits entirely
+            else if (P < hi_nmax) { t = hi_nmax - P; o = P; }              // the row that fills the list
+            else { t = min(c, 1); o = hi_nmax + Q; }                       // the list is full: one sample per row that has any
             take[sy] = t;
-            offset[sy] = hi_n;
-            hi_n += t;
+            offset[sy] = o;
         }
-    else
-        for (int sy = 0; sy < nsy; sy++) { take[sy] = 0; offset[sy] = 0; }
-    D.dd[f].hi_n = hi_n;
+        base_p += tot;
+        base_q += totq;
+    }
+    if (tid == 0) D.dd[f].hi_n = any ? (base_p <= hi_nmax ? base_p : hi_nmax + base_q) : 0;
 }
 
 // the winning slope: the FIRST candidate with the highest score, if that score is above zero (hdr.c:764-771)
@@ -1171,7 +1202,7 @@ int di_launch_decide_quantiles(const DiBatch &b, const DiDecideBuffers &D, hipSt
 }
 int di_launch_decide_rows(const DiBatch &b, const DiDecideBuffers &D, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_di_decide_rows, dim3(b.nframes), dim3(64), 0, s, D);
+    hipLaunchKernelGGL(k_di_decide_rows, dim3(b.nframes), dim3(256), 0, s, D);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
