@@ -86,11 +86,15 @@ __device__ __forceinline__ int repair_value(int kind, int black, const uint16_t 
 // of a focus-pixel map) that is all of them, tens of thousands per frame for some cameras -- has no order to keep: one lane per
 // entry and frame over the whole grid.
 // The raw2ev table (16 KiB) is staged in LDS -- twelve look-ups per cross-shaped repair that would otherwise be twelve more
-// gathers through the texture path -- and a workgroup takes FLAT_PER_WG entries so that the copy is paid once per 1024 entries.
+// gathers through the texture path --; a workgroup takes FLAT_PER_WG entries, reads them ONCE (8 bytes each: the compact list
+// that clip.cpp puts behind the entries) and walks the frames of its share of the batch with them in registers.
 constexpr int FLAT_PER_WG = 1024;
+// frames one workgroup walks with its entries / records in registers: as many as leave the launch with some 4000 workgroups (a
+// sparse map on a short batch keeps one frame per workgroup: the chip's parallelism is worth more than the re-reads)
+static inline int frames_per_wg(int wgs_x, int nframes) { const long long all = (long long)wgs_x * nframes; const int fr = (int)(all / 4096); return fr < 1 ? 1 : (fr > 16 ? 16 : fr); }
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_pixfix_flat(const uint8_t *__restrict__ frames, size_t stride, int w, int black,
-                                                     const PixEntry *__restrict__ entries, int n_level0, int n_entries,
+                                                     const PixEntry *__restrict__ entries, int n_level0, int n_entries, int nframes, int fpw,
                                                      int2 *__restrict__ patches, const uint16_t *__restrict__ t16,
                                                      const uint16_t *__restrict__ u16)
 {
@@ -101,16 +105,29 @@ __global__ __launch_bounds__(256) void k_pixfix_flat(const uint8_t *__restrict__
         for (int i = threadIdx.x; i < MLV_T16_N * 2 / 16; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
-    const uint8_t *frame = frames + (size_t)blockIdx.y * stride;
-    const int m_end = min((int)(blockIdx.x + 1) * FLAT_PER_WG, n_level0);
-    for (int m = blockIdx.x * FLAT_PER_WG + threadIdx.x; m < m_end; m += blockDim.x) {
-        const int pos = entries[m].pos, kind = entries[m].kind, emit = entries[m].emit;
-        int val = 0;
-        if (kind != 0) {
-            auto tap = [&](int t) { return fetch_px<PACKED>(frame, pos + tap_offset(t, w)); };
-            val = repair_value(kind, black, (const uint16_t *)s_t16, u16, tap) & 0xFFFF;
+    const int2 *flat = (const int2 *)(entries + n_entries);
+    constexpr int PER = FLAT_PER_WG / 256;
+    int2 ent[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int m = blockIdx.x * FLAT_PER_WG + k * 256 + threadIdx.x;
+        ent[k] = m < n_level0 ? flat[m] : make_int2(-1, 0);
+    }
+    const int f_end = min((int)(blockIdx.y + 1) * fpw, nframes);
+    for (int f = blockIdx.y * fpw; f < f_end; f++) {
+        const uint8_t *frame = frames + (size_t)f * stride;
+#pragma unroll 1
+        for (int k = 0; k < PER; k++) {                            // (not unrolled: four inlined repairs halve the occupancy)
+            const int m = blockIdx.x * FLAT_PER_WG + k * 256 + threadIdx.x;
+            if (m >= n_level0) continue;
+            const int pos = ent[k].x, kind = ent[k].y & 0xFF, emit = ent[k].y >> 8;
+            int val = 0;
+            if (kind != 0) {
+                auto tap = [&](int t) { return fetch_px<PACKED>(frame, pos + tap_offset(t, w)); };
+                val = repair_value(kind, black, (const uint16_t *)s_t16, u16, tap) & 0xFFFF;
+            }
+            patches[(size_t)f * n_entries + m] = make_int2((kind != 0 && emit) ? pos : -1, val);
         }
-        patches[(size_t)blockIdx.y * n_entries + m] = make_int2((kind != 0 && emit) ? pos : -1, val);
     }
 }
 
@@ -159,18 +176,19 @@ int launch_pixfix(bool packed, const void *frames, size_t stride, int w, int bla
                   size_t scatter_stride, int nframes, const DeviceLuts &luts, hipStream_t stream)
 {
     if (n_entries <= 0 || nframes <= 0) return MLVFS_AMD_OK;
-    const dim3 flat((n_level0 + FLAT_PER_WG - 1) / FLAT_PER_WG, nframes), all((n_entries + 255) / 256, nframes);
+    const int flat_x = (n_level0 + FLAT_PER_WG - 1) / FLAT_PER_WG, fpw = frames_per_wg(flat_x, nframes);
+    const dim3 flat(flat_x, (nframes + fpw - 1) / fpw), all((n_entries + 255) / 256, nframes);
     if (packed) {
         if (n_level0 > 0)
             hipLaunchKernelGGL(k_pixfix_flat<true>, flat, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
-                               (const PixEntry *)entries, n_level0, n_entries, (int2 *)patches, luts.t16, luts.u16);
+                               (const PixEntry *)entries, n_level0, n_entries, nframes, fpw, (int2 *)patches, luts.t16, luts.u16);
         if (n_levels > 1)
             hipLaunchKernelGGL(k_pixfix<true>, dim3(nframes), dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
                                (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches, luts.t16, luts.u16);
     } else {
         if (n_level0 > 0)
             hipLaunchKernelGGL(k_pixfix_flat<false>, flat, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
-                               (const PixEntry *)entries, n_level0, n_entries, (int2 *)patches, luts.t16, luts.u16);
+                               (const PixEntry *)entries, n_level0, n_entries, nframes, fpw, (int2 *)patches, luts.t16, luts.u16);
         if (n_levels > 1)
             hipLaunchKernelGGL(k_pixfix<false>, dim3(nframes), dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
                                (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches, luts.t16, luts.u16);
@@ -185,35 +203,42 @@ int launch_pixfix(bool packed, const void *frames, size_t stride, int w, int bla
 // The fused kernel (k_frame.hip) takes the repair cell by cell: the four pixels of every Bayer cell that holds a repaired pixel
 // -- the repaired ones from the patch list, the others from the frame --, in the order of its per-tile lists.  One lane per
 // listed cell and frame; the kernel then reads one 16-byte record per cell and never looks at the patch list.
+// (a lane reads its record once and walks the frames of its share of the batch: the records are 20 bytes each, 190 000 of them for
+// the densest focus-pixel map)
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_pixfix_cells(const uint8_t *__restrict__ frames, size_t stride, int w, int h,
-                                                      const CellRec *__restrict__ recs, int n_rec,
+                                                      const CellRec *__restrict__ recs, int n_rec, int nframes, int fpw,
                                                       const int2 *__restrict__ patches, int n_entries, int4 *__restrict__ cells)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rec) return;
-    const uint8_t *frame = frames + (size_t)blockIdx.y * stride;
     const CellRec rec = recs[r];
     const int cx = rec.cell & 0xFFFF, cy = rec.cell >> 16;
-    int v[4];
+    int pos[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int x = min(2 * cx + (q & 1), w - 1), y = min(2 * cy + (q >> 1), h - 1);
-        v[q] = rec.e[q] >= 0 ? (patches[(size_t)blockIdx.y * n_entries + rec.e[q]].y & 0xFFFF) : fetch_px<PACKED>(frame, y * w + x);
+    for (int q = 0; q < 4; q++) pos[q] = min(2 * cy + (q >> 1), h - 1) * w + min(2 * cx + (q & 1), w - 1);
+    const int f_end = min((int)(blockIdx.y + 1) * fpw, nframes);
+    for (int f = blockIdx.y * fpw; f < f_end; f++) {
+        const uint8_t *frame = frames + (size_t)f * stride;
+        int v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            v[q] = rec.e[q] >= 0 ? (patches[(size_t)f * n_entries + rec.e[q]].y & 0xFFFF) : fetch_px<PACKED>(frame, pos[q]);
+        cells[(size_t)f * n_rec + r] = make_int4(rec.cell, v[0] | (v[1] << 16), v[2] | (v[3] << 16), 0);
     }
-    cells[(size_t)blockIdx.y * n_rec + r] = make_int4(rec.cell, v[0] | (v[1] << 16), v[2] | (v[3] << 16), 0);
 }
 
 int launch_pixfix_cells(bool packed, const void *frames, size_t stride, int w, int h, const CellRec *recs, int n_rec,
                         const void *patches, int n_entries, void *cells, int nframes, hipStream_t stream)
 {
     if (n_rec <= 0 || nframes <= 0) return MLVFS_AMD_OK;
-    const dim3 grid((n_rec + 255) / 256, nframes);
+    const int fpw = frames_per_wg((n_rec + 255) / 256, nframes);
+    const dim3 grid((n_rec + 255) / 256, (nframes + fpw - 1) / fpw);
     if (packed)
-        hipLaunchKernelGGL(k_pixfix_cells<true>, grid, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, h, recs, n_rec,
+        hipLaunchKernelGGL(k_pixfix_cells<true>, grid, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, h, recs, n_rec, nframes, fpw,
                            (const int2 *)patches, n_entries, (int4 *)cells);
     else
-        hipLaunchKernelGGL(k_pixfix_cells<false>, grid, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, h, recs, n_rec,
+        hipLaunchKernelGGL(k_pixfix_cells<false>, grid, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, h, recs, n_rec, nframes, fpw,
                            (const int2 *)patches, n_entries, (int4 *)cells);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
