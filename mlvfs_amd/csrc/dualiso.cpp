@@ -475,6 +475,13 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
     MLV_HIP(hipStreamSynchronize(stream));                  // <- the round trip of the batch
     pt.mark("decisions (device) + D2H");
 
+    if (getenv("MLVFS_AMD_DI_DEBUG"))
+        for (int f = 0; f < nframes; f++) {
+            const DiDecide &d = dd[f];
+            fprintf(stderr, "[di] frame %d: check %.6g/%.6g ok %d rggb %d bright %d%d%d%d raw %d %d %d %d whites %d %d n %lld bmed %d b_lo %d b_hi %d dmed %d hi_n %d best %d (%d)\n",
+                    f, d.check_sum, d.check_n, d.check_ok, d.rggb, d.is_bright[0], d.is_bright[1], d.is_bright[2], d.is_bright[3], d.bd_raw[0], d.bd_raw[1],
+                    d.bd_raw[2], d.bd_raw[3], d.white_dark, d.white_bright, d.n, d.bmed, d.b_lo, d.b_hi, d.dmed, d.hi_n, d.best, d.best_score);
+        }
     // ---- host: checks, libm scalars, progress lines; the tables of the first frame that converts
     int nconv = 0;
     bt.nheights = 0;

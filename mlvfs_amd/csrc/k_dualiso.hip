@@ -832,8 +832,7 @@ __global__ __launch_bounds__(DNT) void k_di_decide_pattern(const uint16_t *__res
     if (tid == 0) {
         const unsigned *C[4] = { g, g + 16385, g + 2 * 16385, g + 3 * 16385 };
         const int white = 10000;
-        long long total = 0;
-        for (int k = 0; k < 4; k++) total += C[k][16384];
+        const long long total = C[0][16384];               // hdr.c:553-555: the count of the FIRST row phase stands for all four
         const int ref_max = (int)(total * 0.998), ref_off = (int)(total * 0.05);
         int raw[4] = { 0, 0, 0, 0 }, off[4] = { 0, 0, 0, 0 };
         if (ref_max > 0) {
