@@ -260,3 +260,17 @@ def test_cr2hdr20_batch_full_size(gpu):
     assert list(res) == [1, 1, 1]
     for g in got:
         assert fnv1a(g) == full["dualiso_3584x1320_i0_f1_a1_cs0"]
+
+
+def test_cr2hdr20_batch_decisions_on_random_material(gpu):
+    """tools/dualiso_decision_sweep.py: mixed batches of random material -- ISO ratios 1..16, scenes from deep shadow to mostly
+    clipped, noise, black levels 512..2049, any of the four bright-row phases, GBRG-like starts, normal / flat / noise frames that
+    are no dual ISO -- through the batch entry point against the checker, results and pixels frame by frame.  (The first run of
+    this sweep found what the fixed frames could not: the bright / dark walk takes ONE row phase's count as its total,
+    hdr.c:553-555.)  A fixed seed here; the tool takes any."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dualiso_decision_sweep.py"), "11", "60"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 mismatches" in r.stderr, r.stderr[-3000:]
