@@ -285,6 +285,9 @@ int mlvfs_amd_cr2hdr20_dev(const mlvfs_amd_geom_t *geom, void *d_frame, int inte
 int mlvfs_amd_cr2hdr20_batch_dev(const mlvfs_amd_geom_t *geom, void *d_frames, size_t stride, int nframes, int interp_method,
                                  int fullres, int use_alias_map, int chroma_smooth, int *results, void *stream);
 void mlvfs_amd_dualiso_reset(void);
+/* gives back the dual-ISO work memory the calling thread holds (it grows with the largest batch and is otherwise kept until the
+ * thread ends) */
+void mlvfs_amd_dualiso_trim(void);
 /* the global decisions of the calling thread's last conversion: {RGGB?, is_bright[0..3] as bits 3..0, white, white of the bright
  * rows (20 bit), a, b of the exposure fit (hdr.c:638-823), ISO difference in EV, darkened white} */
 void mlvfs_amd_dualiso_last_scalars(double out[8]);
