@@ -246,6 +246,12 @@ int    mlvfs_amd_mlv_read_frames(const void *reader, int first, int count, void 
  * belong to the device of the thread that first streams from it.                                                     */
 int    mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first, int count, void *h_out, size_t out_stride,
                              int cs_method, int fix_pixels, int apply_stripes, int batch_frames, int io_threads);
+/* A DUAL-ISO clip, file -> batched full conversion -> h_out (main.c:942 + 956-959 per frame, cr2hdr20 with the headers' levels):
+ * batches of batch_frames frames (<= 0: 8) are read while the previous batch is unpacked and converted in ONE submission
+ * (mlvfs_amd_cr2hdr20_batch_dev) and the batch before travels back.  results[i] = 1: frame first + i converted (black and white
+ * level 4x the headers'), 0: no dual-ISO frame, h_out holds it unpacked.  Plain and LZMA clips. */
+int    mlvfs_amd_mlv_process_dualiso(const void *reader, int first, int count, void *h_out, size_t out_stride, int interp_method,
+                                     int fullres, int use_alias_map, int chroma_smooth, int batch_frames, int io_threads, int *results);
 
 /* -- animated GIF preview (gif.c:82-244) ---------------------- */
 /* = gif_get_size: size of the preview file of a clip with these frame headers                                        */

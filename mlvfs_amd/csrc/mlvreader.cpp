@@ -78,9 +78,14 @@ struct Reader {
     mutable hipStream_t s_run = nullptr, s_down = nullptr;
     mutable hipEvent_t fin_done[2] = { nullptr, nullptr }, down_done[2] = { nullptr, nullptr };
     mutable std::mutex stage_mu;
+    // dual-ISO clips (mlvfs_amd_mlv_process_dualiso): packed payloads of one batch and two buffers of 16-bit frames in HBM
+    mutable void *d_di_packed = nullptr, *d_di_frames[2] = { nullptr, nullptr };
+    mutable size_t di_packed_bytes = 0, di_frames_bytes = 0;
 
     ~Reader()
     {
+        if (d_di_packed) (void)hipFree(d_di_packed);
+        for (int k = 0; k < 2; k++) if (d_di_frames[k]) (void)hipFree(d_di_frames[k]);
         for (int fd : fds) if (fd >= 0) close(fd);
         mlvfs_amd_host_free(stage[0]);
         mlvfs_amd_host_free(stage[1]);
@@ -520,6 +525,98 @@ int mlvfs_amd_mlv_process(const void *reader, mlvfs_amd_clip_t *clip, int first,
 
 // = gif_get_data (gif.c:82-221) on an opened clip: the animated preview of 10 frames spread over the clip, 1/4 x 1/4 size; copies
 // min(max_size, size - offset) bytes of the file from `offset` on and returns max_size like the reference, 0 on failure.
+// A dual-ISO clip, file -> host: main.c:942 + 956-959 for every frame of a clip (get_image_data, then cr2hdr20_convert_data with the
+// frame headers' levels), batched: the payloads of batch k + 1 are read into page-locked staging by the reader threads while batch k
+// is on the GPU -- upload, unpack (k_unpack), ONE submission of the batched conversion (mlvfs_amd_cr2hdr20_batch_dev) --, and the
+// finished frames of batch k travel back on their own stream under the next batch's kernels.  results[i] = 1: frame first + i was
+// converted (its black and white level are 4x the headers', hdr.c:1951-1952); 0: it is no dual ISO frame (or the detection
+// failed) and h_out holds it unpacked, as process_frame would go on with it (main.c:961-973).
+int mlvfs_amd_mlv_process_dualiso(const void *reader, int first, int count, void *h_out, size_t out_stride, int interp_method, int fullres,
+                                  int use_alias_map, int chroma_smooth, int batch_frames, int io_threads, int *results)
+{
+    if (!reader || !h_out || !results) { set_error("mlv: null argument"); return MLVFS_AMD_ERR_ARG; }
+    const Reader &r = *(const Reader *)reader;
+    if (count <= 0) return MLVFS_AMD_OK;
+    if (first < 0 || (size_t)first + (size_t)count > r.vidf.size()) { set_error("mlv: frames %d..%d outside the clip (%zu frames)", first, first + count - 1, r.vidf.size()); return MLVFS_AMD_ERR_ARG; }
+    frame_headers fh0;
+    if (!frame_headers_of(r, first, &fh0)) { set_error("mlv: frame %d has no usable headers", first); return MLVFS_AMD_ERR_ARG; }
+    if ((fh0.file_hdr.videoClass & CLASS_LJ92) && !(fh0.file_hdr.videoClass & CLASS_LZMA)) { set_error("mlv: dual-ISO batches take plain and LZMA clips"); return MLVFS_AMD_ERR_ARG; }
+    const int w = fh0.rawi_hdr.xRes, h = fh0.rawi_hdr.yRes, bpp = fh0.rawi_hdr.raw_info.bits_per_pixel;
+    const mlvfs_amd_geom_t geom{ w, h, bpp, (int32_t)fh0.rawi_hdr.raw_info.black_level, (int32_t)fh0.rawi_hdr.raw_info.white_level, 0, 0 };
+    const size_t px_bytes = (size_t)w * h * 2;
+    if (out_stride < px_bytes) { set_error("mlv: out_stride smaller than a frame"); return MLVFS_AMD_ERR_ARG; }
+    if (batch_frames <= 0) batch_frames = 8;
+    batch_frames = std::min(batch_frames, count);
+    Span s0;
+    if (!payload_span(r, first, &s0)) return MLVFS_AMD_ERR_ARG;
+    const size_t stride = (s0.bytes + 2 + 15) / 16 * 16, dstride = (px_bytes + 255) / 256 * 256;
+    mlv::ThreadCtx *c = mlv::thread_ctx();
+    if (!c) return MLVFS_AMD_ERR_HIP;
+    std::lock_guard<std::mutex> lk(r.stage_mu);                     // one streaming call per reader at a time
+    if (r.stage_bytes < stride * batch_frames) {
+        mlvfs_amd_host_free(r.stage[0]);
+        mlvfs_amd_host_free(r.stage[1]);
+        r.stage[0] = (uint8_t *)mlvfs_amd_host_alloc(stride * batch_frames);
+        r.stage[1] = (uint8_t *)mlvfs_amd_host_alloc(stride * batch_frames);
+        r.stage_bytes = (r.stage[0] && r.stage[1]) ? stride * batch_frames : 0;
+        if (!r.stage_bytes) return MLVFS_AMD_ERR_NOMEM;
+    }
+    if (r.di_packed_bytes < stride * batch_frames) {
+        if (r.d_di_packed) (void)hipFree(r.d_di_packed);
+        r.d_di_packed = nullptr; r.di_packed_bytes = 0;
+        MLV_HIP(hipMalloc(&r.d_di_packed, stride * batch_frames));
+        r.di_packed_bytes = stride * batch_frames;
+    }
+    if (r.di_frames_bytes < dstride * batch_frames) {
+        for (int k = 0; k < 2; k++) {
+            if (r.d_di_frames[k]) (void)hipFree(r.d_di_frames[k]);
+            r.d_di_frames[k] = nullptr;
+        }
+        r.di_frames_bytes = 0;
+        for (int k = 0; k < 2; k++) MLV_HIP(hipMalloc(&r.d_di_frames[k], dstride * batch_frames));
+        r.di_frames_bytes = dstride * batch_frames;
+    }
+    if (!r.s_down) {
+        MLV_HIP(hipStreamCreateWithFlags(&r.s_run, hipStreamNonBlocking));
+        MLV_HIP(hipStreamCreateWithFlags(&r.s_down, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            MLV_HIP(hipEventCreateWithFlags(&r.fin_done[k], hipEventDisableTiming));
+            MLV_HIP(hipEventCreateWithFlags(&r.down_done[k], hipEventDisableTiming));
+        }
+    }
+    uint8_t *const *stage = r.stage;
+    int rc = read_frames(r, first, batch_frames, stage[0], stride, io_threads);
+    for (int f0 = 0, k = 0; rc == MLVFS_AMD_OK && f0 < count; f0 += batch_frames, k++) {
+        const int n = std::min(batch_frames, count - f0), n_next = std::min(batch_frames, count - f0 - n), slot = k & 1;
+        int rc_io = MLVFS_AMD_OK;
+        std::thread io;                                             // the next batch is read while this one is on the GPU
+        if (n_next > 0) io = std::thread([&, k, f0, n, n_next]() { rc_io = read_frames(r, first + f0 + n, n_next, stage[(k + 1) & 1], stride, io_threads); });
+        // (no early returns in here: the reader thread of the next batch is running)
+        auto ok = [&](hipError_t e) { if (e != hipSuccess && rc == MLVFS_AMD_OK) { set_error("mlv: %s", hipGetErrorString(e)); rc = MLVFS_AMD_ERR_HIP; } };
+        ok(hipMemcpyAsync(r.d_di_packed, stage[slot], stride * n, hipMemcpyHostToDevice, r.s_run));
+        if (rc == MLVFS_AMD_OK && k >= 2) ok(hipStreamWaitEvent(r.s_run, r.down_done[slot], 0));          // this slot's frames of two batches ago are out
+        if (rc == MLVFS_AMD_OK) rc = mlvfs_amd_unpack_dev(&geom, r.d_di_packed, stride, r.d_di_frames[slot], dstride, n, r.s_run);
+        if (rc == MLVFS_AMD_OK) rc = mlvfs_amd_cr2hdr20_batch_dev(&geom, r.d_di_frames[slot], dstride, n, interp_method, fullres, use_alias_map, chroma_smooth,
+                                                                  results + f0, r.s_run);          // (returns with the stream drained)
+        if (rc == MLVFS_AMD_OK) {
+            ok(hipEventRecord(r.fin_done[slot], r.s_run));
+            ok(hipStreamWaitEvent(r.s_down, r.fin_done[slot], 0));
+            ok(hipMemcpy2DAsync((uint8_t *)h_out + (size_t)f0 * out_stride, out_stride, r.d_di_frames[slot], dstride, px_bytes, n, hipMemcpyDeviceToHost, r.s_down));
+            ok(hipEventRecord(r.down_done[slot], r.s_down));
+        }
+        if (io.joinable()) io.join();
+        if (rc == MLVFS_AMD_OK && rc_io != MLVFS_AMD_OK) {
+            set_error("mlv: prefetch of frames %d..%d failed", first + f0 + n, first + f0 + n + n_next - 1);
+            rc = rc_io;
+        }
+    }
+    if (hipStreamSynchronize(r.s_down) != hipSuccess || hipStreamSynchronize(r.s_run) != hipSuccess) {
+        set_error("mlv: copying finished frames to the host failed");
+        if (rc == MLVFS_AMD_OK) rc = MLVFS_AMD_ERR_HIP;
+    }
+    return rc;
+}
+
 static size_t gif_data(const void *reader, uint8_t *output_buffer, off_t offset, size_t max_size);
 size_t mlvfs_amd_mlv_gif_data(const void *reader, uint8_t *output_buffer, off_t offset, size_t max_size)
 {

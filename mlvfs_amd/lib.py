@@ -45,7 +45,7 @@ DEVICE_SYMBOLS = [
     "mlvfs_amd_cr2hdr20_dev", "mlvfs_amd_cr2hdr20_batch_dev", "mlvfs_amd_dualiso_reset", "mlvfs_amd_dualiso_trim", "mlvfs_amd_dualiso_last_scalars", "mlvfs_amd_amaze_demosaic_dev",
     "mlvfs_amd_timer_begin", "mlvfs_amd_timer_end", "mlvfs_amd_selftest_host", "mlvfs_amd_selftest_tables", "mlvfs_amd_frame_begin", "mlvfs_amd_frame_end", "mlvfs_amd_frame_sync", "mlvfs_amd_dropin_stats",
     "mlvfs_amd_mlv_open", "mlvfs_amd_mlv_close", "mlvfs_amd_mlv_frame_count", "mlvfs_amd_mlv_chunk_count",
-    "mlvfs_amd_mlv_xref", "mlvfs_amd_mlv_frame_headers", "mlvfs_amd_mlv_read_frames", "mlvfs_amd_mlv_process",
+    "mlvfs_amd_mlv_xref", "mlvfs_amd_mlv_frame_headers", "mlvfs_amd_mlv_read_frames", "mlvfs_amd_mlv_process", "mlvfs_amd_mlv_process_dualiso",
     "mlvfs_amd_lj92_info", "mlvfs_amd_lj92_decode_dev", "mlvfs_amd_lzma_uncompress",
     "mlvfs_amd_gif_size", "mlvfs_amd_gif_render", "mlvfs_amd_mlv_gif_data", "mlvfs_amd_process_unpacked_dev", "mlvfs_amd_deflicker_dev",
 ]
@@ -173,6 +173,7 @@ def load() -> C.CDLL:
     sig("mlvfs_amd_mlv_frame_headers", i, [vp, i, fhp])
     sig("mlvfs_amd_mlv_read_frames", i, [vp, i, i, vp, sz, i])
     sig("mlvfs_amd_mlv_process", i, [vp, vp, i, i, vp, sz, i, i, i, i, i])
+    sig("mlvfs_amd_mlv_process_dualiso", i, [vp, i, i, vp, sz, i, i, i, i, i, i, vp])
     _lib = L
     return L
 

@@ -172,3 +172,11 @@ class MlvReader:
         lib.check(self.L.mlvfs_amd_mlv_process(self.h, clip, first, count, lib.ptr(out), stride, cs, int(fix_pixels), int(stripes),
                                                batch, io_threads), "mlv_process")
         return out
+
+    def process_dualiso(self, first: int, count: int, out: np.ndarray, interp: int = 0, fullres: int = 1, alias_map: int = 1, cs: int = 0,
+                        batch: int = 0, io_threads: int = 0) -> np.ndarray:
+        """file -> unpack -> batched full dual-ISO conversion -> `out` (count x h x w uint16); returns the per-frame results (1 converted)."""
+        res = np.zeros(count, np.int32)
+        lib.check(self.L.mlvfs_amd_mlv_process_dualiso(self.h, first, count, lib.ptr(out), out.strides[0], interp, fullres, alias_map, cs, batch,
+                                                       io_threads, lib.ptr(res)), "mlv_process_dualiso")
+        return res

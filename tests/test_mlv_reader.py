@@ -282,3 +282,24 @@ def test_process_refuses_a_clip_state_of_another_geometry(gpu, tmp_path):
         with pytest.raises(Exception, match="clip state"):
             r.process(s.clip, 0, 3, np.zeros((3, H, W + 16), np.uint16), cs=0, fix_pixels=False, stripes=False)
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("interp", [0, 1])
+def test_dual_iso_clip_from_file_equals_the_checker(gpu, oracle, tmp_path, interp):
+    """mlvfs_amd_mlv_process_dualiso: a two-chunk clip of dual-ISO frames with one normal frame in it, batches of 3 (so that the
+    prefetch, the two frame slots and a short last batch are all exercised), against get_image_data + cr2hdr20_convert_data frame by
+    frame in clip order (the table caches carry the first converted frame's white level through the clip)."""
+    w, h, n = 416, 264, 8
+    frames = [synth.normal_frame(w, h, seed=4) if k == 2 else synth.dual_iso_frame(w, h, seed=3 + k, frame=k) for k in range(n)]
+    pl = [np.ascontiguousarray(synth.pack_bits(f), "<u2").tobytes() for f in frames]
+    names = mlvfile.write_clip(str(tmp_path / "D.MLV"), pl, w, h, chunks=2, frame_space=16, shuffle=True)
+    oracle.L.orc_dualiso_reset()
+    gpu.mlvfs_amd_dualiso_reset()
+    want = [oracle.cr2hdr20(f, synth.BLACK, synth.WHITE, interp, 1, 1, 0, reset=False) for f in frames]
+    out = np.zeros((n, h, w), np.uint16)
+    with mlvfile.MlvReader(names[0]) as r:
+        res = r.process_dualiso(0, n, out, interp=interp, batch=3, io_threads=2)
+    assert list(res) == [wr for wr, _, _ in want] == [1, 1, 0, 1, 1, 1, 1, 1]
+    for k, (wr, img, _) in enumerate(want):
+        assert np.array_equal(out[k], img if wr == 1 else frames[k]), k
