@@ -303,6 +303,11 @@ void mlvfs_amd_dualiso_last_scalars(double out[8]);
  * the caller's scale.  width must be a multiple of 4 (the reference's SSE2 build needs that for a fully
  * written green plane) and the plane at least 36x36.  Bit-identical to the x86-64 reference build.        */
 int mlvfs_amd_amaze_demosaic_dev(const float *d_raw, int width, int height, float *d_red, float *d_green, float *d_blue, void *stream);
+/* Debug: the same with the tile planes copied out (26 planes per 160x160 tile, the layout of k_amaze.hip's block).  mode 0: every
+ * tile through k_amaze.hip, blocks in tile order; mode 1: the complete tiles through k_amaze_rows.hip (LDS row streaming), their
+ * planes numbered ty * nfx + tx; nfx x nfy = the complete tiles of the plane.  Synchronous. */
+int mlvfs_amd_amaze_debug(const float *d_raw, int width, int height, float *d_red, float *d_green, float *d_blue, int mode,
+                          float *d_planes, size_t planes_floats, int *nfx, int *nfy);
 
 /* HIP-event timer around the dominant kernel (k_frame) of the calling thread's
  * launches, recorded on the stream the kernel is launched on (bench.py's

@@ -77,6 +77,9 @@ struct DeviceTables {            // per device copies + the host version they mi
     unsigned ver[4] = { 0, 0, 0, 0 };
     double *fullres = nullptr, *log2sig = nullptr, *evf = nullptr;
     unsigned curves_ver = 0;
+    DiBright *by_bright = nullptr;       // curves + the mix table, re-packed (DiLuts::by_bright, mix_pair)
+    int2 *mix_pair = nullptr;
+    unsigned packed_curves_ver = 0, packed_mix_ver = 0;
     std::vector<void *> retired;
     void retire(void *p)
     {
@@ -151,6 +154,20 @@ static int prepare_tables(int device, int black, int white, int interp_method, D
         MLV_HIP(hipMemcpy(T.log2sig, g_curves.log2sig.data(), sizeof(double) * N20, hipMemcpyHostToDevice));
         T.curves_ver = g_curves.version;
     }
+    if (T.packed_curves_ver != g_curves.version || T.packed_mix_ver != g_lut_mix.version || !T.by_bright) {
+        T.retire(T.by_bright); T.retire(T.mix_pair);
+        T.by_bright = nullptr; T.mix_pair = nullptr;
+        std::vector<DiBright> bb(N20);
+        for (int i = 0; i < N20; i++) bb[i] = DiBright{ g_curves.log2sig[i], g_lut_mix.raw2ev[i], g_curves.fullres[i] > 0.8 ? 1 : 0 };
+        std::vector<int2> mp((size_t)24 * EVR);
+        for (int i = 0; i < 24 * EVR; i++) { const int r = g_lut_mix.ev2raw[i]; mp[i] = int2{ r, g_lut_mix.raw2ev[r] }; }
+        MLV_HIP(hipMalloc(&T.by_bright, sizeof(DiBright) * N20));
+        MLV_HIP(hipMalloc(&T.mix_pair, sizeof(int2) * 24 * EVR));
+        MLV_HIP(hipMemcpy(T.by_bright, bb.data(), sizeof(DiBright) * N20, hipMemcpyHostToDevice));
+        MLV_HIP(hipMemcpy(T.mix_pair, mp.data(), sizeof(int2) * 24 * EVR, hipMemcpyHostToDevice));
+        T.packed_curves_ver = g_curves.version; T.packed_mix_ver = g_lut_mix.version;
+    }
+    L->by_bright = T.by_bright; L->mix_pair = T.mix_pair + 10 * EVR;
     L->interp_raw2ev = T.raw2ev[ik]; L->interp_ev2raw = T.ev2raw[ik] + 10 * EVR;
     L->mix_raw2ev = T.raw2ev[1];    L->mix_ev2raw = T.ev2raw[1] + 10 * EVR;
     L->blend_raw2ev = T.raw2ev[2];  L->blend_ev2raw = T.ev2raw[2] + 10 * EVR;
@@ -392,7 +409,7 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
     const size_t o_full_s = take(cs ? NF * S * 4 : 0), o_half_s = take(cs ? NF * S * 4 : 0), o_cells = take(cs ? NF * cells_stride * 4 : 0);
     const bool amaze = o.interp_method == 0;
     const size_t o_cfa = take(amaze ? NF * S * 4 : 0), o_red = take(amaze ? NF * S * 4 : 0), o_green = take(amaze ? NF * S * 4 : 0),
-                 o_blue = take(amaze ? NF * S * 4 : 0), o_gray = take(amaze ? NF * S * 4 : 0), o_dir = take(amaze ? NF * S : 0),
+                 o_blue = take(amaze ? NF * S * 4 : 0), o_ev = take(amaze ? NF * S * 12 : 0), o_gray = take(amaze ? NF * S * 4 : 0), o_dir = take(amaze ? NF * S : 0),
                  o_sq = take(amaze ? NF * (size_t)H * 8 : 0), o_stats = take(NF * 16);
     DiWork &wk = t_work[c->dev->id];
     rc = wk.ensure(off);
@@ -533,6 +550,7 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
             as.slot_h[f] = pp[f].h;
         }
         P.cfa = (float *)(B + o_cfa); P.red = (float *)(B + o_red); P.green = (float *)(B + o_green); P.blue = (float *)(B + o_blue);
+        P.ev_red = (int *)(B + o_ev); P.ev_green = P.ev_red + NF * S; P.ev_blue = P.ev_green + NF * S;
         P.gray_ev = (int *)(B + o_gray); P.dir = (uint8_t *)(B + o_dir);
         P.sq_dst = (const int *)(B + o_sq); P.sq_row = P.sq_dst + H;
         P.stats = (unsigned *)(B + o_stats); P.amaze_scratch = (float *)as.base; P.amaze_scratch_stride = a_stride;
@@ -637,6 +655,37 @@ int mlvfs_amd_amaze_demosaic_dev(const float *d_raw, int width, int height, floa
     const int rc = amaze_scratch_for(c->dev->id, width, height, s, &scratch);
     if (rc) return rc;
     return amaze_launch(d_raw, width, height, d_red, d_green, d_blue, scratch, s);
+}
+
+// Debug: the AMaZE demosaic with its tile planes copied out.  mode 0: every tile through k_amaze.hip, d_planes gets the blocks in
+// tile order (ty * tiles_x + tx); mode 1: the complete tiles through k_amaze_rows.hip, d_planes gets THEIR planes in the same
+// layout, numbered ty * nfx + tx (nfx x nfy complete tiles, returned).  tests/ compare the two plane by plane.
+int mlvfs_amd_amaze_debug(const float *d_raw, int width, int height, float *d_red, float *d_green, float *d_blue, int mode,
+                          float *d_planes, size_t planes_floats, int *nfx, int *nfy)
+{
+    ThreadCtx *c = thread_ctx();
+    if (!c) return MLVFS_AMD_ERR_HIP;
+    if ((width & 3) || width < 36 || height < 36) { set_error("amaze_demosaic: width must be a multiple of 4 and the plane at least 36x36"); return MLVFS_AMD_ERR_ARG; }
+    hipStream_t s = c->stream;
+    float *scratch = nullptr;
+    int rc = amaze_scratch_for(c->dev->id, width, height, s, &scratch);
+    if (rc) return rc;
+    const int before = g_amaze_rows_mode;
+    g_amaze_rows_mode = mode ? 1 : 0;
+    int fx = 0, fy = 0;
+    amaze_rows_extent(width, height, &fx, &fy);
+    if (nfx) *nfx = fx;
+    if (nfy) *nfy = fy;
+    if (mode && (size_t)fx * fy * AMAZE_TILE_FLOATS > planes_floats) { g_amaze_rows_mode = before; set_error("amaze_debug: plane buffer too small"); return MLVFS_AMD_ERR_ARG; }
+    rc = amaze_launch(d_raw, width, height, d_red, d_green, d_blue, scratch, s, 1, 0, 0, nullptr, 0, mode ? d_planes : nullptr);
+    g_amaze_rows_mode = before;
+    if (rc) return rc;
+    if (!mode) {
+        const size_t n = std::min(planes_floats, amaze_scratch_bytes(width, height) / sizeof(float));
+        MLV_HIP(hipMemcpyAsync(d_planes, scratch, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    MLV_HIP(hipStreamSynchronize(s));
+    return MLVFS_AMD_OK;
 }
 
 // Debug getter: the global decisions of the calling thread's last full dual-ISO conversion that got as far as the exposure

@@ -66,7 +66,11 @@ struct DiLuts {                // device pointers; *_ev2raw are indexable from -
     const int *blend_raw2ev, *blend_ev2raw;
     const double *fullres_curve;   // [2^20]
     const double *log2sig;         // [2^20] log2(max(i/64 - black/64, 1))
+    // the same tables re-packed for k_di_interp, whose time is the number of its table gathers (1.2 GB of L2 requests per batch of 8):
+    const struct DiBright *by_bright;  // [2^20] what the mix needs of a bright value in one 16-byte entry
+    const int2 *mix_pair;              // indexable from -10*32768: { mix_ev2raw[e], mix_raw2ev[mix_ev2raw[e]] }
 };
+struct alignas(16) DiBright { double log2sig; int mix_raw2ev; int fullres_hi; };       // fullres_hi: fullres_curve[i] > 0.8
 
 struct DiPlanes {
     uint32_t *raw, *dark, *bright, *fullres, *halfres, *fullres_s, *halfres_s;
@@ -74,6 +78,7 @@ struct DiPlanes {
     int *cells;                // [3][h/2][w/2] work planes of the chroma smoothing
     // AMaZE path only
     float *cfa, *red, *green, *blue;   // squeezed Bayer plane and its demosaic, [h][w]
+    int *ev_red, *ev_green, *ev_blue;  // interp_raw2ev of the clamped demosaic (k_di_amaze_clamp): each is looked up by up to six pixels
     int *gray_ev;              // raw2ev of the de-squeezed gray image, [h][w]
     uint8_t *dir;              // chosen edge direction, [h][w]
     const int *sq_dst, *sq_row;        // per image row: squeezed row it is written to (-1 none) / looked up at (0 if none)
@@ -88,8 +93,14 @@ constexpr int AMAZE_TILE_FLOATS = 13 * AMAZE_TS * AMAZE_TS + 13 * AMAZE_TS * AMA
 // nframes planes of `plane_stride` floats each; h_of (device, per frame, stride in ints `h_stride`; null: every frame has `h` rows)
 // gives the rows of each frame, 0 = skip the frame
 int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, float *d_scratch, hipStream_t s,
-                 int nframes = 1, size_t plane_stride = 0, size_t scratch_stride = 0, const int *h_of = nullptr, int h_stride = 0);
+                 int nframes = 1, size_t plane_stride = 0, size_t scratch_stride = 0, const int *h_of = nullptr, int h_stride = 0,
+                 float *d_rows_dbg = nullptr);
 size_t amaze_scratch_bytes(int w, int h);
+// k_amaze_rows.hip: the complete tiles (the first nfx x nfy of the tile grid), row-streamed through LDS
+extern int g_amaze_rows_mode;
+void amaze_rows_extent(int w, int h, int *nfx, int *nfy);
+int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, hipStream_t s, int nframes,
+                      size_t plane_stride, const int *h_of, int h_stride, float *d_dbg);
 int di_launch_amaze_interp(const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s);
 
 int di_launch_analyse(const void *d_img, int w, int H, int black, int white, const double *d_evf, unsigned *d_hist,

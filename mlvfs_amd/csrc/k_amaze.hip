@@ -18,72 +18,20 @@
 // Arithmetic is IEEE binary32 in the reference's operation order (built with -ffp-contract=off; HIP's float
 // division is correctly rounded), the vector loops' overrun past the scalar bounds included, so the three
 // planes come out bit-identical to the reference's.  No MFMA: this is stencil/select work.
-#include "clip.h"
-#include "dualiso.h"
+#include "amaze_math.h"
 #include <cstdlib>
 
 namespace mlv {
 
-namespace {
+using namespace amz;
 
-constexpr int T = AMAZE_TS, TT = T * T, HALF = TT / 2;
-constexpr int V1 = T, V2 = 2 * T, V3 = 3 * T, P1 = -T + 1, P2 = -2 * T + 2, P3 = -3 * T + 3, M1 = T + 1, M2 = 2 * T + 2, M3 = 3 * T + 3;
-constexpr float EPS = 1e-5f, EPSSQ = 1e-10f, ARTHRESH = 0.75f, NYQTHRESH = 0.5f, CLIP_PT = 1.0f, CLIP_PT8 = 0.8f;
+namespace {
 
 struct Tile {                       // pointers into this tile's scratch block
     float *cfa, *green, *delsq, *dw0, *dw1, *vcd, *hcd, *vcdalt, *hcdalt, *cdsq, *dgv, *dgh, *hcd2;
     float *hvwt, *dgrb0, *dgrb1, *delp, *delm, *rbint, *curv_h, *curv_v, *sqm, *sqp, *pmwt, *rbm, *rbp;
 };
 static_assert(AMAZE_TILE_FLOATS == 13 * TT + 13 * HALF, "scratch layout");
-
-__device__ __forceinline__ int fc(int r, int c) { return (r & 1) == (c & 1) ? ((r & 1) ? 2 : 0) : 1; }
-__device__ __forceinline__ float sq(float a) { return a * a; }
-__device__ __forceinline__ float fminv(float a, float b) { return a < b ? a : b; }
-__device__ __forceinline__ float fmaxv(float a, float b) { return a > b ? a : b; }
-__device__ __forceinline__ float lim(float a, float lo, float hi) { return fmaxv(lo, fminv(a, hi)); }
-__device__ __forceinline__ float ulim(float a, float b, float c) { return b < c ? lim(a, b, c) : lim(a, c, b); }
-__device__ __forceinline__ float half_exp(float d)          // xdiv2f: exponent - 1 unless zero
-{
-    int i = __float_as_int(d);
-    if (i & 0x7FFFFFFF) i -= 1 << 23;
-    return __int_as_float(i);
-}
-__device__ __forceinline__ float quarter_exp(float d)       // xdivf(d, 2)
-{
-    int i = __float_as_int(d);
-    if (i & 0x7FFFFFFF) i -= 2 << 23;
-    return __int_as_float(i);
-}
-__device__ __forceinline__ int iters(int start, int end, int step) { return end > start ? (end - start + step - 1) / step : 0; }
-__device__ __forceinline__ float var3(float a, float b, float c) { return 3.0f * (sq(a) + sq(b) + sq(c)) - sq(a + b + c); }
-
-// amaze_demosaic_RT.c:777-799
-__device__ __forceinline__ float bound_difference(float cd, float sgn, float centre, float lo, float hi)
-{
-    const float nsgn = -sgn, sgn3 = 3.0f * sgn;
-    const float gint = sgn * cd + centre, t2 = sgn3 * cd;
-    const float wt = 1.0f + t2 / (EPS + gint + centre);
-    const float alt = nsgn * (centre - ulim(gint, lo, hi));
-    float r = (t2 < -(centre + gint)) ? alt : wt * cd + (1.0f - wt) * alt;
-    r = (nsgn * cd > 0.0f) ? r : cd;
-    return gint > CLIP_PT ? alt : r;
-}
-// :1120-1124
-__device__ __forceinline__ float diag_estimate(float centre, float near, float far)
-{
-    const float ratio = (near + near) / (EPS + centre + far);
-    return fabsf(1.0f - ratio) < ARTHRESH ? centre * ratio : near + 0.5f * (centre - far);
-}
-// :1133-1139
-__device__ __forceinline__ float diag_bound(float rb, float centre, float lo, float hi)
-{
-    const float lim1 = ulim(rb, lo, hi);
-    const float wt = 2.0f * (centre - rb) / (EPS + rb + centre);
-    float r = wt * rb + (1.0f - wt) * lim1;
-    r = (rb + rb < centre) ? lim1 : r;
-    r = (rb < centre) ? r : rb;
-    return r > CLIP_PT ? ulim(r, lo, hi) : r;
-}
 
 }  // namespace
 
@@ -112,7 +60,8 @@ __device__ unsigned long long g_amaze_stamps[16];
 __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, int w, int h, float *__restrict__ red,
                                                  float *__restrict__ green_out, float *__restrict__ blue, float *__restrict__ scratch,
                                                  int tiles_x, int row0, int wgs_per_row, int chain_len, int rows_per_wg, int copy_from,
-                                                 size_t plane_stride, size_t scratch_stride, const int *__restrict__ h_of, int h_stride)
+                                                 size_t plane_stride, size_t scratch_stride, const int *__restrict__ h_of, int h_stride,
+                                                 int nfx, int nfy)
 {
     __shared__ unsigned char s_nyq[HALF];
     __shared__ float s_w[HALF];
@@ -124,6 +73,8 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
         scratch += f * scratch_stride;
     }
     const int ty0 = row0 + (int)(blockIdx.x / wgs_per_row), tx0 = (int)(blockIdx.x % wgs_per_row);
+    const int ntiles = (tx0 == wgs_per_row - 1) ? chain_len : 1;
+    if (tx0 < nfx && ty0 < nfy && ntiles == 1 && rows_per_wg == 1 && copy_from < 0) return;       // a complete tile: k_amaze_rows has it
     float *const block = scratch + (size_t)(ty0 * tiles_x + tx0) * AMAZE_TILE_FLOATS;
     if (copy_from >= 0) {
         const float4 *src = (const float4 *)(scratch + (size_t)copy_from * AMAZE_TILE_FLOATS);
@@ -131,7 +82,6 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
         for (int n = tid; n < AMAZE_TILE_FLOATS / 4; n += nt) dst[n] = src[n];
         __syncthreads();
     }
-    const int ntiles = (tx0 == wgs_per_row - 1) ? chain_len : 1;
     for (int tk = 0; tk < rows_per_wg * ntiles; tk++) {
     const int ty = ty0 + tk / ntiles, tx = tx0 + tk % ntiles;
     const int top = -16 + ty * (T - 32), left = -16 + tx * (T - 32);
@@ -636,16 +586,24 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
 }
 
 int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, float *d_scratch, hipStream_t s,
-                 int nframes, size_t plane_stride, size_t scratch_stride, const int *h_of, int h_stride)
+                 int nframes, size_t plane_stride, size_t scratch_stride, const int *h_of, int h_stride, float *d_rows_dbg)
 {
     const int step = AMAZE_TS - 32;
     const int tiles_x = (w + 16 + step - 1) / step, tiles_y = (h + 16 + step - 1) / step;
     const int cc1_last = w + 16 - (-16 + (tiles_x - 1) * step), rr1_last = h + 16 - (-16 + (tiles_y - 1) * step);
     static const int threads = [] { const char *e = getenv("MLVFS_AMD_AMAZE_THREADS"); const int v = e ? atoi(e) : 1024; return v >= 64 && v <= 1024 ? v / 64 * 64 : 1024; }();
+    int nfx = 0, nfy = 0;
+    amaze_rows_extent(w, h, &nfx, &nfy);                                         // the complete tiles go through LDS (k_amaze_rows.hip)
     auto launch = [&](int row0, int nrows, int wgs_per_row, int chain_len, int rows_per_wg, int copy_from) {
         hipLaunchKernelGGL(k_amaze, dim3(nrows * wgs_per_row, nframes), dim3(threads), 0, s, d_raw, w, h, d_red, d_green, d_blue, d_scratch, tiles_x,
-                           row0, wgs_per_row, chain_len, rows_per_wg, copy_from, plane_stride, scratch_stride, h_of, h_stride);
+                           row0, wgs_per_row, chain_len, rows_per_wg, copy_from, plane_stride, scratch_stride, h_of, h_stride, nfx, nfy);
     };
+    if (nfx) {
+        const int rc = amaze_rows_launch(d_raw, w, h, d_red, d_green, d_blue, s, nframes, plane_stride, h_of, h_stride, d_rows_dbg);
+        if (rc) return rc;
+    }
+    static const bool rows_only = [] { const char *e = getenv("MLVFS_AMD_AMAZE_ROWS_ONLY"); return e && atoi(e); }();      // timing experiments
+    if (rows_only && nfx) return MLVFS_AMD_OK;
     // incomplete tiles at the right end of a row, chained behind the last complete one
     const int incomplete_x = cc1_last >= AMAZE_TS ? 0 : (cc1_last < 32 ? 2 : 1);
     if (tiles_x < incomplete_x + 1 || tiles_x < 3) {

@@ -286,6 +286,47 @@ __device__ __forceinline__ void di_mix_pixel(const DiParams &p, const DiLuts &L,
     if (amap) amap[i] = (uint16_t)di_alias_err(p, L, b, f, hr);
 }
 
+// the same with the re-packed tables (DiLuts::by_bright, mix_pair): 4 gathers instead of 8 -- one entry for everything that is looked
+// up at the bright value, the full-res pick f is b or d (its table value is already here), and ev2raw comes with its raw2ev
+__device__ __forceinline__ void di_mix_pixel_packed(const DiParams &p, const DiLuts &L, size_t i, int br, int b, int d,
+                                                    uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
+                                                    uint16_t *__restrict__ over, uint16_t *__restrict__ amap)
+{
+    const DiBright tb = L.by_bright[b & 0xFFFFF];
+    const int ev_b = tb.mix_raw2ev, ev_d = L.mix_raw2ev[d];
+    int f = 0, ev_f = 0;
+    if (p.use_fullres) {
+        const bool take_b = br && (b < p.white_darkened || b >= d);              // f = br ? (b < white_darkened ? b : max(b, d)) : d
+        f = take_b ? b : d;
+        ev_f = take_b ? ev_b : ev_d;
+    }
+    fullres[i] = (uint32_t)f;
+    const double ev = tb.log2sig + p.corr_ev;
+    double t = ev - (p.max_ev - p.overlap);
+    t = t < p.overlap ? t : p.overlap;
+    t = t > 0 ? t : 0;
+    double k = (-cos(t * 3.14159265358979323846 / p.overlap) + 1) / 2;
+    k = k < 0 ? 0 : (k > 1 ? 1 : k);
+    const int mixed = (int)(ev_b * (1 - k) + ev_d * k);
+    const int2 hp = L.mix_pair[mixed];
+    const int hr = hp.x;
+    halfres[i] = (uint32_t)hr;
+    over[i] = (b >= p.white_darkened || d >= p.white20) ? 100 : 0;
+    if (amap) {                                                                   // di_alias_err
+        int err = 0;
+        if (!tb.fullres_hi) {
+            if (!p.use_fullres) ev_f = L.mix_raw2ev[0];
+            int e_lin = f - hr;
+            e_lin = e_lin > 0 ? e_lin : -e_lin;
+            e_lin = max(e_lin - p.dark_noise * 3 / 2, 0);
+            int e_log = ev_f - hp.y;
+            e_log = e_log > 0 ? e_log : -e_log;
+            err = min(min(e_lin / 2, e_log / 16), 65530);
+        }
+        amap[i] = (uint16_t)err;
+    }
+}
+
 // edge directions of the AMaZE-based interpolation, hdr.c:916-938: {ack, a, b, bck} x {x, y}; y is multiplied by s
 __constant__ signed char k_edge_dirs[11][8] = {
     { -4, 2, -2, 1, 4, -2, 6, -3 }, { -3, 2, -1, 1, 3, -2, 4, -3 }, { -2, 2, -1, 1, 2, -2, 3, -3 }, { -1, 2, -1, 1, 1, -2, 2, -3 },
@@ -293,7 +334,7 @@ __constant__ signed char k_edge_dirs[11][8] = {
     { 2, 2, 1, 1, -2, -2, -3, -3 }, { 3, 2, 1, 1, -3, -2, -4, -3 }, { 4, 2, 2, 1, -4, -2, -6, -3 } };
 
 struct DiAmazeIn {              // inputs of the edge-directed interpolation (null planes = mean23)
-    const float *red, *green, *blue;
+    const int *red, *green, *blue;      // interp_raw2ev of the clamped demosaic (k_di_amaze_clamp)
     const uint8_t *dir;
     const int *sq_row;
     size_t sq_stride;           // ints between the frames' squeezed-row maps
@@ -328,18 +369,16 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
         else if (y >= h - 4) { interp = R(x, y - 2); native = R(x, y); }
         else if (AMAZE) {                                         // hdr.c:940-952, 1181-1208
             const int s = (di_bright(p, y) == di_bright(p, y + 1)) ? -1 : 1;
-            const float *plane = (y & 1) == 0 ? ((x & 1) == 0 ? A.red : A.green) : ((x & 1) == 0 ? A.green : A.blue);
+            const int *plane = (y & 1) == 0 ? ((x & 1) == 0 ? A.red : A.green) : ((x & 1) == 0 ? A.green : A.blue);
             const int d = A.dir[i];
             const int dd[3] = { d, min(d + 1, 10), max(d - 1, 0) };
             int pi[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const signed char *e = k_edge_dirs[dd[k]];
-                int pa = (int)plane[(size_t)A.sq_row[y + e[3] * s] * w + x + e[2]];
-                int pb = (int)plane[(size_t)A.sq_row[y + e[5] * s] * w + x + e[4]];
-                pa = pa < 0 ? 0 : (pa > 0xFFFFF ? 0xFFFFF : pa);
-                pb = pb < 0 ? 0 : (pb > 0xFFFFF ? 0xFFFFF : pb);
-                pi[k] = (ir2e[pa] * 2 + ir2e[pb]) / 3;
+                const int ea = plane[(size_t)A.sq_row[y + e[3] * s] * w + x + e[2]];       // raw2ev of the clamped plane value
+                const int eb = plane[(size_t)A.sq_row[y + e[5] * s] * w + x + e[4]];
+                pi[k] = (ea * 2 + eb) / 3;
             }
             interp = ie2r[(2 * pi[0] + pi[1] + pi[2]) / 4];
             native = R(x, y);
@@ -362,7 +401,8 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
         const int b = br ? native : interp, d = br ? interp : native;
         bright[i] = (uint32_t)b;
         dark[i] = (uint32_t)d;
-        di_mix_pixel(p, L, i, br, b, d, fullres, halfres, over, amap);
+        if (AMAZE) di_mix_pixel_packed(p, L, i, br, b, d, fullres, halfres, over, amap);
+        else di_mix_pixel(p, L, i, br, b, d, fullres, halfres, over, amap);
     }
 }
 
@@ -386,20 +426,23 @@ __global__ __launch_bounds__(256) void k_di_squeeze(const uint32_t *__restrict__
 }
 
 // undo the green scaling, clamp (hdr.c:1041-1050), in place on the squeezed planes
+// + raw2ev of the three clamped values (what the edge-directed interpolation looks up, hdr.c:1181-1208: up to six pixels ask for each)
 __global__ __launch_bounds__(256) void k_di_amaze_clamp(float *__restrict__ red, float *__restrict__ green, float *__restrict__ blue,
-                                                        DiBatch bt)
+                                                        DiBatch bt, const int *__restrict__ r2e, int *__restrict__ ev_red,
+                                                        int *__restrict__ ev_green, int *__restrict__ ev_blue)
 {
     int f; DiParams p;
     if (!di_frame<1>(bt, f, p)) return;
     red += (size_t)f * bt.S; green += (size_t)f * bt.S; blue += (size_t)f * bt.S;
+    ev_red += (size_t)f * bt.S; ev_green += (size_t)f * bt.S; ev_blue += (size_t)f * bt.S;
     const size_t n = (size_t)p.w * p.h;
     const int black = p.black20;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float fb = (float)black, hi = 1048575.0f;
         const float g = (green[i] - fb) * 2.0f + fb, r = red[i], b = blue[i];
-        green[i] = g < hi ? (g > 0.0f ? g : 0.0f) : hi;
-        red[i] = r < hi ? (r > 0.0f ? r : 0.0f) : hi;
-        blue[i] = b < hi ? (b > 0.0f ? b : 0.0f) : hi;
+        const float gc = g < hi ? (g > 0.0f ? g : 0.0f) : hi, rc = r < hi ? (r > 0.0f ? r : 0.0f) : hi, bc = b < hi ? (b > 0.0f ? b : 0.0f) : hi;
+        green[i] = gc; red[i] = rc; blue[i] = bc;
+        ev_green[i] = r2e[(int)gc]; ev_red[i] = r2e[(int)rc]; ev_blue[i] = r2e[(int)bc];
     }
 }
 
@@ -640,7 +683,7 @@ __global__ __launch_bounds__(256) void k_di_blend(const uint32_t *__restrict__ d
             c = co / 15000.0;
             c = c < 0 ? 0 : (c > 1 ? 1 : c);
         }
-        const int hrev = r2e[halfres_s[i]], frev = r2e[fullres[i]], frsev = r2e[fullres_s[i]];
+        const int hrev = r2e[halfres_s[i]], frev = r2e[fullres[i]], frsev = fullres_s == fullres ? frev : r2e[fullres_s[i]];   // (no chroma smoothing: one plane)
         double f = L.fullres_curve[b & 0xFFFFF];
         double ovf = ov / 200.0;
         ovf = ovf < 0 ? 0 : (ovf > 1 ? 1 : ovf);
@@ -1137,7 +1180,7 @@ int di_launch_amaze_interp(const DiBatch &b, int h_launch, const DiLuts &L, cons
                               (int)(sizeof(DiParams) / sizeof(int)));
     } else rc = amaze_launch(P.cfa, w, b.p0.h, P.red, P.green, P.blue, P.amaze_scratch, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_di_amaze_clamp, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b);
+    hipLaunchKernelGGL(k_di_amaze_clamp, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b, L.interp_raw2ev, P.ev_red, P.ev_green, P.ev_blue);
     hipLaunchKernelGGL(k_di_gray, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b, P.sq_row, sq_stride, L.interp_raw2ev, P.gray_ev);
     hipLaunchKernelGGL(k_di_edge_dir, flat_grid(n, nf), dim3(256), 0, s, P.raw, P.gray_ev, b, L.fullres_curve, P.dir, P.stats);
     MLV_HIP(hipGetLastError());
@@ -1151,7 +1194,7 @@ int di_launch_convert(const DiBatch &b, int h_launch, const DiLuts &L, const DiP
     const int nf = b.nframes;
     const size_t n = (size_t)p.w * h_launch;
     uint16_t *amap_fused = (p.use_alias_map && !p.chroma_smooth) ? P.amap : nullptr;
-    const DiAmazeIn A{ P.red, P.green, P.blue, P.dir, P.sq_row, 2 * (size_t)h_launch };
+    const DiAmazeIn A{ P.ev_red, P.ev_green, P.ev_blue, P.dir, P.sq_row, 2 * (size_t)h_launch };
     if (amaze)
         hipLaunchKernelGGL(k_di_interp<true>, flat_grid(n, nf), dim3(256), 0, s, P.raw, b, L, A, P.dark, P.bright, P.fullres, P.halfres,
                            P.over, amap_fused);
