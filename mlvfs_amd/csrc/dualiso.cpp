@@ -59,6 +59,7 @@ static void host_lut_build(HostLut &L, int black, int white)          // hdr.c:8
 
 struct HostCurves {              // build_fullres_curve (hdr.c:890-913) + the log2 part of the mix curve (hdr.c:1566)
     int black = -1;
+    int thr = N20;                   // fullres[i] > 0.8 <=> i >= thr
     unsigned version = 0;
     std::vector<double> fullres, log2sig;
 };
@@ -142,6 +143,11 @@ static int prepare_tables(int device, int black, int white, int interp_method, D
             t = t < 0 ? 0 : (t > 4 ? 4 : t);
             g_curves.fullres[i] = (-cos(t * M_PI / 4) + 1) / 2;
         }
+        int thr = N20;
+        for (int i = N20 - 1; i >= 0 && g_curves.fullres[i] > 0.8; i--) thr = i;
+        for (int i = 0; i < thr; i++)
+            if (g_curves.fullres[i] > 0.8) { set_error("dual ISO: the full-res curve is not monotone"); return MLVFS_AMD_ERR_ARG; }
+        g_curves.thr = thr;
         g_curves.black = black;
         g_curves.version++;
     }
@@ -168,6 +174,7 @@ static int prepare_tables(int device, int black, int white, int interp_method, D
         T.packed_curves_ver = g_curves.version; T.packed_mix_ver = g_lut_mix.version;
     }
     L->by_bright = T.by_bright; L->mix_pair = T.mix_pair + 10 * EVR;
+    L->fullres_thr = g_curves.thr;
     L->interp_raw2ev = T.raw2ev[ik]; L->interp_ev2raw = T.ev2raw[ik] + 10 * EVR;
     L->mix_raw2ev = T.raw2ev[1];    L->mix_ev2raw = T.ev2raw[1] + 10 * EVR;
     L->blend_raw2ev = T.raw2ev[2];  L->blend_ev2raw = T.ev2raw[2] + 10 * EVR;
@@ -410,7 +417,7 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
     const bool amaze = o.interp_method == 0;
     const size_t o_cfa = take(amaze ? NF * S * 4 : 0), o_red = take(amaze ? NF * S * 4 : 0), o_green = take(amaze ? NF * S * 4 : 0),
                  o_blue = take(amaze ? NF * S * 4 : 0), o_ev = take(amaze ? NF * S * 12 : 0), o_gray = take(amaze ? NF * S * 4 : 0), o_dir = take(amaze ? NF * S : 0),
-                 o_sq = take(amaze ? NF * (size_t)H * 8 : 0), o_stats = take(NF * 16);
+                 o_sq = take(amaze ? NF * (size_t)H * 8 : 0), o_stats = take(NF * 16 * DI_STAT_SLOTS);
     DiWork &wk = t_work[c->dev->id];
     rc = wk.ensure(off);
     if (rc) return rc;
@@ -419,7 +426,7 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
     // page-locked landing zone: every copy of this path starts or ends here (a copy from or to pageable memory waits inside the
     // runtime for the stream to reach it, and the calls of the other host threads wait with it)
     const size_t ph_dd = 0, ph_pp = ph_dd + up(NF * sizeof(DiDecide)), ph_sq = ph_pp + up(NF * sizeof(DiParams)),
-                 ph_st = ph_sq + up(NF * (size_t)H * 8), ph_check = ph_st + up(NF * 16), ph_end = ph_check + up(NF * 16);
+                 ph_st = ph_sq + up(NF * (size_t)H * 8), ph_check = ph_st + up(NF * 16 * DI_STAT_SLOTS), ph_end = ph_check + up(NF * 16);
     PinnedWork &pw = t_pinned[c->dev->id];
     rc = pw.ensure(ph_end);
     if (rc) return rc;
@@ -561,11 +568,13 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
     if (rc) return rc;
     if (amaze) {
         unsigned *st = (unsigned *)(PH + ph_st);
-        MLV_HIP(hipMemcpyAsync(st, B + o_stats, NF * 16, hipMemcpyDeviceToHost, stream));
+        MLV_HIP(hipMemcpyAsync(st, B + o_stats, NF * 16 * DI_STAT_SLOTS, hipMemcpyDeviceToHost, stream));
         MLV_HIP(hipStreamSynchronize(stream));               // (also keeps the pinned parameter blocks alive until their uploads have happened)
         for (int f = 0; f < nframes; f++) {
             if (results[f] != 1) continue;
-            const unsigned *s4 = st + 4 * f;
+            unsigned long long s4[4] = { 0, 0, 0, 0 };                          // the workgroups count into DI_STAT_SLOTS slots per frame
+            for (int k = 0; k < DI_STAT_SLOTS; k++)
+                for (int c4 = 0; c4 < 4; c4++) s4[c4] += st[((size_t)f * DI_STAT_SLOTS + k) * 4 + c4];
             printf("AMaZE interpolation ...\nEdge-directed interpolation...\n");
             printf("Semi-overexposed: %.02f%%\n", s4[0] * 100.0 / (s4[0] + s4[1]));
             printf("Deep shadows    : %.02f%%\n", s4[2] * 100.0 / (s4[2] + s4[3]));

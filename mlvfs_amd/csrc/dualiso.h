@@ -69,9 +69,11 @@ struct DiLuts {                // device pointers; *_ev2raw are indexable from -
     // the same tables re-packed for k_di_interp, whose time is the number of its table gathers (1.2 GB of L2 requests per batch of 8):
     const struct DiBright *by_bright;  // [2^20] what the mix needs of a bright value in one 16-byte entry
     const int2 *mix_pair;              // indexable from -10*32768: { mix_ev2raw[e], mix_raw2ev[mix_ev2raw[e]] }
+    int fullres_thr;                   // fullres_curve[i] > 0.8 <=> i >= fullres_thr (the curve is monotone; checked when it is built)
 };
 struct alignas(16) DiBright { double log2sig; int mix_raw2ev; int fullres_hi; };       // fullres_hi: fullres_curve[i] > 0.8
 
+constexpr int DI_STAT_SLOTS = 64;     // k_di_edge_dir spreads its four counters per frame over this many slots (same-address atomics serialise)
 struct DiPlanes {
     uint32_t *raw, *dark, *bright, *fullres, *halfres, *fullres_s, *halfres_s;
     uint16_t *over, *amap, *aux, *amap2;
@@ -82,7 +84,7 @@ struct DiPlanes {
     int *gray_ev;              // raw2ev of the de-squeezed gray image, [h][w]
     uint8_t *dir;              // chosen edge direction, [h][w]
     const int *sq_dst, *sq_row;        // per image row: squeezed row it is written to (-1 none) / looked up at (0 if none)
-    unsigned *stats;           // semi-overexposed, not overexposed, deep shadow, not shadow (4 per frame)
+    unsigned *stats;           // semi-overexposed, not overexposed, deep shadow, not shadow (4 per slot, DI_STAT_SLOTS slots per frame)
     float *amaze_scratch;
     size_t amaze_scratch_stride;   // floats between the frames' scratch blocks
     size_t cells_stride;           // ints between the frames' chroma-smoothing work planes

@@ -465,48 +465,87 @@ __global__ __launch_bounds__(256) void k_di_gray(const float *__restrict__ red, 
 }
 
 // best of 11 edge directions where the interpolation has to be good (hdr.c:1096-1173)
-__global__ __launch_bounds__(256) void k_di_edge_dir(const uint32_t *__restrict__ raw, const int *__restrict__ gray_ev, DiBatch bt,
-                                                     const double *__restrict__ fullres_curve, uint8_t *__restrict__ dir,
-                                                     unsigned *__restrict__ stats)
+// A workgroup owns 256 pixels of one row.  All eleven directions compare the same four rows (y + 2s, y + s, y - 2s, y - 3s) at
+// column shifts within +-11: the rows' 278 values are staged in LDS once (only when a pixel of the segment searches at all),
+// biased to unsigned, each searching lane takes its 4 x 23 window into registers and the 363 |a - b| + c of the search are one
+// v_sad_u32 each -- 92 LDS reads and 363 instructions where the per-direction loops made 484 loads and ~1 100 instructions.
+// Columns left of 0 / right of w - 1 are the flat neighbours of the reference's indexing (the previous / next row).
+constexpr signed char EDGE_DIRS[11][8] = {
+    { -4, 2, -2, 1, 4, -2, 6, -3 }, { -3, 2, -1, 1, 3, -2, 4, -3 }, { -2, 2, -1, 1, 2, -2, 3, -3 }, { -1, 2, -1, 1, 1, -2, 2, -3 },
+    { -1, 2, 0, 1, 1, -2, 1, -3 },  { 0, 2, 0, 1, 0, -2, 0, -3 },   { 1, 2, 0, 1, -1, -2, -1, -3 }, { 1, 2, 1, 1, -1, -2, -2, -3 },
+    { 2, 2, 1, 1, -2, -2, -3, -3 }, { 3, 2, 1, 1, -3, -2, -4, -3 }, { 4, 2, 2, 1, -4, -2, -6, -3 } };
+__device__ __forceinline__ unsigned di_sad(unsigned a, unsigned b, unsigned c)
 {
-    __shared__ unsigned s_stats[4];
+    unsigned r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__global__ __launch_bounds__(256) void k_di_edge_dir(const uint32_t *__restrict__ raw, const int *__restrict__ gray_ev, DiBatch bt,
+                                                     int fullres_thr, uint8_t *__restrict__ dir, unsigned *__restrict__ stats)
+{
+    constexpr int REACH = 11, SPAN = 256 + 2 * REACH, BIAS = 10 * DI_EVR;        // raw2ev >= -10 EV
+    __shared__ unsigned s_rows[4][SPAN];
     int f; DiParams p;
-    if (!di_frame<1>(bt, f, p)) return;
-    raw += (size_t)f * bt.S; gray_ev += (size_t)f * bt.S; dir += (size_t)f * bt.S; stats += (size_t)f * 4;
-    if (threadIdx.x < 4) s_stats[threadIdx.x] = 0;
-    __syncthreads();
-    const int w = p.w, h = p.h;
+    if (!di_frame<2>(bt, f, p)) return;
+    raw += (size_t)f * bt.S; gray_ev += (size_t)f * bt.S; dir += (size_t)f * bt.S;
+    stats += ((size_t)f * DI_STAT_SLOTS + ((blockIdx.x + blockIdx.y) & (DI_STAT_SLOTS - 1))) * 4;
+    const int w = p.w, h = p.h, x0 = blockIdx.x * 256, x = x0 + (int)threadIdx.x;
     const size_t n = (size_t)w * h;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % w), y = (int)(i / w);
-        int best = 5;
-        if (x >= 5 && x < w - 5 && y >= 5 && y < h - 5) {
-            const int v = (int)raw[i];
-            bool search;
-            if (!di_bright(p, y)) { search = !(fullres_curve[v] > 0.8); atomicAdd(&s_stats[search ? 2 : 3], 1u); }
-            else { search = !(v < p.white_darkened); atomicAdd(&s_stats[search ? 0 : 1], 1u); }
-            if (search) {
-                const int s = (di_bright(p, y) == di_bright(p, y + 1)) ? -1 : 1;
-                int e_best = 0x7FFFFFFF;
-                for (int d = 0; d < 11; d++) {
-                    const signed char *e = k_edge_dirs[d];
-                    const int *r1 = gray_ev + (size_t)(y + e[1] * s) * w + x + e[0], *r2 = gray_ev + (size_t)(y + e[3] * s) * w + x + e[2];
-                    const int *r3 = gray_ev + (size_t)(y + e[5] * s) * w + x + e[4], *r4 = gray_ev + (size_t)(y + e[7] * s) * w + x + e[6];
-                    int err = 0;
+    unsigned n_search = 0, n_plain = 0;                                          // this lane's pixels, bright rows in the low half, dark rows << 16
+    for (int y = blockIdx.y; y < h; y += gridDim.y) {                            // (a band of rows per workgroup: 4 atomics per workgroup, not per row)
+    const size_t i = (size_t)y * w + x;
+    const int br = di_bright(p, y);
+    bool search = false;
+    if (x >= 5 && x < w - 5 && y >= 5 && y < h - 5) {
+        const int v = (int)raw[i];
+        search = br ? !(v < p.white_darkened) : v < fullres_thr;                  // !(fullres_curve[v] > 0.8)
+        if (search) n_search += br ? 1u : 0x10000u; else n_plain += br ? 1u : 0x10000u;
+    }
+    int best = 5;
+    if (__syncthreads_or(search)) {
+        const int s = (br == di_bright(p, y + 1)) ? -1 : 1;
+        for (int k = threadIdx.x; k < 4 * SPAN; k += 256) {
+            const int rr = k / SPAN, cc = k - rr * SPAN;
+            const int row = y + (rr == 0 ? 2 : rr == 1 ? 1 : rr == 2 ? -2 : -3) * s;
+            size_t o = (size_t)row * w + x0 + cc - REACH;                        // flat, like the reference's index arithmetic
+            o = o < n ? o : n - 1;                                               // (beyond the segment's last pixel: nobody reads it)
+            s_rows[rr][cc] = (unsigned)(gray_ev[o] + BIAS);
+        }
+        __syncthreads();
+        if (search) {
+            unsigned win[4][2 * REACH + 1];
 #pragma unroll
-                    for (int j = -5; j <= 5; j++) {
-                        const int p1 = r1[j], p2 = r2[j], p3 = r3[j], p4 = r4[j];
-                        err += abs(p1 - p2) + abs(p2 - p3) + abs(p3 - p4);
-                    }
-                    err += abs(d - 5) * DI_EVR / 8;
-                    if (err < e_best) { e_best = err; best = d; }
+            for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+                for (int c = 0; c < 2 * REACH + 1; c++) win[rr][c] = s_rows[rr][threadIdx.x + c];
+            unsigned e_best = 0xFFFFFFFFu;
+#pragma unroll
+            for (int d = 0; d < 11; d++) {
+                unsigned err = (unsigned)((d > 5 ? d - 5 : 5 - d) * DI_EVR / 8);
+#pragma unroll
+                for (int j = -5; j <= 5; j++) {
+                    const unsigned p1 = win[0][REACH + EDGE_DIRS[d][0] + j], p2 = win[1][REACH + EDGE_DIRS[d][2] + j];
+                    const unsigned p3 = win[2][REACH + EDGE_DIRS[d][4] + j], p4 = win[3][REACH + EDGE_DIRS[d][6] + j];
+                    err = di_sad(p1, p2, err); err = di_sad(p2, p3, err); err = di_sad(p3, p4, err);
                 }
+                if (err < e_best) { e_best = err; best = d; }
             }
         }
-        dir[i] = (uint8_t)best;
     }
-    __syncthreads();
-    if (threadIdx.x < 4 && s_stats[threadIdx.x]) atomicAdd(&stats[threadIdx.x], s_stats[threadIdx.x]);
+    if (x < w) dir[i] = (uint8_t)best;
+    __syncthreads();                                                             // (s_rows is reused by the next row)
+    }
+    {   // the reference's four counters: semi-overexposed / not (bright rows), deep shadow / not (dark rows)
+        unsigned a = n_search & 0xFFFFu, b = n_plain & 0xFFFFu, c = n_search >> 16, d = n_plain >> 16;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); d += __shfl_xor(d, o); }
+        if ((threadIdx.x & 63) == 0) {
+            if (a) atomicAdd(&stats[0], a);
+            if (b) atomicAdd(&stats[1], b);
+            if (c) atomicAdd(&stats[2], c);
+            if (d) atomicAdd(&stats[3], d);
+        }
+    }
 }
 
 // alias error from the chroma-smoothed planes (hdr.c:1620: build_alias_map gets fullres_smooth / halfres_smooth)
@@ -581,8 +620,7 @@ __global__ __launch_bounds__(256) void k_di_cs_apply(const int *__restrict__ cel
 
 // 6th largest of the 37 neighbours (kth_smallest(negated, 37, 5)), hdr.c:1423-1443
 __global__ __launch_bounds__(256) void k_di_alias_rank(const uint16_t *__restrict__ amap, const uint32_t *__restrict__ bright,
-                                                       const double *__restrict__ fullres_curve, DiBatch bt,
-                                                       uint16_t *__restrict__ aux)
+                                                       int fullres_thr, DiBatch bt, uint16_t *__restrict__ aux)
 {
     int f; DiParams p;
     if (!di_frame<2>(bt, f, p)) return;
@@ -592,7 +630,7 @@ __global__ __launch_bounds__(256) void k_di_alias_rank(const uint16_t *__restric
     if (x >= w || y >= h) return;
     const size_t i = x + (size_t)y * w;
     int out = amap[i];
-    if (x >= 6 && x < w - 6 && y >= 6 && y < h - 6 && !(fullres_curve[bright[i]] > 0.8)) {
+    if (x >= 6 && x < w - 6 && y >= 6 && y < h - 6 && (int)bright[i] < fullres_thr) {                          // !(fullres_curve[bright] > 0.8)
         int t0 = -1, t1 = -1, t2 = -1, t3 = -1, t4 = -1, t5 = -1;      // six largest, descending
         auto push = [&](int v) {
             if (v > t5) {
@@ -619,7 +657,7 @@ __global__ __launch_bounds__(256) void k_di_alias_rank(const uint16_t *__restric
 
 // integer gaussian, hdr.c:1446-1466 (terms exactly as written there, duplicates included)
 __global__ __launch_bounds__(256) void k_di_alias_blur(const uint16_t *__restrict__ aux, const uint16_t *__restrict__ amap_in,
-                                                       const uint32_t *__restrict__ bright, const double *__restrict__ fullres_curve,
+                                                       const uint32_t *__restrict__ bright, int fullres_thr,
                                                        DiBatch bt, uint16_t *__restrict__ out)
 {
     int f; DiParams p;
@@ -630,7 +668,7 @@ __global__ __launch_bounds__(256) void k_di_alias_blur(const uint16_t *__restric
     if (x >= w || y >= h) return;
     const size_t i = x + (size_t)y * w;
     int v = amap_in[i];
-    if (x >= 6 && x < w - 6 && y >= 6 && y < h - 6 && !(fullres_curve[bright[i]] > 0.8)) {
+    if (x >= 6 && x < w - 6 && y >= 6 && y < h - 6 && (int)bright[i] < fullres_thr) {
         auto A = [&](int dx, int dy) { return (int)aux[(x + dx) + (size_t)(y + dy) * w]; };
         const int plus2 = A(0, -2) + A(-2, 0) + A(2, 0) + A(0, 2);
         const int diag2 = A(-2, -2) + A(2, -2) + A(-2, 2) + A(2, 2);
@@ -1169,7 +1207,7 @@ int di_launch_amaze_interp(const DiBatch &b, int h_launch, const DiLuts &L, cons
     const int w = b.p0.w, nf = b.nframes;
     const size_t n = (size_t)w * h_launch, sq_stride = 2 * (size_t)h_launch;
     MLV_HIP(hipMemsetAsync(P.cfa, 0, (nf > 1 ? b.S * nf : n) * sizeof(float), s));          // rows no exposure lands on stay zero (hdr.c:971)
-    MLV_HIP(hipMemsetAsync(P.stats, 0, 4 * sizeof(unsigned) * nf, s));
+    MLV_HIP(hipMemsetAsync(P.stats, 0, 4 * sizeof(unsigned) * nf * DI_STAT_SLOTS, s));
     hipLaunchKernelGGL(k_di_squeeze, flat_grid(n, nf), dim3(256), 0, s, P.raw, b, P.sq_dst, sq_stride, P.cfa);
     // a frame's AMaZE geometry follows its own row count (one less for GBRG): the launch plan is made per distinct height
     int rc = MLVFS_AMD_OK;
@@ -1182,7 +1220,7 @@ int di_launch_amaze_interp(const DiBatch &b, int h_launch, const DiLuts &L, cons
     if (rc) return rc;
     hipLaunchKernelGGL(k_di_amaze_clamp, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b, L.interp_raw2ev, P.ev_red, P.ev_green, P.ev_blue);
     hipLaunchKernelGGL(k_di_gray, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b, P.sq_row, sq_stride, L.interp_raw2ev, P.gray_ev);
-    hipLaunchKernelGGL(k_di_edge_dir, flat_grid(n, nf), dim3(256), 0, s, P.raw, P.gray_ev, b, L.fullres_curve, P.dir, P.stats);
+    hipLaunchKernelGGL(k_di_edge_dir, dim3((w + 255) / 256, (h_launch + 3) / 4, nf), dim3(256), 0, s, P.raw, P.gray_ev, b, L.fullres_thr, P.dir, P.stats);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
@@ -1218,8 +1256,8 @@ int di_launch_convert(const DiBatch &b, int h_launch, const DiLuts &L, const DiP
     const uint16_t *amap_final = nullptr;
     if (p.use_alias_map) {
         dim3 g((p.w + 255) / 256, h_launch, nf);
-        hipLaunchKernelGGL(k_di_alias_rank, g, dim3(256), 0, s, P.amap, P.bright, L.fullres_curve, b, P.aux);
-        hipLaunchKernelGGL(k_di_alias_blur, g, dim3(256), 0, s, P.aux, P.amap, P.bright, L.fullres_curve, b, P.amap2);
+        hipLaunchKernelGGL(k_di_alias_rank, g, dim3(256), 0, s, P.amap, P.bright, L.fullres_thr, b, P.aux);
+        hipLaunchKernelGGL(k_di_alias_blur, g, dim3(256), 0, s, P.aux, P.amap, P.bright, L.fullres_thr, b, P.amap2);
         amap_final = P.amap2;
     }
     hipLaunchKernelGGL(k_di_blend, flat_grid(n, nf), dim3(256), 0, s, P.dark, P.bright, P.fullres, fullres_s, halfres_s, P.over, amap_final,
