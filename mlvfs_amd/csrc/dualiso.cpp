@@ -80,7 +80,8 @@ struct DeviceTables {            // per device copies + the host version they mi
     unsigned curves_ver = 0;
     DiBright *by_bright = nullptr;       // curves + the mix table, re-packed (DiLuts::by_bright, mix_pair)
     int2 *mix_pair = nullptr;
-    unsigned packed_curves_ver = 0, packed_mix_ver = 0;
+    unsigned packed_curves_ver = 0, packed_mix_ver = 0, same_mix_ver = 0, same_blend_ver = 0;
+    int blend_is_mix = 0;
     std::vector<void *> retired;
     void retire(void *p)
     {
@@ -175,6 +176,11 @@ static int prepare_tables(int device, int black, int white, int interp_method, D
     }
     L->by_bright = T.by_bright; L->mix_pair = T.mix_pair + 10 * EVR;
     L->fullres_thr = g_curves.thr;
+    if (T.same_mix_ver != g_lut_mix.version || T.same_blend_ver != g_lut_blend.version) {
+        T.blend_is_mix = g_lut_mix.raw2ev == g_lut_blend.raw2ev;
+        T.same_mix_ver = g_lut_mix.version; T.same_blend_ver = g_lut_blend.version;
+    }
+    L->blend_is_mix = T.blend_is_mix;
     L->interp_raw2ev = T.raw2ev[ik]; L->interp_ev2raw = T.ev2raw[ik] + 10 * EVR;
     L->mix_raw2ev = T.raw2ev[1];    L->mix_ev2raw = T.ev2raw[1] + 10 * EVR;
     L->blend_raw2ev = T.raw2ev[2];  L->blend_ev2raw = T.ev2raw[2] + 10 * EVR;

@@ -70,6 +70,8 @@ struct DiLuts {                // device pointers; *_ev2raw are indexable from -
     const struct DiBright *by_bright;  // [2^20] what the mix needs of a bright value in one 16-byte entry
     const int2 *mix_pair;              // indexable from -10*32768: { mix_ev2raw[e], mix_raw2ev[mix_ev2raw[e]] }
     int fullres_thr;                   // fullres_curve[i] > 0.8 <=> i >= fullres_thr (the curve is monotone; checked when it is built)
+    int blend_is_mix;                  // the blend's raw2ev table equals the mix's (always, in practice: both are rebuilt in the same call with
+                                       // the same levels): without chroma smoothing the interpolation hands the blend EV values instead of raw ones
 };
 struct alignas(16) DiBright { double log2sig; int mix_raw2ev; int fullres_hi; };       // fullres_hi: fullres_curve[i] > 0.8
 

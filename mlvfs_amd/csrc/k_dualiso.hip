@@ -288,9 +288,10 @@ __device__ __forceinline__ void di_mix_pixel(const DiParams &p, const DiLuts &L,
 
 // the same with the re-packed tables (DiLuts::by_bright, mix_pair): 4 gathers instead of 8 -- one entry for everything that is looked
 // up at the bright value, the full-res pick f is b or d (its table value is already here), and ev2raw comes with its raw2ev
+// ev_out: the two planes go out as EV values (what k_di_blend looks up of them anyway, when no chroma smoothing sits in between)
 __device__ __forceinline__ void di_mix_pixel_packed(const DiParams &p, const DiLuts &L, size_t i, int br, int b, int d,
                                                     uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
-                                                    uint16_t *__restrict__ over, uint16_t *__restrict__ amap)
+                                                    uint16_t *__restrict__ over, uint16_t *__restrict__ amap, bool ev_out)
 {
     const DiBright tb = L.by_bright[b & 0xFFFFF];
     const int ev_b = tb.mix_raw2ev, ev_d = L.mix_raw2ev[d];
@@ -299,8 +300,8 @@ __device__ __forceinline__ void di_mix_pixel_packed(const DiParams &p, const DiL
         const bool take_b = br && (b < p.white_darkened || b >= d);              // f = br ? (b < white_darkened ? b : max(b, d)) : d
         f = take_b ? b : d;
         ev_f = take_b ? ev_b : ev_d;
-    }
-    fullres[i] = (uint32_t)f;
+    } else if (ev_out || amap) ev_f = L.mix_raw2ev[0];
+    fullres[i] = ev_out ? (uint32_t)ev_f : (uint32_t)f;
     const double ev = tb.log2sig + p.corr_ev;
     double t = ev - (p.max_ev - p.overlap);
     t = t < p.overlap ? t : p.overlap;
@@ -310,12 +311,11 @@ __device__ __forceinline__ void di_mix_pixel_packed(const DiParams &p, const DiL
     const int mixed = (int)(ev_b * (1 - k) + ev_d * k);
     const int2 hp = L.mix_pair[mixed];
     const int hr = hp.x;
-    halfres[i] = (uint32_t)hr;
+    halfres[i] = ev_out ? (uint32_t)hp.y : (uint32_t)hr;
     over[i] = (b >= p.white_darkened || d >= p.white20) ? 100 : 0;
     if (amap) {                                                                   // di_alias_err
         int err = 0;
         if (!tb.fullres_hi) {
-            if (!p.use_fullres) ev_f = L.mix_raw2ev[0];
             int e_lin = f - hr;
             e_lin = e_lin > 0 ? e_lin : -e_lin;
             e_lin = max(e_lin - p.dark_noise * 3 / 2, 0);
@@ -344,7 +344,7 @@ template <bool AMAZE>
 __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ raw, DiBatch bt, DiLuts L, DiAmazeIn A,
                                                    uint32_t *__restrict__ dark, uint32_t *__restrict__ bright,
                                                    uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
-                                                   uint16_t *__restrict__ over, uint16_t *__restrict__ amap)
+                                                   uint16_t *__restrict__ over, uint16_t *__restrict__ amap, bool ev_out)
 {
     int f; DiParams p;
     if (!di_frame<1>(bt, f, p)) return;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
         const int b = br ? native : interp, d = br ? interp : native;
         bright[i] = (uint32_t)b;
         dark[i] = (uint32_t)d;
-        if (AMAZE) di_mix_pixel_packed(p, L, i, br, b, d, fullres, halfres, over, amap);
+        if (AMAZE) di_mix_pixel_packed(p, L, i, br, b, d, fullres, halfres, over, amap, ev_out);
         else di_mix_pixel(p, L, i, br, b, d, fullres, halfres, over, amap);
     }
 }
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256) void k_di_blend(const uint32_t *__restrict__ d
                                                   const uint32_t *__restrict__ fullres, const uint32_t *__restrict__ fullres_s,
                                                   const uint32_t *__restrict__ halfres_s, const uint16_t *__restrict__ over,
                                                   const uint16_t *__restrict__ amap, DiBatch bt, DiLuts L,
-                                                  uint16_t *__restrict__ img_base)
+                                                  uint16_t *__restrict__ img_base, bool ev_planes)
 {
     int f; DiParams p;
     if (!di_frame<1>(bt, f, p)) return;
@@ -721,7 +721,9 @@ __global__ __launch_bounds__(256) void k_di_blend(const uint32_t *__restrict__ d
             c = co / 15000.0;
             c = c < 0 ? 0 : (c > 1 ? 1 : c);
         }
-        const int hrev = r2e[halfres_s[i]], frev = r2e[fullres[i]], frsev = fullres_s == fullres ? frev : r2e[fullres_s[i]];   // (no chroma smoothing: one plane)
+        int hrev, frev, frsev;
+        if (ev_planes) { hrev = (int)halfres_s[i]; frev = frsev = (int)fullres[i]; }                       // k_di_interp<true> wrote EV values
+        else { hrev = r2e[halfres_s[i]]; frev = r2e[fullres[i]]; frsev = fullres_s == fullres ? frev : r2e[fullres_s[i]]; }
         double f = L.fullres_curve[b & 0xFFFFF];
         double ovf = ov / 200.0;
         ovf = ovf < 0 ? 0 : (ovf > 1 ? 1 : ovf);
@@ -1233,12 +1235,13 @@ int di_launch_convert(const DiBatch &b, int h_launch, const DiLuts &L, const DiP
     const size_t n = (size_t)p.w * h_launch;
     uint16_t *amap_fused = (p.use_alias_map && !p.chroma_smooth) ? P.amap : nullptr;
     const DiAmazeIn A{ P.ev_red, P.ev_green, P.ev_blue, P.dir, P.sq_row, 2 * (size_t)h_launch };
+    const bool ev_planes = amaze && !p.chroma_smooth && L.blend_is_mix;       // halfres / fullres travel as EV (the blend's lookups, done early)
     if (amaze)
         hipLaunchKernelGGL(k_di_interp<true>, flat_grid(n, nf), dim3(256), 0, s, P.raw, b, L, A, P.dark, P.bright, P.fullres, P.halfres,
-                           P.over, amap_fused);
+                           P.over, amap_fused, ev_planes);
     else
         hipLaunchKernelGGL(k_di_interp<false>, flat_grid(n, nf), dim3(256), 0, s, P.raw, b, L, A, P.dark, P.bright, P.fullres, P.halfres,
-                           P.over, amap_fused);
+                           P.over, amap_fused, false);
     MLV_HIP(hipGetLastError());
     const uint32_t *fullres_s = P.fullres, *halfres_s = P.halfres;
     if (p.chroma_smooth) {                                             // hdr.c:1612-1619
@@ -1261,7 +1264,7 @@ int di_launch_convert(const DiBatch &b, int h_launch, const DiLuts &L, const DiP
         amap_final = P.amap2;
     }
     hipLaunchKernelGGL(k_di_blend, flat_grid(n, nf), dim3(256), 0, s, P.dark, P.bright, P.fullres, fullres_s, halfres_s, P.over, amap_final,
-                       b, L, (uint16_t *)d_out);
+                       b, L, (uint16_t *)d_out, ev_planes);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
