@@ -28,6 +28,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
+#include <algorithm>
 
 namespace mlv {
 
@@ -57,31 +59,14 @@ enum { P_LOAD, P_DIRDIFF, P_NYQTEST, P_HVWT, P_AREA, P_CURV, P_CGRAD, P_PMSWEEP,
        P_GRAD, P_HREF, P_VWALK, P_VOTE, P_HVSWEEP, P_DIAG, P_RBINT, P_GFINAL, P_OUTPUT, NPASS };      // phase B
 constexpr int LAG[NPASS] = { 0, 3, 6, 7, 11, 13, 9, 12, 17,   1, 3, 4, 7, 12, 10, 12, 14, 18 };
 constexpr int LAG_MAX = 18;
-constexpr unsigned long long lag_bits(int from, int to) { unsigned long long v = 0; for (int k = to - 1; k >= from; k--) v = (v << 5) | (unsigned)LAG[k]; return v; }
-constexpr unsigned long long LAGS_LO = lag_bits(0, 12), LAGS_HI = lag_bits(12, NPASS);       // 5 bits per pass
 #define IT(p, c) ((p) * 8 + (c))
-// The items of a phase, longest first, dealt to the 16 waves in snake order (wave w takes items w and 31 - w): no counter, no
-// traffic.  (Taking items from a counter in LDS balanced better and cost more: 54 same-address atomics per step are 2 500 cycles.)
-// AREA is first: where the Nyquist test fired it is by far the longest, elsewhere it returns at once.  LOAD is not in the list: it
-// keeps the next row pair in registers across steps and stays with one wave.
-constexpr unsigned char LIST_A[] = { IT(P_AREA, 0), IT(P_AREA, 1), IT(P_AREA, 2), IT(P_HVWT, 0), IT(P_HVWT, 1), IT(P_HVWT, 2),
-                                     IT(P_DIRDIFF, 0), IT(P_DIRDIFF, 2), IT(P_DIRDIFF, 4), IT(P_CHROMA, 0), IT(P_CHROMA, 1), IT(P_CHROMA, 2),
-                                     IT(P_NYQTEST, 0), IT(P_NYQTEST, 1),
-                                     IT(P_NYQTEST, 2), IT(P_PMSWEEP, 0), IT(P_CGRAD, 0), IT(P_CGRAD, 1), IT(P_CGRAD, 2), IT(P_CURV, 0), IT(P_CURV, 1), IT(P_CURV, 2) };
-constexpr unsigned char LIST_B[] = { IT(P_GFINAL, 0), IT(P_GFINAL, 1), IT(P_GFINAL, 2), IT(P_OUTPUT, 0), IT(P_OUTPUT, 1), IT(P_OUTPUT, 2),
-                                     IT(P_OUTPUT, 3), IT(P_DIAG, 0), IT(P_DIAG, 1), IT(P_DIAG, 2), IT(P_HVSWEEP, 0), IT(P_HREF, 0), IT(P_HREF, 1), IT(P_HREF, 2),
-                                     IT(P_HREF, 3), IT(P_HREF, 4),
-                                     IT(P_VWALK, 0), IT(P_VWALK, 1), IT(P_VWALK, 2), IT(P_VWALK, 3), IT(P_VWALK, 4), IT(P_VOTE, 0), IT(P_RBINT, 0), IT(P_RBINT, 1),
-                                     IT(P_RBINT, 2), IT(P_GRAD, 0), IT(P_GRAD, 1), IT(P_GRAD, 2), IT(P_GRAD, 3), IT(P_GRAD, 4) };
-constexpr int NLIST_A = sizeof LIST_A, NLIST_B = sizeof LIST_B;
-static_assert(NLIST_A <= 32 && NLIST_B <= 32, "four 64-bit words per list");
-constexpr unsigned long long list_word(const unsigned char *l, int n, int w)
-{
-    unsigned long long v = 0;
-    for (int k = 7; k >= 0; k--) v = (v << 8) | (8 * w + k < n ? l[8 * w + k] : 255u);
-    return v;
-}
-constexpr int LOADER_WAVE = 3;
+// Which wave runs which items is decided on the host (amaze_rows_launch): the items of a phase, longest first, each to the wave with
+// the least work so far (measured cycles per item below, MLVFS_AMD_AMAZE_ROWS_PROF=2; taking items from a counter in LDS balanced
+// no better and cost 54 same-address atomics per step).  AREA is priced as if idle: where the Nyquist test fired it is by far the
+// longest item, elsewhere it returns at once.  LOAD keeps the next row pair in registers across steps: it must stay with one wave.
+constexpr int NCHUNKS[NPASS] = { 1, 5, 3, 3, 3, 3, 3, 1, 3,   5, 5, 5, 1, 1, 3, 3, 3, 4 };
+constexpr int COST[NPASS] = { 1500, 2350, 1400, 1870, 600, 700, 950, 1580, 1400,   790, 2500, 1520, 1070, 2340, 2970, 680, 1660, 1540 };
+__constant__ unsigned long long c_desc[2][16];      // per phase and wave: up to four items, 16 bits each: item code | lag of its pass << 8
 bool g_tab_ready[64] = {};                          // per device: the kernels' LDS attribute is set
 
 // legacy plane numbering of k_amaze.hip's block, for the debug dump: 13 full planes, then 13 half planes
@@ -222,7 +207,8 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
         return (size_t)y * w + x;
     };
     float pf[5] = { 0, 0, 0, 0, 0 };                              // the loader's row pair, one step ahead
-    const bool loader = wave == LOADER_WAVE;
+    bool loader = false;
+    for (int it = 0; it < 4; it++) loader = loader || ((c_desc[0][wave] >> (16 * it)) & 255ull) == IT(P_LOAD, 0);
     if (loader) {
         int top, left;
         tile_of(0, top, left);
@@ -234,29 +220,7 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
     }
     __syncthreads();
 
-    // this wave's items: those of each phase's list (longest first) dealt in snake order -- wave w takes items w and 31 - w --, LOAD
-    // in front for its wave; 16 bits each: item code, lag of its pass << 8
-    unsigned long long desc_a = ~0ull, desc_b = ~0ull;
-    {
-        auto lag_of = [](int pass) { return (unsigned)((pass < 12 ? LAGS_LO >> (5 * pass) : LAGS_HI >> (5 * (pass - 12))) & 31ull); };
-        auto item_of = [](const unsigned long long w0, const unsigned long long w1, const unsigned long long w2, const unsigned long long w3, int k) {
-            const unsigned long long wd = k < 8 ? w0 : k < 16 ? w1 : k < 24 ? w2 : w3;
-            return (unsigned)((wd >> (8 * (k & 7))) & 255ull);
-        };
-        int na = 0, nb = 0;
-        auto push = [&](unsigned long long &d, int &n, unsigned code) {
-            if (code == 255u) return;
-            const unsigned v = code | lag_of((int)(code >> 3)) << 8;
-            d = (d & ~(0xFFFFull << (16 * n))) | ((unsigned long long)v << (16 * n));
-            n++;
-        };
-        if (loader) push(desc_a, na, IT(P_LOAD, 0));
-        for (int round = 0; round < 2; round++) {
-            const int k = round ? 31 - wave : wave;
-            if (k < NLIST_A) push(desc_a, na, item_of(list_word(LIST_A, NLIST_A, 0), list_word(LIST_A, NLIST_A, 1), list_word(LIST_A, NLIST_A, 2), list_word(LIST_A, NLIST_A, 3), k));
-            if (k < NLIST_B) push(desc_b, nb, item_of(list_word(LIST_B, NLIST_B, 0), list_word(LIST_B, NLIST_B, 1), list_word(LIST_B, NLIST_B, 2), list_word(LIST_B, NLIST_B, 3), k));
-        }
-    }
+    const unsigned long long desc_a = c_desc[0][wave], desc_b = c_desc[1][wave];       // this wave's items
     unsigned long long prof_busy[2] = { 0, 0 }, prof_wait[2] = { 0, 0 }, prof_n = 0, t_phase = 0;
     const bool prof_detail = prof && prof[2 * NPASS + 5 * 16] != 0;
     const int nsteps = nq + LAG_MAX;
@@ -264,7 +228,7 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
 #pragma unroll 1
         for (int phase = 0; phase < 2; phase++) {
 #pragma unroll 1
-            for (int it = 0; it < 3; it++) {
+            for (int it = 0; it < 4; it++) {
                 const unsigned d16 = (unsigned)((phase ? desc_b : desc_a) >> (16 * it)) & 0xFFFFu;
                 if (d16 == 0xFFFFu) break;
                 const int pass = (d16 & 255u) >> 3, ck = d16 & 7u;
@@ -325,8 +289,8 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
                 case P_DIRDIFF: {
 #undef PT
 #define PT TAB_DIRDIFF
-                    // two chunks per item, no branches: two independent instruction streams in one block hide each other's LDS and
-                    // division latencies (an item is bound by its dependency chain, not by its instruction count)
+                    // no branches: one block for the scheduler.  (Two chunks per item -- two independent streams in one block -- took
+                    // 1.49x the time of one: a gain per chunk, a loss for the balance of the phase, whose longest item it became.)
                     struct Out { float halt, valt, vcd, hcd, dgv, dgh; };
                     auto body = [&](const int ck) -> Out {
                         FULL_LANES();
@@ -356,12 +320,11 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
                         o.dgh = in ? fminv(sq(glha - grha), sq(glar - grar)) : 0.0f;
                         return o;
                     };
-                    const Out oa = body(ck), ob = body(ck + 1);
-#pragma unroll
-                    for (int half = 0; half < 2; half++) {
-                        const Out &o = half ? ob : oa;
-                        const int n = (ck + half) * 64 + lane;
-                        if (n < 2 * T) {
+                    const Out oa = body(ck);
+                    {
+                        const Out &o = oa;
+                        const int n = ck * 64 + lane;
+                        {
                             const int rho = n >= T, col = n - T * rho, r = 2 * p + rho; (void)col; (void)r;
                             ST(R_HCDALT, n, o.halt); ST(R_VCDALT, n, o.valt); ST(R_VCD, n, o.vcd);
                             ST(R_HCD, n, o.hcd); ST(R_DGV, n, o.dgv); ST(R_DGH, n, o.dgh);
@@ -919,6 +882,33 @@ int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_g
         std::lock_guard<std::mutex> lk(mu);
         if (dev < 64 && !g_tab_ready[dev]) {
             MLV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tables), &H_TABLES, sizeof H_TABLES));
+            {   // items to waves: longest first, each to the wave with the least work so far
+                int cost[NPASS];
+                for (int k = 0; k < NPASS; k++) cost[k] = COST[k];
+                if (const char *e = getenv("MLVFS_AMD_AMAZE_ROWS_COSTS")) {          // tuning: NPASS comma separated cycle counts
+                    int k = 0;
+                    for (const char *q = e; *q && k < NPASS; k++) { cost[k] = atoi(q); while (*q && *q != ',') q++; if (*q) q++; }
+                }
+                unsigned long long desc[2][16];
+                for (int ph = 0; ph < 2; ph++) {
+                    struct Item { int code, cost; };
+                    std::vector<Item> items;
+                    for (int pass = ph ? P_GRAD : 0; pass < (ph ? NPASS : P_GRAD); pass++)
+                        for (int ck = 0; ck < NCHUNKS[pass]; ck++) items.push_back({ IT(pass, ck), cost[pass] });
+                    std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.cost > y.cost; });
+                    int load[16] = {}, cnt[16] = {};
+                    for (int w2 = 0; w2 < 16; w2++) desc[ph][w2] = ~0ull;
+                    for (const Item &it : items) {
+                        int best = -1;
+                        for (int w2 = 0; w2 < 16; w2++)
+                            if (cnt[w2] < 4 && (best < 0 || load[w2] < load[best])) best = w2;
+                        const unsigned long long v = (unsigned)it.code | (unsigned)LAG[it.code >> 3] << 8;
+                        desc[ph][best] = (desc[ph][best] & ~(0xFFFFull << (16 * cnt[best]))) | v << (16 * cnt[best]);
+                        cnt[best]++; load[best] += it.cost;
+                    }
+                }
+                MLV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_desc), desc, sizeof desc));
+            }
             MLV_HIP(hipFuncSetAttribute((const void *)k_amaze_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * 4));
             MLV_HIP(hipFuncSetAttribute((const void *)k_amaze_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * 4));
             hipDeviceProp_t pr;

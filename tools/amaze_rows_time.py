@@ -4,6 +4,7 @@ import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MLVFS_AMD_AMAZE_ROWS_ONLY", "1")
+os.environ.setdefault("MLVFS_AMD_AMAZE_ROWS", "1")
 from mlvfs_amd import lib, synth
 import torch
 L = lib.load(); L.mlvfs_amd_init(0)
