@@ -83,7 +83,7 @@ struct DiPlanes {
     // AMaZE path only
     float *cfa, *red, *green, *blue;   // squeezed Bayer plane and its demosaic, [h][w]
     int *ev_red, *ev_green, *ev_blue;  // interp_raw2ev of the clamped demosaic (k_di_amaze_clamp): each is looked up by up to six pixels
-    int *gray_ev;              // raw2ev of the de-squeezed gray image, [h][w]
+    int *gray_ev;              // raw2ev of the gray image, squeezed like the planes it comes from, [h][w]
     uint8_t *dir;              // chosen edge direction, [h][w]
     const int *sq_dst, *sq_row;        // per image row: squeezed row it is written to (-1 none) / looked up at (0 if none)
     unsigned *stats;           // semi-overexposed, not overexposed, deep shadow, not shadow (4 per slot, DI_STAT_SLOTS slots per frame)

@@ -12,7 +12,7 @@
 //                   (match_exposures, :650-722)
 //   k_di_score      RANSAC-like score of every candidate slope (:752-772)
 //   k_di_match      14 -> 20 bit and per-pixel exposure correction in double (:781-803, :825-837)
-//   k_di_squeeze, k_di_amaze_clamp, k_di_gray, k_di_edge_dir   the AMaZE-based interpolator around k_amaze.hip
+//   k_di_squeeze, k_di_amaze_ev, k_di_edge_dir   the AMaZE-based interpolator around k_amaze.hip
 //                   (:954-1173); k_di_interp<true> then interpolates along the chosen edge direction (:1181-1208)
 //   k_di_interp     mean23 + borders + full-res pick + half-res mix + overexposure flag +
 //                   alias-map error, fused per pixel (:1231-1380, :1588-1612, :1404-1418, :1620-1626)
@@ -69,8 +69,8 @@ __global__ __launch_bounds__(256) void k_di_analyse(const uint16_t *__restrict__
     const int q = blockIdx.y, y_base = blockIdx.x * DI_BAND + q;
     unsigned *h_w0 = hist + DI_D_WHITE0, *h_w1 = hist + DI_D_WHITE1;
     double sum = 0, n = 0;
-    for (int k = threadIdx.x; k < (DI_BAND / 4) * w; k += blockDim.x) {
-        const int y = y_base + 4 * (k / w), x = k % w;
+    for (int k = threadIdx.x; k < (DI_BAND / 4) * w; k += blockDim.x) {          // (a run of pixels per thread instead -- fewer collisions in the
+        const int y = y_base + 4 * (k / w), x = k % w;                             // LDS counters -- was slower: 0.59 -> 0.71 ms per batch of 8)
         if (y >= H) break;
         const size_t i = (size_t)y * w + x;
         const int p = img[i];
@@ -425,42 +425,25 @@ __global__ __launch_bounds__(256) void k_di_squeeze(const uint32_t *__restrict__
     }
 }
 
-// undo the green scaling, clamp (hdr.c:1041-1050), in place on the squeezed planes
-// + raw2ev of the three clamped values (what the edge-directed interpolation looks up, hdr.c:1181-1208: up to six pixels ask for each)
-__global__ __launch_bounds__(256) void k_di_amaze_clamp(float *__restrict__ red, float *__restrict__ green, float *__restrict__ blue,
-                                                        DiBatch bt, const int *__restrict__ r2e, int *__restrict__ ev_red,
-                                                        int *__restrict__ ev_green, int *__restrict__ ev_blue)
+// undo the green scaling, clamp (hdr.c:1041-1050); what leaves this kernel are the table values everything downstream looks up:
+// raw2ev of the three clamped planes (the edge-directed interpolation, hdr.c:1181-1208: up to six pixels ask for each) and raw2ev of
+// the gray image (hdr.c:1055-1059, 1157-1168) -- still squeezed: k_di_edge_dir de-squeezes through the row map when it stages its rows
+__global__ __launch_bounds__(256) void k_di_amaze_ev(const float *__restrict__ red, const float *__restrict__ green, const float *__restrict__ blue,
+                                                     DiBatch bt, const int *__restrict__ r2e, int *__restrict__ ev_red,
+                                                     int *__restrict__ ev_green, int *__restrict__ ev_blue, int *__restrict__ gray_sq)
 {
     int f; DiParams p;
     if (!di_frame<1>(bt, f, p)) return;
     red += (size_t)f * bt.S; green += (size_t)f * bt.S; blue += (size_t)f * bt.S;
-    ev_red += (size_t)f * bt.S; ev_green += (size_t)f * bt.S; ev_blue += (size_t)f * bt.S;
+    ev_red += (size_t)f * bt.S; ev_green += (size_t)f * bt.S; ev_blue += (size_t)f * bt.S; gray_sq += (size_t)f * bt.S;
     const size_t n = (size_t)p.w * p.h;
     const int black = p.black20;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float fb = (float)black, hi = 1048575.0f;
         const float g = (green[i] - fb) * 2.0f + fb, r = red[i], b = blue[i];
         const float gc = g < hi ? (g > 0.0f ? g : 0.0f) : hi, rc = r < hi ? (r > 0.0f ? r : 0.0f) : hi, bc = b < hi ? (b > 0.0f ? b : 0.0f) : hi;
-        green[i] = gc; red[i] = rc; blue[i] = bc;
         ev_green[i] = r2e[(int)gc]; ev_red[i] = r2e[(int)rc]; ev_blue[i] = r2e[(int)bc];
-    }
-}
-
-// de-squeezed gray image in EV (hdr.c:1055-1059 + the raw2ev lookups of :1157-1168)
-__global__ __launch_bounds__(256) void k_di_gray(const float *__restrict__ red, const float *__restrict__ green,
-                                                 const float *__restrict__ blue, DiBatch bt, const int *__restrict__ sq_row, size_t sq_stride,
-                                                 const int *__restrict__ r2e, int *__restrict__ gray_ev)
-{
-    int f; DiParams p;
-    if (!di_frame<1>(bt, f, p)) return;
-    red += (size_t)f * bt.S; green += (size_t)f * bt.S; blue += (size_t)f * bt.S; gray_ev += (size_t)f * bt.S;
-    sq_row += (size_t)f * sq_stride;
-    const size_t n = (size_t)p.w * p.h;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % p.w), y = (int)(i / p.w);
-        const size_t o = (size_t)sq_row[y] * p.w + x;
-        const unsigned gray = (unsigned)(green[o] / 2 + red[o] / 4 + blue[o] / 4);
-        gray_ev[i] = r2e[gray];
+        gray_sq[i] = r2e[(unsigned)(gc / 2 + rc / 4 + bc / 4)];
     }
 }
 
@@ -480,17 +463,17 @@ __device__ __forceinline__ unsigned di_sad(unsigned a, unsigned b, unsigned c)
     asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__global__ __launch_bounds__(256) void k_di_edge_dir(const uint32_t *__restrict__ raw, const int *__restrict__ gray_ev, DiBatch bt,
-                                                     int fullres_thr, uint8_t *__restrict__ dir, unsigned *__restrict__ stats)
+__global__ __launch_bounds__(256) void k_di_edge_dir(const uint32_t *__restrict__ raw, const int *__restrict__ gray_sq, DiBatch bt,
+                                                     const int *__restrict__ sq_row, size_t sq_stride, int fullres_thr,
+                                                     uint8_t *__restrict__ dir, unsigned *__restrict__ stats)
 {
     constexpr int REACH = 11, SPAN = 256 + 2 * REACH, BIAS = 10 * DI_EVR;        // raw2ev >= -10 EV
     __shared__ unsigned s_rows[4][SPAN];
     int f; DiParams p;
     if (!di_frame<2>(bt, f, p)) return;
-    raw += (size_t)f * bt.S; gray_ev += (size_t)f * bt.S; dir += (size_t)f * bt.S;
+    raw += (size_t)f * bt.S; gray_sq += (size_t)f * bt.S; dir += (size_t)f * bt.S; sq_row += (size_t)f * sq_stride;
     stats += ((size_t)f * DI_STAT_SLOTS + ((blockIdx.x + blockIdx.y) & (DI_STAT_SLOTS - 1))) * 4;
     const int w = p.w, h = p.h, x0 = blockIdx.x * 256, x = x0 + (int)threadIdx.x;
-    const size_t n = (size_t)w * h;
     unsigned n_search = 0, n_plain = 0;                                          // this lane's pixels, bright rows in the low half, dark rows << 16
     for (int y = blockIdx.y; y < h; y += gridDim.y) {                            // (a band of rows per workgroup: 4 atomics per workgroup, not per row)
     const size_t i = (size_t)y * w + x;
@@ -507,9 +490,11 @@ __global__ __launch_bounds__(256) void k_di_edge_dir(const uint32_t *__restrict_
         for (int k = threadIdx.x; k < 4 * SPAN; k += 256) {
             const int rr = k / SPAN, cc = k - rr * SPAN;
             const int row = y + (rr == 0 ? 2 : rr == 1 ? 1 : rr == 2 ? -2 : -3) * s;
-            size_t o = (size_t)row * w + x0 + cc - REACH;                        // flat, like the reference's index arithmetic
-            o = o < n ? o : n - 1;                                               // (beyond the segment's last pixel: nobody reads it)
-            s_rows[rr][cc] = (unsigned)(gray_ev[o] + BIAS);
+            int gy = row, gx = x0 + cc - REACH;                                  // the reference indexes the gray image flat: columns off
+            if (gx < 0) { gy--; gx += w; }                                       // the row's ends are the neighbouring rows'
+            while (gx >= w && gy < h - 1) { gy++; gx -= w; }
+            gx = gx < w ? gx : w - 1;                                            // (beyond the image's last pixel: nobody reads it)
+            s_rows[rr][cc] = (unsigned)(gray_sq[(size_t)sq_row[gy] * w + gx] + BIAS);    // de-squeezed here (hdr.c:1055-1059)
         }
         __syncthreads();
         if (search) {
@@ -1220,9 +1205,10 @@ int di_launch_amaze_interp(const DiBatch &b, int h_launch, const DiLuts &L, cons
                               (int)(sizeof(DiParams) / sizeof(int)));
     } else rc = amaze_launch(P.cfa, w, b.p0.h, P.red, P.green, P.blue, P.amaze_scratch, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_di_amaze_clamp, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b, L.interp_raw2ev, P.ev_red, P.ev_green, P.ev_blue);
-    hipLaunchKernelGGL(k_di_gray, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b, P.sq_row, sq_stride, L.interp_raw2ev, P.gray_ev);
-    hipLaunchKernelGGL(k_di_edge_dir, dim3((w + 255) / 256, (h_launch + 3) / 4, nf), dim3(256), 0, s, P.raw, P.gray_ev, b, L.fullres_thr, P.dir, P.stats);
+    hipLaunchKernelGGL(k_di_amaze_ev, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b, L.interp_raw2ev, P.ev_red, P.ev_green, P.ev_blue,
+                       P.gray_ev);
+    hipLaunchKernelGGL(k_di_edge_dir, dim3((w + 255) / 256, (h_launch + 3) / 4, nf), dim3(256), 0, s, P.raw, P.gray_ev, b, P.sq_row, sq_stride,
+                       L.fullres_thr, P.dir, P.stats);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
