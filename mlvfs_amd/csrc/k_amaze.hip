@@ -20,6 +20,7 @@
 // planes come out bit-identical to the reference's.  No MFMA: this is stencil/select work.
 #include "amaze_math.h"
 #include <cstdlib>
+#include <map>
 
 namespace mlv {
 
@@ -598,12 +599,50 @@ int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green,
         hipLaunchKernelGGL(k_amaze, dim3(nrows * wgs_per_row, nframes), dim3(threads), 0, s, d_raw, w, h, d_red, d_green, d_blue, d_scratch, tiles_x,
                            row0, wgs_per_row, chain_len, rows_per_wg, copy_from, plane_stride, scratch_stride, h_of, h_stride, nfx, nfy);
     };
+    // The complete tiles run on a side stream, next to this stream's launches for the incomplete ones: those are few workgroups in
+    // two dependent launches (1.5 ms of a mostly idle chip per batch of 8 at 3584x1320); k_amaze_rows draws its tiles from a counter,
+    // so its workgroups that start late (behind the first launch below) just take fewer.
+    struct Side {
+        hipStream_t st = nullptr; hipEvent_t go = nullptr, done = nullptr; int *ctr = nullptr; int cap = 0;
+        ~Side() { if (ctr) (void)hipFree(ctr); if (go) (void)hipEventDestroy(go); if (done) (void)hipEventDestroy(done); if (st) (void)hipStreamDestroy(st); }
+    };
+    static thread_local std::map<int, Side> t_side;
+    Side *side = nullptr;
+    bool rows_pending = false;
     if (nfx) {
-        const int rc = amaze_rows_launch(d_raw, w, h, d_red, d_green, d_blue, s, nframes, plane_stride, h_of, h_stride, d_rows_dbg);
-        if (rc) return rc;
+        int dev = 0;
+        MLV_HIP(hipGetDevice(&dev));
+        side = &t_side[dev];
+        if (!side->st) {
+            MLV_HIP(hipStreamCreateWithFlags(&side->st, hipStreamNonBlocking));
+            MLV_HIP(hipEventCreateWithFlags(&side->go, hipEventDisableTiming));
+            MLV_HIP(hipEventCreateWithFlags(&side->done, hipEventDisableTiming));
+        }
+        if (side->cap < nframes) {
+            if (side->ctr) { MLV_HIP(hipStreamSynchronize(side->st)); MLV_HIP(hipFree(side->ctr)); side->ctr = nullptr; }
+            side->cap = nframes > 64 ? nframes : 64;
+            MLV_HIP(hipMalloc(&side->ctr, sizeof(int) * side->cap));
+        }
+        MLV_HIP(hipEventRecord(side->go, s));
+        MLV_HIP(hipStreamWaitEvent(side->st, side->go, 0));
+        MLV_HIP(hipMemsetAsync(side->ctr, 0, sizeof(int) * nframes, side->st));
+        rows_pending = true;
     }
+    auto rows_now = [&]() -> int {                                              // after this stream's first launch has been submitted
+        if (!rows_pending) return MLVFS_AMD_OK;
+        rows_pending = false;
+        const int rc = amaze_rows_launch(d_raw, w, h, d_red, d_green, d_blue, side->st, nframes, plane_stride, h_of, h_stride, d_rows_dbg, side->ctr);
+        if (rc) return rc;
+        MLV_HIP(hipEventRecord(side->done, side->st));
+        return MLVFS_AMD_OK;
+    };
     static const bool rows_only = [] { const char *e = getenv("MLVFS_AMD_AMAZE_ROWS_ONLY"); return e && atoi(e); }();      // timing experiments
-    if (rows_only && nfx) return MLVFS_AMD_OK;
+    if (rows_only && nfx) {
+        const int rc = rows_now();
+        if (rc) return rc;
+        MLV_HIP(hipStreamWaitEvent(s, side->done, 0));
+        return MLVFS_AMD_OK;
+    }
     // incomplete tiles at the right end of a row, chained behind the last complete one
     const int incomplete_x = cc1_last >= AMAZE_TS ? 0 : (cc1_last < 32 ? 2 : 1);
     if (tiles_x < incomplete_x + 1 || tiles_x < 3) {
@@ -614,6 +653,7 @@ int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green,
         const int rows_a = tiles_y - incomplete_y > 0 ? tiles_y - incomplete_y : 0;
         const bool garbage = rr1_last > 32 && rr1_last < 48;                   // the row above the last ran its bottom apron into pmwt
         if (rows_a > 0) launch(0, rows_a, wgs_per_row, chain_len, 1, -1);
+        { const int rc = rows_now(); if (rc) return rc; }
         for (int ty = rows_a; ty < tiles_y; ty++) {
             const int src = ty > 0 ? (ty - 1) * tiles_x + (wgs_per_row - 1) : -1;   // block the previous row ended in
             if (garbage && ty == tiles_y - 1) {
@@ -624,6 +664,8 @@ int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green,
             }
         }
     }
+    { const int rc = rows_now(); if (rc) return rc; }
+    if (side && nfx) MLV_HIP(hipStreamWaitEvent(s, side->done, 0));
     MLV_HIP(hipGetLastError());
 #ifdef AMAZE_DIAG
     {

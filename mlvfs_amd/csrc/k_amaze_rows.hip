@@ -51,7 +51,8 @@ constexpr int pitch_of(int k) { return k < NFULL ? T : HT; }
 constexpr int LDS_PAD = 16;                                       // floats in front of the first ring (reads left of column 0)
 constexpr int ring_off(int k) { int o = LDS_PAD; for (int j = 0; j < k; j++) o += (RR[j] + 1) * pitch_of(j); return o; }
 constexpr int NYQ_OFF = ring_off(NRINGS);                         // floats; the flags are bytes, HT per row
-constexpr int RINGS_FLOATS = NYQ_OFF + ((NYQ_ROWS + 1) * HT + 3) / 4 + LDS_PAD;           // everything that starts as zero
+constexpr int AREA_LIST_FLOATS = 3 * T / 4;                      // three byte lists of up to 160 flagged sites (P_AREA)
+constexpr int RINGS_FLOATS = NYQ_OFF + ((NYQ_ROWS + 1) * HT + 3) / 4 + AREA_LIST_FLOATS + LDS_PAD;           // everything that starts as zero
 
 
 // ---- schedule: lag in row pairs, phase (0 = A, 1 = B)
@@ -172,7 +173,7 @@ template <bool DBG>
 __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ raw, int w, int h, float *__restrict__ red,
                                                       float *__restrict__ green_out, float *__restrict__ blue, int nfx, int ntiles,
                                                       size_t plane_stride, const int *__restrict__ h_of, int h_stride,
-                                                      float *__restrict__ dbg, unsigned long long *__restrict__ prof, unsigned skip_mask)
+                                                      float *__restrict__ dbg, unsigned long long *__restrict__ prof, unsigned skip_mask, int *__restrict__ tile_ctr)
 {
     extern __shared__ float sm[];
     {
@@ -182,15 +183,18 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
         if (DBG) dbg += f * (size_t)ntiles * AMAZE_TILE_FLOATS;
     }
     if ((int)blockIdx.x >= ntiles) return;
-    const int nmine = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles blockIdx.x, + gridDim.x, ...
-    const int nq = nmine * NP;
+    // Tiles come from a counter per frame (tile_ctr): a workgroup that starts late -- the CUs are shared with k_amaze.hip's launches
+    // for the incomplete tiles, on another stream -- simply takes fewer.  ctl[0..3]: the numbers of the tiles in flight (tile k of
+    // this workgroup in ctl[k & 3]), ctl[4]: the pair counter at which the tiles ran out (INT_MAX until then).
+    tile_ctr += blockIdx.y;
+    int *const ctl = (int *)(sm + RINGS_FLOATS - 8);
     for (int n = threadIdx.x; n < RINGS_FLOATS; n += blockDim.x) sm[n] = 0.0f;
     for (int n = threadIdx.x; n < TAB_FLOATS; n += blockDim.x) ((unsigned *)(sm + RINGS_FLOATS))[n] = ((const unsigned *)&c_tables)[n];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
 
     // tile of pair counter q: its number and its origin in the image
     auto tile_of = [&](int q, int &top, int &left) -> int {
-        const int id = (int)blockIdx.x + (q / NP) * (int)gridDim.x;
+        const int id = __builtin_amdgcn_readfirstlane(ctl[(q / NP) & 3]);
         top = -16 + (id / nfx) * (T - 32);
         left = -16 + (id % nfx) * (T - 32);
         return id;
@@ -209,13 +213,18 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
     float pf[5] = { 0, 0, 0, 0, 0 };                              // the loader's row pair, one step ahead
     bool loader = false;
     for (int it = 0; it < 4; it++) loader = loader || ((c_desc[0][wave] >> (16 * it)) & 255ull) == IT(P_LOAD, 0);
+    __syncthreads();                                               // (the rings are zero)
+    auto next_tile = [&]() { int id = 0; if (lane == 0) id = atomicAdd(tile_ctr, 1); return __builtin_amdgcn_readfirstlane(id); };
     if (loader) {
-        int top, left;
-        tile_of(0, top, left);
+        const int id = next_tile();
+        if (lane == 0) { ctl[0] = id; ctl[4] = id < ntiles ? 0x7FFFFFFF : 0; }
+        if (id < ntiles) {
+            const int top = -16 + (id / nfx) * (T - 32), left = -16 + (id % nfx) * (T - 32);
 #pragma unroll
-        for (int ck = 0; ck < 5; ck++) {
-            const int n = ck * 64 + lane, rho = n >= T, col = n - T * rho;
-            pf[ck] = raw[source(top, left, rho, col)];
+            for (int ck = 0; ck < 5; ck++) {
+                const int n = ck * 64 + lane, rho = n >= T, col = n - T * rho;
+                pf[ck] = raw[source(top, left, rho, col)];
+            }
         }
     }
     __syncthreads();
@@ -223,8 +232,9 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
     const unsigned long long desc_a = c_desc[0][wave], desc_b = c_desc[1][wave];       // this wave's items
     unsigned long long prof_busy[2] = { 0, 0 }, prof_wait[2] = { 0, 0 }, prof_n = 0, t_phase = 0;
     const bool prof_detail = prof && prof[2 * NPASS + 5 * 16] != 0;
-    const int nsteps = nq + LAG_MAX;
-    for (int s = 0; s < nsteps; s++) {
+    for (int s = 0;; s++) {
+        const int nq = __builtin_amdgcn_readfirstlane(ctl[4]);         // (written in phase A of an earlier step, if at all)
+        if (s - LAG_MAX >= nq) break;
 #pragma unroll 1
         for (int phase = 0; phase < 2; phase++) {
 #pragma unroll 1
@@ -258,10 +268,14 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
                         ST(R_C, n, v);
                         if (DBG) { const int rho = n >= T, col = n - T * rho, r = 2 * p + rho; DBGF(D_CFA, v); }
                     }
-                    if (q + 1 < nq) {
-                        int top, left;
-                        tile_of(q + 1, top, left);
-                        const int p1 = (q + 1) % NP;
+                    const int p1 = (q + 1) % NP;
+                    int id1 = __builtin_amdgcn_readfirstlane(ctl[((q + 1) / NP) & 3]);
+                    if (p1 == 0) {                                                 // the next pair opens a tile: which one, if any
+                        id1 = next_tile();
+                        if (lane == 0) { if (id1 < ntiles) ctl[((q + 1) / NP) & 3] = id1; else ctl[4] = q + 1; }
+                    }
+                    if (id1 < ntiles) {
+                        const int top = -16 + (id1 / nfx) * (T - 32), left = -16 + (id1 % nfx) * (T - 32);
 #pragma unroll
                         for (int c5 = 0; c5 < 5; c5++) {
                             const int n = c5 * 64 + lane, rho = n >= T, col = n - T * rho;
@@ -487,25 +501,50 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
                 case P_AREA: {
 #undef PT
 #define PT TAB_AREA
-                    HALF_LANES();
-                    const bool in = act && r >= 8 && r < T - 8 && hj >= 4 && hj < 76;
-                    const bool flag = in && FPN(0)[n] != 0;
-                    if (!__any(flag)) break;
+                    // The flagged sites of the pair are few where they exist at all, and a wave pays for the 49-tap loop whether one
+                    // of its lanes works or all: each of the three items lists the pair's flagged sites (ballots, ranks, a byte list in
+                    // LDS of its own) and takes the 64 * ck-th ... of them -- one loop per 64 flagged sites, not per 64 sites.
+                    unsigned char *list = (unsigned char *)(sm + RINGS_FLOATS - LDS_PAD - AREA_LIST_FLOATS) + ck * T;
+                    int nflag = 0;
+#pragma unroll
+                    for (int c3 = 0; c3 < 3; c3++) {
+                        const int n3 = c3 * 64 + lane, rho3 = n3 >= HT, hj3 = n3 - HT * rho3, r3 = 2 * p + rho3;
+                        const bool fl3 = n3 < T && r3 >= 8 && r3 < T - 8 && hj3 >= 4 && hj3 < 76 && FPN(0)[n3] != 0;
+                        const unsigned long long m = __ballot(fl3);
+                        if (fl3) list[nflag + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned char)n3;
+                        nflag += __popcll(m);
+                    }
+                    if (nflag <= 64 * ck) break;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const bool flag = 64 * ck + lane < nflag;
+                    const int n = flag ? list[64 * ck + lane] : 0;
+                    const int rho = n >= HT, hj = n - HT * rho, col = 2 * hj + rho, r = 2 * p + rho, f0 = T * rho + col; (void)col; (void)r;
                     if (flag) {
+                        // a row of the 7x7 window at a time: its seven flags and its 29 cfa values are loaded together, whatever the flags
+                        // say (one LDS round trip per row instead of two per tap), and a tap that is not flagged adds nothing -- by
+                        // select, in the reference's order of additions
                         float sumh = 0, sumv = 0, sumsqh = 0, sumsqv = 0, area = 0;
 #pragma unroll 1
                         for (int a = -6; a < 7; a += 2) {
                             const unsigned char *ny = FPN(a) + n;
                             const float *ca = FP(R_C, a) + f0, *cu = FP(R_C, a - 1) + f0, *cd = FP(R_C, a + 1) + f0;
+                            unsigned char fl[7];
+                            float vc_[15], vu_[7], vd_[7];
 #pragma unroll
-                            for (int b = -6; b < 7; b += 2) {
-                                if (!ny[b / 2]) continue;
-                                const float cj = ca[b];
-                                sumh += cj - half_exp(ca[b - 1] + ca[b + 1]);
-                                sumv += cj - half_exp(cu[b] + cd[b]);
-                                sumsqh += half_exp(sq(cj - ca[b - 1]) + sq(cj - ca[b + 1]));
-                                sumsqv += half_exp(sq(cj - cu[b]) + sq(cj - cd[b]));
-                                area += 1;
+                            for (int k = 0; k < 7; k++) { fl[k] = ny[k - 3]; vu_[k] = cu[2 * k - 6]; vd_[k] = cd[2 * k - 6]; }
+#pragma unroll
+                            for (int k = 0; k < 15; k++) vc_[k] = ca[k - 7];
+#pragma unroll
+                            for (int k = 0; k < 7; k++) {
+                                const bool on = fl[k] != 0;
+                                const float cj = vc_[2 * k + 1], cl = vc_[2 * k], cr = vc_[2 * k + 2];
+                                const float th = cj - half_exp(cl + cr), tv = cj - half_exp(vu_[k] + vd_[k]);
+                                const float qh = half_exp(sq(cj - cl) + sq(cj - cr)), qv = half_exp(sq(cj - vu_[k]) + sq(cj - vd_[k]));
+                                sumh = on ? sumh + th : sumh;
+                                sumv = on ? sumv + tv : sumv;
+                                sumsqh = on ? sumsqh + qh : sumsqh;
+                                sumsqv = on ? sumsqv + qv : sumsqv;
+                                area = on ? area + 1.0f : area;
                             }
                         }
                         const float hvar = EPSSQ + fabsf(area * sumsqh - sumh * sumh), vvar = EPSSQ + fabsf(area * sumsqv - sumv * sumv);
@@ -818,13 +857,13 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
 #undef C
 #undef HP
 
-int g_amaze_rows_mode = -1;        // -1: MLVFS_AMD_AMAZE_ROWS decides (default off), 0 / 1: forced (the debug entry point)
+int g_amaze_rows_mode = -1;        // -1: MLVFS_AMD_AMAZE_ROWS decides (default on), 0 / 1: forced (the debug entry point)
 
 // Complete tiles of a w x h plane that this kernel takes: the first nfx columns and nfy rows of the tile grid -- tiles whose
 // 160 rows and columns lie inside the image (no right / bottom apron) and that do not head a chain of incomplete tiles.
 void amaze_rows_extent(int w, int h, int *nfx, int *nfy)
 {
-    static const bool off = [] { const char *e = getenv("MLVFS_AMD_AMAZE_ROWS"); return !e || atoi(e) == 0; }();       // opt-in while it is not the faster one
+    static const bool off = [] { const char *e = getenv("MLVFS_AMD_AMAZE_ROWS"); return e && atoi(e) == 0; }();
     *nfx = *nfy = 0;
     if (g_amaze_rows_mode == 0 || (g_amaze_rows_mode < 0 && off)) return;
     const int step = T - 32;
@@ -841,7 +880,7 @@ void amaze_rows_extent(int w, int h, int *nfx, int *nfy)
 }
 
 int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, hipStream_t s, int nframes,
-                      size_t plane_stride, const int *h_of, int h_stride, float *d_dbg)
+                      size_t plane_stride, const int *h_of, int h_stride, float *d_dbg, int *d_ctr)
 {
     // MLVFS_AMD_AMAZE_ROWS_PROF=1: cycles per item of each pass and per wave at the barriers (workgroup 0, steady state), printed at exit
     static unsigned long long *d_prof = [] {
@@ -926,10 +965,10 @@ int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_g
     per_frame = per_frame < 1 ? 1 : (per_frame > ntiles ? ntiles : per_frame);
     if (d_dbg)
         hipLaunchKernelGGL(k_amaze_rows<true>, dim3(per_frame, nframes), dim3(1024), LDS_FLOATS * 4, s, d_raw, w, h, d_red, d_green, d_blue, nfx,
-                           ntiles, plane_stride, h_of, h_stride, d_dbg, d_prof, skip);
+                           ntiles, plane_stride, h_of, h_stride, d_dbg, d_prof, skip, d_ctr);
     else
         hipLaunchKernelGGL(k_amaze_rows<false>, dim3(per_frame, nframes), dim3(1024), LDS_FLOATS * 4, s, d_raw, w, h, d_red, d_green, d_blue, nfx,
-                           ntiles, plane_stride, h_of, h_stride, d_dbg, d_prof, skip);
+                           ntiles, plane_stride, h_of, h_stride, d_dbg, d_prof, skip, d_ctr);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
