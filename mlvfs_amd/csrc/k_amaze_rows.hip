@@ -66,7 +66,7 @@ constexpr int LAG_MAX = 18;
 // no better and cost 54 same-address atomics per step).  AREA is priced as if idle: where the Nyquist test fired it is by far the
 // longest item, elsewhere it returns at once.  LOAD keeps the next row pair in registers across steps: it must stay with one wave.
 constexpr int NCHUNKS[NPASS] = { 1, 5, 3, 3, 3, 3, 3, 1, 3,   5, 5, 5, 1, 1, 3, 3, 3, 4 };
-constexpr int COST[NPASS] = { 1500, 2350, 1400, 1870, 600, 700, 950, 1580, 1400,   790, 2500, 1520, 1070, 2340, 2970, 680, 1660, 1540 };
+constexpr int COST[NPASS] = { 2630, 2060, 2780, 2620, 1160, 950, 1160, 2940, 2550,   890, 2360, 1590, 1360, 2970, 3200, 810, 4010, 2860 };
 __constant__ unsigned long long c_desc[2][16];      // per phase and wave: up to four items, 16 bits each: item code | lag of its pass << 8
 bool g_tab_ready[64] = {};                          // per device: the kernels' LDS attribute is set
 
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
                                                       size_t plane_stride, const int *__restrict__ h_of, int h_stride,
                                                       float *__restrict__ dbg, unsigned long long *__restrict__ prof, unsigned skip_mask, int *__restrict__ tile_ctr)
 {
-    extern __shared__ float sm[];
+    __shared__ float sm[LDS_FLOATS];                          // static: row offsets are compile-time constants (a dynamic array costs an add each)
     {
         const size_t f = blockIdx.y;
         if (h_of && h_of[f * (size_t)h_stride] != h) return;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
     __syncthreads();
 
     const unsigned long long desc_a = c_desc[0][wave], desc_b = c_desc[1][wave];       // this wave's items
-    unsigned long long prof_busy[2] = { 0, 0 }, prof_wait[2] = { 0, 0 }, prof_n = 0, t_phase = 0;
+    unsigned long long prof_busy[2] = { 0, 0 }, prof_wait[2] = { 0, 0 }, prof_items[2] = { 0, 0 }, prof_n = 0, t_phase = 0;
     const bool prof_detail = prof && prof[2 * NPASS + 5 * 16] != 0;
     for (int s = 0;; s++) {
         const int nq = __builtin_amdgcn_readfirstlane(ctl[4]);         // (written in phase A of an earlier step, if at all)
@@ -836,6 +836,7 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
                 }
                 if (prof_detail && s >= 2 * LAG_MAX && s < nq && blockIdx.x == 0 && blockIdx.y == 0) {   // steady state: cycles per item
                     const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_item;
+                    prof_items[phase] += dt;
                     if (lane == 0) { atomicAdd(&prof[2 * pass], dt); atomicAdd(&prof[2 * pass + 1], 1ull); }
                 }
             }
@@ -851,6 +852,7 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
     if (prof && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && prof_n) {     // per wave of workgroup 0: busy A, wait A, busy B, wait B, phases
         unsigned long long *o = prof + 2 * NPASS + 5 * wave;
         o[0] = prof_busy[0]; o[1] = prof_wait[0]; o[2] = prof_busy[1]; o[3] = prof_wait[1];
+        if (prof_detail) { o[1] = prof_items[0]; o[3] = prof_items[1]; }                // (detail mode: the items' own time in place of the waits)
         o[4] = prof_n | (unsigned long long)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)) << 56;       // HW_ID.SIMD_ID
     }
 }
@@ -935,12 +937,13 @@ int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_g
                     for (int pass = ph ? P_GRAD : 0; pass < (ph ? NPASS : P_GRAD); pass++)
                         for (int ck = 0; ck < NCHUNKS[pass]; ck++) items.push_back({ IT(pass, ck), cost[pass] });
                     std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.cost > y.cost; });
-                    int load[16] = {}, cnt[16] = {};
+                    int load[16] = {}, cnt[16] = {}, simd[4] = {};                     // waves w, w + 4, w + 8, w + 12 share a SIMD: its sum counts too
                     for (int w2 = 0; w2 < 16; w2++) desc[ph][w2] = ~0ull;
                     for (const Item &it : items) {
                         int best = -1;
                         for (int w2 = 0; w2 < 16; w2++)
-                            if (cnt[w2] < 4 && (best < 0 || load[w2] < load[best])) best = w2;
+                            if (cnt[w2] < 4 && (best < 0 || 2 * load[w2] + simd[w2 & 3] < 2 * load[best] + simd[best & 3])) best = w2;
+                        simd[best & 3] += it.cost;
                         const unsigned long long v = (unsigned)it.code | (unsigned)LAG[it.code >> 3] << 8;
                         desc[ph][best] = (desc[ph][best] & ~(0xFFFFull << (16 * cnt[best]))) | v << (16 * cnt[best]);
                         cnt[best]++; load[best] += it.cost;
@@ -948,8 +951,6 @@ int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_g
                 }
                 MLV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_desc), desc, sizeof desc));
             }
-            MLV_HIP(hipFuncSetAttribute((const void *)k_amaze_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * 4));
-            MLV_HIP(hipFuncSetAttribute((const void *)k_amaze_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * 4));
             hipDeviceProp_t pr;
             MLV_HIP(hipGetDeviceProperties(&pr, dev));
             cus[dev] = pr.multiProcessorCount;
@@ -964,10 +965,10 @@ int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_g
     if (cap > 0 && per_frame > cap) per_frame = cap;
     per_frame = per_frame < 1 ? 1 : (per_frame > ntiles ? ntiles : per_frame);
     if (d_dbg)
-        hipLaunchKernelGGL(k_amaze_rows<true>, dim3(per_frame, nframes), dim3(1024), LDS_FLOATS * 4, s, d_raw, w, h, d_red, d_green, d_blue, nfx,
+        hipLaunchKernelGGL(k_amaze_rows<true>, dim3(per_frame, nframes), dim3(1024), 0, s, d_raw, w, h, d_red, d_green, d_blue, nfx,
                            ntiles, plane_stride, h_of, h_stride, d_dbg, d_prof, skip, d_ctr);
     else
-        hipLaunchKernelGGL(k_amaze_rows<false>, dim3(per_frame, nframes), dim3(1024), LDS_FLOATS * 4, s, d_raw, w, h, d_red, d_green, d_blue, nfx,
+        hipLaunchKernelGGL(k_amaze_rows<false>, dim3(per_frame, nframes), dim3(1024), 0, s, d_raw, w, h, d_red, d_green, d_blue, nfx,
                            ntiles, plane_stride, h_of, h_stride, d_dbg, d_prof, skip, d_ctr);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
