@@ -244,8 +244,8 @@ def extra_footage(F=48):
 def extra_dualiso(golden, fnv1a, batch=8, reps=4, threads=3):
     """configs[3]: full dual-ISO conversion (AMaZE + edge-directed interpolation, full-res, alias map) of 3584x1320 frames resident
     in HBM: (a) one conversion at a time (latency), (b) mlvfs_amd_cr2hdr20_batch_dev with `batch` frames per submission from one
-    host thread, (c) the same from `threads` host threads, each with its own stream and batch (the analysis kernels of one batch
-    overlap the AMaZE tiles of another).  Every converted frame is hashed against the reference's output."""
+    host thread, (c) the same from `threads` and `threads + 1` host threads, each with its own stream and batch (the analysis kernels of
+    one batch overlap the AMaZE tiles of another).  Every converted frame is hashed against the reference's output."""
     import torch
     from mlvfs_amd import lib, synth
     L = lib.load()
@@ -289,7 +289,7 @@ def extra_dualiso(golden, fnv1a, batch=8, reps=4, threads=3):
         oks[i] = sum(run() for _ in range(n_batches))
         t_end[i] = time.perf_counter()
 
-    for T in (1, threads):
+    for T in (1, threads, threads + 1):
         streams = [torch.cuda.Stream() for _ in range(T)]
         bufs = [torch.empty((batch, H, W), dtype=torch.int16, device="cuda") for _ in range(T)]
         t_begin, t_end, oks, go = [0.0] * T, [0.0] * T, [0] * T, threading.Barrier(T)

@@ -502,8 +502,10 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
             if (fabsf(0.5f - s_w[j]) < fabsf(0.5f - hw)) continue;
             // sic: the half-width rbint plane is offset by a FULL row in the reference (indx1 - v1), :1289-1290
             const float rb = t.rbint[j], rbu = t.rbint[j - V1], rbd = t.rbint[j + V1], rbl = t.rbint[j - 1], rbr = t.rbint[j + 1];
-            const float cru = (float)((double)c[i - V1] * 2.0 / (double)(EPS + rb + rbu)), crd = (float)((double)c[i + V1] * 2.0 / (double)(EPS + rb + rbd));
-            const float crl = (float)((double)c[i - 1] * 2.0 / (double)(EPS + rb + rbl)), crr = (float)((double)c[i + 1] * 2.0 / (double)(EPS + rb + rbr));
+            // the reference divides in double (a 2.0 literal) and stores a float: for float operands that IS the correctly rounded
+            // float quotient (53 >= 2 * 24 + 2 bits: the second rounding is innocuous), so binary32 division gives the same bits
+            const float cru = (c[i - V1] * 2.0f) / (EPS + rb + rbu), crd = (c[i + V1] * 2.0f) / (EPS + rb + rbd);
+            const float crl = (c[i - 1] * 2.0f) / (EPS + rb + rbl), crr = (c[i + 1] * 2.0f) / (EPS + rb + rbr);
             const float gu = fabsf(1.0f - cru) < ARTHRESH ? rb * cru : c[i - V1] + half_exp(rb - rbu);
             const float gd = fabsf(1.0f - crd) < ARTHRESH ? rb * crd : c[i + V1] + half_exp(rb - rbd);
             const float gl = fabsf(1.0f - crl) < ARTHRESH ? rb * crl : c[i - 1] + half_exp(rb - rbl);
@@ -512,11 +514,11 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
             float gh = (t.dw1[i - 1] * gr + t.dw1[i + 1] * gl) / (t.dw1[i - 1] + t.dw1[i + 1]);
             if (gv < rb) {
                 if (2.0f * gv < rb) gv = ulim(gv, c[i - V1], c[i + V1]);
-                else { const float wt = (float)(2.0 * (double)(rb - gv) / (double)(EPS + gv + rb)); gv = wt * gv + (1.0f - wt) * ulim(gv, c[i - V1], c[i + V1]); }
+                else { const float wt = (2.0f * (rb - gv)) / (EPS + gv + rb); gv = wt * gv + (1.0f - wt) * ulim(gv, c[i - V1], c[i + V1]); }
             }
             if (gh < rb) {
                 if (2.0f * gh < rb) gh = ulim(gh, c[i - 1], c[i + 1]);
-                else { const float wt = (float)(2.0 * (double)(rb - gh) / (double)(EPS + gh + rb)); gh = wt * gh + (1.0f - wt) * ulim(gh, c[i - 1], c[i + 1]); }
+                else { const float wt = (2.0f * (rb - gh)) / (EPS + gh + rb); gh = wt * gh + (1.0f - wt) * ulim(gh, c[i - 1], c[i + 1]); }
             }
             if (gh > CLIP_PT) gh = ulim(gh, c[i - 1], c[i + 1]);
             if (gv > CLIP_PT) gv = ulim(gv, c[i - V1], c[i + V1]);

@@ -66,7 +66,7 @@ constexpr int LAG_MAX = 18;
 // no better and cost 54 same-address atomics per step).  AREA is priced as if idle: where the Nyquist test fired it is by far the
 // longest item, elsewhere it returns at once.  LOAD keeps the next row pair in registers across steps: it must stay with one wave.
 constexpr int NCHUNKS[NPASS] = { 1, 5, 3, 3, 3, 3, 3, 1, 3,   5, 5, 5, 1, 1, 3, 3, 3, 4 };
-constexpr int COST[NPASS] = { 2630, 2060, 2780, 2620, 1160, 950, 1160, 2940, 2550,   890, 2360, 1590, 1360, 2970, 3200, 810, 4010, 2860 };
+constexpr int COST[NPASS] = { 2630, 2060, 2780, 2620, 1160, 950, 1160, 2940, 2550,   890, 2360, 1590, 1360, 2970, 3200, 810, 2610, 2860 };
 __constant__ unsigned long long c_desc[2][16];      // per phase and wave: up to four items, 16 bits each: item code | lag of its pass << 8
 bool g_tab_ready[64] = {};                          // per device: the kernels' LDS attribute is set
 
@@ -737,8 +737,10 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
                             // sic: the half-width rbint plane is offset by a FULL row in the reference (indx1 - v1), :1289-1290
                             const float rb = FP(R_RBINT, 0)[n], rbu = FP(R_RBINT, -2)[n], rbd = FP(R_RBINT, 2)[n], rbl = FP(R_RBINT, 0)[n - 1], rbr = FP(R_RBINT, 0)[n + 1];
                             const float cu1 = C(-1, 0), cd1 = C(1, 0), cl1 = c0[-1], cr1 = c0[1];
-                            const float cru = (float)((double)cu1 * 2.0 / (double)(EPS + rb + rbu)), crd = (float)((double)cd1 * 2.0 / (double)(EPS + rb + rbd));
-                            const float crl = (float)((double)cl1 * 2.0 / (double)(EPS + rb + rbl)), crr = (float)((double)cr1 * 2.0 / (double)(EPS + rb + rbr));
+                            // the reference divides in double (a 2.0 literal) and stores a float: for float operands that IS the correctly rounded
+                            // float quotient (53 >= 2 * 24 + 2 bits: the second rounding is innocuous), so binary32 division gives the same bits
+                            const float cru = (cu1 * 2.0f) / (EPS + rb + rbu), crd = (cd1 * 2.0f) / (EPS + rb + rbd);
+                            const float crl = (cl1 * 2.0f) / (EPS + rb + rbl), crr = (cr1 * 2.0f) / (EPS + rb + rbr);
                             const float gu = fabsf(1.0f - cru) < ARTHRESH ? rb * cru : cu1 + half_exp(rb - rbu);
                             const float gd = fabsf(1.0f - crd) < ARTHRESH ? rb * crd : cd1 + half_exp(rb - rbd);
                             const float gl = fabsf(1.0f - crl) < ARTHRESH ? rb * crl : cl1 + half_exp(rb - rbl);
@@ -753,11 +755,11 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
                             float gh = (dw1l * gr + dw1r * gl) / (dw1l + dw1r);
                             if (gv < rb) {
                                 if (2.0f * gv < rb) gv = ulim(gv, cu1, cd1);
-                                else { const float wt = (float)(2.0 * (double)(rb - gv) / (double)(EPS + gv + rb)); gv = wt * gv + (1.0f - wt) * ulim(gv, cu1, cd1); }
+                                else { const float wt = (2.0f * (rb - gv)) / (EPS + gv + rb); gv = wt * gv + (1.0f - wt) * ulim(gv, cu1, cd1); }
                             }
                             if (gh < rb) {
                                 if (2.0f * gh < rb) gh = ulim(gh, cl1, cr1);
-                                else { const float wt = (float)(2.0 * (double)(rb - gh) / (double)(EPS + gh + rb)); gh = wt * gh + (1.0f - wt) * ulim(gh, cl1, cr1); }
+                                else { const float wt = (2.0f * (rb - gh)) / (EPS + gh + rb); gh = wt * gh + (1.0f - wt) * ulim(gh, cl1, cr1); }
                             }
                             if (gh > CLIP_PT) gh = ulim(gh, cl1, cr1);
                             if (gv > CLIP_PT) gv = ulim(gv, cu1, cd1);
