@@ -293,11 +293,12 @@ def extra_dualiso(golden, fnv1a, batch=8, reps=4, threads=3):
         streams = [torch.cuda.Stream() for _ in range(T)]
         bufs = [torch.empty((batch, H, W), dtype=torch.int16, device="cuda") for _ in range(T)]
         t_begin, t_end, oks, go = [0.0] * T, [0.0] * T, [0] * T, threading.Barrier(T)
-        ths = [threading.Thread(target=batch_worker, args=(i, bufs, streams, reps, t_begin, t_end, oks, go)) for i in range(T)]
+        nb = reps if T == 1 else 2 * reps                      # (several threads: a longer run, the start-up is uneven)
+        ths = [threading.Thread(target=batch_worker, args=(i, bufs, streams, nb, t_begin, t_end, oks, go)) for i in range(T)]
         for t in ths: t.start()
         for t in ths: t.join()
         torch.cuda.synchronize()
-        n = T * batch * reps
+        n = T * batch * nb
         if sum(oks) != n:
             raise RuntimeError("cr2hdr20_batch_dev did not convert every frame")
         dt = max(t_end) - min(t_begin)

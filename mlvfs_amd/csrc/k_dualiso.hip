@@ -1207,7 +1207,8 @@ int di_launch_amaze_interp(const DiBatch &b, int h_launch, const DiLuts &L, cons
     if (rc) return rc;
     hipLaunchKernelGGL(k_di_amaze_ev, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b, L.interp_raw2ev, P.ev_red, P.ev_green, P.ev_blue,
                        P.gray_ev);
-    hipLaunchKernelGGL(k_di_edge_dir, dim3((w + 255) / 256, (h_launch + 3) / 4, nf), dim3(256), 0, s, P.raw, P.gray_ev, b, P.sq_row, sq_stride,
+    static const int edge_rows = [] { const char *e = getenv("MLVFS_AMD_EDGE_ROWS"); const int v = e ? atoi(e) : 4; return v > 0 ? v : 4; }();   // rows per workgroup
+    hipLaunchKernelGGL(k_di_edge_dir, dim3((w + 255) / 256, (h_launch + edge_rows - 1) / edge_rows, nf), dim3(256), 0, s, P.raw, P.gray_ev, b, P.sq_row, sq_stride,
                        L.fullres_thr, P.dir, P.stats);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
