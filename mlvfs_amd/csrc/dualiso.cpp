@@ -370,6 +370,7 @@ static void squeezed_rows(const DiParams &p, int *sq, int hs)
             if (is_bright(y) == pass && sq[y] >= 0) owner[sq[y]] = y;
     for (int y = 0; y < h; y++)
         if (sq[y] >= 0 && owner[sq[y]] != y) sq[y] = -1;
+    for (int y = 0; y < hs; y++) sq[2 * hs + y] = y < h ? owner[y] : 0;         // squeezed row -> its source row, -1: no exposure lands on it (stays zero)
 }
 
 // AMaZE tile planes of a batch: frame f's blocks at f * stride; a slot is zeroed when it is (re)allocated or when the rows of the
@@ -423,7 +424,7 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
     const bool amaze = o.interp_method == 0;
     const size_t o_cfa = take(amaze ? NF * S * 4 : 0), o_red = take(amaze ? NF * S * 4 : 0), o_green = take(amaze ? NF * S * 4 : 0),
                  o_blue = take(amaze ? NF * S * 4 : 0), o_ev = take(amaze ? NF * S * 12 : 0), o_gray = take(amaze ? NF * S * 4 : 0), o_dir = take(amaze ? NF * S : 0),
-                 o_sq = take(amaze ? NF * (size_t)H * 8 : 0), o_stats = take(NF * 16 * DI_STAT_SLOTS);
+                 o_sq = take(amaze ? NF * (size_t)H * 12 : 0), o_stats = take(NF * 16 * DI_STAT_SLOTS);
     DiWork &wk = t_work[c->dev->id];
     rc = wk.ensure(off);
     if (rc) return rc;
@@ -432,7 +433,7 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
     // page-locked landing zone: every copy of this path starts or ends here (a copy from or to pageable memory waits inside the
     // runtime for the stream to reach it, and the calls of the other host threads wait with it)
     const size_t ph_dd = 0, ph_pp = ph_dd + up(NF * sizeof(DiDecide)), ph_sq = ph_pp + up(NF * sizeof(DiParams)),
-                 ph_st = ph_sq + up(NF * (size_t)H * 8), ph_check = ph_st + up(NF * 16 * DI_STAT_SLOTS), ph_end = ph_check + up(NF * 16);
+                 ph_st = ph_sq + up(NF * (size_t)H * 12), ph_check = ph_st + up(NF * 16 * DI_STAT_SLOTS), ph_end = ph_check + up(NF * 16);
     PinnedWork &pw = t_pinned[c->dev->id];
     rc = pw.ensure(ph_end);
     if (rc) return rc;
@@ -537,15 +538,17 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
                 (uint32_t *)(B + o_half), (uint32_t *)(B + o_full_s), (uint32_t *)(B + o_half_s), (uint16_t *)(B + o_over),
                 (uint16_t *)(B + o_amap), (uint16_t *)(B + o_aux), (uint16_t *)(B + o_amap2), (int *)(B + o_cells) };
     P.cells_stride = cells_stride;
-    rc = di_launch_match(d_frames, bt, H, P, stream);
-    if (rc) return rc;
+    if (!amaze) {
+        rc = di_launch_match(d_frames, bt, H, P, stream);
+        if (rc) return rc;
+    }
     if (amaze) {
-        int *sq = (int *)(PH + ph_sq);                         // per frame: sq_dst | sq_row, H entries each
+        int *sq = (int *)(PH + ph_sq);                         // per frame: sq_dst | sq_row | source row of a squeezed row, H entries each
         for (int f = 0; f < nframes; f++) {
-            if (results[f] == 1) squeezed_rows(pp[f], sq + (size_t)f * 2 * H, H);
-            else memset(sq + (size_t)f * 2 * H, 0, (size_t)2 * H * 4);
+            if (results[f] == 1) squeezed_rows(pp[f], sq + (size_t)f * 3 * H, H);
+            else memset(sq + (size_t)f * 3 * H, 0, (size_t)3 * H * 4);
         }
-        MLV_HIP(hipMemcpyAsync(B + o_sq, sq, NF * (size_t)2 * H * 4, hipMemcpyHostToDevice, stream));
+        MLV_HIP(hipMemcpyAsync(B + o_sq, sq, NF * (size_t)3 * H * 4, hipMemcpyHostToDevice, stream));
         // AMaZE's tile planes
         AmazeSlots &as = t_amaze_slots[c->dev->id];
         const size_t a_stride = amaze_scratch_bytes(w, H) / sizeof(float);
@@ -567,7 +570,7 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
         P.gray_ev = (int *)(B + o_gray); P.dir = (uint8_t *)(B + o_dir);
         P.sq_dst = (const int *)(B + o_sq); P.sq_row = P.sq_dst + H;
         P.stats = (unsigned *)(B + o_stats); P.amaze_scratch = (float *)as.base; P.amaze_scratch_stride = a_stride;
-        rc = di_launch_amaze_interp(bt, H, L, P, stream);
+        rc = di_launch_amaze_interp(d_frames, bt, H, L, P, stream);
         if (rc) return rc;
     }
     rc = di_launch_convert(bt, H, L, P, amaze, d_frames, stream);

@@ -105,7 +105,7 @@ extern int g_amaze_rows_mode;
 void amaze_rows_extent(int w, int h, int *nfx, int *nfy);
 int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, hipStream_t s, int nframes,
                       size_t plane_stride, const int *h_of, int h_stride, float *d_dbg, int *d_ctr /* nframes zeroed ints: the tile counters */);
-int di_launch_amaze_interp(const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s);
+int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s);   // incl. the exposure match
 
 int di_launch_analyse(const void *d_img, int w, int H, int black, int white, const double *d_evf, unsigned *d_hist,
                       double *d_check, hipStream_t s, int nframes = 1, size_t img_stride = 0, size_t hist_stride = 0, size_t check_stride = 0);

@@ -12,7 +12,7 @@
 //                   (match_exposures, :650-722)
 //   k_di_score      RANSAC-like score of every candidate slope (:752-772)
 //   k_di_match      14 -> 20 bit and per-pixel exposure correction in double (:781-803, :825-837)
-//   k_di_squeeze, k_di_amaze_ev, k_di_edge_dir   the AMaZE-based interpolator around k_amaze.hip
+//   k_di_match (with the squeeze), k_di_amaze_ev, k_di_edge_dir   the AMaZE-based interpolator around k_amaze.hip
 //                   (:954-1173); k_di_interp<true> then interpolates along the chosen edge direction (:1181-1208)
 //   k_di_interp     mean23 + borders + full-res pick + half-res mix + overexposure flag +
 //                   alias-map error, fused per pixel (:1231-1380, :1588-1612, :1404-1418, :1620-1626)
@@ -222,12 +222,17 @@ __global__ __launch_bounds__(256) void k_di_score(const int *__restrict__ hd_bas
     if (threadIdx.x == 0) score[(size_t)f * score_stride + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void k_di_match(const uint16_t *__restrict__ img_base, uint32_t *__restrict__ raw, DiBatch bt)
+// With `cfa` (the AMaZE-based interpolator) the squeeze of hdr.c:977-1026 rides along: rows of one exposure become adjacent, greens
+// halved around black, and a squeezed row that no exposure lands on is zeroed by the thread whose image row has its number (sq: per
+// frame sq_dst | sq_row | source row of a squeezed row) -- one pass over the frame instead of a 151 MB memset and two.
+__global__ __launch_bounds__(256) void k_di_match(const uint16_t *__restrict__ img_base, uint32_t *__restrict__ raw, DiBatch bt,
+                                                  const int *__restrict__ sq, size_t sq_stride, int hs, float *__restrict__ cfa)
 {
     int f; DiParams p;
     if (!di_frame<1>(bt, f, p)) return;
     const uint16_t *img = di_img(img_base, bt, f, p);
     raw += (size_t)f * bt.S;
+    if (cfa) { cfa += (size_t)f * bt.S; sq += (size_t)f * sq_stride; }
     const size_t n = (size_t)p.w * p.h;
     const double a = p.a, b20 = p.b20;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -241,6 +246,12 @@ __global__ __launch_bounds__(256) void k_di_match(const uint16_t *__restrict__ i
             v = v < 0 ? 0 : (v > 0xFFFFF ? 0xFFFFF : v);
         }
         raw[i] = (uint32_t)v;
+        if (cfa) {
+            const int x = (int)(i % p.w), y = (int)(i / p.w);
+            const int yh = sq[y];
+            if (yh >= 0) cfa[(size_t)yh * p.w + x] = (float)(((x & 1) != (y & 1)) ? (v - p.black20) / 2 + p.black20 : v);
+            if (sq[2 * hs + y] < 0) cfa[i] = 0.0f;
+        }
     }
 }
 
@@ -407,24 +418,6 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------ AMaZE-based interpolation, hdr.c:954-1229
-// squeeze: rows of one exposure become adjacent, greens halved around black (hdr.c:977-1026)
-__global__ __launch_bounds__(256) void k_di_squeeze(const uint32_t *__restrict__ raw, DiBatch bt, const int *__restrict__ sq_dst,
-                                                    size_t sq_stride, float *__restrict__ cfa)
-{
-    int f; DiParams p;
-    if (!di_frame<1>(bt, f, p)) return;
-    raw += (size_t)f * bt.S; cfa += (size_t)f * bt.S; sq_dst += (size_t)f * sq_stride;
-    const size_t n = (size_t)p.w * p.h;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % p.w), y = (int)(i / p.w);
-        const int yh = sq_dst[y];
-        if (yh < 0) continue;
-        int v = (int)raw[i];
-        if ((x & 1) != (y & 1)) v = (v - p.black20) / 2 + p.black20;
-        cfa[(size_t)yh * p.w + x] = (float)v;
-    }
-}
-
 // undo the green scaling, clamp (hdr.c:1041-1050); what leaves this kernel are the table values everything downstream looks up:
 // raw2ev of the three clamped planes (the edge-directed interpolation, hdr.c:1181-1208: up to six pixels ask for each) and raw2ev of
 // the gray image (hdr.c:1055-1059, 1157-1168) -- still squeezed: k_di_edge_dir de-squeezes through the row map when it stages its rows
@@ -1182,20 +1175,20 @@ static int di_chroma_smooth(const uint32_t *plane, uint32_t *plane_s, const DiBa
 // 14 -> 20 bit with the exposures matched (hdr.c:781-803); d_img: frame 0 of the batch, NOT offset for GBRG (the kernels do that)
 int di_launch_match(const void *d_img, const DiBatch &b, int h_launch, const DiPlanes &P, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_di_match, flat_grid((size_t)b.p0.w * h_launch, b.nframes), dim3(256), 0, s, (const uint16_t *)d_img, P.raw, b);
+    hipLaunchKernelGGL(k_di_match, flat_grid((size_t)b.p0.w * h_launch, b.nframes), dim3(256), 0, s, (const uint16_t *)d_img, P.raw, b,
+                       (const int *)nullptr, (size_t)0, 0, (float *)nullptr);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
 
 // squeeze -> AMaZE -> clamp -> gray -> edge directions; the planes feed k_di_interp<true>.  P.sq_dst: per frame sq_dst | sq_row of
 // h_launch ints each
-int di_launch_amaze_interp(const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s)
+int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s)
 {
     const int w = b.p0.w, nf = b.nframes;
-    const size_t n = (size_t)w * h_launch, sq_stride = 2 * (size_t)h_launch;
-    MLV_HIP(hipMemsetAsync(P.cfa, 0, (nf > 1 ? b.S * nf : n) * sizeof(float), s));          // rows no exposure lands on stay zero (hdr.c:971)
+    const size_t n = (size_t)w * h_launch, sq_stride = 3 * (size_t)h_launch;
     MLV_HIP(hipMemsetAsync(P.stats, 0, 4 * sizeof(unsigned) * nf * DI_STAT_SLOTS, s));
-    hipLaunchKernelGGL(k_di_squeeze, flat_grid(n, nf), dim3(256), 0, s, P.raw, b, P.sq_dst, sq_stride, P.cfa);
+    hipLaunchKernelGGL(k_di_match, flat_grid(n, nf), dim3(256), 0, s, (const uint16_t *)d_img, P.raw, b, P.sq_dst, sq_stride, h_launch, P.cfa);
     // a frame's AMaZE geometry follows its own row count (one less for GBRG): the launch plan is made per distinct height
     int rc = MLVFS_AMD_OK;
     if (b.pp) {
@@ -1221,7 +1214,7 @@ int di_launch_convert(const DiBatch &b, int h_launch, const DiLuts &L, const DiP
     const int nf = b.nframes;
     const size_t n = (size_t)p.w * h_launch;
     uint16_t *amap_fused = (p.use_alias_map && !p.chroma_smooth) ? P.amap : nullptr;
-    const DiAmazeIn A{ P.ev_red, P.ev_green, P.ev_blue, P.dir, P.sq_row, 2 * (size_t)h_launch };
+    const DiAmazeIn A{ P.ev_red, P.ev_green, P.ev_blue, P.dir, P.sq_row, 3 * (size_t)h_launch };
     const bool ev_planes = amaze && !p.chroma_smooth && L.blend_is_mix;       // halfres / fullres travel as EV (the blend's lookups, done early)
     if (amaze)
         hipLaunchKernelGGL(k_di_interp<true>, flat_grid(n, nf), dim3(256), 0, s, P.raw, b, L, A, P.dark, P.bright, P.fullres, P.halfres,
