@@ -54,11 +54,14 @@ __device__ __forceinline__ const uint16_t *di_img(const uint16_t *base, const Di
 // flushed with one global atomic per non-empty bin into the 8 class histograms [y % 4][x & 1][16384], from which the
 // host derives the Bayer-phase and the two green-by-row-phase histograms (dualiso.cpp).  The every-3rd-pixel "white"
 // histograms (1/9 of the pixels) and the hdr_check sum use global atomics directly.
-constexpr int DI_BAND = 16;
+// band: rows per workgroup (a multiple of 4).  The taller, the fewer global atomics flush the same bins (a 16-row band of 3584 pixels
+// touches ~5 000 of its 32 768 counters for 14 336 pixels: 13 M flush atomics per batch of 8 were most of the kernel); the 16-bit
+// counters hold band / 4 * w / 2 pixels per class.
 __global__ __launch_bounds__(256) void k_di_analyse(const uint16_t *__restrict__ img, int w, int H, int black, int white,
                                                     const double *__restrict__ evf /* [16384] log2(i)*32768 */,
                                                     unsigned *__restrict__ hist /* device layout, dualiso.h */, double *__restrict__ check /* sum, count */,
-                                                    size_t img_stride /* bytes */, size_t hist_stride /* words */, size_t check_stride /* doubles */)
+                                                    size_t img_stride /* bytes */, size_t hist_stride /* words */, size_t check_stride /* doubles */,
+                                                    int band)
 {
     __shared__ unsigned cnt[16384];                          // slot = (x & 1) * 16384 + value; two slots per word
     for (int i = threadIdx.x; i < 16384; i += blockDim.x) cnt[i] = 0;
@@ -66,10 +69,10 @@ __global__ __launch_bounds__(256) void k_di_analyse(const uint16_t *__restrict__
     img = (const uint16_t *)((const uint8_t *)img + (size_t)blockIdx.z * img_stride);        // frame of the batch
     hist += (size_t)blockIdx.z * hist_stride;
     check += (size_t)blockIdx.z * check_stride;
-    const int q = blockIdx.y, y_base = blockIdx.x * DI_BAND + q;
+    const int q = blockIdx.y, y_base = blockIdx.x * band + q;
     unsigned *h_w0 = hist + DI_D_WHITE0, *h_w1 = hist + DI_D_WHITE1;
     double sum = 0, n = 0;
-    for (int k = threadIdx.x; k < (DI_BAND / 4) * w; k += blockDim.x) {          // (a run of pixels per thread instead -- fewer collisions in the
+    for (int k = threadIdx.x; k < (band / 4) * w; k += blockDim.x) {          // (a run of pixels per thread instead -- fewer collisions in the
         const int y = y_base + 4 * (k / w), x = k % w;                             // LDS counters -- was slower: 0.59 -> 0.71 ms per batch of 8)
         if (y >= H) break;
         const size_t i = (size_t)y * w + x;
@@ -1109,8 +1112,12 @@ int di_launch_analyse(const void *d_img, int w, int H, int black, int white, con
             MLV_HIP(hipMemsetAsync(d_check, 0, 2 * sizeof(double), s));
         }
     }
-    hipLaunchKernelGGL(k_di_analyse, dim3((H + DI_BAND - 1) / DI_BAND, 4, nframes), dim3(256), 0, s, (const uint16_t *)d_img, w, H, black, white,
-                       d_evf, d_hist, d_check, img_stride, hist_stride, check_stride);
+    static const int band_max = [] { const char *e = getenv("MLVFS_AMD_ANALYSE_BAND"); const int v = e ? atoi(e) : 128; return v >= 4 ? v / 4 * 4 : 128; }();
+    int band = H * 4 * nframes / 256 / 4 * 4;                                   // at least a workgroup per CU
+    band = band < 16 ? 16 : (band > band_max ? band_max : band);
+    while (band > 4 && (band / 4) * (w / 2 + 1) >= 65536) band -= 4;            // the 16-bit counters of a class
+    hipLaunchKernelGGL(k_di_analyse, dim3((H + band - 1) / band, 4, nframes), dim3(256), 0, s, (const uint16_t *)d_img, w, H, black, white,
+                       d_evf, d_hist, d_check, img_stride, hist_stride, check_stride, band);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
