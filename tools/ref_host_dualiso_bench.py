@@ -14,7 +14,7 @@ pl = [np.ascontiguousarray(synth.pack_bits(synth.dual_iso_frame(w, h, frame=k)),
 mlvfile.write_clip(str(d / "M07-1234.MLV"), pl, w, h, chunks=2, frame_space=32, shuffle=True, video_class=1)
 vp = ["/M07-1234.MLV/M07-1234_%06d.dng" % k for k in range(n)]
 for T in [int(a) for a in sys.argv[1:]] or [1, 4, 8, 16]:
-    r = subprocess.run([host, str(d), "-", "dual_iso=2", "hdr_interp=0", "threads=%d" % T, "loops=%d" % max(1, 16 // T), "--", *vp],
+    r = subprocess.run([host, str(d), "-", "dual_iso=2", "hdr_interp=0", "threads=%d" % T, "loops=%d" % max(2, int(os.environ.get("FRAMES", "512")) // (8 * T)), "--", *vp],
                        capture_output=True, text=True, timeout=900)
     line = [l for l in r.stderr.splitlines() if '"fps"' in l]
     print(T, line[-1] if line else r.stderr[-500:], flush=True)
