@@ -310,7 +310,7 @@ def extra_dualiso(golden, fnv1a, batch=8, reps=4, threads=3):
         del bufs
         torch.cuda.empty_cache()
     # (d) one conversion per call through the drop-in symbol, host memory in and out: the reference's own process_frame text
-    # (oracle/_ref/ref_host_amd_wrap, main.c's functions linked against the library) with --dual-iso 2 --amaze-edge from 4 threads
+    # (oracle/_ref/ref_host_amd_wrap, main.c's functions linked against the library) with --dual-iso 2 --amaze-edge from 8 threads
     try:
         import shutil, tempfile
         from mlvfs_amd import mlvfile
@@ -322,16 +322,16 @@ def extra_dualiso(golden, fnv1a, batch=8, reps=4, threads=3):
                 pl = [np.ascontiguousarray(synth.pack_bits(synth.dual_iso_frame(W, H, frame=k)), "<u2").tobytes() for k in range(nfr)]
                 mlvfile.write_clip(os.path.join(d, "B02-0001.MLV"), pl, W, H, chunks=2)
                 vp = ["/B02-0001.MLV/B02-0001_%06d.dng" % k for k in range(nfr)]
-                r = subprocess.run([exe, d, "-", "dual_iso=2", "hdr_interp=0", "threads=4", "loops=4", "--", *vp], capture_output=True, text=True, timeout=300)
+                r = subprocess.run([exe, d, "-", "dual_iso=2", "hdr_interp=0", "threads=8", "loops=8", "--", *vp], capture_output=True, text=True, timeout=300)
                 line = [ln for ln in r.stderr.splitlines() if ln.startswith("{")]
-                res["reference_process_frame_text_host_4_threads"] = {"fps": json.loads(line[-1])["fps"] if line else f"failed rc {r.returncode}",
+                res["reference_process_frame_text_host_8_threads"] = {"fps": json.loads(line[-1])["fps"] if line else f"failed rc {r.returncode}",
                                                                       "includes": "file reads, unpack, upload, one conversion per call, download"}
             finally:
                 shutil.rmtree(d, ignore_errors=True)
         else:
-            res["reference_process_frame_text_host_4_threads"] = {"skipped": "oracle/_ref/ref_host_amd_wrap not built"}
+            res["reference_process_frame_text_host_8_threads"] = {"skipped": "oracle/_ref/ref_host_amd_wrap not built"}
     except Exception as e:
-        res["reference_process_frame_text_host_4_threads"] = {"failed": str(e)[:200]}
+        res["reference_process_frame_text_host_8_threads"] = {"failed": str(e)[:200]}
     best = max(v["conversions_per_s"] for k, v in res.items() if k.startswith("batch_"))
     # SURVEY 8(d)'s convention for this path too: packed in + 16-bit out per frame against the HBM peak (the conversion's own
     # multi-pass traffic is ~15 GB per batch of 8: profiles/r03/dualiso_batch_pmc_summary.txt)
