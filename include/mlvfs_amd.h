@@ -303,6 +303,9 @@ void mlvfs_amd_dualiso_last_scalars(double out[8]);
  * the caller's scale.  width must be a multiple of 4 (the reference's SSE2 build needs that for a fully
  * written green plane) and the plane at least 36x36.  Bit-identical to the x86-64 reference build.        */
 int mlvfs_amd_amaze_demosaic_dev(const float *d_raw, int width, int height, float *d_red, float *d_green, float *d_blue, void *stream);
+/* The split of a width x height plane between the two AMaZE kernels: the first nfx x nfy tiles (128-pixel grid, origin -16) are complete
+ * -- 160 rows and columns inside the image, not the head of a chain of incomplete tiles -- and are row-streamed through LDS.  No GPU needed. */
+void mlvfs_amd_amaze_rows_extent(int width, int height, int *nfx, int *nfy);
 /* Debug: the same with the tile planes copied out (26 planes per 160x160 tile, the layout of k_amaze.hip's block).  mode 0: every
  * tile through k_amaze.hip, blocks in tile order; mode 1: the complete tiles through k_amaze_rows.hip (LDS row streaming), their
  * planes numbered ty * nfx + tx; nfx x nfy = the complete tiles of the plane.  Synchronous. */

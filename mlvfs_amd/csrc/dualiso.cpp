@@ -675,6 +675,19 @@ int mlvfs_amd_amaze_demosaic_dev(const float *d_raw, int width, int height, floa
     return amaze_launch(d_raw, width, height, d_red, d_green, d_blue, scratch, s);
 }
 
+// How amaze_launch splits a width x height plane (no GPU needed; tests): the first nfx x nfy tiles of the 128-pixel tile grid are
+// complete and go through k_amaze_rows.hip, every other tile through k_amaze.hip.
+void mlvfs_amd_amaze_rows_extent(int width, int height, int *nfx, int *nfy)
+{
+    const int before = g_amaze_rows_mode;
+    g_amaze_rows_mode = 1;
+    int fx = 0, fy = 0;
+    amaze_rows_extent(width, height, &fx, &fy);
+    g_amaze_rows_mode = before;
+    if (nfx) *nfx = fx;
+    if (nfy) *nfy = fy;
+}
+
 // Debug: the AMaZE demosaic with its tile planes copied out.  mode 0: every tile through k_amaze.hip, d_planes gets the blocks in
 // tile order (ty * tiles_x + tx); mode 1: the complete tiles through k_amaze_rows.hip, d_planes gets THEIR planes in the same
 // layout, numbered ty * nfx + tx (nfx x nfy complete tiles, returned).  tests/ compare the two plane by plane.
