@@ -42,7 +42,10 @@ for k in range(N):
     cand = [[list(w) for w in ph] for ph in best]
     ph = random.randrange(2)
     a, b = random.sample(range(16), 2)
-    if random.random() < 0.5 and cand[ph][a]:                         # move an item
+    kind = random.random()
+    if kind < 0.15 and len(cand[ph][a]) > 1:                          # another order of a wave's items
+        random.shuffle(cand[ph][a])
+    elif kind < 0.55 and cand[ph][a]:                                 # move an item
         if len(cand[ph][b]) < 4: cand[ph][b].append(cand[ph][a].pop(random.randrange(len(cand[ph][a]))))
     elif cand[ph][a] and cand[ph][b]:                                  # swap two items
         i, j = random.randrange(len(cand[ph][a])), random.randrange(len(cand[ph][b]))
