@@ -69,11 +69,11 @@ constexpr int NCHUNKS[NPASS] = { 1, 5, 3, 3, 3, 3, 3, 1, 3,   5, 5, 5, 1, 1, 3, 
 constexpr int COST[NPASS] = { 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000,   1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000 };
 // The deal in use: found by local search (moves and swaps of items between waves; tools/amaze_rows_assign_search.py), first with the
 // kernel's time on 2 254 unflagged tiles as the objective (3.26 ms where the deal by item count takes 3.71 and the one by measured
-// cycles per item 4.07), then with a batch of 8 dual-ISO conversions (9.15 -> 8.92 ms, best of 5, 460 candidates in all).  What an item costs depends on what runs
+// cycles per item 4.07), then with a batch of 8 dual-ISO conversions (9.15 -> 8.92 ms, best of 5; after the analysis kernel's change 8.78 -> 8.67; 760 candidates in all).  What an item costs depends on what runs
 // beside it on its SIMD, and no cost table captures that.
 constexpr unsigned long long TUNED[2][16] = {
-    { 0xffffffff06100c38ull, 0xffffffff030a0718ull, 0xffffffff0d280309ull, 0xffffffffffff030cull, 0xffffffffffff030bull, 0xffffffff00000931ull, 0xffffffff06121140ull, 0xffffffff06110b21ull, 0xffffffff11420d29ull, 0xffffffff09320b22ull, 0xffffffffffff0719ull, 0xffffffff0d2a071aull, 0xffffffffffff1141ull, 0xffffffffffff0b20ull, 0xffffffffffff0930ull, 0xffffffffffff0308ull },
-    { 0xffffffff0c680e82ull, 0xffffffff0a700352ull, 0xffffffff0a71014aull, 0xffffffffffff0a72ull, 0xffff0148014b0354ull, 0xffffffff0c790e80ull, 0xffffffff0c7a0351ull, 0xffffffff03500353ull, 0xffffffffffff0e81ull, 0xffffffff0c780149ull, 0xffffffff12880458ull, 0xffffffff12890459ull, 0xffffffff128a045aull, 0xffffffff0760128bull, 0xffffffff014c045cull, 0xffffffffffff045bull } };
+    { 0xffffffff06100c38ull, 0xffffffff030a0612ull, 0xffffffff03090d28ull, 0xffffffffffff030cull, 0xffffffffffff030bull, 0xffffffff00000931ull, 0xffffffff07181140ull, 0xffffffff06110b21ull, 0xffffffff11420d29ull, 0xffffffff09320b22ull, 0xffffffffffff0308ull, 0xffffffff0d2a071aull, 0xffffffffffff1141ull, 0xffffffffffff0b20ull, 0xffffffffffff0930ull, 0xffffffffffff0719ull },
+    { 0xffffffff0c680e82ull, 0xffffffff0a700352ull, 0xffffffff0a71014aull, 0xffffffffffff0a72ull, 0xffff0148014b0351ull, 0xffffffff0c790e80ull, 0xffff045a0c7a0354ull, 0xffffffff03500353ull, 0xffffffffffff0e81ull, 0xffffffff0c780149ull, 0xffffffff12880458ull, 0xffffffff12890459ull, 0xffffffffffff128aull, 0xffffffff0760128bull, 0xffffffff014c045cull, 0xffffffffffff045bull } };
 __constant__ unsigned long long c_desc[2][16];      // per phase and wave: up to four items, 16 bits each: item code | lag of its pass << 8
 bool g_tab_ready[64] = {};                          // per device: the kernels' LDS attribute is set
 
