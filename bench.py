@@ -309,6 +309,25 @@ def extra_dualiso(golden, fnv1a, batch=8, reps=4, threads=3):
                                              "Mpix/s": round(n * W * H / dt / 1e6, 1)}
         del bufs
         torch.cuda.empty_cache()
+    # (c') the reference's default interpolator (mean23, `--dual-iso 2` without `--amaze-edge`), batches of 8 from one thread
+    try:
+        bb = torch.empty((batch, H, W), dtype=torch.int16, device="cuda")
+        r8 = np.zeros(batch, np.int32)
+        def run_m23():
+            bb.copy_(src.unsqueeze(0).expand(batch, -1, -1))
+            rc = L.mlvfs_amd_cr2hdr20_batch_dev(C.byref(geom), C.c_void_p(bb.data_ptr()), W * H * 2, batch, 1, 1, 1, 0, lib.ptr(r8), None)
+            torch.cuda.synchronize()
+            return rc == 0 and int(r8.sum()) == batch
+        ok = run_m23()
+        t0 = time.perf_counter()
+        for _ in range(reps): ok = run_m23() and ok
+        dt = time.perf_counter() - t0
+        h23 = fnv1a(bb[0].cpu().numpy().view(np.uint16))
+        res["batch_%d_mean23" % batch] = {"conversions_per_s": round(batch * reps / dt, 1), "ok": bool(ok),
+                                          "parity": {"hash": h23, "reference": golden.get("dualiso_3584x1320_i1_f1_a1_cs0"), "equal": h23 == golden.get("dualiso_3584x1320_i1_f1_a1_cs0")}}
+        del bb
+    except Exception as e:
+        res["batch_%d_mean23" % batch] = {"failed": str(e)[:200]}
     # (d) one conversion per call through the drop-in symbol, host memory in and out: the reference's own process_frame text
     # (oracle/_ref/ref_host_amd_wrap, main.c's functions linked against the library) with --dual-iso 2 --amaze-edge from 8 threads
     try:
@@ -332,7 +351,7 @@ def extra_dualiso(golden, fnv1a, batch=8, reps=4, threads=3):
             res["reference_process_frame_text_host_8_threads"] = {"skipped": "oracle/_ref/ref_host_amd_wrap not built"}
     except Exception as e:
         res["reference_process_frame_text_host_8_threads"] = {"failed": str(e)[:200]}
-    best = max(v["conversions_per_s"] for k, v in res.items() if k.startswith("batch_"))
+    best = max(v["conversions_per_s"] for k, v in res.items() if k.startswith("batch_") and "_threads_" in k)
     # SURVEY 8(d)'s convention for this path too: packed in + 16-bit out per frame against the HBM peak (the conversion's own
     # multi-pass traffic is ~15 GB per batch of 8: profiles/r03/dualiso_batch_pmc_summary.txt)
     res["hbm_frac_compulsory_bytes"] = round(best * W * H * BYTES_PER_PX / 1e9 / HBM_PEAK_GBS, 5)

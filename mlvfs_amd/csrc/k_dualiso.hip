@@ -278,29 +278,9 @@ __device__ __forceinline__ int di_alias_err(const DiParams &p, const DiLuts &L, 
     return min(min(e_lin / 2, e_log / 16), 65530);
 }
 
-// everything that follows the interpolation for one pixel: full-res pick (hdr.c:1355-1380), half-res mix
-// (hdr.c:1588-1612), overexposure flag (hdr.c:1620-1626) and, when no chroma smoothing sits in between, the alias error
-__device__ __forceinline__ void di_mix_pixel(const DiParams &p, const DiLuts &L, size_t i, int br, int b, int d,
-                                             uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
-                                             uint16_t *__restrict__ over, uint16_t *__restrict__ amap)
-{
-    int f = 0;
-    if (p.use_fullres) f = br ? (b < p.white_darkened ? b : max(b, d)) : d;
-    fullres[i] = (uint32_t)f;
-    const double ev = L.log2sig[b & 0xFFFFF] + p.corr_ev;
-    double t = ev - (p.max_ev - p.overlap);
-    t = t < p.overlap ? t : p.overlap;
-    t = t > 0 ? t : 0;
-    double k = (-cos(t * 3.14159265358979323846 / p.overlap) + 1) / 2;
-    k = k < 0 ? 0 : (k > 1 ? 1 : k);
-    const int mixed = (int)(L.mix_raw2ev[b] * (1 - k) + L.mix_raw2ev[d] * k);
-    const int hr = L.mix_ev2raw[mixed];
-    halfres[i] = (uint32_t)hr;
-    over[i] = (b >= p.white_darkened || d >= p.white20) ? 100 : 0;
-    if (amap) amap[i] = (uint16_t)di_alias_err(p, L, b, f, hr);
-}
-
-// the same with the re-packed tables (DiLuts::by_bright, mix_pair): 4 gathers instead of 8 -- one entry for everything that is looked
+// everything that follows the interpolation for one pixel: full-res pick (hdr.c:1355-1380), half-res mix (hdr.c:1588-1612),
+// overexposure flag (hdr.c:1620-1626) and, when no chroma smoothing sits in between, the alias error --
+// with the re-packed tables (DiLuts::by_bright, mix_pair): 4 gathers instead of 8 -- one entry for everything that is looked
 // up at the bright value, the full-res pick f is b or d (its table value is already here), and ev2raw comes with its raw2ev
 // ev_out: the two planes go out as EV values (what k_di_blend looks up of them anyway, when no chroma smoothing sits in between)
 __device__ __forceinline__ void di_mix_pixel_packed(const DiParams &p, const DiLuts &L, size_t i, int br, int b, int d,
@@ -415,8 +395,7 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
         const int b = br ? native : interp, d = br ? interp : native;
         bright[i] = (uint32_t)b;
         dark[i] = (uint32_t)d;
-        if (AMAZE) di_mix_pixel_packed(p, L, i, br, b, d, fullres, halfres, over, amap, ev_out);
-        else di_mix_pixel(p, L, i, br, b, d, fullres, halfres, over, amap);
+        di_mix_pixel_packed(p, L, i, br, b, d, fullres, halfres, over, amap, ev_out);
     }
 }
 
@@ -1222,13 +1201,13 @@ int di_launch_convert(const DiBatch &b, int h_launch, const DiLuts &L, const DiP
     const size_t n = (size_t)p.w * h_launch;
     uint16_t *amap_fused = (p.use_alias_map && !p.chroma_smooth) ? P.amap : nullptr;
     const DiAmazeIn A{ P.ev_red, P.ev_green, P.ev_blue, P.dir, P.sq_row, 3 * (size_t)h_launch };
-    const bool ev_planes = amaze && !p.chroma_smooth && L.blend_is_mix;       // halfres / fullres travel as EV (the blend's lookups, done early)
+    const bool ev_planes = !p.chroma_smooth && L.blend_is_mix;                // halfres / fullres travel as EV (the blend's lookups, done early)
     if (amaze)
         hipLaunchKernelGGL(k_di_interp<true>, flat_grid(n, nf), dim3(256), 0, s, P.raw, b, L, A, P.dark, P.bright, P.fullres, P.halfres,
                            P.over, amap_fused, ev_planes);
     else
         hipLaunchKernelGGL(k_di_interp<false>, flat_grid(n, nf), dim3(256), 0, s, P.raw, b, L, A, P.dark, P.bright, P.fullres, P.halfres,
-                           P.over, amap_fused, false);
+                           P.over, amap_fused, ev_planes);
     MLV_HIP(hipGetLastError());
     const uint32_t *fullres_s = P.fullres, *halfres_s = P.halfres;
     if (p.chroma_smooth) {                                             // hdr.c:1612-1619
