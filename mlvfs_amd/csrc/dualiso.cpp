@@ -423,7 +423,7 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
     const size_t o_full_s = take(cs ? NF * S * 4 : 0), o_half_s = take(cs ? NF * S * 4 : 0), o_cells = take(cs ? NF * cells_stride * 4 : 0);
     const bool amaze = o.interp_method == 0;
     const size_t o_cfa = take(amaze ? NF * S * 4 : 0), o_red = take(amaze ? NF * S * 4 : 0), o_green = take(amaze ? NF * S * 4 : 0),
-                 o_blue = take(amaze ? NF * S * 4 : 0), o_ev = take(amaze ? NF * S * 12 : 0), o_gray = take(amaze ? NF * S * 4 : 0), o_dir = take(amaze ? NF * S : 0),
+                 o_blue = take(amaze ? NF * S * 4 : 0), o_ev = take(amaze ? NF * S * 12 : NF * S * 4), o_gray = take(amaze ? NF * S * 4 : 0), o_dir = take(amaze ? NF * S : 0),
                  o_sq = take(amaze ? NF * (size_t)H * 12 : 0), o_stats = take(NF * 16 * DI_STAT_SLOTS);
     DiWork &wk = t_work[c->dev->id];
     rc = wk.ensure(off);
@@ -539,7 +539,8 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
                 (uint16_t *)(B + o_amap), (uint16_t *)(B + o_aux), (uint16_t *)(B + o_amap2), (int *)(B + o_cells) };
     P.cells_stride = cells_stride;
     if (!amaze) {
-        rc = di_launch_match(d_frames, bt, H, P, stream);
+        P.ev_red = (int *)(B + o_ev);                        // mean23: raw2ev of the matched frame, written with it
+        rc = di_launch_match(d_frames, bt, H, L, P, stream);
         if (rc) return rc;
     }
     if (amaze) {

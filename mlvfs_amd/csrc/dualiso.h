@@ -117,7 +117,7 @@ int di_launch_hi_compact(const int *d_ds, const int *d_bs, int nsx, int nsy_max,
                          const DiBatch &b, const int *d_rows, int *d_hi, size_t hi_stride, hipStream_t s);
 int di_launch_score(const int *d_hi, size_t hi_stride, int hi_n, const double *d_ta, int ncand, int dmed, int bmed, const DiDecide *dd,
                     int nframes, int *d_score, int score_stride, hipStream_t s);
-int di_launch_match(const void *d_img, const DiBatch &b, int h_launch, const DiPlanes &P, hipStream_t s);
+int di_launch_match(const void *d_img, const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s);   // mean23: + raw2ev of the result (P.ev_red)
 int di_launch_convert(const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, bool interp_done, void *d_out, hipStream_t s);
 // device-side decisions of a batch (k_dualiso.hip: k_di_decide_*)
 struct DiDecideBuffers {

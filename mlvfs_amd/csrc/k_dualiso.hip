@@ -228,14 +228,17 @@ __global__ __launch_bounds__(256) void k_di_score(const int *__restrict__ hd_bas
 // With `cfa` (the AMaZE-based interpolator) the squeeze of hdr.c:977-1026 rides along: rows of one exposure become adjacent, greens
 // halved around black, and a squeezed row that no exposure lands on is zeroed by the thread whose image row has its number (sq: per
 // frame sq_dst | sq_row | source row of a squeezed row) -- one pass over the frame instead of a 151 MB memset and two.
+// With `ev` (mean23) the interpolator's raw2ev of every matched pixel rides along instead: each is asked for by two or three neighbours.
 __global__ __launch_bounds__(256) void k_di_match(const uint16_t *__restrict__ img_base, uint32_t *__restrict__ raw, DiBatch bt,
-                                                  const int *__restrict__ sq, size_t sq_stride, int hs, float *__restrict__ cfa)
+                                                  const int *__restrict__ sq, size_t sq_stride, int hs, float *__restrict__ cfa,
+                                                  const int *__restrict__ r2e, int *__restrict__ ev)
 {
     int f; DiParams p;
     if (!di_frame<1>(bt, f, p)) return;
     const uint16_t *img = di_img(img_base, bt, f, p);
     raw += (size_t)f * bt.S;
     if (cfa) { cfa += (size_t)f * bt.S; sq += (size_t)f * sq_stride; }
+    if (ev) ev += (size_t)f * bt.S;
     const size_t n = (size_t)p.w * p.h;
     const double a = p.a, b20 = p.b20;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(256) void k_di_match(const uint16_t *__restrict__ i
             v = v < 0 ? 0 : (v > 0xFFFFF ? 0xFFFFF : v);
         }
         raw[i] = (uint32_t)v;
+        if (ev) ev[i] = r2e[v];
         if (cfa) {
             const int x = (int)(i % p.w), y = (int)(i / p.w);
             const int yh = sq[y];
@@ -347,6 +351,7 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
         raw += o; dark += o; bright += o; fullres += o; halfres += o; over += o;
         if (amap) amap += o;
         if (AMAZE) { A.red += o; A.green += o; A.blue += o; A.dir += o; A.sq_row += (size_t)f * A.sq_stride; }
+        else A.red += o;
     }
     const int w = p.w, h = p.h;
     const size_t n = (size_t)w * h;
@@ -379,15 +384,16 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
         } else {
             const int wl = !br ? p.white_darkened : p.white20;
             const int wev = ir2e[wl];
+            auto E = [&](int xx, int yy) { return A.red[xx + (size_t)yy * w]; };        // (mean23: A.red is raw2ev of the matched frame)
             const int s = (di_bright(p, y) == di_bright(p, y + 1)) ? -1 : 1;
             const int xe = x & ~1;                                // the pair (xe, xe+1) is produced together
             int ev;
             if ((y & 1) == 0) {
-                if (x == xe) ev = di_mean2(ir2e[R(xe, y - 2)], ir2e[R(xe, y + 2)], wev);
-                else ev = di_mean3(ir2e[R(xe + 2, y + s)], ir2e[R(xe, y + s)], ir2e[R(xe + 1, y - 2 * s)], wev);
+                if (x == xe) ev = di_mean2(E(xe, y - 2), E(xe, y + 2), wev);
+                else ev = di_mean3(E(xe + 2, y + s), E(xe, y + s), E(xe + 1, y - 2 * s), wev);
             } else {
-                if (x == xe) ev = di_mean3(ir2e[R(xe + 1, y + s)], ir2e[R(xe - 1, y + s)], ir2e[R(xe, y - 2 * s)], wev);
-                else ev = di_mean2(ir2e[R(xe + 1, y - 2)], ir2e[R(xe + 1, y + 2)], wev);
+                if (x == xe) ev = di_mean3(E(xe + 1, y + s), E(xe - 1, y + s), E(xe, y - 2 * s), wev);
+                else ev = di_mean2(E(xe + 1, y - 2), E(xe + 1, y + 2), wev);
             }
             interp = ie2r[ev];
             native = R(x, y);
@@ -1159,10 +1165,10 @@ static int di_chroma_smooth(const uint32_t *plane, uint32_t *plane_s, const DiBa
 }
 
 // 14 -> 20 bit with the exposures matched (hdr.c:781-803); d_img: frame 0 of the batch, NOT offset for GBRG (the kernels do that)
-int di_launch_match(const void *d_img, const DiBatch &b, int h_launch, const DiPlanes &P, hipStream_t s)
+int di_launch_match(const void *d_img, const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s)
 {
     hipLaunchKernelGGL(k_di_match, flat_grid((size_t)b.p0.w * h_launch, b.nframes), dim3(256), 0, s, (const uint16_t *)d_img, P.raw, b,
-                       (const int *)nullptr, (size_t)0, 0, (float *)nullptr);
+                       (const int *)nullptr, (size_t)0, 0, (float *)nullptr, L.interp_raw2ev, P.ev_red);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
@@ -1174,7 +1180,8 @@ int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, co
     const int w = b.p0.w, nf = b.nframes;
     const size_t n = (size_t)w * h_launch, sq_stride = 3 * (size_t)h_launch;
     MLV_HIP(hipMemsetAsync(P.stats, 0, 4 * sizeof(unsigned) * nf * DI_STAT_SLOTS, s));
-    hipLaunchKernelGGL(k_di_match, flat_grid(n, nf), dim3(256), 0, s, (const uint16_t *)d_img, P.raw, b, P.sq_dst, sq_stride, h_launch, P.cfa);
+    hipLaunchKernelGGL(k_di_match, flat_grid(n, nf), dim3(256), 0, s, (const uint16_t *)d_img, P.raw, b, P.sq_dst, sq_stride, h_launch, P.cfa,
+                       (const int *)nullptr, (int *)nullptr);
     // a frame's AMaZE geometry follows its own row count (one less for GBRG): the launch plan is made per distinct height
     int rc = MLVFS_AMD_OK;
     if (b.pp) {
