@@ -262,6 +262,21 @@ def test_cr2hdr20_batch_full_size(gpu):
         assert fnv1a(g) == full["dualiso_3584x1320_i0_f1_a1_cs0"]
 
 
+@pytest.mark.parametrize("interp,cs,key", [(1, 0, "dualiso_3584x1320_i1_f1_a1_cs0"), (0, 5, "dualiso_3584x1320_i0_f1_a1_cs5")])
+def test_cr2hdr20_batch_full_size_other_switches(gpu, interp, cs, key):
+    """3584x1320 with the reference's default interpolator (mean23) and with --amaze-edge + cs5x5 (the planes then travel as raw
+    values through the 20-bit chroma smoothing, not as EV): a batch of two against the hashes of the reference's output."""
+    import json
+    import os
+    from conftest import fnv1a
+    full = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))["full_size"]
+    f = synth.dual_iso_frame(3584, 1320)
+    res, got = batch_convert(gpu, [f, f], interp, 1, 1, cs, pad_rows=0)
+    assert list(res) == [1, 1]
+    for g in got:
+        assert fnv1a(g) == full[key]
+
+
 def test_cr2hdr20_batch_decisions_on_random_material(gpu):
     """tools/dualiso_decision_sweep.py: mixed batches of random material -- ISO ratios 1..16, scenes from deep shadow to mostly
     clipped, noise, black levels 512..2049, any of the four bright-row phases, GBRG-like starts, normal / flat / noise frames that
