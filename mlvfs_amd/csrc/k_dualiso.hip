@@ -371,12 +371,16 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
             const int *plane = (y & 1) == 0 ? ((x & 1) == 0 ? A.red : A.green) : ((x & 1) == 0 ? A.green : A.blue);
             const int d = A.dir[i];
             const int dd[3] = { d, min(d + 1, 10), max(d - 1, 0) };
+            // of a direction's table row only a.x and b.x vary (a.y = 1, b.y = -2 for all eleven, hdr.c:916-938): two rows of the
+            // plane for the three directions, the column offsets from two packed constants instead of twelve byte loads per pixel
+            const int *row_a = plane + (size_t)A.sq_row[y + s] * w + x, *row_b = plane + (size_t)A.sq_row[y - 2 * s] * w + x;
+            constexpr unsigned long long AX = 0x43332221110ull, BX = 0x01233455678ull;       // a.x + 2, b.x + 4 of directions 0..10, 4 bits each
             int pi[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const signed char *e = k_edge_dirs[dd[k]];
-                const int ea = plane[(size_t)A.sq_row[y + e[3] * s] * w + x + e[2]];       // raw2ev of the clamped plane value
-                const int eb = plane[(size_t)A.sq_row[y + e[5] * s] * w + x + e[4]];
+                const int ax = (int)((AX >> (4 * dd[k])) & 15) - 2, bx = (int)((BX >> (4 * dd[k])) & 15) - 4;
+                const int ea = row_a[ax];                                                    // raw2ev of the clamped plane value
+                const int eb = row_b[bx];
                 pi[k] = (ea * 2 + eb) / 3;
             }
             interp = ie2r[(2 * pi[0] + pi[1] + pi[2]) / 4];
