@@ -571,11 +571,50 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
         P.gray_ev = (int *)(B + o_gray); P.dir = (uint8_t *)(B + o_dir);
         P.sq_dst = (const int *)(B + o_sq); P.sq_row = P.sq_dst + H;
         P.stats = (unsigned *)(B + o_stats); P.amaze_scratch = (float *)as.base; P.amaze_scratch_stride = a_stride;
-        rc = di_launch_amaze_interp(d_frames, bt, H, L, P, stream);
+        // A batch of 8 or more goes out in two halves on two streams, the second held back until the first one's AMaZE is through:
+        // the first half's table- and bandwidth-bound tail (interpolation, alias map, blend) then runs under the second half's
+        // AMaZE, which is bound by instruction issue -- what two host threads with a batch each get, for one.
+        static const bool split_on = [] { const char *e = getenv("MLVFS_AMD_DI_SPLIT"); return !e || atoi(e) != 0; }();
+        if (split_on && nframes >= 8) {
+            struct Half {
+                hipStream_t st = nullptr; hipEvent_t fork = nullptr, amaze_a = nullptr, join = nullptr;
+                ~Half() { if (fork) (void)hipEventDestroy(fork); if (amaze_a) (void)hipEventDestroy(amaze_a); if (join) (void)hipEventDestroy(join); if (st) (void)hipStreamDestroy(st); }
+            };
+            static thread_local std::map<int, Half> t_half;
+            Half &hf = t_half[c->dev->id];
+            if (!hf.st) {
+                MLV_HIP(hipStreamCreateWithFlags(&hf.st, hipStreamNonBlocking));
+                MLV_HIP(hipEventCreateWithFlags(&hf.fork, hipEventDisableTiming));
+                MLV_HIP(hipEventCreateWithFlags(&hf.amaze_a, hipEventDisableTiming));
+                MLV_HIP(hipEventCreateWithFlags(&hf.join, hipEventDisableTiming));
+            }
+            // parts of 4 frames (at least two), alternately on the caller's stream and the second one: part k starts its AMaZE when
+            // part k - 1 is through with its own, and its tail follows on its stream
+            const int nparts = nframes / 4 > 2 ? nframes / 4 : 2;
+            MLV_HIP(hipEventRecord(hf.fork, stream));
+            MLV_HIP(hipStreamWaitEvent(hf.st, hf.fork, 0));
+            for (int k = 0; k < nparts; k++) {
+                DiBatch bk = bt;
+                bk.f0 = (int)((long long)nframes * k / nparts);
+                bk.nframes = (int)((long long)nframes * (k + 1) / nparts) - bk.f0;
+                hipStream_t sk = (k & 1) ? hf.st : stream;
+                if (k > 0) MLV_HIP(hipStreamWaitEvent(sk, hf.amaze_a, 0));       // (recorded by part k - 1 on the other stream)
+                rc = di_launch_amaze_interp(d_frames, bk, H, L, P, sk, k + 1 < nparts ? hf.amaze_a : nullptr);
+                if (!rc) rc = di_launch_convert(bk, H, L, P, amaze, d_frames, sk);
+                if (rc) return rc;
+            }
+            MLV_HIP(hipEventRecord(hf.join, hf.st));
+            MLV_HIP(hipStreamWaitEvent(stream, hf.join, 0));
+        } else {
+            rc = di_launch_amaze_interp(d_frames, bt, H, L, P, stream);
+            if (rc) return rc;
+            rc = di_launch_convert(bt, H, L, P, amaze, d_frames, stream);
+            if (rc) return rc;
+        }
+    } else {
+        rc = di_launch_convert(bt, H, L, P, amaze, d_frames, stream);
         if (rc) return rc;
     }
-    rc = di_launch_convert(bt, H, L, P, amaze, d_frames, stream);
-    if (rc) return rc;
     if (amaze) {
         unsigned *st = (unsigned *)(PH + ph_st);
         MLV_HIP(hipMemcpyAsync(st, B + o_stats, NF * 16 * DI_STAT_SLOTS, hipMemcpyDeviceToHost, stream));

@@ -608,13 +608,13 @@ int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green,
         hipStream_t st = nullptr; hipEvent_t go = nullptr, done = nullptr; int *ctr = nullptr; int cap = 0;
         ~Side() { if (ctr) (void)hipFree(ctr); if (go) (void)hipEventDestroy(go); if (done) (void)hipEventDestroy(done); if (st) (void)hipStreamDestroy(st); }
     };
-    static thread_local std::map<int, Side> t_side;
+    static thread_local std::map<std::pair<int, hipStream_t>, Side> t_side;      // per device and stream of the caller (a batch in two halves: two)
     Side *side = nullptr;
     bool rows_pending = false;
     if (nfx) {
         int dev = 0;
         MLV_HIP(hipGetDevice(&dev));
-        side = &t_side[dev];
+        side = &t_side[{ dev, s }];
         if (!side->st) {
             MLV_HIP(hipStreamCreateWithFlags(&side->st, hipStreamNonBlocking));
             MLV_HIP(hipEventCreateWithFlags(&side->go, hipEventDisableTiming));

@@ -38,7 +38,7 @@ __device__ __forceinline__ int di_bright(const DiParams &p, int y) { return (p.i
 template <int DIM>
 __device__ __forceinline__ bool di_frame(const DiBatch &b, int &f, DiParams &p)
 {
-    f = DIM == 1 ? (int)blockIdx.y : (int)blockIdx.z;
+    f = b.f0 + (DIM == 1 ? (int)blockIdx.y : (int)blockIdx.z);
     p = b.pp ? b.pp[f] : b.p0;
     return p.h > 0;
 }
@@ -1155,7 +1155,8 @@ static int di_chroma_smooth(const uint32_t *plane, uint32_t *plane_s, const DiBa
 {
     const DiParams &p = b.p0;                            // width and options are the batch's; the rows are each frame's
     const int w = p.w, cw = w / 2, ch = h_launch / 2;
-    MLV_HIP(hipMemcpyAsync(plane_s, plane, (b.nframes > 1 ? b.S * b.nframes : (size_t)w * h_launch) * 4, hipMemcpyDeviceToDevice, s));
+    MLV_HIP(hipMemcpyAsync(plane_s + (size_t)b.f0 * b.S, plane + (size_t)b.f0 * b.S, (b.nframes > 1 || b.f0 ? b.S * b.nframes : (size_t)w * h_launch) * 4,
+                           hipMemcpyDeviceToDevice, s));
     if (cw <= 0 || ch <= 0) return MLVFS_AMD_OK;
     dim3 g((cw + 255) / 256, ch, b.nframes);
     hipLaunchKernelGGL(k_di_cs_cells, g, dim3(256), 0, s, plane, b, P.cells_stride, L.mix_raw2ev, P.cells);
@@ -1179,11 +1180,11 @@ int di_launch_match(const void *d_img, const DiBatch &b, int h_launch, const DiL
 
 // squeeze -> AMaZE -> clamp -> gray -> edge directions; the planes feed k_di_interp<true>.  P.sq_dst: per frame sq_dst | sq_row of
 // h_launch ints each
-int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s)
+int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s, hipEvent_t after_amaze)
 {
     const int w = b.p0.w, nf = b.nframes;
-    const size_t n = (size_t)w * h_launch, sq_stride = 3 * (size_t)h_launch;
-    MLV_HIP(hipMemsetAsync(P.stats, 0, 4 * sizeof(unsigned) * nf * DI_STAT_SLOTS, s));
+    const size_t n = (size_t)w * h_launch, sq_stride = 3 * (size_t)h_launch, fo = (size_t)b.f0 * b.S;
+    MLV_HIP(hipMemsetAsync(P.stats + (size_t)b.f0 * 4 * DI_STAT_SLOTS, 0, 4 * sizeof(unsigned) * nf * DI_STAT_SLOTS, s));
     hipLaunchKernelGGL(k_di_match, flat_grid(n, nf), dim3(256), 0, s, (const uint16_t *)d_img, P.raw, b, P.sq_dst, sq_stride, h_launch, P.cfa,
                        (const int *)nullptr, (int *)nullptr);
     // a frame's AMaZE geometry follows its own row count (one less for GBRG): the launch plan is made per distinct height
@@ -1191,10 +1192,11 @@ int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, co
     if (b.pp) {
         static_assert(sizeof(DiParams) % sizeof(int) == 0, "h of frame f sits f * sizeof(DiParams) / 4 ints behind h of frame 0");
         for (int k = 0; k < b.nheights && !rc; k++)
-            rc = amaze_launch(P.cfa, w, b.heights[k], P.red, P.green, P.blue, P.amaze_scratch, s, nf, b.S, P.amaze_scratch_stride, &b.pp->h,
-                              (int)(sizeof(DiParams) / sizeof(int)));
+            rc = amaze_launch(P.cfa + fo, w, b.heights[k], P.red + fo, P.green + fo, P.blue + fo, P.amaze_scratch + (size_t)b.f0 * P.amaze_scratch_stride, s,
+                              nf, b.S, P.amaze_scratch_stride, &b.pp[b.f0].h, (int)(sizeof(DiParams) / sizeof(int)));
     } else rc = amaze_launch(P.cfa, w, b.p0.h, P.red, P.green, P.blue, P.amaze_scratch, s);
     if (rc) return rc;
+    if (after_amaze) MLV_HIP(hipEventRecord(after_amaze, s));
     hipLaunchKernelGGL(k_di_amaze_ev, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b, L.interp_raw2ev, P.ev_red, P.ev_green, P.ev_blue,
                        P.gray_ev);
     static const int edge_rows = [] { const char *e = getenv("MLVFS_AMD_EDGE_ROWS"); const int v = e ? atoi(e) : 4; return v > 0 ? v : 4; }();   // rows per workgroup

@@ -51,6 +51,7 @@ for k in range(N):
         i, j = random.randrange(len(cand[ph][a])), random.randrange(len(cand[ph][b]))
         cand[ph][a][i], cand[ph][b][j] = cand[ph][b][j], cand[ph][a][i]
     t, _ = run(cand)
+    if k % 20 == 19: print("...", k + 1, "candidates, best", best_t, flush=True)      # (a silent run is taken for a hung one)
     if t < best_t - (0.02 if OBJ == "batch" else 0.005):
         best, best_t = cand, t
         print(k, t, flush=True)
