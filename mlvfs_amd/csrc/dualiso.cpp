@@ -201,9 +201,16 @@ struct DiWork {
     int ensure(size_t bytes)
     {
         if (bytes <= cap) return MLVFS_AMD_OK;
-        if (base) (void)hipFree(base);
-        base = nullptr; cap = 0;
-        MLV_HIP(hipMalloc(&base, bytes));
+        // the larger block first, then the old one goes: a block that grows into the hole its predecessor left (4 -> 8 frames) ran the
+        // conversion 8 % slower than one allocated at its size (9.2 vs 8.5 ms per batch of 8, reproducibly)
+        void *grown = nullptr;
+        if (hipMalloc(&grown, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            if (base) (void)hipFree(base);                       // (no room for both: the old way)
+            base = nullptr; cap = 0;
+            MLV_HIP(hipMalloc(&grown, bytes));
+        } else if (base) (void)hipFree(base);
+        base = grown;
         cap = bytes;
         return MLVFS_AMD_OK;
     }

@@ -39,7 +39,7 @@ try:
         sys.stderr.write(f"batch {n:3d}: {mean * 1e3:8.2f} ms per batch, {n / mean:7.1f} conversions/s (best {n / best:.1f})\n")
         del buf
         torch.cuda.empty_cache()
-        L.mlvfs_amd_dualiso_trim()          # the next size starts from fresh work memory (a buffer that GROWS from 4 to 8 frames in one process
+        if os.environ.get('DI_BENCH_TRIM', '1') == '1': L.mlvfs_amd_dualiso_trim()          # the next size starts from fresh work memory (a buffer that GROWS from 4 to 8 frames in one process
                                             # lands 8 % slower than one allocated at 8: 9.2 vs 8.5 ms per batch, reproducibly; placement)
 finally:
     os.dup2(saved, 1)
