@@ -201,15 +201,10 @@ struct DiWork {
     int ensure(size_t bytes)
     {
         if (bytes <= cap) return MLVFS_AMD_OK;
-        // the larger block first, then the old one goes: a block that grows into the hole its predecessor left (4 -> 8 frames) ran the
-        // conversion 8 % slower than one allocated at its size (9.2 vs 8.5 ms per batch of 8, reproducibly)
+        if (base) (void)hipFree(base);
+        base = nullptr; cap = 0;
         void *grown = nullptr;
-        if (hipMalloc(&grown, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            if (base) (void)hipFree(base);                       // (no room for both: the old way)
-            base = nullptr; cap = 0;
-            MLV_HIP(hipMalloc(&grown, bytes));
-        } else if (base) (void)hipFree(base);
+        MLV_HIP(hipMalloc(&grown, bytes));
         base = grown;
         cap = bytes;
         return MLVFS_AMD_OK;
@@ -578,9 +573,13 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
         P.gray_ev = (int *)(B + o_gray); P.dir = (uint8_t *)(B + o_dir);
         P.sq_dst = (const int *)(B + o_sq); P.sq_row = P.sq_dst + H;
         P.stats = (unsigned *)(B + o_stats); P.amaze_scratch = (float *)as.base; P.amaze_scratch_stride = a_stride;
-        // A batch of 8 or more goes out in two halves on two streams, the second held back until the first one's AMaZE is through:
-        // the first half's table- and bandwidth-bound tail (interpolation, alias map, blend) then runs under the second half's
-        // AMaZE, which is bound by instruction issue -- what two host threads with a batch each get, for one.
+        // A batch of 8 or more goes out in parts of 4 frames: the parts' AMaZE one after the other on the caller's stream, everything
+        // behind a part's AMaZE (interpolation, alias map, blend: table- and bandwidth-bound) on a second stream, where it runs under
+        // the next part's AMaZE, which is bound by instruction issue -- what two host threads with a batch each get, for one.
+        // (The first form alternated the PARTS between the two streams.  Same dependencies for two parts, yet its speed depended on
+        // the order in which the process had created its streams -- 8.5 or 9.2 ms per batch of 8, each reproducible: the tail then
+        // competes with the NEXT part's AMaZE from whichever queue it happens to share, and loses where that queue is served last,
+        // exactly as when the tail's stream is given low priority.  tools/hwq_probe.sh.)
         static const bool split_on = [] { const char *e = getenv("MLVFS_AMD_DI_SPLIT"); return !e || atoi(e) != 0; }();
         if (split_on && nframes >= 8) {
             struct Half {
@@ -590,24 +589,22 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
             static thread_local std::map<int, Half> t_half;
             Half &hf = t_half[c->dev->id];
             if (!hf.st) {
-                MLV_HIP(hipStreamCreateWithFlags(&hf.st, hipStreamNonBlocking));
+                static const int prio = [] { const char *e = getenv("MLVFS_AMD_DI_TAIL_PRIO"); return e ? atoi(e) : 0; }();
+                MLV_HIP(hipStreamCreateWithPriority(&hf.st, hipStreamNonBlocking, prio));
                 MLV_HIP(hipEventCreateWithFlags(&hf.fork, hipEventDisableTiming));
                 MLV_HIP(hipEventCreateWithFlags(&hf.amaze_a, hipEventDisableTiming));
                 MLV_HIP(hipEventCreateWithFlags(&hf.join, hipEventDisableTiming));
             }
-            // parts of 4 frames (at least two), alternately on the caller's stream and the second one: part k starts its AMaZE when
-            // part k - 1 is through with its own, and its tail follows on its stream
-            const int nparts = nframes / 4 > 2 ? nframes / 4 : 2;
+            static const int part = [] { const char *e = getenv("MLVFS_AMD_DI_PART"); const int v = e ? atoi(e) : 4; return v > 0 ? v : 4; }();
+            const int nparts = nframes / part > 2 ? nframes / part : 2;
             MLV_HIP(hipEventRecord(hf.fork, stream));
             MLV_HIP(hipStreamWaitEvent(hf.st, hf.fork, 0));
             for (int k = 0; k < nparts; k++) {
                 DiBatch bk = bt;
                 bk.f0 = (int)((long long)nframes * k / nparts);
                 bk.nframes = (int)((long long)nframes * (k + 1) / nparts) - bk.f0;
-                hipStream_t sk = (k & 1) ? hf.st : stream;
-                if (k > 0) MLV_HIP(hipStreamWaitEvent(sk, hf.amaze_a, 0));       // (recorded by part k - 1 on the other stream)
-                rc = di_launch_amaze_interp(d_frames, bk, H, L, P, sk, k + 1 < nparts ? hf.amaze_a : nullptr);
-                if (!rc) rc = di_launch_convert(bk, H, L, P, amaze, d_frames, sk);
+                rc = di_launch_amaze_interp(d_frames, bk, H, L, P, stream, hf.amaze_a, hf.st);
+                if (!rc) rc = di_launch_convert(bk, H, L, P, amaze, d_frames, hf.st);
                 if (rc) return rc;
             }
             MLV_HIP(hipEventRecord(hf.join, hf.st));

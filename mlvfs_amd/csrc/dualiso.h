@@ -40,7 +40,7 @@ struct DiBatch {
     size_t S;                  // plane stride between frames, in pixels (a multiple of 64)
     size_t img_stride;         // bytes between the 16-bit input / output frames
     int nframes;
-    int f0;                    // first frame of this launch: the kernels' frame index is f0 + the grid's (a batch may be launched in two halves)
+    int f0;                    // first frame of this launch: the kernels' frame index is f0 + the grid's (a batch may be launched in parts)
     int heights[2], nheights;  // the distinct row counts among the frames that are converted (H, and H - 1 for GBRG frames): AMaZE's
                                // launch plan depends on the rows, one plan per height
 };
@@ -107,7 +107,8 @@ void amaze_rows_extent(int w, int h, int *nfx, int *nfy);
 int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, hipStream_t s, int nframes,
                       size_t plane_stride, const int *h_of, int h_stride, float *d_dbg, int *d_ctr /* nframes zeroed ints: the tile counters */);
 int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s,
-                           hipEvent_t after_amaze = nullptr);   // incl. the exposure match; after_amaze: recorded on s when AMaZE is through
+                           hipEvent_t after_amaze = nullptr, hipStream_t tail = nullptr);
+// incl. the exposure match; after_amaze: recorded on s when AMaZE is through; tail: the stream that takes over from there (waits for after_amaze)
 
 int di_launch_analyse(const void *d_img, int w, int H, int black, int white, const double *d_evf, unsigned *d_hist,
                       double *d_check, hipStream_t s, int nframes = 1, size_t img_stride = 0, size_t hist_stride = 0, size_t check_stride = 0);

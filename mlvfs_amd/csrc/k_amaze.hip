@@ -608,7 +608,7 @@ int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green,
         hipStream_t st = nullptr; hipEvent_t go = nullptr, done = nullptr; int *ctr = nullptr; int cap = 0;
         ~Side() { if (ctr) (void)hipFree(ctr); if (go) (void)hipEventDestroy(go); if (done) (void)hipEventDestroy(done); if (st) (void)hipStreamDestroy(st); }
     };
-    static thread_local std::map<std::pair<int, hipStream_t>, Side> t_side;      // per device and stream of the caller (a batch in two halves: two)
+    static thread_local std::map<std::pair<int, hipStream_t>, Side> t_side;      // per device and stream of the caller
     Side *side = nullptr;
     bool rows_pending = false;
     if (nfx) {

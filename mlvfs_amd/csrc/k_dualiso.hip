@@ -1180,7 +1180,8 @@ int di_launch_match(const void *d_img, const DiBatch &b, int h_launch, const DiL
 
 // squeeze -> AMaZE -> clamp -> gray -> edge directions; the planes feed k_di_interp<true>.  P.sq_dst: per frame sq_dst | sq_row of
 // h_launch ints each
-int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s, hipEvent_t after_amaze)
+int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s, hipEvent_t after_amaze,
+                           hipStream_t tail)
 {
     const int w = b.p0.w, nf = b.nframes;
     const size_t n = (size_t)w * h_launch, sq_stride = 3 * (size_t)h_launch, fo = (size_t)b.f0 * b.S;
@@ -1197,6 +1198,11 @@ int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, co
     } else rc = amaze_launch(P.cfa, w, b.p0.h, P.red, P.green, P.blue, P.amaze_scratch, s);
     if (rc) return rc;
     if (after_amaze) MLV_HIP(hipEventRecord(after_amaze, s));
+    if (tail && tail != s) {                                           // what follows AMaZE goes on with the planes on another stream
+        if (!after_amaze) return MLVFS_AMD_ERR_ARG;
+        MLV_HIP(hipStreamWaitEvent(tail, after_amaze, 0));
+        s = tail;
+    }
     hipLaunchKernelGGL(k_di_amaze_ev, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b, L.interp_raw2ev, P.ev_red, P.ev_green, P.ev_blue,
                        P.gray_ev);
     static const int edge_rows = [] { const char *e = getenv("MLVFS_AMD_EDGE_ROWS"); const int v = e ? atoi(e) : 4; return v > 0 ? v : 4; }();   // rows per workgroup

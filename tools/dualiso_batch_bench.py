@@ -39,8 +39,7 @@ try:
         sys.stderr.write(f"batch {n:3d}: {mean * 1e3:8.2f} ms per batch, {n / mean:7.1f} conversions/s (best {n / best:.1f})\n")
         del buf
         torch.cuda.empty_cache()
-        if os.environ.get('DI_BENCH_TRIM', '1') == '1': L.mlvfs_amd_dualiso_trim()          # the next size starts from fresh work memory (a buffer that GROWS from 4 to 8 frames in one process
-                                            # lands 8 % slower than one allocated at 8: 9.2 vs 8.5 ms per batch, reproducibly; placement)
+        if os.environ.get('DI_BENCH_TRIM', '1') == '1': L.mlvfs_amd_dualiso_trim()          # the next size starts from fresh work memory
 finally:
     os.dup2(saved, 1)
 print(json.dumps({"workload": f"{w}x{h} cr2hdr20 interp={interp} fullres alias-map, frames resident in HBM", "batch": out}))
