@@ -766,14 +766,18 @@ __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long
     return base + inc - v;
 }
 // in place: hist[0..n) -> C[r] = sum of hist[v], v < r, for r = 0..n (n + 1 words, the array has room); DNT threads, n % DNT == 0
-__device__ void block_prefix_in_place(unsigned *hist, int n, unsigned long long *sh)
+template <int n> __device__ void block_prefix_in_place(unsigned *hist, unsigned long long *sh)
 {
-    const int per = n / DNT, i0 = threadIdx.x * per;
+    constexpr int per = n / DNT;
+    const int i0 = threadIdx.x * per;
+    unsigned v[per];
     unsigned long long s = 0;
-    for (int i = 0; i < per; i++) s += hist[i0 + i];
+#pragma unroll
+    for (int i = 0; i < per; i++) { v[i] = hist[i0 + i]; s += v[i]; }
     unsigned long long tot;
     unsigned long long run = block_excl_scan(s, sh, &tot);
-    for (int i = 0; i < per; i++) { const unsigned v = hist[i0 + i]; hist[i0 + i] = (unsigned)run; run += v; }
+#pragma unroll
+    for (int i = 0; i < per; i++) { hist[i0 + i] = (unsigned)run; run += v[i]; }
     if (threadIdx.x == DNT - 1) hist[n] = (unsigned)run;
     __syncthreads();
 }
@@ -786,23 +790,54 @@ __device__ __forceinline__ int quantile_of(const unsigned *C, int n, long long r
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((long long)C[mid] >= ref) hi = mid; else lo = mid; }
     return hi;
 }
-// first index i (ascending) with sum of hist[0..i] > k, bins - 1 if none: kth_from_hist of rounds 1-2's host code; DNT threads, bins % DNT == 0
-__device__ int block_kth_from_hist(const unsigned *hist, int bins, long long k, unsigned long long *sh, int *sh_i)
+// kth_from_hist of rounds 1-2's host code -- the first index i (ascending) with sum of hist[0..i] > k, BINS - 1 if none -- in two steps,
+// so that several k of one histogram share the sweep: kth_scan sums a chunk of BINS / DNT bins per thread and scans the sums
+// (DNT threads, BINS % DNT == 0, at most 128 bins per thread); kth_resolve finds up to four k: the thread whose chunk holds a
+// crossing names it, and wave t finds k[t] inside that chunk with one scan over its lanes (the walk of one thread through its chunk,
+// a dependent load per bin, was most of the two decision kernels' 300 us).
+struct KthScan { unsigned long long s, run, tot; };
+struct KthScratch { unsigned long long run[4]; int chunk[4], res[4]; };
+template <int BINS> __device__ __forceinline__ KthScan kth_scan(const unsigned *hist, unsigned long long *sh)
 {
-    const int per = bins / DNT, i0 = threadIdx.x * per;
-    unsigned long long s = 0;
-    for (int i = 0; i < per; i++) s += hist[i0 + i];
-    unsigned long long tot;
-    unsigned long long run = block_excl_scan(s, sh, &tot);
-    if (threadIdx.x == 0) *sh_i = bins - 1;
+    constexpr int per = BINS / DNT;
+    const int i0 = threadIdx.x * per;
+    KthScan r;
+    r.s = 0;
+#pragma unroll 16
+    for (int i = 0; i < per; i++) r.s += hist[i0 + i];
+    r.run = block_excl_scan(r.s, sh, &r.tot);
+    return r;
+}
+template <int BINS> __device__ __forceinline__ void kth_resolve(const unsigned *hist, const KthScan &sc, const long long *k, int nk, int *out,
+                                                                KthScratch &ks)
+{
+    constexpr int per = BINS / DNT, m = (per + 63) / 64;      // bins per lane of the resolving wave
+    static_assert(per <= 128, "a chunk is resolved by one wave, two bins per lane");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 4) { ks.chunk[tid] = -1; ks.res[tid] = BINS - 1; }
     __syncthreads();
-    if ((long long)run <= k && (long long)(run + s) > k) {          // the crossing lies in this thread's chunk
-        for (int i = 0; i < per; i++) { run += hist[i0 + i]; if ((long long)run > k) { *sh_i = i0 + i; break; } }
+    for (int t = 0; t < nk; t++)
+        if ((long long)sc.run <= k[t] && (long long)(sc.run + sc.s) > k[t]) { ks.chunk[t] = tid * per; ks.run[t] = sc.run; }
+    __syncthreads();
+    if (wv < nk && ks.chunk[wv] >= 0) {
+        const int c0 = ks.chunk[wv];
+        const long long kk = k[wv];
+        unsigned v[m];
+        unsigned long long ls = 0;
+#pragma unroll
+        for (int j = 0; j < m; j++) { const int b = lane * m + j; v[j] = b < per ? hist[c0 + b] : 0u; ls += v[j]; }
+        unsigned long long inc = ls;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        unsigned long long before = ks.run[wv] + inc - ls;
+        if ((long long)before <= kk && (long long)(before + ls) > kk) {
+#pragma unroll
+            for (int j = 0; j < m; j++) { before += v[j]; if ((long long)before > kk) { ks.res[wv] = c0 + lane * m + j; break; } }
+        }
     }
     __syncthreads();
-    const int r = *sh_i;
+    for (int t = 0; t < nk; t++) out[t] = ks.res[t];
     __syncthreads();
-    return r;
 }
 
 }  // namespace
@@ -811,6 +846,12 @@ __device__ int block_kth_from_hist(const unsigned *hist, int bins, long long k, 
 // wh [2][32768] (white histograms by exposure, overwritten samples taken out)
 constexpr size_t DI_DERIVED_WORDS = 4 * 16384 + 4 * 16385 + 3 + 2 * 32768;
 
+#ifdef DI_DIAG
+__device__ unsigned long long g_dp_stamps[16];
+#define DP_STAMP(k) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_dp_stamps[k] = wall_clock64(); } while (0)
+#else
+#define DP_STAMP(k) do {} while (0)
+#endif
 // analyse()'s host half, the pattern, the bright / dark fields and the white levels of dualiso.cpp (is_rggb_from_hist,
 // bright_dark_from_hist, whites_from_hist) for frame blockIdx.x; writes dd[f] and the geometry part of pp[f]
 __global__ __launch_bounds__(DNT) void k_di_decide_pattern(const uint16_t *__restrict__ frames, size_t img_stride, int w, int H, int black14,
@@ -818,7 +859,8 @@ __global__ __launch_bounds__(DNT) void k_di_decide_pattern(const uint16_t *__res
 {
     __shared__ unsigned long long sh[DNT / 64];
     __shared__ long long shl[DNT / 64];
-    __shared__ int sh_i, s_rggb, s_bright[4], s_rows[512][2], s_nrows;
+    __shared__ int s_rggb, s_bright[4], s_rows[512][2], s_nrows, s_raw[4], s_off[4];
+    __shared__ KthScratch ks;
     const int f = blockIdx.x, tid = threadIdx.x;
     const uint16_t *frame = (const uint16_t *)((const uint8_t *)frames + (size_t)f * img_stride);
     const unsigned *dev = D.hist + (size_t)f * D.hist_stride;
@@ -830,7 +872,9 @@ __global__ __launch_bounds__(DNT) void k_di_decide_pattern(const uint16_t *__res
         dd.n = 0; dd.bmed = dd.b_lo = dd.b_hi = dd.dmed = 0; dd.hi_n = 0; dd.best = -1; dd.best_score = 0;
         dd.check_ok = D.check_passed || (dd.check_n > 0 && dd.check_sum / dd.check_n > 0.5);      // hdr.c:432-438
     }
+    DP_STAMP(0);
     // ---- the four Bayer-phase histograms over rows [0, H / 4 * 4) (hdr.c:453): all rows' classes minus the rows below that range
+#pragma unroll 16
     for (int i = tid; i < 4 * 16384; i += DNT) {
         const int k = i >> 14, v = i & 16383, qb = k >> 1, px = k & 1;
         hb[i] = dev[DI_D_CLASS + (size_t)(qb * 2 + px) * 16384 + v] + dev[DI_D_CLASS + (size_t)((qb + 2) * 2 + px) * 16384 + v];
@@ -840,16 +884,20 @@ __global__ __launch_bounds__(DNT) void k_di_decide_pattern(const uint16_t *__res
     for (int y = R0; y < H; y++)
         for (int x = tid; x < w; x += DNT) atomicSub(&hb[(size_t)((y & 1) * 2 + (x & 1)) * 16384 + (frame[(size_t)y * w + x] & 16383)], 1u);
     __syncthreads();
+    DP_STAMP(1);
     {   // is_rggb_from_hist: sum over v of |acc1 - acc2| against |acc0 - acc3| (integers far below 2^53: the doubles of the host are exact)
         const int per = 16384 / DNT, i0 = tid * per;
         unsigned long long run[4];
         for (int k = 0; k < 4; k++) {
             unsigned long long s = 0;
+#pragma unroll
             for (int i = 0; i < per; i++) s += hb[(size_t)k * 16384 + i0 + i];
             run[k] = block_excl_scan(s, sh, nullptr);
         }
         unsigned long long d_rggb = 0, d_gbrg = 0;
+#pragma unroll
         for (int i = 0; i < per; i++) {
+#pragma unroll
             for (int k = 0; k < 4; k++) run[k] += hb[(size_t)k * 16384 + i0 + i];
             d_rggb += run[1] > run[2] ? run[1] - run[2] : run[2] - run[1];
             d_gbrg += run[0] > run[3] ? run[0] - run[3] : run[3] - run[0];
@@ -859,8 +907,10 @@ __global__ __launch_bounds__(DNT) void k_di_decide_pattern(const uint16_t *__res
         if (tid == 0) s_rggb = d_rggb < d_gbrg;
         __syncthreads();
     }
+    DP_STAMP(2);
     const int rggb = s_rggb, ay1 = rggb ? 0 : 1, h = rggb ? H : H - 1;
     // ---- greens by row phase: the frame as it is (RGGB: x & 1 != y & 1, rows [0, R0)) or one row lower (GBRG: rows 4 <= y - 1 < R1)
+#pragma unroll 16
     for (int i = tid; i < 4 * 16384; i += DNT) {
         const int ph = i >> 14, v = i & 16383;
         const int q = rggb ? ph : ((ph + 1) & 3);                 // GBRG: class q feeds phase (q + 3) & 3
@@ -868,6 +918,7 @@ __global__ __launch_bounds__(DNT) void k_di_decide_pattern(const uint16_t *__res
         g[(size_t)ph * 16385 + v] = dev[DI_D_CLASS + (size_t)(q * 2 + px) * 16384 + v];
     }
     __syncthreads();
+    DP_STAMP(3);
     // rows outside the range (dualiso.cpp: take_out): RGGB [R0, H); GBRG y - 1 < 4 or y - 1 >= R1, i.e. [0, 5) and [R1 + 1, H)
     for (int pass = 0; pass < 2; pass++) {
         const int ya = rggb ? (pass ? H : R0) : (pass ? R1 + 1 : 0), yb = rggb ? H : (pass ? H : min(5, H));
@@ -878,31 +929,36 @@ __global__ __launch_bounds__(DNT) void k_di_decide_pattern(const uint16_t *__res
         }
     }
     __syncthreads();
+    DP_STAMP(4);
     // ---- bright_dark_from_hist in closed form.  The host walks ref upwards and moves every class to raw_i(ref) = the smallest r whose
     // count of values below r reaches ref; it records `off` while ref < ref_off and all classes are below the threshold, and stops at
     // the first ref that takes a class to 10000 or at ref_max.  The state only depends on ref, so the stops are evaluated directly.
-    for (int k = 0; k < 4; k++) block_prefix_in_place(g + (size_t)k * 16385, 16384, sh);
-    if (tid == 0) {
-        const unsigned *C[4] = { g, g + 16385, g + 2 * 16385, g + 3 * 16385 };
+    for (int k = 0; k < 4; k++) block_prefix_in_place<16384>(g + (size_t)k * 16385, sh);
+    DP_STAMP(5);
+    if (tid < 64) {
+        // lanes 0..3: raw of row phase k = lane, lanes 4..7: off of phase k = lane - 4 (eight binary searches side by side; the other
+        // lanes repeat them); the minima over the four phases by shuffles within the groups of four lanes
+        const int k4 = tid & 3;
+        const unsigned *Ck = g + (size_t)k4 * 16385;
         const int white = 10000;
-        const long long total = C[0][16384];               // hdr.c:553-555: the count of the FIRST row phase stands for all four
+        const long long total = g[16384];                  // hdr.c:553-555: the count of the FIRST row phase stands for all four
         const int ref_max = (int)(total * 0.998), ref_off = (int)(total * 0.05);
-        int raw[4] = { 0, 0, 0, 0 }, off[4] = { 0, 0, 0, 0 };
-        if (ref_max > 0) {
-            long long ref_b = (long long)1 << 62;
-            for (int k = 0; k < 4; k++) ref_b = min(ref_b, (long long)C[k][white - 1] + 1);       // first ref with raw_k >= white
-            const long long ref_end = ref_b < ref_max ? ref_b : (long long)ref_max - 1;
-            for (int k = 0; k < 4; k++) raw[k] = quantile_of(C[k], 16384, ref_end);
-            const int thr = black14 + (white - black14) / 4;
-            if (thr > 0) {
-                const int t1 = min(thr - 1, 16384);
-                long long r_thr = (long long)1 << 62;
-                for (int k = 0; k < 4; k++) r_thr = min(r_thr, (long long)C[k][t1]);           // largest ref with every raw_k < thr
-                const long long ref_o = min(min((long long)ref_off - 1, r_thr), ref_end);
-                if (ref_o >= 0)
-                    for (int k = 0; k < 4; k++) off[k] = quantile_of(C[k], 16384, ref_o);
-            }
-        }
+        long long ref_b = (long long)Ck[white - 1] + 1;      // first ref with raw_k >= white
+        { long long u = __shfl_xor(ref_b, 1); ref_b = u < ref_b ? u : ref_b; u = __shfl_xor(ref_b, 2); ref_b = u < ref_b ? u : ref_b; }
+        const long long ref_end = ref_b < ref_max ? ref_b : (long long)ref_max - 1;
+        const int thr = black14 + (white - black14) / 4;
+        long long r_thr = thr > 0 ? (long long)Ck[min(thr - 1, 16384)] : 0;                    // largest ref with every raw_k < thr
+        { long long u = __shfl_xor(r_thr, 1); r_thr = u < r_thr ? u : r_thr; u = __shfl_xor(r_thr, 2); r_thr = u < r_thr ? u : r_thr; }
+        const long long ref_o = min(min((long long)ref_off - 1, r_thr), ref_end);
+        const bool is_off = (tid >> 2) & 1;
+        int val = 0;
+        if (ref_max > 0 && (!is_off || (thr > 0 && ref_o >= 0))) val = quantile_of(Ck, 16384, is_off ? ref_o : ref_end);
+        if (tid < 4) s_raw[k4] = val;
+        else if (tid < 8) s_off[k4] = val;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int raw[4] = { s_raw[0], s_raw[1], s_raw[2], s_raw[3] }, off[4] = { s_off[0], s_off[1], s_off[2], s_off[3] };
         int d[4], sv[4];
         for (int k = 0; k < 4; k++) { d[k] = raw[k] - off[k]; sv[k] = d[k]; }
         for (int a = 0; a < 4; a++) for (int b = a + 1; b < 4; b++) if (sv[b] < sv[a]) { const int t = sv[a]; sv[a] = sv[b]; sv[b] = t; }
@@ -911,32 +967,45 @@ __global__ __launch_bounds__(DNT) void k_di_decide_pattern(const uint16_t *__res
         dd.rggb = rggb;
     }
     __syncthreads();
+    DP_STAMP(6);
     // ---- whites_from_hist: the every-3rd-pixel histograms by exposure; the samples the reference's list cap overwrote (class
     // indices max_pix - 1 .. total - 2, only ever in the last rows) are taken out; 11th / 51st largest
     const int isb[4] = { s_bright[0], s_bright[1], s_bright[2], s_bright[3] };
     const uint16_t *img = frame + (size_t)ay1 * w;
     const unsigned *hw = dev + (rggb ? DI_D_WHITE0 : DI_D_WHITE1);
-    for (int i = tid; i < 2 * 32768; i += DNT) {
-        const int c = i >> 15, v = i & 32767;
-        unsigned s = 0;
-        for (int ph = 0; ph < 4; ph++) if (isb[ph] == c) s += hw[(size_t)ph * 32768 + v];
-        wh[i] = s;
+#pragma unroll 8
+    for (int v = tid; v < 32768; v += DNT) {                                     // all four phases loaded, then dealt to the two exposures
+        unsigned s0 = 0, s1 = 0;
+#pragma unroll
+        for (int ph = 0; ph < 4; ph++) { const unsigned n = hw[(size_t)ph * 32768 + v]; if (isb[ph]) s1 += n; else s0 += n; }
+        wh[v] = s0;
+        wh[32768 + v] = s1;
     }
+    DP_STAMP(7);
     const int spr = (w + 2) / 3, tail_rows = min(h, 32);
     const long long max_pix = (long long)w * h / 2 / 9;
     if (tid == 0) {
-        long long total[2] = { 0, 0 }, idx[2] = { 0, 0 };
-        for (int y = ay1; y < h; y += 3) total[isb[y % 4]] += spr;
+        // sample rows y = ay1 + 3 j, j < J; the class of a row depends on j % 4, so what the reference's running indices hold at row j
+        // is a count of earlier rows per residue; only the last rows can reach the cap
+        const int J = h > ay1 ? (h - ay1 + 2) / 3 : 0;
+        auto before = [&](int j, int c) {                              // samples of class c in the rows before row j
+            long long nrows = 0;
+            for (int r = 0; r < 4; r++) if (isb[(ay1 + 3 * r) % 4] == c) nrows += (j - r + 3) / 4;
+            return nrows * spr;
+        };
+        const long long total[2] = { before(J, 0), before(J, 1) };
         shl[0] = total[0]; shl[1] = total[1];
         int n = 0;
-        for (int y = ay1; y < h; y += 3) {
-            const int c = isb[y % 4];
-            if (total[c] > max_pix && idx[c] + spr > max_pix - 1 && y >= h - tail_rows && n < 512) { s_rows[n][0] = y; s_rows[n][1] = (int)idx[c]; n++; }
-            idx[c] += spr;
+        const int y_first = h - tail_rows;
+        for (int j = y_first > ay1 ? (y_first - ay1 + 2) / 3 : 0; j < J; j++) {
+            const int y = ay1 + 3 * j, c = isb[y % 4];
+            const long long idx = before(j, c);
+            if (total[c] > max_pix && idx + spr > max_pix - 1 && n < 512) { s_rows[n][0] = y; s_rows[n][1] = (int)idx; n++; }
         }
         s_nrows = n;
     }
     __syncthreads();
+    DP_STAMP(8);
     unsigned long long removed[2] = { 0, 0 };
     for (int r = 0; r < s_nrows; r++) {
         const int y = s_rows[r][0], c = isb[y % 4];
@@ -953,6 +1022,7 @@ __global__ __launch_bounds__(DNT) void k_di_decide_pattern(const uint16_t *__res
     removed[0] = block_sum_u64(removed[0], sh);
     removed[1] = block_sum_u64(removed[1], sh);
     __syncthreads();
+    DP_STAMP(9);
     int wlev[2];
     for (int c = 0; c < 2; c++) {
         const long long kept = shl[c] - (long long)removed[c];
@@ -961,10 +1031,13 @@ __global__ __launch_bounds__(DNT) void k_di_decide_pattern(const uint16_t *__res
         if (kept > 0) {
             if (k > kept - 1) k = kept - 1;
             // (k + 1)-th largest = first index from the top whose running count exceeds k = from the bottom: exceeds kept - 1 - k
-            val = block_kth_from_hist(wh + (size_t)c * 32768, 32768, kept - 1 - k, sh, &sh_i);
+            const long long kk = kept - 1 - k;
+            const KthScan sc = kth_scan<32768>(wh + (size_t)c * 32768, sh);
+            kth_resolve<32768>(wh + (size_t)c * 32768, sc, &kk, 1, &val, ks);
         }
         wlev[c] = val;
     }
+    DP_STAMP(10);
     if (tid == 0) {
         const int w0 = wlev[0] - 100, w1 = wlev[1] - 1500;
         dd.white_dark = w0 < 10000 ? 10000 : (w0 > 16383 ? 16383 : w0);
@@ -984,21 +1057,23 @@ __global__ __launch_bounds__(DNT) void k_di_decide_pattern(const uint16_t *__res
 __global__ __launch_bounds__(DNT) void k_di_decide_quantiles(DiDecideBuffers D)
 {
     __shared__ unsigned long long sh[DNT / 64];
-    __shared__ int sh_i;
+    __shared__ KthScratch ks;
     const int f = blockIdx.x;
     const unsigned *hb = D.hist_bd + (size_t)f * 2 * DI_HIST_N, *hd = hb + DI_HIST_N;
     DiDecide &dd = D.dd[f];
     if (D.pp[f].h <= 0) return;
-    unsigned long long s = 0;
-    for (int i = threadIdx.x; i < DI_HIST_N; i += DNT) s += hb[i];
-    const long long n = (long long)block_sum_u64(s, sh);
+    const KthScan sb = kth_scan<DI_HIST_N>(hb, sh);             // one sweep over each histogram: n, then three k of hist_b and one of hist_d
+    const long long n = (long long)sb.tot;
     const long long mk = (n & 1) ? n / 2 : n / 2 - 1;
     int bmed = 0, b_lo = 0, b_hi = 0, dmed = 0;
     if (n > 0) {
-        bmed = block_kth_from_hist(hb, DI_HIST_N, mk, sh, &sh_i) - DI_HIST_OFF;
-        b_lo = block_kth_from_hist(hb, DI_HIST_N, n * 98 / 100, sh, &sh_i) - DI_HIST_OFF;
-        b_hi = block_kth_from_hist(hb, DI_HIST_N, (long long)(n * 99.9 / 100), sh, &sh_i) - DI_HIST_OFF;
-        dmed = block_kth_from_hist(hd, DI_HIST_N, mk, sh, &sh_i) - DI_HIST_OFF;
+        const long long kb[3] = { mk, n * 98 / 100, (long long)(n * 99.9 / 100) };
+        int rb[3];
+        kth_resolve<DI_HIST_N>(hb, sb, kb, 3, rb, ks);
+        const KthScan sd = kth_scan<DI_HIST_N>(hd, sh);
+        int rd;
+        kth_resolve<DI_HIST_N>(hd, sd, &mk, 1, &rd, ks);
+        bmed = rb[0] - DI_HIST_OFF; b_lo = rb[1] - DI_HIST_OFF; b_hi = rb[2] - DI_HIST_OFF; dmed = rd - DI_HIST_OFF;
     }
     if (threadIdx.x == 0) { dd.n = n; dd.bmed = bmed; dd.b_lo = b_lo; dd.b_hi = b_hi; dd.dmed = dmed; }
 }
@@ -1259,6 +1334,19 @@ size_t di_derived_words() { return DI_DERIVED_WORDS; }
 int di_launch_decide_pattern(const void *d_frames, const DiBatch &b, int H, int black14, const DiDecideBuffers &D, hipStream_t s)
 {
     hipLaunchKernelGGL(k_di_decide_pattern, dim3(b.nframes), dim3(DNT), 0, s, (const uint16_t *)d_frames, b.img_stride, b.p0.w, H, black14, D);
+#ifdef DI_DIAG
+    {
+        static int shown = 0;
+        if (shown++ == 3) {
+            unsigned long long st[16];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_dp_stamps), sizeof st);
+            fprintf(stderr, "DI_DIAG k_di_decide_pattern, 10 ns ticks between stamps:");
+            for (int k = 0; k < 10; k++) fprintf(stderr, " %lld", (long long)(st[k + 1] - st[k]));
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
