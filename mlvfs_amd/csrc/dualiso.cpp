@@ -589,6 +589,8 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
             static thread_local std::map<int, Half> t_half;
             Half &hf = t_half[c->dev->id];
             if (!hf.st) {
+                // (priority: a knob for experiments.  Which of the queues is served first while AMaZE workgroups wait for a free CU decides
+                // whether the tail overlaps at all)
                 static const int prio = [] { const char *e = getenv("MLVFS_AMD_DI_TAIL_PRIO"); return e ? atoi(e) : 0; }();
                 MLV_HIP(hipStreamCreateWithPriority(&hf.st, hipStreamNonBlocking, prio));
                 MLV_HIP(hipEventCreateWithFlags(&hf.fork, hipEventDisableTiming));

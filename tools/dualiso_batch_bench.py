@@ -15,6 +15,8 @@ w, h = 3584, 1320
 frames = [synth.dual_iso_frame(w, h, seed=3, frame=k) for k in range(2)]
 src = [torch.from_numpy(f.view(np.int16)).cuda() for f in frames]
 geom = lib.Geom(w, h, 14, synth.BLACK, synth.WHITE, 0, 0)
+own = torch.cuda.Stream() if os.environ.get('DI_BENCH_STREAM') == '1' else None        # the caller's own stream instead of the library's
+sp = C.c_void_p(own.cuda_stream) if own else None
 devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(1); os.dup2(devnull, 1)      # the reference's progress printf()s
 out = {}
 try:
@@ -26,7 +28,7 @@ try:
                 buf[k] = src[k & 1]
             torch.cuda.synchronize()
         def run():
-            rc = L.mlvfs_amd_cr2hdr20_batch_dev(C.byref(geom), C.c_void_p(buf.data_ptr()), w * h * 2, n, interp, 1, 1, 0, lib.ptr(res), None)
+            rc = L.mlvfs_amd_cr2hdr20_batch_dev(C.byref(geom), C.c_void_p(buf.data_ptr()), w * h * 2, n, interp, 1, 1, 0, lib.ptr(res), sp)
             torch.cuda.synchronize()
             assert rc == 0 and res.sum() == n, (rc, res)
         fill(); run()                                      # buffers, tables
