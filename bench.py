@@ -518,7 +518,16 @@ def main():
     rehearsal = world > 1 and os.environ.get("MLVFS_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
-    if world > 1:
+    # MLVFS_BENCH_GROUP1=1 (never what the driver runs): the N = 1 run as the only rank of an "nccl" process group, so that every
+    # collective of this file -- broadcasts, the sharded histogram's all_gather / all_reduce, barriers, the max over ranks -- goes
+    # through RCCL on a box with one card (tests/test_bench_cli.py)
+    grouped = world > 1 or os.environ.get("MLVFS_BENCH_GROUP1") == "1"
+    if grouped and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if grouped:
         if not rehearsal and torch.cuda.device_count() < world:
             sys.exit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPUs visible")
         torch.cuda.set_device(local)
@@ -554,7 +563,7 @@ def main():
         frame0 = s.chroma_smooth(frame0, args.cs) if args.cs else frame0
     else:
         frame0 = s.alloc_out(1)
-    if world > 1:
+    if grouped:
         n_pix = torch.tensor([len(pix) if rank == 0 else 0], dtype=torch.int64, device=dev)
         dist.broadcast(n_pix, src=0)
         pix_t = torch.from_numpy(pix.copy()).to(dev) if rank == 0 else \
@@ -586,7 +595,7 @@ def main():
     for i in range(Wm):
         step(i % K)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     lib.check(L.mlvfs_amd_timer_begin(K), "timer_begin")
     torch.cuda.synchronize()
@@ -594,12 +603,12 @@ def main():
     for i in range(K):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     dt = time.perf_counter() - t0
     ms = np.zeros(K, np.float32)
     n_timed = L.mlvfs_amd_timer_end(lib.ptr(ms), K)
-    if world > 1:
+    if grouped:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -607,7 +616,7 @@ def main():
     # ---- strong scaling, reported beside the weak headline (never `value`): ONE clip of K*F frames -- the N = 1 workload -- split
     # into contiguous frame ranges (mlvfs_amd.dist.frame_range), no data-path collective; time = slowest rank between two barriers
     strong = None
-    if world > 1:
+    if grouped:
         a, b = mdist.frame_range(K * F, rank, world)
         def strong_pass():
             for lo in range(a, b, F):
@@ -638,7 +647,7 @@ def main():
                              "(hashes of the reference's output), stripe coefficients, pixel-map size",
                   "hashes": got, "reference": want, "ok": bool(got == want and co_ok and map_ok)}
     ok_flag = torch.tensor([1 if (parity is None or parity["ok"]) else 0], dtype=torch.int32, device=dev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(ok_flag, op=dist.ReduceOp.MIN)
 
     npx = W * H
@@ -685,7 +694,7 @@ def main():
                    "frames_per_step": F, "frames_per_rank": K * F, "chroma_smooth": args.cs,
                    "bad_pixels_in_map": int(len(s.get_pixel_map())), "stripe_coeffs": [int(c) for c in coeffs],
                    "parallelism": f"frames x{world}", "first_frame_ms": round(first_frame_ms, 2), "strong_scaling": strong,
-                   "collective": None if world == 1 else ("gloo (rehearsal)" if rehearsal else "RCCL all_gather + all_reduce int32[8][65536], once per clip")},
+                   "collective": None if not grouped else ("gloo (rehearsal)" if rehearsal else "RCCL all_gather + all_reduce int32[8][65536], once per clip")},
         "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_source": traffic_src,
@@ -724,7 +733,7 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
         os.dup2(2, 1)                              # whatever is still buffered in C stdio at exit stays off stdout
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
     s.close()
     if not all_ok:

@@ -49,7 +49,8 @@ def sharded_stripes_histogram(count_rows: Callable[[int, int], int],
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     row0, row1 = row_range(height, rank, world)
     mine = int(count_rows(row0, row1))
-    if world > 1:
+    grouped = dist.is_initialized()          # a group of one still takes the collectives (a one-card box can exercise RCCL that way)
+    if grouped:
         parts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
         dist.all_gather(parts, torch.tensor([mine], dtype=torch.int64, device=device), group=group)
         counts = [int(p.item()) for p in parts]
@@ -57,7 +58,7 @@ def sharded_stripes_histogram(count_rows: Callable[[int, int], int],
         counts = [mine]
     first = int(sum(counts[:rank]))
     hist, num = hist_rows(row0, row1, first, mine)
-    if world > 1:
+    if grouped:
         dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(num, op=dist.ReduceOp.SUM, group=group)
     return hist, num, int(sum(counts))

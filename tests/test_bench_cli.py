@@ -115,3 +115,40 @@ def test_row_sharded_stripes_over_rccl_world2(gpu, oracle):
     for rank, needed, co, calls, nsum in res:
         assert needed == want_needed and co == [int(c) for c in want_co]
         assert calls == int(num.sum()) == nsum
+
+
+@pytest.mark.gpu
+def test_row_sharded_stripes_over_rccl_world1(gpu, oracle):
+    """What a one-GPU box can show of the RCCL path: the same worker as above as the only rank of an "nccl" process group (the
+    communicator is built, the all_gather / all_reduce of the sharded histogram go through RCCL), against the oracle."""
+    import torch.multiprocessing as mp
+    from mlvfs_amd import synth
+    w, h = 640, 402
+    want_needed, want_co, hist, num = oracle.stripes_compute(synth.normal_frame(w, h), synth.BLACK, synth.WHITE, want_hist=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    p = ctx.Process(target=_nccl_worker, args=(0, 1, port, q))
+    p.start()
+    rank, needed, co, calls, nsum = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert needed == want_needed and co == [int(c) for c in want_co]
+    assert calls == int(num.sum()) == nsum
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_in_an_rccl_group(gpu):
+    """bench.py's N = 1 run as the only rank of an "nccl" process group (MLVFS_BENCH_GROUP1=1): the broadcasts of the pixel map and of
+    frame 0, the sharded histogram's collectives, the barriers and the max over ranks all go through RCCL on this one card, and the
+    output still equals the reference's."""
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["full_size"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MLVFS_BENCH_GROUP1="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "2", "--warmup", "1", "--frames-per-step", "6", "--preheat-ms", "20",
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert res["n_gpus"] == 1 and res["parity"]["ok"] is True
+    assert res["config"]["stripe_coeffs"] == golden["B_cs5_badpix_stripes_coeffs"]
+    assert "RCCL" in res["config"]["collective"] and res["config"]["strong_scaling"]["frames_per_rank"] == [12]
