@@ -43,17 +43,40 @@ __global__ __launch_bounds__(256) void k_pn_transpose(const int16_t *__restrict_
     }
 }
 
-// lower median of v[lo..hi] (inclusive, LDS int16) by bisection on the value, bracketed by the run's extremes
-__device__ __forceinline__ int lower_median_run(const int16_t *v, int lo, int hi)
+// The lower median of a run of at most 50 values around a pixel, four times per half-res pixel, is what the correction costs.
+// A thread takes the 54 values around its pixel (27 aligned dwords, [ws, ws + 54) with ws = x - 26 rounded down to even) from the
+// staged row into registers, replaces what lies outside the run by a value no bisection step ever counts (32767: a step asks for
+// #{v <= mid} with mid below the run's maximum), and bisects on the value between the run's extremes with packed 16-bit arithmetic:
+// sat(mid - v) is negative exactly where v > mid, its sign bits are summed two per instruction.  (The first form bisected over LDS,
+// a 16-bit read, a compare and an add per value and step inside lane-divergent loops: 1.62 ms per pass at 3584x1320.)
+typedef short pn_s2 __attribute__((ext_vector_type(2)));
+constexpr int PN_WD = 27;                                    // dwords of a pixel's window
+constexpr int PN_PAD = 32;                                   // int16 elements either side of a staged row (never read as values: masked)
+
+__device__ __forceinline__ pn_s2 pn_as_s2(unsigned u) { return __builtin_bit_cast(pn_s2, u); }
+
+// arr: a staged row (element 0 at arr[PN_PAD]); m: per dword of the window, which halves belong to the run; need = rank of the lower median
+__device__ __forceinline__ int pn_lower_median(const int16_t *arr, int ws, const unsigned (&m)[PN_WD], int need)
 {
-    const int n = hi - lo + 1, need = (n - 1) / 2 + 1;
-    int a = v[lo], b = a;
-    for (int i = lo + 1; i <= hi; i++) { const int x = v[i]; a = min(a, x); b = max(b, x); }
+    const unsigned *p = (const unsigned *)(arr + PN_PAD + ws);          // 4-byte aligned: PN_PAD and ws are even
+    unsigned v[PN_WD];
+    pn_s2 mn = { 32767, 32767 }, mx = { -32768, -32768 };
+#pragma unroll
+    for (int d = 0; d < PN_WD; d++) {
+        const unsigned u = p[d];
+        v[d] = (u & m[d]) | (~m[d] & 0x7FFF7FFFu);
+        mn = __builtin_elementwise_min(mn, pn_as_s2(v[d]));
+        mx = __builtin_elementwise_max(mx, pn_as_s2((u & m[d]) | (~m[d] & 0x80008000u)));
+    }
+    int a = min((int)mn.x, (int)mn.y), b = max((int)mx.x, (int)mx.y);
     while (a < b) {
         const int mid = (a + b) >> 1;                        // floor
-        int cnt = 0;
-        for (int i = lo; i <= hi; i++) cnt += (v[i] <= mid);
-        if (cnt >= need) b = mid; else a = mid + 1;
+        const pn_s2 mp = { (short)mid, (short)mid };
+        pn_s2 acc = { 0, 0 };
+#pragma unroll
+        for (int d = 0; d < PN_WD; d++) acc += __builtin_elementwise_sub_sat(mp, pn_as_s2(v[d])) >> 15;      // -1 where v > mid
+        const int le = 2 * PN_WD + acc.x + acc.y;
+        if (le >= need) b = mid; else a = mid + 1;
     }
     return a;
 }
@@ -61,33 +84,41 @@ __device__ __forceinline__ int lower_median_run(const int16_t *v, int lo, int hi
 __global__ __launch_bounds__(256) void k_pn_smooth(const int16_t *__restrict__ raw, int w, int hw, int reach, int thr,
                                                    int16_t *__restrict__ smooth /* [4][hh][hw] */, int hh)
 {
-    extern __shared__ int16_t row[];                          // avg, g1, g2, drg, dbg: 5 x hw
-    int16_t *avg = row, *g1 = row + hw, *g2 = row + 2 * hw, *drg = row + 3 * hw, *dbg = row + 4 * hw;
+    extern __shared__ __attribute__((aligned(16))) int16_t row[];     // avg, g1, g2, drg, dbg: 5 x (hw + 2 PN_PAD), hw rounded up to even
+    const int hs = ((hw + 1) & ~1) + 2 * PN_PAD;
+    int16_t *avg = row, *g1 = row + hs, *g2 = row + 2 * hs, *drg = row + 3 * hs, *dbg = row + 4 * hs;
     const int y = blockIdx.x;
     for (int x = threadIdx.x; x < hw; x += blockDim.x) {
         const int r = plane_px(raw, w, 0, x, y), a = plane_px(raw, w, 1, x, y), b2 = plane_px(raw, w, 2, x, y),
                   b = plane_px(raw, w, 3, x, y);
         const int16_t av = (int16_t)((a + b2) / 2);            // patternnoise.c:59-65 (C division)
-        avg[x] = av; g1[x] = (int16_t)a; g2[x] = (int16_t)b2;
-        drg[x] = (int16_t)(r - av);
-        dbg[x] = (int16_t)(b - av);
+        avg[PN_PAD + x] = av; g1[PN_PAD + x] = (int16_t)a; g2[PN_PAD + x] = (int16_t)b2;
+        drg[PN_PAD + x] = (int16_t)(r - av);
+        dbg[PN_PAD + x] = (int16_t)(b - av);
     }
     __syncthreads();
     const size_t plane = (size_t)hw * hh;
     for (int x = threadIdx.x; x < hw; x += blockDim.x) {
-        const int centre = avg[x];
+        const int16_t *av = avg + PN_PAD;
+        const int centre = av[x];
         const int hi_lim = min(x + reach, hw), lo_lim = max(x - reach, 0);
         int xr = x + 1, xl = x - 1;
-        while (xr < hi_lim && abs(avg[xr] - centre) <= thr) xr++;
-        while (xl >= lo_lim && abs(avg[xl] - centre) <= thr) xl--;
-        const int lo = xl + 1, hi = xr - 1;
-        const int mg1 = lower_median_run(g1, lo, hi), mg2 = lower_median_run(g2, lo, hi);
+        while (xr < hi_lim && abs(av[xr] - centre) <= thr) xr++;
+        while (xl >= lo_lim && abs(av[xl] - centre) <= thr) xl--;
+        const int lo = xl + 1, hi = xr - 1, n = hi - lo + 1, need = (n - 1) / 2 + 1;
+        const int ws = (x - 26) & ~1;                          // lo >= x - 25 > ws, hi <= x + 24 < ws + 54
+        const unsigned long long run = ((1ull << n) - 1) << (lo - ws);       // bit j: element ws + j belongs to the run
+        unsigned m[PN_WD];
+#pragma unroll
+        for (int d = 0; d < PN_WD; d++)
+            m[d] = (((run >> (2 * d)) & 1) ? 0x0000FFFFu : 0u) | (((run >> (2 * d + 1)) & 1) ? 0xFFFF0000u : 0u);
+        const int mg1 = pn_lower_median(g1, ws, m, need), mg2 = pn_lower_median(g2, ws, m, need);
         const int mg = (mg1 + mg2) / 2;
         const size_t at = (size_t)y * hw + x;
-        smooth[at] = (int16_t)(lower_median_run(drg, lo, hi) + mg);          // r
-        smooth[plane + at] = (int16_t)mg1;                                     // g1
-        smooth[2 * plane + at] = (int16_t)mg2;                                 // g2
-        smooth[3 * plane + at] = (int16_t)(lower_median_run(dbg, lo, hi) + mg);   // b
+        smooth[at] = (int16_t)(pn_lower_median(drg, ws, m, need) + mg);          // r
+        smooth[plane + at] = (int16_t)mg1;                                        // g1
+        smooth[2 * plane + at] = (int16_t)mg2;                                    // g2
+        smooth[3 * plane + at] = (int16_t)(pn_lower_median(dbg, ws, m, need) + mg);   // b
     }
 }
 
@@ -185,7 +216,7 @@ static int column_pass(int16_t *d_raw, int w, int h, int white, int16_t *d_smoot
 {
     const int hw = w / 2, hh = h / 2;
     if (hw <= 0 || hh <= 0) return MLVFS_AMD_OK;
-    const size_t shmem = (size_t)5 * hw * sizeof(int16_t);
+    const size_t shmem = (size_t)5 * (((hw + 1) & ~1) + 2 * PN_PAD) * sizeof(int16_t);
     if (shmem > 150 * 1024) { set_error("fix_pattern_noise: rows of %d pixels do not fit in LDS", w); return MLVFS_AMD_ERR_ARG; }
     MLV_HIP(hipFuncSetAttribute((const void *)k_pn_smooth, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(k_pn_smooth, dim3(hh), dim3(256), shmem, stream, d_raw, w, hw, 50 / 2, 500, d_smooth, hh);

@@ -269,7 +269,7 @@ def test_against_reference_build(gpu, reference):
 
 # ------------------------------------------------------------------ pattern noise
 @pytest.mark.parametrize("kind", KINDS)
-@pytest.mark.parametrize("w,h", [(64, 48), (136, 72), (258, 130), (416, 264)])
+@pytest.mark.parametrize("w,h", [(64, 48), (136, 72), (258, 130), (416, 264), (70, 50), (54, 38), (34, 44), (1002, 46), (46, 1002)])
 def test_fix_pattern_noise_dropin(gpu, oracle, w, h, kind):
     """patternnoise.c:357-380: column pass, then the same pass on the transposed frame;
     int16 arithmetic, lower medians -- bit-exact."""
