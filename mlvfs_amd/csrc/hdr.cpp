@@ -11,7 +11,7 @@
 namespace mlv {
 
 int launch_hdr_row_hist(const void *d_frame, int w, int h, int white, unsigned *d_hist, hipStream_t stream);
-int launch_hdr_preview(void *d_frame, int w, int h, int black, int white, int dark_row_start, int shadow, double a,
+int launch_hdr_preview(const void *d_frame, void *d_out, int w, int h, int black, int white, int dark_row_start, int shadow, double a,
                        double b, size_t shift_count, hipStream_t stream);
 
 struct HdrFit {
@@ -95,9 +95,9 @@ static int hdr_analyse(const unsigned *hist32, int w_in, int h_in, int black_in,
     return 1;
 }
 
-// d_frame: one 16-bit frame in HBM; d_hist: scratch of 4*(white+1) unsigned.
-// pre_transform (optional) runs between detection and matching (focus pixels, hdr.c:104).
-int hdr_preview_device(const Geom &g, void *d_frame, size_t max_size, unsigned *d_hist, hipStream_t stream,
+// d_frame: one 16-bit frame in HBM; d_out: where the converted frame goes (another buffer of the same size); d_hist: scratch of
+// 4*(white+1) unsigned.  pre_transform (optional) runs between detection and matching (focus pixels, hdr.c:104).
+int hdr_preview_device(const Geom &g, const void *d_frame, void *d_out, size_t max_size, unsigned *d_hist, hipStream_t stream,
                        int (*pre_transform)(void *), void *pre_arg)
 {
     const int white16 = (int)(uint16_t)g.white, black16 = (int)(uint16_t)g.black;
@@ -115,7 +115,7 @@ int hdr_preview_device(const Geom &g, void *d_frame, size_t max_size, unsigned *
         rc = pre_transform(pre_arg);
         if (rc) return rc;
     }
-    rc = launch_hdr_preview(d_frame, g.w, g.h, black16, white16, fit.dark_row_start, fit.shadow, fit.a, fit.b,
+    rc = launch_hdr_preview(d_frame, d_out, g.w, g.h, black16, white16, fit.dark_row_start, fit.shadow, fit.a, fit.b,
                             max_size / 2, stream);
     if (rc) return rc;
     return 1;
@@ -141,7 +141,8 @@ int hdr_convert_data(struct frame_headers *fh, uint16_t *image_data, off_t offse
     if (drop_resident(c, image_data)) return 0;             // this call rewrites the host frame: no resident copy of it (dropin.cpp)
     const size_t bytes = (size_t)w * h * 2;
     const size_t hist_bytes = 4 * (size_t)((uint16_t)g.white + 1) * sizeof(unsigned);
-    if (c->ensure(bytes, hist_bytes)) return 0;
+    const size_t out_at = (hist_bytes + 255) & ~(size_t)255;                // the converted frame follows the histograms in d_b
+    if (c->ensure(bytes, out_at + bytes)) return 0;
     if (hipMemcpyAsync(c->d_a, image_data, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return 0;
 
     struct Pre { struct frame_headers *fh; uint16_t *img; ThreadCtx *c; size_t bytes; } pre{ fh, image_data, c, bytes };
@@ -156,9 +157,9 @@ int hdr_convert_data(struct frame_headers *fh, uint16_t *image_data, off_t offse
             MLV_HIP(hipMemcpyAsync(q->c->d_a, q->img, q->bytes, hipMemcpyHostToDevice, q->c->stream));
         return MLVFS_AMD_OK;
     };
-    const int r = hdr_preview_device(g, c->d_a, max_size, (unsigned *)c->d_b, c->stream, focus, &pre);
+    const int r = hdr_preview_device(g, c->d_a, (uint8_t *)c->d_b + out_at, max_size, (unsigned *)c->d_b, c->stream, focus, &pre);
     if (r != 1) return 0;
-    if (hipMemcpyAsync(image_data, c->d_a, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+    if (hipMemcpyAsync(image_data, (uint8_t *)c->d_b + out_at, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) {
         set_error("hdr_convert_data: download failed");
         return 0;
@@ -173,9 +174,13 @@ int mlvfs_amd_hdr_preview_dev(const mlvfs_amd_geom_t *geom, void *d_frame, size_
     ThreadCtx *c = thread_ctx();
     if (!c) return MLVFS_AMD_ERR_HIP;
     const Geom g{ geom->width, geom->height, geom->bpp, geom->black, geom->white };
-    const size_t hist_bytes = 4 * (size_t)((uint16_t)g.white + 1) * sizeof(unsigned);
-    if (c->ensure(0, hist_bytes)) return MLVFS_AMD_ERR_HIP;
-    return hdr_preview_device(g, d_frame, max_size, (unsigned *)c->d_b, pick_stream(stream, c), nullptr, nullptr);
+    const size_t hist_bytes = 4 * (size_t)((uint16_t)g.white + 1) * sizeof(unsigned), bytes = (size_t)g.w * g.h * 2;
+    const size_t out_at = (hist_bytes + 255) & ~(size_t)255;
+    if (c->ensure(0, out_at + bytes)) return MLVFS_AMD_ERR_HIP;
+    hipStream_t s = pick_stream(stream, c);
+    const int r = hdr_preview_device(g, d_frame, (uint8_t *)c->d_b + out_at, max_size, (unsigned *)c->d_b, s, nullptr, nullptr);
+    if (r == 1) MLV_HIP(hipMemcpyAsync(d_frame, (uint8_t *)c->d_b + out_at, bytes, hipMemcpyDeviceToDevice, s));    // in place for the caller
+    return r;
 }
 
 // deflicker of main.c:895-906 on a device frame: exposure_bias as the reference stores it in raw_info (numerator = (int)

@@ -9,64 +9,82 @@
 //                      operations whose summation order must be the reference's.
 //   k_hdr_preview    : the per-row exposure matching (hdr.c:178-215) and the final
 //                      << 2 (hdr.c:217-222).  The reference rewrites rows top-down in
-//                      place and every pixel only depends on rows y-2 (already
-//                      rewritten) and y+2 (not yet rewritten) of ITS OWN COLUMN, so
-//                      one lane owns one column and walks it top-down: coalesced
-//                      row-wise across the wave, sequential in y.
+//                      place; a pixel reads row y+2 as it was and -- only where a bright
+//                      pixel is clipped or a dark one lies in deep shadow -- the REWRITTEN
+//                      row y-2 of its own column.  One thread per pixel, out of place: it
+//                      walks up its column for as long as that dependency holds (one step
+//                      at most on real material, never more than the column), then
+//                      rewrites down to its own row.  (Rounds 1-2: a lane per column
+//                      walking it top-down, 0.52 ms of dependent loads at 3584x1320.)
 //                      Doubles, no FMA contraction -> bit-identical to the x86 path.
 #include "clip.h"
 
 namespace mlv {
 
+// one workgroup per sampled row; with `lds_bins` the row is counted in LDS first and its non-empty bins flushed (neighbouring
+// samples of a smooth row hit the same few counters: 0.09 ms of same-address global atomics at 3584x1320)
 __global__ __launch_bounds__(256) void k_hdr_row_hist(const uint16_t *__restrict__ img, int w, int h, int white,
-                                                      unsigned *__restrict__ hist /* [4][white+1] */)
+                                                      unsigned *__restrict__ hist /* [4][white+1] */, int lds_bins)
 {
-    // blockIdx.y enumerates the sampled rows y = 4 + 5*k
-    const int y = 4 + 5 * blockIdx.y;
+    extern __shared__ unsigned cnt[];
+    // blockIdx.x enumerates the sampled rows y = 4 + 5*k
+    const int y = 4 + 5 * blockIdx.x;
     if (y >= h - 4) return;
     const int first = (y + 1) % 2;
     const int size = w - first;
     unsigned *hg = hist + (size_t)(y % 4) * (white + 1);
-    for (int i = 4 * (blockIdx.x * blockDim.x + threadIdx.x); i < size; i += 4 * gridDim.x * blockDim.x) {
+    if (lds_bins) {
+        for (int i = threadIdx.x; i < lds_bins; i += blockDim.x) cnt[i] = 0;
+        __syncthreads();
+    }
+    for (int i = 4 * threadIdx.x; i < size; i += 4 * blockDim.x) {
         const int v = img[(size_t)y * w + first + i];
-        atomicAdd(&hg[v < white ? v : white], 1u);
+        atomicAdd(lds_bins ? &cnt[v < white ? v : white] : &hg[v < white ? v : white], 1u);
+    }
+    if (lds_bins) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < lds_bins; i += blockDim.x) { const unsigned c = cnt[i]; if (c) atomicAdd(&hg[i], c); }
     }
 }
 
 __device__ __forceinline__ uint16_t d2u16(double v) { return (uint16_t)(int)v; }
 
-__global__ __launch_bounds__(64) void k_hdr_preview(uint16_t *__restrict__ img, int w, int h, int black, int white,
-                                                    int dark_row_start, int shadow, double a, double b, size_t shift_count)
+__global__ __launch_bounds__(256) void k_hdr_preview(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, int w, int h, int black,
+                                                     int white, int dark_row_start, int shadow, double a, double b, size_t shift_count)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     auto scaled = [&](int p) {
         const double v = (p - black) * a + black + b;                   // hdr.c:198
         return (double)white < v ? (double)white : v;
     };
-    // pm2 = rewritten value two rows up; nxt holds original rows y, y+1, y+2
-    int done_m2 = 0, done_m1 = 0;
-    for (int y = 0; y < h; y++) {
-        const size_t i = (size_t)y * w + x;
-        const int p = img[i];
-        const int below = (y + 2 < h) ? img[i + 2 * (size_t)w] : 0;    // original row y+2 (not yet rewritten)
-        const int above = done_m2;                                      // rewritten row y-2
-        int out = p;
-        if (((y - dark_row_start + 4) % 4) >= 2) {                      // bright row
-            if (p >= white) out = (y > 2) ? ((y < h - 2) ? (above + below) / 2 : above) : below;
-            else out = d2u16(scaled(p));
+    auto px = [&](int yy) { return (int)in[(size_t)yy * w + x]; };
+    auto bright = [&](int yy) { return ((yy - dark_row_start + 4) % 4) >= 2; };
+    // where a pixel takes the rewritten value two rows up
+    auto needs_above = [&](int yy, int p) { return yy > 2 && (bright(yy) ? p >= white : p < shadow); };
+    int y0 = y, p0 = px(y);
+    while (needs_above(y0, p0)) { y0 -= 2; p0 = px(y0); }
+    int above = 0, res = 0;
+    for (int yy = y0;; yy += 2) {
+        const int p = yy == y0 ? p0 : px(yy);
+        const int below = (yy + 2 < h) ? px(yy + 2) : 0;                // original row yy+2
+        int o = p;
+        if (bright(yy)) {
+            if (p >= white) o = (yy > 2) ? ((yy < h - 2) ? (above + below) / 2 : above) : below;
+            else o = d2u16(scaled(p));
         } else if (p < shadow) {                                        // dark row in deep shadow
             double v;
-            if (y > 2) v = (y < h - 2) ? (above + scaled(below)) / 2 : (double)above;
+            if (yy > 2) v = (yy < h - 2) ? (above + scaled(below)) / 2 : (double)above;
             else v = scaled(below);
-            out = d2u16(v);
+            o = d2u16(v);
         }
-        out &= 0xFFFF;
-        done_m2 = done_m1;
-        done_m1 = out;
-        // the final 14 -> 16 bit shift applies to the first max_size/2 pixels (hdr.c:218-222)
-        img[i] = (uint16_t)(i < shift_count ? (out << 2) : out);
+        o &= 0xFFFF;
+        if (yy == y) { res = o; break; }
+        above = o;
     }
+    // the final 14 -> 16 bit shift applies to the first max_size/2 pixels (hdr.c:218-222)
+    const size_t i = (size_t)y * w + x;
+    out[i] = (uint16_t)(i < shift_count ? (res << 2) : res);
 }
 
 int launch_hdr_row_hist(const void *d_frame, int w, int h, int white, unsigned *d_hist, hipStream_t stream)
@@ -74,17 +92,19 @@ int launch_hdr_row_hist(const void *d_frame, int w, int h, int white, unsigned *
     MLV_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * 4 * (size_t)(white + 1), stream));
     const int rows = (h - 4 - 4 + 4) / 5 + 1;       // generous; the kernel re-checks y < h-4
     if (rows <= 0) return MLVFS_AMD_OK;
-    dim3 grid((w / 4 + 255) / 256 + 1, rows);
-    hipLaunchKernelGGL(k_hdr_row_hist, grid, dim3(256), 0, stream, (const uint16_t *)d_frame, w, h, white, d_hist);
+    const int lds_bins = (size_t)(white + 1) * sizeof(unsigned) <= 64 * 1024 ? white + 1 : 0;        // 14-bit levels fit
+    hipLaunchKernelGGL(k_hdr_row_hist, dim3(rows), dim3(256), (size_t)lds_bins * sizeof(unsigned), stream, (const uint16_t *)d_frame, w, h, white,
+                       d_hist, lds_bins);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
 
-int launch_hdr_preview(void *d_frame, int w, int h, int black, int white, int dark_row_start, int shadow, double a,
+// d_out: a second frame buffer (the rewrite reads rows as they were)
+int launch_hdr_preview(const void *d_frame, void *d_out, int w, int h, int black, int white, int dark_row_start, int shadow, double a,
                        double b, size_t shift_count, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_hdr_preview, dim3((w + 63) / 64), dim3(64), 0, stream, (uint16_t *)d_frame, w, h, black, white,
-                       dark_row_start, shadow, a, b, shift_count);
+    hipLaunchKernelGGL(k_hdr_preview, dim3((w + 255) / 256, h), dim3(256), 0, stream, (const uint16_t *)d_frame, (uint16_t *)d_out, w, h, black,
+                       white, dark_row_start, shadow, a, b, shift_count);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }

@@ -209,6 +209,35 @@ def test_hdr_preview_dropin(gpu, oracle, w, h):
     assert np.array_equal(got, n) and fh.rawi_hdr.raw_info.black_level == BLACK
 
 
+@pytest.mark.parametrize("w,h", [(416, 264), (258, 131)])
+def test_hdr_preview_chains_of_rewritten_rows(gpu, oracle, w, h):
+    """hdr.c:178-215 rewrites rows top-down in place: a clipped bright pixel and a dark pixel in deep shadow take the REWRITTEN row
+    two above.  Columns where such pixels follow each other for the whole height (and random mixtures, and the first / last rows)
+    make chains of any length; the per-pixel kernel must follow them like the reference's walk does."""
+    import torch
+    rng = np.random.default_rng(7)
+    f = synth.dual_iso_frame(w, h)
+    bright = (np.arange(h) % 4 >= 2)[:, None] & np.ones((1, w), bool)
+    special = np.where(bright, 16383, BLACK - 40).astype(np.uint16)
+    cols = np.zeros((h, w), bool)
+    cols[:, 10:w:9] = True                                               # whole columns
+    cols[:, 14:w:9] = rng.random((h, len(range(14, w, 9)))) < 0.6        # mixtures: chains of every length
+    cols[:, 17:w:9] = (np.arange(h) % 8 < 6)[:, None]                    # runs of three pairs
+    f = np.where(cols, special, f).astype(np.uint16)
+    ok, want, levels = oracle.hdr_preview(f, BLACK, WHITE)
+    assert ok == 1
+    fh = fh_for(w, h)
+    got = f.copy()
+    assert gpu.hdr_convert_data(C.byref(fh), lib.ptr(got), 0, got.nbytes) == 1
+    assert np.array_equal(got, want), f"{(got != want).sum()} px differ"
+    # the device-resident entry rewrites the caller's buffer
+    geom = lib.Geom(w, h, 14, BLACK, WHITE, 0, 0)
+    t = torch.from_numpy(f.view(np.int16)).cuda()
+    assert gpu.mlvfs_amd_hdr_preview_dev(C.byref(geom), C.c_void_p(t.data_ptr()), t.numel() * 2, None) == 1
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy().view(np.uint16), want)
+
+
 def test_hdr_preview_with_focus_map(gpu, oracle, tmp_path, monkeypatch):
     """hdr.c:104: the preview repairs the camera's focus pixels (dual-ISO rule) on the host frame before it matches the
     exposures -- a drop-in symbol calling another one, in every MLVFS_AMD_RESIDENT mode."""
