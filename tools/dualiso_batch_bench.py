@@ -10,6 +10,7 @@ import torch
 sizes = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,2,4,8,16").split(",")]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 interp = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+cs = int(os.environ.get('DI_BENCH_CS', '0'))                  # chroma smoothing of the conversion: 0, 2, 3, 5
 L = lib.load(); L.mlvfs_amd_init(0)
 w, h = 3584, 1320
 frames = [synth.dual_iso_frame(w, h, seed=3, frame=k) for k in range(2)]
@@ -28,7 +29,7 @@ try:
                 buf[k] = src[k & 1]
             torch.cuda.synchronize()
         def run():
-            rc = L.mlvfs_amd_cr2hdr20_batch_dev(C.byref(geom), C.c_void_p(buf.data_ptr()), w * h * 2, n, interp, 1, 1, 0, lib.ptr(res), sp)
+            rc = L.mlvfs_amd_cr2hdr20_batch_dev(C.byref(geom), C.c_void_p(buf.data_ptr()), w * h * 2, n, interp, 1, 1, cs, lib.ptr(res), sp)
             torch.cuda.synchronize()
             assert rc == 0 and res.sum() == n, (rc, res)
         fill(); run()                                      # buffers, tables
@@ -44,4 +45,4 @@ try:
         if os.environ.get('DI_BENCH_TRIM', '1') == '1': L.mlvfs_amd_dualiso_trim()          # the next size starts from fresh work memory
 finally:
     os.dup2(saved, 1)
-print(json.dumps({"workload": f"{w}x{h} cr2hdr20 interp={interp} fullres alias-map, frames resident in HBM", "batch": out}))
+print(json.dumps({"workload": f"{w}x{h} cr2hdr20 interp={interp} cs={cs} fullres alias-map, frames resident in HBM", "batch": out}))
