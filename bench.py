@@ -698,8 +698,8 @@ def main():
         "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "void mlv::k_frame<5, true, true, false>(mlv::FrameArgs)" if args.cs == 5 else f"void mlv::k_frame<{args.cs}, true, true, false>(mlv::FrameArgs)",
-                     "kernel_template_arguments": "METHOD (chroma smoothing 2 / 3 / 5), PACKED (14-bit stream in), VEC (width % 16 == 0), SPREAD (dark-clip table layout)",
+                     "kernel": "void mlv::k_frame<5, true, 1, false>(mlv::FrameArgs)" if args.cs == 5 else f"void mlv::k_frame<{args.cs}, true, 1, false>(mlv::FrameArgs)",
+                     "kernel_template_arguments": "METHOD (chroma smoothing 2 / 3 / 5), PACKED (14-bit stream in), VEC (1: width % 16 == 0; 2: width % 16 == 8; 0: any width), SPREAD (dark-clip table layout)",
                      "kernel_ms_per_launch": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(F * npx * BYTES_PER_PX)},
         "parity": parity,
     }

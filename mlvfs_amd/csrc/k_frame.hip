@@ -377,6 +377,83 @@ __device__ __forceinline__ void unpack16(const uint32_t (&d)[Words<PACKED>::N], 
     }
 }
 
+// ---- widths that are a multiple of 8 but not of 16 (1736: the 3x crop of most APS-C bodies; 1880: the 5D2).  Rows then start
+// alternately at a 16-pixel group and in the middle of one: a 14-bit group begins 14 bytes into the stream words of the pair it
+// shares (dword-aligned address minus 2), and the row's last group has eight pixels in the frame.  Everything else -- item =
+// 16 pixels x 2 rows, strips of 8 pixels, vector stores -- is the w % 16 == 0 path.  (Until round 3 such widths took the any-geometry
+// path, a load per pixel: cs5x5 9.6 us per 1736x976 frame where 1728 takes 3.5.)
+struct Half8 {                     // where one row of an item comes from
+    uint32_t at;                   // byte offset in the frame of the first dword to load
+    bool mis;                      // packed stream: the group starts in the upper half of that dword
+    bool shift8;                   // the window lies 8 pixels further left than the item (the last row's half group): take pixels 8..15
+};
+// x: a multiple of 16, or beyond the frame; yy: a row of the frame.  whole: all 16 pixels are loaded (of a right halo only the first
+// 12 bytes, which lie inside the frame wherever the group starts)
+template <bool PACKED>
+__device__ __forceinline__ Half8 half8_row(int w, int h, int x, int yy, bool whole)
+{
+    Half8 r;
+    x = x < 0 ? 0 : (x >= w ? w - 16 : x);               // (beyond the frame: any group of the row will do)
+    r.shift8 = whole && (yy == h - 1) && (x == w - 8);   // its 16 pixels would run past the end of the frame
+    if (r.shift8) x -= 8;
+    const uint32_t px = (uint32_t)yy * (uint32_t)w + (uint32_t)x;      // a multiple of 8
+    const uint32_t byte = PACKED ? (px >> 3) * 14u : px * 2u;
+    r.mis = PACKED && (byte & 2u);
+    r.at = PACKED ? (byte & ~3u) : byte;
+    return r;
+}
+// t0 / t1: the 16 stream bits behind the seven dwords of each row (a misaligned group ends there)
+template <bool PACKED, int N_FULL>
+__device__ __forceinline__ void issue_item_half8(uint32_t (&r0)[Words<PACKED>::N], uint32_t (&r1)[Words<PACKED>::N], uint32_t &t0, uint32_t &t1,
+                                                 const uint8_t *frame, int w, int h, int tx0, int ty0, int tid)
+{
+    constexpr int N = Words<PACKED>::N;
+    const bool edge = tid >= N_FULL;
+    const int pr = edge ? tid - N_FULL : tid >> 3;
+    const int y = ty0 - 2 * HC + 2 * pr;
+    const int x_main = edge ? tx0 - 16 : tx0 + 16 * (tid & 7), x_right = tx0 + 2 * TCW;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int yy = clampi(y + rr, 0, h - 1);
+        const Half8 m = half8_row<PACKED>(w, h, x_main, yy, true), r = half8_row<PACKED>(w, h, x_right, yy, false);
+        const uint32_t *sm_ = (const uint32_t *)(frame + m.at);
+        const uint32_t *sr_ = (const uint32_t *)(frame + r.at);
+        uint32_t (&d)[N] = rr ? r1 : r0;
+        // edge items: the right halo's four pixels are the first 56 bits of its group -- dwords 0, 1 and, when the group is
+        // misaligned, the lower half of dword 2 --, the left halo's the last 56 of its own (dwords 5, 6 and the tail)
+#pragma unroll
+        for (int i = 0; i < N; i++) d[i] = ((edge && i < (PACKED ? 3 : 2)) ? sr_ : sm_)[i];
+        if (PACKED) (rr ? t1 : t0) = *(const uint16_t *)((const uint8_t *)sm_ + (m.mis ? 28 : 24));
+    }
+}
+// the seven MSB-first stream words of a group from seven dwords + tail; nxt_sel / own_sel: v_perm selectors of a misaligned / aligned group
+__device__ __forceinline__ uint32_t half8_word(uint32_t d, uint32_t nxt, bool mis)
+{
+    return __builtin_amdgcn_perm(nxt, d, mis ? 0x03020504u : 0x01000302u);      // (d & 0xFFFF0000) | (nxt & 0xFFFF)  :  halves of d swapped
+}
+template <bool PACKED>
+__device__ __forceinline__ void unpack16_half8(const uint32_t (&d)[Words<PACKED>::N], uint32_t tail, bool edge, Half8 m, Half8 r, uint32_t (&px)[16])
+{
+    if constexpr (PACKED) {
+        uint32_t s[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) s[i] = half8_word(d[i], i < 6 ? d[i + 1] : tail, (edge && i < 2) ? r.mis : m.mis);
+        px[0] = px14<0>(s);   px[1] = px14<1>(s);   px[2] = px14<2>(s);   px[3] = px14<3>(s);
+        px[4] = px14<4>(s);   px[5] = px14<5>(s);   px[6] = px14<6>(s);   px[7] = px14<7>(s);
+        px[8] = px14<8>(s);   px[9] = px14<9>(s);   px[10] = px14<10>(s); px[11] = px14<11>(s);
+        px[12] = px14<12>(s); px[13] = px14<13>(s); px[14] = px14<14>(s); px[15] = px14<15>(s);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { px[2 * k] = d[k] & 0xFFFFu; px[2 * k + 1] = d[k] >> 16; }
+    }
+    // the frame's last row: a window that was moved 8 pixels to the left (one item per frame; the left halo never is such a group)
+    const bool sh = m.shift8 && !edge;
+    if (__any(sh)) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) px[k] = sh ? px[k + 8] : px[k];
+    }
+}
+
 // any geometry: one pixel with clamped coordinates
 template <bool PACKED>
 __device__ __forceinline__ uint32_t fetch_clamped(const uint8_t *frame, int w, int h, int x, int y)
@@ -920,7 +997,7 @@ __device__ __forceinline__ void stripe_strip_pk(uint32_t (&top)[STRIP], uint32_t
     }
 }
 
-template <int METHOD, bool PACKED, bool VEC, bool SPREAD>
+template <int METHOD, bool PACKED, int VEC, bool SPREAD>
 __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 {
     using Smem = SmemT<SPREAD, tile_rows_of(METHOD)>;
@@ -965,11 +1042,13 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     const int band_start = grank * gq + min(grank, grem);
     const int band_end = band_start + gq + (grank < grem ? 1 : 0);
     const int black16 = (int)(uint16_t)a.black, white16 = (int)(uint16_t)a.white;
-    constexpr bool vec = VEC;                            // w % 16 == 0: dword/vector loads and stores
+    constexpr bool vec = VEC != 0;                       // w % 16 == 0 (1) or w % 16 == 8 (2): dword/vector loads and stores
+    constexpr bool half8 = VEC == 2;
 
     const mlv_i32x4 rs_e2r = table_rsrc(a.e2r, 2, E2R_ENTRIES);
     constexpr int NW = Words<PACKED>::N;
     uint32_t r0[NW], r1[NW];                             // prefetch registers of this thread's item
+    uint32_t tl0 = 0, tl1 = 0;                           // half8: the stream's 16 bits behind them
     const int tid = threadIdx.x;
     const int item_row = tid >= N_FULL ? tid - N_FULL : tid >> 3, item_g = tid & 7;
 
@@ -1002,7 +1081,8 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     auto issue_tile = [&](int tt) {
         int f, tr, tx0, ty0;
         tile_coords(tt, f, tr, tx0, ty0);
-        issue_item<PACKED, N_FULL>(r0, r1, a.src + (size_t)f * a.src_stride, a.w, a.h, tx0, ty0, load_tid);
+        if (half8) issue_item_half8<PACKED, N_FULL>(r0, r1, tl0, tl1, a.src + (size_t)f * a.src_stride, a.w, a.h, tx0, ty0, load_tid);
+        else issue_item<PACKED, N_FULL>(r0, r1, a.src + (size_t)f * a.src_stride, a.w, a.h, tx0, ty0, load_tid);
     };
     if (vec) issue_tile(min(t, max(total - 1, 0)));
     __syncthreads();                           // T16 copy complete
@@ -1045,7 +1125,13 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         const bool edge = tid_o >= N_FULL;
         if (has_item) {
             uint32_t p0[16], p1[16];
-            if (vec) { unpack16<PACKED>(r0, p0); unpack16<PACKED>(r1, p1); }
+            if (half8) {
+                const int iy = ty0 - 2 * HC + 2 * item_row;
+                const int x_main = edge ? tx0 - 16 : tx0 + 16 * item_g, x_right = tx0 + 2 * TCW;
+                const int y0c = clampi(iy, 0, a.h - 1), y1c = clampi(iy + 1, 0, a.h - 1);
+                unpack16_half8<PACKED>(r0, tl0, edge, half8_row<PACKED>(a.w, a.h, x_main, y0c, true), half8_row<PACKED>(a.w, a.h, x_right, y0c, false), p0);
+                unpack16_half8<PACKED>(r1, tl1, edge, half8_row<PACKED>(a.w, a.h, x_main, y1c, true), half8_row<PACKED>(a.w, a.h, x_right, y1c, false), p1);
+            } else if (vec) { unpack16<PACKED>(r0, p0); unpack16<PACKED>(r1, p1); }
             else fetch_rows<PACKED>(frame, a.w, a.h, tx0 + 16 * item_g, ty0 - 2 * HC + 2 * item_row, edge, tx0, p0, p1);
             // Pixels at or below black (ev = INT_MIN / 0) or beyond the table need the fix-ups of cell_pair_ev: decided once
             // per item from the extremes of its 32 pixels (three-input min/max), wave-uniformly.
@@ -1393,7 +1479,7 @@ static int e2r_table(const Device *dev, int black, const uint16_t **out, hipStre
     return MLVFS_AMD_OK;
 }
 
-template <int METHOD, bool PACKED, bool VEC, bool SPREAD>
+template <int METHOD, bool PACKED, int VEC, bool SPREAD>
 static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
 {
     const long long total = (long long)a_in.tiles_x * a_in.tiles_y * a_in.nframes;
@@ -1485,14 +1571,18 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
         if (a.coef[i] - 65536 <= -32768 || a.coef[i] - 65536 >= 32768) a.coef_fast = 0;
     }
     a.coef_pk = a.coef_fast && packed && (int)(uint16_t)g.white > (int)(uint16_t)g.black + 64 && g.black >= 0 && g.black <= 16384;
-    // vector path: rows are whole 16-pixel groups and every row starts 16-byte aligned
-    const bool vec = (g.w % 16) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 &&
-                     (nframes == 1 || (src_stride % 16 == 0 && dst_stride % 16 == 0));
+    // vector path: rows are whole 16-pixel groups and every row starts 16-byte aligned (1), or rows of whole 8-pixel half groups (2)
+    static const bool no_half8 = [] { const char *e = getenv("MLVFS_AMD_KF_HALF8"); return e && atoi(e) == 0; }();      // (A/B: the any-geometry path instead)
+    const bool strides_ok = nframes == 1 || (src_stride % 16 == 0 && dst_stride % 16 == 0);
+    const int vec = ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 && strides_ok
+                        ? ((g.w % 16) == 0 ? 1 : ((g.w % 16) == 8 && g.w >= 24 && !no_half8 ? 2 : 0)) : 0;
 #define MLV_DISPATCH_S(M, S)                                                                              \
-    return packed ? (vec ? launch_frame_t<M, true, true, S>(a, dev->num_cu, stream)                       \
-                         : launch_frame_t<M, true, false, S>(a, dev->num_cu, stream))                     \
-                  : (vec ? launch_frame_t<M, false, true, S>(a, dev->num_cu, stream)                      \
-                         : launch_frame_t<M, false, false, S>(a, dev->num_cu, stream))
+    return packed ? (vec == 1 ? launch_frame_t<M, true, 1, S>(a, dev->num_cu, stream)                     \
+                   : vec == 2 ? launch_frame_t<M, true, 2, S>(a, dev->num_cu, stream)                     \
+                              : launch_frame_t<M, true, 0, S>(a, dev->num_cu, stream))                    \
+                  : (vec == 1 ? launch_frame_t<M, false, 1, S>(a, dev->num_cu, stream)                    \
+                   : vec == 2 ? launch_frame_t<M, false, 2, S>(a, dev->num_cu, stream)                    \
+                              : launch_frame_t<M, false, 0, S>(a, dev->num_cu, stream))
 #define MLV_DISPATCH(M)                                                                                   \
     if (spread && M != 0) { MLV_DISPATCH_S(M, true); }                                                    \
     MLV_DISPATCH_S(M, false)

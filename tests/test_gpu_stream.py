@@ -68,6 +68,30 @@ def test_fused_pipeline_matches_oracle(torch_cuda, oracle, w, h, cs, bad, stripe
     s.close()
 
 
+@pytest.mark.parametrize("w,h", [(136, 62), (392, 58), (264, 88), (152, 46), (1736, 64), (1880, 34)])
+@pytest.mark.parametrize("cs", [0, 2, 3, 5])
+def test_fused_pipeline_rows_of_half_groups(torch_cuda, oracle, w, h, cs):
+    """Widths that are a multiple of 8 but not of 16 (1736, 1880: real crop modes): every other row starts in the middle of a
+    16-pixel group of the 14-bit stream, the last group of a row has eight pixels in the frame, and where w = 128 k + 8 that
+    half group is also a tile's right halo -- on the frame's last row the one place where a 16-pixel read would leave the frame.
+    Packed and 16-bit input, heights that end inside a tile, frames with pixels at black."""
+    from mlvfs_amd.stream import to_numpy_u16
+    assert w % 16 == 8
+    for kind in ("normal", "low_light"):
+        gen = getattr(synth, kind + "_frame")
+        frames = [gen(w, h, seed=5 + k) if kind == "low_light" else gen(w, h, frame=k) for k in range(3)]
+        want, pixels, corr = oracle_clip(oracle, frames, w, h, cs, 1, 1)
+        s = make_stream(w, h)
+        packed = s.upload_packed([synth.pack_bits(f) for f in frames])
+        s.analyse_first_frame(packed, cs=cs, bad_pix=1, stripes=True, rand_mode=1)
+        got = to_numpy_u16(s.process(packed, cs=cs, fix_pixels=True, stripes=True))
+        got16 = to_numpy_u16(s.process_unpacked(s.unpack(packed), cs=cs, fix_pixels=True, stripes=True))
+        for k in range(3):
+            assert np.array_equal(got[k], want[k]), f"{kind} frame {k}: {(got[k] != want[k]).sum()} px differ"
+            assert np.array_equal(got16[k], want[k]), f"{kind} frame {k}, 16-bit input: {(got16[k] != want[k]).sum()} px differ"
+        s.close()
+
+
 def test_fused_adversarial(torch_cuda, oracle):
     """INT_MIN-heavy frame (40 % of pixels at black+-4) with thousands of bad pixels:
     exercises wrap-around EV arithmetic and multi-level ordered repair."""

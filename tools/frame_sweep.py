@@ -44,7 +44,10 @@ try:
                 img = o.stripes_apply(img, synth.BLACK, synth.WHITE, *corr)
             if not np.array_equal(got[k].reshape(h, w), img):
                 ok = False
-                sys.stderr.write(f"MISMATCH w={w} h={h} cs={cs} badpix={badpix} st={st} kind={kind} frame={k} ndiff={(got[k].reshape(h, w) != img).sum()}\n")
+                g2 = got[k].reshape(h, w)
+                ys, xs = np.nonzero(g2 != img)
+                where = ", ".join(f"({x},{y}): {g2[y, x]} want {img[y, x]}" for y, x in list(zip(ys, xs))[:6])
+                sys.stderr.write(f"MISMATCH w={w} h={h} cs={cs} badpix={badpix} st={st} kind={kind} frame={k} ndiff={len(ys)}  {where}\n")
         s.close()
         n += 1; bad += (not ok)
 finally:

@@ -8,7 +8,8 @@ import torch
 from mlvfs_amd import lib, synth
 from mlvfs_amd.stream import ClipStream
 
-W, H, F = 3584, 1320, int(os.environ.get("KB_FRAMES", "50"))
+W, H = (int(v) for v in os.environ.get("KB_SIZE", "3584x1320").split("x"))          # KB_SIZE=1736x976: a width that is no multiple of 16 (VEC = 0)
+F = int(os.environ.get("KB_FRAMES", "50"))
 s = ClipStream(W, H)
 L = s.L
 base = s.synth_packed(8, seed=1)

@@ -12,7 +12,7 @@ for ln in sys.stdin:
     m = re.search(r"remark:\s+([A-Za-z /\[\]]+): (\d+)", ln)
     if m and cur: rows[cur][m.group(1).strip()] = int(m.group(2))
 for k, v in rows.items():
-    t = re.search(r"k_frameILi(\d)ELb(\d)ELb(\d)ELb(\d)", k)
+    t = re.search(r"k_frameILi(\d)ELb(\d)ELi(\d)ELb(\d)", k)
     if not t: continue
     print("k_frame<%s,%s,%s,%s>" % t.groups(), "VGPRs", v.get("VGPRs"), "SGPR spill", v.get("SGPRs Spill"), "VGPR spill", v.get("VGPRs Spill"), "occ", v.get("Occupancy [waves/SIMD]"))
 '
