@@ -5,9 +5,9 @@
 // bit stream stored as little-endian 16-bit words.
 //
 // HBM-bound: 14/8 B read + 2 B written per pixel = 3.75 B/px.
-//   k_unpack14 : one lane = 16 pixels = 7 coalesced dword loads (28 B, always
-//                4-byte aligned because 16 px * 14 bit = 224 bit) and two
-//                128-bit stores.  Frames are batched in grid.y.
+//   k_unpack_x16<14 | 12 | 10> : one lane = 16 pixels = 7 / 6 / 5 coalesced dword loads
+//                (always 4-byte aligned: 16 px * bpp bits) and two 128-bit stores.
+//                Frames are batched in grid.y.
 //   k_unpack_generic : any bpp in 1..16, any length; one lane = one pixel.
 #include "clip.h"
 
@@ -17,31 +17,37 @@ namespace mlv {
 // MSB-first order.
 __device__ __forceinline__ uint32_t stream_word(uint32_t le_dword) { return (le_dword << 16) | (le_dword >> 16); }
 
-// 16 pixels of 14 bits from seven MSB-first 32-bit stream words
-__device__ __forceinline__ void unpack14x16(const uint32_t (&s)[7], uint32_t (&px)[16])
+// 16 pixels of BPP bits (BPP even) from BPP / 2 MSB-first 32-bit stream words
+template <int BPP>
+__device__ __forceinline__ void unpack_x16(const uint32_t (&s)[BPP / 2], uint32_t (&px)[16])
 {
+    constexpr uint32_t mask = (1u << BPP) - 1u;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const int bit = 14 * k, wi = bit >> 5, sh = bit & 31;
-        if (sh + 14 <= 32) {
-            px[k] = (s[wi] >> (32 - 14 - sh)) & 0x3FFFu;
+        const int bit = BPP * k, wi = bit >> 5, sh = bit & 31;
+        if (sh + BPP <= 32) {
+            px[k] = (s[wi] >> (32 - BPP - sh)) & mask;
         } else {
             const uint64_t two = ((uint64_t)s[wi] << 32) | s[wi + 1];
-            px[k] = (uint32_t)(two >> (64 - 14 - sh)) & 0x3FFFu;
+            px[k] = (uint32_t)(two >> (64 - BPP - sh)) & mask;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_unpack14(const uint8_t *__restrict__ packed, size_t packed_stride,
-                                                  uint8_t *__restrict__ out, size_t out_stride, uint32_t groups)
+// one lane = 16 pixels = BPP / 2 coalesced dword loads (always 4-byte aligned: 16 px * BPP bits) and two 128-bit stores:
+// 14 bits, and the reduced depths of ML's raw video (12, 10), which took the pixel-per-lane kernel until the end of round 3
+template <int BPP>
+__global__ __launch_bounds__(256) void k_unpack_x16(const uint8_t *__restrict__ packed, size_t packed_stride,
+                                                    uint8_t *__restrict__ out, size_t out_stride, uint32_t groups)
 {
+    constexpr int NW = BPP / 2;
     const uint32_t *src = (const uint32_t *)(packed + (size_t)blockIdx.y * packed_stride);
     uint4 *dst = (uint4 *)(out + (size_t)blockIdx.y * out_stride);
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += gridDim.x * blockDim.x) {
-        uint32_t s[7], px[16];
+        uint32_t s[NW], px[16];
 #pragma unroll
-        for (int i = 0; i < 7; i++) s[i] = stream_word(src[(size_t)g * 7 + i]);
-        unpack14x16(s, px);
+        for (int i = 0; i < NW; i++) s[i] = stream_word(src[(size_t)g * NW + i]);
+        unpack_x16<BPP>(s, px);
         uint4 lo, hi;
         lo.x = px[0] | (px[1] << 16);   lo.y = px[2] | (px[3] << 16);
         lo.z = px[4] | (px[5] << 16);   lo.w = px[6] | (px[7] << 16);
@@ -74,14 +80,14 @@ int launch_unpack(const void *d_packed, size_t packed_stride, void *d_out, size_
 {
     if (npix == 0 || nframes <= 0) return MLVFS_AMD_OK;
     if (bpp < 1 || bpp > 16) { set_error("unsupported bits_per_pixel %d", bpp); return MLVFS_AMD_ERR_ARG; }
-    const bool fast = bpp == 14 && first_px == 0 && npix % 16 == 0 && ((uintptr_t)d_packed % 4 == 0) &&
+    const bool fast = (bpp == 14 || bpp == 12 || bpp == 10) && first_px == 0 && npix % 16 == 0 && ((uintptr_t)d_packed % 4 == 0) &&
                       ((uintptr_t)d_out % 16 == 0) && (nframes == 1 || (packed_stride % 4 == 0 && out_stride % 16 == 0));
     if (fast) {
         const uint32_t groups = npix / 16;
         dim3 grid((groups + 255) / 256, nframes);
         if (grid.x > 8192) grid.x = 8192;
-        hipLaunchKernelGGL(k_unpack14, grid, dim3(256), 0, stream, (const uint8_t *)d_packed, packed_stride,
-                           (uint8_t *)d_out, out_stride, groups);
+        auto kern = bpp == 14 ? k_unpack_x16<14> : (bpp == 12 ? k_unpack_x16<12> : k_unpack_x16<10>);
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, (const uint8_t *)d_packed, packed_stride, (uint8_t *)d_out, out_stride, groups);
     } else {
         dim3 grid((npix + 255) / 256, nframes);
         if (grid.x > 16384) grid.x = 16384;
