@@ -597,8 +597,14 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
                 MLV_HIP(hipEventCreateWithFlags(&hf.amaze_a, hipEventDisableTiming));
                 MLV_HIP(hipEventCreateWithFlags(&hf.join, hipEventDisableTiming));
             }
-            static const int part = [] { const char *e = getenv("MLVFS_AMD_DI_PART"); const int v = e ? atoi(e) : 4; return v > 0 ? v : 4; }();
-            const int nparts = nframes / part > 2 ? nframes / part : 2;
+            // frames per part: enough complete AMaZE tiles for about four rounds of k_amaze_rows' 256 workgroups (3584x1320: 282 per
+            // frame -> 4 frames; 1736x976: 84 -> 13, a batch of 8 stays whole -- in parts of 4 it took 4.4 instead of 3.9 ms)
+            static const int part_env = [] { const char *e = getenv("MLVFS_AMD_DI_PART"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+            int nfx = 0, nfy = 0;
+            amaze_rows_extent(w, H, &nfx, &nfy);
+            const int per_frame = nfx * nfy > 0 ? nfx * nfy : 1;
+            const int part = part_env ? part_env : std::max(4, (1024 + per_frame - 1) / per_frame);
+            const int nparts = nframes / part > 1 ? nframes / part : 1;
             MLV_HIP(hipEventRecord(hf.fork, stream));
             MLV_HIP(hipStreamWaitEvent(hf.st, hf.fork, 0));
             for (int k = 0; k < nparts; k++) {

@@ -12,7 +12,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 interp = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 cs = int(os.environ.get('DI_BENCH_CS', '0'))                  # chroma smoothing of the conversion: 0, 2, 3, 5
 L = lib.load(); L.mlvfs_amd_init(0)
-w, h = 3584, 1320
+w, h = (int(v) for v in os.environ.get('DI_BENCH_SIZE', '3584x1320').split('x'))
 frames = [synth.dual_iso_frame(w, h, seed=3, frame=k) for k in range(2)]
 src = [torch.from_numpy(f.view(np.int16)).cuda() for f in frames]
 geom = lib.Geom(w, h, 14, synth.BLACK, synth.WHITE, 0, 0)
