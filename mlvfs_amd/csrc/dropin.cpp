@@ -78,7 +78,7 @@ Clip *make_clip(const FrameView &v, ThreadCtx *c)
 // load_chunks / close_chunks directly and reads the frame right after get_image_data (gif.c:164) -- it never sees a deferred unpack.
 // (Round 2 selected this behaviour process-wide with MLVFS_AMD_RESIDENT=2, which was wrong for exactly that caller; the value is
 // now read as 1.)  MLVFS_AMD_DEFER=0 in the environment makes the bracket calls do nothing.
-enum { RANK_UNPACK = 0, RANK_FOCUS = 1, RANK_BAD = 2, RANK_CS = 3, RANK_STRIPES_READ = 4, RANK_STRIPES = 5 };
+enum { RANK_UNPACK = 0, RANK_PNOISE = 1, RANK_FOCUS = 2, RANK_BAD = 3, RANK_CS = 4, RANK_STRIPES_READ = 5, RANK_STRIPES = 6 };      // process_frame's order (main.c:942-997)
 
 thread_local bool t_bracket = false;               // this thread is between mlvfs_amd_frame_begin and mlvfs_amd_frame_end
 
@@ -325,6 +325,22 @@ std::vector<FocusMap *> g_focus_maps;
 std::mutex g_focus_mutex;
 
 }  // namespace
+
+// fix_pattern_noise (patternnoise.cpp) as a stage like the others: it comes right behind the unpack in process_frame's order and
+// works in place on the 16-bit frame -- on the copy the unpack left on the device when there is one (inside a frame bracket
+// nothing crosses the link for it; rounds 1-3 downloaded the unpacked frame, uploaded it again and downloaded the result)
+int mlv::pnoise_stage_begin(ThreadCtx *c, void *host, size_t bytes, void **d_frame, int *which, bool *was_dirty)
+{
+    const int rc = stage_frame(c, host, bytes, RANK_PNOISE, d_frame, nullptr);
+    *which = c->res_cur;
+    *was_dirty = c->res_dirty;
+    return rc;
+}
+void mlv::pnoise_stage_end(ThreadCtx *c, void *host, size_t bytes, int which, bool was_dirty, bool done)
+{
+    if (!done) abandon_stage(c, host, bytes, which, was_dirty);
+    else if (finish_frame(c, host, bytes, RANK_PNOISE, which)) abandon_stage(c, host, bytes, which, false);
+}
 
 int mlv::drop_resident(ThreadCtx *c, void *host)
 {

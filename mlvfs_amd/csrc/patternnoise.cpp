@@ -1,6 +1,6 @@
 // patternnoise.cpp -- drop-in fix_pattern_noise (mlvfs/patternnoise.c:357-380) on
-// top of the kernels of k_pnoise.hip: stage the int16 frame, run the column pass and
-// the row pass (transposed), copy back.  Only debug_flags == 0 (what MLVFS passes,
+// top of the kernels of k_pnoise.hip: the int16 frame on the device -- the copy the unpack left there, or an upload --,
+// the column pass and the row pass (transposed) in place, back to the host unless a frame bracket is open (dropin.cpp).  Only debug_flags == 0 (what MLVFS passes,
 // main.c:948) is supported; the reference's debug views are not reproduced.
 #include "clip.h"
 
@@ -19,12 +19,12 @@ extern "C" void fix_pattern_noise(int16_t *raw, int w, int h, int white, int deb
     if (w < 2 || h < 2 || (w & 1) || (h & 1)) { set_error("fix_pattern_noise: %dx%d frame not supported", w, h); return; }
     ThreadCtx *c = thread_ctx();
     if (!c) return;
-    if (drop_resident(c, raw)) return;             // this call rewrites the host frame: no resident copy of it (dropin.cpp)
     const size_t bytes = (size_t)w * h * 2;
-    if (c->ensure(bytes, pattern_noise_scratch_bytes(w, h))) return;
-    if (hipMemcpyAsync(c->d_a, raw, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { set_error("fix_pattern_noise: upload failed"); return; }
-    if (launch_pattern_noise(c->d_a, w, h, white, c->d_b, c->stream)) return;
-    if (hipMemcpyAsync(raw, c->d_a, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess)
-        set_error("fix_pattern_noise: download failed");
+    void *d_frame = nullptr;
+    int which = 0;
+    bool was_dirty = false;
+    if (pnoise_stage_begin(c, raw, bytes, &d_frame, &which, &was_dirty)) return;       // the unpack's device copy, or an upload
+    const bool done = c->ensure(0, pattern_noise_scratch_bytes(w, h)) == MLVFS_AMD_OK &&
+                      launch_pattern_noise(d_frame, w, h, white, c->d_b, c->stream) == MLVFS_AMD_OK;
+    pnoise_stage_end(c, raw, bytes, which, was_dirty, done);                              // downloads unless a frame bracket is open
 }

@@ -185,8 +185,9 @@ def test_bracket_is_per_thread_and_disabled_by_environment(gpu, oracle):
 
 
 def test_bracketed_result_is_fetched_by_symbols_that_read_the_host_frame(gpu, oracle):
-    """A stage called out of process_frame's order, and the symbols that stage the host frame themselves (pattern noise here),
-    first bring the host buffer up to date."""
+    """A stage called out of process_frame's order and the symbols that read the host frame themselves first bring the host buffer
+    up to date.  Pattern noise is a stage of the sequence (right behind the unpack, main.c:946-949): inside a bracket it works on the
+    device copy and its result stays there like any other stage's."""
     w, h = 416, 264
     f = synth.normal_frame(w, h)
     fh = abi.make_frame_headers(w, h, black=BLACK, white=WHITE)
@@ -194,9 +195,11 @@ def test_bracketed_result_is_fetched_by_symbols_that_read_the_host_frame(gpu, or
     gpu.mlvfs_amd_frame_begin()
     _unpack_into(gpu, fh, f, img)
     gpu.fix_pattern_noise(lib.ptr(img), w, h, WHITE, 0)                  # main.c:946-949: right after the unpack
+    assert (img == 0xABCD).all()                                         # nothing has crossed the link for it
     want = oracle.fix_pattern_noise(f, WHITE)
+    assert gpu.mlvfs_amd_frame_sync(lib.ptr(img)) == 0
     assert np.array_equal(img, want)
-    gpu.chroma_smooth(C.byref(fh), lib.ptr(img), 3)                      # uploads (nothing resident), result deferred
+    gpu.chroma_smooth(C.byref(fh), lib.ptr(img), 3)                      # takes up the device copy, result deferred
     gpu.chroma_smooth(C.byref(fh), lib.ptr(img), 2)                      # not "the next stage": fetched, uploaded again
     assert gpu.mlvfs_amd_frame_end() == 0
     assert np.array_equal(img, oracle.chroma_smooth(oracle.chroma_smooth(want, BLACK, 3), BLACK, 2))
