@@ -126,9 +126,11 @@ int flush_pending(ThreadCtx *c);
 // a symbol that reads or rewrites the host frame itself: bring the host copy up to date if a deferred result of this thread is
 // pending for it (frame bracket), then forget the resident copy (dropin.cpp)
 int drop_resident(ThreadCtx *c, void *host);
-// fix_pattern_noise as a stage of the drop-in sequence (dropin.cpp): the device frame to work on in place, then what became of it
-int pnoise_stage_begin(ThreadCtx *c, void *host, size_t bytes, void **d_frame, int *which, bool *was_dirty);
-void pnoise_stage_end(ThreadCtx *c, void *host, size_t bytes, int which, bool was_dirty, bool done);
+// the in-place stages that live outside dropin.cpp as stages of the drop-in sequence: the device frame to work on, then what
+// became of it (dropin.cpp)
+enum InplaceStage { STAGE_DUALISO, STAGE_PNOISE };
+int inplace_stage_begin(ThreadCtx *c, InplaceStage st, void *host, size_t bytes, void **d_frame, int *which, bool *was_dirty);
+void inplace_stage_end(ThreadCtx *c, InplaceStage st, void *host, size_t bytes, int which, bool was_dirty, bool done, bool changed);
 
 int bind_device(int device);
 

@@ -78,7 +78,7 @@ Clip *make_clip(const FrameView &v, ThreadCtx *c)
 // load_chunks / close_chunks directly and reads the frame right after get_image_data (gif.c:164) -- it never sees a deferred unpack.
 // (Round 2 selected this behaviour process-wide with MLVFS_AMD_RESIDENT=2, which was wrong for exactly that caller; the value is
 // now read as 1.)  MLVFS_AMD_DEFER=0 in the environment makes the bracket calls do nothing.
-enum { RANK_UNPACK = 0, RANK_PNOISE = 1, RANK_FOCUS = 2, RANK_BAD = 3, RANK_CS = 4, RANK_STRIPES_READ = 5, RANK_STRIPES = 6 };      // process_frame's order (main.c:942-997)
+enum { RANK_UNPACK = 0, RANK_DUALISO = 1, RANK_PNOISE = 2, RANK_FOCUS = 3, RANK_BAD = 4, RANK_CS = 5, RANK_STRIPES_READ = 6, RANK_STRIPES = 7 };      // process_frame's order (main.c:942-997)
 
 thread_local bool t_bracket = false;               // this thread is between mlvfs_amd_frame_begin and mlvfs_amd_frame_end
 
@@ -326,20 +326,22 @@ std::mutex g_focus_mutex;
 
 }  // namespace
 
-// fix_pattern_noise (patternnoise.cpp) as a stage like the others: it comes right behind the unpack in process_frame's order and
-// works in place on the 16-bit frame -- on the copy the unpack left on the device when there is one (inside a frame bracket
-// nothing crosses the link for it; rounds 1-3 downloaded the unpacked frame, uploaded it again and downloaded the result)
-int mlv::pnoise_stage_begin(ThreadCtx *c, void *host, size_t bytes, void **d_frame, int *which, bool *was_dirty)
+// The full dual-ISO conversion (dualiso.cpp) and fix_pattern_noise (patternnoise.cpp) as stages like the others: they come right
+// behind the unpack in process_frame's order and work in place on the 16-bit frame -- on the copy the unpack left on the device
+// when there is one (inside a frame bracket nothing crosses the link for them; until the end of round 3 they downloaded the
+// unpacked frame, uploaded it again and downloaded their result).  changed = false: the stage left the frame as it was.
+int mlv::inplace_stage_begin(ThreadCtx *c, InplaceStage st, void *host, size_t bytes, void **d_frame, int *which, bool *was_dirty)
 {
-    const int rc = stage_frame(c, host, bytes, RANK_PNOISE, d_frame, nullptr);
+    const int rc = stage_frame(c, host, bytes, st == STAGE_DUALISO ? RANK_DUALISO : RANK_PNOISE, d_frame, nullptr);
     *which = c->res_cur;
     *was_dirty = c->res_dirty;
     return rc;
 }
-void mlv::pnoise_stage_end(ThreadCtx *c, void *host, size_t bytes, int which, bool was_dirty, bool done)
+void mlv::inplace_stage_end(ThreadCtx *c, InplaceStage st, void *host, size_t bytes, int which, bool was_dirty, bool done, bool changed)
 {
     if (!done) abandon_stage(c, host, bytes, which, was_dirty);
-    else if (finish_frame(c, host, bytes, RANK_PNOISE, which)) abandon_stage(c, host, bytes, which, false);
+    else if (finish_frame(c, host, bytes, st == STAGE_DUALISO ? RANK_DUALISO : RANK_PNOISE, which, changed ? -1 : 0))
+        abandon_stage(c, host, bytes, which, false);
 }
 
 int mlv::drop_resident(ThreadCtx *c, void *host)

@@ -674,21 +674,19 @@ int cr2hdr20_convert_data(struct frame_headers *fh, uint16_t *image_data, int in
     const int w = fh->rawi_hdr.xRes, h = fh->rawi_hdr.yRes;
     ThreadCtx *c = thread_ctx();
     if (!c) return 0;
-    if (drop_resident(c, image_data)) return 0;             // this call rewrites the host frame: no resident copy of it (dropin.cpp)
+    // a stage of the drop-in sequence, right behind the unpack (dropin.cpp): on the device copy the unpack left, or on an upload;
+    // inside a frame bracket the result stays on the device
     const size_t bytes = (size_t)w * h * 2;
-    if (c->ensure(bytes, 0)) return 0;
-    if (hipMemcpyAsync(c->d_a, image_data, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { set_error("cr2hdr20: upload failed"); return 0; }
+    void *d_frame = nullptr;
+    int which = 0;
+    bool was_dirty = false;
+    if (inplace_stage_begin(c, STAGE_DUALISO, image_data, bytes, &d_frame, &which, &was_dirty)) return 0;
     bool touched = false;
-    const int r = cr2hdr20_device(c, fh, c->d_a, w, h, fh->rawi_hdr.raw_info.black_level, fh->rawi_hdr.raw_info.white_level,
+    const int r = cr2hdr20_device(c, fh, d_frame, w, h, fh->rawi_hdr.raw_info.black_level, fh->rawi_hdr.raw_info.white_level,
                                   interp_method, fullres, use_alias_map, chroma_smooth, fix_bad_pixels_mode, c->stream, &touched);
-    if (r != 1) {
-        // not converted: the frame only carries the pixel repairs the reference would have made by now
-        if (touched) (void)hipMemcpyAsync(image_data, c->d_a, bytes, hipMemcpyDeviceToHost, c->stream);
-        (void)hipStreamSynchronize(c->stream);
-        return 0;
-    }
-    if (hipMemcpyAsync(image_data, c->d_a, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess) { set_error("cr2hdr20: download failed"); return 0; }
+    // not converted: the frame only carries the pixel repairs the reference would have made by now
+    inplace_stage_end(c, STAGE_DUALISO, image_data, bytes, which, was_dirty, true, r == 1 || touched);
+    if (r != 1) return 0;
     fh->rawi_hdr.raw_info.black_level *= 4;                            // hdr.c:1951-1952
     fh->rawi_hdr.raw_info.white_level *= 4;
     return 1;

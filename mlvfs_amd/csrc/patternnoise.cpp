@@ -23,8 +23,8 @@ extern "C" void fix_pattern_noise(int16_t *raw, int w, int h, int white, int deb
     void *d_frame = nullptr;
     int which = 0;
     bool was_dirty = false;
-    if (pnoise_stage_begin(c, raw, bytes, &d_frame, &which, &was_dirty)) return;       // the unpack's device copy, or an upload
+    if (inplace_stage_begin(c, STAGE_PNOISE, raw, bytes, &d_frame, &which, &was_dirty)) return;       // the unpack's device copy, or an upload
     const bool done = c->ensure(0, pattern_noise_scratch_bytes(w, h)) == MLVFS_AMD_OK &&
                       launch_pattern_noise(d_frame, w, h, white, c->d_b, c->stream) == MLVFS_AMD_OK;
-    pnoise_stage_end(c, raw, bytes, which, was_dirty, done);                              // downloads unless a frame bracket is open
+    inplace_stage_end(c, STAGE_PNOISE, raw, bytes, which, was_dirty, done, true);                              // downloads unless a frame bracket is open
 }
