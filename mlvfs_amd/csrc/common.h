@@ -129,7 +129,7 @@ int drop_resident(ThreadCtx *c, void *host);
 // the in-place stages that live outside dropin.cpp as stages of the drop-in sequence: the device frame to work on, then what
 // became of it (dropin.cpp)
 enum InplaceStage { STAGE_DUALISO, STAGE_PNOISE };
-int inplace_stage_begin(ThreadCtx *c, InplaceStage st, void *host, size_t bytes, void **d_frame, int *which, bool *was_dirty);
+int inplace_stage_begin(ThreadCtx *c, InplaceStage st, void *host, size_t bytes, void **d_frame, int *which, bool *was_dirty, void **d_other = nullptr);
 void inplace_stage_end(ThreadCtx *c, InplaceStage st, void *host, size_t bytes, int which, bool was_dirty, bool done, bool changed);
 
 int bind_device(int device);

@@ -329,10 +329,11 @@ std::mutex g_focus_mutex;
 // The full dual-ISO conversion (dualiso.cpp) and fix_pattern_noise (patternnoise.cpp) as stages like the others: they come right
 // behind the unpack in process_frame's order and work in place on the 16-bit frame -- on the copy the unpack left on the device
 // when there is one (inside a frame bracket nothing crosses the link for them; until the end of round 3 they downloaded the
-// unpacked frame, uploaded it again and downloaded their result).  changed = false: the stage left the frame as it was.
-int mlv::inplace_stage_begin(ThreadCtx *c, InplaceStage st, void *host, size_t bytes, void **d_frame, int *which, bool *was_dirty)
+// unpacked frame, uploaded it again and downloaded their result).  d_other: the second frame buffer, for a stage that works out of
+// place (it then ends with `which ^ 1`).  changed = false: the stage left the frame as it was.
+int mlv::inplace_stage_begin(ThreadCtx *c, InplaceStage st, void *host, size_t bytes, void **d_frame, int *which, bool *was_dirty, void **d_other)
 {
-    const int rc = stage_frame(c, host, bytes, st == STAGE_DUALISO ? RANK_DUALISO : RANK_PNOISE, d_frame, nullptr);
+    const int rc = stage_frame(c, host, bytes, st == STAGE_DUALISO ? RANK_DUALISO : RANK_PNOISE, d_frame, d_other);
     *which = c->res_cur;
     *was_dirty = c->res_dirty;
     return rc;

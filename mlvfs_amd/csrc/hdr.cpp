@@ -138,32 +138,24 @@ int hdr_convert_data(struct frame_headers *fh, uint16_t *image_data, off_t offse
                   fh->rawi_hdr.raw_info.white_level };
     ThreadCtx *c = thread_ctx();
     if (!c) return 0;
-    if (drop_resident(c, image_data)) return 0;             // this call rewrites the host frame: no resident copy of it (dropin.cpp)
+    // a stage of the drop-in sequence, right behind the unpack (dropin.cpp): it reads the device copy the unpack left (or an upload)
+    // and writes the other frame buffer; inside a frame bracket the result stays on the device
     const size_t bytes = (size_t)w * h * 2;
     const size_t hist_bytes = 4 * (size_t)((uint16_t)g.white + 1) * sizeof(unsigned);
-    const size_t out_at = (hist_bytes + 255) & ~(size_t)255;                // the converted frame follows the histograms in d_b
-    if (c->ensure(bytes, out_at + bytes)) return 0;
-    if (hipMemcpyAsync(c->d_a, image_data, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return 0;
-
-    struct Pre { struct frame_headers *fh; uint16_t *img; ThreadCtx *c; size_t bytes; } pre{ fh, image_data, c, bytes };
-    auto focus = [](void *p) -> int {
-        Pre *q = (Pre *)p;
-        // hdr.c:104: focus pixels are repaired (horizontal interpolation) on the host frame
-        // before the exposure matching; re-stage the frame only if something changed it
-        std::vector<uint16_t> before(q->img, q->img + q->bytes / 2);
-        fix_focus_pixels(q->fh, q->img, 1);
-        if (mlvfs_amd_frame_sync(q->img)) return MLVFS_AMD_ERR_HIP;       // (frame bracket: the repair is wanted on the host now)
-        if (memcmp(before.data(), q->img, q->bytes) != 0)
-            MLV_HIP(hipMemcpyAsync(q->c->d_a, q->img, q->bytes, hipMemcpyHostToDevice, q->c->stream));
-        return MLVFS_AMD_OK;
-    };
-    const int r = hdr_preview_device(g, c->d_a, (uint8_t *)c->d_b + out_at, max_size, (unsigned *)c->d_b, c->stream, focus, &pre);
-    if (r != 1) return 0;
-    if (hipMemcpyAsync(image_data, (uint8_t *)c->d_b + out_at, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess) {
-        set_error("hdr_convert_data: download failed");
+    void *d_frame = nullptr, *d_out = nullptr;
+    int which = 0;
+    bool was_dirty = false;
+    if (inplace_stage_begin(c, STAGE_DUALISO, image_data, bytes, &d_frame, &which, &was_dirty, &d_out)) return 0;
+    if (c->ensure(0, hist_bytes)) { inplace_stage_end(c, STAGE_DUALISO, image_data, bytes, which, was_dirty, false, false); return 0; }
+    struct Pre { struct frame_headers *fh; ThreadCtx *c; void *d_frame; } pre{ fh, c, d_frame };
+    // hdr.c:104: focus pixels are repaired (dual-ISO rule) before the exposure matching, once the frame is known to be dual ISO
+    auto focus = [](void *p) -> int { Pre *q = (Pre *)p; return focus_pixels_device(q->fh, q->c, q->d_frame, 1, nullptr); };
+    const int r = hdr_preview_device(g, d_frame, d_out, max_size, (unsigned *)c->d_b, c->stream, focus, &pre);
+    if (r != 1) {                                                       // not dual ISO: the frame is what it was
+        inplace_stage_end(c, STAGE_DUALISO, image_data, bytes, which, was_dirty, r == 0, false);
         return 0;
     }
+    inplace_stage_end(c, STAGE_DUALISO, image_data, bytes, which ^ 1, was_dirty, true, true);
     fh->rawi_hdr.raw_info.black_level *= 4;                             // hdr.c:223-224
     fh->rawi_hdr.raw_info.white_level *= 4;
     return 1;
