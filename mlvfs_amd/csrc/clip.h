@@ -149,6 +149,7 @@ int launch_pixfix_for_frame_kernel(bool packed, const void *frames, size_t strid
 int launch_pixfix_cells(bool packed, const void *frames, size_t stride, int w, int h, const CellRec *recs, int n_rec,
                         const void *patches, int n_entries, void *cells, int nframes, hipStream_t stream);
 int launch_deflicker_hist(const void *d_frame, uint32_t samples, uint32_t white, unsigned *d_hist, hipStream_t s);
+int launch_hist_add(const void *d_frame, uint32_t first, uint32_t step, uint32_t samples, uint32_t white, unsigned *d_hist, hipStream_t s);
 int launch_badpix_detect(const void *d_frame, int w, int h, int black, int aggressive, int crop_x, int crop_y,
                          void *d_mask, int words_per_row, int *d_row_count, void *d_list, int cap,
                          const DeviceLuts &luts, hipStream_t stream);

@@ -841,14 +841,37 @@ struct histogram *hist_create(uint16_t white)                                   
 void hist_add(struct histogram *h, uint16_t *data, uint32_t size, uint16_t skip)     // histogram.c:52-59
 {
     // main.c:943 runs deflicker() -- hist_add on the frame buffer -- right after the unpack: inside a frame bracket the pixels
-    // are still on the GPU then
-    if (resident_level() == 2) {
+    // are still on the GPU then, and that is where they are counted (64 KB of counts cross the link instead of the frame, and
+    // the 2.4 M-sample loop below does not run); anything that goes wrong there falls back to fetching the frame
+    if (resident_level() == 2 && h && h->data && size > 0) {
         ThreadCtx *c = thread_ctx_if_any();
-        if (c && c->lazy.active && (const uint8_t *)data >= (const uint8_t *)c->lazy.host &&
-            (const uint8_t *)data < (const uint8_t *)c->lazy.host + c->lazy.bytes)
+        const uint8_t *p = (const uint8_t *)data;
+        const bool in_lazy = c && c->lazy.active && p >= (const uint8_t *)c->lazy.host && p + (size_t)size * 2 <= (const uint8_t *)c->lazy.host + c->lazy.bytes;
+        const bool in_res = c && !c->lazy.active && c->res_dirty && p >= (const uint8_t *)c->res_host &&
+                            p + (size_t)size * 2 <= (const uint8_t *)c->res_host + c->res_bytes;
+        if (in_lazy || in_res) {
+            const uint8_t *base = (const uint8_t *)(in_lazy ? c->lazy.host : c->res_host);
+            const uint32_t step = (uint32_t)skip + 1, samples = (size + step - 1) / step;
+            const size_t hbytes = sizeof(unsigned) * ((size_t)h->white + 1);
+            bool counted = false;
+            if (((p - base) & 1) == 0 && lazy_run(c, false) == MLVFS_AMD_OK && c->res_dirty && c->ensure(0, hbytes) == MLVFS_AMD_OK) {
+                const uint16_t *d = (const uint16_t *)c->d_res[c->res_cur];
+                std::vector<unsigned> cnt((size_t)h->white + 1);
+                counted = launch_hist_add(d, (uint32_t)((p - base) / 2), step, samples, h->white, (unsigned *)c->d_b, c->stream) == MLVFS_AMD_OK &&
+                          hipMemcpyAsync(cnt.data(), c->d_b, hbytes, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                          hipStreamSynchronize(c->stream) == hipSuccess;
+                if (counted) {
+                    for (uint32_t i = 0; i <= h->white; i++) h->data[i] = (uint16_t)(h->data[i] + cnt[i]);      // 16-bit counters wrap
+                    h->count += size / step;
+                    return;
+                }
+            }
+            (void)hipGetLastError();
+        }
+        // (a range that only starts inside the frame, an odd offset, a failure above: the frame comes to the host and is counted there)
+        if (c && c->lazy.active && p >= (const uint8_t *)c->lazy.host && p < (const uint8_t *)c->lazy.host + c->lazy.bytes)
             (void)mlvfs_amd_frame_sync(c->lazy.host);
-        else if (c && c->res_dirty && (const uint8_t *)data >= (const uint8_t *)c->res_host &&
-            (const uint8_t *)data < (const uint8_t *)c->res_host + c->res_bytes)
+        else if (c && c->res_dirty && p >= (const uint8_t *)c->res_host && p < (const uint8_t *)c->res_host + c->res_bytes)
             (void)mlvfs_amd_frame_sync(const_cast<void *>(c->res_host));
     }
     const uint32_t step = (uint32_t)skip + 1;

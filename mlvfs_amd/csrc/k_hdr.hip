@@ -116,19 +116,26 @@ int launch_hdr_preview(const void *d_frame, void *d_out, int w, int h, int black
 // skip 1), values clipped to 2^bpp + 1), its median, BaselineExposure = log2((target - black) / (median - black)).
 // The kernel counts with 32-bit atomics; the host folds to the reference's 16-bit counters (histogram.h:30) and does the rest.
 namespace mlv {
-__global__ __launch_bounds__(256) void k_deflicker_hist(const uint16_t *__restrict__ img, uint32_t samples, uint32_t white,
-                                                        unsigned *__restrict__ hist)
+// samples img[first + step * s], s < samples
+__global__ __launch_bounds__(256) void k_deflicker_hist(const uint16_t *__restrict__ img, uint32_t first, uint32_t step, uint32_t samples,
+                                                        uint32_t white, unsigned *__restrict__ hist)
 {
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < samples; s += gridDim.x * blockDim.x) {
-        const uint32_t v = img[1 + 2 * (size_t)s];
+        const uint32_t v = img[first + (size_t)step * s];
         atomicAdd(&hist[v < white ? v : white], 1u);
     }
 }
 
 int launch_deflicker_hist(const void *d_frame, uint32_t samples, uint32_t white, unsigned *d_hist, hipStream_t s)
 {
+    return launch_hist_add(d_frame, 1, 2, samples, white, d_hist, s);
+}
+
+// hist_add (histogram.c:52-59) on device memory: counts of img[first], img[first + step], ... (`samples` of them), values clipped to `white`
+int launch_hist_add(const void *d_frame, uint32_t first, uint32_t step, uint32_t samples, uint32_t white, unsigned *d_hist, hipStream_t s)
+{
     MLV_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * ((size_t)white + 1), s));
-    if (samples) hipLaunchKernelGGL(k_deflicker_hist, dim3(1024), dim3(256), 0, s, (const uint16_t *)d_frame, samples, white, d_hist);
+    if (samples) hipLaunchKernelGGL(k_deflicker_hist, dim3(1024), dim3(256), 0, s, (const uint16_t *)d_frame, first, step, samples, white, d_hist);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }

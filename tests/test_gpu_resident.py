@@ -208,10 +208,20 @@ def test_bracketed_result_is_fetched_by_symbols_that_read_the_host_frame(gpu, or
     gpu.mlvfs_amd_frame_begin()
     _unpack_into(gpu, fh, f, img2)
     assert (img2 == 0xABCD).all()
+    # -- inside a bracket the samples are counted where the pixels are, the host frame stays as it was; the counts are the host loop's
     hist = gpu.hist_create(1 << 14)
     gpu.hist_add(hist, C.c_void_p(img2.ctypes.data + 2), (img2.size - 1) // 2, 1)
-    assert np.array_equal(img2, f)
-    gpu.hist_destroy(hist)
+    assert (img2 == 0xABCD).all()
+    ref_hist = gpu.hist_create(1 << 14)
+    flat = np.ascontiguousarray(f.reshape(-1))
+    gpu.hist_add(ref_hist, C.c_void_p(flat.ctypes.data + 2), (flat.size - 1) // 2, 1)      # a buffer the library knows nothing about: the host loop
+    class Hist(C.Structure):                                          # histogram.h / include/mlvfs_amd.h
+        _fields_ = [("white", C.c_uint16), ("count", C.c_uint32), ("data", C.POINTER(C.c_uint16))]
+    a, b = C.cast(hist, C.POINTER(Hist)).contents, C.cast(ref_hist, C.POINTER(Hist)).contents
+    assert a.count == b.count == ((img2.size - 1) // 2) // 2
+    assert np.array_equal(np.ctypeslib.as_array(a.data, ((1 << 14) + 1,)), np.ctypeslib.as_array(b.data, ((1 << 14) + 1,)))
+    assert gpu.hist_median(hist) == gpu.hist_median(ref_hist)
+    gpu.hist_destroy(hist); gpu.hist_destroy(ref_hist)
     # a window that is not the whole frame is written at once (dng.c:815-826 arithmetic), bracket or not
     part = pipeline.get_image_data(fh, synth.pack_bits(f)[512 * 14 // 16:], offset=1024, max_size=4096)      # from the first pixel's word on
     assert np.array_equal(part, f.reshape(-1)[512:512 + 2048])
