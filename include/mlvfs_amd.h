@@ -217,6 +217,15 @@ int mlvfs_amd_lj92_info(const void *stream, size_t size, int dims[4]);
 int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_t *sizes, int nframes, int xres, int yres,
                               void *d_out, size_t out_stride, void *stream);
 
+/* The reference decoder's own three calls (lj92.h:40-58), what get_image_data makes of an LJ92 frame (main.c:626-647: lj92_open,
+ * lj92_decode into a temporary buffer, then its own untiling loop): with them `lj92.o` can leave MLVFS's link too and the decode
+ * runs on the GPU.  Values in the decoder's own order, width x height of the JPEG.  Only what MLVFS passes is supported:
+ * skiplen 0, linearize NULL (anything else: LJ92_ERROR_CORRUPT, -1).  lj92_encode is not provided (MLVFS never calls it).   */
+typedef struct _ljp *lj92;
+int lj92_open(lj92 *lj, uint8_t *data, int datalen, int *width, int *height, int *bitdepth);
+void lj92_close(lj92 lj);
+int lj92_decode(lj92 lj, uint16_t *target, int tlen, int skiplen, uint16_t *linearize, int linlen);
+
 /* -- LZMA payloads ----------------------------------------- */
 /* One VIDF payload of an LZMA-compressed clip (MLV_VIDEO_CLASS_FLAG_LZMA; main.c:598-616): [u32 size of the packed frame][5 LZMA
  * property bytes][LZMA stream] -> the packed frame, exactly what LzmaUncompress leaves in lzma_out for dng_get_image_data.  Host

@@ -491,7 +491,9 @@ __device__ __forceinline__ bool first_column_only(int pred) { return pred == 0 |
 __device__ __forceinline__ void emit_untiled(const LjFrame &f, int r, int c, int px)
 {
     const uint32_t xres = (uint32_t)f.xres, yres = (uint32_t)f.yres;
-    const uint32_t i = (uint32_t)r * (uint32_t)f.W + (uint32_t)c, sy = i / xres, sx = i - sy * xres;
+    const uint32_t i = (uint32_t)r * (uint32_t)f.W + (uint32_t)c;
+    if (xres == 0) { f.out[i] = (uint16_t)px; return; }                  // the decoder's own order (the drop-in lj92_decode: main.c untiles itself)
+    const uint32_t sy = i / xres, sx = i - sy * xres;
     const uint32_t dy = 2 * sy < yres ? 2 * sy : 2 * sy - yres + 1, dx = 2 * sx < xres ? 2 * sx : 2 * sx - xres + 1;
     f.out[(size_t)dy * xres + dx] = (uint16_t)px;
 }
@@ -595,8 +597,11 @@ __global__ __launch_bounds__(256) void k_lj_columns(const LjFrame *frames)
     for (int k = 0; k < seg; k++) x += f.colsum[(size_t)k * W + cc];
     // main.c:646-667 reads the decoded values as yres rows of xres, whatever the JPEG's own dimensions are: position of
     // element (r, c) in that reading, advanced row by row without divisions
-    const uint32_t i0 = (uint32_t)r0 * W + (uint32_t)c, qW = W / xres, mW = W - qW * xres;
-    uint32_t sy = i0 / xres, sx = i0 - sy * xres;
+    // (xres == 0: the values stay in the decoder's own order -- the drop-in lj92_decode --, handled as one row per JPEG row)
+    const bool raw_order = xres == 0;
+    const uint32_t xr = raw_order ? W : xres;
+    const uint32_t i0 = (uint32_t)r0 * W + (uint32_t)c, qW = W / xr, mW = W - qW * xr;
+    uint32_t sy = i0 / xr, sx = i0 - sy * xr;
     for (int r = r0; r < r1; r++) {
         int px;
         if (r == 0) px = f.diff[c];
@@ -607,10 +612,10 @@ __global__ __launch_bounds__(256) void k_lj_columns(const LjFrame *frames)
                 px = c ? (f.pred == 0 ? e : x + e) : x;
             } else { x += e; px = x; }                          // 2, 4, 6: sums down every column
         }
-        const uint32_t dy = 2 * sy < yres ? 2 * sy : 2 * sy - yres + 1, dx = 2 * sx < xres ? 2 * sx : 2 * sx - xres + 1;
-        f.out[(size_t)dy * xres + dx] = (uint16_t)px;
+        const uint32_t dy = raw_order ? sy : (2 * sy < yres ? 2 * sy : 2 * sy - yres + 1), dx = raw_order ? sx : (2 * sx < xres ? 2 * sx : 2 * sx - xres + 1);
+        f.out[(size_t)dy * xr + dx] = (uint16_t)px;
         sy += qW; sx += mW;
-        if (sx >= xres) { sx -= xres; sy++; }
+        if (sx >= xr) { sx -= xr; sy++; }
     }
 }
 

@@ -174,7 +174,9 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
     ThreadCtx *c = thread_ctx();
     if (!c) return MLVFS_AMD_ERR_HIP;
     if (nframes <= 0) return MLVFS_AMD_OK;
-    if (!streams || !sizes || !d_out || xres <= 0 || yres <= 0 || out_stride < (size_t)xres * yres * 2) { set_error("lj92: bad argument"); return MLVFS_AMD_ERR_ARG; }
+    // xres == 0 (and yres == 0): the values stay in the decoder's own order, W x H of the JPEG (what lj92_decode hands to main.c)
+    const bool raw_order = xres == 0 && yres == 0;
+    if (!streams || !sizes || !d_out || (!raw_order && (xres <= 0 || yres <= 0 || out_stride < (size_t)xres * yres * 2))) { set_error("lj92: bad argument"); return MLVFS_AMD_ERR_ARG; }
     hipStream_t s = pick_stream(stream, c);
     std::vector<Parsed> hdr(nframes);
     // ---- layout: one staging block (raw scans, tables, frame records) and one device arena
@@ -189,7 +191,8 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
         if (!streams[i] || sizes[i] > 0x7FFFFFFF || !parse((const uint8_t *)streams[i], (int)sizes[i], &h, &why)) { set_error("lj92: frame %d: %s", i, why); return MLVFS_AMD_ERR_ARG; }
         if (h.pred < 0 || h.pred > 7) { set_error("lj92: frame %d: predictor %d does not exist", i, h.pred); return MLVFS_AMD_ERR_ARG; }
         if (h.pred == 7 && h.height > LJ_WAVE_MAX_H) { set_error("lj92: frame %d: predictor 7 is limited to %d rows", i, LJ_WAVE_MAX_H); return MLVFS_AMD_ERR_ARG; }
-        if ((long long)h.width * h.height != (long long)xres * yres) {
+        if (raw_order && out_stride < (size_t)h.width * h.height * 2) { set_error("lj92: frame %d: output stride smaller than the %dx%d values", i, h.width, h.height); return MLVFS_AMD_ERR_ARG; }
+        if (!raw_order && (long long)h.width * h.height != (long long)xres * yres) {
             set_error("lj92: frame %d: %dx%d values decoded, the video frame is %dx%d", i, h.width, h.height, xres, yres);
             return MLVFS_AMD_ERR_ARG;
         }
@@ -276,3 +279,56 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
         }
     return MLVFS_AMD_OK;
 }
+
+
+// ---------------------------------------------------------------- lj92.h: the decoder's own three calls (main.c:626-647)
+// MLVFS's get_image_data opens the frame's JPEG, decodes it into a temporary buffer and untiles that into the frame itself.  With
+// these three symbols `lj92.o` can leave the link as well: the decode runs on the GPU (32 ms per 3584x1320 frame in the
+// reference's decoder on one host core).  Only what MLVFS passes is supported: skiplen 0, no linearisation table.
+namespace {
+struct LjHandle { const uint8_t *data; int len; int width, height, bits; };
+enum { LJ92_OK = 0, LJ92_CORRUPT = -1, LJ92_NO_MEMORY = -2, LJ92_BAD_HANDLE = -3 };      // lj92.h:29-35
+}
+
+extern "C" {
+
+int lj92_open(lj92 *lj, uint8_t *data, int datalen, int *width, int *height, int *bitdepth)        // lj92.h:42-46
+{
+    if (!lj) return LJ92_BAD_HANDLE;
+    *lj = nullptr;
+    Parsed h;
+    const char *why = "";
+    if (!data || datalen <= 0 || !parse(data, datalen, &h, &why)) { set_error("lj92_open: %s", why); return LJ92_CORRUPT; }
+    LjHandle *hd = (LjHandle *)malloc(sizeof *hd);
+    if (!hd) return LJ92_NO_MEMORY;
+    *hd = LjHandle{ data, datalen, h.width, h.height, h.bits };
+    if (width) *width = h.width;
+    if (height) *height = h.height;
+    if (bitdepth) *bitdepth = h.bits;
+    *lj = (lj92)hd;
+    return LJ92_OK;
+}
+
+void lj92_close(lj92 lj) { free(lj); }                                                                   // lj92.h:47
+
+int lj92_decode(lj92 lj, uint16_t *target, int tlen, int skiplen, uint16_t *linearize, int linlen)     // lj92.h:55-58
+{
+    (void)linlen;
+    LjHandle *hd = (LjHandle *)lj;
+    if (!hd) return LJ92_BAD_HANDLE;
+    const size_t npix = (size_t)hd->width * hd->height;
+    if (!target || skiplen != 0 || linearize || (size_t)(tlen < 0 ? 0 : tlen) < npix) { set_error("lj92_decode: only whole frames without a linearisation table"); return LJ92_CORRUPT; }
+    LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
+    ThreadCtx *c = thread_ctx();
+    if (!c || c->ensure(npix * 2, 0)) return LJ92_NO_MEMORY;
+    const void *streams[1] = { hd->data };
+    const size_t sizes[1] = { (size_t)hd->len };
+    if (mlvfs_amd_lj92_decode_dev(streams, sizes, 1, 0, 0, c->d_a, npix * 2, c->stream) != MLVFS_AMD_OK) return LJ92_CORRUPT;
+    if (hipMemcpyAsync(target, c->d_a, npix * 2, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+        set_error("lj92_decode: download failed");
+        return LJ92_CORRUPT;
+    }
+    return LJ92_OK;
+}
+
+}  // extern "C"

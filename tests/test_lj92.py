@@ -144,6 +144,63 @@ def test_gpu_reference_encoder_streams_and_odd_shapes(gpu, oracle, reference):
         assert np.array_equal(gpu_decode([s], w, h)[0], want(oracle, s, w, h))
 
 
+def dropin_decode(gpu, stream):
+    """The reference decoder's own three calls (lj92.h:40-58) as the library exports them, the way main.c:626-647 uses them."""
+    import ctypes as C
+    buf = np.frombuffer(stream, np.uint8).copy()
+    h = C.c_void_p()
+    w_, h_, b_ = C.c_int(), C.c_int(), C.c_int()
+    st = gpu.lj92_open(C.byref(h), C.c_void_p(buf.ctypes.data), buf.size, C.byref(w_), C.byref(h_), C.byref(b_))
+    if st != 0:
+        return st, None, None
+    out = np.zeros((h_.value, w_.value), np.uint16)
+    st = gpu.lj92_decode(h, C.c_void_p(out.ctypes.data), out.size, 0, None, 0)
+    gpu.lj92_close(h)
+    return st, out, (w_.value, h_.value, b_.value)
+
+
+@pytest.mark.gpu
+def test_dropin_lj92_symbols_equal_the_reference_decoder(gpu, oracle, reference):
+    """lj92_open / lj92_decode / lj92_close of the library against the reference's (oracle/_ref builds lj92.c): dimensions, every
+    value in the decoder's own order (main.c untiles afterwards), the reference encoder's streams in three JPEG shapes, every
+    predictor, a full-size frame; damage and the arguments MLVFS never passes come back as errors."""
+    import ctypes as C
+    w, h = 256, 130
+    f = synth.normal_frame(w, h, seed=9)
+    q = quadrants(f)
+    for shape in ((h, w), (h // 2, w * 2), (h * 2, w // 2)):
+        s = reference.lj92_encode(np.ascontiguousarray(q.reshape(shape)), 14)
+        st, got, dims = dropin_decode(gpu, s)
+        rst, rimg = reference.lj92_decode(s)
+        assert st == 0 and rst == 0 and dims[:2] == (rimg.shape[1], rimg.shape[0]) and dims[2] == 14 and np.array_equal(got, rimg), shape
+        assert np.array_equal(oracle.lj92_untile(got, w, h), f)                                   # what main.c's loop makes of it
+    noise = images(136, 72)["noise"]
+    for p in range(8):
+        s = enc.encode(noise, p, 14)
+        st, got, dims = dropin_decode(gpu, s)
+        ost, oimg = oracle.lj92_decode(s)
+        assert st == 0 and ost == 0 and np.array_equal(got, oimg), p
+    big = synth.normal_frame(3584, 1320, seed=1)
+    s = reference.lj92_encode(quadrants(big), 14)
+    st, got, dims = dropin_decode(gpu, s)
+    assert st == 0 and np.array_equal(oracle.lj92_untile(got, 3584, 1320), big)
+    # errors
+    good = enc.encode(images(136, 72)["smooth"], 6, 14)
+    assert dropin_decode(gpu, good[: len(good) // 2])[0] != 0                 # the data ends before the last pixel
+    assert dropin_decode(gpu, b"\xff\xd8 no jpeg")[0] != 0
+    buf = np.frombuffer(good, np.uint8).copy()
+    hd = C.c_void_p()
+    assert gpu.lj92_open(C.byref(hd), C.c_void_p(buf.ctypes.data), buf.size, None, None, None) == 0
+    out = np.zeros(136 * 72, np.uint16)
+    lin = np.zeros(16, np.uint16)
+    assert gpu.lj92_decode(hd, C.c_void_p(out.ctypes.data), out.size, 4, None, 0) != 0             # skiplen
+    assert gpu.lj92_decode(hd, C.c_void_p(out.ctypes.data), out.size, 0, C.c_void_p(lin.ctypes.data), 16) != 0
+    assert gpu.lj92_decode(hd, C.c_void_p(out.ctypes.data), out.size - 1, 0, None, 0) != 0         # target too small
+    assert gpu.lj92_decode(hd, C.c_void_p(out.ctypes.data), out.size, 0, None, 0) == 0
+    gpu.lj92_close(hd)
+    assert gpu.lj92_decode(None, C.c_void_p(out.ctypes.data), out.size, 0, None, 0) != 0
+
+
 @pytest.mark.gpu
 def test_gpu_full_size_frame(gpu, oracle, reference):
     w, h = 3584, 1320
