@@ -272,6 +272,10 @@ int mlvfs_amd_gif_render(const mlvfs_amd_geom_t *geom, const void *h_frames, siz
 /* = gif_get_data on an opened clip (frames k * count / 10, k = 0..9; uncompressed, LZMA and LJ92 clips): copies
  * min(max_size, size - offset) bytes from `offset` on, returns max_size (0 on failure).                              */
 size_t mlvfs_amd_mlv_gif_data(const void *reader, uint8_t *output_buffer, off_t offset, size_t max_size);
+/* gif.h:27-28, the two calls MLVFS makes for a clip's _PREVIEW.GIF (main.c:1018-1022, 1212): gif_get_data opens the clip at `path`
+ * with the library's reader and is mlvfs_amd_mlv_gif_data on it; with them `gif.o` can leave the link too.             */
+size_t gif_get_data(const char *path, uint8_t *output_buffer, off_t offset, size_t max_size);
+size_t gif_get_size(struct frame_headers *frame_headers);
 
 /* dual-ISO preview on one device frame (hdr.c:40-227); returns 1 / 0 / <0    */
 int mlvfs_amd_hdr_preview_dev(const mlvfs_amd_geom_t *geom, void *d_frame, size_t max_size, void *stream);

@@ -676,3 +676,19 @@ static size_t gif_data(const void *reader, uint8_t *output_buffer, off_t offset,
 }
 
 }  // extern "C"
+
+
+// ---------------------------------------------------------------- gif.h: the preview's two calls (main.c:1018-1022, 1212)
+// With them `gif.o` can leave MLVFS's link as well: the clip is opened by the library's own reader (index walk, LZMA and LJ92
+// payloads included), the ten frames are picked and gamma-mapped on the GPU, the file is byte for byte the reference's.
+extern "C" size_t gif_get_size(struct frame_headers *frame_headers) { return mlvfs_amd_gif_size(frame_headers); }      // gif.c:63-80
+
+extern "C" size_t gif_get_data(const char *path, uint8_t *output_buffer, off_t offset, size_t max_size)               // gif.c:82-221
+{
+    if (!path || !output_buffer) return 0;
+    void *r = mlvfs_amd_mlv_open(path, 0);
+    if (!r) return 0;
+    const size_t n = mlvfs_amd_mlv_gif_data(r, output_buffer, offset, max_size);
+    mlvfs_amd_mlv_close(r);
+    return n;
+}

@@ -31,7 +31,7 @@ DROPIN_SYMBOLS = [
     "stripes_get_correction", "stripes_new_correction", "stripes_free_corrections",
     "stripes_compute_correction", "stripes_apply_correction",
     "hdr_convert_data", "cr2hdr20_convert_data", "fix_pattern_noise",
-    "hist_create", "hist_add", "hist_median", "hist_destroy", "lj92_open", "lj92_decode", "lj92_close",
+    "hist_create", "hist_add", "hist_median", "hist_destroy", "lj92_open", "lj92_decode", "lj92_close", "gif_get_data", "gif_get_size",
 ]
 DEVICE_SYMBOLS = [
     "mlvfs_amd_device_count", "mlvfs_amd_init", "mlvfs_amd_last_error", "mlvfs_amd_version",
@@ -111,6 +111,8 @@ def load() -> C.CDLL:
     sig("fix_pattern_noise", None, [vp, i, i, i, i])
     sig("lj92_open", i, [C.POINTER(vp), vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)])
     sig("lj92_close", None, [vp])
+    sig("gif_get_size", sz, [fhp])
+    sig("gif_get_data", sz, [C.c_char_p, vp, C.c_long, sz])
     sig("lj92_decode", i, [vp, vp, i, i, vp, i])
     sig("hist_create", vp, [C.c_uint16])
     sig("hist_add", None, [vp, vp, C.c_uint32, C.c_uint16])

@@ -183,6 +183,12 @@ def gif_of(amd, path):
     assert amd.mlvfs_amd_mlv_gif_data(r, lib.ptr(part), 777, 1000) == 1000 and bytes(part) == bytes(out[777:1777])
     amd.mlvfs_amd_mlv_close(r)
     assert got == n
+    # gif.h's own two calls, exported by the library (main.c:1018-1022 calls them with the clip's path)
+    assert amd.gif_get_size(C.byref(fh)) == n
+    again = np.zeros(n, np.uint8)
+    assert amd.gif_get_data(path.encode(), lib.ptr(again), 0, n) == n and bytes(again) == bytes(out)
+    assert amd.gif_get_data(path.encode(), lib.ptr(part), 777, 1000) == 1000 and bytes(part) == bytes(out[777:1777])
+    assert amd.gif_get_data(b"/nonexistent/clip.MLV", lib.ptr(part), 0, 1000) == 0
     return out.tobytes()
 
 
