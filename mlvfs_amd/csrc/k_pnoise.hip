@@ -14,10 +14,11 @@
 //                        <= 24 right), lower medians of g1, g2, r-avg_g, b-avg_g over
 //                        the run (patternnoise.c:88-180); one workgroup per plane row,
 //                        the row's five int16 arrays staged in LDS
-//   k_pn_column_offsets  per plane column: lower median of (orig - smoothed) over the
-//                        unmasked rows (mask: |flat-array gradient| > 500 or >= white),
-//                        offset = -median when >= 10 samples (patternnoise.c:185-254)
-//   k_pn_offset_median   lower median of a plane's column offsets (patternnoise.c:268)
+//   k_pn_noise_t         the noise samples (orig - smoothed, or "masked": |flat-array gradient| > 500 or >= white) of
+//                        every plane, written transposed so that a column's samples lie side by side
+//   k_pn_column_offsets  per plane column: lower median of its unmasked samples, offset = -median when >= 10 samples
+//                        (patternnoise.c:185-254)
+//                        (the same kernel, "plain", gives the lower median of a plane's column offsets, patternnoise.c:268)
 //   k_pn_apply           add offsets (clamp +-32767), remove their median (clamp 0..32760)
 #include "clip.h"
 
@@ -137,66 +138,78 @@ __device__ __forceinline__ bool noise_at(const int16_t *raw, int w, int hw, size
     return !((abs(grad) > 500) || (o >= white));
 }
 
-// one workgroup (256 threads) per (column, plane): the column's noise samples are computed once into LDS
-// (masked samples as a sentinel above every int16), then bisected between their extremes
-constexpr int PN_MAX_ROWS = 8192;
-__global__ __launch_bounds__(256) void k_pn_column_offsets(const int16_t *__restrict__ raw, int w, int hw, int hh, int white,
-                                                           const int16_t *__restrict__ smooth, int *__restrict__ offs /* [4][hw] */)
+// The noise samples of a plane, transposed: T[c][x][y] = orig - smoothed, or MASKED (|flat-array gradient| > 500 or >= white).  Read
+// row-wise (coalesced), written column-wise through a 32 x 32 tile in LDS, so that the next kernel finds a column's samples side by
+// side.  (Until the end of round 3 a workgroup per column and plane walked the column in the frame itself: 83 us per pass.)
+constexpr int PN_MASKED = 1 << 20;                           // above every int16
+__global__ __launch_bounds__(256) void k_pn_noise_t(const int16_t *__restrict__ raw, int w, int hw, int hh, int white,
+                                                    const int16_t *__restrict__ smooth, int *__restrict__ T /* [4][hw][hh] */)
 {
-    extern __shared__ int samples[];                         // hh entries
-    __shared__ int red[4], red2[4], red3[4];
-    const int x = blockIdx.x, c = blockIdx.y;
+    __shared__ int tile[32][33];
+    const int c = blockIdx.z, bx = blockIdx.x * 32, by = blockIdx.y * 32;
     const size_t n = (size_t)hw * hh;
     const int16_t *sm = smooth + (size_t)c * n;
-    constexpr int MASKED = 1 << 20;
-    int cnt = 0, lo = 32767, hi = -32768;
-    for (int y = threadIdx.x; y < hh; y += blockDim.x) {
-        int nz;
-        const bool ok = noise_at(raw, w, hw, n, c, sm, (size_t)x + (size_t)y * hw, white, nz);
-        samples[y] = ok ? nz : MASKED;
-        if (ok) { cnt++; lo = min(lo, nz); hi = max(hi, nz); }
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int x = bx + threadIdx.x, y = by + r;
+        if (x < hw && y < hh) {
+            int nz;
+            const bool ok = noise_at(raw, w, hw, n, c, sm, (size_t)x + (size_t)y * hw, white, nz);
+            tile[r][threadIdx.x] = ok ? nz : PN_MASKED;
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int x = bx + r, y = by + threadIdx.x;
+        if (x < hw && y < hh) T[((size_t)c * hw + x) * hh + y] = tile[threadIdx.x][r];
+    }
+}
+
+// one workgroup per column, one wave per plane: lower median of the column's unmasked samples by bisection between their extremes
+// -- a step is a ballot per 64 rows --, offset = -median when >= 10 samples (patternnoise.c:185-254)
+// R: samples per lane held in registers (hh <= 64 R); R = 0: any height, the column is re-read in every step
+// plain: the lower median itself, whatever the number of samples (the median of a plane's column offsets, patternnoise.c:268:
+// T = the offsets [4][1][hw], one "column" per plane)
+template <int R>
+__global__ __launch_bounds__(256) void k_pn_column_offsets(const int *__restrict__ T, int hw, int hh, int *__restrict__ offs /* [4][hw] */, bool plain)
+{
+    const int x = blockIdx.x, c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int *col = T + ((size_t)c * hw + x) * hh;
+    int v[R > 0 ? R : 1];
+    int cnt = 0, lo = 0x7FFFFFFF, hi = -0x7FFFFFFF - 1;
+    if (R > 0) {
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int y = lane + 64 * i;
+            v[i] = y < hh ? col[y] : PN_MASKED;
+            if (v[i] != PN_MASKED) { cnt++; lo = min(lo, v[i]); hi = max(hi, v[i]); }
+        }
+    } else {
+        for (int y = lane; y < hh; y += 64) {
+            const int s = col[y];
+            if (s != PN_MASKED) { cnt++; lo = min(lo, s); hi = max(hi, s); }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o); lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = cnt; red2[threadIdx.x >> 6] = lo; red3[threadIdx.x >> 6] = hi; }
-    __syncthreads();
-    const int k = red[0] + red[1] + red[2] + red[3];
-    if (k < 10) { if (threadIdx.x == 0) offs[c * hw + x] = 0; return; }      // patternnoise.c:250
-    int a = min(min(red2[0], red2[1]), min(red2[2], red2[3])), b = max(max(red3[0], red3[1]), max(red3[2], red3[3]));
+    const int k = cnt;
+    if (plain ? k < 1 : k < 10) { if (lane == 0) offs[c * hw + x] = 0; return; }      // patternnoise.c:250
+    int a = lo, b = hi;
     const int need = (k - 1) / 2 + 1;
     while (a < b) {
         const int mid = (a + b) >> 1;
         int le = 0;
-        for (int y = threadIdx.x; y < hh; y += blockDim.x) le += (samples[y] <= mid);
+        if (R > 0) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) le += __shfl_xor(le, o);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = le;
-        __syncthreads();
-        if (red[0] + red[1] + red[2] + red[3] >= need) b = mid; else a = mid + 1;
+            for (int i = 0; i < R; i++) le += __popcll(__ballot(v[i] <= mid));
+        } else {
+            for (int y0 = 0; y0 < hh; y0 += 64) {
+                const int y = y0 + lane;
+                le += __popcll(__ballot(y < hh && col[y] <= mid));
+            }
+        }
+        if (le >= need) b = mid; else a = mid + 1;
     }
-    if (threadIdx.x == 0) offs[c * hw + x] = -a;
-}
-
-// lower median of offs[c][0..hw) ; one workgroup per plane
-__global__ __launch_bounds__(256) void k_pn_offset_median(const int *__restrict__ offs, int hw, int *__restrict__ mc /* [4] */)
-{
-    __shared__ int red[4];
-    const int c = blockIdx.x;
-    const int need = (hw - 1) / 2 + 1;
-    int a = -40000, b = 40000;
-    while (a < b) {
-        const int mid = (a + b) >> 1;
-        int le = 0;
-        for (int x = threadIdx.x; x < hw; x += blockDim.x) le += (offs[c * hw + x] <= mid);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) le += __shfl_xor(le, o);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = le;
-        __syncthreads();
-        if (red[0] + red[1] + red[2] + red[3] >= need) b = mid; else a = mid + 1;
-    }
-    if (threadIdx.x == 0) mc[c] = a;
+    if (lane == 0) offs[c * hw + x] = plain ? a : -a;
 }
 
 __global__ __launch_bounds__(256) void k_pn_apply(int16_t *__restrict__ raw, int w, int h, int hw, const int *__restrict__ offs,
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(256) void k_pn_apply(int16_t *__restrict__ raw, int
 }
 
 // one direction on a device frame (w x h int16).  scratch: smooth 4*hw*hh int16, offs 4*hw int, mc 4 int
-static int column_pass(int16_t *d_raw, int w, int h, int white, int16_t *d_smooth, int *d_offs, int *d_mc, hipStream_t stream)
+static int column_pass(int16_t *d_raw, int w, int h, int white, int16_t *d_smooth, int *d_offs, int *d_mc, int *d_noise_t, hipStream_t stream)
 {
     const int hw = w / 2, hh = h / 2;
     if (hw <= 0 || hh <= 0) return MLVFS_AMD_OK;
@@ -220,9 +233,11 @@ static int column_pass(int16_t *d_raw, int w, int h, int white, int16_t *d_smoot
     if (shmem > 150 * 1024) { set_error("fix_pattern_noise: rows of %d pixels do not fit in LDS", w); return MLVFS_AMD_ERR_ARG; }
     MLV_HIP(hipFuncSetAttribute((const void *)k_pn_smooth, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(k_pn_smooth, dim3(hh), dim3(256), shmem, stream, d_raw, w, hw, 50 / 2, 500, d_smooth, hh);
-    if (hh > PN_MAX_ROWS) { set_error("fix_pattern_noise: columns of %d pixels do not fit in LDS", h); return MLVFS_AMD_ERR_ARG; }
-    hipLaunchKernelGGL(k_pn_column_offsets, dim3(hw, 4), dim3(256), (size_t)hh * sizeof(int), stream, d_raw, w, hw, hh, white, d_smooth, d_offs);
-    hipLaunchKernelGGL(k_pn_offset_median, dim3(4), dim3(256), 0, stream, d_offs, hw, d_mc);
+    hipLaunchKernelGGL(k_pn_noise_t, dim3((hw + 31) / 32, (hh + 31) / 32, 4), dim3(32, 8), 0, stream, d_raw, w, hw, hh, white, d_smooth, d_noise_t);
+    auto offsets = hh <= 64 * 12 ? k_pn_column_offsets<12> : (hh <= 64 * 32 ? k_pn_column_offsets<32> : k_pn_column_offsets<0>);
+    hipLaunchKernelGGL(offsets, dim3(hw), dim3(256), 0, stream, d_noise_t, hw, hh, d_offs, false);
+    auto median = hw <= 64 * 12 ? k_pn_column_offsets<12> : (hw <= 64 * 32 ? k_pn_column_offsets<32> : k_pn_column_offsets<0>);
+    hipLaunchKernelGGL(median, dim3(1), dim3(256), 0, stream, d_offs, 1, hw, d_mc, true);      // lower median of each plane's offsets
     hipLaunchKernelGGL(k_pn_apply, dim3((w + 255) / 256, h), dim3(256), 0, stream, d_raw, w, h, hw, d_offs, d_mc);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
@@ -231,7 +246,8 @@ static int column_pass(int16_t *d_raw, int w, int h, int white, int16_t *d_smoot
 size_t pattern_noise_scratch_bytes(int w, int h)
 {
     const size_t n = (size_t)w * h;
-    return n * 2 /* transposed frame */ + n * 2 /* 4 smoothed half-res planes */ + (size_t)4 * (w > h ? w : h) * 4 + 64;
+    return n * 2 /* transposed frame */ + n * 2 /* 4 smoothed half-res planes */ + (size_t)4 * (w > h ? w : h) * 4 + 64 + 256 +
+           n * 4 /* transposed noise samples */;
 }
 
 int launch_pattern_noise(void *d_raw, int w, int h, int white, void *d_scratch, hipStream_t stream)
@@ -242,10 +258,11 @@ int launch_pattern_noise(void *d_raw, int w, int h, int white, void *d_scratch, 
     int16_t *d_smooth = d_t + n;
     int *d_offs = (int *)(d_smooth + n);
     int *d_mc = d_offs + (size_t)4 * (w > h ? w : h) / 2 + 4;
-    int rc = column_pass(raw, w, h, white, d_smooth, d_offs, d_mc, stream);
+    int *d_noise_t = (int *)(((uintptr_t)((uint8_t *)d_scratch + n * 4 + (size_t)4 * (w > h ? w : h) * 4 + 64) + 255) & ~(uintptr_t)255);
+    int rc = column_pass(raw, w, h, white, d_smooth, d_offs, d_mc, d_noise_t, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pn_transpose, dim3((w + 31) / 32, (h + 31) / 32), dim3(32, 8), 0, stream, raw, d_t, w, h);
-    rc = column_pass(d_t, h, w, white, d_smooth, d_offs, d_mc, stream);
+    rc = column_pass(d_t, h, w, white, d_smooth, d_offs, d_mc, d_noise_t, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pn_transpose, dim3((h + 31) / 32, (w + 31) / 32), dim3(32, 8), 0, stream, d_t, raw, h, w);
     MLV_HIP(hipGetLastError());
