@@ -99,6 +99,27 @@ def test_host_parser(amd, reference):
             lj92.info(junk)
 
 
+def test_dropin_lj92_open_on_the_cpu(amd, reference):
+    """lj92_open / lj92_close of the library need no GPU: dimensions and bit depth as the reference's lj92_open reports them
+    (main.c:626), damage refused, a null handle tolerated by lj92_close like free()."""
+    import ctypes as C
+    for w, h, bits, shape in ((64, 48, 14, (48, 64)), (256, 130, 14, (65, 512)), (136, 72, 12, (72, 136))):
+        img = (images(w, h)["smooth"] >> (14 - bits)).astype(np.uint16)
+        s = reference.lj92_encode(np.ascontiguousarray(img.reshape(shape)), bits)
+        buf = np.frombuffer(s, np.uint8).copy()
+        hd = C.c_void_p()
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        assert amd.lj92_open(C.byref(hd), C.c_void_p(buf.ctypes.data), buf.size, C.byref(a), C.byref(b), C.byref(c)) == 0 and hd.value
+        rst, rimg = reference.lj92_decode(s)
+        assert rst == 0 and (a.value, b.value, c.value) == (rimg.shape[1], rimg.shape[0], bits)
+        amd.lj92_close(hd)
+    for junk in (b"\xff\xd8\xff\xd9", b"not a jpeg at all, not even close"):
+        buf = np.frombuffer(junk, np.uint8).copy()
+        hd = C.c_void_p(1)
+        assert amd.lj92_open(C.byref(hd), C.c_void_p(buf.ctypes.data), buf.size, None, None, None) != 0 and not hd.value
+    amd.lj92_close(None)
+
+
 # ---------------------------------------------------------------- GPU
 def gpu_decode(streams, xres, yres):
     from mlvfs_amd import lj92
