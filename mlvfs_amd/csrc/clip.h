@@ -12,8 +12,9 @@ namespace mlv {
 
 // tile geometry of the fused kernel (k_frame.hip); the per-tile patch lists are built
 // on the host with the same numbers
-// Two tile heights: 16 cell rows, and 15 for chroma smoothing 5x5 (its medians use one lane per row for the halo group: k_frame.hip)
-constexpr int FRAME_TCW = 64, FRAME_TCH = 16, FRAME_TCH5 = 15, FRAME_HC = 2;
+// One tile height since round 4: 15 cell rows (15 rows x 17 lanes of the 5x5 medians, 15 x 17 loader items: k_frame.hip).  The
+// two-geometry plumbing of rounds 2-3 (16 rows without 5x5) is kept: both entries are the same now.
+constexpr int FRAME_TCW = 64, FRAME_TCH = 15, FRAME_TCH5 = 15, FRAME_HC = 2;
 constexpr int FRAME_GEOS = 2;                                   // tile geometries: 0 = FRAME_TCH rows, 1 = FRAME_TCH5 rows
 inline int frame_tile_rows(int geo) { return geo == 1 ? FRAME_TCH5 : FRAME_TCH; }
 inline int frame_geo_of(int method) { return method == 5 ? 1 : 0; }

@@ -9,26 +9,26 @@
 //   chroma smooth   mlvfs/chroma_smooth.c:22-71 via mlvfs/cs.c:49-84
 //   stripes apply   mlvfs/stripes.c:250-266
 //
-// Work decomposition (gfx950: 256 CUs, 8 XCDs, wave64, 160 KiB LDS/CU):
-//   * tile = 64 x 16 Bayer cells (128 x 32 px) per 256-thread workgroup, halo 2 cells;
-//     39 KiB of LDS and <= 128 VGPRs so that FOUR workgroups (16 waves) share a CU and
-//     cover each other's barriers, LDS and HBM latencies
-//   * LOADER: one thread = one "item" = 8 cells (2 rows x 16 px, i.e. 2 x 28 B of
-//     packed stream as 7 dwords each).  It unpacks in registers and writes, per
-//     cell, the EV triple {ge, dr = ev(R)-ge, db = ev(B)-ge} to LDS planes (the
-//     planes are what the medians run on; every pixel's EV is computed once).
-//     The 2-cell halo columns left and right are separate small "edge" items.
-//     The packed dwords of the NEXT tile are prefetched into registers before
-//     the median phase, so HBM latency hides behind the selection networks.
-//   * MEDIANS: one thread = a strip of 4 horizontally adjacent cells with shared
-//     column sorts / pair merges / quad selections (median_nets.h), 10 ds_read_b128
-//     per plane, conflict-free lane -> (row, strip) map.
+// Work decomposition (gfx950: 256 CUs, 8 XCDs, wave64, 160 KiB LDS/CU), round 4:
+//   * tile = 64 x 15 Bayer cells (128 x 30 px) per 256-thread workgroup, halo 2 cells; 39.7 KiB of LDS and <= 128 VGPRs so that
+//     FOUR workgroups (16 waves) share a CU and cover each other's barriers, LDS and HBM latencies
+//   * a workgroup walks DOWN a column of tiles (tile list in column-major order, handed out in runs): the four plane rows
+//     the next tile shares with this one -- and the pixels and green EVs of the two of them that are the next tile's first
+//     rows -- stay in LDS, so every pixel's EV is computed once per column instead of 19/15 times, and only the first tile of a
+//     run loads its upper halo
+//   * LOADER: one thread = one "item" = 4 cells (2 rows x 8 px = 2 x 14 B of packed stream, fetched as 2 x 2 dwords per row);
+//     15 rows x (16 items + 1 edge item for the halo columns) = 255 items: every wave converts, none waits.  It unpacks in
+//     registers and writes, per cell, the EV triple {ge, dr = ev(R)-ge, db = ev(B)-ge} to LDS planes (the planes are what the
+//     medians run on).  The packed dwords of the NEXT tile are prefetched into registers before the median phase, so HBM
+//     latency hides behind the selection networks.
+//   * MEDIANS: one thread = a strip of 4 horizontally adjacent cells; 5x5: 17 lanes per tile row (16 strips + the halo group),
+//     neighbour sharing through DPP (see strip_chain_*)
 //   * raw2ev lives in LDS as the 8192-entry mantissa-normalised 16-bit table (common.h),
-//     ev2raw's 64 KiB table is gathered from L2 (all gathers of a strip in flight at once)
+//     the output pixel by EV is one 16-bit look-up in a per-black table served from L2
 //   * pixel-map patches: per-tile lists of repaired cells (built once per clip on the host; values per frame: k_pixfix_cells)
 //     recompute just the cells they touch
-//   * persistent workgroups; the four residents of a CU draw tiles by ticket from that CU's contiguous
-//     range of the tile list (the ranges of an XCD's CUs adjacent, so halo re-reads hit its own L2)
+//   * persistent workgroups; the four residents of a CU draw runs of tiles from that CU's contiguous range of the tile list
+//     (the ranges of an XCD's CUs adjacent, so halo re-reads hit its own L2), the last tiles of a range one by one
 // No MFMA: this is a stencil / gather / selection path.
 #include "clip.h"
 #include <cstdlib>
@@ -49,15 +49,22 @@ __device__ __forceinline__ mlv_pk16 mlv_max_(mlv_pk16 a, mlv_pk16 b) { return __
 #define mlv_mx(a, b) mlv_max_((a), (b))
 #include "median_nets.h"
 
+
 namespace mlv {
 
 constexpr int TCW = FRAME_TCW;          // tile width  in cells (64)
+constexpr int TCH = FRAME_TCH;          // tile height in cells (15): 15 rows x 17 lanes = 255 of the 256 threads
 constexpr int HC = FRAME_HC;            // halo in cells (2)
 constexpr int PW = TCW + 2 * HC;        // plane width  (68)
+constexpr int PH = TCH + 2 * HC;        // plane height (19)
+constexpr int RH = TCH + HC;            // rows of interior pixels / green EVs kept: the tile's own and the first two of the tile below
 constexpr int STRIP = 4;                // cells per thread in the median phase
-constexpr int GROUPS = TCW / 8;         // full items per plane row (8)
+constexpr int GROUPS = TCW / 4;         // loader items (8 px) per tile row (16)
+constexpr int N_MAIN = TCH * GROUPS;    // threads 0..239: item (row t / 16, group t % 16); threads 240..254: edge item of row t - 240
+constexpr int N_ITEMS = N_MAIN + TCH;
+constexpr int N_TOP_MAIN = 2 * HC * GROUPS, N_TOP = N_TOP_MAIN + 2 * HC;      // first tile of a run: the four rows above, threads 0..67
 #ifndef KF_DARK_ITEMS_MIN
-#define KF_DARK_ITEMS_MIN 16
+#define KF_DARK_ITEMS_MIN 24
 #endif
 constexpr int DARK_ITEMS_MIN = KF_DARK_ITEMS_MIN;      // of the loader items of a tile
 #ifndef KF_FB_ROBUST
@@ -75,14 +82,13 @@ constexpr int FB_WAIT_MIN = KF_FB_WAIT_MIN, FB_WAIT_MAX = KF_FB_WAIT_MAX;     //
 #define KF_FB_DIRECT 60
 #endif
 constexpr int FB_DIRECT = KF_FB_DIRECT;          // 5x5: more uncertain strips than this (of 240): the next tiles go to the 32-bit networks directly
-constexpr int PMAP_WORDS = 64;          // tiles per frame covered by the LDS patch bitmap: 2048 (3584x1320 has 1176 / 1232)
-// Tile height in cells: 16 rows of 16 strips fill the 256 threads; 5x5 tiles have 15 rows, the 16 lanes that this frees
-// compute the right-hand halo group of every row for the neighbour-sharing medians (strip_chain_*, below).
-constexpr int tile_rows_of(int method) { return method == 5 ? FRAME_TCH5 : FRAME_TCH; }
+constexpr int PMAP_WORDS = 64;          // tiles per frame covered by the LDS patch bitmap: 2048 (3584x1320 has 1232)
+static_assert(N_ITEMS <= 255 && TCH * 17 <= 256 && N_TOP <= 128, "one item per thread; 17 median lanes per tile row");
 
 struct FrameArgs {
     const uint8_t *src;      // packed stream or u16 frames
     size_t src_stride;       // bytes between frames
+    unsigned src_bytes;      // bytes of one frame (rounded up to a dword): the range the loader's buffer loads are checked against
     uint8_t *dst;
     size_t dst_stride;
     int w, h, black, white;
@@ -99,8 +105,9 @@ struct FrameArgs {
     int coef_fast;           // all |coef - 65536| < 32768: 32-bit epilogue
     int coef_pk;             // additionally 14-bit input, white > black + 64, black <= 16384: packed 16-bit epilogue
     int patch, stripes;      // wave-uniform stage switches
-    int *tickets;            // [groups] next tile of each group's range + [1] workgroups done (the last one zeroes them all)
+    int *tickets;            // per group: [2g] tiles handed out in runs, [2g + 1] tiles handed out singly; [2 groups] workgroups done (the last one zeroes them all)
     int groups;              // workgroups b, b + groups, b + 2 groups, ... form a group (one CU's residents) and share a tile range
+    int run, singles;        // tiles per run; tiles at the end of a group's range that go out one by one
 #ifdef KF_DIAG_TIMES
     unsigned long long *times;
 #endif
@@ -126,29 +133,24 @@ constexpr int E2R_ENTRIES = 14 * MLV_EV_RES;
 // SPREAD: the T16 table with entry i at i + (i >> 7).  A pixel below 2^e above black uses only every 2^(13-e)-th entry, so
 // the look-ups of dark footage crowd into a few LDS banks (below 128 DN: one); the spread form puts those entries into
 // different banks for two more operations per pixel.  Chosen per clip from its first frame (launch_frame's `spread`).
-constexpr int XCHG_WORDS = 28;          // per tile row: what the halo group lane hands to the last strip of the row (7 x 16 bytes)
-template <bool SPREAD_, int TCH_>
+constexpr int XCHG_WORDS = 28;          // what the first lane of a wave hands to the last lane of the wave before it (7 x 16 bytes)
+template <bool SPREAD_, bool CHAIN_>
 struct __align__(16) SmemT {
     static constexpr bool SPREAD = SPREAD_;
-    static constexpr int TCH = TCH_;                    // tile height in cells
-    static constexpr int PH = TCH_ + 2 * HC;            // plane height
-    static constexpr int N_FULL = PH * GROUPS;          // full loader items per tile (threads 0 .. N_FULL-1)
-    static constexpr int N_ITEMS = N_FULL + PH;         // + one edge item per plane row
-    static constexpr bool CHAIN = TCH_ == FRAME_TCH5;   // the 5x5 geometry
-    uint16_t raw[2 * TCH][2 * TCW];     // interior pixels (post patch), 8 KiB
-    int dr[PH][PW];                     // 5.3 KiB
+    static constexpr bool CHAIN = CHAIN_;               // 5x5: neighbour-sharing medians
+    uint16_t raw[2 * RH][2 * TCW];      // interior pixels (post patch) + the four pixel rows below (the next tile's first), 8.5 KiB
+    int dr[PH][PW];                     // 5 KiB
     int db[PH][PW];
-    int ge[TCH][TCW];                   // 4 KiB
+    int ge[RH][TCW];                    // 4.25 KiB
     uint16_t t16[MLV_T16_N + (SPREAD_ ? 64 : 0)];   // mantissa-normalised raw2ev (common.h), 16 KiB
     uint32_t has_patch[PMAP_WORDS];     // one bit per tile of a frame: some pixel-map entry touches it
-    uint32_t xchg[CHAIN ? TCH_ : 1][XCHG_WORDS];     // 5x5: sorted columns / pair list / rank window of each row's halo group
-    uint8_t fb_queue[CHAIN ? 256 : 4];  // 5x5: strips whose packed medians are not certain (row * 16 + strip), settled densely
+    uint32_t xchg[CHAIN_ ? 3 : 1][XCHG_WORDS];      // 5x5: sorted columns / pair list / rank window of the group held by lane 0 of waves 1..3
+    uint8_t fb_queue[CHAIN_ ? 256 : 4]; // 5x5: strips whose packed medians are not certain (row * 16 + strip), settled densely
     int fb_count;
-    int next_ticket;
+    int next_tile, next_end;            // the tile after this one and the end of the run it belongs to (thread 0 -> all)
     int dark_items[2];                  // loader items of the current / next tile that hold pixels at or below black (5x5 only)
 };
-static_assert(SmemT<false, FRAME_TCH>::N_ITEMS <= 256 && FRAME_TCH * (TCW / STRIP) == 256, "one item and one strip per thread");
-static_assert(SmemT<false, FRAME_TCH5>::N_ITEMS <= 256 && FRAME_TCH5 * (TCW / STRIP) + FRAME_TCH5 <= 256, "strips + one halo-group lane per row");
+static_assert(sizeof(SmemT<true, true>) <= 40 * 1024, "four workgroups per CU need <= 40 KiB of LDS each");
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
 // vector-memory counter, which would stall every wave on its own global stores (and
@@ -308,52 +310,104 @@ __device__ __forceinline__ void cell_ev(int r, int g1, int g2, int b, int black,
     ge = g[0]; dr = a[0]; db = c[0];
 }
 
+
 // ---------------------------------------------------------------- loader
-// Thread t < 160 owns the full item (plane row t/8, group t%8); threads 160..179 own the
-// edge item (two halo cells left + right) of plane row t-160.  An item is NW dwords per
-// row in plain register arrays.  An edge item loads the two dwords that hold the right
-// halo's first 4 px into positions 0,1 and the two dwords that hold the left halo's last
-// 4 px into the last two positions, so the SAME unpack yields right halo = px 0..3 and
-// left halo = px 12..15: one uniform code path, no per-lane variant of the register layout.
-template <bool PACKED> struct Words { static constexpr int N = PACKED ? 7 : 8; };
+// An item is 8 pixels on two rows = 4 Bayer cells: 2 x 14 bytes of the 14-bit stream (2 x 16 bytes of a 16-bit frame), fetched as
+// two 8-byte loads per row into d[0..1] and d[2..3].
+//   main item : the 8-pixel group at (x, y).  A group starts at an even byte of the stream: dword-aligned ("aligned": d = the 16
+//               bytes from the group's first byte) or in the upper half of a dword ("mis": d = the 16 bytes from two bytes BEFORE
+//               the group).  Which of the two depends on the group's number in its row and -- widths that are a multiple of 8 but
+//               not of 16 (1736: the 3x crop of most APS-C bodies; 1880: the 5D2) -- on the row's parity.
+//   edge item : d[0..1] = the 8 bytes that hold the four pixels RIGHT of the tile (the first 56 bits of their group), d[2..3] = the
+//               8 bytes that hold the four pixels LEFT of it (the last 56 bits of theirs), each at its exact (even) byte address.
+// Three v_perm selectors per lane turn d into the stream words S0..S3 (MSB-first) that hold the item's 112 bits, and the same
+// eight bit-field extractions yield px 0..7 for every lane -- of an edge item px 0..3 = right halo, px 4..7 = left halo: one
+// code path, no per-lane variant of the register layout.
+typedef uint32_t mlv_u32x2 __attribute__((ext_vector_type(2)));
+__device__ mlv_u32x2 mlv_rbl_x2(mlv_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2i32");
+// one frame as a raw buffer: loads are range-checked by the address unit (an offset beyond the frame reads zeros, never faults)
+__device__ __forceinline__ mlv_i32x4 frame_rsrc(const void *p, unsigned bytes)
+{
+    const unsigned long long a = (unsigned long long)p;
+    mlv_i32x4 r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)((unsigned)(a >> 32) & 0xFFFFu);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// byte offset of the 16-px group starting at pixel (x, y) inside a frame
-// (32-bit: a frame has fewer than 2^28 pixels, checked by the launcher; the 64-bit form cost ten 64-bit multiply-adds per prefetch)
-template <bool PACKED>
-__device__ __forceinline__ uint32_t group_offset(int w, int x, int y)
+constexpr uint32_t SEL_SWAP = 0x01000302u;      // v_perm_b32(nxt, d, .): the halves of d swapped
+constexpr uint32_t SEL_MIS = 0x03020504u;       //                        (d & 0xFFFF0000) | (nxt & 0xFFFF)
+constexpr uint32_t SEL_EDGE1 = 0x01000304u;     //                        halves of d swapped, lowest byte from nxt
+
+// what a lane's item is, for the whole kernel (x offsets of the two loads relative to the tile; how their byte offsets are formed)
+struct ItemLane {
+    int xoff_a, xoff_b;      // main: 8 * group both; edge: 128 (right of the tile), -8 (the group whose last four pixels lie left of it)
+    uint32_t amask;          // main: ~3 (loads start at the dword that holds the group's first byte); edge: ~0 (exact)
+    uint32_t boff;           // second load: main: first + 8; edge: group b + 6
+    uint32_t s0, s1, s23;    // v_perm selectors on an even row
+    uint32_t flip;           // w % 16 == 8: what an odd row changes about them (main items: aligned <-> mis)
+    bool edge;
+};
+
+template <bool PACKED, int VEC>
+__device__ __forceinline__ ItemLane item_lane(int lk, bool edge)
 {
-    const uint32_t px = (uint32_t)y * (uint32_t)w + (uint32_t)x;
-    return PACKED ? (px >> 4) * 28u : px * 2u;
+    ItemLane L;
+    L.edge = edge;
+    L.xoff_a = edge ? 2 * TCW : 8 * lk;
+    L.xoff_b = edge ? -8 : 8 * lk;
+    L.amask = edge ? ~0u : ~3u;
+    L.boff = (PACKED && edge) ? 6u : 8u;
+    // rows of a tile start at a multiple of 128 pixels = 224 bytes: on an even row group lk is aligned when lk is even
+    // (w % 16 == 8: odd rows start two bytes into a dword, so there it is the other way round)
+    const bool mis = (lk & 1) != 0;
+    L.s0 = edge ? SEL_SWAP : (mis ? SEL_MIS : SEL_SWAP);
+    L.s1 = edge ? SEL_EDGE1 : L.s0;
+    L.s23 = edge ? SEL_MIS : L.s0;
+    L.flip = (VEC == 2 && !edge) ? (SEL_SWAP ^ SEL_MIS) : 0u;
+    return L;
 }
 
-template <bool PACKED, int N_FULL>
-__device__ __forceinline__ void issue_item(uint32_t (&r0)[Words<PACKED>::N], uint32_t (&r1)[Words<PACKED>::N],
-                                           const uint8_t *frame, int w, int h, int tx0, int ty0, int tid)
+// byte offsets, inside the frame, of the two loads of one row of an item
+template <bool PACKED>
+__device__ __forceinline__ void item_offsets(const ItemLane &L, int w, int tx0, int yy, uint32_t &oa, uint32_t &ob)
 {
-    constexpr int N = Words<PACKED>::N;
-    const bool edge = tid >= N_FULL;
-    const int pr = edge ? tid - N_FULL : tid >> 3;
-    const int y = ty0 - 2 * HC + 2 * pr;
-    const int x_main = edge ? clampi(tx0 - 16, 0, w - 16) : clampi(tx0 + 16 * (tid & 7), 0, w - 16);
-    const int x_right = clampi(tx0 + 2 * TCW, 0, w - 16);
-#pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const int yy = clampi(y + rr, 0, h - 1);
-        const uint32_t *sm_ = (const uint32_t *)(frame + group_offset<PACKED>(w, x_main, yy));
-        const uint32_t *sr_ = (const uint32_t *)(frame + group_offset<PACKED>(w, x_right, yy));
-        uint32_t (&r)[N] = rr ? r1 : r0;
-#pragma unroll
-        for (int i = 0; i < N; i++) r[i] = ((edge && i < 2) ? sr_ : sm_)[i];
+    const int xa = min(tx0 + L.xoff_a, w - 8), xb = max(min(tx0 + L.xoff_b, w - 8), 0);
+    const uint32_t row = (uint32_t)yy * (uint32_t)w;           // < 2^28 pixels per frame (launcher)
+    if (PACKED) {
+        const uint32_t ga = ((row + (uint32_t)xa) >> 3) * 14u, gb = ((row + (uint32_t)xb) >> 3) * 14u;
+        oa = ga & L.amask;
+        ob = (L.edge ? gb : oa) + L.boff;
+    } else {
+        oa = (row + (uint32_t)xa) * 2u;
+        ob = (L.edge ? (row + (uint32_t)xb) * 2u : oa) + 8u;
     }
 }
 
-__device__ __forceinline__ uint32_t sw16(uint32_t d) { return (d << 16) | (d >> 16); }
+// plane row p of the tile at (tx0, ty0): the item's two pixel rows into d0 / d1
+template <bool PACKED>
+__device__ __forceinline__ void issue_item(uint32_t (&d0)[4], uint32_t (&d1)[4], mlv_i32x4 rs, const ItemLane &L, int w, int h, int tx0,
+                                           int ty0, int p)
+{
+    const int y = ty0 - 2 * HC + 2 * p;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int yy = clampi(y + rr, 0, h - 1);
+        uint32_t oa, ob;
+        item_offsets<PACKED>(L, w, tx0, yy, oa, ob);
+        const mlv_u32x2 a = mlv_rbl_x2(rs, (int)oa, 0, 0), b = mlv_rbl_x2(rs, (int)ob, 0, 0);
+        uint32_t (&d)[4] = rr ? d1 : d0;
+        d[0] = a.x; d[1] = a.y; d[2] = b.x; d[3] = b.y;
+    }
+}
 
-// pixel K (0..15) of a 16-pixel group from its seven MSB-first stream words
+// pixel K (0..7) of an item from its four MSB-first stream words
 template <int K>
-__device__ __forceinline__ uint32_t px14(const uint32_t (&s)[7])
+__device__ __forceinline__ uint32_t px14(const uint32_t (&s)[4])
 {
     constexpr int bit = 14 * K, wi = bit >> 5, sh = bit & 31;
     if constexpr (sh + 14 <= 32) return (s[wi] >> (32 - 14 - sh)) & 0x3FFFu;
@@ -361,96 +415,19 @@ __device__ __forceinline__ uint32_t px14(const uint32_t (&s)[7])
 }
 
 template <bool PACKED>
-__device__ __forceinline__ void unpack16(const uint32_t (&d)[Words<PACKED>::N], uint32_t (&px)[16])
+__device__ __forceinline__ void unpack8(const uint32_t (&d)[4], uint32_t s0, uint32_t s1, uint32_t s23, uint32_t (&px)[8])
 {
     if constexpr (PACKED) {
-        uint32_t s[7];
-#pragma unroll
-        for (int i = 0; i < 7; i++) s[i] = sw16(d[i]);
-        px[0] = px14<0>(s);   px[1] = px14<1>(s);   px[2] = px14<2>(s);   px[3] = px14<3>(s);
-        px[4] = px14<4>(s);   px[5] = px14<5>(s);   px[6] = px14<6>(s);   px[7] = px14<7>(s);
-        px[8] = px14<8>(s);   px[9] = px14<9>(s);   px[10] = px14<10>(s); px[11] = px14<11>(s);
-        px[12] = px14<12>(s); px[13] = px14<13>(s); px[14] = px14<14>(s); px[15] = px14<15>(s);
+        uint32_t s[4];
+        s[0] = __builtin_amdgcn_perm(d[1], d[0], s0);
+        s[1] = __builtin_amdgcn_perm(d[2], d[1], s1);
+        s[2] = __builtin_amdgcn_perm(d[3], d[2], s23);
+        s[3] = __builtin_amdgcn_perm(d[3], d[3], s23);
+        px[0] = px14<0>(s); px[1] = px14<1>(s); px[2] = px14<2>(s); px[3] = px14<3>(s);
+        px[4] = px14<4>(s); px[5] = px14<5>(s); px[6] = px14<6>(s); px[7] = px14<7>(s);
     } else {
 #pragma unroll
-        for (int k = 0; k < 8; k++) { px[2 * k] = d[k] & 0xFFFFu; px[2 * k + 1] = d[k] >> 16; }
-    }
-}
-
-// ---- widths that are a multiple of 8 but not of 16 (1736: the 3x crop of most APS-C bodies; 1880: the 5D2).  Rows then start
-// alternately at a 16-pixel group and in the middle of one: a 14-bit group begins 14 bytes into the stream words of the pair it
-// shares (dword-aligned address minus 2), and the row's last group has eight pixels in the frame.  Everything else -- item =
-// 16 pixels x 2 rows, strips of 8 pixels, vector stores -- is the w % 16 == 0 path.  (Until round 3 such widths took the any-geometry
-// path, a load per pixel: cs5x5 9.6 us per 1736x976 frame where 1728 takes 3.5.)
-struct Half8 {                     // where one row of an item comes from
-    uint32_t at;                   // byte offset in the frame of the first dword to load
-    bool mis;                      // packed stream: the group starts in the upper half of that dword
-    bool shift8;                   // the window lies 8 pixels further left than the item (the last row's half group): take pixels 8..15
-};
-// x: a multiple of 16, or beyond the frame; yy: a row of the frame.  whole: all 16 pixels are loaded (of a right halo only the first
-// 12 bytes, which lie inside the frame wherever the group starts)
-template <bool PACKED>
-__device__ __forceinline__ Half8 half8_row(int w, int h, int x, int yy, bool whole)
-{
-    Half8 r;
-    x = x < 0 ? 0 : (x >= w ? w - 16 : x);               // (beyond the frame: any group of the row will do)
-    r.shift8 = whole && (yy == h - 1) && (x == w - 8);   // its 16 pixels would run past the end of the frame
-    if (r.shift8) x -= 8;
-    const uint32_t px = (uint32_t)yy * (uint32_t)w + (uint32_t)x;      // a multiple of 8
-    const uint32_t byte = PACKED ? (px >> 3) * 14u : px * 2u;
-    r.mis = PACKED && (byte & 2u);
-    r.at = PACKED ? (byte & ~3u) : byte;
-    return r;
-}
-// t0 / t1: the 16 stream bits behind the seven dwords of each row (a misaligned group ends there)
-template <bool PACKED, int N_FULL>
-__device__ __forceinline__ void issue_item_half8(uint32_t (&r0)[Words<PACKED>::N], uint32_t (&r1)[Words<PACKED>::N], uint32_t &t0, uint32_t &t1,
-                                                 const uint8_t *frame, int w, int h, int tx0, int ty0, int tid)
-{
-    constexpr int N = Words<PACKED>::N;
-    const bool edge = tid >= N_FULL;
-    const int pr = edge ? tid - N_FULL : tid >> 3;
-    const int y = ty0 - 2 * HC + 2 * pr;
-    const int x_main = edge ? tx0 - 16 : tx0 + 16 * (tid & 7), x_right = tx0 + 2 * TCW;
-#pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const int yy = clampi(y + rr, 0, h - 1);
-        const Half8 m = half8_row<PACKED>(w, h, x_main, yy, true), r = half8_row<PACKED>(w, h, x_right, yy, false);
-        const uint32_t *sm_ = (const uint32_t *)(frame + m.at);
-        const uint32_t *sr_ = (const uint32_t *)(frame + r.at);
-        uint32_t (&d)[N] = rr ? r1 : r0;
-        // edge items: the right halo's four pixels are the first 56 bits of its group -- dwords 0, 1 and, when the group is
-        // misaligned, the lower half of dword 2 --, the left halo's the last 56 of its own (dwords 5, 6 and the tail)
-#pragma unroll
-        for (int i = 0; i < N; i++) d[i] = ((edge && i < (PACKED ? 3 : 2)) ? sr_ : sm_)[i];
-        if (PACKED) (rr ? t1 : t0) = *(const uint16_t *)((const uint8_t *)sm_ + (m.mis ? 28 : 24));
-    }
-}
-// the seven MSB-first stream words of a group from seven dwords + tail; nxt_sel / own_sel: v_perm selectors of a misaligned / aligned group
-__device__ __forceinline__ uint32_t half8_word(uint32_t d, uint32_t nxt, bool mis)
-{
-    return __builtin_amdgcn_perm(nxt, d, mis ? 0x03020504u : 0x01000302u);      // (d & 0xFFFF0000) | (nxt & 0xFFFF)  :  halves of d swapped
-}
-template <bool PACKED>
-__device__ __forceinline__ void unpack16_half8(const uint32_t (&d)[Words<PACKED>::N], uint32_t tail, bool edge, Half8 m, Half8 r, uint32_t (&px)[16])
-{
-    if constexpr (PACKED) {
-        uint32_t s[7];
-#pragma unroll
-        for (int i = 0; i < 7; i++) s[i] = half8_word(d[i], i < 6 ? d[i + 1] : tail, (edge && i < 2) ? r.mis : m.mis);
-        px[0] = px14<0>(s);   px[1] = px14<1>(s);   px[2] = px14<2>(s);   px[3] = px14<3>(s);
-        px[4] = px14<4>(s);   px[5] = px14<5>(s);   px[6] = px14<6>(s);   px[7] = px14<7>(s);
-        px[8] = px14<8>(s);   px[9] = px14<9>(s);   px[10] = px14<10>(s); px[11] = px14<11>(s);
-        px[12] = px14<12>(s); px[13] = px14<13>(s); px[14] = px14<14>(s); px[15] = px14<15>(s);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; k++) { px[2 * k] = d[k] & 0xFFFFu; px[2 * k + 1] = d[k] >> 16; }
-    }
-    // the frame's last row: a window that was moved 8 pixels to the left (one item per frame; the left halo never is such a group)
-    const bool sh = m.shift8 && !edge;
-    if (__any(sh)) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) px[k] = sh ? px[k + 8] : px[k];
+        for (int k = 0; k < 4; k++) { px[2 * k] = d[k] & 0xFFFFu; px[2 * k + 1] = d[k] >> 16; }
     }
 }
 
@@ -470,76 +447,56 @@ __device__ __forceinline__ uint32_t fetch_clamped(const uint8_t *frame, int w, i
     return ((const uint16_t *)frame)[i];
 }
 
-// slow path (w % 16 != 0): fill the two pixel rows of an item pixel by pixel
+// slow path (w % 8 != 0, unaligned buffers): fill the two pixel rows of an item pixel by pixel
 template <bool PACKED>
-__device__ __forceinline__ void fetch_rows(const uint8_t *frame, int w, int h, int x, int y, bool edge, int tx0,
-                                           uint32_t (&p0)[16], uint32_t (&p1)[16])
+__device__ __forceinline__ void fetch_rows(const uint8_t *frame, int w, int h, int tx0, int lk, int y, bool edge, uint32_t (&p0)[8],
+                                           uint32_t (&p1)[8])
 {
 #pragma unroll 1
-    for (int k = 0; k < 16; k++) {
-        // edge items: px 0..3 = right halo, px 12..15 = left halo (same layout as the fast path)
-        const int xx = edge ? (k < 4 ? tx0 + 2 * TCW + k : tx0 - 16 + k) : x + k;
+    for (int k = 0; k < 8; k++) {
+        // edge items: px 0..3 = right halo, px 4..7 = left halo (same layout as the fast path)
+        const int xx = edge ? (k < 4 ? tx0 + 2 * TCW + k : tx0 - 8 + k) : tx0 + 8 * lk + k;
         p0[k] = fetch_clamped<PACKED>(frame, w, h, xx, y);
         p1[k] = fetch_clamped<PACKED>(frame, w, h, xx, y + 1);
     }
 }
 
-// EV triples of NCELL (even) cells into the planes: plane row r, first plane column col0
-template <int NCELL, class SM>
-__device__ __forceinline__ void store_cells(SM &sm, int black, bool slow, int r, int col0, const uint32_t *p0, const uint32_t *p1)
-{
-    const bool row_in = r >= HC && r < HC + SM::TCH;
-    if (NCELL == 8 && !slow) {                           // wave-uniform; against pairs: cs2x2 -2.5 %, cs5x5 -2 %; all eight at once: no better
-#pragma unroll
-        for (int c = 0; c < 8; c += 4) {
-            int ge[4], dr[4], db[4];
-            cell_multi_ev_fast<4, SM::SPREAD>(p0 + 2 * c, p1 + 2 * c, black, sm.t16, ge, dr, db);
-            *(int4 *)&sm.dr[r][col0 + c] = make_int4(dr[0], dr[1], dr[2], dr[3]);
-            *(int4 *)&sm.db[r][col0 + c] = make_int4(db[0], db[1], db[2], db[3]);
-            if (row_in) *(int4 *)&sm.ge[r - HC][col0 + c - HC] = make_int4(ge[0], ge[1], ge[2], ge[3]);
-        }
-        return;
-    }
-#pragma unroll
-    for (int c = 0; c < NCELL; c += 2) {
-        int ge[2], dr[2], db[2];
-        cell_pair_ev<SM::SPREAD>(p0 + 2 * c, p1 + 2 * c, black, sm.t16, slow, ge, dr, db);
-        *(int2 *)&sm.dr[r][col0 + c] = make_int2(dr[0], dr[1]);
-        *(int2 *)&sm.db[r][col0 + c] = make_int2(db[0], db[1]);
-        const int ci = col0 + c - HC;
-        if (row_in && ci >= 0 && ci < TCW) *(int2 *)&sm.ge[r - HC][ci] = make_int2(ge[0], ge[1]);
-    }
-}
-
-template <class SM>
-__device__ __forceinline__ void store_raw(SM &sm, int row, int g, const uint32_t (&p)[16])
-{
-    uint4 *o = (uint4 *)&sm.raw[row][16 * g];
-    o[0] = make_uint4(p[0] | (p[1] << 16), p[2] | (p[3] << 16), p[4] | (p[5] << 16), p[6] | (p[7] << 16));
-    o[1] = make_uint4(p[8] | (p[9] << 16), p[10] | (p[11] << 16), p[12] | (p[13] << 16), p[14] | (p[15] << 16));
-}
-
-// pixels of one item -> planes (+ interior raw)
+// pixels of one item -> planes (+ the interior pixels and green EVs of the rows that have them).  p: plane row
 template <int METHOD, class SM>
-__device__ __forceinline__ void emit_item(SM &sm, int black, bool slow, int pr, int g, bool edge, const uint32_t (&p0)[16],
-                                          const uint32_t (&p1)[16])
+__device__ __forceinline__ void emit_item(SM &sm, int black, bool slow, int p, int lk, bool edge, const uint32_t (&p0)[8],
+                                          const uint32_t (&p1)[8])
 {
-    if (!edge) {
-        if (METHOD != 0) store_cells<8, SM>(sm, black, slow, pr, HC + 8 * g, p0, p1);
-        if (pr >= HC && pr < HC + SM::TCH) {
-            store_raw(sm, 2 * (pr - HC), g, p0);
-            store_raw(sm, 2 * (pr - HC) + 1, g, p1);
+    const int jj = p - HC;                               // >= 0: a row whose pixels are output by this tile or the one below
+    const bool keep = !edge && jj >= 0;
+    if (METHOD != 0) {
+        int ge[4], dr[4], db[4];
+        if (!slow) cell_multi_ev_fast<4, SM::SPREAD>(p0, p1, black, sm.t16, ge, dr, db);       // wave-uniform
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; c += 2) {
+                int g2[2], r2[2], b2[2];
+                cell_pair_ev<SM::SPREAD>(p0 + 2 * c, p1 + 2 * c, black, sm.t16, true, g2, r2, b2);
+                ge[c] = g2[0]; ge[c + 1] = g2[1]; dr[c] = r2[0]; dr[c + 1] = r2[1]; db[c] = b2[0]; db[c + 1] = b2[1];
+            }
         }
-    } else if (METHOD != 0) {
-        store_cells<2, SM>(sm, black, slow, pr, 0, p0 + 12, p1 + 12);    // left halo  (px 12..15)
-        store_cells<2, SM>(sm, black, slow, pr, HC + TCW, p0, p1);       // right halo (px 0..3)
+        // main item: plane columns HC + 4 lk ..; edge item: cells 0, 1 = right halo, cells 2, 3 = left halo
+        const int ca = edge ? PW - HC : HC + 4 * lk, cb = edge ? 0 : ca + 2;
+        *(int2 *)&sm.dr[p][ca] = make_int2(dr[0], dr[1]);
+        *(int2 *)&sm.dr[p][cb] = make_int2(dr[2], dr[3]);
+        *(int2 *)&sm.db[p][ca] = make_int2(db[0], db[1]);
+        *(int2 *)&sm.db[p][cb] = make_int2(db[2], db[3]);
+        if (keep) *(int4 *)&sm.ge[jj][4 * lk] = make_int4(ge[0], ge[1], ge[2], ge[3]);
+    }
+    if (keep) {
+        *(uint4 *)&sm.raw[2 * jj][8 * lk] = make_uint4(p0[0] | (p0[1] << 16), p0[2] | (p0[3] << 16), p0[4] | (p0[5] << 16), p0[6] | (p0[7] << 16));
+        *(uint4 *)&sm.raw[2 * jj + 1][8 * lk] = make_uint4(p1[0] | (p1[1] << 16), p1[2] | (p1[3] << 16), p1[4] | (p1[5] << 16), p1[6] | (p1[7] << 16));
     }
 }
 
 // ---------------------------------------------------------------- pixel map
-// A tile's repaired cells arrive as records {cell, R | G1 << 16, G2 | B << 16} (k_pixfix_cells): the EV triple of a record is
-// computed by a lane that has no loader item (the fourth wave, while the other three convert the tile), and goes into the
-// planes -- with the four pixels into the interior raw tile -- once the loader's stores are behind a barrier.
+// A tile's repaired cells arrive as records {cell, R | G1 << 16, G2 | B << 16} (k_pixfix_cells): a record's EV triple goes into the
+// planes -- with the four pixels into the interior pixel rows -- once the loader's stores are behind a barrier.  (A tile's list
+// covers its halo too, so the rows a tile hands down to the one below are patched again there: same values.)
 struct PatchCell { int i, j, ge, dr, db; uint32_t top, bot; };      // i < 0: nothing to store
 
 template <int METHOD, bool PACKED, class SM>
@@ -551,7 +508,7 @@ __device__ __forceinline__ PatchCell patch_cell(const SM &sm, const FrameArgs &a
     const bool have = rec.x >= 0;
     const int cx = rec.x & 0xFFFF, cy = rec.x >> 16;
     const int i = cx - (tx0 / 2 - HC), j = cy - (ty0 / 2 - HC);
-    if (have && i >= 0 && i < PW && j >= 0 && j < SM::PH) { c.i = i; c.j = j; }
+    if (have && i >= 0 && i < PW && j >= 0 && j < PH) { c.i = i; c.j = j; }
     if (METHOD != 0) {
         const int px[4] = { (int)(c.top & 0xFFFFu), (int)(c.top >> 16), (int)(c.bot & 0xFFFFu), (int)(c.bot >> 16) };
         bool odd = false;
@@ -573,7 +530,7 @@ __device__ __forceinline__ void patch_store(SM &sm, const PatchCell &c)
         sm.db[c.j][c.i] = c.db;
     }
     const int ii = c.i - HC, jj = c.j - HC;
-    if (ii >= 0 && ii < TCW && jj >= 0 && jj < SM::TCH) {
+    if (ii >= 0 && ii < TCW && jj >= 0 && jj < RH) {
         if (METHOD != 0) sm.ge[jj][ii] = c.ge;
         *(uint32_t *)&sm.raw[2 * jj][2 * ii] = c.top;
         *(uint32_t *)&sm.raw[2 * jj + 1][2 * ii] = c.bot;
@@ -997,12 +954,12 @@ __device__ __forceinline__ void stripe_strip_pk(uint32_t (&top)[STRIP], uint32_t
     }
 }
 
+
 template <int METHOD, bool PACKED, int VEC, bool SPREAD>
 __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 {
-    using Smem = SmemT<SPREAD, tile_rows_of(METHOD)>;
-    constexpr int TCH = Smem::TCH, N_FULL = Smem::N_FULL, N_ITEMS = Smem::N_ITEMS;
-    constexpr bool CHAIN = Smem::CHAIN;
+    constexpr bool CHAIN = METHOD == 5;
+    using Smem = SmemT<SPREAD, CHAIN>;
     __shared__ Smem sm;                                  // static: a compile-time LDS base (a dynamic one costs an add per access)
 
     if (METHOD != 0) {
@@ -1025,13 +982,15 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             if (a.tile_off[i + 1] != a.tile_off[i]) atomicOr(&sm.has_patch[i >> 5], 1u << (i & 31));
     }
 
-    // Persistent tile walk.  Group g = blockIdx % groups: with 4 x CUs workgroups in the grid the dispatcher puts blocks
+    // Persistent tile walk.  The tile list runs DOWN the columns of a frame (tile tt of a frame: column tt / tiles_y, row tt %
+    // tiles_y), frame after frame.  Group g = blockIdx % groups: with 4 x CUs workgroups in the grid the dispatcher puts blocks
     // b, b + CUs, b + 2 CUs, b + 3 CUs on one CU (tools/hwid_probe.hip), so a group is one CU's four residents.  Each group
     // owns a contiguous range of the tile list -- the groups of an XCD (blocks b, b + 8, ... share one) next to each other,
-    // so halo re-reads hit that XCD's L2 -- and its members draw tiles from it by ticket: the four workgroups of a CU do not
-    // progress at the same pace (the oldest waves issue first), and with a fixed share each the slowest one ended up alone
-    // on its CU (measured with s_memrealtime stamps: the first-dispatched quarter of the grid finished at 70 % of the kernel
-    // time).  Whatever the placement, every tile is drawn exactly once.
+    // so halo re-reads hit that XCD's L2 -- and its members draw RUNS of `run` consecutive tiles from it (one atomicAdd per
+    // run, by one thread, issued a whole tile ahead): a tile that lies right below the tile its workgroup did before finds
+    // its upper four plane rows in LDS.  The last `singles` tiles of a range go out one by one, so that the four workgroups
+    // of a CU end together (with a fixed share each the slowest one ended up alone on its CU: the SIMD arbiter favours the
+    // oldest waves).  Whatever the placement and whoever draws what, every tile is drawn exactly once.
     const int tiles_per_frame = a.tiles_x * a.tiles_y;
     const int total = tiles_per_frame * a.nframes;          // < 2^30 (checked by the launcher)
     const int nx = 8;
@@ -1041,48 +1000,74 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     const int gq = total / a.groups, grem = total - gq * a.groups;
     const int band_start = grank * gq + min(grank, grem);
     const int band_end = band_start + gq + (grank < grem ? 1 : 0);
+    const int run = max(a.run, 1);
+    const int runs_len = max(band_end - band_start - a.singles, 0) / run * run;  // tiles of the range that go out in runs
     const int black16 = (int)(uint16_t)a.black, white16 = (int)(uint16_t)a.white;
-    constexpr bool vec = VEC != 0;                       // w % 16 == 0 (1) or w % 16 == 8 (2): dword/vector loads and stores
-    constexpr bool half8 = VEC == 2;
+    constexpr bool vec = VEC != 0;                       // w % 8 == 0, aligned buffers: vector loads and stores
+    constexpr int NEW0 = METHOD == 0 ? HC : 2 * HC;      // first plane row a tile loads itself (without chroma smoothing: no halo at all)
 
     const mlv_i32x4 rs_e2r = table_rsrc(a.e2r, 2, E2R_ENTRIES);
-    constexpr int NW = Words<PACKED>::N;
-    uint32_t r0[NW], r1[NW];                             // prefetch registers of this thread's item
-    uint32_t tl0 = 0, tl1 = 0;                           // half8: the stream's 16 bits behind them
+    uint32_t r0[4], r1[4];                               // prefetch registers of this thread's item
     const int tid = threadIdx.x;
-    const int item_row = tid >= N_FULL ? tid - N_FULL : tid >> 3, item_g = tid & 7;
-
-    // median phase: lane -> (row, strip).  The 16 lanes that one ds_read_b128 pass serves
-    // together ({0-3,12-15,20-27} / {4-11,16-19,28-31} of each half wave) share one row and
-    // take its 16 strips, so their 16-byte accesses fall into 16 different bank groups.
     const int lane = tid & 63;
-    const int la = (lane >> 4) & 1, lb = (lane >> 3) & 1, lc = (lane >> 2) & 1;
-    // 5x5 (neighbour sharing): the 16 strips of a row in 16 consecutive lanes, four rows per wave; the fourth wave holds rows
-    // 12..14 and, in lanes 48..62, the halo groups of rows 0..14 (lane 63 repeats row 14's).  Other methods: the conflict-free map.
-    const bool is_strip = !CHAIN || tid < TCH * 16;
-    const int k = CHAIN ? (lane & 15) : ((la << 3) | (lb << 2) | (lane & 3));
-    const int j = CHAIN ? (is_strip ? (tid >> 4) : min(tid - TCH * 16, TCH - 1)) : (tid >> 6) * 4 + ((lane >> 5) << 1) + (la ^ lb ^ lc);
+    // loader: threads 0..239 own the main item (row t / 16, group t % 16) of the tile's new rows, threads 240..254 the edge items
+    const bool l_edge = tid >= N_MAIN;
+    const int l_row = l_edge ? tid - N_MAIN : tid >> 4, l_k = tid & 15;
+    const ItemLane IL = item_lane<PACKED, VEC>(l_k, l_edge);
+    // median phase: lane -> (row j, strip k).  5x5 (neighbour sharing): 17 consecutive lanes per tile row -- its 16 strips and, as
+    // the 17th, the group of plane columns 64..67 (halo) that the last strip needs --, so that EVERY lane finds the group to its
+    // right in the next lane; the plane reads are then linear in the thread number (16 bytes per lane: PW = 17 x 4) and free of
+    // bank conflicts.  Other methods: 16 lanes per row.
+    const int j_ = CHAIN ? (tid * 241) >> 12 : tid >> 4;                     // tid / 17 for tid < 256
+    const int k = CHAIN ? tid - 17 * j_ : tid & 15;
+    const int j = min(j_, TCH - 1);
+    const bool is_strip = CHAIN ? (k < 16 && tid < 17 * TCH) : tid < N_MAIN;
+    // rows handed down to the tile below (threads 0..67: dr rows TCH.. -> 0..3, 68..135: db, 136..199: pixel rows, 200..231: green EVs)
+    constexpr int C_PL = 2 * HC * PW * 4 / 16, C_RAW = 2 * HC * 2 * TCW * 2 / 16, C_GE = HC * TCW * 4 / 16, C_ALL = 2 * C_PL + C_RAW + C_GE;
+    static_assert(C_ALL <= 256, "one 16-byte piece per thread");
+    int c_dst, c_delta;
+    if (tid < C_PL) { c_dst = (int)offsetof(Smem, dr) + 16 * tid; c_delta = TCH * PW * 4; }
+    else if (tid < 2 * C_PL) { c_dst = (int)offsetof(Smem, db) + 16 * (tid - C_PL); c_delta = TCH * PW * 4; }
+    else if (tid < 2 * C_PL + C_RAW) { c_dst = (int)offsetof(Smem, raw) + 16 * (tid - 2 * C_PL); c_delta = 2 * TCH * 2 * TCW * 2; }
+    else { c_dst = (int)offsetof(Smem, ge) + 16 * (tid - 2 * C_PL - C_RAW); c_delta = TCH * TCW * 4; }
 
-    if (threadIdx.x == 0) { sm.next_ticket = atomicAdd(&a.tickets[grp], 1); sm.dark_items[0] = 0; sm.dark_items[1] = 0; sm.fb_count = 0; }
+    bool singly = false;                                 // thread 0: the runs of this group's range are all handed out
+    auto draw = [&](int &nt, int &ne) {                  // thread 0: the next run of the group's range, or its next single tile
+        if (!singly) {
+            const int p = atomicAdd(&a.tickets[2 * grp], run);
+            if (p < runs_len) { nt = band_start + p; ne = nt + run; return; }
+            singly = true;
+        }
+        const int q = atomicAdd(&a.tickets[2 * grp + 1], 1);
+        nt = min(band_start + runs_len + q, band_end);
+        ne = nt + 1;
+    };
+    if (threadIdx.x == 0) {
+        int nt, ne;
+        draw(nt, ne);
+        sm.next_tile = nt; sm.next_end = ne;
+        sm.dark_items[0] = 0; sm.dark_items[1] = 0; sm.fb_count = 0;
+    }
     __syncthreads();
-    int t = band_start + sm.next_ticket;
-    auto tile_coords = [&](int tt, int &f, int &tr, int &tx0, int &ty0) {
+    int t = __builtin_amdgcn_readfirstlane(sm.next_tile), t_end = __builtin_amdgcn_readfirstlane(sm.next_end);
+    auto tile_coords = [&](int tt, int &f, int &tr, int &tx0, int &ty0, int &trow) {
         f = tt / tiles_per_frame;
-        tr = tt - f * tiles_per_frame;
-        const int trow = tr / a.tiles_x;
-        tx0 = (tr - trow * a.tiles_x) * 2 * TCW;
+        const int r = tt - f * tiles_per_frame;
+        const int tcol = r / a.tiles_y;
+        trow = r - tcol * a.tiles_y;
+        tr = trow * a.tiles_x + tcol;              // the tile's number in the (row-major) pixel-map lists
+        tx0 = tcol * 2 * TCW;
         ty0 = trow * 2 * TCH;
     };
     // The prefetch is unconditional on purpose: threads without an item and the last
     // iteration re-load a valid item / tile.  A conditional load would need the old
     // register value on the other path, and the copies the compiler inserts for that
     // merge wait for the load right where it is issued.
-    const int load_tid = min(tid, N_ITEMS - 1);
     auto issue_tile = [&](int tt) {
-        int f, tr, tx0, ty0;
-        tile_coords(tt, f, tr, tx0, ty0);
-        if (half8) issue_item_half8<PACKED, N_FULL>(r0, r1, tl0, tl1, a.src + (size_t)f * a.src_stride, a.w, a.h, tx0, ty0, load_tid);
-        else issue_item<PACKED, N_FULL>(r0, r1, a.src + (size_t)f * a.src_stride, a.w, a.h, tx0, ty0, load_tid);
+        int f, tr, tx0, ty0, trow;
+        tile_coords(tt, f, tr, tx0, ty0, trow);
+        const mlv_i32x4 rs = frame_rsrc(a.src + (size_t)f * a.src_stride, (unsigned)a.src_bytes);
+        issue_item<PACKED>(r0, r1, rs, IL, a.w, a.h, tx0, ty0, NEW0 + l_row);
     };
     if (vec) issue_tile(min(t, max(total - 1, 0)));
     __syncthreads();                           // T16 copy complete
@@ -1094,52 +1079,53 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     int fb_skip = 0, fb_wait = FB_WAIT_MIN;    // 5x5: tiles still to go straight to the 32-bit chain; how many after the next busy tile
     bool robust = false;                       // 5x5: rows of lanes agree on their references (robust_ref)
     int calm = 0;                              //      tiles in a row without an uncertain strip
+    bool cont = false;                         // this tile lies right below the one this workgroup did before: its upper rows are in LDS
     while (t < band_end) {
-        int my_ticket = 0;
-        if (threadIdx.x == 0) my_ticket = atomicAdd(&a.tickets[grp], 1);       // the tile after this one: back long before it is needed
-        int f, tr, tx0, ty0;
-        tile_coords(t, f, tr, tx0, ty0);
+        int nt = 0, ne = 0;
+        if (threadIdx.x == 0) {                // the tile after this one: known, or drawn now and back long before it is needed
+            if (t + 1 < t_end) { nt = t + 1; ne = t_end; }
+            else draw(nt, ne);
+        }
+        int f, tr, tx0, ty0, trow;
+        tile_coords(t, f, tr, tx0, ty0, trow);
         const uint8_t *frame = a.src + (size_t)f * a.src_stride;
         uint16_t *out = (uint16_t *)(a.dst + (size_t)f * a.dst_stride);
         // ---- pixel-map entries of this tile (few tiles have any): list bounds now -- the wait that the uniform load implies is
-        // for data the loader needs anyway --, the entries themselves in flight while the loader phase runs
+        // for data the loader needs anyway --, the first 256 records themselves in flight while the loader phase runs
         const bool tile_patched = a.patch && (!pmap_ok || ((sm.has_patch[tr >> 5] >> (tr & 31)) & 1u));      // wave-uniform
         int pbeg = 0, pend = 0;
         int4 my_rec = make_int4(-1, 0, 0, 0);
-        static_assert(N_ITEMS <= 192, "the fourth wave has no loader item: it takes the pixel-map cells");
-        const bool patch_wave = tid >= 192;                    // wave-uniform
         const int4 *cells = a.cells + (size_t)f * a.n_rec;
         if (tile_patched) {
             pbeg = a.tile_off[tr];
             pend = a.tile_off[tr + 1];
-            if (patch_wave && pbeg + (tid - 192) < pend) my_rec = cells[pbeg + (tid - 192)];
+            if (pbeg + tid < pend) my_rec = cells[pbeg + tid];
         }
         // ---- loader: prefetched registers -> EV planes + interior raw pixels
+#if !defined(KF_PRIO) || KF_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
+#elif KF_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);
+#endif
         // Lane predicates and wave-uniform switches are re-derived per tile from opaque copies: hoisted out of the loop they
         // became 64-bit SGPR masks, two scalar registers each, of which the kernel kept more than it has -- they were spilt
         // to VGPR lanes and came back through v_readlane, VECTOR instructions (about 40 per tile and wave).
         int tid_o = tid;
         asm volatile("" : "+v"(tid_o));
-        const bool has_item = tid_o < N_ITEMS;
-        const bool edge = tid_o >= N_FULL;
-        if (has_item) {
-            uint32_t p0[16], p1[16];
-            if (half8) {
-                const int iy = ty0 - 2 * HC + 2 * item_row;
-                const int x_main = edge ? tx0 - 16 : tx0 + 16 * item_g, x_right = tx0 + 2 * TCW;
-                const int y0c = clampi(iy, 0, a.h - 1), y1c = clampi(iy + 1, 0, a.h - 1);
-                unpack16_half8<PACKED>(r0, tl0, edge, half8_row<PACKED>(a.w, a.h, x_main, y0c, true), half8_row<PACKED>(a.w, a.h, x_right, y0c, false), p0);
-                unpack16_half8<PACKED>(r1, tl1, edge, half8_row<PACKED>(a.w, a.h, x_main, y1c, true), half8_row<PACKED>(a.w, a.h, x_right, y1c, false), p1);
-            } else if (vec) { unpack16<PACKED>(r0, p0); unpack16<PACKED>(r1, p1); }
-            else fetch_rows<PACKED>(frame, a.w, a.h, tx0 + 16 * item_g, ty0 - 2 * HC + 2 * item_row, edge, tx0, p0, p1);
+        // one item: stream words -> pixels -> EV triples -> planes.  d0 / d1: its two rows as loaded; p: plane row
+        auto do_item = [&](const ItemLane &L, const uint32_t (&d0)[4], const uint32_t (&d1)[4], int p, int lk) {
+            uint32_t p0[8], p1[8];
+            if (vec) {
+                unpack8<PACKED>(d0, L.s0, L.s1, L.s23, p0);
+                unpack8<PACKED>(d1, L.s0 ^ L.flip, L.s1 ^ L.flip, L.s23 ^ L.flip, p1);
+            } else fetch_rows<PACKED>(frame, a.w, a.h, tx0, lk, ty0 - 2 * HC + 2 * p, L.edge, p0, p1);
             // Pixels at or below black (ev = INT_MIN / 0) or beyond the table need the fix-ups of cell_pair_ev: decided once
-            // per item from the extremes of its 32 pixels (three-input min/max), wave-uniformly.
+            // per item from the extremes of its 16 pixels (three-input min/max), wave-uniformly.
             bool odd = false;
             if (METHOD != 0) {
                 uint32_t lo = min(p0[0], p1[0]), hi = max(p0[0], p1[0]);
 #pragma unroll
-                for (int i = 1; i < 16; i++) {
+                for (int i = 1; i < 8; i++) {
                     lo = min(min(lo, p0[i]), p1[i]);
                     if (!PACKED) hi = max(max(hi, p0[i]), p1[i]);
                 }
@@ -1150,19 +1136,33 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 const unsigned long long who = __ballot(odd);
                 if (lane == 0) atomicAdd(&sm.dark_items[par], __popcll(who));
             }
-            emit_item<METHOD, Smem>(sm, a.black, slow, item_row, item_g, edge, p0, p1);
+            emit_item<METHOD, Smem>(sm, a.black, slow, p, lk, L.edge, p0, p1);
+        };
+        if (METHOD != 0 && !cont) {
+            // the first tile of a run (or of a column): the four plane rows above the tile's own, straight from memory -- threads
+            // 0..63 the main items of rows 0..3, 64..67 their edge items -- while the other waves convert the prefetched rows
+            if (tid_o < N_TOP) {
+                const bool te = tid_o >= N_TOP_MAIN;
+                const int trw = te ? tid_o - N_TOP_MAIN : tid_o >> 4;
+                const ItemLane TL = item_lane<PACKED, VEC>(l_k, te);
+                uint32_t q0[4] = { 0, 0, 0, 0 }, q1[4] = { 0, 0, 0, 0 };
+                if (vec) issue_item<PACKED>(q0, q1, frame_rsrc(frame, (unsigned)a.src_bytes), TL, a.w, a.h, tx0, ty0, trw);
+                do_item(TL, q0, q1, trw, l_k);
+            }
         }
-        PatchCell my_cell;
-        my_cell.i = -1;
-        if (tile_patched && patch_wave) my_cell = patch_cell<METHOD, PACKED, Smem>(sm, a, my_rec, tx0, ty0);      // the first 64 cells of the tile
-        if (threadIdx.x == 0) sm.next_ticket = my_ticket;
+        const bool has_item = METHOD == 0 ? tid_o < N_MAIN : tid_o < N_ITEMS;
+        if (has_item) do_item(IL, r0, r1, NEW0 + l_row, l_k);
+        if (threadIdx.x == 0) { sm.next_tile = nt; sm.next_end = ne; }
         lds_barrier();
-        const int t_next = band_start + __builtin_amdgcn_readfirstlane(sm.next_ticket);
+        const int t_next = __builtin_amdgcn_readfirstlane(sm.next_tile), t_end_next = __builtin_amdgcn_readfirstlane(sm.next_end);
+        // the tile after this one continues it when it is the next of the list and not the top of a column
+        const bool cont_next = METHOD != 0 && t_next == t + 1 && trow + 1 < a.tiles_y && t_next < band_end;       // scalar
         if (tile_patched) {
-            if (patch_wave) patch_store<METHOD, Smem>(sm, my_cell);
-            for (int base = pbeg + 64; base < pend; base += 256) {          // a dense map (focus pixels): the rest, all lanes
+            PatchCell c = patch_cell<METHOD, PACKED, Smem>(sm, a, my_rec, tx0, ty0);
+            patch_store<METHOD, Smem>(sm, c);
+            for (int base = pbeg + 256; base < pend; base += 256) {         // a dense map (focus pixels): the rest
                 const int4 rec = base + tid < pend ? cells[base + tid] : make_int4(-1, 0, 0, 0);
-                const PatchCell c = patch_cell<METHOD, PACKED, Smem>(sm, a, rec, tx0, ty0);
+                c = patch_cell<METHOD, PACKED, Smem>(sm, a, rec, tx0, ty0);
                 patch_store<METHOD, Smem>(sm, c);
             }
             lds_barrier();
@@ -1171,7 +1171,11 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         // is about to finish finishes sooner, its workgroup's barrier opens sooner, and the loader instructions of the others
         // fill the gaps.  Measured (tools/kbench.py): cs5x5 11.2-11.5 -> 10.2-10.4 us per frame, cs2x2 8.2 -> 7.8; which of the
         // levels 1..3 is used, and a third level for the output stage, make no difference.
+#if !defined(KF_PRIO) || KF_PRIO == 1
         if (METHOD != 0) __builtin_amdgcn_s_setprio(1);       // (without chroma smoothing the kernel is load-bound and this costs 8 %)
+#elif KF_PRIO == 2
+        if (METHOD != 0) __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- prefetch the next tile while the medians run
         if (vec) issue_tile(min(t_next, band_end - 1));
 
@@ -1268,47 +1272,48 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             if (fb_skip > 0) fb_skip--;
             if (SPREAD && tid == 0) sm.dark_items[par ^ 1] = 0;
             bool unknown = true;
-            const bool chain32 = skip_packed;                  // the same for every wave of the workgroup
-            if (chain32) {
-                // a tile that skips the packed attempt: both planes through the 32-bit chain, one after the other (the rows'
+            // a wave's first lane holds the group that the last lane of the wave before it needs: through LDS
+            const bool publishes = lane == 0 && tid != 0, collects = lane == 63 && tid < 192;
+            const int wv = tid >> 6;
+            if (skip_packed) {
+                // a tile that skips the packed attempt: both planes through the 32-bit chain, one after the other (the
                 // exchange records are reused)
 #pragma unroll 1
                 for (int pln = 0; pln < 2; pln++) {
                     Chain32 g;
-                    chain32_group(pln ? sm.db : sm.dr, j, is_strip ? STRIP * k : TCW, g);
-                    if (!is_strip) chain32_publish(g, sm.xchg[j]);
+                    chain32_group(pln ? sm.db : sm.dr, j, STRIP * k, g);
+                    if (publishes) chain32_publish(g, sm.xchg[wv - 1]);
                     lds_barrier();
                     Next32 n;
                     chain32_fetch(g, n);
-                    if (k == 15) chain32_collect(sm.xchg[j], n);
+                    if (collects) chain32_collect(sm.xchg[wv], n);
                     if (pln) chain32_finish(g, n, mb);
                     else {
                         chain32_finish(g, n, mr);
-                        lds_barrier();                         // every row's record has been read: the second plane may overwrite it
+                        lds_barrier();                         // every record has been read: the second plane may overwrite it
                     }
                 }
                 unknown = false;
-            } else
-            if (!skip_packed) {
+            } else {
                 ChainGroup g;
-                chain_group(sm.dr, sm.db, j, is_strip ? STRIP * k : TCW, robust, g);  // a strip's own group, or a row's halo group
-                const bool halo_wave = tid >= 192;                     // the wave that holds the halo groups' lanes (uniform)
-                if (halo_wave) {
+                chain_group(sm.dr, sm.db, j, STRIP * k, robust, g);    // a strip's own group, or (k = 16) a row's halo group
+                const bool early = tid >= 64;                          // the waves that publish (uniform): their rank window first
+                if (early) {
                     chain_group_window(g);
-                    if (!is_strip) chain_publish(g, sm.xchg[j]);
+                    if (publishes) chain_publish(g, sm.xchg[wv - 1]);
                 }
-                lds_barrier();                                         // the halo groups are in LDS
+                lds_barrier();                                         // the records are in LDS
                 ChainNext n;
                 chain_fetch_lists(g, n);
-                if (k == 15) chain_collect_lists(sm.xchg[j], n);       // (lanes without a strip read a row's record too: harmless)
-                if (!halo_wave) chain_group_window(g);                 // the lane's own rank window, while those reads are under way
+                if (collects) chain_collect_lists(sm.xchg[wv], n);
+                if (!early) chain_group_window(g);                     // the lane's own rank window, while those reads are under way
                 chain_fetch_window(g, n);
-                if (k == 15) chain_collect_window(sm.xchg[j], n);
+                if (collects) chain_collect_window(sm.xchg[wv], n);
                 unknown = chain_finish(g, n, mr, mb);
             }
             unknown = unknown && is_strip && smooth_row;
             if (unknown) sm.fb_queue[atomicAdd(&sm.fb_count, 1)] = (uint8_t)(j * 16 + k);      // settled below, densely
-            if (is_strip && !unknown) finish_strip(j, k, smooth_row && (!skip_packed || chain32), mr, mb, true);
+            if (is_strip && !unknown) finish_strip(j, k, smooth_row, mr, mb, true);
         } else {
             if (smooth_row) {
                 if (METHOD == 3) {
@@ -1319,8 +1324,14 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                     strip_median5(sm.db, j + 1, STRIP * k + 1, mb);
                 }
             }
-            finish_strip(j, k, smooth_row, mr, mb, true);
+            if (is_strip) finish_strip(j, k, smooth_row, mr, mb, true);
         }
+        // ---- the rows the tile below shares with this one: read before the barrier that ends the tile, stored behind it
+        int4 carry = make_int4(0, 0, 0, 0);
+        int tid_c = tid;
+        asm volatile("" : "+v"(tid_c));
+        const bool do_carry = cont_next && tid_c < C_ALL;
+        if (do_carry) carry = *(const int4 *)((const char *)&sm + c_dst + c_delta);
         if (CHAIN) {
             // Strips whose packed medians were not certain: all of the tile's, gathered in LDS, go through the 32-bit networks
             // one per lane -- as many waves as ceil(count / 64) run them, instead of every wave that had one such strip.
@@ -1341,6 +1352,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 atomicAdd(&a.times[4096], 1ull);
                 if (skip_packed) atomicAdd(&a.times[4097], 1ull);
                 atomicAdd(&a.times[4098], (unsigned long long)nfb);
+                if (cont) atomicAdd(&a.times[4099], 1ull);
             }
 #endif
             if (nfb > 0) {
@@ -1358,11 +1370,14 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             }
         } else
         lds_barrier();                       // all strips done with the planes before the next tile's loader
+        if (do_carry) *(int4 *)((char *)&sm + c_dst) = carry;
         t = t_next;
+        t_end = t_end_next;
+        cont = cont_next;
         if (SPREAD) par ^= 1;
     }
-    if (threadIdx.x == 0 && atomicAdd(&a.tickets[a.groups], 1) == (int)gridDim.x - 1) {
-        for (int i = 0; i <= a.groups; i++) a.tickets[i] = 0;       // last workgroup out: ready for the next launch on this stream
+    if (threadIdx.x == 0 && atomicAdd(&a.tickets[2 * a.groups], 1) == (int)gridDim.x - 1) {
+        for (int i = 0; i <= 2 * a.groups; i++) a.tickets[i] = 0;   // last workgroup out: ready for the next launch on this stream
     }
 #ifdef KF_DIAG_TIMES
     if (threadIdx.x == 0 && a.times) { a.times[2 * blockIdx.x] = rt0; a.times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); }
@@ -1372,6 +1387,12 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 // ---------------------------------------------------------------- host launcher
 // zeroed counters per stream (launches on one stream run one after the other and leave the counters zeroed)
 constexpr int MAX_GROUPS = 1024;
+#ifndef KF_RUN_DEFAULT
+#define KF_RUN_DEFAULT 11
+#endif
+#ifndef KF_SINGLES_DEFAULT
+#define KF_SINGLES_DEFAULT 24
+#endif
 namespace {
 std::mutex g_ticket_mu;
 std::map<std::pair<int, hipStream_t>, int *> g_tickets;
@@ -1386,8 +1407,8 @@ static int *ticket_counters(hipStream_t stream)
         // zeroed ON THE LAUNCHING STREAM: the streams are non-blocking, a null-stream hipMemset is not ordered before their
         // kernels (it once landed in the middle of the first launch, the "done" count never completed and the next launch
         // on that stream started from stale tickets)
-        if (hipMalloc(&p, (MAX_GROUPS + 1) * sizeof(int)) != hipSuccess ||
-            hipMemsetAsync(p, 0, (MAX_GROUPS + 1) * sizeof(int), stream) != hipSuccess) {
+        if (hipMalloc(&p, (2 * MAX_GROUPS + 1) * sizeof(int)) != hipSuccess ||
+            hipMemsetAsync(p, 0, (2 * MAX_GROUPS + 1) * sizeof(int), stream) != hipSuccess) {
             set_error("ticket counters: allocation failed");
             if (p) (void)hipFree(p);
             g_tickets.erase({ dev, stream });
@@ -1486,12 +1507,16 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
     int grid = num_cu > 0 ? num_cu * 4 : 1024;          // 4 workgroups per CU (39 KiB LDS, <= 128 VGPRs)
     grid = (grid + 7) / 8 * 8;
     if (grid > total) grid = (int)((total + 7) / 8 * 8);
-    static_assert(sizeof(SmemT<SPREAD, tile_rows_of(METHOD)>) <= 40 * 1024, "four workgroups per CU need <= 40 KiB of LDS each");
     auto kern = k_frame<METHOD, PACKED, VEC, SPREAD>;
     FrameArgs a = a_in;
     a.tickets = ticket_counters(stream);
     if (!a.tickets) return MLVFS_AMD_ERR_HIP;
     a.groups = std::min(std::max(grid / 4, 1), MAX_GROUPS);
+    // tiles per run and tiles that go out one by one at the end of a group's range (tools/kbench.py sweeps them: KB_RUN / KB_SINGLES)
+    static const int env_run = [] { const char *e = getenv("MLVFS_AMD_KF_RUN"); return e ? atoi(e) : 0; }();
+    static const int env_singles = [] { const char *e = getenv("MLVFS_AMD_KF_SINGLES"); return e ? atoi(e) : -1; }();
+    a.run = env_run > 0 ? env_run : KF_RUN_DEFAULT;
+    a.singles = env_singles >= 0 ? env_singles : KF_SINGLES_DEFAULT;
 #ifdef KF_DIAG_TIMES
     static unsigned long long *d_times = nullptr;
     if (!d_times) hipMalloc(&d_times, (2048 * 2 + 8) * sizeof(unsigned long long));
@@ -1552,6 +1577,7 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
     if (packed && g.bpp != 14) { set_error("fused path needs 14-bit input"); return MLVFS_AMD_ERR_ARG; }
     FrameArgs a{};
     a.src = (const uint8_t *)src; a.src_stride = src_stride;
+    a.src_bytes = (unsigned)(((size_t)g.w * g.h * (packed ? 14 : 16) / 8 + 3) / 4 * 4);     // one frame as the loader's range-checked buffer
     a.dst = (uint8_t *)dst; a.dst_stride = dst_stride;
     a.w = g.w; a.h = g.h; a.black = g.black; a.white = g.white;
     a.nframes = nframes;
@@ -1571,11 +1597,13 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
         if (a.coef[i] - 65536 <= -32768 || a.coef[i] - 65536 >= 32768) a.coef_fast = 0;
     }
     a.coef_pk = a.coef_fast && packed && (int)(uint16_t)g.white > (int)(uint16_t)g.black + 64 && g.black >= 0 && g.black <= 16384;
-    // vector path: rows are whole 16-pixel groups and every row starts 16-byte aligned (1), or rows of whole 8-pixel half groups (2)
+    // vector path: rows are whole 8-pixel groups (14 bytes of stream) and the buffers 16-byte aligned: every row of a 16-pixel-multiple
+    // width starts dword-aligned (1); widths that are 8 mod 16 alternate between dword-aligned rows and rows that start in the upper
+    // half of a dword (2; an even height keeps the frame's last group off the end of the buffer)
     static const bool no_half8 = [] { const char *e = getenv("MLVFS_AMD_KF_HALF8"); return e && atoi(e) == 0; }();      // (A/B: the any-geometry path instead)
     const bool strides_ok = nframes == 1 || (src_stride % 16 == 0 && dst_stride % 16 == 0);
-    const int vec = ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 && strides_ok
-                        ? ((g.w % 16) == 0 ? 1 : ((g.w % 16) == 8 && g.w >= 24 && !no_half8 ? 2 : 0)) : 0;
+    const int vec = ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 && strides_ok && g.w >= 16
+                        ? ((g.w % 16) == 0 ? 1 : ((g.w % 16) == 8 && (g.h % 2) == 0 && !no_half8 ? 2 : 0)) : 0;
 #define MLV_DISPATCH_S(M, S)                                                                              \
     return packed ? (vec == 1 ? launch_frame_t<M, true, 1, S>(a, dev->num_cu, stream)                     \
                    : vec == 2 ? launch_frame_t<M, true, 2, S>(a, dev->num_cu, stream)                     \
