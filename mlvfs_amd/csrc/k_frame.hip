@@ -118,6 +118,9 @@ struct FrameArgs {
 // the struct forms, and unlike inline asm the compiler counts these loads in its s_waitcnt bookkeeping.
 typedef int mlv_i32x4 __attribute__((ext_vector_type(4)));
 __device__ unsigned short mlv_sbl_u16(mlv_i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.i16");
+// the same look-up as a dword load (entry `vindex` in the lower half, its successor above it): no zero-extension instruction for a
+// value that a byte permute consumes; the table carries one entry of padding behind its last
+__device__ int mlv_sbl_u32(mlv_i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.i32");
 __device__ __forceinline__ mlv_i32x4 table_rsrc(const void *p, unsigned stride, unsigned entries)
 {
     const unsigned long long a = (unsigned long long)p;
@@ -360,8 +363,8 @@ __device__ __forceinline__ ItemLane item_lane(int lk, bool edge)
     L.edge = edge;
     L.xoff_a = edge ? 2 * TCW : 8 * lk;
     L.xoff_b = edge ? -8 : 8 * lk;
-    L.amask = edge ? ~0u : ~3u;
-    L.boff = (PACKED && edge) ? 6u : 8u;
+    L.amask = (PACKED && !edge) ? ~3u : ~0u;
+    L.boff = edge ? (PACKED ? 6u : 8u) : 8u;
     // rows of a tile start at a multiple of 128 pixels = 224 bytes: on an even row group lk is aligned when lk is even
     // (w % 16 == 8: odd rows start two bytes into a dword, so there it is the other way round)
     const bool mis = (lk & 1) != 0;
@@ -372,33 +375,24 @@ __device__ __forceinline__ ItemLane item_lane(int lk, bool edge)
     return L;
 }
 
-// byte offsets, inside the frame, of the two loads of one row of an item
-template <bool PACKED>
-__device__ __forceinline__ void item_offsets(const ItemLane &L, int w, int tx0, int yy, uint32_t &oa, uint32_t &ob)
-{
-    const int xa = min(tx0 + L.xoff_a, w - 8), xb = max(min(tx0 + L.xoff_b, w - 8), 0);
-    const uint32_t row = (uint32_t)yy * (uint32_t)w;           // < 2^28 pixels per frame (launcher)
-    if (PACKED) {
-        const uint32_t ga = ((row + (uint32_t)xa) >> 3) * 14u, gb = ((row + (uint32_t)xb) >> 3) * 14u;
-        oa = ga & L.amask;
-        ob = (L.edge ? gb : oa) + L.boff;
-    } else {
-        oa = (row + (uint32_t)xa) * 2u;
-        ob = (L.edge ? (row + (uint32_t)xb) * 2u : oa) + 8u;
-    }
-}
-
-// plane row p of the tile at (tx0, ty0): the item's two pixel rows into d0 / d1
+// plane row p of the tile at (tx0, ty0): the item's two pixel rows into d0 / d1.  Rows are whole 8-pixel groups (w % 8 == 0), so the
+// byte offset of the group at (x, y) is y * pitch + (x / 8) * gb, pitch = bytes per row, gb = bytes per group (14 / 16): 24-bit
+// multiplies (v_mul_lo_u32 costs four issue slots), and a main item's second load follows from its first (amask / boff, item_lane)
 template <bool PACKED>
 __device__ __forceinline__ void issue_item(uint32_t (&d0)[4], uint32_t (&d1)[4], mlv_i32x4 rs, const ItemLane &L, int w, int h, int tx0,
                                            int ty0, int p)
 {
+    constexpr uint32_t GB = PACKED ? 14u : 16u;
     const int y = ty0 - 2 * HC + 2 * p;
+    const uint32_t pitch = (uint32_t)(w >> 3) * GB;                                    // scalar
+    const int gmax = (w >> 3) - 1, g0 = tx0 >> 3;
+    const uint32_t ga = __umul24((uint32_t)min(g0 + (L.xoff_a >> 3), gmax), GB);
+    const uint32_t gb = __umul24((uint32_t)max(min(g0 + (L.xoff_b >> 3), gmax), 0), GB);
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         const int yy = clampi(y + rr, 0, h - 1);
-        uint32_t oa, ob;
-        item_offsets<PACKED>(L, w, tx0, yy, oa, ob);
+        const uint32_t row = __umul24((uint32_t)yy, pitch);                            // rows and row pitch < 2^24 (launcher)
+        const uint32_t oa = (row + ga) & L.amask, ob = ((row + gb) & L.amask) + L.boff;
         const mlv_u32x2 a = mlv_rbl_x2(rs, (int)oa, 0, 0), b = mlv_rbl_x2(rs, (int)ob, 0, 0);
         uint32_t (&d)[4] = rr ? d1 : d0;
         d[0] = a.x; d[1] = a.y; d[2] = b.x; d[3] = b.y;
@@ -481,10 +475,12 @@ __device__ __forceinline__ void emit_item(SM &sm, int black, bool slow, int p, i
         }
         // main item: plane columns HC + 4 lk ..; edge item: cells 0, 1 = right halo, cells 2, 3 = left halo
         const int ca = edge ? PW - HC : HC + 4 * lk, cb = edge ? 0 : ca + 2;
-        *(int2 *)&sm.dr[p][ca] = make_int2(dr[0], dr[1]);
-        *(int2 *)&sm.dr[p][cb] = make_int2(dr[2], dr[3]);
-        *(int2 *)&sm.db[p][ca] = make_int2(db[0], db[1]);
-        *(int2 *)&sm.db[p][cb] = make_int2(db[2], db[3]);
+        const uint32_t prow = __umul24((uint32_t)p, (uint32_t)(PW * 4));              // (v_mul_lo_u32 otherwise)
+        char *pdr = (char *)&sm.dr[0][0] + prow, *pdb = (char *)&sm.db[0][0] + prow;
+        *(int2 *)(pdr + 4 * ca) = make_int2(dr[0], dr[1]);
+        *(int2 *)(pdr + 4 * cb) = make_int2(dr[2], dr[3]);
+        *(int2 *)(pdb + 4 * ca) = make_int2(db[0], db[1]);
+        *(int2 *)(pdb + 4 * cb) = make_int2(db[2], db[3]);
         if (keep) *(int4 *)&sm.ge[jj][4 * lk] = make_int4(ge[0], ge[1], ge[2], ge[3]);
     }
     if (keep) {
@@ -1203,8 +1199,8 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 for (int c = 0; c < STRIP; c++) {
                     er[c] = wadd(gev[c], mr[c]);
                     eb[c] = wadd(gev[c], mb[c]);
-                    ur[c] = mlv_sbl_u16(rs_e2r, min(max(er[c], 0), MLV_EV_MAX), 0, 0, 0);
-                    ub[c] = mlv_sbl_u16(rs_e2r, min(max(eb[c], 0), MLV_EV_MAX), 0, 0, 0);
+                    ur[c] = mlv_sbl_u32(rs_e2r, min(max(er[c], 0), MLV_EV_MAX), 0, 0, 0);
+                    ub[c] = mlv_sbl_u32(rs_e2r, min(max(eb[c], 0), MLV_EV_MAX), 0, 0, 0);
                 }
                 read_raw();
                 // chroma_smooth.c:27 leaves columns 0..3 and w-4.. alone: only the tiles at the frame's left and right margin test for that
@@ -1223,9 +1219,9 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 #pragma unroll
                 for (int c = 0; c < STRIP; c++) {
                     const bool ok = okc[c];
-                    const uint32_t pr_ = (uint32_t)ur[c], pb_ = (uint32_t)ub[c];
-                    top[c] = ok ? ((top[c] & 0xFFFF0000u) | pr_) : top[c];
-                    bot[c] = ok ? ((bot[c] & 0x0000FFFFu) | (pb_ << 16)) : bot[c];
+                    // R = the lower half of top, B = the upper half of bot: one v_perm_b32 each (selector: new value or the word as it is)
+                    top[c] = __builtin_amdgcn_perm((uint32_t)ur[c], top[c], ok ? 0x03020504u : 0x03020100u);
+                    bot[c] = __builtin_amdgcn_perm((uint32_t)ub[c], bot[c], ok ? 0x05040100u : 0x03020100u);
                 }
             }
             if (stripe_mode != 0) {
@@ -1461,7 +1457,7 @@ static int e2r_table(const Device *dev, int black, const uint16_t **out, hipStre
         if (it != g_e2r.end()) { it->second.used = ++g_e2r_clock; *out = it->second.table; return MLVFS_AMD_OK; }
     }
     uint16_t *t = nullptr;
-    MLV_HIP(hipMalloc(&t, sizeof(uint16_t) * E2R_ENTRIES));
+    MLV_HIP(hipMalloc(&t, sizeof(uint16_t) * (E2R_ENTRIES + 2)));      // (+ padding: the fused kernel reads entries as dwords)
     hipLaunchKernelGGL(k_build_e2r, dim3((E2R_ENTRIES + 255) / 256), dim3(256), 0, stream, dev->luts.u16, black, t);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {       // other streams use the table from now on
         (void)hipFree(t);
