@@ -378,7 +378,7 @@ __device__ __forceinline__ ItemLane item_lane(int lk, bool edge)
 // plane row p of the tile at (tx0, ty0): the item's two pixel rows into d0 / d1.  Rows are whole 8-pixel groups (w % 8 == 0), so the
 // byte offset of the group at (x, y) is y * pitch + (x / 8) * gb, pitch = bytes per row, gb = bytes per group (14 / 16): 24-bit
 // multiplies (v_mul_lo_u32 costs four issue slots), and a main item's second load follows from its first (amask / boff, item_lane)
-template <bool PACKED>
+template <bool PACKED, bool TOP = false>
 __device__ __forceinline__ void issue_item(uint32_t (&d0)[4], uint32_t (&d1)[4], mlv_i32x4 rs, const ItemLane &L, int w, int h, int tx0,
                                            int ty0, int p)
 {
@@ -390,7 +390,7 @@ __device__ __forceinline__ void issue_item(uint32_t (&d0)[4], uint32_t (&d1)[4],
     const uint32_t gb = __umul24((uint32_t)max(min(g0 + (L.xoff_b >> 3), gmax), 0), GB);
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
-        const int yy = clampi(y + rr, 0, h - 1);
+        const int yy = TOP ? clampi(y + rr, 0, h - 1) : min(y + rr, h - 1);     // (only the rows above a tile's own can lie above the frame)
         const uint32_t row = __umul24((uint32_t)yy, pitch);                            // rows and row pitch < 2^24 (launcher)
         const uint32_t oa = (row + ga) & L.amask, ob = ((row + gb) & L.amask) + L.boff;
         const mlv_u32x2 a = mlv_rbl_x2(rs, (int)oa, 0, 0), b = mlv_rbl_x2(rs, (int)ob, 0, 0);
@@ -775,16 +775,21 @@ __device__ __forceinline__ bool chain_finish(const ChainGroup &g, ChainNext &n, 
     mlv_final6of11(n.q, g.s[3], o[3]);        // 4..7 | 3
     // certain when strictly inside (-32768 + |D|, 32767 - |D|): v - lo <= hi - lo as unsigned, lo = -32767 + |D|, hi = 32766 - |D|
     const int ar = (int)min((unsigned)wabs(dr_), 32767u), ab = (int)min((unsigned)wabs(db_), 32767u);
+    // both lanes of a pair at once: t = v - lo (wraps), excess = t -sat span (unsigned saturating: 0 when inside), any excess -> unknown
+    typedef unsigned short upk16 __attribute__((ext_vector_type(2)));
     const int lo_r = ar - 32767, span_r = 65533 - 2 * ar, lo_b = ab - 32767, span_b = 65533 - 2 * ab;
+    const mlv_pk16 lo_pk = { (short)lo_r, (short)lo_b };
+    const upk16 span_pk = { (unsigned short)max(span_r, 0), (unsigned short)max(span_b, 0) };
     bool unknown = ar >= 32767 || ab >= 32767;           // the references themselves are more than the 16-bit range apart
+    upk16 excess = { 0, 0 };
 #pragma unroll
     for (int c = 0; c < STRIP; c++) {
-        const int vr = (int)o[c][0].x, vb = (int)o[c][0].y;
-        unknown |= (unsigned)(vr - lo_r) > (unsigned)span_r;
-        unknown |= (unsigned)(vb - lo_b) > (unsigned)span_b;
-        mr[c] = vr + g.ref_r;
-        mb[c] = vb + g.ref_b;
+        const upk16 t = __builtin_bit_cast(upk16, o[c][0]) - __builtin_bit_cast(upk16, lo_pk);
+        excess |= __builtin_elementwise_sub_sat(t, span_pk);
+        mr[c] = (int)o[c][0].x + g.ref_r;
+        mb[c] = (int)o[c][0].y + g.ref_b;
     }
+    unknown |= __builtin_bit_cast(uint32_t, excess) != 0u;
     return unknown;
 }
 
@@ -1142,7 +1147,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 const int trw = te ? tid_o - N_TOP_MAIN : tid_o >> 4;
                 const ItemLane TL = item_lane<PACKED, VEC>(l_k, te);
                 uint32_t q0[4] = { 0, 0, 0, 0 }, q1[4] = { 0, 0, 0, 0 };
-                if (vec) issue_item<PACKED>(q0, q1, frame_rsrc(frame, (unsigned)a.src_bytes), TL, a.w, a.h, tx0, ty0, trw);
+                if (vec) issue_item<PACKED, true>(q0, q1, frame_rsrc(frame, (unsigned)a.src_bytes), TL, a.w, a.h, tx0, ty0, trw);
                 do_item(TL, q0, q1, trw, l_k);
             }
         }
@@ -1383,11 +1388,8 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 // ---------------------------------------------------------------- host launcher
 // zeroed counters per stream (launches on one stream run one after the other and leave the counters zeroed)
 constexpr int MAX_GROUPS = 1024;
-#ifndef KF_RUN_DEFAULT
-#define KF_RUN_DEFAULT 11
-#endif
-#ifndef KF_SINGLES_DEFAULT
-#define KF_SINGLES_DEFAULT 24
+#ifndef KF_RUN_MAX
+#define KF_RUN_MAX 22
 #endif
 namespace {
 std::mutex g_ticket_mu;
@@ -1511,8 +1513,11 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
     // tiles per run and tiles that go out one by one at the end of a group's range (tools/kbench.py sweeps them: KB_RUN / KB_SINGLES)
     static const int env_run = [] { const char *e = getenv("MLVFS_AMD_KF_RUN"); return e ? atoi(e) : 0; }();
     static const int env_singles = [] { const char *e = getenv("MLVFS_AMD_KF_SINGLES"); return e ? atoi(e) : -1; }();
-    a.run = env_run > 0 ? env_run : KF_RUN_DEFAULT;
-    a.singles = env_singles >= 0 ? env_singles : KF_SINGLES_DEFAULT;
+    // default: about sixteen draws per group's range, at most half a column of the benchmark's geometry per run (same-box sweep:
+    // 4 / 8 / 11 / 22 / 44 tiles per run -> 117.2 / 117.5 / 117.7 / 118.0-121.0 / 120.5 k fps), one and a half runs' worth of single tiles
+    const int band = (int)(total / a.groups);
+    a.run = env_run > 0 ? env_run : std::min(std::max(band / 16, 1), KF_RUN_MAX);
+    a.singles = env_singles >= 0 ? env_singles : (a.run > 1 ? a.run * 3 / 2 : 0);
 #ifdef KF_DIAG_TIMES
     static unsigned long long *d_times = nullptr;
     if (!d_times) hipMalloc(&d_times, (2048 * 2 + 8) * sizeof(unsigned long long));
