@@ -352,6 +352,14 @@ int mlvfs_amd_frame_sync(void *image_data);
  * had to run earlier (a call outside process_frame's order, the first frame of a clip, a focus-pixel map, pattern noise, dual ISO,
  * hist_add on the frame). */
 void mlvfs_amd_dropin_stats(long long out[2]);
+/* What the drop-in stages moved between host and device since the process started: {frame uploads, frame downloads, bytes up, bytes
+ * down} (pixel repairs that fetch their few patched pixels are not counted).  Inside a frame bracket a frame costs one upload of its
+ * payload and one download, whatever stages run in between. */
+void mlvfs_amd_dropin_transfers(long long out[4]);
+/* Test hook: the calling thread's next fused launch of a bracketed frame (what = 1) or next frame download (what = 2) reports a HIP
+ * error without touching the device.  What the caller then finds -- a zeroed frame and one line on stderr, never the bytes its
+ * malloc returned -- is the library's failure policy ("When the device fails"; tests/test_failure_policy.py). */
+void mlvfs_amd_test_fail_next(int what);
 
 /* self tests that need no GPU (selection networks, LUT identities): 0 = pass */
 int mlvfs_amd_selftest_host(void);

@@ -29,6 +29,9 @@ FILE **__wrap_mlvfs_load_chunks(const char *path, uint32_t *chunk_count)
 
 void __wrap_mlvfs_close_chunks(FILE **chunk_files, uint32_t chunk_count)
 {
-    mlvfs_amd_frame_end();                                                      /* image_buffer->data is current from here on */
+    /* image_buffer->data is current from here on.  Should the fused launch or the download fail, the library has zeroed the frame
+     * (never process_frame's malloc'ed bytes) and said so on stderr; the line below names the clip's side of it, like the
+     * reference's err_printf does for its own failures */
+    if (mlvfs_amd_frame_end() != 0) fprintf(stderr, "MLVFS: frame served black: %s\n", mlvfs_amd_last_error());
     __real_mlvfs_close_chunks(chunk_files, chunk_count);
 }

@@ -78,7 +78,7 @@ Clip *make_clip(const FrameView &v, ThreadCtx *c)
 // load_chunks / close_chunks directly and reads the frame right after get_image_data (gif.c:164) -- it never sees a deferred unpack.
 // (Round 2 selected this behaviour process-wide with MLVFS_AMD_RESIDENT=2, which was wrong for exactly that caller; the value is
 // now read as 1.)  MLVFS_AMD_DEFER=0 in the environment makes the bracket calls do nothing.
-enum { RANK_UNPACK = 0, RANK_DUALISO = 1, RANK_PNOISE = 2, RANK_FOCUS = 3, RANK_BAD = 4, RANK_CS = 5, RANK_STRIPES_READ = 6, RANK_STRIPES = 7 };      // process_frame's order (main.c:942-997)
+enum { RANK_UNPACK = 0, RANK_PNOISE = 1, RANK_DUALISO = 2, RANK_FOCUS = 3, RANK_BAD = 4, RANK_CS = 5, RANK_STRIPES_READ = 6, RANK_STRIPES = 7 };      // process_frame's order (main.c:942-997: unpack, pattern noise :946-949, dual ISO :952-959, focus / bad pixels, chroma smoothing, stripes)
 
 thread_local bool t_bracket = false;               // this thread is between mlvfs_amd_frame_begin and mlvfs_amd_frame_end
 
@@ -126,6 +126,16 @@ void warn_unsynced(const void *host)
 
 int download(ThreadCtx *c, void *host, const void *dev, size_t bytes);
 
+// FAILURE POLICY ("When the device fails"): there is no CPU path in this library.  dng_get_image_data is the one
+// stage whose failure would leave the caller with a buffer nobody has written (process_frame mallocs it: main.c:931) -- the frame is
+// then ZEROED (a black DNG, never the heap's old contents) and one line goes to stderr, like the reference's err_printf; a later
+// stage that fails leaves the frame as the stage before it left it (abandon_stage).
+void unfilled_frame(void *host, size_t bytes, const char *where)
+{
+    if (host && bytes) memset(host, 0, bytes);
+    fprintf(stderr, "mlvfs_amd: %s failed (%s): the frame is served black\n", where, mlvfs_amd_last_error());
+}
+
 // ---- frame bracket: recorded stages, one fused launch ------------------------------------------------------------------------
 // Inside a bracket nothing has to be in host memory before mlvfs_amd_frame_end, so nothing has to RUN before it either: the unpack,
 // the bad-pixel repair (once the clip's map is cached), the chroma smoothing and the stripe correction that process_frame asks
@@ -133,6 +143,11 @@ int download(ThreadCtx *c, void *host, const void *dev, size_t bytes);
 // batch) when the frame is fetched -- or earlier, when a call arrives that is not the next stage of process_frame's order or
 // needs the pixels (first frame of a clip: bad-pixel detection, stripe histogram; focus-pixel maps; pattern noise; dual ISO).
 std::atomic<long long> g_lazy_fused{ 0 }, g_lazy_early{ 0 };
+// test hook (mlvfs_amd_test_fail_next): the calling thread's next fused launch of a bracketed frame [1] / next frame download [2]
+// reports a HIP error without touching the device -- how tests/test_failure_policy.py shows what MLVFS serves when the device is lost
+thread_local int t_fail_next[3] = { 0, 0, 0 };
+// what the drop-in stages moved over the link, process-wide: {uploads, downloads, bytes up, bytes down} (mlvfs_amd_dropin_transfers)
+std::atomic<long long> g_xfer[4] = { { 0 }, { 0 }, { 0 }, { 0 } };
 
 int lazy_run(ThreadCtx *c, bool at_sync)
 {
@@ -145,6 +160,7 @@ int lazy_run(ThreadCtx *c, bool at_sync)
     const Geom g{ z.w, z.h, 14, z.black, z.white };
     const bool patch = pix && pix->n_entries > 0;
     int rc = c->ensure_res((z.bytes + 15) / 16 * 16);
+    if (!rc && t_fail_next[1]) { t_fail_next[1] = 0; set_error("injected failure of the fused launch (test hook)"); rc = MLVFS_AMD_ERR_HIP; }
     if (!rc) {
         if (!patch && z.cs == 0 && !z.stripes)
             rc = launch_unpack(c->d_a, 0, c->d_res[0], 0, 0, (uint32_t)(z.bytes / 2), 14, 1, c->stream);
@@ -184,6 +200,7 @@ bool lazy_next(ThreadCtx *c, const void *host, size_t bytes, int rank)
 // reaches 1 840 at, tools/zerocopy_probe.hip -- and slower without MLVFS_AMD_RESIDENT.)
 int upload(ThreadCtx *c, void *dev, const void *host, size_t bytes)
 {
+    g_xfer[0]++; g_xfer[2] += (long long)bytes;
     MLV_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
     return MLVFS_AMD_OK;
 }
@@ -236,6 +253,8 @@ void commit_frame(ThreadCtx *c, const void *host, size_t bytes, int rank, int wh
 
 int download(ThreadCtx *c, void *host, const void *dev, size_t bytes)
 {
+    if (t_fail_next[2]) { t_fail_next[2] = 0; set_error("injected failure of the frame's download (test hook)"); return MLVFS_AMD_ERR_HIP; }
+    g_xfer[1]++; g_xfer[3] += (long long)bytes;
     MLV_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
     MLV_HIP(hipStreamSynchronize(c->stream));
     return MLVFS_AMD_OK;
@@ -363,14 +382,17 @@ int mlv::drop_resident(ThreadCtx *c, void *host)
 int mlv::flush_pending(ThreadCtx *c)
 {
     if (c->lazy.active) {
+        // (inside a bracket the host buffer has not been written at all yet: a failure here must not hand the caller its malloc'ed bytes)
+        void *lazy_host = c->lazy.host;
+        const size_t lazy_bytes = c->lazy.bytes;
         int rc = lazy_run(c, true);
-        if (rc) return rc;
+        if (rc) { unfilled_frame(lazy_host, lazy_bytes, "the frame's fused launch"); return rc; }
     }
     if (!c->res_dirty) return MLVFS_AMD_OK;
     void *host = const_cast<void *>(c->res_host);
     const int rc = download(c, host, c->d_res[c->res_cur], c->res_bytes);
     c->res_dirty = false;
-    if (rc) { c->res_host = nullptr; return rc; }
+    if (rc) { c->res_host = nullptr; unfilled_frame(host, c->res_bytes, "the frame's download"); return rc; }
     sample_host(host, c->res_bytes, c->res_sig);
     return MLVFS_AMD_OK;
 }
@@ -409,6 +431,12 @@ int mlvfs_amd_frame_sync(void *image_data)
     return flush_pending(c);
 }
 
+// whole-frame transfers of the drop-in stages since the process started: {uploads, downloads, bytes up, bytes down}
+void mlvfs_amd_dropin_transfers(long long out[4]) { for (int i = 0; i < 4; i++) out[i] = g_xfer[i].load(); }
+
+// test hook: see t_fail_next (1: the next fused launch of a bracketed frame, 2: the next frame download, on the calling thread)
+void mlvfs_amd_test_fail_next(int what) { if (what == 1 || what == 2) t_fail_next[what] = 1; }
+
 // how often this process ran recorded stages as one fused launch at the fetch [0], and how often earlier because a call could not
 // be recorded [1] (for tests and tuning)
 void mlvfs_amd_dropin_stats(long long out[2])
@@ -439,9 +467,12 @@ size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8
     const size_t out_bytes = max_size - lead;
     const uint32_t npix = (uint32_t)(out_bytes / 2);
     if (npix == 0) return max_size;
-    if (bpp < 1 || bpp > 16) { set_error("dng_get_image_data: unsupported bits_per_pixel %d", bpp); return 0; }
+    // (a failure from here on zeroes what was asked for: see unfilled_frame)
+    uint8_t *const want = output_buffer + lead + offset % 2;
+    auto fail = [&]() -> size_t { unfilled_frame(want, out_bytes / 2 * 2, "dng_get_image_data"); return 0; };
+    if (bpp < 1 || bpp > 16) { set_error("dng_get_image_data: unsupported bits_per_pixel %d", bpp); return fail(); }
     ThreadCtx *c = thread_ctx();
-    if (!c) return 0;
+    if (!c) return fail();
     // the reference fetches, per pixel, the two 16-bit words that hold it; packed_bits
     // starts at the word of the first requested pixel
     const uint32_t first_word = first_px * (uint32_t)bpp / 16;
@@ -454,17 +485,17 @@ size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8
     if (c->lazy.active) { warn_unsynced(c->lazy.host); c->lazy.active = false; c->lazy.pix.reset(); }
     c->res_host = nullptr;
     c->res_dirty = false;
-    if (c->ensure((in_bytes + 15) / 16 * 16, 0) || c->ensure_res((out_b + 15) / 16 * 16)) return 0;
+    if (c->ensure((in_bytes + 15) / 16 * 16, 0) || c->ensure_res((out_b + 15) / 16 * 16)) return fail();
     if (upload(c, c->d_a, packed_bits, in_bytes)) {
         set_error("dng_get_image_data: upload failed");
-        return 0;
+        return fail();
     }
     // inside a frame bracket the call returns without waiting for the stream, but packed_bits is the caller's again on return: if it is
     // page-locked memory the copy above is still under way then (from pageable memory it is not), so its end gets an event
     const bool deferred = resident_level() == 2 && offset == 0 && out_b == dng_get_image_size(fh);
     if (deferred) {
-        if (!c->ev_up && hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming) != hipSuccess) return 0;
-        if (hipEventRecord(c->ev_up, c->stream) != hipSuccess) return 0;
+        if (!c->ev_up && hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming) != hipSuccess) return fail();
+        if (hipEventRecord(c->ev_up, c->stream) != hipSuccess) return fail();
     }
     uint8_t *dst = output_buffer + lead + offset % 2;
     if (deferred && bpp == 14 && fh->rawi_hdr.raw_info.black_level >= 0) {
@@ -474,17 +505,17 @@ size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8
         z.w = fh->rawi_hdr.xRes; z.h = fh->rawi_hdr.yRes;
         z.black = fh->rawi_hdr.raw_info.black_level; z.white = fh->rawi_hdr.raw_info.white_level;
         z.rank = RANK_UNPACK; z.pix.reset(); z.cs = 0; z.stripes = false;
-        if (hipEventSynchronize(c->ev_up) != hipSuccess) return 0;
+        if (hipEventSynchronize(c->ev_up) != hipSuccess) { z.active = false; return fail(); }
         return max_size;
     }
-    if (launch_unpack(c->d_a, 0, c->d_res[0], 0, first_px, npix, bpp, 1, c->stream)) return 0;
+    if (launch_unpack(c->d_a, 0, c->d_res[0], 0, first_px, npix, bpp, 1, c->stream)) return fail();
     // process_frame's call -- the whole frame (main.c:942) --: the next stage on this buffer finds it on the device
     // (MLVFS_AMD_RESIDENT=1, frame bracket); a window of the frame is delivered at once in every mode
     if (offset == 0 && out_b == dng_get_image_size(fh)) {
-        if (finish_frame(c, dst, out_b, RANK_UNPACK, 0)) return 0;
-        if (deferred && hipEventSynchronize(c->ev_up) != hipSuccess) return 0;
+        if (finish_frame(c, dst, out_b, RANK_UNPACK, 0)) return fail();
+        if (deferred && hipEventSynchronize(c->ev_up) != hipSuccess) { c->res_dirty = false; c->res_host = nullptr; return fail(); }
     } else {
-        if (download(c, dst, c->d_res[0], out_b)) return 0;
+        if (download(c, dst, c->d_res[0], out_b)) return fail();
         commit_frame(c, dst, out_b, RANK_UNPACK, 0);
     }
     return max_size;

@@ -613,10 +613,17 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
                 bk.nframes = (int)((long long)nframes * (k + 1) / nparts) - bk.f0;
                 rc = di_launch_amaze_interp(d_frames, bk, H, L, P, stream, hf.amaze_a, hf.st);
                 if (!rc) rc = di_launch_convert(bk, H, L, P, amaze, d_frames, hf.st);
-                if (rc) return rc;
+                if (rc) break;
             }
-            MLV_HIP(hipEventRecord(hf.join, hf.st));
-            MLV_HIP(hipStreamWaitEvent(stream, hf.join, 0));
+            // the second stream joins the caller's whether or not every part went out: what it has queued reads and writes the batch's
+            // planes, and the caller may free or reuse them as soon as this call has returned an error
+            const hipError_t ej = hipEventRecord(hf.join, hf.st);
+            const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(stream, hf.join, 0) : ej;
+            if (ew != hipSuccess) {
+                (void)hipStreamSynchronize(hf.st);
+                if (!rc) { set_error("cr2hdr20_batch: joining the second stream failed: %s", hipGetErrorString(ew)); rc = MLVFS_AMD_ERR_HIP; }
+            }
+            if (rc) return rc;
         } else {
             rc = di_launch_amaze_interp(d_frames, bt, H, L, P, stream);
             if (rc) return rc;
@@ -684,8 +691,9 @@ int cr2hdr20_convert_data(struct frame_headers *fh, uint16_t *image_data, int in
     bool touched = false;
     const int r = cr2hdr20_device(c, fh, d_frame, w, h, fh->rawi_hdr.raw_info.black_level, fh->rawi_hdr.raw_info.white_level,
                                   interp_method, fullres, use_alias_map, chroma_smooth, fix_bad_pixels_mode, c->stream, &touched);
-    // not converted: the frame only carries the pixel repairs the reference would have made by now
-    inplace_stage_end(c, STAGE_DUALISO, image_data, bytes, which, was_dirty, true, r == 1 || touched);
+    // not converted: the frame only carries the pixel repairs the reference would have made by now.  A library error (r < 0: a launch
+    // may have failed after the blend had begun to rewrite the frame in place) abandons the device copy like every other stage does
+    inplace_stage_end(c, STAGE_DUALISO, image_data, bytes, which, was_dirty, r >= 0, r == 1 || touched);
     if (r != 1) return 0;
     fh->rawi_hdr.raw_info.black_level *= 4;                            // hdr.c:1951-1952
     fh->rawi_hdr.raw_info.white_level *= 4;

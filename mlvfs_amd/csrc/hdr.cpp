@@ -171,7 +171,12 @@ int mlvfs_amd_hdr_preview_dev(const mlvfs_amd_geom_t *geom, void *d_frame, size_
     if (c->ensure(0, out_at + bytes)) return MLVFS_AMD_ERR_HIP;
     hipStream_t s = pick_stream(stream, c);
     const int r = hdr_preview_device(g, d_frame, (uint8_t *)c->d_b + out_at, max_size, (unsigned *)c->d_b, s, nullptr, nullptr);
-    if (r == 1) MLV_HIP(hipMemcpyAsync(d_frame, (uint8_t *)c->d_b + out_at, bytes, hipMemcpyDeviceToDevice, s));    // in place for the caller
+    if (r == 1) {
+        MLV_HIP(hipMemcpyAsync(d_frame, (uint8_t *)c->d_b + out_at, bytes, hipMemcpyDeviceToDevice, s));    // in place for the caller
+        // d_b is the thread's scratch, shared by every stream the thread uses: the copy out of it is complete before the next call --
+        // possibly on another stream -- may write it again (the fit above has synchronised this stream once already)
+        MLV_HIP(hipStreamSynchronize(s));
+    }
     return r;
 }
 

@@ -608,13 +608,17 @@ int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green,
         hipStream_t st = nullptr; hipEvent_t go = nullptr, done = nullptr; int *ctr = nullptr; int cap = 0;
         ~Side() { if (ctr) (void)hipFree(ctr); if (go) (void)hipEventDestroy(go); if (done) (void)hipEventDestroy(done); if (st) (void)hipStreamDestroy(st); }
     };
-    static thread_local std::map<std::pair<int, hipStream_t>, Side> t_side;      // per device and stream of the caller
+    // per thread and device (until round 4: per caller stream as well -- an entry per stream a caller ever passed, never pruned, and a
+    // recycled stream handle inherited the old one).  One side stream serves all of a thread's caller streams: everything that touches
+    // `ctr` is queued on it, in order, and an event's wait is bound to the record that precedes it, so re-recording go / done for the
+    // next call does not disturb a wait that is already queued
+    static thread_local std::map<int, Side> t_side;
     Side *side = nullptr;
     bool rows_pending = false;
     if (nfx) {
         int dev = 0;
         MLV_HIP(hipGetDevice(&dev));
-        side = &t_side[{ dev, s }];
+        side = &t_side[dev];
         if (!side->st) {
             MLV_HIP(hipStreamCreateWithFlags(&side->st, hipStreamNonBlocking));
             MLV_HIP(hipEventCreateWithFlags(&side->go, hipEventDisableTiming));

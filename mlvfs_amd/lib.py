@@ -43,7 +43,7 @@ DEVICE_SYMBOLS = [
     "mlvfs_amd_rand_stream", "mlvfs_amd_rand_stream_dev", "mlvfs_amd_process_frames_dev", "mlvfs_amd_process_frames_host",
     "mlvfs_amd_host_alloc", "mlvfs_amd_host_free", "mlvfs_amd_host_trim", "mlvfs_amd_hdr_preview_dev",
     "mlvfs_amd_cr2hdr20_dev", "mlvfs_amd_cr2hdr20_batch_dev", "mlvfs_amd_dualiso_reset", "mlvfs_amd_dualiso_trim", "mlvfs_amd_dualiso_last_scalars", "mlvfs_amd_amaze_demosaic_dev", "mlvfs_amd_amaze_debug", "mlvfs_amd_amaze_rows_extent",
-    "mlvfs_amd_timer_begin", "mlvfs_amd_timer_end", "mlvfs_amd_selftest_host", "mlvfs_amd_selftest_tables", "mlvfs_amd_frame_begin", "mlvfs_amd_frame_end", "mlvfs_amd_frame_sync", "mlvfs_amd_dropin_stats",
+    "mlvfs_amd_timer_begin", "mlvfs_amd_timer_end", "mlvfs_amd_selftest_host", "mlvfs_amd_selftest_tables", "mlvfs_amd_frame_begin", "mlvfs_amd_frame_end", "mlvfs_amd_frame_sync", "mlvfs_amd_dropin_stats", "mlvfs_amd_test_fail_next", "mlvfs_amd_dropin_transfers",
     "mlvfs_amd_mlv_open", "mlvfs_amd_mlv_close", "mlvfs_amd_mlv_frame_count", "mlvfs_amd_mlv_chunk_count",
     "mlvfs_amd_mlv_xref", "mlvfs_amd_mlv_frame_headers", "mlvfs_amd_mlv_read_frames", "mlvfs_amd_mlv_process", "mlvfs_amd_mlv_process_dualiso",
     "mlvfs_amd_lj92_info", "mlvfs_amd_lj92_decode_dev", "mlvfs_amd_lzma_uncompress",
@@ -164,6 +164,8 @@ def load() -> C.CDLL:
     sig("mlvfs_amd_frame_end", i, [])
     sig("mlvfs_amd_frame_sync", i, [vp])
     sig("mlvfs_amd_dropin_stats", None, [vp])
+    sig("mlvfs_amd_test_fail_next", None, [C.c_int])
+    sig("mlvfs_amd_dropin_transfers", None, [vp])
     sig("mlvfs_amd_process_unpacked_dev", i, [vp, vp, sz, vp, sz, i, i, i, i, vp])
     sig("mlvfs_amd_deflicker_dev", i, [gp, vp, sz, i, vp, vp])
     sig("mlvfs_amd_lzma_uncompress", i, [vp, sz, vp, sz, C.POINTER(sz)])
