@@ -537,6 +537,15 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     dev = torch.device(f"cuda:{local}")
     F, K, Wm = args.frames_per_step, args.steps, args.warmup
+    # ---- what this run really runs on: every rank's card by PCI bus id, gathered; two ranks on one card is an error outside the
+    # rehearsal mode (mlvfs_amd.dist.describe_ranks)
+    _L0 = lib.load()
+    _bus = C.create_string_buffer(64)
+    my_dev_id = _bus.value.decode() if _L0.mlvfs_amd_device_pci_bus_id(local, _bus, 64) == 0 and _bus.value else f"cuda:{local}"
+    try:
+        ranks_info = mdist.describe_ranks(mdist.gather_device_ids(my_dev_id) if grouped else [my_dev_id], rehearsal=rehearsal)
+    except RuntimeError as e:
+        sys.exit(f"bench.py: {e}")
 
     s = ClipStream(W, H, BPP, synth.BLACK, synth.WHITE, device=local)
     L = s.L
@@ -555,14 +564,26 @@ def main():
     # main.c:969-988: the clip's pixel map and stripe coefficients come from frame 0, which
     # lives on rank 0; the other ranks receive the map and the post-chroma-smooth frame, and
     # the stripes histogram of that frame is row-sharded over all ranks
+    torch.cuda.synchronize()
+    ff = {}                                            # where the first frame's time goes (ms, wall, each part synchronised)
+    def _lap(name, t_from):
+        torch.cuda.synchronize()
+        ff[name] = round((time.perf_counter() - t_from) * 1e3, 3)
+        return time.perf_counter()
     t0 = time.perf_counter()
+    tl = t0
     if rank == 0:
         frame0 = s.unpack(packed[:1])
+        tl = _lap("unpack", tl)
         pix = s.detect_bad_pixels(frame0[0], 0)
+        tl = _lap("detect_bad_pixels", tl)
         s.fix_pixels(frame0)
+        tl = _lap("fix_pixels", tl)
         frame0 = s.chroma_smooth(frame0, args.cs) if args.cs else frame0
+        tl = _lap("chroma_smooth", tl)
     else:
         frame0 = s.alloc_out(1)
+    t_coll = time.perf_counter()
     if grouped:
         n_pix = torch.tensor([len(pix) if rank == 0 else 0], dtype=torch.int64, device=dev)
         dist.broadcast(n_pix, src=0)
@@ -572,12 +593,16 @@ def main():
         dist.broadcast(frame0.view(torch.uint8), src=0)
         if rank != 0:
             s.set_pixel_map(pix_t.cpu().numpy())
+    tl = _lap("broadcasts", t_coll)
     count_rows, hist_rows = mdist.gpu_callbacks(s, frame0[0])
     hist, num, calls = mdist.sharded_stripes_histogram(count_rows, hist_rows, H, dev)
+    tl = _lap("stripes_count_rand_hist_allreduce", tl)
     needed, coeffs = mdist.solve_coefficients(hist, num, s.frame_size)
     s.set_stripes(needed, coeffs)
-    torch.cuda.synchronize()
+    tl = _lap("stripes_solve", tl)
     first_frame_ms = (time.perf_counter() - t0) * 1e3
+    ff["collectives_and_sharded_histogram"] = round(ff.get("broadcasts", 0) + ff["stripes_count_rand_hist_allreduce"], 3)
+    ff["local"] = round(first_frame_ms - ff["collectives_and_sharded_histogram"], 3)
 
     def step(b):
         s.process(packed[b * F:(b + 1) * F], out[b * F:(b + 1) * F], cs=args.cs, fix_pixels=True, stripes=True)
@@ -608,10 +633,16 @@ def main():
     dt = time.perf_counter() - t0
     ms = np.zeros(K, np.float32)
     n_timed = L.mlvfs_amd_timer_end(lib.ptr(ms), K)
+    # each rank's own rate from its kernel timer (HIP events around its launches): what the slowest-rank wall time hides
+    my_kernel_fps = float(K * F / (ms[:n_timed].sum() * 1e-3)) if n_timed else 0.0
+    per_rank_fps = [round(my_kernel_fps, 1)]
     if grouped:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        parts = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(parts, torch.tensor([my_kernel_fps], dtype=torch.float64, device=dev))
+        per_rank_fps = [round(float(p.item()), 1) for p in parts]
 
     # ---- strong scaling, reported beside the weak headline (never `value`): ONE clip of K*F frames -- the N = 1 workload -- split
     # into contiguous frame ranges (mlvfs_amd.dist.frame_range), no data-path collective; time = slowest rank between two barriers
@@ -693,7 +724,9 @@ def main():
         "config": {"workload": "configs[2]: 3584x1320 unpack + cs5x5 + stripes + bad-pix, frame stream resident in HBM",
                    "frames_per_step": F, "frames_per_rank": K * F, "chroma_smooth": args.cs,
                    "bad_pixels_in_map": int(len(s.get_pixel_map())), "stripe_coeffs": [int(c) for c in coeffs],
-                   "parallelism": f"frames x{world}", "first_frame_ms": round(first_frame_ms, 2), "strong_scaling": strong,
+                   "parallelism": f"frames x{world}", "first_frame_ms": round(first_frame_ms, 2), "first_frame_split_ms": ff,
+                   "ranks_seen": ranks_info["ranks_seen"], "devices_seen": ranks_info["devices_seen"], "device_ids": ranks_info["device_ids"],
+                   "ranks_sharing_a_device": ranks_info["shared"], "per_rank_kernel_fps": per_rank_fps, "strong_scaling": strong,
                    "collective": None if not grouped else ("gloo (rehearsal)" if rehearsal else "RCCL all_gather + all_reduce int32[8][65536], once per clip")},
         "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),

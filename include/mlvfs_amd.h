@@ -117,6 +117,11 @@ typedef struct {
 
 /* context: one per (host thread, device); created lazily */
 int         mlvfs_amd_device_count(void);
+/* PCI bus id ("0000:c1:00.0") of visible device `device` into out (len >= 16): the physical card, whatever the enumeration order;
+ * and the device the calling thread is bound to (-1: not yet).  Threads that do not choose a device (mlvfs_amd_init) are spread
+ * round-robin over the visible GPUs in the order of their PCI bus ids; the mapping is printed once (MLVFS_AMD_QUIET=1: not). */
+int mlvfs_amd_device_pci_bus_id(int device, char *out, int len);
+int mlvfs_amd_thread_device(void);
 int         mlvfs_amd_init(int device);              /* binds the calling thread to `device` */
 const char *mlvfs_amd_last_error(void);
 const char *mlvfs_amd_version(void);

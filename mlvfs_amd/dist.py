@@ -26,6 +26,32 @@ import torch
 import torch.distributed as dist
 
 
+def describe_ranks(device_ids, rehearsal: bool = False) -> dict:
+    """What a multi-process run really ran on: `device_ids[r]` is the identity of the card rank r computes
+    on -- its PCI bus id, gathered from every rank.  Returns {"ranks_seen", "devices_seen", "device_ids", "shared"} and raises
+    when two ranks share a card outside a rehearsal (N ranks on fewer cards measure contention, not scaling)."""
+    ids = [str(x) for x in device_ids]
+    seen = {}
+    for r, d in enumerate(ids):
+        seen.setdefault(d, []).append(r)
+    shared = {d: rs for d, rs in seen.items() if len(rs) > 1}
+    info = {"ranks_seen": len(ids), "devices_seen": len(seen), "device_ids": ids,
+            "shared": {d: rs for d, rs in sorted(shared.items())} or None}
+    if shared and not rehearsal:
+        raise RuntimeError("ranks share a GPU outside rehearsal mode: " +
+                           ", ".join(f"{d}: ranks {rs}" for d, rs in sorted(shared.items())))
+    return info
+
+
+def gather_device_ids(my_id: str, group=None):
+    """all_gather of each rank's device identity (a group of one included: the collective still runs)."""
+    if not dist.is_initialized():
+        return [my_id]
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, my_id, group=group)
+    return out
+
+
 def frame_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous block of frames for `rank` (frames are the unit of parallelism)."""
     return n_frames * rank // world, n_frames * (rank + 1) // world

@@ -34,7 +34,7 @@ DROPIN_SYMBOLS = [
     "hist_create", "hist_add", "hist_median", "hist_destroy", "lj92_open", "lj92_decode", "lj92_close", "gif_get_data", "gif_get_size",
 ]
 DEVICE_SYMBOLS = [
-    "mlvfs_amd_device_count", "mlvfs_amd_init", "mlvfs_amd_last_error", "mlvfs_amd_version",
+    "mlvfs_amd_device_count", "mlvfs_amd_device_pci_bus_id", "mlvfs_amd_thread_device", "mlvfs_amd_init", "mlvfs_amd_last_error", "mlvfs_amd_version",
     "mlvfs_amd_clip_create", "mlvfs_amd_clip_destroy", "mlvfs_amd_clip_set_stripes", "mlvfs_amd_clip_get_stripes",
     "mlvfs_amd_clip_set_pixel_map", "mlvfs_amd_clip_get_pixel_map", "mlvfs_amd_clip_set_t16_layout", "mlvfs_amd_clip_get_t16_layout",
     "mlvfs_amd_unpack_dev", "mlvfs_amd_chroma_smooth_dev", "mlvfs_amd_detect_bad_pixels_dev",
@@ -120,6 +120,8 @@ def load() -> C.CDLL:
     sig("hist_destroy", None, [vp])
     # device API
     sig("mlvfs_amd_device_count", i, [])
+    sig("mlvfs_amd_device_pci_bus_id", i, [i, C.c_char_p, i])
+    sig("mlvfs_amd_thread_device", i, [])
     sig("mlvfs_amd_init", i, [i])
     sig("mlvfs_amd_last_error", C.c_char_p, [])
     sig("mlvfs_amd_version", C.c_char_p, [])

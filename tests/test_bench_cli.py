@@ -51,6 +51,24 @@ def test_bench_gpus2_starts_two_ranks_rehearsal(gpu):
     assert res["config"]["stripe_coeffs"] == golden["B_cs5_badpix_stripes_coeffs"]
     assert res["parity"]["ok"] is True and res["parity"]["hashes"] == res["parity"]["reference"]
     assert res["roofline"]["frac"] and res["value"] > 0
+    # the run describes what it ran on: two ranks, ONE card (both on device 0 -- allowed in a rehearsal only), each rank's own rate
+    c = res["config"]
+    assert c["ranks_seen"] == 2 and c["devices_seen"] == 1 and len(c["device_ids"]) == 2 and c["device_ids"][0] == c["device_ids"][1]
+    assert c["ranks_sharing_a_device"] == {c["device_ids"][0]: [0, 1]}
+    assert len(c["per_rank_kernel_fps"]) == 2 and all(v > 0 for v in c["per_rank_kernel_fps"])
+    sp = c["first_frame_split_ms"]
+    assert abs(sp["local"] + sp["collectives_and_sharded_histogram"] - c["first_frame_ms"]) < 0.02
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_card_is_refused_outside_a_rehearsal(gpu):
+    """Two ranks, one visible card, no rehearsal switch: the run must not produce a number."""
+    if gpu.mlvfs_amd_device_count() >= 2:
+        pytest.skip("two cards visible: the ranks get one each")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MLVFS_BENCH_REHEARSAL")}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--frames-per-step", "2",
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '"metric"' not in r.stdout
 
 
 @pytest.mark.gpu

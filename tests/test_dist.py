@@ -71,3 +71,43 @@ def test_ranges():
         got = [mdist.frame_range(n, r, world) for r in range(world)]
         assert got[0][0] == 0 and got[-1][1] == n and all(a[1] == b[0] for a, b in zip(got, got[1:]))
     assert mdist.row_range(1320, 3, 8) == (495, 660)
+
+
+def test_describe_ranks_counts_devices_and_refuses_shared_cards():
+    """bench.py gathers every rank's PCI bus id; N ranks on fewer than N cards is an error outside the rehearsal mode."""
+    from mlvfs_amd import dist as mdist
+    ids = [f"0000:{b:02x}:00.0" for b in (0x0c, 0x22, 0x38, 0x5c, 0x9f, 0xaf, 0xbf, 0xdf)]
+    info = mdist.describe_ranks(ids)
+    assert info["ranks_seen"] == 8 and info["devices_seen"] == 8 and info["shared"] is None and info["device_ids"] == ids
+    with pytest.raises(RuntimeError, match="share a GPU"):
+        mdist.describe_ranks([ids[0], ids[1], ids[0]])
+    reh = mdist.describe_ranks([ids[0], ids[0]], rehearsal=True)
+    assert reh["ranks_seen"] == 2 and reh["devices_seen"] == 1 and reh["shared"] == {ids[0]: [0, 1]}
+    assert mdist.gather_device_ids("x") == ["x"]                      # no process group: the rank itself
+
+
+def _gather_ids_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from mlvfs_amd import dist as mdist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        q.put((rank, mdist.gather_device_ids(f"card-{rank // 2}")))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_ids_are_gathered_from_every_rank_gloo_world3():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    ps = [ctx.Process(target=_gather_ids_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert all(got[r] == ["card-0", "card-0", "card-1"] for r in range(3))
+    from mlvfs_amd import dist as mdist
+    with pytest.raises(RuntimeError):
+        mdist.describe_ranks(got[0])
