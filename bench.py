@@ -564,45 +564,57 @@ def main():
     # main.c:969-988: the clip's pixel map and stripe coefficients come from frame 0, which
     # lives on rank 0; the other ranks receive the map and the post-chroma-smooth frame, and
     # the stripes histogram of that frame is row-sharded over all ranks
-    torch.cuda.synchronize()
-    ff = {}                                            # where the first frame's time goes (ms, wall, each part synchronised)
-    def _lap(name, t_from):
+    def first_frame(st):
+        """The clip's pixel map and stripe coefficients from its frame 0, on stream object `st`; returns (split in ms, total ms, ...)."""
         torch.cuda.synchronize()
-        ff[name] = round((time.perf_counter() - t_from) * 1e3, 3)
-        return time.perf_counter()
-    t0 = time.perf_counter()
-    tl = t0
-    if rank == 0:
-        frame0 = s.unpack(packed[:1])
-        tl = _lap("unpack", tl)
-        pix = s.detect_bad_pixels(frame0[0], 0)
-        tl = _lap("detect_bad_pixels", tl)
-        s.fix_pixels(frame0)
-        tl = _lap("fix_pixels", tl)
-        frame0 = s.chroma_smooth(frame0, args.cs) if args.cs else frame0
-        tl = _lap("chroma_smooth", tl)
-    else:
-        frame0 = s.alloc_out(1)
-    t_coll = time.perf_counter()
-    if grouped:
-        n_pix = torch.tensor([len(pix) if rank == 0 else 0], dtype=torch.int64, device=dev)
-        dist.broadcast(n_pix, src=0)
-        pix_t = torch.from_numpy(pix.copy()).to(dev) if rank == 0 else \
-            torch.zeros((int(n_pix.item()), 2), dtype=torch.int32, device=dev)
-        dist.broadcast(pix_t, src=0)
-        dist.broadcast(frame0.view(torch.uint8), src=0)
-        if rank != 0:
-            s.set_pixel_map(pix_t.cpu().numpy())
-    tl = _lap("broadcasts", t_coll)
-    count_rows, hist_rows = mdist.gpu_callbacks(s, frame0[0])
-    hist, num, calls = mdist.sharded_stripes_histogram(count_rows, hist_rows, H, dev)
-    tl = _lap("stripes_count_rand_hist_allreduce", tl)
-    needed, coeffs = mdist.solve_coefficients(hist, num, s.frame_size)
-    s.set_stripes(needed, coeffs)
-    tl = _lap("stripes_solve", tl)
-    first_frame_ms = (time.perf_counter() - t0) * 1e3
-    ff["collectives_and_sharded_histogram"] = round(ff.get("broadcasts", 0) + ff["stripes_count_rand_hist_allreduce"], 3)
-    ff["local"] = round(first_frame_ms - ff["collectives_and_sharded_histogram"], 3)
+        ff = {}                                        # where the first frame's time goes (ms, wall, each part synchronised)
+        def _lap(name, t_from):
+            torch.cuda.synchronize()
+            ff[name] = round((time.perf_counter() - t_from) * 1e3, 3)
+            return time.perf_counter()
+        t0 = time.perf_counter()
+        tl = t0
+        pix = None
+        if rank == 0:
+            frame0 = st.unpack(packed[:1])
+            tl = _lap("unpack", tl)
+            pix = st.detect_bad_pixels(frame0[0], 0)
+            tl = _lap("detect_bad_pixels", tl)
+            st.fix_pixels(frame0)
+            tl = _lap("fix_pixels", tl)
+            frame0 = st.chroma_smooth(frame0, args.cs) if args.cs else frame0
+            tl = _lap("chroma_smooth", tl)
+        else:
+            frame0 = st.alloc_out(1)
+        t_coll = time.perf_counter()
+        if grouped:
+            n_pix = torch.tensor([len(pix) if rank == 0 else 0], dtype=torch.int64, device=dev)
+            dist.broadcast(n_pix, src=0)
+            pix_t = torch.from_numpy(pix.copy()).to(dev) if rank == 0 else \
+                torch.zeros((int(n_pix.item()), 2), dtype=torch.int32, device=dev)
+            dist.broadcast(pix_t, src=0)
+            dist.broadcast(frame0.view(torch.uint8), src=0)
+            if rank != 0:
+                st.set_pixel_map(pix_t.cpu().numpy())
+        tl = _lap("broadcasts", t_coll)
+        count_rows, hist_rows = mdist.gpu_callbacks(st, frame0[0])
+        hist, num, calls = mdist.sharded_stripes_histogram(count_rows, hist_rows, H, dev)
+        tl = _lap("stripes_count_rand_hist_allreduce", tl)
+        needed, coeffs = mdist.solve_coefficients(hist, num, st.frame_size)
+        st.set_stripes(needed, coeffs)
+        tl = _lap("stripes_solve", tl)
+        total = (time.perf_counter() - t0) * 1e3
+        ff["collectives_and_sharded_histogram"] = round(ff.get("broadcasts", 0) + ff["stripes_count_rand_hist_allreduce"], 3)
+        ff["local"] = round(total - ff["collectives_and_sharded_histogram"], 3)
+        return ff, total, needed, coeffs
+
+    ff, first_frame_ms, needed, coeffs = first_frame(s)
+    # the same on a SECOND clip object: what every further clip of a mounted directory costs, without what the process pays once
+    # (code objects of the analysis kernels, the black level's output table, the thread's scratch buffers)
+    s2 = ClipStream(W, H, BPP, synth.BLACK, synth.WHITE, device=local)
+    ff2, first_frame_next_clip_ms, needed2, coeffs2 = first_frame(s2)
+    assert int(needed2) == int(needed) and [int(c) for c in coeffs2] == [int(c) for c in coeffs]
+    s2.close()
 
     def step(b):
         s.process(packed[b * F:(b + 1) * F], out[b * F:(b + 1) * F], cs=args.cs, fix_pixels=True, stripes=True)
@@ -725,6 +737,7 @@ def main():
                    "frames_per_step": F, "frames_per_rank": K * F, "chroma_smooth": args.cs,
                    "bad_pixels_in_map": int(len(s.get_pixel_map())), "stripe_coeffs": [int(c) for c in coeffs],
                    "parallelism": f"frames x{world}", "first_frame_ms": round(first_frame_ms, 2), "first_frame_split_ms": ff,
+                   "first_frame_next_clip_ms": round(first_frame_next_clip_ms, 2), "first_frame_next_clip_split_ms": ff2,
                    "ranks_seen": ranks_info["ranks_seen"], "devices_seen": ranks_info["devices_seen"], "device_ids": ranks_info["device_ids"],
                    "ranks_sharing_a_device": ranks_info["shared"], "per_rank_kernel_fps": per_rank_fps, "strong_scaling": strong,
                    "collective": None if not grouped else ("gloo (rehearsal)" if rehearsal else "RCCL all_gather + all_reduce int32[8][65536], once per clip")},

@@ -1645,8 +1645,16 @@ __global__ __launch_bounds__(256) void k_dark_share(const uint8_t *frame, int w,
 
 int dark_share(bool packed, const void *d_frame, int w, int h, int black, hipStream_t stream, int *share_1024)
 {
-    int *d_counts = nullptr, hc[2] = { 0, 0 };
-    MLV_HIP(hipMalloc(&d_counts, 2 * sizeof(int)));
+    // the two counters live as long as the thread (an allocation and a release per clip were a fifth of this call's time)
+    struct Counts {
+        std::map<int, int *> m;
+        ~Counts() { for (auto &kv : m) if (kv.second) (void)hipFree(kv.second); }
+    };
+    static thread_local Counts t_counts;
+    int dev = 0, hc[2] = { 0, 0 };
+    MLV_HIP(hipGetDevice(&dev));
+    int *&d_counts = t_counts.m[dev];
+    if (!d_counts) MLV_HIP(hipMalloc(&d_counts, 2 * sizeof(int)));
     hipError_t e = hipMemsetAsync(d_counts, 0, 2 * sizeof(int), stream);
     if (e == hipSuccess) {
         if (packed) hipLaunchKernelGGL(k_dark_share<true>, dim3(64), dim3(256), 0, stream, (const uint8_t *)d_frame, w, h, black, d_counts);
@@ -1655,7 +1663,6 @@ int dark_share(bool packed, const void *d_frame, int w, int h, int black, hipStr
     }
     if (e == hipSuccess) e = hipMemcpyAsync(hc, d_counts, sizeof(hc), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(d_counts);
     if (e != hipSuccess) { set_error("dark_share: %s", hipGetErrorString(e)); return MLVFS_AMD_ERR_HIP; }
     *share_1024 = hc[1] > 0 ? (int)((long long)hc[0] * 1024 / hc[1]) : 0;
     return MLVFS_AMD_OK;
