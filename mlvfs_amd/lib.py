@@ -68,20 +68,24 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(SO_PATH):
+    # MLVFS_AMD_LIB: another build of the same library -- the sanitizer build of the host-only code (`make -C mlvfs_amd/csrc
+    # hostcheck`, tests/test_hostcheck.py); never set by the tests proper or by bench.py
+    so_path = os.environ.get("MLVFS_AMD_LIB") or SO_PATH
+    if not os.path.exists(so_path):
         raise FileNotFoundError(
-            f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{so_path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(mlvfs_amd has no CPU fallback)")
     # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.  If our
     # library pulled in /opt/rocm's copy first, torch (imported later for device memory and
     # streams) would bring up a second runtime that sees no GPU.  Importing torch first makes
     # the dynamic linker resolve our DT_NEEDED libamdhip64.so.* to the copy already loaded.
     # (A C host such as MLVFS has no torch and simply uses the system runtime.)
-    try:
-        import torch  # noqa: F401
-    except Exception:  # pragma: no cover - torch is optional for the drop-in symbols
-        pass
-    L = C.CDLL(SO_PATH)
+    if not os.environ.get("MLVFS_AMD_LIB"):
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the drop-in symbols
+            pass
+    L = C.CDLL(so_path)
     vp, sz, i, i64 = C.c_void_p, C.c_size_t, C.c_int, C.c_int64
     gp = C.POINTER(Geom)
     fhp = C.POINTER(abi.FrameHeaders)
