@@ -463,7 +463,7 @@ def extra_pcie(N=128, threads=16):
         import shutil
         import tempfile
         from mlvfs_amd import mlvfile
-        hosts = {k: os.path.join(ROOT, "oracle", "_ref", "ref_host_" + k) for k in ("amd", "amd_wrap")}
+        hosts = {k: os.path.join(ROOT, "oracle", "_ref", "ref_host_" + k) for k in ("amd", "amd_wrap", "amd_wrap_alloc")}
         if all(os.path.exists(h) for h in hosts.values()):
             d = tempfile.mkdtemp(prefix="mlvfs_amd_bench_")
             try:
@@ -478,6 +478,7 @@ def extra_pcie(N=128, threads=16):
                     line = [ln for ln in r.stderr.splitlines() if ln.startswith("{")]
                     rh[k] = json.loads(line[-1])["fps"] if line else f"failed rc {r.returncode}"
                 res["reference_process_frame_text_host"] = {f"fps_{threads}_threads_plain_link": rh["amd"], f"fps_{threads}_threads_wrap_link": rh["amd_wrap"],
+                                                            f"fps_{threads}_threads_wrap_and_alloc_shim_link": rh["amd_wrap_alloc"],
                                                             "includes": "mlv_get_frame_headers + index walk + fopen/fread of a 32-frame two-chunk clip per frame (page cache)"}
             finally:
                 shutil.rmtree(d, ignore_errors=True)

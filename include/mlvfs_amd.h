@@ -208,6 +208,10 @@ void *mlvfs_amd_host_alloc(size_t bytes);
 /* Gives the buffer back to the pool.  A pointer that did not come from mlvfs_amd_host_alloc, and a buffer freed a second time,
  * are reported on stderr and otherwise ignored (the library frees nothing it does not own). */
 void mlvfs_amd_host_free(void *p);
+/* 1 when [p, p + bytes) lies inside a live buffer of mlvfs_amd_host_alloc (page-locked and mapped: the GPU can address it), else 0 */
+int mlvfs_amd_host_owns(const void *p, size_t bytes);
+/* bytes from p to the end of the live mlvfs_amd_host_alloc buffer that holds it (its size rounded up to 64 KiB); 0: in none */
+size_t mlvfs_amd_host_size(const void *p);
 /* Returns the pool's cached (free) buffers to the runtime; result: bytes released. */
 size_t mlvfs_amd_host_trim(void);
 
@@ -361,6 +365,10 @@ void mlvfs_amd_dropin_stats(long long out[2]);
  * down} (pixel repairs that fetch their few patched pixels are not counted).  Inside a frame bracket a frame costs one upload of its
  * payload and one download, whatever stages run in between. */
 void mlvfs_amd_dropin_transfers(long long out[4]);
+/* MLVFS_AMD_DROPIN_PROFILE=1 in the environment: where the wall time of the bracketed frames went, in ms summed over all threads:
+ * {inside dng_get_image_data, of it the upload call, of it the wait for the upload's end, inside the recorded stage calls, inside
+ * mlvfs_amd_frame_end, of it the fused launch's calls, of it the download call + the wait for it, number of frames}. */
+void mlvfs_amd_dropin_profile(double out[8]);
 /* Test hook: the calling thread's next fused launch of a bracketed frame (what = 1) or next frame download (what = 2) reports a HIP
  * error without touching the device.  What the caller then finds -- a zeroed frame and one line on stderr, never the bytes its
  * malloc returned -- is the library's failure policy ("When the device fails"; tests/test_failure_policy.py). */

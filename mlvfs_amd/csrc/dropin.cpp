@@ -10,6 +10,7 @@
 #include "clip.h"
 
 #include <atomic>
+#include <chrono>
 
 #include <cerrno>
 #include <cstdlib>
@@ -126,6 +127,20 @@ void warn_unsynced(const void *host)
 
 int download(ThreadCtx *c, void *host, const void *dev, size_t bytes);
 
+// How a worker waits for its stream.  hipStreamSynchronize spins; with as many workers as the process has CPUs (libfuse's pool on a
+// 16-CPU cgroup) the spinning workers take the CPUs the runtime's own threads need.  MLVFS_AMD_WAIT=block: the wait is an event
+// created with hipEventBlockingSync, i.e. the thread sleeps until the interrupt.  (A/B: tools/dropin_bench_c.sh)
+const int g_wait_mode = [] { const char *e = getenv("MLVFS_AMD_WAIT"); return e && !strcmp(e, "block") ? 1 : 0; }();
+thread_local hipEvent_t t_wait_ev = nullptr;
+hipError_t wait_stream(hipStream_t st)
+{
+    if (!g_wait_mode) return hipStreamSynchronize(st);
+    if (!t_wait_ev) { const hipError_t e = hipEventCreateWithFlags(&t_wait_ev, hipEventDisableTiming | hipEventBlockingSync); if (e != hipSuccess) return e; }
+    hipError_t e = hipEventRecord(t_wait_ev, st);
+    if (e == hipSuccess) e = hipEventSynchronize(t_wait_ev);
+    return e;
+}
+
 // FAILURE POLICY ("When the device fails"): there is no CPU path in this library.  dng_get_image_data is the one
 // stage whose failure would leave the caller with a buffer nobody has written (process_frame mallocs it: main.c:931) -- the frame is
 // then ZEROED (a black DNG, never the heap's old contents) and one line goes to stderr, like the reference's err_printf; a later
@@ -146,6 +161,16 @@ std::atomic<long long> g_lazy_fused{ 0 }, g_lazy_early{ 0 };
 // test hook (mlvfs_amd_test_fail_next): the calling thread's next fused launch of a bracketed frame [1] / next frame download [2]
 // reports a HIP error without touching the device -- how tests/test_failure_policy.py shows what MLVFS serves when the device is lost
 thread_local int t_fail_next[3] = { 0, 0, 0 };
+// where the wall time of a bracketed frame goes, per process, in ns (MLVFS_AMD_DROPIN_PROFILE=1; mlvfs_amd_dropin_profile):
+// [0] inside dng_get_image_data, [1] of it the upload call, [2] of it the wait for the upload's end, [3] inside the recorded stage
+// calls, [4] inside mlvfs_amd_frame_end, [5] of it the fused launch's calls, [6] of it the download call + the wait for it, [7] frames
+std::atomic<long long> g_prof[8] = { { 0 }, { 0 }, { 0 }, { 0 }, { 0 }, { 0 }, { 0 }, { 0 } };
+const bool g_prof_on = [] { const char *e = getenv("MLVFS_AMD_DROPIN_PROFILE"); return e && e[0] == '1'; }();
+struct ProfScope {
+    int slot; std::chrono::steady_clock::time_point t0;
+    explicit ProfScope(int s) : slot(s) { if (g_prof_on) t0 = std::chrono::steady_clock::now(); }
+    ~ProfScope() { if (g_prof_on) g_prof[slot] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
 // what the drop-in stages moved over the link, process-wide: {uploads, downloads, bytes up, bytes down} (mlvfs_amd_dropin_transfers)
 std::atomic<long long> g_xfer[4] = { { 0 }, { 0 }, { 0 }, { 0 } };
 
@@ -153,6 +178,7 @@ int lazy_run(ThreadCtx *c, bool at_sync)
 {
     LazyFrame &z = c->lazy;
     if (!z.active) return MLVFS_AMD_OK;
+    ProfScope prof_launch(5);
     z.active = false;
     (at_sync ? g_lazy_fused : g_lazy_early)++;
     std::shared_ptr<Clip> pix;
@@ -160,10 +186,18 @@ int lazy_run(ThreadCtx *c, bool at_sync)
     const Geom g{ z.w, z.h, 14, z.black, z.white };
     const bool patch = pix && pix->n_entries > 0;
     int rc = c->ensure_res((z.bytes + 15) / 16 * 16);
+    // At the fetch, a frame buffer that comes from mlvfs_amd_host_alloc (page-locked, mapped: integration/mlvfs_amd_wrap_alloc.c
+    // makes process_frame's malloc one) is written by the fused kernel itself, over the link: no download, no copy engine.  Sixteen
+    // workers' downloads queue up behind each other on the engines (1.6-2.5 ms of waiting per frame for 0.19 ms of transfer); the
+    // kernel's stores do not: 2 420 -> 3 618 fps from 16 threads, 1 550 -> 1 615 from one (tools/dropin_bench_c.sh, round 4).
+    // MLVFS_AMD_ZEROCOPY=0 switches it off.
+    static const bool zc_on = [] { const char *e = getenv("MLVFS_AMD_ZEROCOPY"); return !(e && e[0] == '0'); }();
+    const bool zero_copy = zc_on && at_sync && ((uintptr_t)z.host % 16) == 0 && mlvfs_amd_host_owns(z.host, z.bytes) != 0;
+    void *const d_out = zero_copy ? z.host : c->d_res[0];
     if (!rc && t_fail_next[1]) { t_fail_next[1] = 0; set_error("injected failure of the fused launch (test hook)"); rc = MLVFS_AMD_ERR_HIP; }
     if (!rc) {
         if (!patch && z.cs == 0 && !z.stripes)
-            rc = launch_unpack(c->d_a, 0, c->d_res[0], 0, 0, (uint32_t)(z.bytes / 2), 14, 1, c->stream);
+            rc = launch_unpack(c->d_a, 0, d_out, 0, 0, (uint32_t)(z.bytes / 2), 14, 1, c->stream);
         else {
             PatchView pv{};
             if (patch) {
@@ -176,8 +210,14 @@ int lazy_run(ThreadCtx *c, bool at_sync)
                 pv = pix->patch_view(c->d_patch, 1, geo);
             }
             if (!rc)
-                rc = launch_frame(c->dev, g, true, c->d_a, 0, c->d_res[0], 0, 1, z.cs, patch ? &pv : nullptr, z.stripes, z.coef, c->stream);
+                rc = launch_frame(c->dev, g, true, c->d_a, 0, d_out, 0, 1, z.cs, patch ? &pv : nullptr, z.stripes, z.coef, c->stream);
         }
+    }
+    if (!rc && zero_copy) {                        // the frame is in the caller's buffer once the stream has drained; no device copy is kept
+        ProfScope prof_down(6);
+        if (wait_stream(c->stream) != hipSuccess) { set_error("fused launch (zero copy): stream wait failed"); rc = MLVFS_AMD_ERR_HIP; }
+        c->res_host = nullptr; c->res_dirty = false;
+        return rc;
     }
     if (rc) { c->res_host = nullptr; c->res_dirty = false; return rc; }
     c->res_cur = 0;
@@ -200,6 +240,7 @@ bool lazy_next(ThreadCtx *c, const void *host, size_t bytes, int rank)
 // reaches 1 840 at, tools/zerocopy_probe.hip -- and slower without MLVFS_AMD_RESIDENT.)
 int upload(ThreadCtx *c, void *dev, const void *host, size_t bytes)
 {
+    ProfScope prof_up(1);
     g_xfer[0]++; g_xfer[2] += (long long)bytes;
     MLV_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
     return MLVFS_AMD_OK;
@@ -254,9 +295,10 @@ void commit_frame(ThreadCtx *c, const void *host, size_t bytes, int rank, int wh
 int download(ThreadCtx *c, void *host, const void *dev, size_t bytes)
 {
     if (t_fail_next[2]) { t_fail_next[2] = 0; set_error("injected failure of the frame's download (test hook)"); return MLVFS_AMD_ERR_HIP; }
+    ProfScope prof_down(6);
     g_xfer[1]++; g_xfer[3] += (long long)bytes;
     MLV_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
-    MLV_HIP(hipStreamSynchronize(c->stream));
+    MLV_HIP(wait_stream(c->stream));
     return MLVFS_AMD_OK;
 }
 
@@ -416,6 +458,8 @@ int mlvfs_amd_frame_end(void)
     ThreadCtx *c = thread_ctx_if_any();             // a bracket without pixel work never creates a stream
     if (!c || (!c->lazy.active && !c->res_dirty)) return MLVFS_AMD_OK;
     LibcRandGuard rand_guard;
+    ProfScope prof_end(4);
+    if (g_prof_on) g_prof[7]++;
     return flush_pending(c);
 }
 
@@ -430,6 +474,11 @@ int mlvfs_amd_frame_sync(void *image_data)
     LibcRandGuard rand_guard;
     return flush_pending(c);
 }
+
+// MLVFS_AMD_DROPIN_PROFILE=1: where the wall time of the bracketed frames went, in milliseconds summed over all threads: {inside
+// dng_get_image_data, of it the upload call, of it the wait for the upload, inside the recorded stage calls, inside
+// mlvfs_amd_frame_end, of it the fused launch's calls, of it download + wait, number of frames}
+void mlvfs_amd_dropin_profile(double out[8]) { for (int i = 0; i < 8; i++) out[i] = i < 7 ? g_prof[i].load() * 1e-6 : (double)g_prof[i].load(); }
 
 // whole-frame transfers of the drop-in stages since the process started: {uploads, downloads, bytes up, bytes down}
 void mlvfs_amd_dropin_transfers(long long out[4]) { for (int i = 0; i < 4; i++) out[i] = g_xfer[i].load(); }
@@ -459,6 +508,7 @@ size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8
                           size_t max_size)
 {
     LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
+    ProfScope prof_unpack(0);
     const int bpp = fh->rawi_hdr.raw_info.bits_per_pixel;
     // window arithmetic of dng.c:815-826
     const uint32_t first_px = (uint32_t)(offset > 0 ? offset : 0) / 2;
@@ -486,6 +536,8 @@ size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8
     c->res_host = nullptr;
     c->res_dirty = false;
     if (c->ensure((in_bytes + 15) / 16 * 16, 0) || c->ensure_res((out_b + 15) / 16 * 16)) return fail();
+    // (The same for the way in -- the payload fetched by a kernel instead of a copy engine -- was measured and is not there: 2 481
+    // instead of 3 618 fps at 16 threads, 1 410 instead of 1 615 from one; reads over the link stall the whole launch.)
     if (upload(c, c->d_a, packed_bits, in_bytes)) {
         set_error("dng_get_image_data: upload failed");
         return fail();
@@ -494,7 +546,7 @@ size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8
     // page-locked memory the copy above is still under way then (from pageable memory it is not), so its end gets an event
     const bool deferred = resident_level() == 2 && offset == 0 && out_b == dng_get_image_size(fh);
     if (deferred) {
-        if (!c->ev_up && hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming) != hipSuccess) return fail();
+        if (!c->ev_up && hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming | (g_wait_mode ? hipEventBlockingSync : 0)) != hipSuccess) return fail();
         if (hipEventRecord(c->ev_up, c->stream) != hipSuccess) return fail();
     }
     uint8_t *dst = output_buffer + lead + offset % 2;
@@ -505,7 +557,10 @@ size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8
         z.w = fh->rawi_hdr.xRes; z.h = fh->rawi_hdr.yRes;
         z.black = fh->rawi_hdr.raw_info.black_level; z.white = fh->rawi_hdr.raw_info.white_level;
         z.rank = RANK_UNPACK; z.pix.reset(); z.cs = 0; z.stripes = false;
-        if (hipEventSynchronize(c->ev_up) != hipSuccess) { z.active = false; return fail(); }
+        {
+            ProfScope prof_wait(2);
+            if (hipEventSynchronize(c->ev_up) != hipSuccess) { z.active = false; return fail(); }
+        }
         return max_size;
     }
     if (launch_unpack(c->d_a, 0, c->d_res[0], 0, first_px, npix, bpp, 1, c->stream)) return fail();
@@ -524,6 +579,7 @@ size_t dng_get_image_data(struct frame_headers *fh, uint16_t *packed_bits, uint8
 // ============================================================== cs.h
 void chroma_smooth(struct frame_headers *fh, uint16_t *image_data, int method)
 {
+    ProfScope prof_stage(3);
     LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     const FrameView v = view_of(fh);
     if (v.black > 16384) { fprintf(stderr, "Black level too large for processing\n"); return; }   // main.c:170-174
@@ -693,6 +749,7 @@ extern "C" {
 
 void fix_bad_pixels(struct frame_headers *fh, uint16_t *image_data, int aggressive, int dual_iso)
 {
+    ProfScope prof_stage(3);
     LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     ThreadCtx *c = thread_ctx();
     if (!c) return;
@@ -718,6 +775,7 @@ void fix_bad_pixels(struct frame_headers *fh, uint16_t *image_data, int aggressi
 
 void fix_focus_pixels(struct frame_headers *fh, uint16_t *image_data, int dual_iso)
 {
+    ProfScope prof_stage(3);
     LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     ThreadCtx *c = nullptr;
     // no map file for this camera is the common case: decide before touching the GPU
@@ -818,6 +876,7 @@ void stripes_compute_correction(struct frame_headers *fh, struct stripes_correct
 void stripes_apply_correction(struct frame_headers *fh, struct stripes_correction *correction, uint16_t *image_data,
                               off_t offset, size_t size)
 {
+    ProfScope prof_stage(3);
     LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     if (!correction || !correction->correction_needed) return;                       // stripes.c:252-253
     const FrameView v = view_of(fh);

@@ -5,6 +5,8 @@ mlvfs_load_chunks / mlvfs_close_chunks) linked three ways by oracle/Makefile --
     oracle/_ref/ref_host_ref        with the reference's dng.o cs.o stripes.o hdr.o amaze_demosaic_RT.o histogram.o patternnoise.o
     oracle/_ref/ref_host_amd        with libmlvfs_amd.so in their place
     oracle/_ref/ref_host_amd_wrap   the same plus integration/mlvfs_amd_wrap.c and the two --wrap flags (the frame bracket)
+    oracle/_ref/ref_host_amd_wrap_alloc   ... plus integration/mlvfs_amd_wrap_alloc.c and --wrap of malloc / calloc / realloc / free (page-locked
+                                    frame buffers from the library's pool: the fused kernel writes image_buffer->data itself)
 
 -- and run as three processes over the same synthetic .MLV clips.  What process_frame leaves in struct image_buffer
 (->data and ->header, main.c:929-998) must be byte-equal between them for every option set.  The programs hold the reference's
@@ -22,7 +24,7 @@ from mlvfs_amd import mlvfile, synth
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REFDIR = os.path.join(ROOT, "oracle", "_ref")
-HOSTS = {k: os.path.join(REFDIR, "ref_host_" + k) for k in ("ref", "amd", "amd_wrap")}
+HOSTS = {k: os.path.join(REFDIR, "ref_host_" + k) for k in ("ref", "amd", "amd_wrap", "amd_wrap_alloc")}
 W, H = 416, 264
 
 
@@ -102,7 +104,7 @@ def test_reference_process_frame_text_linked_against_the_hip_library(gpu, refere
     d, _ = make_clip(tmp_path, kind, reference=reference)
     order = [vpath(2), vpath(0), vpath(4), vpath(1), "/M07-1234.MLV/_PREVIEW.gif", vpath(3)]   # first frame served is NOT frame 0
     want, r0 = run_host("ref", d, tmp_path / "ref", opts, order)
-    for host in ("amd", "amd_wrap"):
+    for host in ("amd", "amd_wrap", "amd_wrap_alloc"):
         for f in os.listdir(d):                                     # every host builds its own .IDX, like a fresh mount
             if f.endswith(".IDX"):
                 os.remove(d / f)
@@ -123,9 +125,10 @@ def test_reference_text_hosts_full_size_and_throughput(gpu, tmp_path):
     d, _ = make_clip(tmp_path, "plain", n=4, w=3584, h=1320)
     opts = dict(cs=5, badpix=1, stripes=1)
     want, _ = run_host("ref", d, tmp_path / "ref", opts, [vpath(0), vpath(3)])
-    for host in ("amd", "amd_wrap"):
+    for host in ("amd", "amd_wrap", "amd_wrap_alloc"):
         got, _ = run_host(host, d, tmp_path / host, opts, [vpath(0), vpath(3)])
         assert got == want, host
-    r = subprocess.run([HOSTS["amd_wrap"], str(d), "-", "cs=5", "badpix=1", "stripes=1", "threads=8", "loops=3", "--", *[vpath(k) for k in range(4)]],
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and '"fps"' in r.stderr, r.stderr[-2000:]
+    for bench_host in ("amd_wrap", "amd_wrap_alloc"):
+      r = subprocess.run([HOSTS[bench_host], str(d), "-", "cs=5", "badpix=1", "stripes=1", "threads=8", "loops=3", "--", *[vpath(k) for k in range(4)]],
+                         capture_output=True, text=True, timeout=600)
+      assert r.returncode == 0 and '"fps"' in r.stderr, (bench_host, r.stderr[-2000:])

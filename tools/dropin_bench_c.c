@@ -134,6 +134,14 @@ int main(int argc, char **argv)
     fprintf(stderr, "{\"host\": \"C, pthreads\", \"resident\": \"%s\", \"fused_at_fetch\": %lld, \"run_early\": %lld, \"pinned_frame_buffers\": %s, \"frames_per_thread\": %d, \"fps_1_threads\": %.1f, "
             "\"fps_%d_threads\": %.1f, \"frame1_hash\": \"%016llx\", \"identical_between_threads\": %s}\n", mode ? mode : "0", st[0], st[1],
             g_pinned ? "true" : "false", g_frames, fps[0], T, fps[1], (unsigned long long)ref, same ? "true" : "false");
+    if (getenv("MLVFS_AMD_DROPIN_PROFILE")) {              /* where a bracketed frame's wall time goes (summed over the threads, both passes) */
+        double pr[8];
+        mlvfs_amd_dropin_profile(pr);
+        const double n = pr[7] > 0 ? pr[7] : 1;
+        fprintf(stderr, "{\"profile_us_per_frame\": {\"dng_get_image_data\": %.1f, \"of_it_upload_call\": %.1f, \"of_it_wait_for_upload\": %.1f, "
+                "\"recorded_stage_calls\": %.1f, \"frame_end\": %.1f, \"of_it_launch_calls\": %.1f, \"of_it_download_and_wait\": %.1f, \"frames\": %.0f}}\n",
+                1e3 * pr[0] / n, 1e3 * pr[1] / n, 1e3 * pr[2] / n, 1e3 * pr[3] / n, 1e3 * pr[4] / n, 1e3 * pr[5] / n, 1e3 * pr[6] / n, pr[7]);
+    }
     stripes_free_corrections();
     free_focus_pixel_maps();
     return 0;

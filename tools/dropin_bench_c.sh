@@ -10,6 +10,9 @@ LINK="-L mlvfs_amd -lmlvfs_amd -Wl,-rpath,$R/mlvfs_amd -L/opt/rocm/lib -Wl,-rpat
 gcc -std=gnu99 -O2 -pthread -I include tools/dropin_bench_c.c tests/c_host_chunks.c -o build/dropin_bench_c $LINK || exit 1
 gcc -std=gnu99 -O2 -pthread -I include tools/dropin_bench_c.c tests/c_host_chunks.c integration/mlvfs_amd_wrap.c \
     -Wl,--wrap=mlvfs_load_chunks -Wl,--wrap=mlvfs_close_chunks -o build/dropin_bench_c_wrap $LINK || exit 1
+gcc -std=gnu99 -O2 -pthread -I include tools/dropin_bench_c.c tests/c_host_chunks.c integration/mlvfs_amd_wrap.c integration/mlvfs_amd_wrap_alloc.c \
+    -Wl,--wrap=mlvfs_load_chunks -Wl,--wrap=mlvfs_close_chunks -Wl,--wrap=malloc -Wl,--wrap=calloc -Wl,--wrap=realloc -Wl,--wrap=free \
+    -o build/dropin_bench_c_wrap_alloc $LINK || exit 1
 python - <<'PY'
 import sys, numpy as np
 sys.path.insert(0, ".")
@@ -24,3 +27,5 @@ for pinned in 0 1; do
   timeout -k 10 300 build/dropin_bench_c_wrap build/dropin_frame0.bin build/dropin_frame1.bin $T $N $pinned 2>&1 | grep '^{' | sed 's/"resident": "0"/"resident": "wrap"/'
 
 done
+# the source unchanged (malloc / free), both shims in the link: process_frame's buffers come from the library's page-locked pool
+timeout -k 10 300 build/dropin_bench_c_wrap_alloc build/dropin_frame0.bin build/dropin_frame1.bin $T $N 0 2>&1 | grep '^{' | sed 's/"resident": "0"/"resident": "wrap+alloc shim"/'
