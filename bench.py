@@ -431,19 +431,25 @@ def extra_pcie(N=128, threads=16):
         subprocess.run(cc + srcs + ["-o", exe] + link, check=True, capture_output=True, timeout=120)
         subprocess.run(cc + srcs + [os.path.join(ROOT, "integration", "mlvfs_amd_wrap.c"), "-Wl,--wrap=mlvfs_load_chunks",
                                     "-Wl,--wrap=mlvfs_close_chunks", "-o", exe + "_wrap"] + link, check=True, capture_output=True, timeout=120)
+        # ... and with the optional second shim (integration/mlvfs_amd_wrap_alloc.c: process_frame's malloc'ed buffers come from the
+        # library's page-locked pool, the fused kernel writes the frame itself over the link)
+        subprocess.run(cc + srcs + [os.path.join(ROOT, "integration", "mlvfs_amd_wrap.c"), os.path.join(ROOT, "integration", "mlvfs_amd_wrap_alloc.c"),
+                                    "-Wl,--wrap=mlvfs_load_chunks", "-Wl,--wrap=mlvfs_close_chunks", "-Wl,--wrap=malloc", "-Wl,--wrap=calloc",
+                                    "-Wl,--wrap=realloc", "-Wl,--wrap=free", "-o", exe + "_wrap_alloc"] + link, check=True, capture_output=True, timeout=120)
         frames = []
         for k in range(2):
             fn = os.path.join(ROOT, "build", f"dropin_frame{k}.bin")
             synth.pack14(synth.normal_frame(W, H, seed=1, frame=k)).astype("<u2").tofile(fn)
             frames.append(fn)
         chost = {}
-        for mode in ("0", "1", "wrap"):
-            key = "wrap" if mode == "wrap" else f"resident{mode}"
+        for mode in ("0", "1", "wrap", "wrap_alloc"):
+            key = mode if mode.startswith("wrap") else f"resident{mode}"
             dump = os.path.join(ROOT, "build", "dropin_frame1_out.bin")
             if os.path.exists(dump):
                 os.remove(dump)
-            r = subprocess.run([exe + "_wrap" if mode == "wrap" else exe, frames[0], frames[1], str(threads), "24", "0"],
-                               env=dict(os.environ, MLVFS_AMD_RESIDENT="0" if mode == "wrap" else mode, DROPIN_DUMP=dump),
+            # (48 frames per thread after two of warm-up: the steady state of a long-running mount; 24 left thread start-up in the figure)
+            r = subprocess.run([exe + "_" + mode if mode.startswith("wrap") else exe, frames[0], frames[1], str(threads), "48", "0"],
+                               env=dict(os.environ, MLVFS_AMD_RESIDENT="0" if mode.startswith("wrap") else mode, DROPIN_DUMP=dump),
                                capture_output=True, text=True, timeout=300)
             line = [ln for ln in r.stderr.splitlines() if ln.startswith("{")]
             if line:
