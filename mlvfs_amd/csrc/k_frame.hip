@@ -1051,26 +1051,38 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     }
     __syncthreads();
     int t = __builtin_amdgcn_readfirstlane(sm.next_tile), t_end = __builtin_amdgcn_readfirstlane(sm.next_end);
-    auto tile_coords = [&](int tt, int &f, int &tr, int &tx0, int &ty0, int &trow) {
-        f = tt / tiles_per_frame;
-        const int r = tt - f * tiles_per_frame;
-        const int tcol = r / a.tiles_y;
-        trow = r - tcol * a.tiles_y;
-        tr = trow * a.tiles_x + tcol;              // the tile's number in the (row-major) pixel-map lists
-        tx0 = tcol * 2 * TCW;
-        ty0 = trow * 2 * TCH;
+    // Where a tile lies: frame, tile column, tile row.  Two divisions by run-time numbers -- forty scalar instructions and two
+    // reciprocals that would live in scalar registers through the whole loop -- only where a run starts; inside a run the next tile
+    // is one step further down (or at the top of the next column / frame).  The divisors are made opaque INSIDE the function, so
+    // that the compiler does not hoist their reciprocals out of the loop.
+    struct Pos { int f, tcol, trow; };
+    auto pos_of = [&](int tt) {
+        int tpf = tiles_per_frame, tys = a.tiles_y;
+        asm volatile("" : "+s"(tpf), "+s"(tys));
+        Pos p;
+        p.f = tt / tpf;
+        const int r = tt - p.f * tpf;
+        p.tcol = r / tys;
+        p.trow = r - p.tcol * tys;
+        return p;
+    };
+    auto pos_below = [&](Pos p) {
+        if (++p.trow == a.tiles_y) {
+            p.trow = 0;
+            if (++p.tcol == a.tiles_x) { p.tcol = 0; p.f++; }
+        }
+        return p;
     };
     // The prefetch is unconditional on purpose: threads without an item and the last
     // iteration re-load a valid item / tile.  A conditional load would need the old
     // register value on the other path, and the copies the compiler inserts for that
     // merge wait for the load right where it is issued.
-    auto issue_tile = [&](int tt) {
-        int f, tr, tx0, ty0, trow;
-        tile_coords(tt, f, tr, tx0, ty0, trow);
-        const mlv_i32x4 rs = frame_rsrc(a.src + (size_t)f * a.src_stride, (unsigned)a.src_bytes);
-        issue_item<PACKED>(r0, r1, rs, IL, a.w, a.h, tx0, ty0, NEW0 + l_row);
+    auto issue_tile = [&](const Pos &p) {
+        const mlv_i32x4 rs = frame_rsrc(a.src + (size_t)p.f * a.src_stride, (unsigned)a.src_bytes);
+        issue_item<PACKED>(r0, r1, rs, IL, a.w, a.h, p.tcol * 2 * TCW, p.trow * 2 * TCH, NEW0 + l_row);
     };
-    if (vec) issue_tile(min(t, max(total - 1, 0)));
+    Pos cur = pos_of(min(t, max(total - 1, 0)));
+    if (vec) issue_tile(cur);
     __syncthreads();                           // T16 copy complete
 
 #ifdef KF_DIAG_TIMES
@@ -1087,8 +1099,8 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             if (t + 1 < t_end) { nt = t + 1; ne = t_end; }
             else draw(nt, ne);
         }
-        int f, tr, tx0, ty0, trow;
-        tile_coords(t, f, tr, tx0, ty0, trow);
+        const int f = cur.f, trow = cur.trow, tx0 = cur.tcol * 2 * TCW, ty0 = cur.trow * 2 * TCH;
+        const int tr = cur.trow * a.tiles_x + cur.tcol;          // the tile's number in the (row-major) pixel-map lists
         const uint8_t *frame = a.src + (size_t)f * a.src_stride;
         uint16_t *out = (uint16_t *)(a.dst + (size_t)f * a.dst_stride);
         // ---- pixel-map entries of this tile (few tiles have any): list bounds now -- the wait that the uniform load implies is
@@ -1178,7 +1190,9 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         if (METHOD != 0) __builtin_amdgcn_s_setprio(0);
 #endif
         // ---- prefetch the next tile while the medians run
-        if (vec) issue_tile(min(t_next, band_end - 1));
+        Pos nxt = pos_below(cur);
+        if (t_next != t + 1) nxt = pos_of(min(t_next, band_end - 1));         // (scalar branch: the first tile of another run)
+        if (vec) issue_tile(nxt);
 
         // ---- medians + output: one thread = 4 cells = 8 px on two rows
         int stripe_mode = a.stripes ? ((PACKED && a.coef_pk) ? 1 : (a.coef_fast ? 2 : 3)) : 0;      // scalar, re-read per tile (see above)
@@ -1375,6 +1389,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         t = t_next;
         t_end = t_end_next;
         cont = cont_next;
+        cur = nxt;
         if (SPREAD) par ^= 1;
     }
     if (threadIdx.x == 0 && atomicAdd(&a.tickets[2 * a.groups], 1) == (int)gridDim.x - 1) {

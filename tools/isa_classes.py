@@ -13,9 +13,9 @@ How (no GPU needed):
     (".loc ... ; k_frame.hip:L @[ k_frame.hip:L' @[ ... ] ]");
  3. gives every instruction a weight = wave-executions per tile on the benchmark's frames (common path), from WHERE in the source
     it sits -- found by searching the source for the statements that delimit each region, so the table below survives edits:
-        loader, full items        3   (waves 0..2 hold full items: 152 of them in the 5x5 geometry)
-        loader, edge items        1   (wave 2 only)
-        cell_pair_ev, slow path   0   (pixels at / below black: not on these frames)   ... and so on, see REGIONS
+        loader, items of 4 cells          4   (all four waves: 255 items per tile since round 4)
+        the rows above a run's first tile 0.2 (waves 0-1, one tile in nine)
+        cell_pair_ev, slow path           0   (pixels at / below black: not on these frames)   ... and so on, see weight_of
  4. classes every instruction by mnemonic and prices the class with the measured rates (profiles/r01/valu_rate2.log,
     profiles/r03/valu_rate3.log; unknown mnemonics at the quarter rate);
  5. checks the weighted total against SQ_INSTS_VALU of the same build (profiles/r03/*pmc*: per frame / tiles per frame) when given.
@@ -103,31 +103,36 @@ def build_regions():
     R = {}
     R["kernel"] = func("__global__ __launch_bounds__(256, 4) void k_frame(")
     k0 = R["kernel"][0]
-    R["loop"] = (find("while (t < band_end) {", k0), None)
-    R["loop"] = (R["loop"][0], block_end(R["loop"][0]))
-    R["loader"] = (find("if (has_item) {", k0), None)
-    R["loader"] = (R["loader"][0], block_end(R["loader"][0]))
-    R["chain32"] = (find("if (chain32) {", k0), None)
-    R["chain32"] = (R["chain32"][0], block_end(R["chain32"][0]))
-    R["packed"] = (find("if (!skip_packed) {", k0), None)
-    R["packed"] = (R["packed"][0], block_end(R["packed"][0]))
-    R["halo_wave"] = (find("if (halo_wave) {", k0), None)
-    R["halo_wave"] = (R["halo_wave"][0], block_end(R["halo_wave"][0]))
-    R["own_window"] = (find("if (!halo_wave) chain_group_window(g);", k0),) * 2
-    R["queue_push"] = (find("if (unknown) sm.fb_queue[", k0),) * 2
-    R["fallback"] = (find("if (nfb > 0) {", k0), None)
-    R["fallback"] = (R["fallback"][0], block_end(R["fallback"][0]))
-    R["patch_fetch"] = (find("if (tile_patched) {", k0), None)
-    R["patch_fetch"] = (R["patch_fetch"][0], block_end(R["patch_fetch"][0]))
-    R["patch_cell"] = (find("if (tile_patched && patch_wave) my_cell = patch_cell", k0),) * 2
-    R["patch_store"] = (find("if (tile_patched) {", R["patch_fetch"][1]), None)
-    R["patch_store"] = (R["patch_store"][0], block_end(R["patch_store"][0]))
+
+    def block(marker, after=k0):
+        a = find(marker, after)
+        return a, block_end(a)
+
+    def line(marker, after=k0):
+        a = find(marker, after)
+        return a, a
+
+    R["loop"] = block("while (t < band_end) {")
+    R["top_rows"] = block("if (METHOD != 0 && !cont) {")                  # the four plane rows above a run's first tile
+    R["loader"] = line("if (has_item) do_item(IL, r0, r1, NEW0 + l_row, l_k);")
+    R["chain32"] = block("if (skip_packed) {")
+    R["packed"] = (find("ChainGroup g;", k0), find("unknown = chain_finish(g, n, mr, mb);", k0))
+    R["early"] = block("if (early) {")
+    R["own_window"] = line("if (!early) chain_group_window(g);")
+    R["collect"] = (find("if (collects) chain_collect_lists", k0), find("if (collects) chain_collect_window", k0))
+    R["queue_push"] = line("if (unknown) sm.fb_queue[")
+    R["fallback"] = block("if (nfb > 0) {")
+    R["patch_fetch"] = block("if (tile_patched) {")
+    R["patch_store"] = block("if (tile_patched) {", R["patch_fetch"][1])
+    R["carry_read"] = line("if (do_carry) carry = ")
+    R["carry_write"] = line("if (do_carry) *(int4 *)((char *)&sm + c_dst) = carry;")
+    R["draw"] = line("else draw(nt, ne);")
     R["novec_store"] = (find("} else {", find("if (store && y < a.h) {", k0)), None)
     R["novec_store"] = (R["novec_store"][0], block_end(R["novec_store"][0]))
     R["stripe_slow"] = (find("else if (stripe_mode == 2)", k0), find("else stripe_strip<false>", k0))
     for name, sig in {"cell_pair_ev": "__device__ __forceinline__ void cell_pair_ev(", "cell_multi_ev_fast": "__device__ __forceinline__ void cell_multi_ev_fast(",
                       "fetch_rows": "__device__ __forceinline__ void fetch_rows(", "fetch_clamped": "__device__ __forceinline__ uint32_t fetch_clamped(",
-                      "emit_item": "__device__ __forceinline__ void emit_item(", "store_cells": "__device__ __forceinline__ void store_cells(",
+                      "emit_item": "__device__ __forceinline__ void emit_item(",
                       "strip_median25": "__device__ __forceinline__ void strip_median25(", "robust_ref": "__device__ __forceinline__ int robust_ref(",
                       "chain_publish": "__device__ __forceinline__ void chain_publish(", "patch_cell_fn": "__device__ __forceinline__ PatchCell patch_cell(",
                       "patch_store_fn": "__device__ __forceinline__ void patch_store(", "stripe_px": "__device__ __forceinline__ uint32_t stripe_px(",
@@ -137,15 +142,16 @@ def build_regions():
     R["sort5_32"] = func("__device__ __forceinline__ void sort5(int (&v)[5])")
     cp = R["cell_pair_ev"][0]
     R["cell_pair_slow"] = (find("int l[8];", cp) - 1, R["cell_pair_ev"][1])        # the block after `if (!slow) { ... return; }`
-    em = R["emit_item"][0]
-    R["emit_edge"] = (find("} else if (METHOD != 0) {", em), R["emit_item"][1])
-    sc = R["store_cells"][0]
-    R["store_pairs"] = (find("for (int c = 0; c < NCELL; c += 2) {", sc), R["store_cells"][1])
     return R
 
 
 def inside(line, rng):
     return rng[0] <= line <= rng[1]
+
+
+# tiles of the benchmark's launch that do NOT continue the tile above them (first tiles of runs, tiles drawn singly): runs of 22 tiles
+# and 33 single tiles per 481-tile range (k_frame.hip, launch_frame_t) -> 21 + 33 of 481
+FIRST_TILE_SHARE = (481 - 33) / 22 / 481 + 33 / 481
 
 
 def weight_of(chain, R, tiles_per_workgroup):
@@ -168,7 +174,7 @@ def weight_of(chain, R, tiles_per_workgroup):
     if any_in("cell_pair_slow"):
         return 0.0, "loader: out-of-table pixels (slow path)"
     if any_in("fetch_rows") or any_in("fetch_clamped") or any_in("novec_store"):
-        return 0.0, "widths that are no multiple of 16"
+        return 0.0, "widths that are no multiple of 8"
     if inside(outer, R["chain32"]):
         return 0.0, "32-bit chain (tiles that skip the packed attempt)"
     if inside(outer, R["fallback"]) or inside(outer, R["queue_push"]) or any_in("strip_median25"):
@@ -177,19 +183,25 @@ def weight_of(chain, R, tiles_per_workgroup):
         return 0.0, "shared references (noisy shadows)"
     if any_in("stripe_px") or any_in("stripe_strip") or inside(outer, R["stripe_slow"]):
         return 0.0, "stripes, 32-bit / generic epilogue"
-    if inside(outer, R["patch_fetch"]) or inside(outer, R["patch_cell"]) or inside(outer, R["patch_store"]) or any_in("patch_cell_fn") or any_in("patch_store_fn"):
-        return 0.1, "pixel-map cells (one tile in ten has any)"
+    if inside(outer, R["patch_fetch"]) or inside(outer, R["patch_store"]) or any_in("patch_cell_fn") or any_in("patch_store_fn"):
+        return 0.4, "pixel-map cells (one tile in ten has any; all four waves)"
+    if inside(outer, R["top_rows"]):
+        return 2.0 * FIRST_TILE_SHARE, "loader: the four rows above a run's first tile (waves 0-1, one tile in nine)"
     if inside(outer, R["loader"]):
-        if any_in("emit_edge") or (any_in("cell_pair_ev") and not any_in("cell_multi_ev_fast")) or any_in("store_pairs"):
-            return 1.0, "loader: edge items (wave 2)"
-        return 3.0, "loader: full items (waves 0-2)"
+        return 4.0, "loader: items of 4 cells (all waves)"
+    if inside(outer, R["draw"]):
+        return 0.25 * FIRST_TILE_SHARE, "drawing the next run (one wave, one tile in nine)"
+    if inside(outer, R["carry_read"]) or inside(outer, R["carry_write"]):
+        return 4.0 * (1 - FIRST_TILE_SHARE), "rows handed down to the tile below"
     if inside(outer, R["packed"]):
-        if inside(outer, R["halo_wave"]) or any_in("chain_publish"):
-            return 1.0, "medians: halo groups' window + publish (wave 3)"
+        if any_in("chain_publish") or inside(outer, R["collect"]):
+            return 3.0, "medians: hand-over between waves (lane 0 of waves 1-3 publishes, lane 63 of waves 0-2 collects)"
+        if inside(outer, R["early"]):
+            return 3.0, "medians: own rank window, waves 1-3"
         if inside(outer, R["own_window"]):
-            return 3.0, "medians: own rank window (waves 0-2)"
+            return 1.0, "medians: own rank window, wave 0"
         return 4.0, "medians: packed neighbour-sharing chain"
-    return 4.0, "output stage, loop control (all waves)"
+    return 4.0, "output stage, prefetch, loop control (all waves)"
 
 
 # ---------------------------------------------------------------- instruction classes
