@@ -1087,6 +1087,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 
 #ifdef KF_DIAG_TIMES
     const uint64_t rt0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long diag_n[4] = { 0, 0, 0, 0 };
 #endif
     int par = 0;                               // tile parity: which of the two dark_items counters this tile uses
     int fb_skip = 0, fb_wait = FB_WAIT_MIN;    // 5x5: tiles still to go straight to the 32-bit chain; how many after the next busy tile
@@ -1363,12 +1364,9 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 robust = nfb > FB_ROBUST || (robust && calm < 4);
             }
 #ifdef KF_DIAG_TIMES
-            if (tid == 0 && a.times) {                         // tiles, tiles that skipped the packed networks, strips settled densely
-                atomicAdd(&a.times[4096], 1ull);
-                if (skip_packed) atomicAdd(&a.times[4097], 1ull);
-                atomicAdd(&a.times[4098], (unsigned long long)nfb);
-                if (cont) atomicAdd(&a.times[4099], 1ull);
-            }
+            // tiles, tiles that skipped the packed networks, strips settled densely, tiles that continued the one above (summed per
+            // workgroup, added once at its end: an atomic per tile on one address serialised the whole launch)
+            diag_n[0]++; diag_n[1] += skip_packed ? 1 : 0; diag_n[2] += nfb; diag_n[3] += cont ? 1 : 0;
 #endif
             if (nfb > 0) {
                 if ((tid & ~63) < nfb) {                               // this wave has entries
@@ -1396,7 +1394,10 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         for (int i = 0; i <= 2 * a.groups; i++) a.tickets[i] = 0;   // last workgroup out: ready for the next launch on this stream
     }
 #ifdef KF_DIAG_TIMES
-    if (threadIdx.x == 0 && a.times) { a.times[2 * blockIdx.x] = rt0; a.times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); }
+    if (threadIdx.x == 0 && a.times) {
+        a.times[2 * blockIdx.x] = rt0; a.times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 4; i++) atomicAdd(&a.times[4096 + i], diag_n[i]);
+    }
 #endif
 }
 
@@ -1524,15 +1525,24 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
     FrameArgs a = a_in;
     a.tickets = ticket_counters(stream);
     if (!a.tickets) return MLVFS_AMD_ERR_HIP;
-    a.groups = std::min(std::max(grid / 4, 1), MAX_GROUPS);
+    // Groups: workgroups that draw from one range of the tile list.  Until round 4 a group was one CU's four residents; the CUs
+    // of a chip do not run at one speed (their workgroups ended between 780 and 835 us of an 844-us launch: 5.5 % of the launch
+    // was its tail, -DKF_DIAG_TIMES), and drawing runs instead of single tiles made the atomics rare enough for larger groups:
+    // eight CUs (a quarter of an XCD: blocks b, b + groups, ... share b % 8, i.e. their XCD, as long as groups is a multiple of 8)
+    // share a range, 123.0 -> 128.4 k fps; 16 / 24 / 32 / 64 groups and runs of 11 / 22 / 44 tiles are within 0.5 % of each other,
+    // one group per XCD (8) loses the gain to its 1 408 single tiles (profiles/r04/ab_groups.log).  MLVFS_AMD_KF_GROUPS overrides.
+    const int per_cu = std::min(std::max(grid / 4, 1), MAX_GROUPS);
+    a.groups = per_cu >= 64 ? per_cu / 8 / 8 * 8 : per_cu;
+    static const int env_groups = [] { const char *e = getenv("MLVFS_AMD_KF_GROUPS"); return e ? atoi(e) : 0; }();
+    if (env_groups > 0 && env_groups <= per_cu) a.groups = env_groups;
     // tiles per run and tiles that go out one by one at the end of a group's range (tools/kbench.py sweeps them: KB_RUN / KB_SINGLES)
     static const int env_run = [] { const char *e = getenv("MLVFS_AMD_KF_RUN"); return e ? atoi(e) : 0; }();
     static const int env_singles = [] { const char *e = getenv("MLVFS_AMD_KF_SINGLES"); return e ? atoi(e) : -1; }();
-    // default: about sixteen draws per group's range, at most half a column of the benchmark's geometry per run (same-box sweep:
-    // 4 / 8 / 11 / 22 / 44 tiles per run -> 117.2 / 117.5 / 117.7 / 118.0-121.0 / 120.5 k fps), one and a half runs' worth of single tiles
+    // default: at most half a column of the benchmark's geometry per run (same-box sweep with one CU per group: 4 / 8 / 11 / 22 / 44
+    // tiles per run -> 117.2 / 117.5 / 117.7 / 118.0-121.0 / 120.5 k fps), a sixteenth of the range for short launches
     const int band = (int)(total / a.groups);
     a.run = env_run > 0 ? env_run : std::min(std::max(band / 16, 1), KF_RUN_MAX);
-    a.singles = env_singles >= 0 ? env_singles : (a.run > 1 ? a.run * 3 / 2 : 0);
+    a.singles = env_singles >= 0 ? env_singles : (a.run > 1 ? 8 * std::max(grid / a.groups, 1) : 0);      // eight per workgroup of the group
 #ifdef KF_DIAG_TIMES
     static unsigned long long *d_times = nullptr;
     if (!d_times) hipMalloc(&d_times, (2048 * 2 + 8) * sizeof(unsigned long long));
@@ -1556,10 +1566,10 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
             for (int b = 0; b < grid; b++) { t0 = std::min(t0, h[2 * b]); t1 = std::max(t1, h[2 * b + 1]); }
             double end_q[4] = { 0, 0, 0, 0 }, start_q[4] = { 0, 0, 0, 0 };
             for (int b = 0; b < grid; b++) { end_q[b * 4 / grid] += (double)(h[2 * b + 1] - t0); start_q[b * 4 / grid] += (double)(h[2 * b] - t0); }
-            unsigned long long fbc[3];
+            unsigned long long fbc[4];
             hipMemcpy(fbc, d_times + 4096, sizeof(fbc), hipMemcpyDeviceToHost);
-            fprintf(stderr, "KF_TIMES tiles %llu, of which %llu skipped the packed networks; strips settled densely %llu (%.1f %% of all)\n", fbc[0], fbc[1],
-                    fbc[2], fbc[0] ? 100.0 * fbc[2] / (240.0 * fbc[0]) : 0.0);
+            fprintf(stderr, "KF_TIMES tiles %llu, of which %llu skipped the packed networks and %llu continued the tile above; strips settled densely %llu (%.1f %% of all)\n", fbc[0], fbc[1],
+                    fbc[3], fbc[2], fbc[0] ? 100.0 * fbc[2] / (240.0 * fbc[0]) : 0.0);
             fprintf(stderr, "KF_TIMES grid %d: kernel %.1f us; mean start / end of the workgroups of each quarter of the grid (us):", grid, (t1 - t0) * 0.01);
             for (int q = 0; q < 4; q++) fprintf(stderr, "  %.1f / %.1f", start_q[q] / (grid / 4) * 0.01, end_q[q] / (grid / 4) * 0.01);
             fprintf(stderr, "\n");

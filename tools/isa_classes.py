@@ -127,6 +127,7 @@ def build_regions():
     R["carry_read"] = line("if (do_carry) carry = ")
     R["carry_write"] = line("if (do_carry) *(int4 *)((char *)&sm + c_dst) = carry;")
     R["draw"] = line("else draw(nt, ne);")
+    R["pos_of"] = line("if (t_next != t + 1) nxt = pos_of(")
     R["novec_store"] = (find("} else {", find("if (store && y < a.h) {", k0)), None)
     R["novec_store"] = (R["novec_store"][0], block_end(R["novec_store"][0]))
     R["stripe_slow"] = (find("else if (stripe_mode == 2)", k0), find("else stripe_strip<false>", k0))
@@ -189,6 +190,8 @@ def weight_of(chain, R, tiles_per_workgroup):
         return 2.0 * FIRST_TILE_SHARE, "loader: the four rows above a run's first tile (waves 0-1, one tile in nine)"
     if inside(outer, R["loader"]):
         return 4.0, "loader: items of 4 cells (all waves)"
+    if inside(outer, R["pos_of"]):
+        return 4.0 * FIRST_TILE_SHARE, "coordinates of a run's first tile (two divisions, one tile in nine)"
     if inside(outer, R["draw"]):
         return 0.25 * FIRST_TILE_SHARE, "drawing the next run (one wave, one tile in nine)"
     if inside(outer, R["carry_read"]) or inside(outer, R["carry_write"]):
