@@ -1191,8 +1191,10 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         if (METHOD != 0) __builtin_amdgcn_s_setprio(0);
 #endif
         // ---- prefetch the next tile while the medians run
+        // (scalar branch: the first tile of another run -- or nothing left: the prefetch is unconditional, so it gets a valid tile;
+        // the tile "below" the list's last one would lie in a frame behind the buffer)
         Pos nxt = pos_below(cur);
-        if (t_next != t + 1) nxt = pos_of(min(t_next, band_end - 1));         // (scalar branch: the first tile of another run)
+        if (t_next != t + 1 || t_next >= band_end) nxt = pos_of(min(t_next, band_end - 1));
         if (vec) issue_tile(nxt);
 
         // ---- medians + output: one thread = 4 cells = 8 px on two rows
