@@ -127,7 +127,7 @@ def build_regions():
     R["carry_read"] = line("if (do_carry) carry = ")
     R["carry_write"] = line("if (do_carry) *(int4 *)((char *)&sm + c_dst) = carry;")
     R["draw"] = line("else draw(nt, ne);")
-    R["pos_of"] = line("if (t_next != t + 1) nxt = pos_of(")
+    R["pos_of"] = line("if (t_next != t + 1 || t_next >= band_end) nxt = pos_of(")
     R["novec_store"] = (find("} else {", find("if (store && y < a.h) {", k0)), None)
     R["novec_store"] = (R["novec_store"][0], block_end(R["novec_store"][0]))
     R["stripe_slow"] = (find("else if (stripe_mode == 2)", k0), find("else stripe_strip<false>", k0))
