@@ -138,16 +138,19 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
                  size_t dst_stride, int nframes, int method, const PatchView *pv, bool stripes,
                  const int32_t *coef, hipStream_t stream, bool spread = false);       // spread: T16 layout for dark clips (k_frame.hip)
 // share of sampled pixels of one frame that lie 1 .. 511 above black, in 1/1024 (synchronises the stream)
-int dark_share(bool packed, const void *d_frame, int w, int h, int black, hipStream_t stream, int *share_1024);
-int launch_pixfix(bool packed, const void *frames, size_t stride, int w, int black, const void *entries,
+int dark_share(int packed_bpp, const void *d_frame, int w, int h, int black, hipStream_t stream, int *share_1024);      // packed_bpp 0: 16-bit frames
+// does the fused kernel read this packed stream itself (k_frame.hip), or does it take an unpack pass first?
+bool frame_kernel_takes(const Geom &g, const void *src, size_t src_stride, const void *dst, size_t dst_stride, int nframes);
+// packed: 0 = 16-bit frames, 1 (`true`) = 14-bit stream, else the stream's bits per pixel (12, 10)
+int launch_pixfix(int packed, const void *frames, size_t stride, int w, int black, const void *entries,
                   const int *level_off, int n_levels, int n_level0, int n_entries, void *patches, void *scatter,
                   size_t scatter_stride, int nframes, const DeviceLuts &luts, hipStream_t stream);
 // both of the above for the fused kernel (one launch when the map is small)
-int launch_pixfix_for_frame_kernel(bool packed, const void *frames, size_t stride, int w, int h, int black, const void *entries,
+int launch_pixfix_for_frame_kernel(int packed, const void *frames, size_t stride, int w, int h, int black, const void *entries,
                                    const int *level_off, int n_levels, int n_level0, int n_entries, void *patches,
                                    const CellRec *recs, int n_rec, void *cells, int nframes, const DeviceLuts &luts, hipStream_t stream);
 // the four pixels of every listed cell after the repair (for the fused kernel): after launch_pixfix, on the same stream
-int launch_pixfix_cells(bool packed, const void *frames, size_t stride, int w, int h, const CellRec *recs, int n_rec,
+int launch_pixfix_cells(int packed, const void *frames, size_t stride, int w, int h, const CellRec *recs, int n_rec,
                         const void *patches, int n_entries, void *cells, int nframes, hipStream_t stream);
 int launch_deflicker_hist(const void *d_frame, uint32_t samples, uint32_t white, unsigned *d_hist, hipStream_t s);
 int launch_hist_add(const void *d_frame, uint32_t first, uint32_t step, uint32_t samples, uint32_t white, unsigned *d_hist, hipStream_t s);

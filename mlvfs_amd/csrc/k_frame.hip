@@ -342,6 +342,12 @@ __device__ __forceinline__ mlv_i32x4 frame_rsrc(const void *p, unsigned bytes)
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// The kernel's third template argument, VEC, names the input's layout: 0 = any geometry (a load per pixel), 1 = rows of whole
+// 8-pixel groups whose rows all start dword-aligned, 2 = the same with rows that start alternately dword-aligned and in the upper
+// half of a dword (14-bit stream, w % 16 == 8) -- and, for the reduced bit depths of newer Magic Lantern builds, 3 = 12-bit and
+// 4 = 10-bit stream, rows dword-aligned (round 4: such clips took an unpack pass to 16 bits first).  bits per pixel of a layout:
+constexpr int bpp_of(bool packed, int vec) { return !packed ? 16 : (vec == 3 ? 12 : (vec == 4 ? 10 : 14)); }
+
 constexpr uint32_t SEL_SWAP = 0x01000302u;      // v_perm_b32(nxt, d, .): the halves of d swapped
 constexpr uint32_t SEL_MIS = 0x03020504u;       //                        (d & 0xFFFF0000) | (nxt & 0xFFFF)
 constexpr uint32_t SEL_EDGE1 = 0x01000304u;     //                        halves of d swapped, lowest byte from nxt
@@ -359,18 +365,24 @@ struct ItemLane {
 template <bool PACKED, int VEC>
 __device__ __forceinline__ ItemLane item_lane(int lk, bool edge)
 {
+    constexpr int BPP = bpp_of(PACKED, VEC);
     ItemLane L;
     L.edge = edge;
     L.xoff_a = edge ? 2 * TCW : 8 * lk;
     L.xoff_b = edge ? -8 : 8 * lk;
     L.amask = (PACKED && !edge) ? ~3u : ~0u;
-    L.boff = edge ? (PACKED ? 6u : 8u) : 8u;
-    // rows of a tile start at a multiple of 128 pixels = 224 bytes: on an even row group lk is aligned when lk is even
-    // (w % 16 == 8: odd rows start two bytes into a dword, so there it is the other way round)
-    const bool mis = (lk & 1) != 0;
+    // edge item, second load: the last four 16-bit words of the group left of the tile (14 bit: words 3..6; 12: 2..5; 10: 2..5, the
+    // group has five)
+    L.boff = edge ? (BPP == 14 ? 6u : (BPP == 16 ? 8u : 4u)) : 8u;
+    // rows of a tile start at a multiple of 128 pixels = 224 / 192 / 160 bytes: on an even row group lk of a 14- or 10-bit stream is
+    // aligned when lk is even (w % 16 == 8: odd rows start two bytes into a dword, so there it is the other way round); 12-bit groups
+    // (12 bytes) always are
+    const bool mis = BPP != 12 && (lk & 1) != 0;
     L.s0 = edge ? SEL_SWAP : (mis ? SEL_MIS : SEL_SWAP);
-    L.s1 = edge ? SEL_EDGE1 : L.s0;
-    L.s23 = edge ? SEL_MIS : L.s0;
+    // edge item: S1 joins the right group's third word with the left group's (14 bit: the halo's boundary lies inside word 3, 10 bit:
+    // inside word 2, 12 bit: between words 2 and 3); S2 (S3) are words of the left group
+    L.s1 = edge ? (BPP == 14 ? SEL_EDGE1 : (BPP == 12 ? 0x01000706u : 0x01040706u)) : L.s0;
+    L.s23 = edge ? (BPP == 14 ? SEL_MIS : (BPP == 12 ? 0x05040706u : 0x05040504u)) : L.s0;
     L.flip = (VEC == 2 && !edge) ? (SEL_SWAP ^ SEL_MIS) : 0u;
     return L;
 }
@@ -378,11 +390,11 @@ __device__ __forceinline__ ItemLane item_lane(int lk, bool edge)
 // plane row p of the tile at (tx0, ty0): the item's two pixel rows into d0 / d1.  Rows are whole 8-pixel groups (w % 8 == 0), so the
 // byte offset of the group at (x, y) is y * pitch + (x / 8) * gb, pitch = bytes per row, gb = bytes per group (14 / 16): 24-bit
 // multiplies (v_mul_lo_u32 costs four issue slots), and a main item's second load follows from its first (amask / boff, item_lane)
-template <bool PACKED, bool TOP = false>
+template <int BPP, bool TOP = false>
 __device__ __forceinline__ void issue_item(uint32_t (&d0)[4], uint32_t (&d1)[4], mlv_i32x4 rs, const ItemLane &L, int w, int h, int tx0,
                                            int ty0, int p)
 {
-    constexpr uint32_t GB = PACKED ? 14u : 16u;
+    constexpr uint32_t GB = (uint32_t)BPP;              // bytes per 8-pixel group
     const int y = ty0 - 2 * HC + 2 * p;
     const uint32_t pitch = (uint32_t)(w >> 3) * GB;                                    // scalar
     const int gmax = (w >> 3) - 1, g0 = tx0 >> 3;
@@ -399,26 +411,27 @@ __device__ __forceinline__ void issue_item(uint32_t (&d0)[4], uint32_t (&d1)[4],
     }
 }
 
-// pixel K (0..7) of an item from its four MSB-first stream words
-template <int K>
-__device__ __forceinline__ uint32_t px14(const uint32_t (&s)[4])
+// pixel K (0..7) of an item from its MSB-first stream words (B bits per pixel)
+template <int K, int B>
+__device__ __forceinline__ uint32_t pxk(const uint32_t (&s)[4])
 {
-    constexpr int bit = 14 * K, wi = bit >> 5, sh = bit & 31;
-    if constexpr (sh + 14 <= 32) return (s[wi] >> (32 - 14 - sh)) & 0x3FFFu;
-    else return (uint32_t)((((uint64_t)s[wi] << 32) | s[wi + 1]) >> (64 - 14 - sh)) & 0x3FFFu;
+    constexpr int bit = B * K, wi = bit >> 5, sh = bit & 31;
+    constexpr uint32_t mask = (1u << B) - 1u;
+    if constexpr (sh + B <= 32) return (s[wi] >> (32 - B - sh)) & mask;
+    else return (uint32_t)((((uint64_t)s[wi] << 32) | s[wi + 1]) >> (64 - B - sh)) & mask;
 }
 
-template <bool PACKED>
+template <int BPP>
 __device__ __forceinline__ void unpack8(const uint32_t (&d)[4], uint32_t s0, uint32_t s1, uint32_t s23, uint32_t (&px)[8])
 {
-    if constexpr (PACKED) {
+    if constexpr (BPP != 16) {
         uint32_t s[4];
         s[0] = __builtin_amdgcn_perm(d[1], d[0], s0);
         s[1] = __builtin_amdgcn_perm(d[2], d[1], s1);
         s[2] = __builtin_amdgcn_perm(d[3], d[2], s23);
-        s[3] = __builtin_amdgcn_perm(d[3], d[3], s23);
-        px[0] = px14<0>(s); px[1] = px14<1>(s); px[2] = px14<2>(s); px[3] = px14<3>(s);
-        px[4] = px14<4>(s); px[5] = px14<5>(s); px[6] = px14<6>(s); px[7] = px14<7>(s);
+        s[3] = BPP == 14 ? __builtin_amdgcn_perm(d[3], d[3], s23) : 0u;       // (96 / 80 bits of a 12- / 10-bit group end inside S2)
+        px[0] = pxk<0, BPP>(s); px[1] = pxk<1, BPP>(s); px[2] = pxk<2, BPP>(s); px[3] = pxk<3, BPP>(s);
+        px[4] = pxk<4, BPP>(s); px[5] = pxk<5, BPP>(s); px[6] = pxk<6, BPP>(s); px[7] = pxk<7, BPP>(s);
     } else {
 #pragma unroll
         for (int k = 0; k < 4; k++) { px[2 * k] = d[k] & 0xFFFFu; px[2 * k + 1] = d[k] >> 16; }
@@ -426,23 +439,23 @@ __device__ __forceinline__ void unpack8(const uint32_t (&d)[4], uint32_t s0, uin
 }
 
 // any geometry: one pixel with clamped coordinates
-template <bool PACKED>
+template <int BPP>
 __device__ __forceinline__ uint32_t fetch_clamped(const uint8_t *frame, int w, int h, int x, int y)
 {
     x = clampi(x, 0, w - 1);
     y = clampi(y, 0, h - 1);
     const uint32_t i = (uint32_t)y * (uint32_t)w + (uint32_t)x;
-    if (PACKED) {
+    if (BPP != 16) {
         const uint16_t *s = (const uint16_t *)frame;
-        const uint32_t bit = i * 14u;                    // < 2^28 pixels per frame (launcher): fits
+        const uint32_t bit = i * (uint32_t)BPP;          // < 2^28 pixels per frame (launcher): fits
         const uint32_t two = ((uint32_t)s[bit >> 4] << 16) | s[(bit >> 4) + 1];
-        return (two >> (32 - 14 - (bit & 15))) & 0x3FFFu;
+        return (two >> (32 - BPP - (bit & 15))) & ((1u << BPP) - 1u);
     }
     return ((const uint16_t *)frame)[i];
 }
 
 // slow path (w % 8 != 0, unaligned buffers): fill the two pixel rows of an item pixel by pixel
-template <bool PACKED>
+template <int BPP>
 __device__ __forceinline__ void fetch_rows(const uint8_t *frame, int w, int h, int tx0, int lk, int y, bool edge, uint32_t (&p0)[8],
                                            uint32_t (&p1)[8])
 {
@@ -450,8 +463,8 @@ __device__ __forceinline__ void fetch_rows(const uint8_t *frame, int w, int h, i
     for (int k = 0; k < 8; k++) {
         // edge items: px 0..3 = right halo, px 4..7 = left halo (same layout as the fast path)
         const int xx = edge ? (k < 4 ? tx0 + 2 * TCW + k : tx0 - 8 + k) : tx0 + 8 * lk + k;
-        p0[k] = fetch_clamped<PACKED>(frame, w, h, xx, y);
-        p1[k] = fetch_clamped<PACKED>(frame, w, h, xx, y + 1);
+        p0[k] = fetch_clamped<BPP>(frame, w, h, xx, y);
+        p1[k] = fetch_clamped<BPP>(frame, w, h, xx, y + 1);
     }
 }
 
@@ -1005,6 +1018,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     const int runs_len = max(band_end - band_start - a.singles, 0) / run * run;  // tiles of the range that go out in runs
     const int black16 = (int)(uint16_t)a.black, white16 = (int)(uint16_t)a.white;
     constexpr bool vec = VEC != 0;                       // w % 8 == 0, aligned buffers: vector loads and stores
+    constexpr int BPP = bpp_of(PACKED, VEC);             // bits per pixel of the input
     constexpr int NEW0 = METHOD == 0 ? HC : 2 * HC;      // first plane row a tile loads itself (without chroma smoothing: no halo at all)
 
     const mlv_i32x4 rs_e2r = table_rsrc(a.e2r, 2, E2R_ENTRIES);
@@ -1079,7 +1093,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     // merge wait for the load right where it is issued.
     auto issue_tile = [&](const Pos &p) {
         const mlv_i32x4 rs = frame_rsrc(a.src + (size_t)p.f * a.src_stride, (unsigned)a.src_bytes);
-        issue_item<PACKED>(r0, r1, rs, IL, a.w, a.h, p.tcol * 2 * TCW, p.trow * 2 * TCH, NEW0 + l_row);
+        issue_item<BPP>(r0, r1, rs, IL, a.w, a.h, p.tcol * 2 * TCW, p.trow * 2 * TCH, NEW0 + l_row);
     };
     Pos cur = pos_of(min(t, max(total - 1, 0)));
     if (vec) issue_tile(cur);
@@ -1130,9 +1144,9 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         auto do_item = [&](const ItemLane &L, const uint32_t (&d0)[4], const uint32_t (&d1)[4], int p, int lk) {
             uint32_t p0[8], p1[8];
             if (vec) {
-                unpack8<PACKED>(d0, L.s0, L.s1, L.s23, p0);
-                unpack8<PACKED>(d1, L.s0 ^ L.flip, L.s1 ^ L.flip, L.s23 ^ L.flip, p1);
-            } else fetch_rows<PACKED>(frame, a.w, a.h, tx0, lk, ty0 - 2 * HC + 2 * p, L.edge, p0, p1);
+                unpack8<BPP>(d0, L.s0, L.s1, L.s23, p0);
+                unpack8<BPP>(d1, L.s0 ^ L.flip, L.s1 ^ L.flip, L.s23 ^ L.flip, p1);
+            } else fetch_rows<BPP>(frame, a.w, a.h, tx0, lk, ty0 - 2 * HC + 2 * p, L.edge, p0, p1);
             // Pixels at or below black (ev = INT_MIN / 0) or beyond the table need the fix-ups of cell_pair_ev: decided once
             // per item from the extremes of its 16 pixels (three-input min/max), wave-uniformly.
             bool odd = false;
@@ -1160,7 +1174,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 const int trw = te ? tid_o - N_TOP_MAIN : tid_o >> 4;
                 const ItemLane TL = item_lane<PACKED, VEC>(l_k, te);
                 uint32_t q0[4] = { 0, 0, 0, 0 }, q1[4] = { 0, 0, 0, 0 };
-                if (vec) issue_item<PACKED, true>(q0, q1, frame_rsrc(frame, (unsigned)a.src_bytes), TL, a.w, a.h, tx0, ty0, trw);
+                if (vec) issue_item<BPP, true>(q0, q1, frame_rsrc(frame, (unsigned)a.src_bytes), TL, a.w, a.h, tx0, ty0, trw);
                 do_item(TL, q0, q1, trw, l_k);
             }
         }
@@ -1588,6 +1602,17 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
     return MLVFS_AMD_OK;
 }
 
+// Which packed streams the fused kernel reads itself: 14 bits in any geometry; 12 bits (8 pixels = 12 bytes: every group
+// dword-aligned) with rows of whole groups; 10 bits (8 pixels = 10 bytes) with rows of whole 16-pixel groups (every row then
+// starts dword-aligned) -- the last two on 16-byte aligned buffers.  Everything else takes an unpack pass to 16 bits first.
+bool frame_kernel_takes(const Geom &g, const void *src, size_t src_stride, const void *dst, size_t dst_stride, int nframes)
+{
+    if (g.bpp == 14) return true;
+    if (g.bpp != 12 && g.bpp != 10) return false;
+    const bool aligned = ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 && (nframes == 1 || (src_stride % 16 == 0 && dst_stride % 16 == 0));
+    return aligned && g.w >= 16 && g.w % (g.bpp == 12 ? 8 : 16) == 0;
+}
+
 int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src, size_t src_stride, void *dst,
                  size_t dst_stride, int nframes, int method, const PatchView *pv, bool stripes,
                  const int32_t *coef, hipStream_t stream, bool spread)
@@ -1602,10 +1627,13 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
         set_error("frame geometry %dx%d unsupported", g.w, g.h);
         return MLVFS_AMD_ERR_ARG;
     }
-    if (packed && g.bpp != 14) { set_error("fused path needs 14-bit input"); return MLVFS_AMD_ERR_ARG; }
+    if (packed && !frame_kernel_takes(g, src, src_stride, dst, dst_stride, nframes)) {
+        set_error("fused path: %d-bit input at %dx%d needs an unpack pass first", g.bpp, g.w, g.h);
+        return MLVFS_AMD_ERR_ARG;
+    }
     FrameArgs a{};
     a.src = (const uint8_t *)src; a.src_stride = src_stride;
-    a.src_bytes = (unsigned)(((size_t)g.w * g.h * (packed ? 14 : 16) / 8 + 3) / 4 * 4);     // one frame as the loader's range-checked buffer
+    a.src_bytes = (unsigned)(((size_t)g.w * g.h * (packed ? g.bpp : 16) / 8 + 3) / 4 * 4);  // one frame as the loader's range-checked buffer
     a.dst = (uint8_t *)dst; a.dst_stride = dst_stride;
     a.w = g.w; a.h = g.h; a.black = g.black; a.white = g.white;
     a.nframes = nframes;
@@ -1630,11 +1658,15 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
     // half of a dword (2; an even height keeps the frame's last group off the end of the buffer)
     static const bool no_half8 = [] { const char *e = getenv("MLVFS_AMD_KF_HALF8"); return e && atoi(e) == 0; }();      // (A/B: the any-geometry path instead)
     const bool strides_ok = nframes == 1 || (src_stride % 16 == 0 && dst_stride % 16 == 0);
-    const int vec = ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 && strides_ok && g.w >= 16
+    int vec = ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 && strides_ok && g.w >= 16
                         ? ((g.w % 16) == 0 ? 1 : ((g.w % 16) == 8 && (g.h % 2) == 0 && !no_half8 ? 2 : 0)) : 0;
+    if (packed && g.bpp == 12) vec = 3;                  // (frame_kernel_takes has checked the geometry)
+    if (packed && g.bpp == 10) vec = 4;
 #define MLV_DISPATCH_S(M, S)                                                                              \
     return packed ? (vec == 1 ? launch_frame_t<M, true, 1, S>(a, dev->num_cu, stream)                     \
                    : vec == 2 ? launch_frame_t<M, true, 2, S>(a, dev->num_cu, stream)                     \
+                   : vec == 3 ? launch_frame_t<M, true, 3, S>(a, dev->num_cu, stream)                     \
+                   : vec == 4 ? launch_frame_t<M, true, 4, S>(a, dev->num_cu, stream)                     \
                               : launch_frame_t<M, true, 0, S>(a, dev->num_cu, stream))                    \
                   : (vec == 1 ? launch_frame_t<M, false, 1, S>(a, dev->num_cu, stream)                    \
                    : vec == 2 ? launch_frame_t<M, false, 2, S>(a, dev->num_cu, stream)                    \
@@ -1655,14 +1687,14 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
 
 // ---------------------------------------------------------------- which T16 layout suits a clip
 // every 7th pixel of every 5th row of one frame: how many lie 1 .. 511 above black (the range whose look-ups collide in the plain layout)
-template <bool PACKED>
+template <int BPP>
 __global__ __launch_bounds__(256) void k_dark_share(const uint8_t *frame, int w, int h, int black, int *counts)
 {
     const int nx = (w + 6) / 7, ny = (h + 4) / 5;
     int dark = 0, all = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nx * ny; i += gridDim.x * blockDim.x) {
         const int y = (i / nx) * 5, x = (i % nx) * 7;
-        const int lin = (int)fetch_clamped<PACKED>(frame, w, h, x, y) - black;
+        const int lin = (int)fetch_clamped<BPP>(frame, w, h, x, y) - black;
         dark += lin >= 1 && lin < 512;
         all++;
     }
@@ -1670,8 +1702,10 @@ __global__ __launch_bounds__(256) void k_dark_share(const uint8_t *frame, int w,
     if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[0], dark); atomicAdd(&counts[1], all); }
 }
 
-int dark_share(bool packed, const void *d_frame, int w, int h, int black, hipStream_t stream, int *share_1024)
+// packed_bpp: 0 = 16-bit frames, else the bits per pixel of the packed stream (14, 12, 10)
+int dark_share(int packed_bpp, const void *d_frame, int w, int h, int black, hipStream_t stream, int *share_1024)
 {
+    if (packed_bpp != 0 && packed_bpp != 14 && packed_bpp != 12 && packed_bpp != 10) { set_error("dark_share: %d-bit stream", packed_bpp); return MLVFS_AMD_ERR_ARG; }
     // the two counters live as long as the thread (an allocation and a release per clip were a fifth of this call's time)
     struct Counts {
         std::map<int, int *> m;
@@ -1684,8 +1718,8 @@ int dark_share(bool packed, const void *d_frame, int w, int h, int black, hipStr
     if (!d_counts) MLV_HIP(hipMalloc(&d_counts, 2 * sizeof(int)));
     hipError_t e = hipMemsetAsync(d_counts, 0, 2 * sizeof(int), stream);
     if (e == hipSuccess) {
-        if (packed) hipLaunchKernelGGL(k_dark_share<true>, dim3(64), dim3(256), 0, stream, (const uint8_t *)d_frame, w, h, black, d_counts);
-        else hipLaunchKernelGGL(k_dark_share<false>, dim3(64), dim3(256), 0, stream, (const uint8_t *)d_frame, w, h, black, d_counts);
+        auto kern = packed_bpp == 14 ? k_dark_share<14> : packed_bpp == 12 ? k_dark_share<12> : packed_bpp == 10 ? k_dark_share<10> : k_dark_share<16>;
+        hipLaunchKernelGGL(kern, dim3(64), dim3(256), 0, stream, (const uint8_t *)d_frame, w, h, black, d_counts);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(hc, d_counts, sizeof(hc), hipMemcpyDeviceToHost, stream);

@@ -30,19 +30,21 @@ __device__ __forceinline__ int tap_offset(int t, int w)
     return t < 6 ? d : d * w;
 }
 
+// bpp: bits per pixel of a packed stream (14; 12 / 10 for Magic Lantern's reduced bit depths) -- a run-time number here: these
+// kernels are bound by their gathers, and the fused kernel's launch plan (k_frame.hip) decides which streams come in packed at all
 template <bool PACKED>
-__device__ __forceinline__ int fetch_px(const uint8_t *frame, int pos)
+__device__ __forceinline__ int fetch_px(const uint8_t *frame, int pos, int bpp)
 {
     if (PACKED) {
         // the two 16-bit words that hold the pixel as ONE 32-bit load (2-byte aligned: global memory takes that), halves swapped
         // back into stream order: a lane-wide gather costs the texture addresser the same for 2 or 4 bytes, and a dense map
         // (a focus-pixel map: 150 000 entries x 12 taps) is bound by exactly those gathers
         const uint16_t *s = (const uint16_t *)frame;
-        const size_t bit = (size_t)pos * 14;
+        const size_t bit = (size_t)pos * (size_t)bpp;
         uint32_t v;
         __builtin_memcpy(&v, s + (bit >> 4), 4);
         const uint32_t two = (v << 16) | (v >> 16);
-        return (int)((two >> (32 - 14 - (bit & 15))) & 0x3FFFu);
+        return (int)((two >> (32 - bpp - (int)(bit & 15))) & ((1u << bpp) - 1u));
     }
     return ((const uint16_t *)frame)[pos];
 }
@@ -96,7 +98,7 @@ template <bool PACKED>
 __global__ __launch_bounds__(256) void k_pixfix_flat(const uint8_t *__restrict__ frames, size_t stride, int w, int black,
                                                      const PixEntry *__restrict__ entries, int n_level0, int n_entries, int nframes, int fpw,
                                                      int2 *__restrict__ patches, const uint16_t *__restrict__ t16,
-                                                     const uint16_t *__restrict__ u16)
+                                                     const uint16_t *__restrict__ u16, int bpp)
 {
     __shared__ uint16_t s_t16[MLV_T16_N];
     {
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void k_pixfix_flat(const uint8_t *__restrict__
             const int pos = ent[k].x, kind = ent[k].y & 0xFF, emit = ent[k].y >> 8;
             int val = 0;
             if (kind != 0) {
-                auto tap = [&](int t) { return fetch_px<PACKED>(frame, pos + tap_offset(t, w)); };
+                auto tap = [&](int t) { return fetch_px<PACKED>(frame, pos + tap_offset(t, w), bpp); };
                 val = repair_value(kind, black, (const uint16_t *)s_t16, u16, tap) & 0xFFFF;
             }
             patches[(size_t)f * n_entries + m] = make_int2((kind != 0 && emit) ? pos : -1, val);
@@ -137,7 +139,7 @@ template <bool PACKED>
 __global__ __launch_bounds__(256) void k_pixfix(const uint8_t *__restrict__ frames, size_t stride, int w, int black,
                                                 const PixEntry *__restrict__ entries, const int *__restrict__ level_off,
                                                 int n_levels, int n_entries, int2 *__restrict__ patches,
-                                                const uint16_t *__restrict__ t16, const uint16_t *__restrict__ u16)
+                                                const uint16_t *__restrict__ t16, const uint16_t *__restrict__ u16, int bpp)
 {
     const uint8_t *frame = frames + (size_t)blockIdx.x * stride;
     int2 *out = patches + (size_t)blockIdx.x * n_entries;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void k_pixfix(const uint8_t *__restrict__ fram
             if (e.kind != 0) {
                 auto tap = [&](int t) {
                     const int d = e.dep[t];
-                    return d >= 0 ? out[d].y : fetch_px<PACKED>(frame, e.pos + tap_offset(t, w));
+                    return d >= 0 ? out[d].y : fetch_px<PACKED>(frame, e.pos + tap_offset(t, w), bpp);
                 };
                 val = repair_value(e.kind, black, t16, u16, tap) & 0xFFFF;
             }
@@ -171,27 +173,28 @@ __global__ __launch_bounds__(256) void k_pixfix_scatter(const int2 *__restrict__
     if (p.x >= 0) ((uint16_t *)((uint8_t *)scatter_base + (size_t)blockIdx.y * scatter_stride))[p.x] = (uint16_t)p.y;
 }
 
-int launch_pixfix(bool packed, const void *frames, size_t stride, int w, int black, const void *entries,
+int launch_pixfix(int packed, const void *frames, size_t stride, int w, int black, const void *entries,
                   const int *level_off, int n_levels, int n_level0, int n_entries, void *patches, void *scatter,
                   size_t scatter_stride, int nframes, const DeviceLuts &luts, hipStream_t stream)
 {
     if (n_entries <= 0 || nframes <= 0) return MLVFS_AMD_OK;
+    const int bpp = packed == 1 ? 14 : packed;           // 1: what callers that pass `true` mean
     const int flat_x = (n_level0 + FLAT_PER_WG - 1) / FLAT_PER_WG, fpw = frames_per_wg(flat_x, nframes);
     const dim3 flat(flat_x, (nframes + fpw - 1) / fpw), all((n_entries + 255) / 256, nframes);
     if (packed) {
         if (n_level0 > 0)
             hipLaunchKernelGGL(k_pixfix_flat<true>, flat, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
-                               (const PixEntry *)entries, n_level0, n_entries, nframes, fpw, (int2 *)patches, luts.t16, luts.u16);
+                               (const PixEntry *)entries, n_level0, n_entries, nframes, fpw, (int2 *)patches, luts.t16, luts.u16, bpp);
         if (n_levels > 1)
             hipLaunchKernelGGL(k_pixfix<true>, dim3(nframes), dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
-                               (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches, luts.t16, luts.u16);
+                               (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches, luts.t16, luts.u16, bpp);
     } else {
         if (n_level0 > 0)
             hipLaunchKernelGGL(k_pixfix_flat<false>, flat, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
-                               (const PixEntry *)entries, n_level0, n_entries, nframes, fpw, (int2 *)patches, luts.t16, luts.u16);
+                               (const PixEntry *)entries, n_level0, n_entries, nframes, fpw, (int2 *)patches, luts.t16, luts.u16, bpp);
         if (n_levels > 1)
             hipLaunchKernelGGL(k_pixfix<false>, dim3(nframes), dim3(256), 0, stream, (const uint8_t *)frames, stride, w, black,
-                               (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches, luts.t16, luts.u16);
+                               (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches, luts.t16, luts.u16, bpp);
     }
     if (scatter)
         hipLaunchKernelGGL(k_pixfix_scatter, all, dim3(256), 0, stream, (const int2 *)patches, n_entries, (uint16_t *)scatter,
@@ -208,7 +211,7 @@ int launch_pixfix(bool packed, const void *frames, size_t stride, int w, int bla
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_pixfix_cells(const uint8_t *__restrict__ frames, size_t stride, int w, int h,
                                                       const CellRec *__restrict__ recs, int n_rec, int nframes, int fpw,
-                                                      const int2 *__restrict__ patches, int n_entries, int4 *__restrict__ cells)
+                                                      const int2 *__restrict__ patches, int n_entries, int4 *__restrict__ cells, int bpp)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rec) return;
@@ -223,23 +226,24 @@ __global__ __launch_bounds__(256) void k_pixfix_cells(const uint8_t *__restrict_
         int v[4];
 #pragma unroll
         for (int q = 0; q < 4; q++)
-            v[q] = rec.e[q] >= 0 ? (patches[(size_t)f * n_entries + rec.e[q]].y & 0xFFFF) : fetch_px<PACKED>(frame, pos[q]);
+            v[q] = rec.e[q] >= 0 ? (patches[(size_t)f * n_entries + rec.e[q]].y & 0xFFFF) : fetch_px<PACKED>(frame, pos[q], bpp);
         cells[(size_t)f * n_rec + r] = make_int4(rec.cell, v[0] | (v[1] << 16), v[2] | (v[3] << 16), 0);
     }
 }
 
-int launch_pixfix_cells(bool packed, const void *frames, size_t stride, int w, int h, const CellRec *recs, int n_rec,
+int launch_pixfix_cells(int packed, const void *frames, size_t stride, int w, int h, const CellRec *recs, int n_rec,
                         const void *patches, int n_entries, void *cells, int nframes, hipStream_t stream)
 {
     if (n_rec <= 0 || nframes <= 0) return MLVFS_AMD_OK;
+    const int bpp = packed == 1 ? 14 : packed;
     const int fpw = frames_per_wg((n_rec + 255) / 256, nframes);
     const dim3 grid((n_rec + 255) / 256, (nframes + fpw - 1) / fpw);
     if (packed)
         hipLaunchKernelGGL(k_pixfix_cells<true>, grid, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, h, recs, n_rec, nframes, fpw,
-                           (const int2 *)patches, n_entries, (int4 *)cells);
+                           (const int2 *)patches, n_entries, (int4 *)cells, bpp);
     else
         hipLaunchKernelGGL(k_pixfix_cells<false>, grid, dim3(256), 0, stream, (const uint8_t *)frames, stride, w, h, recs, n_rec, nframes, fpw,
-                           (const int2 *)patches, n_entries, (int4 *)cells);
+                           (const int2 *)patches, n_entries, (int4 *)cells, bpp);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(256) void k_pixfix_small(const uint8_t *__restrict_
                                                       const PixEntry *__restrict__ entries, const int *__restrict__ level_off,
                                                       int n_levels, int n_entries, int2 *__restrict__ patches,
                                                       const CellRec *__restrict__ recs, int n_rec, int4 *__restrict__ cells,
-                                                      const uint16_t *__restrict__ t16, const uint16_t *__restrict__ u16)
+                                                      const uint16_t *__restrict__ t16, const uint16_t *__restrict__ u16, int bpp)
 {
     const uint8_t *frame = frames + (size_t)blockIdx.x * stride;
     int2 *out = patches + (size_t)blockIdx.x * n_entries;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void k_pixfix_small(const uint8_t *__restrict_
             if (e.kind != 0) {
                 auto tap = [&](int t) {
                     const int d = e.dep[t];
-                    return d >= 0 ? out[d].y : fetch_px<PACKED>(frame, e.pos + tap_offset(t, w));
+                    return d >= 0 ? out[d].y : fetch_px<PACKED>(frame, e.pos + tap_offset(t, w), bpp);
                 };
                 val = repair_value(e.kind, black, t16, u16, tap) & 0xFFFF;
             }
@@ -279,18 +283,19 @@ __global__ __launch_bounds__(256) void k_pixfix_small(const uint8_t *__restrict_
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int x = min(2 * cx + (q & 1), w - 1), y = min(2 * cy + (q >> 1), h - 1);
-            v[q] = rec.e[q] >= 0 ? (out[rec.e[q]].y & 0xFFFF) : fetch_px<PACKED>(frame, y * w + x);
+            v[q] = rec.e[q] >= 0 ? (out[rec.e[q]].y & 0xFFFF) : fetch_px<PACKED>(frame, y * w + x, bpp);
         }
         cells[(size_t)blockIdx.x * n_rec + r] = make_int4(rec.cell, v[0] | (v[1] << 16), v[2] | (v[3] << 16), 0);
     }
 }
 
 // patch list + cell records for the fused kernel: one launch for a small map, the flat grid + levels + cells for a large one
-int launch_pixfix_for_frame_kernel(bool packed, const void *frames, size_t stride, int w, int h, int black, const void *entries,
+int launch_pixfix_for_frame_kernel(int packed, const void *frames, size_t stride, int w, int h, int black, const void *entries,
                                    const int *level_off, int n_levels, int n_level0, int n_entries, void *patches,
                                    const CellRec *recs, int n_rec, void *cells, int nframes, const DeviceLuts &luts, hipStream_t stream)
 {
     if (n_entries <= 0 || nframes <= 0) return MLVFS_AMD_OK;
+    const int bpp = packed == 1 ? 14 : packed;
     if (n_entries > 1024 || n_rec > 2048) {
         int rc = launch_pixfix(packed, frames, stride, w, black, entries, level_off, n_levels, n_level0, n_entries, patches, nullptr, 0,
                                nframes, luts, stream);
@@ -300,11 +305,11 @@ int launch_pixfix_for_frame_kernel(bool packed, const void *frames, size_t strid
     if (packed)
         hipLaunchKernelGGL(k_pixfix_small<true>, dim3(nframes), dim3(256), 0, stream, (const uint8_t *)frames, stride, w, h, black,
                            (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches, recs, n_rec, (int4 *)cells,
-                           luts.t16, luts.u16);
+                           luts.t16, luts.u16, bpp);
     else
         hipLaunchKernelGGL(k_pixfix_small<false>, dim3(nframes), dim3(256), 0, stream, (const uint8_t *)frames, stride, w, h, black,
                            (const PixEntry *)entries, level_off, n_levels, n_entries, (int2 *)patches, recs, n_rec, (int4 *)cells,
-                           luts.t16, luts.u16);
+                           luts.t16, luts.u16, bpp);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }

@@ -410,6 +410,41 @@ def test_other_bit_depths_through_the_fused_entry_points(gpu, oracle, tmp_path, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bpp", [12, 10])
+@pytest.mark.parametrize("w,h", [(256, 130), (264, 62), (128 + 16, 92), (400, 61), (1736, 64)])
+def test_reduced_bit_depths_straight_into_the_fused_loader(gpu, oracle, bpp, w, h):
+    """Round 4: 12-bit streams (8 pixels = 12 bytes) in rows of whole 8-pixel groups and 10-bit streams (8 pixels = 10 bytes) in rows
+    of whole 16-pixel groups are read by the fused kernel's loader itself (k_frame.hip, VEC = 3 / 4); other geometries still take the
+    unpack pass first.  Either way: every method, with the pixel map, with pixels at and below black, equals the oracle."""
+    from mlvfs_amd.stream import ClipStream, to_numpy_u16
+    shift = 14 - bpp
+    black, white = synth.BLACK >> shift, synth.WHITE >> shift
+    frames = []
+    for k in range(3):
+        f = (synth.normal_frame(w, h, seed=11, frame=k, hot=30, cold=30) >> shift).astype(np.uint16)
+        rng = np.random.default_rng(100 * bpp + k)
+        ys, xs = rng.integers(0, h, 40), rng.integers(0, w, 40)
+        f[ys[:20], xs[:20]] = black                                   # ev = INT_MIN
+        f[ys[20:], xs[20:]] = max(black - 3, 0)                       # below black
+        frames.append(f)
+    s = ClipStream(w, h, bpp, black, white, device=0)
+    dev_packed = s.upload_packed([synth.pack_bits(f, bpp) for f in frames])
+    pixels = oracle.detect_bad_pixels(frames[0], black, 0)
+    s.set_pixel_map(pixels)
+    co = [65536, 65536, 65354, 65738, 65241, 65868, 65450, 65640]
+    s.set_stripes(1, co)
+    for cs in (0, 2, 3, 5):
+        got = to_numpy_u16(s.process(dev_packed, cs=cs, fix_pixels=True, stripes=True))
+        for k, f in enumerate(frames):
+            img = oracle.apply_bad_pixels(f, black, pixels)
+            if cs:
+                img = oracle.chroma_smooth(img, black, cs)
+            img = oracle.stripes_apply(img, black, white, 1, np.array(co, np.int32)) if w % 8 == 0 else img
+            assert np.array_equal(got[k], img), (bpp, w, h, cs, k, int((got[k] != img).sum()))
+    s.close()
+
+
+@pytest.mark.gpu
 def test_deflicker_equals_reference_histogram_and_formula(gpu, reference):
     """main.c:895-906 (static in main.c, restated here) on the reference's own histogram helpers (oracle/_ref): every second
     pixel from pixel 1, 16-bit counters that wrap, median, BaselineExposure numerator."""
