@@ -132,6 +132,9 @@ __device__ __forceinline__ mlv_i32x4 table_rsrc(const void *p, unsigned stride, 
     return r;
 }
 constexpr int E2R_ENTRIES = 14 * MLV_EV_RES;
+#ifndef KF_E2R_AUX
+#define KF_E2R_AUX 0          // cache policy of the output look-ups (experiments: 2 = nt, 16 = sc1, 17 = sc0 sc1)
+#endif
 
 // SPREAD: the T16 table with entry i at i + (i >> 7).  A pixel below 2^e above black uses only every 2^(13-e)-th entry, so
 // the look-ups of dark footage crowd into a few LDS banks (below 128 DN: one); the spread form puts those entries into
@@ -297,6 +300,54 @@ __device__ __forceinline__ void cell_multi_ev_fast(const uint32_t *p0, const uin
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const uint32_t gb = (eb[4 * c + 1] + eb[4 * c + 2]) >> 1;
+        ge[c] = (int)(gb - (127u << 15));
+        dr[c] = (int)(eb[4 * c + 0] - gb);
+        db[c] = (int)(eb[4 * c + 3] - gb);
+    }
+}
+
+// The same for items that hold pixels AT or BELOW black (shadows of any real clip: with 7 DN of read noise a few per cent of a dark
+// region's pixels), still without a branch or a select per pixel.  raw2ev there: lin < 0 -> 0 = raw2ev(1), lin == 0 -> INT_MIN
+// (main.c:163-167), and the cell arithmetic wraps (chroma_smooth.c:32,54 on ints).  With f clamped to 1.0 a pixel's biased EV is
+// that of lin = 1; the sign of |f| - 0.5 is set exactly for lin == 0 and goes into bit 31 of the biased EV: eb'' = eb + z * 2^31,
+// i.e. ev = eb'' - bias (mod 2^32) for every pixel.  A green sum s = eb''(G1) + eb''(G2) is the true sum + 2 bias (mod 2^32); it
+// has bit 31 set exactly when one of the two is INT_MIN, and C's truncating half of it AS A SIGNED number is ge + bias in every
+// case (both INT_MIN: s = 2 bias, ge = 0, as the wrapped sum of the reference gives).  3 more operations per pixel and 2 per
+// cell than the common path (the previous out-of-table path: compare + select per pixel, 3.4x the common path's time; it
+// stays for what lies BEYOND the table, 16-bit input only).  Needs lin <= 16383 for every pixel.
+template <int NC, bool SPREAD>
+__device__ __forceinline__ void cell_multi_ev_dark(const uint32_t *p0, const uint32_t *p1, int black, const uint16_t *t,
+                                                   int (&ge)[NC], int (&dr)[NC], int (&db)[NC])
+{
+    uint32_t fb[4 * NC], tv[4 * NC], ex[4 * NC], eb[4 * NC], z[4 * NC];
+    const float fblack = (float)black;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const uint32_t px[4] = { p0[2 * c], p0[2 * c + 1], p1[2 * c], p1[2 * c + 1] };
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float f = (float)px[i] - fblack;
+            z[4 * c + i] = __float_as_uint(fabsf(f) - 0.5f);
+            fb[4 * c + i] = __float_as_uint(fmaxf(f, 1.0f));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4 * NC; i++) tv[i] = *(const uint16_t *)((const char *)t + t16_offset<SPREAD>(fb[i]));
+#pragma unroll
+    for (int i = 0; i < 4 * NC; i++) ex[i] = bfe_asm<23, 8>(fb[i]);
+#pragma unroll
+    for (int i = 0; i < 4 * NC; i += 8) {
+        asm volatile("" :: "v"(ex[i]), "v"(ex[i + 1]), "v"(ex[i + 2]), "v"(ex[i + 3]), "v"(ex[i + 4]), "v"(ex[i + 5]), "v"(ex[i + 6]), "v"(ex[i + 7]));
+    }
+#pragma unroll
+    for (int i = 0; i < 4 * NC; i += 8) {
+        asm volatile("" :: "v"(tv[i]), "v"(tv[i + 1]), "v"(tv[i + 2]), "v"(tv[i + 3]), "v"(tv[i + 4]), "v"(tv[i + 5]), "v"(tv[i + 6]), "v"(tv[i + 7]));
+    }
+#pragma unroll
+    for (int i = 0; i < 4 * NC; i++) eb[i] = (z[i] & 0x80000000u) | ((ex[i] << 15) + tv[i]);      // v_lshl_add_u32, v_and_or_b32
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const uint32_t gb = (uint32_t)half_trunc((int)(eb[4 * c + 1] + eb[4 * c + 2]));
         ge[c] = (int)(gb - (127u << 15));
         dr[c] = (int)(eb[4 * c + 0] - gb);
         db[c] = (int)(eb[4 * c + 3] - gb);
@@ -470,14 +521,24 @@ __device__ __forceinline__ void fetch_rows(const uint8_t *frame, int w, int h, i
 
 // pixels of one item -> planes (+ the interior pixels and green EVs of the rows that have them).  p: plane row
 template <int METHOD, class SM>
-__device__ __forceinline__ void emit_item(SM &sm, int black, bool slow, int p, int lk, bool edge, const uint32_t (&p0)[8],
+__device__ __forceinline__ void emit_item(SM &sm, int black, bool dark, bool slow, int p, int lk, bool edge, const uint32_t (&p0)[8],
                                           const uint32_t (&p1)[8])
 {
     const int jj = p - HC;                               // >= 0: a row whose pixels are output by this tile or the one below
     const bool keep = !edge && jj >= 0;
     if (METHOD != 0) {
         int ge[4], dr[4], db[4];
-        if (!slow) cell_multi_ev_fast<4, SM::SPREAD>(p0, p1, black, sm.t16, ge, dr, db);       // wave-uniform
+        if (!dark) cell_multi_ev_fast<4, SM::SPREAD>(p0, p1, black, sm.t16, ge, dr, db);       // wave-uniform, all three
+        else if (!slow) {
+            // (two cells at a time: with all sixteen pixels in flight this branch set the kernel's register peak and the loop's
+            // invariants were spilt for it)
+#pragma unroll
+            for (int c = 0; c < 4; c += 2) {
+                int g2[2], r2[2], b2[2];
+                cell_multi_ev_dark<2, SM::SPREAD>(p0 + 2 * c, p1 + 2 * c, black, sm.t16, g2, r2, b2);
+                ge[c] = g2[0]; ge[c + 1] = g2[1]; dr[c] = r2[0]; dr[c + 1] = r2[1]; db[c] = b2[0]; db[c + 1] = b2[1];
+            }
+        }
         else {
 #pragma unroll
             for (int c = 0; c < 4; c += 2) {
@@ -1149,7 +1210,8 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             } else fetch_rows<BPP>(frame, a.w, a.h, tx0, lk, ty0 - 2 * HC + 2 * p, L.edge, p0, p1);
             // Pixels at or below black (ev = INT_MIN / 0) or beyond the table need the fix-ups of cell_pair_ev: decided once
             // per item from the extremes of its 16 pixels (three-input min/max), wave-uniformly.
-            bool odd = false;
+            // and, 16-bit input only, what lies beyond the table.
+            bool odd = false, beyond = false;
             if (METHOD != 0) {
                 uint32_t lo = min(p0[0], p1[0]), hi = max(p0[0], p1[0]);
 #pragma unroll
@@ -1157,14 +1219,20 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                     lo = min(min(lo, p0[i]), p1[i]);
                     if (!PACKED) hi = max(max(hi, p0[i]), p1[i]);
                 }
-                odd = (int)lo <= a.black || (!PACKED && (int)hi - a.black > 16383) || (PACKED && a.black < 0);
+                odd = (int)lo <= a.black;
+                beyond = (!PACKED && (int)hi - a.black > 16383) || (PACKED && a.black < 0);
             }
-            const bool slow = __any(odd);
-            if (METHOD == 5 && SPREAD && slow) {
-                const unsigned long long who = __ballot(odd);
+#ifdef KF_EXP_FASTLOADER
+            const bool slow = false, dark = false;
+#else
+            const bool slow = (!PACKED || a.black < 0) && __any(beyond);
+            const bool dark = slow || __any(odd);
+#endif
+            if (METHOD == 5 && SPREAD && dark) {
+                const unsigned long long who = __ballot(odd || beyond);
                 if (lane == 0) atomicAdd(&sm.dark_items[par], __popcll(who));
             }
-            emit_item<METHOD, Smem>(sm, a.black, slow, p, lk, L.edge, p0, p1);
+            emit_item<METHOD, Smem>(sm, a.black, dark, slow, p, lk, L.edge, p0, p1);
         };
         if (METHOD != 0 && !cont) {
             // the first tile of a run (or of a column): the four plane rows above the tile's own, straight from memory -- threads
@@ -1235,8 +1303,12 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 for (int c = 0; c < STRIP; c++) {
                     er[c] = wadd(gev[c], mr[c]);
                     eb[c] = wadd(gev[c], mb[c]);
-                    ur[c] = mlv_sbl_u32(rs_e2r, min(max(er[c], 0), MLV_EV_MAX), 0, 0, 0);
-                    ub[c] = mlv_sbl_u32(rs_e2r, min(max(eb[c], 0), MLV_EV_MAX), 0, 0, 0);
+#ifdef KF_EXP_NOLOOKUP
+                    ur[c] = min(max(er[c], 0), MLV_EV_MAX); ub[c] = min(max(eb[c], 0), MLV_EV_MAX);
+#else
+                    ur[c] = mlv_sbl_u32(rs_e2r, min(max(er[c], 0), MLV_EV_MAX), 0, 0, KF_E2R_AUX);
+                    ub[c] = mlv_sbl_u32(rs_e2r, min(max(eb[c], 0), MLV_EV_MAX), 0, 0, KF_E2R_AUX);
+#endif
                 }
                 read_raw();
                 // chroma_smooth.c:27 leaves columns 0..3 and w-4.. alone: only the tiles at the frame's left and right margin test for that
@@ -1301,6 +1373,9 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             // everywhere: that is where the packed attempt plus the dense pass cost more than the 32-bit chain).
             const bool dark_tile = SPREAD && __builtin_amdgcn_readfirstlane(sm.dark_items[par]) >= DARK_ITEMS_MIN;
             skip_packed = dark_tile || fb_skip > 0;            // the same for every wave of the workgroup
+#ifdef KF_EXP_NOFALLBACK
+            skip_packed = false;
+#endif
             if (fb_skip > 0) fb_skip--;
             if (SPREAD && tid == 0) sm.dark_items[par ^ 1] = 0;
             bool unknown = true;
@@ -1344,6 +1419,9 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 unknown = chain_finish(g, n, mr, mb);
             }
             unknown = unknown && is_strip && smooth_row;
+#ifdef KF_EXP_NOFALLBACK
+            unknown = false;
+#endif
             if (unknown) sm.fb_queue[atomicAdd(&sm.fb_count, 1)] = (uint8_t)(j * 16 + k);      // settled below, densely
             if (is_strip && !unknown) finish_strip(j, k, smooth_row, mr, mb, true);
         } else {
