@@ -140,6 +140,11 @@ const int32_t *host_ev2raw();       // [24*32768] index 0 is ev = -10*32768
 const uint16_t *host_t16();
 const uint16_t *host_t16d();
 const uint16_t *host_u16();
+// code objects of the frame path, loaded when a device context is created (defined in the .hip files they belong to)
+void preload_k_unpack();
+void preload_k_pixfix();
+void preload_k_stripes();
+void preload_k_frame();
 int luts_ok();
 
 struct Geom {

@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 
 #ifdef KF_DIAG_TIMES
     const uint64_t rt0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long diag_n[4] = { 0, 0, 0, 0 };
+    unsigned long long diag_n[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
     int par = 0;                               // tile parity: which of the two dark_items counters this tile uses
     int fb_skip = 0, fb_wait = FB_WAIT_MIN;    // 5x5: tiles still to go straight to the 32-bit chain; how many after the next busy tile
@@ -1461,6 +1461,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             // tiles, tiles that skipped the packed networks, strips settled densely, tiles that continued the one above (summed per
             // workgroup, added once at its end: an atomic per tile on one address serialised the whole launch)
             diag_n[0]++; diag_n[1] += skip_packed ? 1 : 0; diag_n[2] += nfb; diag_n[3] += cont ? 1 : 0;
+            diag_n[4] += nfb > 0 ? 1 : 0; diag_n[5] += robust ? 1 : 0; diag_n[6] += nfb > 64 ? 1 : 0; diag_n[7] += (nfb > 0 && nfb <= 4) ? 1 : 0;
 #endif
             if (nfb > 0) {
                 if ((tid & ~63) < nfb) {                               // this wave has entries
@@ -1490,7 +1491,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 #ifdef KF_DIAG_TIMES
     if (threadIdx.x == 0 && a.times) {
         a.times[2 * blockIdx.x] = rt0; a.times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-        for (int i = 0; i < 4; i++) atomicAdd(&a.times[4096 + i], diag_n[i]);
+        for (int i = 0; i < 8; i++) atomicAdd(&a.times[4096 + i], diag_n[i]);
     }
 #endif
 }
@@ -1660,10 +1661,11 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
             for (int b = 0; b < grid; b++) { t0 = std::min(t0, h[2 * b]); t1 = std::max(t1, h[2 * b + 1]); }
             double end_q[4] = { 0, 0, 0, 0 }, start_q[4] = { 0, 0, 0, 0 };
             for (int b = 0; b < grid; b++) { end_q[b * 4 / grid] += (double)(h[2 * b + 1] - t0); start_q[b * 4 / grid] += (double)(h[2 * b] - t0); }
-            unsigned long long fbc[4];
+            unsigned long long fbc[8];
             hipMemcpy(fbc, d_times + 4096, sizeof(fbc), hipMemcpyDeviceToHost);
             fprintf(stderr, "KF_TIMES tiles %llu, of which %llu skipped the packed networks and %llu continued the tile above; strips settled densely %llu (%.1f %% of all)\n", fbc[0], fbc[1],
                     fbc[3], fbc[2], fbc[0] ? 100.0 * fbc[2] / (240.0 * fbc[0]) : 0.0);
+            fprintf(stderr, "KF_TIMES tiles with uncertain strips %llu (1..4 strips: %llu, more than 64: %llu); tiles on shared references %llu\n", fbc[4], fbc[7], fbc[6], fbc[5]);
             fprintf(stderr, "KF_TIMES grid %d: kernel %.1f us; mean start / end of the workgroups of each quarter of the grid (us):", grid, (t1 - t0) * 0.01);
             for (int q = 0; q < 4; q++) fprintf(stderr, "  %.1f / %.1f", start_q[q] / (grid / 4) * 0.01, end_q[q] / (grid / 4) * 0.01);
             fprintf(stderr, "\n");
@@ -1806,5 +1808,10 @@ int dark_share(int packed_bpp, const void *d_frame, int w, int h, int black, hip
     *share_1024 = hc[1] > 0 ? (int)((long long)hc[0] * 1024 / hc[1]) : 0;
     return MLVFS_AMD_OK;
 }
+
+
+// the first launch of any kernel of this file loads the file's code object (HIP loads them lazily): the device context asks for a
+// kernel's attributes when it is created, so that a clip's first frame does not pay for it (runtime.cpp: get_device)
+void preload_k_frame() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)k_build_e2r); (void)hipGetLastError(); }
 
 }  // namespace mlv

@@ -393,4 +393,9 @@ int launch_badpix_detect(const void *d_frame, int w, int h, int black, int aggre
     return MLVFS_AMD_OK;
 }
 
+
+// the first launch of any kernel of this file loads the file's code object (HIP loads them lazily): the device context asks for a
+// kernel's attributes when it is created, so that a clip's first frame does not pay for it (runtime.cpp: get_device)
+void preload_k_pixfix() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)k_pixfix_cells<true>); (void)hipGetLastError(); }
+
 }  // namespace mlv

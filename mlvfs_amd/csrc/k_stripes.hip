@@ -341,4 +341,9 @@ int launch_rand_stream(const uint32_t *d_start, const uint32_t *d_pow2, int npow
     return MLVFS_AMD_OK;
 }
 
+
+// the first launch of any kernel of this file loads the file's code object (HIP loads them lazily): the device context asks for a
+// kernel's attributes when it is created, so that a clip's first frame does not pay for it (runtime.cpp: get_device)
+void preload_k_stripes() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)k_stripes_count); (void)hipGetLastError(); }
+
 }  // namespace mlv

@@ -98,4 +98,9 @@ int launch_unpack(const void *d_packed, size_t packed_stride, void *d_out, size_
     return MLVFS_AMD_OK;
 }
 
+
+// the first launch of any kernel of this file loads the file's code object (HIP loads them lazily): the device context asks for a
+// kernel's attributes when it is created, so that a clip's first frame does not pay for it (runtime.cpp: get_device)
+void preload_k_unpack() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)k_unpack_x16<14>); (void)hipGetLastError(); }
+
 }  // namespace mlv
