@@ -115,6 +115,7 @@ def build_regions():
     R["loop"] = block("while (t < band_end) {")
     R["top_rows"] = block("if (METHOD != 0 && !cont) {")                  # the four plane rows above a run's first tile
     R["loader"] = line("if (has_item) do_item(IL, r0, r1, NEW0 + l_row, l_k);")
+    R["dark_items"] = block("if (METHOD == 5 && SPREAD && dark) {")
     R["chain32"] = block("if (skip_packed) {")
     R["packed"] = (find("ChainGroup g;", k0), find("unknown = chain_finish(g, n, mr, mb);", k0))
     R["early"] = block("if (early) {")
@@ -132,6 +133,7 @@ def build_regions():
     R["novec_store"] = (R["novec_store"][0], block_end(R["novec_store"][0]))
     R["stripe_slow"] = (find("else if (stripe_mode == 2)", k0), find("else stripe_strip<false>", k0))
     for name, sig in {"cell_pair_ev": "__device__ __forceinline__ void cell_pair_ev(", "cell_multi_ev_fast": "__device__ __forceinline__ void cell_multi_ev_fast(",
+                      "cell_multi_ev_dark": "__device__ __forceinline__ void cell_multi_ev_dark(",
                       "fetch_rows": "__device__ __forceinline__ void fetch_rows(", "fetch_clamped": "__device__ __forceinline__ uint32_t fetch_clamped(",
                       "emit_item": "__device__ __forceinline__ void emit_item(",
                       "strip_median25": "__device__ __forceinline__ void strip_median25(", "robust_ref": "__device__ __forceinline__ int robust_ref(",
@@ -174,6 +176,8 @@ def weight_of(chain, R, tiles_per_workgroup):
     # paths the benchmark's frames do not take
     if any_in("cell_pair_slow"):
         return 0.0, "loader: out-of-table pixels (slow path)"
+    if any_in("cell_multi_ev_dark") or inside(outer, R["dark_items"]):
+        return 0.0, "loader: items with pixels at or below black"
     if any_in("fetch_rows") or any_in("fetch_clamped") or any_in("novec_store"):
         return 0.0, "widths that are no multiple of 8"
     if inside(outer, R["chain32"]):
