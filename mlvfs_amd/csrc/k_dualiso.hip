@@ -120,36 +120,51 @@ __device__ __forceinline__ int di_p16(const uint16_t *img, size_t i) { return (i
 __device__ __forceinline__ int di_nsy(const DiParams &p) { const int y0 = p.ay1 + 2; return (p.h - 2 > y0) ? (p.h - 2 - y0 + 2) / 3 : 0; }
 
 // Layout of the sample arrays of a batch: frame f at f * ns_stride (dark_s, bright_s), its two histograms back to back at
-// f * 2 * DI_HIST_N (hist_b | hist_d).  grid = (blocks over nsx * nsy_max, frames)
-__global__ __launch_bounds__(256) void k_di_subsample(const uint16_t *__restrict__ img_base, DiBatch bt, int nsx, size_t ns_stride,
-                                                      int *__restrict__ dark_s, int *__restrict__ bright_s, unsigned *__restrict__ hist_bd)
+// f * 2 * DI_HIST_N (hist_b | hist_d).
+// The histograms: a sample's bin is value + DI_HIST_OFF, and value + black is a 16-bit number (a pixel << 2, the mean of two, or the
+// white level), so ONE histogram fits into LDS as 65 536 16-bit counters.  grid = (chunks, frames, 2): a workgroup counts hist_b
+// (z = 0) or hist_d (z = 1) of one chunk of a frame's samples (at most 65 535, so no counter wraps) and flushes the bins it touched
+// with one global atomic each -- a global atomic per sample and histogram (8.4 M per batch of 8, most of them on the few thousand
+// bins a scene occupies) was 340 of the kernel's 357 us.  The z = 0 workgroups write the sample arrays.
+__global__ __launch_bounds__(1024) void k_di_subsample(const uint16_t *__restrict__ img_base, DiBatch bt, int nsx, size_t ns_stride,
+                                                       int per_chunk, int *__restrict__ dark_s, int *__restrict__ bright_s,
+                                                       unsigned *__restrict__ hist_bd)
 {
+    __shared__ unsigned cnt[32768];                          // bin (value + black) >> 1, two 16-bit counters per word
     int f; DiParams p;
     if (!di_frame<1>(bt, f, p)) return;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nsx * di_nsy(p)) return;
+    const int n = nsx * di_nsy(p), first = blockIdx.x * per_chunk, last = min(first + per_chunk, n), which = blockIdx.z;
+    if (first >= n) return;
+    for (int i = threadIdx.x; i < 32768; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
     const uint16_t *img = di_img(img_base, bt, f, p);
     dark_s += (size_t)f * ns_stride; bright_s += (size_t)f * ns_stride;
-    unsigned *hist_b = hist_bd + (size_t)f * 2 * DI_HIST_N, *hist_d = hist_b + DI_HIST_N;
-    const int sx = idx % nsx, sy = idx / nsx;
-    const int x = 3 * sx, y = p.ay1 + 2 + 3 * sy, w = p.w;
-    const int black = p.black20 / 16, white = p.match_white20 / 16;
+    const int w = p.w, black = p.black20 / 16, white = p.match_white20 / 16;
     const int clip0 = white - black, clip = (int)(clip0 * 0.95);
-    const int pa = di_p16(img, x + (size_t)(y - 2) * w) - black, pb = di_p16(img, x + (size_t)(y + 2) * w) - black;
-    int pn = di_p16(img, x + (size_t)y * w) - black;
-    int pi = (pa + pb + 1) / 2;
-    if (pa >= clip || pb >= clip) pi = clip0;
-    if (pi >= clip) pn = clip0;
-    const int br = di_bright(p, y);
-    const int d = br ? pi : pn, b = br ? pn : pi;
-    dark_s[idx] = d;
-    bright_s[idx] = b;
-#ifndef DI_EXP_SUB_NOATOMICS
-    if (b < clip) {
-        atomicAdd(&hist_b[min(max(b + DI_HIST_OFF, 0), DI_HIST_N - 1)], 1u);
-        atomicAdd(&hist_d[min(max(d + DI_HIST_OFF, 0), DI_HIST_N - 1)], 1u);
+    for (int idx = first + (int)threadIdx.x; idx < last; idx += blockDim.x) {
+        const int sx = idx % nsx, sy = idx / nsx;
+        const int x = 3 * sx, y = p.ay1 + 2 + 3 * sy;
+        const int pa = di_p16(img, x + (size_t)(y - 2) * w) - black, pb = di_p16(img, x + (size_t)(y + 2) * w) - black;
+        int pn = di_p16(img, x + (size_t)y * w) - black;
+        int pi = (pa + pb + 1) / 2;
+        if (pa >= clip || pb >= clip) pi = clip0;
+        if (pi >= clip) pn = clip0;
+        const int br = di_bright(p, y);
+        const int d = br ? pi : pn, b = br ? pn : pi;
+        if (which == 0) { dark_s[idx] = d; bright_s[idx] = b; }
+        if (b < clip) {
+            const unsigned slot = (unsigned)((which ? d : b) + black) & 0xFFFFu;          // (in range by construction; masked for the LDS bound)
+            atomicAdd(&cnt[slot >> 1], 1u << (16 * (slot & 1)));
+        }
     }
-#endif
+    __syncthreads();
+    // bin of slot s: s - black + DI_HIST_OFF, clamped as the per-sample form clamped it (never at the ends for 16-bit values)
+    unsigned *hist = hist_bd + (size_t)f * 2 * DI_HIST_N + (size_t)which * DI_HIST_N;
+    for (int i = threadIdx.x; i < 32768; i += blockDim.x) {
+        const unsigned v = cnt[i];
+        if (v & 0xFFFFu) atomicAdd(&hist[min(max(2 * i - black + DI_HIST_OFF, 0), DI_HIST_N - 1)], v & 0xFFFFu);
+        if (v >> 16) atomicAdd(&hist[min(max(2 * i + 1 - black + DI_HIST_OFF, 0), DI_HIST_N - 1)], v >> 16);
+    }
 }
 
 // highlight pairs of match_exposures (hdr.c:735-746): the samples with b_lo < bright < b_hi in raster order.  One workgroup
@@ -432,6 +447,9 @@ __global__ __launch_bounds__(256) void k_di_amaze_ev(const float *__restrict__ r
     ev_red += (size_t)f * bt.S; ev_green += (size_t)f * bt.S; ev_blue += (size_t)f * bt.S; gray_sq += (size_t)f * bt.S;
     const size_t n = (size_t)p.w * p.h;
     const int black = p.black20;
+    // (four pixels per thread -- float4 in, int4 out, sixteen look-ups in flight -- made this kernel 10 % shorter and the batch of 8
+    // 4.5 % LONGER, three rounds round-robin: it runs beside AMaZE's kernels on the other stream and took more of the chip from them;
+    // profiles/r04/ab_di_bench.log)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float fb = (float)black, hi = 1048575.0f;
         const float g = (green[i] - fb) * 2.0f + fb, r = red[i], b = blue[i];
@@ -1200,9 +1218,16 @@ int di_launch_subsample(const void *d_img, const DiBatch &b, int nsx, int nsy_ma
                         unsigned *d_hist_bd, hipStream_t s)
 {
     MLV_HIP(hipMemsetAsync(d_hist_bd, 0, 2 * sizeof(unsigned) * DI_HIST_N * b.nframes, s));
-    if (nsx * nsy_max > 0)
-        hipLaunchKernelGGL(k_di_subsample, dim3((nsx * nsy_max + 255) / 256, b.nframes), dim3(256), 0, s, (const uint16_t *)d_img, b, nsx,
-                           ns_stride, d_dark_s, d_bright_s, d_hist_bd);
+    const int n = nsx * nsy_max;
+    if (n > 0) {
+        // chunks per frame: enough workgroups for the chip from a small batch, few flushes from a large one; a chunk's samples fit a
+        // 16-bit counter
+        int chunks = std::min(64, std::max(16, 256 / (2 * std::max(b.nframes, 1))));
+        chunks = std::max(chunks, (n + 65534) / 65535);
+        const int per_chunk = (n + chunks - 1) / chunks;
+        hipLaunchKernelGGL(k_di_subsample, dim3(chunks, b.nframes, 2), dim3(1024), 0, s, (const uint16_t *)d_img, b, nsx, ns_stride, per_chunk,
+                           d_dark_s, d_bright_s, d_hist_bd);
+    }
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
