@@ -57,10 +57,9 @@ __device__ __forceinline__ const uint16_t *di_img(const uint16_t *base, const Di
 // band: rows per workgroup (a multiple of 4).  The taller, the fewer global atomics flush the same bins (a 16-row band of 3584 pixels
 // touches ~5 000 of its 32 768 counters for 14 336 pixels: 13 M flush atomics per batch of 8 were most of the kernel); the 16-bit
 // counters hold band / 4 * w / 2 pixels per class.
-#ifndef DI_ANALYSE_THREADS
-#define DI_ANALYSE_THREADS 256
-#endif
-__global__ __launch_bounds__(DI_ANALYSE_THREADS) void k_di_analyse(const uint16_t *__restrict__ img, int w, int H, int black, int white,
+// Timing experiments on a batch of 8 (round 4, rocprofv3 --stats, 419 us): without the white histograms' global atomics 323, without
+// hdr_check 329, without the class counters 417; 512 / 1024 threads per workgroup 409 / 453.
+__global__ __launch_bounds__(256) void k_di_analyse(const uint16_t *__restrict__ img, int w, int H, int black, int white,
                                                     const double *__restrict__ evf /* [16384] log2(i)*32768 */,
                                                     unsigned *__restrict__ hist /* device layout, dualiso.h */, double *__restrict__ check /* sum, count */,
                                                     size_t img_stride /* bytes */, size_t hist_stride /* words */, size_t check_stride /* doubles */,
@@ -90,16 +89,12 @@ __global__ __launch_bounds__(DI_ANALYSE_THREADS) void k_di_analyse(const uint16_
                 n += 1;
             }
         }
-#ifndef DI_EXP_NOCLASS
         const int slot = (x & 1) * 16384 + (p & 16383);
         atomicAdd(&cnt[slot >> 1], 1u << (16 * (slot & 1)));
-#endif
         const int vw = p < 32767 ? p : 32767;
-#ifndef DI_EXP_NOWHITE
         if (y % 3 == 0 && x % 3 == 0) atomicAdd(&h_w0[(y & 3) * 32768 + vw], 1u);
         const int y1 = y - 1;                                    // row index in the frame that starts one row lower
         if (y1 >= 1 && y1 % 3 == 1 && x % 3 == 0) atomicAdd(&h_w1[(y1 & 3) * 32768 + vw], 1u);
-#endif
     }
     __syncthreads();
     unsigned *cls = hist + DI_D_CLASS + (size_t)q * 2 * 16384;
@@ -1207,7 +1202,7 @@ int di_launch_analyse(const void *d_img, int w, int H, int black, int white, con
     int band = H * 4 * nframes / 256 / 4 * 4;                                   // at least a workgroup per CU
     band = band < 16 ? 16 : (band > band_max ? band_max : band);
     while (band > 4 && (band / 4) * (w / 2 + 1) >= 65536) band -= 4;            // the 16-bit counters of a class
-    hipLaunchKernelGGL(k_di_analyse, dim3((H + band - 1) / band, 4, nframes), dim3(DI_ANALYSE_THREADS), 0, s, (const uint16_t *)d_img, w, H, black, white,
+    hipLaunchKernelGGL(k_di_analyse, dim3((H + band - 1) / band, 4, nframes), dim3(256), 0, s, (const uint16_t *)d_img, w, H, black, white,
                        d_evf, d_hist, d_check, img_stride, hist_stride, check_stride, band);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
