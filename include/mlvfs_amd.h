@@ -328,6 +328,10 @@ int mlvfs_amd_amaze_demosaic_dev(const float *d_raw, int width, int height, floa
 /* The split of a width x height plane between the two AMaZE kernels: the first nfx x nfy tiles (128-pixel grid, origin -16) are complete
  * -- 160 rows and columns inside the image, not the head of a chain of incomplete tiles -- and are row-streamed through LDS.  No GPU needed. */
 void mlvfs_amd_amaze_rows_extent(int width, int height, int *nfx, int *nfy);
+/* Test hook: tiles that head a chain of incomplete tiles WITHOUT output (widths that are a multiple of 128) through the row-streamed
+ * kernel as well.  mode -1: MLVFS_AMD_AMAZE_ROWS_EXTRA decides (default off: measured 1 % slower per batch), 0 / 1: forced; returns
+ * the mode before; *count (may be NULL): the number of such tiles of a width x height plane.  Results are bit-identical either way. */
+int mlvfs_amd_amaze_rows_extra_mode(int mode, int width, int height, int *count);
 /* Debug: the same with the tile planes copied out (26 planes per 160x160 tile, the layout of k_amaze.hip's block).  mode 0: every
  * tile through k_amaze.hip, blocks in tile order; mode 1: the complete tiles through k_amaze_rows.hip (LDS row streaming), their
  * planes numbered ty * nfx + tx; nfx x nfy = the complete tiles of the plane.  Synchronous. */

@@ -746,6 +746,22 @@ void mlvfs_amd_amaze_rows_extent(int width, int height, int *nfx, int *nfy)
     if (nfy) *nfy = fy;
 }
 
+// Test hook: the heads of output-less chains through k_amaze_rows.hip as well (k_amaze_rows.hip: amaze_rows_extra).  mode -1: the
+// environment decides (default off), 0 / 1: forced; returns the mode before.  *count (may be null): how many such tiles a
+// width x height plane has when the mode is on.
+int mlvfs_amd_amaze_rows_extra_mode(int mode, int width, int height, int *count)
+{
+    const int before = g_amaze_rows_extra_mode;
+    if (count) {
+        const int rows_before = g_amaze_rows_mode;
+        g_amaze_rows_mode = 1; g_amaze_rows_extra_mode = 1;
+        *count = amaze_rows_extra(width, height);
+        g_amaze_rows_mode = rows_before;
+    }
+    g_amaze_rows_extra_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+    return before;
+}
+
 // Debug: the AMaZE demosaic with its tile planes copied out.  mode 0: every tile through k_amaze.hip, d_planes gets the blocks in
 // tile order (ty * tiles_x + tx); mode 1: the complete tiles through k_amaze_rows.hip, d_planes gets THEIR planes in the same
 // layout, numbered ty * nfx + tx (nfx x nfy complete tiles, returned).  tests/ compare the two plane by plane.

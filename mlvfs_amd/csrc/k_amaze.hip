@@ -62,7 +62,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
                                                  float *__restrict__ green_out, float *__restrict__ blue, float *__restrict__ scratch,
                                                  int tiles_x, int row0, int wgs_per_row, int chain_len, int rows_per_wg, int copy_from,
                                                  size_t plane_stride, size_t scratch_stride, const int *__restrict__ h_of, int h_stride,
-                                                 int nfx, int nfy)
+                                                 int nfx, int nfy, int dead_rows)
 {
     __shared__ unsigned char s_nyq[HALF];
     __shared__ float s_w[HALF];
@@ -76,6 +76,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
     const int ty0 = row0 + (int)(blockIdx.x / wgs_per_row), tx0 = (int)(blockIdx.x % wgs_per_row);
     const int ntiles = (tx0 == wgs_per_row - 1) ? chain_len : 1;
     if (tx0 < nfx && ty0 < nfy && ntiles == 1 && rows_per_wg == 1 && copy_from < 0) return;       // a complete tile: k_amaze_rows has it
+    if (tx0 == wgs_per_row - 1 && ty0 < dead_rows && rows_per_wg == 1 && copy_from < 0) return;    // a chain without output whose head k_amaze_rows has (amaze_rows_extra)
     float *const block = scratch + (size_t)(ty0 * tiles_x + tx0) * AMAZE_TILE_FLOATS;
     if (copy_from >= 0) {
         const float4 *src = (const float4 *)(scratch + (size_t)copy_from * AMAZE_TILE_FLOATS);
@@ -597,9 +598,10 @@ int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green,
     static const int threads = [] { const char *e = getenv("MLVFS_AMD_AMAZE_THREADS"); const int v = e ? atoi(e) : 1024; return v >= 64 && v <= 1024 ? v / 64 * 64 : 1024; }();
     int nfx = 0, nfy = 0;
     amaze_rows_extent(w, h, &nfx, &nfy);                                         // the complete tiles go through LDS (k_amaze_rows.hip)
+    const int dead_rows = d_rows_dbg ? 0 : amaze_rows_extra(w, h);               // and so do the heads of chains that have no output
     auto launch = [&](int row0, int nrows, int wgs_per_row, int chain_len, int rows_per_wg, int copy_from) {
         hipLaunchKernelGGL(k_amaze, dim3(nrows * wgs_per_row, nframes), dim3(threads), 0, s, d_raw, w, h, d_red, d_green, d_blue, d_scratch, tiles_x,
-                           row0, wgs_per_row, chain_len, rows_per_wg, copy_from, plane_stride, scratch_stride, h_of, h_stride, nfx, nfy);
+                           row0, wgs_per_row, chain_len, rows_per_wg, copy_from, plane_stride, scratch_stride, h_of, h_stride, nfx, nfy, dead_rows);
     };
     // The complete tiles run on a side stream, next to this stream's launches for the incomplete ones: those are few workgroups in
     // two dependent launches (1.5 ms of a mostly idle chip per batch of 8 at 3584x1320); k_amaze_rows draws its tiles from a counter,

@@ -178,7 +178,7 @@ static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
 template <bool DBG>
 __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ raw, int w, int h, float *__restrict__ red,
-                                                      float *__restrict__ green_out, float *__restrict__ blue, int nfx, int ntiles,
+                                                      float *__restrict__ green_out, float *__restrict__ blue, int nfx, int ntiles, int nrect,
                                                       size_t plane_stride, const int *__restrict__ h_of, int h_stride,
                                                       float *__restrict__ dbg, unsigned long long *__restrict__ prof, unsigned skip_mask, int *__restrict__ tile_ctr)
 {
@@ -200,18 +200,27 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
 
     // tile of pair counter q: its number and its origin in the image
+    // Tiles 0 .. nrect - 1 are the nfx x nfy block of the tile grid; tiles nrect .. ntiles - 1 are the tiles of column nfx in rows
+    // 0, 1, ... (amaze_rows_extra: the last column whose tiles have all their rows and columns, where the image's right edge is
+    // mirrored into their last 16 columns and nothing downstream reads the block they would have left behind in k_amaze.hip)
+    auto origin = [&](int id, int &top, int &left) {
+        const int ty = id < nrect ? id / nfx : id - nrect, tx = id < nrect ? id % nfx : nfx;
+        top = -16 + ty * (T - 32);
+        left = -16 + tx * (T - 32);
+    };
     auto tile_of = [&](int q, int &top, int &left) -> int {
         const int id = __builtin_amdgcn_readfirstlane(ctl[(q / NP) & 3]);
-        top = -16 + (id / nfx) * (T - 32);
-        left = -16 + (id % nfx) * (T - 32);
+        origin(id, top, left);
         return id;
     };
-    // cfa source of tile pixel (r, col): amaze_demosaic_RT.c:361-469 for a tile without right / bottom apron; the top and left
-    // aprons of the image's first tile row / column are mirrored
+    // cfa source of tile pixel (r, col): amaze_demosaic_RT.c:361-469 for a tile without bottom apron; the top and left aprons of
+    // the image's first tile row / column are mirrored, and so is the right apron of the extra tiles (:399-410 and, in the first
+    // tile row, the corner :441-450 -- which, like the top-left one, counts its rows from 32, not from 32 + top)
     auto source = [&](int top, int left, int r, int col) -> size_t {
-        const int rrmin = top < 0 ? 16 : 0, ccmin = left < 0 ? 16 : 0;
+        const int rrmin = top < 0 ? 16 : 0, ccmin = left < 0 ? 16 : 0, ccmax = w - left;      // ccmax >= T: no right apron
         int y, x;
-        if (r >= rrmin && col >= ccmin) { y = r + top; x = col + left; }
+        if (col >= ccmax) { y = r >= rrmin ? r + top : 32 - r; x = w - (col - ccmax) - 2; }
+        else if (r >= rrmin && col >= ccmin) { y = r + top; x = col + left; }
         else if (r < rrmin && col >= ccmin) { y = 32 - r + top; x = col + left; }
         else if (r >= rrmin) { y = r + top; x = 32 - col + left; }
         else { y = 32 - r; x = 32 - (col & ~3) + (col & 3); }
@@ -226,7 +235,8 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
         const int id = next_tile();
         if (lane == 0) { ctl[0] = id; ctl[4] = id < ntiles ? 0x7FFFFFFF : 0; }
         if (id < ntiles) {
-            const int top = -16 + (id / nfx) * (T - 32), left = -16 + (id % nfx) * (T - 32);
+            int top, left;
+            origin(id, top, left);
 #pragma unroll
             for (int ck = 0; ck < 5; ck++) {
                 const int n = ck * 64 + lane, rho = n >= T, col = n - T * rho;
@@ -282,7 +292,8 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
                         if (lane == 0) { if (id1 < ntiles) ctl[((q + 1) / NP) & 3] = id1; else ctl[4] = q + 1; }
                     }
                     if (id1 < ntiles) {
-                        const int top = -16 + (id1 / nfx) * (T - 32), left = -16 + (id1 % nfx) * (T - 32);
+                        int top, left;
+                        origin(id1, top, left);
 #pragma unroll
                         for (int c5 = 0; c5 < 5; c5++) {
                             const int n = c5 * 64 + lane, rho = n >= T, col = n - T * rho;
@@ -890,6 +901,32 @@ void amaze_rows_extent(int w, int h, int *nfx, int *nfy)
     *nfx = fx; *nfy = fy;
 }
 
+// Tiles of column nfx (the heads of k_amaze.hip's chains) that this kernel takes as well, rows 0 .. n - 1.  Where the width is a multiple
+// of 128 the one incomplete tile of a row is 32 columns wide -- all apron, no output pixel (amaze_demosaic_RT.c:1459: the interior
+// starts 16 columns in and ends 16 before the end) -- and the block it leaves behind is read by nobody except, after the LAST
+// row of complete tiles, the launch for the incomplete bottom row (k_amaze.hip: amaze_launch, `src`).  The head of such a chain is a
+// tile like any other but for its last 16 columns, which mirror the image's right edge; k_amaze.hip then skips the whole chain.
+// Measured (tools/ab_di_bench.sh, batch of 8 at 3584x1320, three rounds round-robin): 8.00 ms per batch without, 8.09 with -- the 90 chains
+// ran beside the row kernel on an otherwise idle part of the chip, their 9 heads per frame lengthen the row kernel's last round
+// (1 116 instead of 1 080 tiles over 256 workgroups per half batch), which is what the batch waits for.  OFF unless
+// MLVFS_AMD_AMAZE_ROWS_EXTRA=1 (or the test hook mlvfs_amd_amaze_rows_extra_mode); bit-identical either way (tests/test_gpu_amaze_rows.py).
+int g_amaze_rows_extra_mode = -1;  // -1: the environment decides, 0 / 1: forced
+int amaze_rows_extra(int w, int h)
+{
+    static const bool on = [] { const char *e = getenv("MLVFS_AMD_AMAZE_ROWS_EXTRA"); return e && atoi(e) != 0; }();
+    int nfx, nfy;
+    amaze_rows_extent(w, h, &nfx, &nfy);
+    if (!nfx || g_amaze_rows_extra_mode == 0 || (g_amaze_rows_extra_mode < 0 && !on)) return 0;
+    const int step = T - 32;
+    const int tiles_x = (w + 16 + step - 1) / step, tiles_y = (h + 16 + step - 1) / step;
+    const int cc1_last = w + 16 - (-16 + (tiles_x - 1) * step), rr1_last = h + 16 - (-16 + (tiles_y - 1) * step);
+    if (cc1_last != 32 || nfx != tiles_x - 2) return 0;                          // (cc1_last == 32 <=> w % 128 == 0)
+    const int incomplete_y = rr1_last >= T ? 0 : (rr1_last < 32 ? 2 : 1), rows_a = tiles_y - incomplete_y;
+    if (rr1_last > 32 && rr1_last < 48) return 0;                                // (amaze_launch's `garbage` case walks the last row in one block)
+    const int n = incomplete_y ? rows_a - 1 : rows_a;                            // the last row's chain feeds the bottom row's launch
+    return n < 0 ? 0 : (n < nfy ? n : nfy);
+}
+
 int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, hipStream_t s, int nframes,
                       size_t plane_stride, const int *h_of, int h_stride, float *d_dbg, int *d_ctr)
 {
@@ -978,7 +1015,7 @@ int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_g
         }
     }
     static const unsigned skip = [] { const char *e = getenv("MLVFS_AMD_AMAZE_ROWS_SKIP"); return e ? (unsigned)strtoul(e, nullptr, 16) : 0u; }();
-    const int ntiles = nfx * nfy;
+    const int nrect = nfx * nfy, ntiles = nrect + (d_dbg ? 0 : amaze_rows_extra(w, h));       // (the debug dump is laid out for the block only)
     // one workgroup per CU (the rings fill its LDS); the frames of a batch share the CUs
     int per_frame = (dev < 64 && cus[dev] ? cus[dev] : 256) / (nframes > 0 ? nframes : 1);
     static const int cap = [] { const char *e = getenv("MLVFS_AMD_AMAZE_ROWS_WGS"); return e ? atoi(e) : 0; }();    // tests: few workgroups, many tiles each
@@ -986,10 +1023,10 @@ int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_g
     per_frame = per_frame < 1 ? 1 : (per_frame > ntiles ? ntiles : per_frame);
     if (d_dbg)
         hipLaunchKernelGGL(k_amaze_rows<true>, dim3(per_frame, nframes), dim3(1024), 0, s, d_raw, w, h, d_red, d_green, d_blue, nfx,
-                           ntiles, plane_stride, h_of, h_stride, d_dbg, d_prof, skip, d_ctr);
+                           ntiles, nrect, plane_stride, h_of, h_stride, d_dbg, d_prof, skip, d_ctr);
     else
         hipLaunchKernelGGL(k_amaze_rows<false>, dim3(per_frame, nframes), dim3(1024), 0, s, d_raw, w, h, d_red, d_green, d_blue, nfx,
-                           ntiles, plane_stride, h_of, h_stride, d_dbg, d_prof, skip, d_ctr);
+                           ntiles, nrect, plane_stride, h_of, h_stride, d_dbg, d_prof, skip, d_ctr);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }

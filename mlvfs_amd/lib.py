@@ -42,7 +42,7 @@ DEVICE_SYMBOLS = [
     "mlvfs_amd_stripes_solve", "mlvfs_amd_stripes_compute_dev", "mlvfs_amd_stripes_apply_dev",
     "mlvfs_amd_rand_stream", "mlvfs_amd_rand_stream_dev", "mlvfs_amd_process_frames_dev", "mlvfs_amd_process_frames_host",
     "mlvfs_amd_host_alloc", "mlvfs_amd_host_free", "mlvfs_amd_host_owns", "mlvfs_amd_host_size", "mlvfs_amd_host_trim", "mlvfs_amd_hdr_preview_dev",
-    "mlvfs_amd_cr2hdr20_dev", "mlvfs_amd_cr2hdr20_batch_dev", "mlvfs_amd_dualiso_reset", "mlvfs_amd_dualiso_trim", "mlvfs_amd_dualiso_last_scalars", "mlvfs_amd_amaze_demosaic_dev", "mlvfs_amd_amaze_debug", "mlvfs_amd_amaze_rows_extent",
+    "mlvfs_amd_cr2hdr20_dev", "mlvfs_amd_cr2hdr20_batch_dev", "mlvfs_amd_dualiso_reset", "mlvfs_amd_dualiso_trim", "mlvfs_amd_dualiso_last_scalars", "mlvfs_amd_amaze_demosaic_dev", "mlvfs_amd_amaze_debug", "mlvfs_amd_amaze_rows_extent", "mlvfs_amd_amaze_rows_extra_mode",
     "mlvfs_amd_timer_begin", "mlvfs_amd_timer_end", "mlvfs_amd_selftest_host", "mlvfs_amd_selftest_tables", "mlvfs_amd_frame_begin", "mlvfs_amd_frame_end", "mlvfs_amd_frame_sync", "mlvfs_amd_dropin_stats", "mlvfs_amd_test_fail_next", "mlvfs_amd_dropin_transfers", "mlvfs_amd_dropin_profile",
     "mlvfs_amd_mlv_open", "mlvfs_amd_mlv_close", "mlvfs_amd_mlv_frame_count", "mlvfs_amd_mlv_chunk_count",
     "mlvfs_amd_mlv_xref", "mlvfs_amd_mlv_frame_headers", "mlvfs_amd_mlv_read_frames", "mlvfs_amd_mlv_process", "mlvfs_amd_mlv_process_dualiso",
@@ -163,6 +163,7 @@ def load() -> C.CDLL:
     sig("mlvfs_amd_dualiso_last_scalars", None, [vp])
     sig("mlvfs_amd_amaze_demosaic_dev", i, [vp, i, i, vp, vp, vp, vp])
     sig("mlvfs_amd_amaze_rows_extent", None, [i, i, C.POINTER(C.c_int), C.POINTER(C.c_int)])
+    sig("mlvfs_amd_amaze_rows_extra_mode", i, [i, i, i, C.POINTER(C.c_int)])
     sig("mlvfs_amd_amaze_debug", i, [vp, i, i, vp, vp, vp, i, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)])
     sig("mlvfs_amd_timer_begin", i, [i])
     sig("mlvfs_amd_timer_end", i, [vp, i])

@@ -46,3 +46,15 @@ def test_complete_tiles_are_a_prefix_of_the_grid():
     for w, h in [(688, 560), (1332, 789), (3584, 1320)]:
         fx, fy = split(L, w, h)
         assert -16 + (fx - 1) * 128 + 160 <= w and -16 + (fy - 1) * 128 + 160 <= h
+
+
+def test_heads_of_outputless_chains_only_where_the_width_is_a_multiple_of_128():
+    """mlvfs_amd_amaze_rows_extra_mode's count: the tiles of column nfx in rows 0 .. n - 1 that k_amaze_rows.hip may take as well --
+    only where the row's one incomplete tile is all apron (cc1 == 32), never the row whose chain feeds the incomplete bottom row."""
+    L = lib.load()
+    for w, h, want in [(3584, 1320, 9), (3584, 660, 4), (1920, 1080, 7), (3584, 1264, 8), (1332, 789, 0), (688, 560, 0), (384, 304, 1), (512, 400, 2)]:
+        n = C.c_int(-1)
+        before = L.mlvfs_amd_amaze_rows_extra_mode(-1, w, h, C.byref(n))
+        assert before == -1 and n.value == want, (w, h, n.value)
+        nfx, nfy = split(L, w, h)
+        assert n.value <= nfy

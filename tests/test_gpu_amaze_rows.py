@@ -106,3 +106,27 @@ def test_a_workgroup_streams_through_many_tiles(gpu, oracle, monkeypatch):
     assert nfx * nfy > 256
     for g, x in zip(got, want):
         assert np.array_equal(g.view(np.uint32), x.view(np.uint32))
+
+
+@pytest.mark.parametrize("w,h", [(384, 304), (512, 400), (640, 688), (1920, 540), (3584, 660)])
+def test_heads_of_outputless_chains_through_the_row_kernel(gpu, oracle, w, h):
+    """Widths that are a multiple of 128: the one incomplete tile of a tile row is 32 columns of apron without an output pixel, and
+    the tile it is chained behind may go through k_amaze_rows.hip (right apron mirrored in its loader) -- VERDICT r3 next #2, built
+    for the case where no stale plane is involved; off by default because the batch is no faster with it (k_amaze_rows.hip)."""
+    import torch
+    from mlvfs_amd import lib
+    raw = _textured(w, h, w + 3 * h)
+    want = oracle.amaze_demosaic(raw)
+    n = C.c_int(0)
+    before = gpu.mlvfs_amd_amaze_rows_extra_mode(1, w, h, C.byref(n))
+    try:
+        assert n.value > 0, "the geometry has such tiles"
+        d_raw = torch.from_numpy(raw).cuda()
+        out = [torch.full((h, w), float("nan"), dtype=torch.float32, device="cuda") for _ in range(3)]
+        for rep in range(2):                                   # (twice: the second run finds the blocks the first one left)
+            assert gpu.mlvfs_amd_amaze_demosaic_dev(C.c_void_p(d_raw.data_ptr()), w, h, *[C.c_void_p(t.data_ptr()) for t in out], None) == 0, lib.last_error()
+            torch.cuda.synchronize()
+            for g, x in zip(out, want):
+                assert np.array_equal(g.cpu().numpy().view(np.uint32), x.view(np.uint32))
+    finally:
+        gpu.mlvfs_amd_amaze_rows_extra_mode(before, w, h, None)
