@@ -229,11 +229,22 @@ int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_t *sizes, i
 /* The reference decoder's own three calls (lj92.h:40-58), what get_image_data makes of an LJ92 frame (main.c:626-647: lj92_open,
  * lj92_decode into a temporary buffer, then its own untiling loop): with them `lj92.o` can leave MLVFS's link too and the decode
  * runs on the GPU.  Values in the decoder's own order, width x height of the JPEG.  Only what MLVFS passes is supported:
- * skiplen 0, linearize NULL (anything else: LJ92_ERROR_CORRUPT, -1).  lj92_encode is not provided (MLVFS never calls it).   */
+ * skiplen 0, linearize NULL (anything else: LJ92_ERROR_CORRUPT, -1).                                                 */
 typedef struct _ljp *lj92;
 int lj92_open(lj92 *lj, uint8_t *data, int datalen, int *width, int *height, int *bitdepth);
 void lj92_close(lj92 lj);
 int lj92_decode(lj92 lj, uint16_t *target, int tlen, int skiplen, uint16_t *linearize, int linlen);
+/* The reference's encoder (lj92.h:65-68, lj92.c:711-1144; nothing in MLVFS calls it -- it completes the export table of lj92.o):
+ * a width x height tile read from `image` in runs of readLength values skipLength apart, optionally through a delinearisation
+ * table, written as one-component lossless JPEG with predictor 6 -- byte for byte the reference's stream, its peculiar Huffman
+ * table included (csrc/lj92enc.cpp).  *encoded is malloc'd, the caller frees it.  Host memory in and out; histogram, bit packing
+ * and byte stuffing run on the GPU (csrc/k_lj92enc.hip).  Returns 0, LJ92_ERROR_NO_MEMORY (-2), or LJ92_ERROR_CORRUPT (-1) where
+ * the reference would leave its own arrays (17-bit differences, all 17 classes in use, values beyond the table) or HIP fails. */
+int lj92_encode(uint16_t *image, int width, int height, int bitdepth, int readLength, int skipLength,
+                uint16_t *delinearize, int delinearizeLength, uint8_t **encoded, int *encodedLength);
+/* host-only test hook: the encoder's Huffman table for a histogram of the 17 classes; out[68] = bits[1..16], number of DHT
+ * values, the 17 values, then length and code per class.  0, or -1 (error string set) where lj92_encode would refuse.          */
+int mlvfs_amd_lj92_encode_table(const uint32_t hist[17], int npix, int *out);
 
 /* -- LZMA payloads ----------------------------------------- */
 /* One VIDF payload of an LZMA-compressed clip (MLV_VIDEO_CLASS_FLAG_LZMA; main.c:598-616): [u32 size of the packed frame][5 LZMA

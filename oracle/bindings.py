@@ -90,6 +90,8 @@ class Oracle:
         L.orc_lj92_decode.argtypes = [u8p, C.c_int, u16p]
         L.orc_lj92_info.argtypes = [u8p, C.c_int, C.c_void_p]
         L.orc_lj92_untile.argtypes = [u16p, u16p, C.c_int, C.c_int]
+        L.orc_lj92_encode.argtypes = [u16p] + [C.c_int] * 5 + [C.c_void_p, C.c_int, u8p, C.c_int]
+        L.orc_lj92_encode_table.argtypes = [i32p, C.c_int, i32p]
         f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
         L.orc_amaze_demosaic.restype = C.c_int
         L.orc_amaze_demosaic.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p]
@@ -128,6 +130,23 @@ class Oracle:
         buf = np.frombuffer(data, np.uint8).copy()
         out = np.zeros((info["height"], info["width"]), np.uint16)
         return self.L.orc_lj92_decode(buf, buf.size, out), out
+
+    def lj92_encode(self, flat: np.ndarray, w: int, h: int, bits: int = 14, read_len: int = 0, skip_len: int = 0, delin=None):
+        """The reference's encoder restated (lj92.c:1104-1144): w x h values read from `flat` in runs of read_len, skip_len apart.
+        -> bytes, or None where the reference leaves its arrays."""
+        flat = np.ascontiguousarray(flat, np.uint16).reshape(-1)
+        out = np.zeros(w * h * 5 + 256, np.uint8)
+        d = None if delin is None else np.ascontiguousarray(delin, np.uint16)
+        n = self.L.orc_lj92_encode(flat, w, h, bits, read_len or w * h, skip_len, None if d is None else d.ctypes.data,
+                                   0 if d is None else d.size, out, out.size)
+        return out[:n].tobytes() if n > 0 else None
+
+    def lj92_encode_table(self, hist, npix: int):
+        """-> dict(bits[1..16], nvalues, values, len, code) or None."""
+        t = np.zeros(17 + 17 + 1 + 17 + 17, np.int32)
+        if self.L.orc_lj92_encode_table(np.ascontiguousarray(hist, np.int32), npix, t) != 0:
+            return None
+        return dict(bits=t[1:17].tolist(), nvalues=int(t[34]), values=t[17:34].tolist(), len=t[35:52].tolist(), code=t[52:69].tolist())
 
     def lj92_untile(self, img: np.ndarray, xres: int, yres: int) -> np.ndarray:
         src = np.ascontiguousarray(img, np.uint16).reshape(-1)
@@ -356,6 +375,7 @@ class Reference:
         L.get_raw2evf.argtypes = [C.c_int]
         L.ref_lj92_decode.argtypes = [u8p, C.c_int, u16p, C.c_int, i32p]
         L.ref_lj92_encode.argtypes = [u16p, C.c_int, C.c_int, C.c_int, u8p, C.c_int]
+        L.ref_lj92_encode_tile.argtypes = [u16p] + [C.c_int] * 5 + [C.c_void_p, C.c_int, u8p, C.c_int]
         L.ref_header_data.restype = C.c_size_t
         L.ref_header_data.argtypes = [u8p, u8p, C.c_int64, C.c_size_t, C.c_double, C.c_char_p]
         self._libc = C.CDLL(None)
@@ -365,6 +385,15 @@ class Reference:
         h, w = img.shape
         out = np.zeros(w * h * 3 + 200, np.uint8)
         n = self.L.ref_lj92_encode(img, w, h, bits, out, out.size)
+        assert n > 0, n
+        return out[:n].tobytes()
+
+    def lj92_encode_tile(self, flat: np.ndarray, w: int, h: int, bits: int = 14, read_len: int = 0, skip_len: int = 0, delin=None):
+        flat = np.ascontiguousarray(flat, np.uint16).reshape(-1)
+        out = np.zeros(w * h * 3 + 200, np.uint8)
+        d = None if delin is None else np.ascontiguousarray(delin, np.uint16)
+        n = self.L.ref_lj92_encode_tile(flat, w, h, bits, read_len or w * h, skip_len, None if d is None else d.ctypes.data,
+                                        0 if d is None else d.size, out, out.size)
         assert n > 0, n
         return out[:n].tobytes()
 

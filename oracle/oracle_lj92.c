@@ -183,3 +183,115 @@ void orc_lj92_untile(const uint16_t *src, uint16_t *dst, int xres, int yres)
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * orc_lj92_encode -- the reference's ENCODER (mlvfs/lj92.c:711-1144: frequencyScan 733-786, createEncodeTable 788-937,
+ * writeHeader 939-977, writeBody 986-1099, writePost 979-984, lj92_encode 1104-1144), restated.  The reference keeps two row
+ * caches and walks the tile once per pass; here the tile is gathered first and every prediction reads its three neighbours
+ * directly.  Pinned against the reference's own lj92_encode byte for byte (tests/test_lj92_encode.py).  Cases in which the
+ * reference indexes behind its arrays (a 17-bit difference, 17 classes in use, a code longer than 16 bits) return
+ * ORC_LJ92_CORRUPT and are not compared.
+ */
+typedef struct { int bits[17], values[17], nvalues, len[17], code[17]; } orc_lj92_enctable;
+
+static int enc_class(int d) { int s = 0; unsigned a = (unsigned)(d < 0 ? -d : d); while (a) { s++; a >>= 1; } return s; }
+
+int orc_lj92_encode_table(const int hist[17], int npix, orc_lj92_enctable *t)
+{
+    /* 18 leaves (the 17 classes and a reserved leaf of frequency 1.0); a live group = bitmask of its leaves, kept at the index of
+     * the leaf it grew from.  Two rarest: the LAST index among the smallest, then the FIRST index among the smallest of the rest */
+    float f[18];
+    unsigned members[18];
+    int depth[18] = { 0 }, used = 0;
+    for (int i = 0; i < 17; i++) { f[i] = (float)hist[i] / (float)npix; members[i] = 1u << i; used += hist[i] != 0; }
+    f[17] = 1.0f; members[17] = 1u << 17;
+    if (used == 0 || used == 17) return ORC_LJ92_CORRUPT;
+    for (;;) {
+        int lo = -1, lo2 = -1;
+        for (int i = 0; i < 18; i++) if (f[i] > 0.0f && (lo < 0 || f[i] <= f[lo])) lo = i;
+        for (int i = 17; i >= 0; i--) if (i != lo && f[i] > 0.0f && (lo2 < 0 || f[i] <= f[lo2])) lo2 = i;
+        if (lo2 < 0) break;
+        f[lo] += f[lo2]; f[lo2] = 0.0f;
+        members[lo] |= members[lo2];
+        for (int i = 0; i < 18; i++) if (members[lo] >> i & 1) depth[i]++;
+    }
+    memset(t, 0, sizeof *t);
+    for (int i = 0; i < 18; i++) { if (depth[i] > 16) return ORC_LJ92_CORRUPT; if (depth[i]) { t->bits[depth[i]]++; t->nvalues++; } }
+    int k = 0;
+    for (int l = 1; l <= 16; l++) for (int s = 0; s < 17; s++) if (depth[s] == l) t->values[k++] = s;
+    /* values[k..nvalues-1] stay 0: the reserved leaf has a code but no value */
+    int pos_of[17] = { 0 }, pos = 0, code = 0, plen[18], pcode[18];
+    for (int l = 1; l <= 16; l++, code <<= 1) for (int j = 0; j < t->bits[l]; j++, pos++) { plen[pos] = l; pcode[pos] = code++; }
+    for (int i = 0; i < pos && i < 17; i++) pos_of[t->values[i]] = i;
+    for (int s = 0; s < 17; s++) { t->len[s] = plen[pos_of[s]]; t->code[s] = pcode[pos_of[s]]; }
+    return ORC_LJ92_OK;
+}
+
+/* returns the stream's length (> 0), ORC_LJ92_CORRUPT, or -100 when out is too small */
+int orc_lj92_encode(const uint16_t *image, int width, int height, int bitdepth, int read_len, int skip_len,
+                    const uint16_t *delin, int delin_len, uint8_t *out, int cap)
+{
+    const long long n = (long long)width * height;
+    if (n <= 0 || n >= (1 << 27)) return ORC_LJ92_CORRUPT;
+    int32_t *v = malloc(sizeof(int32_t) * n);
+    int32_t *d = malloc(sizeof(int32_t) * n);
+    const uint16_t *p = image;
+    int run = read_len, bad = 0;
+    for (long long i = 0; i < n; i++) {
+        int x = *p++;
+        if (delin) { if (x >= delin_len) { bad = 1; break; } x = delin[x]; }
+        v[i] = x;
+        if (--run == 0) { p += skip_len; run = read_len; }
+    }
+    int hist[18] = { 0 };
+    for (long long i = 0; i < n && !bad; i++) {
+        const int r = (int)(i / width), c = (int)(i % width);
+        int px;
+        if (r == 0) px = c ? v[i - 1] : 1 << (bitdepth - 1);
+        else if (c == 0) px = v[i - width];
+        else px = v[i - width] + ((v[i - 1] - v[i - width - 1]) >> 1);
+        d[i] = v[i] - px;
+        const int s = enc_class(d[i]);
+        hist[s > 17 ? 17 : s]++;
+    }
+    orc_lj92_enctable t;
+    int w = -1;
+    if (!bad && !hist[17] && orc_lj92_encode_table(hist, (int)n, &t) == ORC_LJ92_OK) {
+        uint8_t head[64];
+        int hl = 0;
+        const int sof[] = { 0xFF, 0xD8, 0xFF, 0xC3, 0, 11, bitdepth, height >> 8, height, width >> 8, width, 1, 0, 0x11, 0, 0xFF, 0xC4, 0, 19 + t.nvalues, 0 };
+        for (unsigned i = 0; i < sizeof sof / sizeof *sof; i++) head[hl++] = (uint8_t)sof[i];
+        for (int l = 1; l <= 16; l++) head[hl++] = (uint8_t)t.bits[l];
+        for (int i = 0; i < t.nvalues; i++) head[hl++] = (uint8_t)t.values[i];
+        const int sos[] = { 0xFF, 0xDA, 0, 8, 1, 0, 0, 6, 0, 0 };
+        for (unsigned i = 0; i < sizeof sos / sizeof *sos; i++) head[hl++] = (uint8_t)sos[i];
+        w = 0;
+        #define ORC_PUT(b) do { if (w < cap) out[w] = (uint8_t)(b); w++; } while (0)
+        for (int i = 0; i < hl; i++) ORC_PUT(head[i]);
+        uint64_t acc = 0;                       /* pending bits, right-aligned */
+        int pending = 0;
+        for (long long i = 0; i < n; i++) {
+            const int s = enc_class(d[i]);
+            const unsigned extra = (unsigned)(d[i] < 0 ? d[i] + (1 << s) - 1 : d[i]) & ((1u << s) - 1u);
+            acc = (acc << t.len[s]) | (unsigned)t.code[s]; pending += t.len[s];
+            acc = (acc << s) | extra; pending += s;
+            while (pending >= 8) {
+                const unsigned byte = (unsigned)(acc >> (pending - 8)) & 0xFF;
+                ORC_PUT(byte);
+                if (byte == 0xFF) ORC_PUT(0);
+                pending -= 8;
+            }
+        }
+        if (pending) {
+            const unsigned byte = (unsigned)(acc << (8 - pending)) & 0xFF;
+            ORC_PUT(byte);
+            if (byte == 0xFF) ORC_PUT(0);
+        }
+        ORC_PUT(0xFF); ORC_PUT(0xD9);
+        #undef ORC_PUT
+    }
+    free(v);
+    free(d);
+    if (w < 0) return ORC_LJ92_CORRUPT;
+    return w <= cap ? w : -100;
+}

@@ -231,6 +231,17 @@ int ref_lj92_encode(uint16_t *img, int w, int h, int bits, uint8_t *out, int cap
     free(enc);
     return n <= cap ? n : -100;
 }
+/* the encoder with all of its arguments (tile runs, delinearisation table): lj92.h:65-68 */
+int ref_lj92_encode_tile(uint16_t *img, int w, int h, int bits, int read_len, int skip_len, uint16_t *delin, int delin_len, uint8_t *out, int cap)
+{
+    uint8_t *enc = NULL;
+    int n = 0;
+    int ret = lj92_encode(img, w, h, bits, read_len, skip_len, delin, delin_len, &enc, &n);
+    if (ret != LJ92_ERROR_NONE) return ret;
+    if (n <= cap) memcpy(out, enc, n);
+    free(enc);
+    return n <= cap ? n : -100;
+}
 
 /* The caller's chunk handling as the sliced mlv_get_frame_headers (main.c:429-558) sees it: resource_manager.c:285-317 without
  * KEEP_FILES_OPEN (the default, resource_manager.h:25) forwards to index.c's load_chunks / close_chunks.  (resource_manager.c

@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "mlvfs_amd", "libmlvfs_amd_hostcheck.so")
 # the CPU tests that exercise host-only code of the library (no kernel launcher is reached: those are aborting stubs in this build)
-SUITES = ["tests/test_lzma_gif.py", "tests/test_header.py", "tests/test_mlv_reader.py", "tests/test_lj92.py", "tests/test_cabi.py",
+SUITES = ["tests/test_lzma_gif.py", "tests/test_header.py", "tests/test_mlv_reader.py", "tests/test_lj92.py", "tests/test_lj92_encode.py", "tests/test_cabi.py",
           "tests/test_golden.py", "tests/test_failure_policy.py"]
 
 
