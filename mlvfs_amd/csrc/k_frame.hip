@@ -95,7 +95,7 @@ struct FrameArgs {
     int nframes;
     int tiles_x, tiles_y;
     const uint16_t *t16;
-    const uint16_t *e2r;     // (uint16)(ev2raw[ev] + black), ev in [0, 14 * 32768): the output pixel by EV, one buffer look-up
+    const uint2 *e2d;        // the output pixel by EV: (uint16)(ev2raw[ev] + black), ev in [0, 14 * 32768), 32 entries per 8-byte record (E2D_RECORDS)
     // pixel map: per frame `n_rec` cell records {cell, R | G1 << 16, G2 | B << 16, -} (k_pixfix_cells), listed tile by tile (CSR)
     const int4 *cells;
     int n_rec;
@@ -118,9 +118,8 @@ struct FrameArgs {
 // the struct forms, and unlike inline asm the compiler counts these loads in its s_waitcnt bookkeeping.
 typedef int mlv_i32x4 __attribute__((ext_vector_type(4)));
 __device__ unsigned short mlv_sbl_u16(mlv_i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.i16");
-// the same look-up as a dword load (entry `vindex` in the lower half, its successor above it): no zero-extension instruction for a
-// value that a byte permute consumes; the table carries one entry of padding behind its last
-__device__ int mlv_sbl_u32(mlv_i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.i32");
+typedef unsigned mlv_tab_u32x2 __attribute__((ext_vector_type(2)));
+__device__ mlv_tab_u32x2 mlv_sbl_x2(mlv_i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v2i32");
 __device__ __forceinline__ mlv_i32x4 table_rsrc(const void *p, unsigned stride, unsigned entries)
 {
     const unsigned long long a = (unsigned long long)p;
@@ -131,7 +130,18 @@ __device__ __forceinline__ mlv_i32x4 table_rsrc(const void *p, unsigned stride, 
     r.w = 0x00020000;
     return r;
 }
+// The output table E2R[ev] = (uint16)(ev2raw[ev] + black), ev in [0, 14 * 32768), in 8 bytes per 32 entries:
+//     record b = { E2R[32 b], bit j: E2R[32 b + j + 1] != E2R[32 b + j] }      E2R[ev] = base + popcount(bits & ((1 << (ev & 31)) - 1))
+// (consecutive entries differ by at most one: d ev2raw / d ev < 0.35; checked when a table is built) -- v_bfe_u32 with the EV itself as
+// the field width, v_bcnt_u32_b32 with the base as its addend: two operations more than a plain 16-bit table, which is what rounds
+// 2-4 used (896 KiB per black level, a 128-byte line fetched per 2-byte entry: footage whose tiles span several EV missed the L1 on
+// most look-ups).  112 KiB: same-box A/B (profiles/r04/ab_dense_kinds.log), us per frame plain -> dense: cs2x2 6.80 -> 6.18 on the
+// benchmark's frames, 9.4 -> 7.0 in low light, 10.8 -> 8.75 on colour patches; cs5x5 8.35 -> 8.22 / 10.8 -> 10.55 / 12.4 -> 11.8.
 constexpr int E2R_ENTRIES = 14 * MLV_EV_RES;
+constexpr int E2D_RECORDS = E2R_ENTRIES / 32;
+#ifndef KF_SRC_AUX
+#define KF_SRC_AUX 0          // cache policy of the loader's stream loads (experiments, same encoding)
+#endif
 #ifndef KF_E2R_AUX
 #define KF_E2R_AUX 0          // cache policy of the output look-ups (experiments: 2 = nt, 16 = sc1, 17 = sc0 sc1)
 #endif
@@ -456,7 +466,7 @@ __device__ __forceinline__ void issue_item(uint32_t (&d0)[4], uint32_t (&d1)[4],
         const int yy = TOP ? clampi(y + rr, 0, h - 1) : min(y + rr, h - 1);     // (only the rows above a tile's own can lie above the frame)
         const uint32_t row = __umul24((uint32_t)yy, pitch);                            // rows and row pitch < 2^24 (launcher)
         const uint32_t oa = (row + ga) & L.amask, ob = ((row + gb) & L.amask) + L.boff;
-        const mlv_u32x2 a = mlv_rbl_x2(rs, (int)oa, 0, 0), b = mlv_rbl_x2(rs, (int)ob, 0, 0);
+        const mlv_u32x2 a = mlv_rbl_x2(rs, (int)oa, 0, KF_SRC_AUX), b = mlv_rbl_x2(rs, (int)ob, 0, KF_SRC_AUX);
         uint32_t (&d)[4] = rr ? d1 : d0;
         d[0] = a.x; d[1] = a.y; d[2] = b.x; d[3] = b.y;
     }
@@ -1082,7 +1092,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     constexpr int BPP = bpp_of(PACKED, VEC);             // bits per pixel of the input
     constexpr int NEW0 = METHOD == 0 ? HC : 2 * HC;      // first plane row a tile loads itself (without chroma smoothing: no halo at all)
 
-    const mlv_i32x4 rs_e2r = table_rsrc(a.e2r, 2, E2R_ENTRIES);
+    const mlv_i32x4 rs_e2d = table_rsrc(a.e2d, 8, E2D_RECORDS);
     uint32_t r0[4], r1[4];                               // prefetch registers of this thread's item
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1297,17 +1307,19 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 // (the green EVs first: the look-ups' indices wait for them; the raw pixels are read once the look-ups are under way)
                 const int4 g4 = *(const int4 *)&sm.ge[jj][STRIP * kk];
                 const int gev[STRIP] = { g4.x, g4.y, g4.z, g4.w };
-                // the output pixel by EV (896 KiB table in L2): all 8 look-ups issued before the first use
-                int er[STRIP], eb[STRIP], ur[STRIP], ub[STRIP];
+                // the output pixel by EV (112 KiB table, one 8-byte record per 32 EV steps): all 8 look-ups issued before the first use
+                int er[STRIP], eb[STRIP], ur[STRIP], ub[STRIP], cr[STRIP], cb[STRIP];
+                mlv_tab_u32x2 dr2[STRIP], db2[STRIP];
 #pragma unroll
                 for (int c = 0; c < STRIP; c++) {
                     er[c] = wadd(gev[c], mr[c]);
                     eb[c] = wadd(gev[c], mb[c]);
+                    cr[c] = min(max(er[c], 0), MLV_EV_MAX); cb[c] = min(max(eb[c], 0), MLV_EV_MAX);
 #ifdef KF_EXP_NOLOOKUP
-                    ur[c] = min(max(er[c], 0), MLV_EV_MAX); ub[c] = min(max(eb[c], 0), MLV_EV_MAX);
+                    dr2[c].x = cr[c]; dr2[c].y = 0; db2[c].x = cb[c]; db2[c].y = 0;
 #else
-                    ur[c] = mlv_sbl_u32(rs_e2r, min(max(er[c], 0), MLV_EV_MAX), 0, 0, KF_E2R_AUX);
-                    ub[c] = mlv_sbl_u32(rs_e2r, min(max(eb[c], 0), MLV_EV_MAX), 0, 0, KF_E2R_AUX);
+                    dr2[c] = mlv_sbl_x2(rs_e2d, cr[c] >> 5, 0, 0, KF_E2R_AUX);
+                    db2[c] = mlv_sbl_x2(rs_e2d, cb[c] >> 5, 0, 0, KF_E2R_AUX);
 #endif
                 }
                 read_raw();
@@ -1323,7 +1335,12 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 }
                 // (the fence keeps the eight look-ups together and comes after the decisions in program order: the compiler
                 // schedules them under the look-ups' latency; with the masks as operands of the fence it also copied them)
-                asm volatile("" :: "v"(ur[0]), "v"(ur[1]), "v"(ur[2]), "v"(ur[3]), "v"(ub[0]), "v"(ub[1]), "v"(ub[2]), "v"(ub[3]));
+                asm volatile("" :: "v"(dr2[0]), "v"(dr2[1]), "v"(dr2[2]), "v"(dr2[3]), "v"(db2[0]), "v"(db2[1]), "v"(db2[2]), "v"(db2[3]));
+#pragma unroll
+                for (int c = 0; c < STRIP; c++) {             // v_bfe_u32 (the width operand's low five bits count), v_bcnt_u32_b32
+                    ur[c] = (int)(__builtin_popcount(__builtin_amdgcn_ubfe(dr2[c].y, 0u, (unsigned)cr[c] & 31u)) + dr2[c].x);
+                    ub[c] = (int)(__builtin_popcount(__builtin_amdgcn_ubfe(db2[c].y, 0u, (unsigned)cb[c] & 31u)) + db2[c].x);
+                }
 #pragma unroll
                 for (int c = 0; c < STRIP; c++) {
                     const bool ok = okc[c];
@@ -1345,8 +1362,15 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 if (vec) {
                     if (x < a.w) {
                         const uint32_t o = (uint32_t)y * (uint32_t)a.w + (uint32_t)x;           // < 2^28 pixels per frame
+#ifdef KF_STORE_NT
+                        typedef unsigned kf_u4 __attribute__((ext_vector_type(4)));
+                        const kf_u4 vt = { top[0], top[1], top[2], top[3] }, vb = { bot[0], bot[1], bot[2], bot[3] };
+                        __builtin_nontemporal_store(vt, (kf_u4 *)(out + o));
+                        if (y + 1 < a.h) __builtin_nontemporal_store(vb, (kf_u4 *)(out + o + (uint32_t)a.w));
+#else
                         *(uint4 *)(out + o) = make_uint4(top[0], top[1], top[2], top[3]);
                         if (y + 1 < a.h) *(uint4 *)(out + o + (uint32_t)a.w) = make_uint4(bot[0], bot[1], bot[2], bot[3]);
+#endif
                     }
                 } else {
 #pragma unroll 1
@@ -1538,16 +1562,28 @@ void release_stream_state(int device, hipStream_t stream)
     g_tickets.erase(it);
 }
 // ---------------------------------------------------------------- per-black output table in HBM
-// E2R[ev] = (uint16)(ev2raw[ev] + black) for ev in [0, 14 * 32768): exactly what chroma_smooth.c:67-68 stores for a clamped EV.
-// One 16-bit look-up by index replaces mask, address, quotient, two shifts, add and mask per output pixel (cs5x5 -2.5 %, A/B in
-// profiles/r02/ab_table_gathers_kbench.log: "e1").  Built on the device from the exact 16-bit re-encoding U16 (common.h) the
-// first time a black level is seen on a device; 896 KiB per black level, served from L2.
+// E2R[ev] = (uint16)(ev2raw[ev] + black) for ev in [0, 14 * 32768): exactly what chroma_smooth.c:67-68 stores for a clamped EV, in
+// the dense form described at E2D_RECORDS.  One look-up replaces mask, address, quotient, two shifts, add and mask per output pixel
+// (cs5x5 -2.5 %, A/B in profiles/r02/ab_table_gathers_kbench.log: "e1").  Built on the device from the exact 16-bit re-encoding U16
+// (common.h) the first time a black level is seen on a device; *bad counts entries that rise by more than one (never).
 // (The same trick for the loader -- raw2ev by pixel value from a 256 KiB table, no conversion arithmetic at all, results
 // identical -- makes the kernel wait for the texture addresser instead: cs5x5 +11 %, cs2x2 +27 %, "e2" in the same log.)
-__global__ __launch_bounds__(256) void k_build_e2r(const uint16_t *u16, int black, uint16_t *e2r)
+__global__ __launch_bounds__(256) void k_build_e2d(const uint16_t *__restrict__ u16, int black, uint2 *__restrict__ e2d, int *__restrict__ bad)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < E2R_ENTRIES) e2r[i] = (uint16_t)((((int)u16[i & 32767]) >> (13 - (i >> 15))) + black);
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= E2D_RECORDS) return;
+    auto entry = [&](int i) { return (uint16_t)((((int)u16[i & 32767]) >> (13 - (i >> 15))) + black); };
+    unsigned bits = 0;
+    uint16_t prev = entry(32 * b);
+    const uint16_t base = prev;
+    for (int j = 0; j < 31; j++) {
+        const uint16_t next = entry(32 * b + j + 1);
+        const unsigned d = (uint16_t)(next - prev);
+        if (d > 1) atomicAdd(bad, 1);
+        bits |= (d & 1u) << j;
+        prev = next;
+    }
+    e2d[b] = make_uint2(base, bits);
 }
 // The black level comes from file headers (and dual ISO multiplies it by 4): a long-running host that serves many clips would
 // otherwise collect one table per level it has ever seen.  At most E2R_CACHE tables per device stay; the least recently used one
@@ -1556,28 +1592,32 @@ __global__ __launch_bounds__(256) void k_build_e2r(const uint16_t *u16, int blac
 // different clips do not queue behind each other's synchronisation.
 namespace {
 constexpr size_t E2R_CACHE = 8;
-struct E2rEntry { uint16_t *table; unsigned long long used; };
+struct E2rEntry { uint2 *table; unsigned long long used; };
 std::mutex g_tables_mu;
 std::map<std::pair<int, int>, E2rEntry> g_e2r;               // (device, black)
-std::map<int, uint16_t *> g_e2r_parked;                       // per device: the table evicted last
+std::map<int, uint2 *> g_e2r_parked;                       // per device: the table evicted last
 unsigned long long g_e2r_clock = 0;
 }
-static int e2r_table(const Device *dev, int black, const uint16_t **out, hipStream_t stream)
+static int e2r_table(const Device *dev, int black, const uint2 **out, hipStream_t stream)
 {
     {
         std::lock_guard<std::mutex> lk(g_tables_mu);
         auto it = g_e2r.find({ dev->id, black });
         if (it != g_e2r.end()) { it->second.used = ++g_e2r_clock; *out = it->second.table; return MLVFS_AMD_OK; }
     }
-    uint16_t *t = nullptr;
-    MLV_HIP(hipMalloc(&t, sizeof(uint16_t) * (E2R_ENTRIES + 2)));      // (+ padding: the fused kernel reads entries as dwords)
-    hipLaunchKernelGGL(k_build_e2r, dim3((E2R_ENTRIES + 255) / 256), dim3(256), 0, stream, dev->luts.u16, black, t);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {       // other streams use the table from now on
+    uint2 *t = nullptr;
+    MLV_HIP(hipMalloc(&t, sizeof(uint2) * (E2D_RECORDS + 1)));          // the records, then the counter of the check
+    int *d_bad = (int *)(t + E2D_RECORDS);
+    int bad = -1;
+    (void)hipMemsetAsync(d_bad, 0, sizeof(int), stream);
+    hipLaunchKernelGGL(k_build_e2d, dim3((E2D_RECORDS + 255) / 256), dim3(256), 0, stream, dev->luts.u16, black, t, d_bad);
+    (void)hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || bad != 0) {       // other streams use the table from now on
         (void)hipFree(t);
         set_error("building the output table for black level %d failed", black);
         return MLVFS_AMD_ERR_HIP;
     }
-    uint16_t *victim = nullptr;
+    uint2 *victim = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_tables_mu);
         auto it = g_e2r.find({ dev->id, black });
@@ -1721,7 +1761,7 @@ int launch_frame(const Device *dev, const Geom &g, bool packed, const void *src,
     a.tiles_y = frame_tiles_y(g.h, geo);
     a.t16 = dev->luts.t16;
     if (method != 0) {
-        int rc = e2r_table(dev, g.black, &a.e2r, stream);
+        int rc = e2r_table(dev, g.black, &a.e2d, stream);
         if (rc) return rc;
     }
     a.patch = pv && pv->n_rec > 0;
@@ -1812,6 +1852,6 @@ int dark_share(int packed_bpp, const void *d_frame, int w, int h, int black, hip
 
 // the first launch of any kernel of this file loads the file's code object (HIP loads them lazily): the device context asks for a
 // kernel's attributes when it is created, so that a clip's first frame does not pay for it (runtime.cpp: get_device)
-void preload_k_frame() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)k_build_e2r); (void)hipGetLastError(); }
+void preload_k_frame() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)k_build_e2d); (void)hipGetLastError(); }
 
 }  // namespace mlv

@@ -224,8 +224,28 @@ __global__ __launch_bounds__(256) void k_pn_apply(int16_t *__restrict__ raw, int
     raw[x + (size_t)y * w] = (int16_t)(v < 0 ? 0 : (v > 32760 ? 32760 : v));  // patternnoise.c:273
 }
 
+// The reference's debug views (patternnoise.c:215-240, debug_flags & FIXPN_DBG_DENOISED / _NOISE / _MASK; MLVFS itself passes 0):
+// what one direction's pass sees instead of its correction -- the smoothed planes, the noise samples (+100, masked ones 0), or the
+// mask (x 1000) -- written into the Bayer frame `view`; the gradient reads neighbours, so not in place.
+__global__ __launch_bounds__(256) void k_pn_debug_view(const int16_t *__restrict__ raw, int w, int hw, int hh, int white,
+                                                       const int16_t *__restrict__ smooth, int flags, int16_t *__restrict__ view)
+{
+    const size_t n = (size_t)hw * hh, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (i >= n) return;
+    const int16_t *sm = smooth + (size_t)c * n;
+    int nz;
+    const bool ok = noise_at(raw, w, hw, n, c, sm, i, white, nz);
+    const int x = (int)(i % hw), y = (int)(i / hw);
+    int16_t v;
+    if (flags & 2) v = sm[i];
+    else if (flags & 4) v = ok ? (int16_t)(nz + 100) : (int16_t)0;
+    else v = ok ? 0 : 1000;
+    view[(size_t)(2 * y + (c >> 1)) * w + 2 * x + (c & 1)] = v;
+}
+
 // one direction on a device frame (w x h int16).  scratch: smooth 4*hw*hh int16, offs 4*hw int, mc 4 int
-static int column_pass(int16_t *d_raw, int w, int h, int white, int16_t *d_smooth, int *d_offs, int *d_mc, int *d_noise_t, hipStream_t stream)
+static int column_pass(int16_t *d_raw, int w, int h, int white, int16_t *d_smooth, int *d_offs, int *d_mc, int *d_noise_t, hipStream_t stream, int flags)
 {
     const int hw = w / 2, hh = h / 2;
     if (hw <= 0 || hh <= 0) return MLVFS_AMD_OK;
@@ -233,6 +253,13 @@ static int column_pass(int16_t *d_raw, int w, int h, int white, int16_t *d_smoot
     if (shmem > 150 * 1024) { set_error("fix_pattern_noise: rows of %d pixels do not fit in LDS", w); return MLVFS_AMD_ERR_ARG; }
     MLV_HIP(hipFuncSetAttribute((const void *)k_pn_smooth, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(k_pn_smooth, dim3(hh), dim3(256), shmem, stream, d_raw, w, hw, 50 / 2, 500, d_smooth, hh);
+    if (flags & (2 | 4 | 8)) {
+        int16_t *d_view = (int16_t *)d_noise_t;                       // the samples' buffer is free in this mode
+        hipLaunchKernelGGL(k_pn_debug_view, dim3((unsigned)(((size_t)hw * hh + 255) / 256), 4), dim3(256), 0, stream, d_raw, w, hw, hh, white, d_smooth, flags, d_view);
+        MLV_HIP(hipGetLastError());
+        MLV_HIP(hipMemcpyAsync(d_raw, d_view, (size_t)w * h * 2, hipMemcpyDeviceToDevice, stream));
+        return MLVFS_AMD_OK;
+    }
     hipLaunchKernelGGL(k_pn_noise_t, dim3((hw + 31) / 32, (hh + 31) / 32, 4), dim3(32, 8), 0, stream, d_raw, w, hw, hh, white, d_smooth, d_noise_t);
     auto offsets = hh <= 64 * 12 ? k_pn_column_offsets<12> : (hh <= 64 * 32 ? k_pn_column_offsets<32> : k_pn_column_offsets<0>);
     hipLaunchKernelGGL(offsets, dim3(hw), dim3(256), 0, stream, d_noise_t, hw, hh, d_offs, false);
@@ -250,7 +277,8 @@ size_t pattern_noise_scratch_bytes(int w, int h)
            n * 4 /* transposed noise samples */;
 }
 
-int launch_pattern_noise(void *d_raw, int w, int h, int white, void *d_scratch, hipStream_t stream)
+// flags: the reference's debug_flags (patternnoise.h:19-24); with any of them set only one direction runs (patternnoise.c:363-379)
+int launch_pattern_noise(void *d_raw, int w, int h, int white, void *d_scratch, hipStream_t stream, int flags)
 {
     int16_t *raw = (int16_t *)d_raw;
     const size_t n = (size_t)w * h;
@@ -259,10 +287,11 @@ int launch_pattern_noise(void *d_raw, int w, int h, int white, void *d_scratch, 
     int *d_offs = (int *)(d_smooth + n);
     int *d_mc = d_offs + (size_t)4 * (w > h ? w : h) / 2 + 4;
     int *d_noise_t = (int *)(((uintptr_t)((uint8_t *)d_scratch + n * 4 + (size_t)4 * (w > h ? w : h) * 4 + 64) + 255) & ~(uintptr_t)255);
-    int rc = column_pass(raw, w, h, white, d_smooth, d_offs, d_mc, d_noise_t, stream);
-    if (rc) return rc;
+    int rc = MLVFS_AMD_OK;
+    if (!flags || !(flags & 1)) rc = column_pass(raw, w, h, white, d_smooth, d_offs, d_mc, d_noise_t, stream, flags);
+    if (rc || (flags && !(flags & 1))) return rc;
     hipLaunchKernelGGL(k_pn_transpose, dim3((w + 31) / 32, (h + 31) / 32), dim3(32, 8), 0, stream, raw, d_t, w, h);
-    rc = column_pass(d_t, h, w, white, d_smooth, d_offs, d_mc, d_noise_t, stream);
+    rc = column_pass(d_t, h, w, white, d_smooth, d_offs, d_mc, d_noise_t, stream, flags);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pn_transpose, dim3((h + 31) / 32, (w + 31) / 32), dim3(32, 8), 0, stream, d_t, raw, h, w);
     MLV_HIP(hipGetLastError());

@@ -85,6 +85,7 @@ class Oracle:
         L.orc_hdr_preview.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.orc_fix_pattern_noise.argtypes = [i16p, C.c_int, C.c_int, C.c_int]
+        L.orc_fix_pattern_noise_dbg.argtypes = [i16p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_cr2hdr20.restype = C.c_int
         L.orc_cr2hdr20.argtypes = [u16p] + [C.c_int] * 8 + [i32p, C.c_void_p]
         L.orc_lj92_decode.argtypes = [u8p, C.c_int, u16p]
@@ -260,10 +261,10 @@ class Oracle:
         """raw: float32 (h, w) Bayer plane in the caller's scale; returns (red, green, blue) float32 (h, w)."""
         return _amaze(self.L.orc_amaze_demosaic, raw)
 
-    def fix_pattern_noise(self, img, white) -> np.ndarray:
+    def fix_pattern_noise(self, img, white, flags: int = 0) -> np.ndarray:
         out = np.ascontiguousarray(img).view(np.int16).copy()
         h, w = out.shape
-        self.L.orc_fix_pattern_noise(out, w, h, white)
+        self.L.orc_fix_pattern_noise_dbg(out, w, h, white, flags)
         return out.view(np.uint16)
 
     def glibc_rand(self, n: int, seed: int = 1) -> np.ndarray:
@@ -357,6 +358,7 @@ class Reference:
         L.ref_cr2hdr20.restype = C.c_int
         L.ref_cr2hdr20.argtypes = [u16p] + [C.c_int] * 9 + [i32p]
         L.ref_fix_pattern_noise.argtypes = [i16p, C.c_int, C.c_int, C.c_int]
+        L.ref_fix_pattern_noise_dbg.argtypes = [i16p, C.c_int, C.c_int, C.c_int, C.c_int]
         f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
         L.ref_amaze_demosaic.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p]
         L.ref_hist_median_of.restype = C.c_uint16
@@ -490,10 +492,10 @@ class Reference:
                                 bad_pix, lv)
         return r, out, (int(lv[0]), int(lv[1]))
 
-    def fix_pattern_noise(self, img, white) -> np.ndarray:
+    def fix_pattern_noise(self, img, white, flags: int = 0) -> np.ndarray:
         out = np.ascontiguousarray(img).view(np.int16).copy()
         h, w = out.shape
-        self.L.ref_fix_pattern_noise(out, w, h, white)
+        self.L.ref_fix_pattern_noise_dbg(out, w, h, white, flags)
         return out.view(np.uint16)
 
     def hist_median(self, data, skip, white) -> int:

@@ -111,6 +111,7 @@ void orc_dualiso_reset(void);
 
 /* ---- pattern noise: mlvfs/patternnoise.c:49-380 -------------------------- */
 void orc_fix_pattern_noise(int16_t *raw, int w, int h, int white);
+void orc_fix_pattern_noise_dbg(int16_t *raw, int w, int h, int white, int flags);   /* debug_flags of patternnoise.h:19-24 */
 
 /* ---- glibc rand() restatement (TYPE_3 additive feedback, seed 1) --------- */
 typedef struct { int32_t ring[31]; int pos; } orc_rand_t;

@@ -1,6 +1,6 @@
 /*
  * oracle_patternnoise.c -- CPU restatement of the row/column pattern-noise
- * correction, mlvfs/patternnoise.c:49-380 (fix_pattern_noise, debug_flags = 0).
+ * correction, mlvfs/patternnoise.c:49-380 (fix_pattern_noise; debug views: orc_fix_pattern_noise_dbg).
  *
  * TEST INFRASTRUCTURE ONLY (see oracle.h).  Own code.
  *
@@ -78,7 +78,7 @@ static void smooth_rows(const planes_t *in, const planes_t *out, int w, int h, i
     free(avg); free(drg); free(dbg);
 }
 
-static void remove_column_offsets(int16_t *orig, const int16_t *smooth, int w, int h, int white)
+static void remove_column_offsets(int16_t *orig, const int16_t *smooth, int w, int h, int white, int flags)
 {
     size_t n = (size_t)w * h;
     int16_t *noise = (int16_t *)malloc(n * 2);
@@ -90,6 +90,12 @@ static void remove_column_offsets(int16_t *orig, const int16_t *smooth, int w, i
         noise[i] = (int16_t)(orig[i] - smooth[i]);
         int16_t grad = (i >= 2 && i + 2 < n) ? (int16_t)(orig[i - 2] - orig[i + 2]) : 0;
         masked[i] = (abs((int)grad) > 500) || (orig[i] >= white);
+    }
+    if (flags & (2 | 4 | 8)) {                  /* patternnoise.c:215-240: debug views instead of the correction */
+        for (size_t i = 0; i < n; i++)
+            orig[i] = (flags & 2) ? smooth[i] : (flags & 4) ? (int16_t)((masked[i] ? -100 : noise[i]) + 100) : (int16_t)(masked[i] * 1000);
+        free(noise); free(masked); free(offs); free(col);
+        return;
     }
     for (int x = 0; x < w; x++) {
         int k = 0;
@@ -110,7 +116,7 @@ static void remove_column_offsets(int16_t *orig, const int16_t *smooth, int w, i
     free(noise); free(masked); free(offs); free(col);
 }
 
-static void column_pass(int16_t *raw, int w, int h, int white)
+static void column_pass(int16_t *raw, int w, int h, int white, int flags)
 {
     int hw = w / 2, hh = h / 2;
     size_t n = (size_t)hw * hh;
@@ -123,7 +129,7 @@ static void column_pass(int16_t *raw, int w, int h, int white)
                 src.p[c][(x / 2) + (size_t)(y / 2) * hw] = raw[x + (size_t)y * w];
 
     smooth_rows(&src, &den, hw, hh, 50 / 2, 500);
-    for (int c = 0; c < 4; c++) remove_column_offsets(src.p[c], den.p[c], hw, hh, white);
+    for (int c = 0; c < 4; c++) remove_column_offsets(src.p[c], den.p[c], hw, hh, white, flags);
 
     for (int c = 0; c < 4; c++)
         for (int y = c >> 1; y < h; y += 2)
@@ -132,14 +138,19 @@ static void column_pass(int16_t *raw, int w, int h, int white)
     for (int c = 0; c < 4; c++) { free(src.p[c]); free(den.p[c]); }
 }
 
-void orc_fix_pattern_noise(int16_t *raw, int w, int h, int white)
+/* flags: the reference's debug_flags (patternnoise.h:19-24; patternnoise.c:363-379: with any flag set only one direction runs --
+ * bit 0 chooses the row direction --, bits 1..3 choose a view) */
+void orc_fix_pattern_noise_dbg(int16_t *raw, int w, int h, int white, int flags)
 {
-    column_pass(raw, w, h, white);
+    if (!flags || !(flags & 1)) column_pass(raw, w, h, white, flags);
+    if (flags && !(flags & 1)) return;
 
     size_t n = (size_t)w * h;
     int16_t *t = (int16_t *)malloc(n * 2);
     for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) t[y + (size_t)x * h] = raw[x + (size_t)y * w];
-    column_pass(t, h, w, white);
+    column_pass(t, h, w, white, flags);
     for (int y = 0; y < w; y++) for (int x = 0; x < h; x++) raw[y + (size_t)x * w] = t[x + (size_t)y * h];
     free(t);
 }
+
+void orc_fix_pattern_noise(int16_t *raw, int w, int h, int white) { orc_fix_pattern_noise_dbg(raw, w, h, white, 0); }

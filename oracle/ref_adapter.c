@@ -150,6 +150,10 @@ void ref_fix_pattern_noise(int16_t *raw, int w, int h, int white)
 {
     fix_pattern_noise(raw, w, h, white, 0);
 }
+void ref_fix_pattern_noise_dbg(int16_t *raw, int w, int h, int white, int flags)
+{
+    fix_pattern_noise(raw, w, h, white, flags);
+}
 
 /* histogram.c pass-through (16-bit counters)                                   */
 uint16_t ref_hist_median_of(const uint16_t *data, uint32_t size, uint16_t skip, uint16_t white)

@@ -310,6 +310,19 @@ def test_fix_pattern_noise_dropin(gpu, oracle, w, h, kind):
     assert (want != f).any()
 
 
+@pytest.mark.parametrize("flags", [1, 2, 3, 4, 5, 8, 9, 6, 12])
+def test_fix_pattern_noise_debug_views(gpu, oracle, flags):
+    """patternnoise.c:215-240, 363-379 (debug_flags != 0; MLVFS passes 0): one direction only, and the denoised / noise / mask
+    view of that direction's pass instead of its correction."""
+    for (w, h) in [(64, 48), (136, 72), (416, 264), (46, 1002)]:
+        f = frame_of(KINDS[0], w, h)
+        f[5:9, 20:30] = WHITE
+        want = oracle.fix_pattern_noise(f, WHITE, flags)
+        got = f.copy()
+        gpu.fix_pattern_noise(lib.ptr(got), w, h, WHITE, flags)
+        assert np.array_equal(got, want), f"{w}x{h} flags {flags}: {(got != want).sum()} px differ"
+
+
 def test_fix_pattern_noise_full_size_hash(gpu):
     """1920x1080 frame against the hash of the reference's output (tests/golden/golden.json)."""
     import json

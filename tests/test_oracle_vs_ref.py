@@ -137,6 +137,18 @@ def test_pattern_noise(oracle, reference, w, h):
         assert np.array_equal(oracle.fix_pattern_noise(f, WHITE), reference.fix_pattern_noise(f, WHITE))
 
 
+@pytest.mark.parametrize("flags", [1, 2, 3, 4, 5, 8, 9, 6, 12])
+def test_pattern_noise_debug_views(oracle, reference, flags):
+    """patternnoise.c:215-240, 363-379: debug_flags choose one direction (bit 0: rows) and a view (denoised / noise / mask; the
+    first of several wins).  MLVFS passes 0; the views complete fix_pattern_noise's behaviour."""
+    for (w, h) in [(64, 48), (136, 72)]:
+        f = frame(FRAMES[0][0], FRAMES[0][1], w, h)
+        f[5:9, 20:30] = WHITE                      # something for the mask
+        a, b = oracle.fix_pattern_noise(f, WHITE, flags), reference.fix_pattern_noise(f, WHITE, flags)
+        assert np.array_equal(a, b)
+        assert (a != f).any()
+
+
 def test_histogram_16bit_counters(oracle, reference):
     data = np.full(70000, 100, np.uint16)                  # one bin receives 70000 samples: the counter wraps
     data[:3000] = 50
