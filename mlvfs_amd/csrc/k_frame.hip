@@ -1362,15 +1362,12 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 if (vec) {
                     if (x < a.w) {
                         const uint32_t o = (uint32_t)y * (uint32_t)a.w + (uint32_t)x;           // < 2^28 pixels per frame
-#ifdef KF_STORE_NT
+                        // non-temporal stores: the output is not read again by this launch (same-box A/B, profiles/r04/ab_cache_policy.log: cs2x2
+                        // -1.3 ... -3.5 %, cs5x5 -1 ... -2.6 %; the stream LOADS marked nt or sc1 are 3-9 % slower: a line serves two loads)
                         typedef unsigned kf_u4 __attribute__((ext_vector_type(4)));
                         const kf_u4 vt = { top[0], top[1], top[2], top[3] }, vb = { bot[0], bot[1], bot[2], bot[3] };
                         __builtin_nontemporal_store(vt, (kf_u4 *)(out + o));
                         if (y + 1 < a.h) __builtin_nontemporal_store(vb, (kf_u4 *)(out + o + (uint32_t)a.w));
-#else
-                        *(uint4 *)(out + o) = make_uint4(top[0], top[1], top[2], top[3]);
-                        if (y + 1 < a.h) *(uint4 *)(out + o + (uint32_t)a.w) = make_uint4(bot[0], bot[1], bot[2], bot[3]);
-#endif
                     }
                 } else {
 #pragma unroll 1
