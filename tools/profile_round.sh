@@ -8,7 +8,7 @@ cd $R
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1
 python bench.py > $O/bench_default.log 2> $O/bench_default.err
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-extras --frames-per-step 100"
+B="python3 $R/bench.py --no-cpu-baseline --no-extras"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 5 --warmup 1 > $O/stats.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B --steps 3 --warmup 1 > $O/pmc_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B --steps 3 --warmup 1 > $O/pmc_write.log 2>&1

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""tools/update_traffic.py PMC_SUMMARY FRAMES_PER_LAUNCH [SOURCE_NOTE] -- refresh profiles/traffic.json (what bench.py quotes as
+roofline.traffic) from a tools/profile_round.sh summary: FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, both
+in KiB per launch, and SQ_INSTS_VALU, for the headline kernel."""
+import json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+path, frames = sys.argv[1], int(sys.argv[2])
+kernel = "void mlv::k_frame<5, true, 1, false>(mlv::FrameArgs)"
+vals, on = {}, False
+for ln in open(path):
+    if not ln.startswith(" "):
+        on = ln.strip().startswith(kernel[:55])
+        continue
+    m = re.match(r"\s+(\S+)\s+n=\s*\d+\s+mean=\s*([0-9.]+)", ln)
+    if on and m:
+        vals[m.group(1)] = float(m.group(2))
+tj_path = os.path.join(ROOT, "profiles", "traffic.json")
+tj = json.load(open(tj_path))
+by = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / frames
+tj["k_frame_bytes_per_frame"] = by
+tj["ratio"] = by / tj["algorithmic_bytes_per_frame"]
+tj["valu_insts_per_frame"] = int(vals["SQ_INSTS_VALU"] / frames)
+rel = os.path.relpath(os.path.abspath(path), ROOT)
+tj["source"] = f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, separate passes of `bench.py --no-cpu-baseline --no-extras`, " \
+               f"{frames} frames per launch, tools/profile_round.sh" + (", " + sys.argv[3] if len(sys.argv) > 3 else "") + ")"
+tj["valu_source"] = f"{rel} SQ_INSTS_VALU / {frames} frames (round 3: 4293213, round 1: 4795296)"
+json.dump(tj, open(tj_path, "w"), indent=1)
+print(json.dumps({k: tj[k] for k in ("k_frame_bytes_per_frame", "ratio", "valu_insts_per_frame")}))
