@@ -755,7 +755,7 @@ int mlvfs_amd_amaze_rows_extra_mode(int mode, int width, int height, int *count)
     if (count) {
         const int rows_before = g_amaze_rows_mode;
         g_amaze_rows_mode = 1; g_amaze_rows_extra_mode = 1;
-        *count = amaze_rows_extra(width, height);
+        *count = amaze_rows_extra(width, height, 0);
         g_amaze_rows_mode = rows_before;
     }
     g_amaze_rows_extra_mode = mode < 0 ? -1 : (mode ? 1 : 0);

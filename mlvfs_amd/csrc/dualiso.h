@@ -105,7 +105,7 @@ size_t amaze_scratch_bytes(int w, int h);
 extern int g_amaze_rows_mode;
 extern int g_amaze_rows_extra_mode;
 void amaze_rows_extent(int w, int h, int *nfx, int *nfy);
-int amaze_rows_extra(int w, int h);            // heads of k_amaze.hip's chains that k_amaze_rows takes too (rows 0 .. n - 1 of column nfx)
+int amaze_rows_extra(int w, int h, int nframes);            // heads of k_amaze.hip's chains that k_amaze_rows takes too (rows 0 .. n - 1 of column nfx)
 int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, hipStream_t s, int nframes,
                       size_t plane_stride, const int *h_of, int h_stride, float *d_dbg, int *d_ctr /* nframes zeroed ints: the tile counters */);
 int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s,

@@ -598,7 +598,7 @@ int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green,
     static const int threads = [] { const char *e = getenv("MLVFS_AMD_AMAZE_THREADS"); const int v = e ? atoi(e) : 1024; return v >= 64 && v <= 1024 ? v / 64 * 64 : 1024; }();
     int nfx = 0, nfy = 0;
     amaze_rows_extent(w, h, &nfx, &nfy);                                         // the complete tiles go through LDS (k_amaze_rows.hip)
-    const int dead_rows = d_rows_dbg ? 0 : amaze_rows_extra(w, h);               // and so do the heads of chains that have no output
+    const int dead_rows = d_rows_dbg ? 0 : amaze_rows_extra(w, h, nframes);               // and so do the heads of chains that have no output
     auto launch = [&](int row0, int nrows, int wgs_per_row, int chain_len, int rows_per_wg, int copy_from) {
         hipLaunchKernelGGL(k_amaze, dim3(nrows * wgs_per_row, nframes), dim3(threads), 0, s, d_raw, w, h, d_red, d_green, d_blue, d_scratch, tiles_x,
                            row0, wgs_per_row, chain_len, rows_per_wg, copy_from, plane_stride, scratch_stride, h_of, h_stride, nfx, nfy, dead_rows);

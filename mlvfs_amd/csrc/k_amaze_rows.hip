@@ -908,15 +908,18 @@ void amaze_rows_extent(int w, int h, int *nfx, int *nfy)
 // tile like any other but for its last 16 columns, which mirror the image's right edge; k_amaze.hip then skips the whole chain.
 // Measured (tools/ab_di_bench.sh, batch of 8 at 3584x1320, three rounds round-robin): 8.00 ms per batch without, 8.09 with -- the 90 chains
 // ran beside the row kernel on an otherwise idle part of the chip, their 9 heads per frame lengthen the row kernel's last round
-// (1 116 instead of 1 080 tiles over 256 workgroups per half batch), which is what the batch waits for.  OFF unless
-// MLVFS_AMD_AMAZE_ROWS_EXTRA=1 (or the test hook mlvfs_amd_amaze_rows_extra_mode); bit-identical either way (tests/test_gpu_amaze_rows.py).
+// (1 116 instead of 1 080 tiles over 256 workgroups per half batch), which is what the batch waits for.  A conversion ON ITS OWN is the
+// other way round: its one chain launch is the critical path and the row kernel has room in its second round -- 1.71 -> 1.645 ms
+// (two rounds, same box).  So: on for launches of one frame, off for batches; MLVFS_AMD_AMAZE_ROWS_EXTRA=0 / 1 (or the test hook
+// mlvfs_amd_amaze_rows_extra_mode) forces it; bit-identical either way (tests/test_gpu_amaze_rows.py).
 int g_amaze_rows_extra_mode = -1;  // -1: the environment decides, 0 / 1: forced
-int amaze_rows_extra(int w, int h)
+int amaze_rows_extra(int w, int h, int nframes)
 {
-    static const bool on = [] { const char *e = getenv("MLVFS_AMD_AMAZE_ROWS_EXTRA"); return e && atoi(e) != 0; }();
+    static const int env = [] { const char *e = getenv("MLVFS_AMD_AMAZE_ROWS_EXTRA"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
     int nfx, nfy;
     amaze_rows_extent(w, h, &nfx, &nfy);
-    if (!nfx || g_amaze_rows_extra_mode == 0 || (g_amaze_rows_extra_mode < 0 && !on)) return 0;
+    const int mode = g_amaze_rows_extra_mode >= 0 ? g_amaze_rows_extra_mode : (env >= 0 ? env : (nframes == 1 ? 1 : 0));
+    if (!nfx || !mode) return 0;
     const int step = T - 32;
     const int tiles_x = (w + 16 + step - 1) / step, tiles_y = (h + 16 + step - 1) / step;
     const int cc1_last = w + 16 - (-16 + (tiles_x - 1) * step), rr1_last = h + 16 - (-16 + (tiles_y - 1) * step);
@@ -1015,7 +1018,7 @@ int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_g
         }
     }
     static const unsigned skip = [] { const char *e = getenv("MLVFS_AMD_AMAZE_ROWS_SKIP"); return e ? (unsigned)strtoul(e, nullptr, 16) : 0u; }();
-    const int nrect = nfx * nfy, ntiles = nrect + (d_dbg ? 0 : amaze_rows_extra(w, h));       // (the debug dump is laid out for the block only)
+    const int nrect = nfx * nfy, ntiles = nrect + (d_dbg ? 0 : amaze_rows_extra(w, h, nframes));       // (the debug dump is laid out for the block only)
     // one workgroup per CU (the rings fill its LDS); the frames of a batch share the CUs
     int per_frame = (dev < 64 && cus[dev] ? cus[dev] : 256) / (nframes > 0 ? nframes : 1);
     static const int cap = [] { const char *e = getenv("MLVFS_AMD_AMAZE_ROWS_WGS"); return e ? atoi(e) : 0; }();    // tests: few workgroups, many tiles each
