@@ -139,6 +139,11 @@ __device__ __forceinline__ mlv_i32x4 table_rsrc(const void *p, unsigned stride, 
 // benchmark's frames, 9.4 -> 7.0 in low light, 10.8 -> 8.75 on colour patches; cs5x5 8.35 -> 8.22 / 10.8 -> 10.55 / 12.4 -> 11.8.
 constexpr int E2R_ENTRIES = 14 * MLV_EV_RES;
 constexpr int E2D_RECORDS = E2R_ENTRIES / 32;
+#ifdef KF_EXP_LEAN          // timing experiment: every rare path compiled out (results are wrong where one would have been taken)
+#define KF_EXP_PKONLY
+#define KF_EXP_NOFALLBACK
+#define KF_EXP_FASTLOADER
+#endif
 #ifndef KF_SRC_AUX
 #define KF_SRC_AUX 0          // cache policy of the loader's stream loads (experiments, same encoding)
 #endif
@@ -1354,9 +1359,13 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 int co[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) { co[i] = a.coef[i]; asm volatile("" : "+s"(co[i])); }
+#ifdef KF_EXP_PKONLY
+                stripe_strip_pk(top, bot, co, black16, white16);
+#else
                 if (stripe_mode == 1) stripe_strip_pk(top, bot, co, black16, white16);
                 else if (stripe_mode == 2) stripe_strip<true>(top, bot, co, black16, white16);
                 else stripe_strip<false>(top, bot, co, black16, white16);
+#endif
             }
             if (store && y < a.h) {
                 if (vec) {
@@ -1467,7 +1476,11 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             // Strips whose packed medians were not certain: all of the tile's, gathered in LDS, go through the 32-bit networks
             // one per lane -- as many waves as ceil(count / 64) run them, instead of every wave that had one such strip.
             lds_barrier();
+#ifdef KF_EXP_LEAN
+            const int nfb = 0;
+#else
             const int nfb = __builtin_amdgcn_readfirstlane(sm.fb_count);
+#endif
             if (!skip_packed) {
                 // more than FB_DIRECT uncertain strips: the next fb_wait tiles go to the 32-bit chain directly, and the wait doubles
                 // (up to FB_WAIT_MAX) each time the tile after it is no better -- a stray busy tile costs its few successors a
