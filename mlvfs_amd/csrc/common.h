@@ -65,6 +65,12 @@ struct LibcRandGuard {
     LibcRandGuard(const LibcRandGuard &) = delete;
     LibcRandGuard &operator=(const LibcRandGuard &) = delete;
     static void draw_mod1024(uint16_t *out, long long n);      // n values of rand() % 1024 from the APPLICATION's stream
+    // The application's generator itself, while it is parked (i.e. inside a guard): its 31 words, oldest first (next value =
+    // x[0] + x[28], output = next >> 1), if it is glibc's default TYPE_3 generator -- what rand() / srand() use unless the application
+    // called initstate() with another size.  put_app_state stores the words back (after the library has produced the values in
+    // between some faster way than by calling rand() millions of times).  false: not parked, or another generator type.
+    static bool take_app_state(uint32_t x[31]);
+    static bool put_app_state(const uint32_t x[31]);
 };
 
 struct Clip;

@@ -53,6 +53,37 @@ LibcRandGuard::~LibcRandGuard()
     if (--g_rg_depth == 0 && g_rg_app) (void)setstate(g_rg_app);
 }
 
+// glibc's random_r.c (public layout of the buffer that initstate() / setstate() hand back): the word in front of the state array
+// holds MAX_TYPES * (rear pointer's index) + type for every type but 0; TYPE_3 has 31 words and the front pointer 3 ahead of the
+// rear one.  The front pointer addresses the OLDEST word (the one the next call overwrites with oldest + rear's word).
+namespace {
+constexpr int RG_MAX_TYPES = 5, RG_TYPE_3 = 3, RG_DEG_3 = 31, RG_SEP_3 = 3;
+}
+
+bool LibcRandGuard::take_app_state(uint32_t x[31])
+{
+    std::lock_guard<std::mutex> lk(g_rg_mu);
+    if (!(g_rg_depth > 0 && g_rg_app)) return false;
+    const int32_t *st = (const int32_t *)g_rg_app;
+    if (st[0] % RG_MAX_TYPES != RG_TYPE_3) return false;
+    const int rear = st[0] / RG_MAX_TYPES;
+    if (rear < 0 || rear >= RG_DEG_3) return false;
+    const int front = (rear + RG_SEP_3) % RG_DEG_3;
+    for (int k = 0; k < RG_DEG_3; k++) x[k] = (uint32_t)st[1 + (front + k) % RG_DEG_3];
+    return true;
+}
+
+bool LibcRandGuard::put_app_state(const uint32_t x[31])
+{
+    std::lock_guard<std::mutex> lk(g_rg_mu);
+    if (!(g_rg_depth > 0 && g_rg_app)) return false;
+    int32_t *st = (int32_t *)g_rg_app;
+    if (st[0] % RG_MAX_TYPES != RG_TYPE_3) return false;
+    for (int k = 0; k < RG_DEG_3; k++) st[1 + k] = (int32_t)x[k];        // oldest word at index 0: front pointer 0, rear pointer 28
+    st[0] = RG_MAX_TYPES * ((RG_DEG_3 - RG_SEP_3) % RG_DEG_3) + RG_TYPE_3;
+    return true;
+}
+
 void LibcRandGuard::draw_mod1024(uint16_t *out, long long n)
 {
     std::lock_guard<std::mutex> lk(g_rg_mu);

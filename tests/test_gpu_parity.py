@@ -89,12 +89,15 @@ def test_chroma_smooth_bad_method_is_noop(gpu):
 
 
 def test_chroma_smooth_other_black_levels(gpu, oracle):
-    for black in (0, 1024, 4000):
+    """Every black level has an output table of its own (k_frame.hip: E2D_RECORDS, built and checked on the device when the level is
+    first seen); 8192 is what dual ISO makes of 2048 (the conversion multiplies the levels by four)."""
+    for black in (0, 1, 1024, 4000, 8192, 12000):
         f = synth.adversarial_frame(128, 64, black=black)
         fh = abi.make_frame_headers(128, 64, black=black, white=WHITE)
-        got = f.copy()
-        gpu.chroma_smooth(C.byref(fh), lib.ptr(got), 5)
-        assert np.array_equal(got, oracle.chroma_smooth(f, black, 5))
+        for method in (2, 3, 5):
+            got = f.copy()
+            gpu.chroma_smooth(C.byref(fh), lib.ptr(got), method)
+            assert np.array_equal(got, oracle.chroma_smooth(f, black, method)), (black, method)
 
 
 # ------------------------------------------------------------------ bad / focus pixels
@@ -174,6 +177,45 @@ def test_stripes_dropin(gpu, oracle, w, h, kind):
     assert gpu.stripes_get_correction(name)
     gpu.stripes_free_corrections()
     assert not gpu.stripes_get_correction(name)
+
+
+def test_stripes_dropin_with_the_applications_own_rand_state(gpu, oracle):
+    """The dither comes from the application's libc generator.  Its default (TYPE_3: what srand() / rand() use) is advanced in bulk from
+    its parked state (runtime.cpp: take_app_state / put_app_state); an application that installed a generator of another size with
+    initstate() gets its values call by call.  Either way: the reference's coefficients and the reference's position in the stream."""
+    libc = C.CDLL(None)
+    libc.initstate.restype = C.c_void_p
+    libc.setstate.restype = C.c_void_p
+    libc.setstate.argtypes = [C.c_void_p]
+    f = frame_of(KINDS[0], 416, 264)
+    fh = fh_for(416, 264)
+    for size, seed in ((256, 7), (8, 9), (128, 11), (64, 5)):            # TYPE_4, TYPE_0, TYPE_3 in a buffer of the application's, TYPE_2
+        want_buf, got_buf = C.create_string_buffer(size), C.create_string_buffer(size)
+        old = libc.initstate(seed, want_buf, size)
+        needed, coeffs = oracle.stripes_compute(f, BLACK, WHITE, reseed=False)
+        want_next = libc.rand()
+        libc.initstate(seed, got_buf, size)
+        corr = gpu.stripes_new_correction(f"own_state_{size}.MLV".encode())
+        gpu.stripes_compute_correction(C.byref(fh), corr, lib.ptr(f), 0, f.size)
+        got_next = libc.rand()
+        libc.setstate(old)                                               # the process's default generator back
+        assert corr.contents.correction_needed == needed and list(corr.contents.coeffficients) == list(coeffs), size
+        assert got_next == want_next, size
+    # a srand() in the middle of a run of calls: the bulk path must pick the state up wherever it is
+    for seed, burn in ((3, 0), (3, 17), (12345, 1000)):
+        libc.srand(seed)
+        for _ in range(burn):
+            libc.rand()
+        needed, coeffs = oracle.stripes_compute(f, BLACK, WHITE, reseed=False)
+        want_next = [libc.rand() for _ in range(40)]
+        libc.srand(seed)
+        for _ in range(burn):
+            libc.rand()
+        corr = gpu.stripes_new_correction(f"burn_{seed}_{burn}.MLV".encode())
+        gpu.stripes_compute_correction(C.byref(fh), corr, lib.ptr(f), 0, f.size)
+        assert [libc.rand() for _ in range(40)] == want_next
+        assert corr.contents.correction_needed == needed and list(corr.contents.coeffficients) == list(coeffs)
+    gpu.stripes_free_corrections()
 
 
 def test_stripes_apply_noop_cases(gpu):
