@@ -690,14 +690,27 @@ static FocusMap *load_focus_map(uint32_t camera, int raw_w, int raw_h)          
     FILE *f = fopen(filename, "r+");                                                 // relative to the CWD, like the reference
     if (!f) return m;
     printf("Loading focus pixel map '%s'...\n", filename);
-    int x = 0, y = 0, ret = 2;
-    while (ret != EOF) {
-        ret = fscanf(f, "%i %i", &x, &y);
-        if (ret == 2) { m->xy.push_back(x); m->xy.push_back(y); }
-        else if (ferror(f)) { fprintf(stderr, "file error: %s\n", strerror(errno)); break; }
-        else if (ret != EOF) break;                                                  // unparsable token: stop instead of spinning
-    }
+    // The reference reads pairs with fscanf("%i %i") until EOF (cs.c:380-392): %i is strtol with base 0 -- decimal, 0x.., 0.. --
+    // behind any white space.  The same on the whole file in memory (151 200 lines: 12 ms through fscanf, 3 through strtol); a
+    // token that is no number ends the list (the reference would spin on it).
+    std::vector<char> text;
+    char chunk[1 << 16];
+    for (size_t got; (got = fread(chunk, 1, sizeof chunk, f)) > 0;) text.insert(text.end(), chunk, chunk + got);
+    if (ferror(f)) fprintf(stderr, "file error: %s\n", strerror(errno));
     fclose(f);
+    text.push_back('\0');
+    for (char &ch : text) if (ch == '\0' && &ch != &text.back()) ch = ' ';          // (an embedded NUL would end strtol's view of the file)
+    const char *p = text.data();
+    for (;;) {
+        char *e = nullptr;
+        const long x = strtol(p, &e, 0);
+        if (e == p) break;
+        p = e;
+        const long y = strtol(p, &e, 0);
+        if (e == p) break;
+        p = e;
+        m->xy.push_back((int)x); m->xy.push_back((int)y);
+    }
     return m;
 }
 
