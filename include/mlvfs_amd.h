@@ -287,7 +287,10 @@ int    mlvfs_amd_mlv_process_dualiso(const void *reader, int first, int count, v
 size_t mlvfs_amd_gif_size(const struct frame_headers *frame_headers);
 /* The preview of 10 frames (host memory, `stride` bytes apart: packed payloads of geom->bpp bits with one word of slack behind
  * each when packed != 0, else 16-bit frames): the pixel picking and the gamma map run on the GPU, the file's framing on the host;
- * file receives mlvfs_amd_gif_size bytes, byte for byte what gif_get_data builds.                                   */
+ * file receives mlvfs_amd_gif_size bytes, byte for byte what gif_get_data builds.  packed == 2: only the rows the preview reads
+ * (it picks ONE pixel of every 4x4 block, gif.c:197): yres / 4 row pieces per frame, stride / (yres / 4) bytes each, piece y
+ * starting at the 16-bit word of the payload that holds pixel y * 4 * (xres / 4 * 4) + 1 (mlvfs_amd_mlv_gif_data reads just those
+ * from an uncompressed clip: a quarter of the file).                                                                  */
 int mlvfs_amd_gif_render(const mlvfs_amd_geom_t *geom, const void *h_frames, size_t stride, int packed, int nframes, uint8_t *file);
 /* = gif_get_data on an opened clip (frames k * count / 10, k = 0..9; uncompressed, LZMA and LJ92 clips): copies
  * min(max_size, size - offset) bytes from `offset` on, returns max_size (0 on failure).                              */

@@ -30,9 +30,15 @@ __global__ __launch_bounds__(256) void k_gif_pixels(const uint8_t *frames, size_
         const uint32_t i = (uint32_t)y * GIF_DOWN * (uint32_t)out_w * GIF_DOWN + (uint32_t)x * GIF_DOWN + 1;      // gif.c:197
         uint32_t p;
         if (packed) {                                     // dng.c:813-843 for this one pixel
-            const uint16_t *s = (const uint16_t *)f;
             const uint64_t bit = (uint64_t)i * (uint32_t)bpp;
-            const uint32_t two = ((uint32_t)s[bit >> 4] << 16) | s[(bit >> 4) + 1];
+            const uint16_t *s = (const uint16_t *)f;
+            uint64_t word = bit >> 4;
+            if (packed == 2) {                            // row pieces: piece y starts at the word of its first pixel
+                const uint64_t bit0 = ((uint64_t)y * GIF_DOWN * (uint32_t)out_w * GIF_DOWN + 1) * (uint32_t)bpp;
+                s = (const uint16_t *)(f + (size_t)y * (stride / (size_t)out_h));
+                word -= bit0 >> 4;
+            }
+            const uint32_t two = ((uint32_t)s[word] << 16) | s[word + 1];
             p = (two >> (32 - bpp - (int)(bit & 15))) & ((1u << bpp) - 1u);
         } else p = ((const uint16_t *)f)[i];
         o[k] = gamma[min(p >> 4, 4095u) & 1023u];         // a 16-bit container never exceeds 4095 here; 14-bit data stays below 1024
@@ -90,13 +96,13 @@ void gif_assemble(int xres, int yres, const uint8_t *pixels, uint8_t *file)
     file[pos++] = 0x3B;
 }
 
-int launch_gif_pixels(const void *d_frames, size_t stride, int bpp, bool packed, int xres, int yres, int nframes, const uint8_t *d_gamma,
+int launch_gif_pixels(const void *d_frames, size_t stride, int bpp, int packed, int xres, int yres, int nframes, const uint8_t *d_gamma,
                       void *d_out, hipStream_t stream)
 {
     const int ow = xres / GIF_DOWN, oh = yres / GIF_DOWN;
     if (ow <= 0 || oh <= 0 || nframes <= 0) return MLVFS_AMD_OK;
     dim3 grid((unsigned)std::min((ow * oh + 255) / 256, 4096), (unsigned)nframes);
-    hipLaunchKernelGGL(k_gif_pixels, grid, dim3(256), 0, stream, (const uint8_t *)d_frames, stride, bpp, packed ? 1 : 0, ow, oh, d_gamma,
+    hipLaunchKernelGGL(k_gif_pixels, grid, dim3(256), 0, stream, (const uint8_t *)d_frames, stride, bpp, packed, ow, oh, d_gamma,
                        (uint8_t *)d_out);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
@@ -116,6 +122,10 @@ extern "C" size_t mlvfs_amd_gif_size(const struct frame_headers *fh)
 extern "C" int mlvfs_amd_gif_render(const mlvfs_amd_geom_t *geom, const void *h_frames, size_t stride, int packed, int nframes, uint8_t *file)
 {
     if (!geom || !h_frames || !file || nframes != GIF_FRAMES) { set_error("gif: needs %d frames", GIF_FRAMES); return MLVFS_AMD_ERR_ARG; }
+    if (packed == 2 && (geom->height / GIF_DOWN <= 0 || stride % (size_t)(geom->height / GIF_DOWN) != 0 || (stride / (size_t)(geom->height / GIF_DOWN)) % 2 != 0)) {
+        set_error("gif: row pieces need a stride that is a multiple of the %d rows", geom->height / GIF_DOWN);
+        return MLVFS_AMD_ERR_ARG;
+    }
     ThreadCtx *c = thread_ctx();
     if (!c) return MLVFS_AMD_ERR_HIP;
     const int ow = geom->width / GIF_DOWN, oh = geom->height / GIF_DOWN;
@@ -127,7 +137,7 @@ extern "C" int mlvfs_amd_gif_render(const mlvfs_amd_geom_t *geom, const void *h_
     uint8_t *d_gamma = (uint8_t *)c->d_b + ((out_bytes + 15) & ~(size_t)15);
     MLV_HIP(hipMemcpyAsync(c->d_a, h_frames, in_bytes, hipMemcpyHostToDevice, c->stream));
     MLV_HIP(hipMemcpyAsync(d_gamma, gamma, sizeof gamma, hipMemcpyHostToDevice, c->stream));
-    rc = launch_gif_pixels(c->d_a, stride, geom->bpp, packed != 0, geom->width, geom->height, nframes, d_gamma, c->d_b, c->stream);
+    rc = launch_gif_pixels(c->d_a, stride, geom->bpp, packed == 2 ? 2 : (packed != 0 ? 1 : 0), geom->width, geom->height, nframes, d_gamma, c->d_b, c->stream);
     if (rc) return rc;
     std::vector<uint8_t> px(out_bytes ? out_bytes : 1);
     if (out_bytes) MLV_HIP(hipMemcpyAsync(px.data(), c->d_b, out_bytes, hipMemcpyDeviceToHost, c->stream));

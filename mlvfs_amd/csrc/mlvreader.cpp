@@ -28,6 +28,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <memory>
 #include <vector>
 
 #include "clip.h"
@@ -661,6 +662,28 @@ static size_t gif_data(const void *reader, uint8_t *output_buffer, off_t offset,
                                    hipStreamSynchronize(c->stream) != hipSuccess)) rc = MLVFS_AMD_ERR_HIP;
         (void)hipFree(d);
         if (rc == MLVFS_AMD_OK) rc = mlvfs_amd_gif_render(&geom, frames.data(), dstride, 0, NF, file.data());
+    } else if (!(fh0.file_hdr.videoClass & CLASS_LZMA) && xres / 4 > 0 && yres / 4 > 0) {
+        // An uncompressed clip: the preview picks ONE pixel of every 4x4 block (gif.c:197: flat index y * 4 * P + x * 4 + 1 with P =
+        // xRes / 4 * 4), i.e. every fourth row -- only those pieces are read, a quarter of ten payloads (3584x1320: 21 MB instead of
+        // 83 MB from the page cache and over the link; the preview 25 -> 8 ms, the reference's gif_get_data: 33 ms).  Piece y of a
+        // frame: from the 16-bit word that holds its first pixel to the word behind the one that holds its last.
+        const int ow = xres / 4, oh = yres / 4;
+        const uint64_t P = (uint64_t)ow * 4;
+        const size_t piece = ((((uint64_t)(ow - 1) * 4 * bpp + bpp + 15) / 16 + 2) * 2 + 15) / 16 * 16;
+        const size_t stride = piece * (size_t)oh;
+        std::unique_ptr<uint8_t[]> rows(new uint8_t[stride * NF]);
+        for (int k = 0; k < NF && rc == MLVFS_AMD_OK; k++) {                                       // gif.c:160: frame k * count / 10
+            Span sp;
+            if (!payload_span(r, k * frame_count / NF, &sp)) return 0;
+            for (int y = 0; y < oh; y++) {
+                uint8_t *dst = rows.get() + (size_t)k * stride + (size_t)y * piece;
+                const uint64_t at = ((((uint64_t)y * 4 * P + 1) * bpp) >> 4) * 2;                  // byte offset of the piece in the payload
+                const size_t have = at < sp.bytes ? (size_t)std::min<uint64_t>(piece, sp.bytes - at) : 0;
+                if (have && !read_at(sp.fd, dst, have, sp.off + at)) { set_error("mlv: short read"); return 0; }
+                if (have < piece) memset(dst + have, 0, piece - have);                             // (the slack word behind a payload)
+            }
+        }
+        if (rc == MLVFS_AMD_OK) rc = mlvfs_amd_gif_render(&geom, rows.get(), stride, 2, NF, file.data());
     } else {
         Span s0;
         if (!payload_span(r, 0, &s0)) return 0;
