@@ -1476,7 +1476,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             // Strips whose packed medians were not certain: all of the tile's, gathered in LDS, go through the 32-bit networks
             // one per lane -- as many waves as ceil(count / 64) run them, instead of every wave that had one such strip.
             lds_barrier();
-#ifdef KF_EXP_LEAN
+#if defined(KF_EXP_LEAN) || defined(KF_EXP_NOSETTLE)
             const int nfb = 0;
 #else
             const int nfb = __builtin_amdgcn_readfirstlane(sm.fb_count);
