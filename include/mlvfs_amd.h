@@ -391,6 +391,10 @@ void mlvfs_amd_dropin_profile(double out[8]);
  * error without touching the device.  What the caller then finds -- a zeroed frame and one line on stderr, never the bytes its
  * malloc returned -- is the library's failure policy ("When the device fails"; tests/test_failure_policy.py). */
 void mlvfs_amd_test_fail_next(int what);
+/* Test hook, host only: can the dither of stripes_compute_correction be taken from the application's libc generator in bulk
+ * (glibc's TYPE_3 state layout, checked once per process on a generator of the library's own; csrc/runtime.cpp)?  1 yes, 0 no (the
+ * values are then drawn by calling rand()).  Leaves the application's stream where it was.                              */
+int mlvfs_amd_test_rand_layout(void);
 
 /* self tests that need no GPU (selection networks, LUT identities): 0 = pass */
 int mlvfs_amd_selftest_host(void);

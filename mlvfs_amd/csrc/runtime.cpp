@@ -60,10 +60,48 @@ namespace {
 constexpr int RG_MAX_TYPES = 5, RG_TYPE_3 = 3, RG_DEG_3 = 31, RG_SEP_3 = 3;
 }
 
+// Is this libc's generator what the two functions below take it for?  Checked once, on a generator of the library's own (the
+// application's stream is not touched): a seeded TYPE_3 buffer is parked, read the way take_app_state reads it, its next value
+// predicted; then it is written back rotated the way put_app_state writes it and asked again.  Any surprise: the bulk path stays off
+// and the values are drawn call by call (draw_mod1024), as before.  Called with g_rg_mu held and the application's state parked.
+static bool rg_layout_ok()
+{
+    static int known = -1;
+    if (known >= 0) return known != 0;
+    known = 0;
+    alignas(8) static char probe[128], aside[128];
+    char *const before = initstate(20240229u, probe, sizeof probe);       // current: probe
+    if (!before) return false;
+    (void)rand(); (void)rand(); (void)rand();
+    if (!initstate(1u, aside, sizeof aside)) { (void)setstate(before); return false; }      // probe is parked now, its rear index stored
+    bool ok = false;
+    const int32_t *st = (const int32_t *)probe;
+    if (st[0] % RG_MAX_TYPES == RG_TYPE_3 && st[0] / RG_MAX_TYPES >= 0 && st[0] / RG_MAX_TYPES < RG_DEG_3) {
+        const int front = (st[0] / RG_MAX_TYPES + RG_SEP_3) % RG_DEG_3;
+        uint32_t x[RG_DEG_3 + 2];
+        for (int k = 0; k < RG_DEG_3; k++) x[k] = (uint32_t)st[1 + (front + k) % RG_DEG_3];
+        x[31] = x[0] + x[28];                                              // the next two values
+        x[32] = x[1] + x[29];
+        (void)setstate(probe);
+        const bool first = (uint32_t)rand() == (x[31] >> 1);
+        (void)setstate(aside);                                             // parked again, one step further
+        int32_t *wr = (int32_t *)probe;
+        for (int k = 0; k < RG_DEG_3; k++) wr[1 + k] = (int32_t)x[1 + k];  // oldest first, as put_app_state stores it
+        wr[0] = RG_MAX_TYPES * ((RG_DEG_3 - RG_SEP_3) % RG_DEG_3) + RG_TYPE_3;
+        (void)setstate(probe);
+        ok = first && (uint32_t)rand() == (x[32] >> 1);
+    }
+    (void)setstate(before);
+    known = ok ? 1 : 0;
+    if (!ok) fprintf(stderr, "mlvfs_amd: this libc's rand() state is not glibc's TYPE_3 layout: stripes dither drawn call by call\n");
+    return ok;
+}
+
 bool LibcRandGuard::take_app_state(uint32_t x[31])
 {
     std::lock_guard<std::mutex> lk(g_rg_mu);
     if (!(g_rg_depth > 0 && g_rg_app)) return false;
+    if (!rg_layout_ok()) return false;
     const int32_t *st = (const int32_t *)g_rg_app;
     if (st[0] % RG_MAX_TYPES != RG_TYPE_3) return false;
     const int rear = st[0] / RG_MAX_TYPES;
@@ -372,6 +410,14 @@ int ThreadCtx::ensure_patch(size_t need)
 extern "C" {
 
 int mlvfs_amd_device_count(void) { return mlv::visible_devices(); }
+
+int mlvfs_amd_test_rand_layout(void)
+{
+    mlv::LibcRandGuard guard;
+    uint32_t x[31];
+    return mlv::LibcRandGuard::take_app_state(x) ? 1 : 0;
+}
+
 // the PCI bus id ("0000:c1:00.0") of a visible device: what identifies the physical card across processes (bench.py gathers it from
 // every rank and refuses a run in which two ranks share a card); and the device the calling thread is bound to (-1: none yet)
 int mlvfs_amd_device_pci_bus_id(int device, char *out, int len)

@@ -65,6 +65,21 @@ def test_rand_stream_is_glibc(amd):
     assert np.array_equal(part, want[3210:3310])
 
 
+def test_libc_rand_state_layout_is_recognised_and_the_applications_stream_untouched(amd):
+    """stripes_compute_correction takes its dither from the application's rand() stream in bulk (runtime.cpp: take_app_state): that
+    rests on glibc's TYPE_3 state layout, which the library checks once on a generator of its own.  Host code: no device needed."""
+    import ctypes as C
+    libc = C.CDLL(None)
+    libc.srand(77)
+    want = [libc.rand() for _ in range(50)]
+    libc.srand(77)
+    head = [libc.rand() for _ in range(7)]
+    amd.mlvfs_amd_test_rand_layout.restype = C.c_int
+    assert amd.mlvfs_amd_test_rand_layout() == 1          # glibc here; 0 would mean the call-by-call path (still correct, 300 ms)
+    assert amd.mlvfs_amd_test_rand_layout() == 1
+    assert head + [libc.rand() for _ in range(43)] == want
+
+
 def test_stripes_solve_matches_oracle(amd, oracle):
     from mlvfs_amd import synth
     f = synth.normal_frame(256, 130)
