@@ -20,6 +20,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace mlv {
@@ -29,31 +30,56 @@ constexpr int EVR = 32768, N20 = 1 << 20;
 // ------------------------------------------------------------------ host tables
 struct HostLut {                 // one per consumer function of the reference
     int black = -1;
+    int built_white = -1;                // the white level the table was built with (not part of its key: hdr.c:833)
     unsigned version = 0;
     std::vector<int> raw2ev, ev2raw;     // ev2raw[0] is EV index -10*32768
 };
+
+// Independent entries over [0, n) on a few host threads: the 2^20-entry tables of a black level are 1.8 M calls of log2 / pow per
+// consumer (a conversion's first call in a process: 64 ms on one thread, and again whenever a clip brings another black level).
+template <typename F> static void table_rows(int n, F fn)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (int)std::min<unsigned>(8, hw ? hw : 1);
+    if (nt <= 1 || n < (1 << 14)) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    const int per = (n + nt - 1) / nt;
+    for (int t = 1; t < nt; t++) { const int a = t * per, b = std::min(n, a + per); if (a < b) th.emplace_back([=] { fn(a, b); }); }
+    fn(0, std::min(n, per));
+    for (auto &x : th) x.join();
+}
 
 static void host_lut_build(HostLut &L, int black, int white)          // hdr.c:839-874
 {
     L.raw2ev.resize(N20);
     L.ev2raw.resize(24 * EVR);
+    int *raw2ev = L.raw2ev.data();
     int *ev2raw = L.ev2raw.data() + 10 * EVR;
-    for (int i = 0; i < N20; i++) {
-        double signal = i / 64.0 - black / 64.0;
-        if (signal < -1023) signal = -1023;
-        L.raw2ev[i] = signal > 0 ? (int)round(log2(1 + signal) * EVR) : -(int)round(log2(1 - signal) * EVR);
-    }
-    for (int i = -10 * EVR; i < 0; i++) {
-        const double v = black + 64 - round(64 * pow(2, (double)-i / EVR));
-        ev2raw[i] = (int)(v < 0 ? 0 : (v > black ? black : v));
-    }
-    for (int i = 0; i < 14 * EVR; i++) {
-        const double v = black - 64 + round(64 * pow(2, (double)i / EVR));
-        ev2raw[i] = (int)(v < black ? black : (v > N20 - 1 ? N20 - 1 : v));
-        if (i >= L.raw2ev[white]) ev2raw[i] = std::max(ev2raw[i], white);
-    }
-    ev2raw[L.raw2ev[0]] = 0;
+    table_rows(N20, [=](int a, int b) {
+        for (int i = a; i < b; i++) {
+            double signal = i / 64.0 - black / 64.0;
+            if (signal < -1023) signal = -1023;
+            raw2ev[i] = signal > 0 ? (int)round(log2(1 + signal) * EVR) : -(int)round(log2(1 - signal) * EVR);
+        }
+    });
+    table_rows(10 * EVR, [=](int a, int b) {
+        for (int k = a; k < b; k++) {
+            const int i = k - 10 * EVR;
+            const double v = black + 64 - round(64 * pow(2, (double)-i / EVR));
+            ev2raw[i] = (int)(v < 0 ? 0 : (v > black ? black : v));
+        }
+    });
+    const int ev_white = raw2ev[white];
+    table_rows(14 * EVR, [=](int a, int b) {
+        for (int i = a; i < b; i++) {
+            const double v = black - 64 + round(64 * pow(2, (double)i / EVR));
+            ev2raw[i] = (int)(v < black ? black : (v > N20 - 1 ? N20 - 1 : v));
+            if (i >= ev_white) ev2raw[i] = std::max(ev2raw[i], white);
+        }
+    });
+    ev2raw[raw2ev[0]] = 0;
     L.black = black;
+    L.built_white = white;
     L.version++;
 }
 
@@ -129,21 +155,30 @@ static int prepare_tables(int device, int black, int white, int interp_method, D
     const int ik = interp_method == 0 ? 3 : 0;
     for (int k = 0; k < 4; k++) {
         if ((k == 0 || k == 3) && k != ik) continue;
-        if (H[k]->black != black) host_lut_build(*H[k], black, white);       // white is not part of the key
+        if (H[k]->black != black) {                                          // white is not part of the key
+            const HostLut *same = nullptr;                                   // (a table another consumer built from the same two levels)
+            for (int j = 0; j < 4; j++)
+                if (j != k && H[j]->black == black && H[j]->built_white == white) same = H[j];
+            if (same) { H[k]->raw2ev = same->raw2ev; H[k]->ev2raw = same->ev2raw; H[k]->black = black; H[k]->built_white = white; H[k]->version++; }
+            else host_lut_build(*H[k], black, white);
+        }
         int rc = upload_lut(T, k, *H[k]);
         if (rc) return rc;
     }
     if (g_curves.black != black) {
         g_curves.fullres.resize(N20);
         g_curves.log2sig.resize(N20);
-        for (int i = 0; i < N20; i++) {
-            const double sig = i / 64.0 - black / 64.0;
-            const double ev2 = log2(sig > 1 ? sig : 1);
-            g_curves.log2sig[i] = ev2;
-            double t = ev2 - 4;
-            t = t < 0 ? 0 : (t > 4 ? 4 : t);
-            g_curves.fullres[i] = (-cos(t * M_PI / 4) + 1) / 2;
-        }
+        double *const c_log2sig = g_curves.log2sig.data(), *const c_fullres = g_curves.fullres.data();
+        table_rows(N20, [=](int a, int b) {
+            for (int i = a; i < b; i++) {
+                const double sig = i / 64.0 - black / 64.0;
+                const double ev2 = log2(sig > 1 ? sig : 1);
+                c_log2sig[i] = ev2;
+                double t = ev2 - 4;
+                t = t < 0 ? 0 : (t > 4 ? 4 : t);
+                c_fullres[i] = (-cos(t * M_PI / 4) + 1) / 2;
+            }
+        });
         int thr = N20;
         for (int i = N20 - 1; i >= 0 && g_curves.fullres[i] > 0.8; i--) thr = i;
         for (int i = 0; i < thr; i++)
