@@ -58,6 +58,41 @@ def test_process_frame_from_many_threads(gpu, oracle):
     gpu.stripes_free_corrections()
 
 
+def test_concurrent_stripes_analyses_share_the_applications_rand_stream(gpu, oracle):
+    """Several clips' first frames at once: each takes its dither from the application's libc generator (in bulk: clip.cpp,
+    runtime.cpp take_app_state / put_app_state).  Which clip gets which stretch of the stream depends on who comes first -- in the
+    reference too -- but no stretch may be handed out twice: afterwards the stream stands where the same analyses one after the
+    other leave it, and each clip's coefficients are those of SOME order's stretch."""
+    import ctypes as C
+    w, h, n = 416, 264, 6
+    libc = C.CDLL(None)
+    frames = [synth.normal_frame(w, h, seed=40 + t) for t in range(n)]
+    libc.srand(9)
+    for f in frames:
+        oracle.stripes_compute(f, BLACK, WHITE, reseed=False)
+    want_next = [libc.rand() for _ in range(8)]
+    libc.srand(9)
+    corrs = [gpu.stripes_new_correction(f"conc{t}.MLV".encode()) for t in range(n)]
+    start, errors = threading.Barrier(n), []
+
+    def worker(t):
+        try:
+            fh = abi.make_frame_headers(w, h, black=BLACK, white=WHITE)
+            start.wait()
+            gpu.stripes_compute_correction(C.byref(fh), corrs[t], lib.ptr(frames[t]), 0, frames[t].size)
+        except Exception as e:  # pragma: no cover
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert [libc.rand() for _ in range(8)] == want_next
+    gpu.stripes_free_corrections()
+
+
 def test_dual_iso_from_many_threads(gpu, oracle):
     """The 20-bit tables are process-global caches (like the reference's function statics, but locked)."""
     w, h, nthreads = 136, 72, 6
