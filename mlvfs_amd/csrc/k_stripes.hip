@@ -16,6 +16,7 @@
 //    a bin edge is not binned on the device: it is appended to a small "recheck"
 //    list and the host bins it with its own libm (mlvfs_amd_stripes_* in clip.cpp).
 #include "clip.h"
+#include <algorithm>
 
 namespace mlv {
 
@@ -125,60 +126,82 @@ int launch_hist_bump(int *d_hist, const int *d_idx, int n, hipStream_t stream)
 
 size_t stripes_hist_copies_bytes() { return (size_t)HIST_COPIES * 8 * 65536 * sizeof(int); }
 
-// pass 2: histogram
-__global__ __launch_bounds__(256) void k_stripes_hist(const uint16_t *__restrict__ img, int w, int row0, int groups_per_row,
-                                                      int n_groups, int black, double too_bright,
-                                                      const unsigned char *__restrict__ counts,
-                                                      const long long *__restrict__ block_off,
-                                                      const uint16_t *__restrict__ rnd, long long n_rand,
-                                                      int *__restrict__ hist, int *__restrict__ num,
-                                                      Recheck *__restrict__ recheck, int recheck_cap, int *__restrict__ n_recheck)
+// pass 2: histogram.  The bins that matter sit within a few thousand of 32768 (ratios of neighbouring pixels): 4.7 M atomic adds of
+// a 3584x1320 frame on a few hundred addresses took 650 us even spread over 16 copies in memory.  Each workgroup -- 1024 threads,
+// one per CU: four blocks of 256 groups per round, the blocks of pass 1 -- now counts the window [32768 - LWIN/2, 32768 + LWIN/2) of
+// all eight histograms in 16-bit counters in LDS (a workgroup sees at most n_groups * 24 / gridDim.x < 65 536 calls: launcher) and
+// adds what it touched to its copy at the end; bins outside the window go to memory directly as before.
+constexpr int LWIN = 8192, LWIN_LO = 32768 - LWIN / 2;
+__global__ __launch_bounds__(1024) void k_stripes_hist(const uint16_t *__restrict__ img, int w, int row0, int groups_per_row,
+                                                       int n_groups, int nblk, int black, double too_bright,
+                                                       const unsigned char *__restrict__ counts,
+                                                       const long long *__restrict__ block_off,
+                                                       const uint16_t *__restrict__ rnd, long long n_rand,
+                                                       int *__restrict__ hist, int *__restrict__ num,
+                                                       Recheck *__restrict__ recheck, int recheck_cap, int *__restrict__ n_recheck)
 {
-    __shared__ int wtot[4];
+    __shared__ unsigned cnt[8 * LWIN / 2];                        // two 16-bit counters per word
+    __shared__ int wtot[4][4];
     __shared__ int lnum[8];
+    for (int i = threadIdx.x; i < 8 * LWIN / 2; i += 1024) cnt[i] = 0;
     if (threadIdx.x < 8) lnum[threadIdx.x] = 0;
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    const int c = g < n_groups ? counts[g] : 0;
-    int inc = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(inc, o);
-        if ((threadIdx.x & 63) >= o) inc += up;
-    }
-    if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
     __syncthreads();
-    long long call = block_off[blockIdx.x] + (inc - c);          // accepted calls before this group
-    for (int k = 0; k < (int)(threadIdx.x >> 6); k++) call += wtot[k];
-
-    if (g < n_groups && c > 0) {
-        const int y = row0 + g / groups_per_row, x = (g % groups_per_row) * 8;
-        int px[10];
-        load_group(img + (size_t)y * w, x, black, px);
+    int *const mine = hist + (size_t)(blockIdx.x % HIST_COPIES) * (8 * 65536);
+    const int sub = threadIdx.x >> 8, lt = threadIdx.x & 255;
+    for (int b0 = blockIdx.x * 4; b0 < nblk; b0 += gridDim.x * 4) {
+        const int blk = b0 + sub;
+        const int g = blk * 256 + lt;
+        const int c = (blk < nblk && g < n_groups) ? counts[g] : 0;
+        int inc = c;
 #pragma unroll
-        for (int i = 0; i < 24; i++) {
-            const int j = k_call[i][0], a = px[k_call[i][1]], b = px[k_call[i][2]];
-            if (!accepted(a, b, too_bright)) continue;
-            const long long ri = 2 * call;
-            call++;
-            if (ri + 1 >= n_rand) continue;                         // host sized the stream; never taken
-            const int r1 = rnd[ri], r2 = rnd[ri + 1];
-            const double af = a + r1 / 1024.0 - 0.5;               // stripes.c:129-130
-            const double bf = b + r2 / 1024.0 - 0.5;
-            const double ev = log2(af / bf);
-            const double pos = 65536 / 2 + ev * 65536 / 2;          // F2H, stripes.c:105
-            const double nearest = rint(pos);
-            if (fabs(pos - nearest) < 1e-6) {
-                const int slot = atomicAdd(n_recheck, 1);
-                if (slot < recheck_cap) recheck[slot] = Recheck{ j, a, b, r1, r2 };
-            } else {
-                int bin = (int)pos;
-                bin = bin < 0 ? 0 : (bin > 65535 ? 65535 : bin);
-                atomicAdd(&hist[(size_t)(blockIdx.x % HIST_COPIES) * (8 * 65536) + j * 65536 + bin], 1);
-            }
-            atomicAdd(&lnum[j], 1);
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(inc, o);
+            if ((lt & 63) >= o) inc += up;
         }
+        if ((lt & 63) == 63) wtot[sub][lt >> 6] = inc;
+        __syncthreads();
+        long long call = (blk < nblk ? block_off[blk] : 0) + (inc - c);      // accepted calls before this group
+        for (int k = 0; k < (int)(lt >> 6); k++) call += wtot[sub][k];
+        if (c > 0) {
+            const int y = row0 + g / groups_per_row, x = (g % groups_per_row) * 8;
+            int px[10];
+            load_group(img + (size_t)y * w, x, black, px);
+#pragma unroll
+            for (int i = 0; i < 24; i++) {
+                const int j = k_call[i][0], a = px[k_call[i][1]], b = px[k_call[i][2]];
+                if (!accepted(a, b, too_bright)) continue;
+                const long long ri = 2 * call;
+                call++;
+                if (ri + 1 >= n_rand) continue;                         // host sized the stream; never taken
+                const int r1 = rnd[ri], r2 = rnd[ri + 1];
+                const double af = a + r1 / 1024.0 - 0.5;               // stripes.c:129-130
+                const double bf = b + r2 / 1024.0 - 0.5;
+                const double ev = log2(af / bf);
+                const double pos = 65536 / 2 + ev * 65536 / 2;          // F2H, stripes.c:105
+                const double nearest = rint(pos);
+                if (fabs(pos - nearest) < 1e-6) {
+                    const int slot = atomicAdd(n_recheck, 1);
+                    if (slot < recheck_cap) recheck[slot] = Recheck{ j, a, b, r1, r2 };
+                } else {
+                    int bin = (int)pos;
+                    bin = bin < 0 ? 0 : (bin > 65535 ? 65535 : bin);
+                    const unsigned rel = (unsigned)(bin - LWIN_LO);
+                    if (rel < (unsigned)LWIN) atomicAdd(&cnt[j * (LWIN / 2) + (rel >> 1)], 1u << (16 * (rel & 1)));
+                    else atomicAdd(&mine[j * 65536 + bin], 1);
+                }
+                atomicAdd(&lnum[j], 1);
+            }
+        }
+        __syncthreads();                                              // wtot is rewritten in the next round
     }
     __syncthreads();
+    for (int i = threadIdx.x; i < 8 * LWIN / 2; i += 1024) {
+        const unsigned v = cnt[i];
+        if (!v) continue;
+        const int j = i / (LWIN / 2), rel = 2 * (i % (LWIN / 2));
+        if (v & 0xFFFFu) atomicAdd(&mine[j * 65536 + LWIN_LO + rel], (int)(v & 0xFFFFu));
+        if (v >> 16) atomicAdd(&mine[j * 65536 + LWIN_LO + rel + 1], (int)(v >> 16));
+    }
     if (threadIdx.x < 8 && lnum[threadIdx.x]) atomicAdd(&num[threadIdx.x], lnum[threadIdx.x]);
 }
 
@@ -239,7 +262,13 @@ int launch_stripes_hist(const void *d_frame, int w, int row0, int row1, int blac
     if (n_groups <= 0) return MLVFS_AMD_OK;
     const int nblk = (n_groups + 255) / 256;
     MLV_HIP(hipMemsetAsync(d_copies, 0, stripes_hist_copies_bytes(), stream));
-    hipLaunchKernelGGL(k_stripes_hist, dim3(nblk), dim3(256), 0, stream, (const uint16_t *)d_frame, w, row0, gpr, n_groups,
+    // one workgroup per CU (its counters fill the LDS), but never so few that one could see 65 536 calls (16-bit counters)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+    const int quads = (nblk + 3) / 4;                             // (a histogram gets at most 4 calls per group: k_call)
+    int wgs = std::min(quads, cus);
+    while ((long long)((quads + wgs - 1) / wgs) * 4 * 256 * 4 >= 65536 && wgs < quads) wgs = std::min(quads, wgs * 2);
+    hipLaunchKernelGGL(k_stripes_hist, dim3(wgs), dim3(1024), 0, stream, (const uint16_t *)d_frame, w, row0, gpr, n_groups, nblk,
                        black, white / 1.5, d_counts, d_block_off, (const uint16_t *)d_rand, n_rand, (int *)d_copies, d_num,
                        (Recheck *)d_recheck, recheck_cap, d_n_recheck);
     hipLaunchKernelGGL(k_stripes_hist_fold, dim3(8 * 65536 / 256), dim3(256), 0, stream, (const int *)d_copies, d_hist);
@@ -274,18 +303,21 @@ int launch_stripes_apply(void *d_frames, size_t stride, size_t npix, int w, int 
 // with the 31-word ring in registers (31 unrolled steps per round), eight values per 16-byte store.
 namespace mlv {
 
+// One workgroup per RAND_GROUP consecutive chunks: the state at the group's first chunk by the set bits of its index (up to npow
+// products with the host-built powers), the states of the chunks behind it by one product each with the first power (A^RAND_CHUNK) --
+// a workgroup per chunk repeated the long walk for every chunk (9 500 chunks of a 3584x1320 frame's dither: 150 us; now 10).
+constexpr int RAND_GROUP = 32;
 __global__ __launch_bounds__(32) void k_rand_states(const uint32_t *__restrict__ start, const uint32_t *__restrict__ pow2 /* [j][31][31] */,
                                                     int npow, uint32_t nchunks, uint32_t *__restrict__ states)
 {
-    const uint32_t c = blockIdx.x;
-    if (c >= nchunks) return;
+    const uint32_t c0 = blockIdx.x * RAND_GROUP;
+    if (c0 >= nchunks) return;
     __shared__ uint32_t v[2][32];
     const int i = threadIdx.x;
     if (i < 31) v[0][i] = start[i];
     __syncthreads();
     int cur = 0;
-    for (int j = 0; j < npow; j++) {
-        if (!((c >> j) & 1u)) continue;                     // uniform
+    auto times = [&](int j) {                                    // v <- pow2[j] * v
         if (i < 31) {
             const uint32_t *row = pow2 + ((size_t)j * 31 + i) * 31;
             uint32_t acc = 0;
@@ -294,8 +326,13 @@ __global__ __launch_bounds__(32) void k_rand_states(const uint32_t *__restrict__
         }
         __syncthreads();
         cur ^= 1;
+    };
+    for (int j = 0; j < npow; j++)
+        if ((c0 >> j) & 1u) times(j);                            // uniform
+    for (uint32_t c = c0; c < min(c0 + RAND_GROUP, nchunks); c++) {
+        if (i < 31) states[(size_t)c * 31 + i] = v[cur][i];
+        if (c + 1 < min(c0 + RAND_GROUP, nchunks)) times(0);
     }
-    if (i < 31) states[(size_t)c * 31 + i] = v[cur][i];
 }
 
 __global__ __launch_bounds__(256) void k_rand_fill(const uint32_t *__restrict__ states, uint32_t nchunks, uint16_t *__restrict__ out, size_t n)
@@ -335,7 +372,7 @@ int launch_rand_stream(const uint32_t *d_start, const uint32_t *d_pow2, int npow
                        size_t n, hipStream_t stream)
 {
     if (!nchunks) return MLVFS_AMD_OK;
-    hipLaunchKernelGGL(k_rand_states, dim3(nchunks), dim3(32), 0, stream, d_start, d_pow2, npow, nchunks, d_states);
+    hipLaunchKernelGGL(k_rand_states, dim3((nchunks + RAND_GROUP - 1) / RAND_GROUP), dim3(32), 0, stream, d_start, d_pow2, npow, nchunks, d_states);
     hipLaunchKernelGGL(k_rand_fill, dim3((nchunks + 255) / 256), dim3(256), 0, stream, (const uint32_t *)d_states, nchunks, d_out, n);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
