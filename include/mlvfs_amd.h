@@ -242,6 +242,10 @@ int lj92_decode(lj92 lj, uint16_t *target, int tlen, int skiplen, uint16_t *line
  * the reference would leave its own arrays (17-bit differences, all 17 classes in use, values beyond the table) or HIP fails. */
 int lj92_encode(uint16_t *image, int width, int height, int bitdepth, int readLength, int skipLength,
                 uint16_t *delinearize, int delinearizeLength, uint8_t **encoded, int *encodedLength);
+/* Optional (needs three changed lines in main.c): lj92_decode plus the untiling loop get_image_data runs behind it
+ * (main.c:646-667: 8-22 ms per 3584x1320 frame on a host core) in one call: xres x yres pixels in host memory, decoded and untiled
+ * on the GPU.  0, or the lj92.h error codes.                                                                             */
+int mlvfs_amd_lj92_decode_untiled(lj92 lj, uint16_t *dst, int xres, int yres);
 /* host-only test hook: the encoder's Huffman table for a histogram of the 17 classes; out[68] = bits[1..16], number of DHT
  * values, the 17 values, then length and code per class.  0, or -1 (error string set) where lj92_encode would refuse.          */
 int mlvfs_amd_lj92_encode_table(const uint32_t hist[17], int npix, int *out);

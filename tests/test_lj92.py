@@ -181,6 +181,27 @@ def dropin_decode(gpu, stream):
 
 
 @pytest.mark.gpu
+def test_decode_untiled_equals_decode_plus_the_callers_loop(gpu, oracle):
+    """mlvfs_amd_lj92_decode_untiled (optional: three changed lines in main.c) = lj92_decode + the untiling loop of main.c:646-667."""
+    import ctypes as C
+    for (w, h, seed) in ((256, 130, 9), (64, 48, 3), (1920, 1080, 5)):
+        f = synth.normal_frame(w, h, seed=seed)
+        q = quadrants(f)
+        for shape in ((h, w), (h // 2, w * 2)):
+            s = enc.encode(np.ascontiguousarray(q.reshape(shape)), 6, 14)
+            buf = np.frombuffer(s, np.uint8).copy()
+            hd = C.c_void_p()
+            w_, h_, b_ = C.c_int(), C.c_int(), C.c_int()
+            assert gpu.lj92_open(C.byref(hd), C.c_void_p(buf.ctypes.data), buf.size, C.byref(w_), C.byref(h_), C.byref(b_)) == 0
+            out = np.zeros((h, w), np.uint16)
+            gpu.mlvfs_amd_lj92_decode_untiled.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+            assert gpu.mlvfs_amd_lj92_decode_untiled(hd, C.c_void_p(out.ctypes.data), w, h) == 0
+            assert gpu.mlvfs_amd_lj92_decode_untiled(hd, C.c_void_p(out.ctypes.data), w + 2, h) == -1      # another geometry than the JPEG's
+            gpu.lj92_close(hd)
+            assert np.array_equal(out, f), (w, h, shape)
+
+
+@pytest.mark.gpu
 def test_dropin_lj92_symbols_equal_the_reference_decoder(gpu, oracle, reference):
     """lj92_open / lj92_decode / lj92_close of the library against the reference's (oracle/_ref builds lj92.c): dimensions, every
     value in the decoder's own order (main.c untiles afterwards), the reference encoder's streams in three JPEG shapes, every
