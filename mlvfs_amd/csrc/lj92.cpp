@@ -253,7 +253,8 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
     MLV_HIP(hipEventRecord(w.ready, s));
     // Sub-batches of frames alternate between two streams, so that the upload of one overlaps the kernels of the other.  The
     // entropy-coded bytes go straight from the caller's memory (page-locked when they come from the reader's staging).
-    const int SUB = nframes >= 8 ? 4 : (nframes + 1) / 2;
+    static const int sub_env = [] { const char *e = getenv("MLVFS_AMD_LJ92_SUB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();   // experiments
+    const int SUB = sub_env ? sub_env : (nframes >= 8 ? 4 : (nframes + 1) / 2);
     for (int j0 = 0, j = 0; j0 < nframes; j0 += SUB, j++) {
         const int n = std::min(SUB, nframes - j0);
         hipStream_t sj = w.sub[j & 1];
