@@ -43,19 +43,24 @@ constexpr int UNSTUFF_BYTES = 16;                       // bytes per thread in t
 __device__ __forceinline__ uint32_t bswap(uint32_t v) { return __builtin_bswap32(v); }
 
 // ---------------------------------------------------------------- byte unstuffing (0xFF 0x00 -> 0xFF)
-// a byte is dropped iff it is 0x00 and the byte before it is 0xFF (lj92.c:358-370)
-__device__ __forceinline__ int dropped_in(const uint8_t *raw, uint32_t len, uint32_t p0, uint32_t *keep_mask)
+// a byte is dropped iff it is 0x00 and the byte before it is 0xFF (lj92.c:358-370).  A thread's 16 bytes arrive as ONE 16-byte load
+// (the raw segment is 256-byte aligned in the arena and has 16 bytes of room behind its end; byte loads made the two kernels below
+// 33 + 75 us per four 3584x1320 frames, a sixth of the whole decode).
+__device__ __forceinline__ int dropped_in(const uint8_t *raw, uint32_t len, uint32_t p0, uint32_t *keep_mask, uint4 *bytes)
 {
+    const uint4 v = *(const uint4 *)(raw + p0);
+    *bytes = v;
+    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
     int n = 0;
     uint32_t mask = 0;
-    uint8_t prev = p0 ? raw[p0 - 1] : 0;
+    uint32_t prev = p0 ? raw[p0 - 1] : 0;
+#pragma unroll
     for (int i = 0; i < UNSTUFF_BYTES; i++) {
-        const uint32_t p = p0 + i;
-        if (p >= len) break;
-        const uint8_t b = raw[p];
-        const bool drop = b == 0 && prev == 0xFF;
+        const uint32_t b = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        const bool in = p0 + i < len;
+        const bool drop = in && b == 0 && prev == 0xFF;
         n += drop;
-        mask |= (drop ? 0u : 1u) << i;
+        mask |= ((in && !drop) ? 1u : 0u) << i;
         prev = b;
     }
     *keep_mask = mask;
@@ -68,13 +73,13 @@ __global__ __launch_bounds__(256) void k_lj_unstuff_count(const LjFrame *frames)
     const uint32_t p0 = (blockIdx.x * 256u + threadIdx.x) * UNSTUFF_BYTES;
     if (blockIdx.x * 256u * UNSTUFF_BYTES >= f.raw_len) return;
     uint32_t mask;
-    int n = p0 < f.raw_len ? dropped_in(f.raw, f.raw_len, p0, &mask) : 0;
-    __shared__ int total;
-    if (threadIdx.x == 0) total = 0;
+    uint4 bytes;
+    int n = p0 < f.raw_len ? dropped_in(f.raw, f.raw_len, p0, &mask, &bytes) : 0;
+    for (int o = 32; o; o >>= 1) n += __shfl_down(n, o);
+    __shared__ int wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
     __syncthreads();
-    if (n) atomicAdd(&total, n);
-    __syncthreads();
-    if (threadIdx.x == 0) f.blk_drop[blockIdx.x] = (uint32_t)total;
+    if (threadIdx.x == 0) f.blk_drop[blockIdx.x] = (uint32_t)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
 }
 
 // exclusive scan of the per-block drop counts (a few hundred to a few thousand values per frame)
@@ -98,34 +103,51 @@ __global__ __launch_bounds__(256) void k_lj_unstuff_scan(const LjFrame *frames)
     for (uint32_t b = b0; b < b1; b++) { const uint32_t v = f.blk_drop[b]; f.blk_drop[b] = run; run += v; }
 }
 
+// The kept bytes of a workgroup's 4 KiB go through LDS -- placed so that LDS dwords and the dwords of the destination line up (the
+// destination starts wherever the drops before this block put it) -- and leave as whole dwords, lane after lane; only a block's
+// first and last dword, which it may share with its neighbours, are written byte by byte.
 __global__ __launch_bounds__(256) void k_lj_unstuff_scatter(const LjFrame *frames)
 {
     const LjFrame &f = frames[blockIdx.y];
-    if (blockIdx.x * 256u * UNSTUFF_BYTES >= f.raw_len) {
+    constexpr uint32_t BLK = 256u * UNSTUFF_BYTES;
+    if (blockIdx.x * BLK >= f.raw_len) {
         // the first idle workgroup clears the look-ahead tail behind the unstuffed data
-        if ((blockIdx.x - 1) * 256u * UNSTUFF_BYTES < f.raw_len || f.raw_len == 0) {
+        if ((blockIdx.x - 1) * BLK < f.raw_len || f.raw_len == 0) {
             const uint32_t n = *f.ust_len;
             for (uint32_t i = threadIdx.x; i < LJ_TAIL; i += 256) f.ust[n + i] = 0;
         }
         return;
     }
+    __shared__ uint32_t stage32[BLK / 4 + 2];
+    __shared__ uint32_t wsum[4];
+    uint8_t *const stage = (uint8_t *)stage32;
     const uint32_t p0 = (blockIdx.x * 256u + threadIdx.x) * UNSTUFF_BYTES;
     uint32_t mask = 0;
-    const int n = p0 < f.raw_len ? dropped_in(f.raw, f.raw_len, p0, &mask) : 0;
-    __shared__ uint32_t sc[256];
-    sc[threadIdx.x] = (uint32_t)n;
+    uint4 bytes = make_uint4(0, 0, 0, 0);
+    const int n = p0 < f.raw_len ? dropped_in(f.raw, f.raw_len, p0, &mask, &bytes) : 0;
+    uint32_t inc = (uint32_t)n;                          // inclusive scan of the 256 drop counts: within the wave, then over the four waves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+    if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {                  // inclusive scan of 256 small counts
-        const uint32_t v = threadIdx.x >= (unsigned)d ? sc[threadIdx.x - d] : 0;
-        __syncthreads();
-        sc[threadIdx.x] += v;
-        __syncthreads();
-    }
-    if (p0 >= f.raw_len) return;
-    uint32_t dst = p0 - (f.blk_drop[blockIdx.x] + sc[threadIdx.x] - (uint32_t)n);
-    for (int i = 0; i < UNSTUFF_BYTES; i++) {
-        if (p0 + i >= f.raw_len) break;
-        if ((mask >> i) & 1u) f.ust[dst++] = f.raw[p0 + i];
+    for (int k = 0; k < wave; k++) inc += wsum[k];
+    const uint32_t dst_base = blockIdx.x * BLK - f.blk_drop[blockIdx.x];       // where this block's first kept byte goes
+    const uint32_t mis = dst_base & 3u;
+    uint32_t at = mis + threadIdx.x * UNSTUFF_BYTES - (inc - (uint32_t)n);     // in the staging buffer
+    const uint32_t w[4] = { bytes.x, bytes.y, bytes.z, bytes.w };
+#pragma unroll
+    for (int i = 0; i < UNSTUFF_BYTES; i++)
+        if ((mask >> i) & 1u) stage[at++] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+    const uint32_t valid = min(BLK, f.raw_len - blockIdx.x * BLK);
+    const uint32_t kept = valid - (wsum[0] + wsum[1] + wsum[2] + wsum[3]);     // bytes this block writes: stage[mis .. mis + kept)
+    __syncthreads();
+    uint32_t *const out32 = (uint32_t *)(f.ust + (dst_base - mis));
+    const uint32_t ndw = (mis + kept + 3) / 4;
+    for (uint32_t k = threadIdx.x; k < ndw; k += 256) {
+        const uint32_t lo = 4 * k, hi = lo + 4;
+        if (lo >= mis && hi <= mis + kept) out32[k] = stage32[k];
+        else
+            for (uint32_t q = max(lo, mis); q < min(hi, mis + kept); q++) f.ust[dst_base - mis + q] = stage[q];
     }
 }
 
