@@ -1,0 +1,698 @@
+// k_frame_p.hip -- the packed-once kernel of the fused pass (round 5); launched by k_frame.hip's launch_frame_t before the
+// list-mode k_frame.  Its own translation unit: its own scheduler flags (Makefile), and the two kernels compile in parallel.
+#include "k_frame_dev.h"
+
+namespace mlv {
+
+#ifndef KF_P_WAIT_MIN
+#define KF_P_WAIT_MIN 1
+#endif
+#ifndef KF_P_WAIT_MAX
+#define KF_P_WAIT_MAX 15
+#endif
+// ================================================================ packed-once kernel (round 5)
+// k_frame_p: the same pass with the colour differences packed ONCE, by the loader.
+//
+// k_frame keeps (dr, db) of a cell as two int32 planes and every median lane packs what it reads -- each cell five times (the
+// five lanes whose windows hold it), relative to a reference of the lane's own, and what a lane takes from its neighbour is rebased
+// by the difference of their references: 181 of the 417 vector instructions of a strip were packing, rebasing, hand-over and
+// certainty tests.  Here a TILE has one reference (ref_r, ref_b) and the loader stores
+//     pk = { sat16(dr - ref_r), sat16(db - ref_b) }                                      one dword per cell, one plane
+// so a median lane reads half the LDS, packs nothing and rebases nothing.  Exactness is the rule k_frame derives above ChainGroup
+// with D = 0: both saturations are monotone, so the packed median is sat16(true median - ref), which IS the true median - ref
+// whenever it comes out strictly inside (-32768, 32767); a strip where it does not is "uncertain".
+//
+// This kernel never settles an uncertain strip itself (that takes the int32 planes it no longer has): a tile with one is pushed on
+// the launch's work list and done again, whole, by k_frame in list mode -- the launch that follows on the same stream.  Tiles after
+// such a tile go to the list unseen (1, 3, 7, 15 tiles, doubling while the tile after them is no better: footage made of hard colour
+// edges costs this kernel a sixteenth of its tiles), a stray one costs itself and nothing else.
+//
+// The reference.  Any reference gives exact medians; it only decides how many strips are certain.  A run's first tile (and every
+// tile that does not continue the one above) takes the median of three cells at the tile's centre, fetched and converted by every
+// wave for itself (16 lanes, one pixel each; scalar arithmetic from there: no exchange, no barrier); the tiles below it keep that
+// reference, so the four plane rows they inherit stay valid as they are.
+template <bool SPREAD_, bool CHAIN_>
+struct __align__(16) SmemP {
+    static constexpr bool SPREAD = SPREAD_;
+    uint16_t raw[2 * RH][2 * TCW];      // interior pixels (post patch) + the four pixel rows below (the next tile's first), 8.5 KiB
+    uint32_t pk[PH][PW];                // 5 KiB
+    int ge[RH][TCW];                    // 4.25 KiB
+    uint16_t t16[MLV_T16_N + (SPREAD_ ? 64 : 0)];
+    uint32_t has_patch[PMAP_WORDS];
+    uint32_t xchg[CHAIN_ ? 3 : 1][XCHG_WORDS];
+    int unc[2];                         // some strip of this tile / of the tile before is uncertain (by tile parity)
+    int low[2];                         // some pixel this tile / the tile before loaded lies at most 64 above black
+    int next_tile, next_end;
+    int walk[5];                        // thread 0's: first tile of the group's range, tiles that go out in runs, tiles per run, group, runs all out
+};
+
+struct PGroup {
+    mlv_pk16 s[4][5];        // sorted columns
+    mlv_pk16 p0[10], p1[10]; // columns 0+1 and 2+3 merged
+    mlv_pk16 q[6];           // ranks 8..13 of the 20
+};
+struct PNext { mlv_pk16 s0[5], s2[5], p0[10], q[6]; };
+
+__device__ __forceinline__ mlv_pk16 as_pk(uint32_t v) { return __builtin_bit_cast(mlv_pk16, v); }
+__device__ __forceinline__ uint32_t as_u(mlv_pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+
+__device__ __forceinline__ void pchain_group(const uint32_t (*pk)[PW], int row_top, int col_left, PGroup &g)
+{
+    mlv_pk16 col[4][5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const uint4 v = *(const uint4 *)&pk[row_top + r][col_left];
+        col[0][r] = as_pk(v.x); col[1][r] = as_pk(v.y); col[2][r] = as_pk(v.z); col[3][r] = as_pk(v.w);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) mlv_sort5(col[c], g.s[c]);
+    mlv_merge55(g.s[0], g.s[1], g.p0);
+    mlv_merge55(g.s[2], g.s[3], g.p1);
+}
+__device__ __forceinline__ void pchain_fetch_lists(const PGroup &g, PNext &n)
+{
+#pragma unroll
+    for (int i = 0; i < 5; i++) { n.s0[i] = dpp_next(g.s[0][i]); n.s2[i] = dpp_next(g.s[2][i]); }
+#pragma unroll
+    for (int i = 0; i < 10; i++) n.p0[i] = dpp_next(g.p0[i]);
+}
+__device__ __forceinline__ void pchain_fetch_window(const PGroup &g, PNext &n)
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++) n.q[i] = dpp_next(g.q[i]);
+}
+// the halo group's lane (and the first lane of waves 1..3) -> LDS -> the last lane of the wave before
+__device__ __forceinline__ void pchain_publish(const PGroup &g, uint32_t *x)
+{
+    uint4 *o = (uint4 *)x;
+    o[0] = make_uint4(as_u(g.s[0][0]), as_u(g.s[0][1]), as_u(g.s[0][2]), as_u(g.s[0][3]));
+    o[1] = make_uint4(as_u(g.s[0][4]), as_u(g.s[2][0]), as_u(g.s[2][1]), as_u(g.s[2][2]));
+    o[2] = make_uint4(as_u(g.s[2][3]), as_u(g.s[2][4]), as_u(g.p0[0]), as_u(g.p0[1]));
+    o[3] = make_uint4(as_u(g.p0[2]), as_u(g.p0[3]), as_u(g.p0[4]), as_u(g.p0[5]));
+    o[4] = make_uint4(as_u(g.p0[6]), as_u(g.p0[7]), as_u(g.p0[8]), as_u(g.p0[9]));
+    o[5] = make_uint4(as_u(g.q[0]), as_u(g.q[1]), as_u(g.q[2]), as_u(g.q[3]));
+    *(uint2 *)&o[6] = make_uint2(as_u(g.q[4]), as_u(g.q[5]));
+}
+__device__ __forceinline__ void pchain_collect_lists(const uint32_t *x, PNext &n)
+{
+    const uint4 *o = (const uint4 *)x;
+    const uint4 a0 = o[0], a1 = o[1], a2 = o[2], a3 = o[3], a4 = o[4];
+    n.s0[0] = as_pk(a0.x); n.s0[1] = as_pk(a0.y); n.s0[2] = as_pk(a0.z); n.s0[3] = as_pk(a0.w); n.s0[4] = as_pk(a1.x);
+    n.s2[0] = as_pk(a1.y); n.s2[1] = as_pk(a1.z); n.s2[2] = as_pk(a1.w); n.s2[3] = as_pk(a2.x); n.s2[4] = as_pk(a2.y);
+    n.p0[0] = as_pk(a2.z); n.p0[1] = as_pk(a2.w); n.p0[2] = as_pk(a3.x); n.p0[3] = as_pk(a3.y); n.p0[4] = as_pk(a3.z);
+    n.p0[5] = as_pk(a3.w); n.p0[6] = as_pk(a4.x); n.p0[7] = as_pk(a4.y); n.p0[8] = as_pk(a4.z); n.p0[9] = as_pk(a4.w);
+}
+__device__ __forceinline__ void pchain_collect_window(const uint32_t *x, PNext &n)
+{
+    const uint4 a5 = *(const uint4 *)(x + 20);
+    const uint2 a6 = *(const uint2 *)(x + 24);
+    n.q[0] = as_pk(a5.x); n.q[1] = as_pk(a5.y); n.q[2] = as_pk(a5.z); n.q[3] = as_pk(a5.w); n.q[4] = as_pk(a6.x); n.q[5] = as_pk(a6.y);
+}
+// medians of the strip's four cells (relative to the tile's reference) from its own group and the neighbour's
+__device__ __forceinline__ void pchain_finish(const PGroup &g, const PNext &n, mlv_pk16 (&o)[STRIP])
+{
+    mlv_pk16 q1[6], t[1];
+    mlv_quad_mid6(g.p1, n.p0, q1);
+    mlv_final6of11(g.q, n.s0, t);  o[0] = t[0];      // window columns 0..3 | 4
+    mlv_final6of11(q1, g.s[1], t); o[1] = t[0];      // 2..5 | 1
+    mlv_final6of11(q1, n.s2, t);   o[2] = t[0];      // 2..5 | 6
+    mlv_final6of11(n.q, g.s[3], t); o[3] = t[0];     // 4..7 | 3
+}
+// plus-shaped 5 (chroma_smooth.c:44-47 with CHROMA_SMOOTH_2X2) and 3x3 on the packed plane: the strip's cells are plane columns
+// col0 + 2 .. col0 + 5 (col0 = 4 k: the halo is two cells), their rows jrow + 1 .. jrow + 3
+__device__ __forceinline__ void pstrip_median5(const uint32_t (*pk)[PW], int jrow, int col0, mlv_pk16 (&o)[STRIP])
+{
+    const uint2 u0 = *(const uint2 *)&pk[jrow + 1][col0 + 2], u1 = *(const uint2 *)&pk[jrow + 1][col0 + 4];
+    const uint4 c0 = *(const uint4 *)&pk[jrow + 2][col0], c1 = *(const uint4 *)&pk[jrow + 2][col0 + 4];
+    const uint2 d0 = *(const uint2 *)&pk[jrow + 3][col0 + 2], d1 = *(const uint2 *)&pk[jrow + 3][col0 + 4];
+    const uint32_t up[4] = { u0.x, u0.y, u1.x, u1.y }, dn[4] = { d0.x, d0.y, d1.x, d1.y };
+    const uint32_t ce[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+#pragma unroll
+    for (int c = 0; c < STRIP; c++) {
+        const mlv_pk16 v[5] = { as_pk(up[c]), as_pk(ce[c + 1]), as_pk(ce[c + 2]), as_pk(ce[c + 3]), as_pk(dn[c]) };
+        mlv_pk16 t[1];
+        mlv_median5(v, t);
+        o[c] = t[0];
+    }
+}
+__device__ __forceinline__ mlv_pk16 pk_med3(mlv_pk16 a, mlv_pk16 b, mlv_pk16 c) { return mlv_mx(mlv_mn(a, b), mlv_mn(mlv_mx(a, b), c)); }
+__device__ __forceinline__ void pstrip_median9(const uint32_t (*pk)[PW], int jrow, int col0, mlv_pk16 (&o)[STRIP])
+{
+    mlv_pk16 lo[STRIP + 2], mi[STRIP + 2], hi[STRIP + 2];
+    uint32_t v[3][8];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const uint4 a = *(const uint4 *)&pk[jrow + 1 + r][col0], b = *(const uint4 *)&pk[jrow + 1 + r][col0 + 4];
+        v[r][0] = a.x; v[r][1] = a.y; v[r][2] = a.z; v[r][3] = a.w; v[r][4] = b.x; v[r][5] = b.y; v[r][6] = b.z; v[r][7] = b.w;
+    }
+#pragma unroll
+    for (int c = 0; c < STRIP + 2; c++) {
+        const mlv_pk16 a = as_pk(v[0][c + 1]), b = as_pk(v[1][c + 1]), d = as_pk(v[2][c + 1]);
+        const mlv_pk16 mn = mlv_mn(a, b), mx = mlv_mx(a, b);
+        lo[c] = mlv_mn(mn, d);
+        hi[c] = mlv_mx(mx, d);
+        mi[c] = mlv_mx(mn, mlv_mn(mx, d));
+    }
+#pragma unroll
+    for (int c = 0; c < STRIP; c++)
+        o[c] = pk_med3(mlv_mx(mlv_mx(lo[c], lo[c + 1]), lo[c + 2]), pk_med3(mi[c], mi[c + 1], mi[c + 2]),
+                       mlv_mn(mlv_mn(hi[c], hi[c + 1]), hi[c + 2]));
+}
+// certain: every half of every median strictly inside (-32768, 32767).  t = v + 32767 (wraps) is in [0, 65533] exactly then;
+// the unsigned saturating t - 65533 is what is left over otherwise
+__device__ __forceinline__ bool pk_uncertain(const mlv_pk16 (&o)[STRIP])
+{
+    typedef unsigned short upk16 __attribute__((ext_vector_type(2)));
+    const upk16 off = { 32767, 32767 }, span = { 65533, 65533 };
+    upk16 excess = { 0, 0 };
+#pragma unroll
+    for (int c = 0; c < STRIP; c++) excess |= __builtin_elementwise_sub_sat(__builtin_bit_cast(upk16, o[c]) + off, span);
+    return __builtin_bit_cast(uint32_t, excess) != 0u;
+}
+
+// EV triples of NC cells on the loader's common path with the colour differences packed against the tile's reference
+template <int NC, bool SPREAD>
+__device__ __forceinline__ void cell_multi_pk_fast(const uint32_t *p0, const uint32_t *p1, int black, const uint16_t *t, int ref_r, int ref_b,
+                                                   int (&ge)[NC], uint32_t (&pk)[NC])
+{
+    int dr[NC], db[NC];
+    cell_multi_ev_fast<NC, SPREAD>(p0, p1, black, t, ge, dr, db);
+#pragma unroll
+    for (int c = 0; c < NC; c++)       // |dr|, |db|, |ref| < 2^20 here: the plain difference does not wrap
+        pk[c] = as_u(__builtin_amdgcn_cvt_pk_i16(dr[c] - ref_r, db[c] - ref_b));
+}
+
+template <int METHOD, class SM>
+__device__ __forceinline__ void emit_item_p(SM &sm, int black, bool dark, bool slow, int ref_r, int ref_b, int p, int lk, bool edge,
+                                            const uint32_t (&p0)[8], const uint32_t (&p1)[8])
+{
+    const int jj = p - HC;
+    const bool keep = !edge && jj >= 0;
+    int ge[4];
+    uint32_t pk[4];
+    if (!dark) cell_multi_pk_fast<4, SM::SPREAD>(p0, p1, black, sm.t16, ref_r, ref_b, ge, pk);
+    else {
+        int dr[4], db[4];
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+            int g2[2], r2[2], b2[2];
+            if (!slow) cell_multi_ev_dark<2, SM::SPREAD>(p0 + 2 * c, p1 + 2 * c, black, sm.t16, g2, r2, b2);
+            else cell_pair_ev<SM::SPREAD>(p0 + 2 * c, p1 + 2 * c, black, sm.t16, true, g2, r2, b2);
+            ge[c] = g2[0]; ge[c + 1] = g2[1]; dr[c] = r2[0]; dr[c + 1] = r2[1]; db[c] = b2[0]; db[c + 1] = b2[1];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++)    // (differences of wrapped values: saturating)
+            pk[c] = as_u(__builtin_amdgcn_cvt_pk_i16(__builtin_elementwise_sub_sat(dr[c], ref_r), __builtin_elementwise_sub_sat(db[c], ref_b)));
+    }
+    const int ca = edge ? PW - HC : HC + 4 * lk, cb = edge ? 0 : ca + 2;
+    const uint32_t prow = __umul24((uint32_t)p, (uint32_t)(PW * 4));
+    char *ppk = (char *)&sm.pk[0][0] + prow;
+    *(uint2 *)(ppk + 4 * ca) = make_uint2(pk[0], pk[1]);
+    *(uint2 *)(ppk + 4 * cb) = make_uint2(pk[2], pk[3]);
+    if (keep) {
+        *(int4 *)&sm.ge[jj][4 * lk] = make_int4(ge[0], ge[1], ge[2], ge[3]);
+        *(uint4 *)&sm.raw[2 * jj][8 * lk] = make_uint4(p0[0] | (p0[1] << 16), p0[2] | (p0[3] << 16), p0[4] | (p0[5] << 16), p0[6] | (p0[7] << 16));
+        *(uint4 *)&sm.raw[2 * jj + 1][8 * lk] = make_uint4(p1[0] | (p1[1] << 16), p1[2] | (p1[3] << 16), p1[4] | (p1[5] << 16), p1[6] | (p1[7] << 16));
+    }
+}
+
+template <int METHOD, bool PACKED, int VEC, bool SPREAD>
+__global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
+{
+    static_assert(METHOD == 2 || METHOD == 3 || METHOD == 5, "chroma smoothing only");
+    static_assert(VEC != 0, "rows of whole 8-pixel groups");
+    constexpr bool CHAIN = METHOD == 5;
+    using Smem = SmemP<SPREAD, CHAIN>;
+    __shared__ Smem sm;
+    constexpr int BPP = bpp_of(PACKED, VEC);
+    constexpr int NEW0 = 2 * HC;
+    const int tid = threadIdx.x;
+
+    {
+        KArgs ka = cold_args();
+        if (SPREAD) {
+            for (int i = tid; i < MLV_T16_N; i += 256) sm.t16[i + (i >> 7)] = ka->t16[i];
+        } else {
+            const uint4 *src = (const uint4 *)ka->t16;
+            uint4 *dstl = (uint4 *)sm.t16;
+            for (int i = tid; i < MLV_T16_N * 2 / 16; i += 256) dstl[i] = src[i];
+        }
+    }
+    const int tiles_per_frame = a.tiles_x * a.tiles_y;
+    const bool pmap_ok = tiles_per_frame <= PMAP_WORDS * 32;
+    int band_end;
+    {
+        KArgs ka = cold_args();
+        if (ka->patch && pmap_ok) {
+            for (int i = tid; i < PMAP_WORDS; i += 256) sm.has_patch[i] = 0;
+            __syncthreads();
+            const int *toff = ka->tile_off;
+            for (int i = tid; i < tiles_per_frame; i += 256)
+                if (toff[i + 1] != toff[i]) atomicOr(&sm.has_patch[i >> 5], 1u << (i & 31));
+        }
+        // the tile walk of k_frame (groups, runs, singles); what only thread 0 needs, when it draws, waits in LDS
+        const int total = tiles_per_frame * ka->nframes;
+        const int groups = ka->groups, nx = 8;
+        const int grp = blockIdx.x % groups;
+        const int gpx = (groups + nx - 1) / nx;
+        const int grank = (groups % nx == 0) ? (grp % nx) * gpx + grp / nx : grp;
+        const int gq = total / groups, grem = total - gq * groups;
+        const int band_start = grank * gq + min(grank, grem);
+        band_end = band_start + gq + (grank < grem ? 1 : 0);
+        const int run = max(ka->run, 1);
+        const int runs_len = max(band_end - band_start - ka->singles, 0) / run * run;
+        if (tid == 0) { sm.walk[0] = band_start; sm.walk[1] = runs_len; sm.walk[2] = run; sm.walk[3] = grp; sm.walk[4] = 0; }
+    }
+    // thread 0: the next run of the group's range, or its next single tile
+    auto draw = [&](int &nt, int &ne) {
+        KArgs ka = cold_args();
+        int *tickets = ka->tickets;
+        const int band_start = sm.walk[0], runs_len = sm.walk[1], run = sm.walk[2], grp = sm.walk[3];
+        if (!sm.walk[4]) {
+            const int p = atomicAdd(&tickets[2 * grp], run);
+            if (p < runs_len) { nt = band_start + p; ne = nt + run; return; }
+            sm.walk[4] = 1;                                 // the runs of this group's range are all handed out
+        }
+        const int q = atomicAdd(&tickets[2 * grp + 1], 1);
+        nt = min(band_start + runs_len + q, band_end);
+        ne = nt + 1;
+    };
+    if (tid == 0) {
+        int nt, ne;
+        draw(nt, ne);
+        sm.next_tile = nt; sm.next_end = ne;
+        sm.unc[0] = 0; sm.unc[1] = 0; sm.low[0] = 0; sm.low[1] = 0;
+    }
+    __syncthreads();
+    int t = __builtin_amdgcn_readfirstlane(sm.next_tile), t_end = __builtin_amdgcn_readfirstlane(sm.next_end);
+    struct Pos { int f, tcol, trow; };
+    auto pos_of = [&](int tt) {
+        Pos p;
+        p.f = tt / tiles_per_frame;
+        const int r = tt - p.f * tiles_per_frame;
+        p.tcol = r / a.tiles_y;
+        p.trow = r - p.tcol * a.tiles_y;
+        return p;
+    };
+    auto pos_below = [&](Pos p) {
+        if (++p.trow == a.tiles_y) {
+            p.trow = 0;
+            if (++p.tcol == a.tiles_x) { p.tcol = 0; p.f++; }
+        }
+        return p;
+    };
+    uint32_t r0[4], r1[4];                               // prefetch registers of this thread's item
+    // loader: threads 0..239 own the main item (row t / 16, group t % 16) of the tile's new rows, threads 240..254 the edge items;
+    // what a lane's item is, is derived from its number where it is needed (a handful of operations per tile: kept in registers
+    // through the median phase the item descriptions were what the allocator spilt)
+    struct Src { const uint8_t *p; size_t stride; unsigned bytes; };
+    auto src_of = [](KArgs ka) { Src s; s.p = ka->src; s.stride = ka->src_stride; s.bytes = ka->src_bytes; return s; };
+    auto issue_tile = [&](const Src &sa, const Pos &p, int tl) {
+        const bool l_edge = tl >= N_MAIN;
+        const int l_row = l_edge ? tl - N_MAIN : tl >> 4;
+        const ItemLane L = item_lane<PACKED, VEC>(tl & 15, l_edge);
+        const uint8_t *frame = sa.p + (size_t)p.f * sa.stride;
+        const unsigned bytes = sa.bytes;
+        const int tx0 = p.tcol * 2 * TCW, ty0 = p.trow * 2 * TCH;
+        if (VEC != 2 && tx0 >= 8 && tx0 + 2 * TCW + 8 <= a.w && ty0 + 2 * TCH + 2 * HC <= a.h) {           // (scalar)
+            // A tile whose new rows and halo columns lie inside the frame -- nine in ten -- clamps nothing, and with rows that are
+            // whole dwords (every layout but VEC 2) the dword alignment of a main item commutes with the row and tile offsets: what
+            // is left per lane is a constant, the tile's part goes into the buffer descriptor (16 bytes early: the left halo's
+            // group lies before the tile) and the second row is the first plus the pitch as the load's scalar offset.
+            // issue_item's general form costs 45 vector instructions per tile, this one a dozen.
+            constexpr uint32_t GB = (uint32_t)BPP;
+            const uint32_t pitch = (uint32_t)(a.w >> 3) * GB;
+            const uint32_t S = (uint32_t)(ty0 + 2 * HC) * pitch + (uint32_t)(tx0 >> 3) * GB - 16u;
+            const mlv_i32x4 rs = frame_rsrc(frame + S, bytes - S);
+            const uint32_t rowoff = __umul24((uint32_t)(2 * l_row), pitch) + 16u;
+            const uint32_t va = rowoff + ((uint32_t)((L.xoff_a >> 3) * (int)GB) & L.amask);
+            const uint32_t vb = rowoff + ((uint32_t)((L.xoff_b >> 3) * (int)GB) & L.amask) + L.boff;
+            const mlv_u32x2 a0 = mlv_rbl_x2(rs, (int)va, 0, KF_SRC_AUX), b0 = mlv_rbl_x2(rs, (int)vb, 0, KF_SRC_AUX);
+            const mlv_u32x2 a1 = mlv_rbl_x2(rs, (int)va, (int)pitch, KF_SRC_AUX), b1 = mlv_rbl_x2(rs, (int)vb, (int)pitch, KF_SRC_AUX);
+            r0[0] = a0.x; r0[1] = a0.y; r0[2] = b0.x; r0[3] = b0.y;
+            r1[0] = a1.x; r1[1] = a1.y; r1[2] = b1.x; r1[3] = b1.y;
+        } else
+            issue_item<BPP>(r0, r1, frame_rsrc(frame, bytes), L, a.w, a.h, tx0, ty0, NEW0 + l_row);
+    };
+    // The reference of a tile that does not continue the one above: pixel (lane & 7, lane >> 3 & 1) of the 8 x 2 block at the tile's
+    // centre (inside the frame, on even coordinates: R G1 / G2 B), one per lane; the loads go out with the tile's prefetch
+    uint32_t smp = 0, smp_sh = 0;          // (the load only: what depends on it waits until the tile starts)
+    // pixel (lane & 15, lane >> 4) of the 16 x 4 block at the tile's centre (inside the frame, on even coordinates: R G1 / G2 B)
+    auto issue_sample = [&](const Src &sa, const Pos &p, int tl) {
+        const uint8_t *frame = sa.p + (size_t)p.f * sa.stride;
+        const int x0 = min(p.tcol * 2 * TCW + TCW, (a.w - 16) & ~1), y0 = min(p.trow * 2 * TCH + TCH - 1, (a.h - 4) & ~1);
+        const uint32_t i = (uint32_t)(y0 + ((tl >> 4) & 3)) * (uint32_t)a.w + (uint32_t)(x0 + (tl & 15));
+        if (BPP != 16) {
+            const uint32_t bit = i * (uint32_t)BPP;          // < 2^28 pixels per frame (launcher): fits
+            __builtin_memcpy(&smp, frame + 2 * (bit >> 4), 4);          // two 16-bit words of the stream (an address that is a multiple of 2)
+            smp_sh = bit & 15u;
+        } else smp = ((const uint16_t *)frame)[i];
+    };
+    // The reference: the median of five cells of the block, no two of them neighbours -- the pixel maps of real clips hold pairs of
+    // defects two pixels apart (and the benchmark's frames do: a twin next to its defect made two of THREE sampled cells outliers, the
+    // reference garbage and the whole tile uncertain)
+    int ref_r = 0, ref_b = 0;
+    auto take_sample = [&]() {
+        uint32_t px = smp;
+        if (BPP != 16) px = (__builtin_amdgcn_alignbit(smp, smp, 16) >> (32 - BPP - smp_sh)) & ((1u << BPP) - 1u);          // MSB-first: first word high
+        const int l = min(max((int)px - a.black, 1), 16383);
+        const int ix = ev_index(l);
+        const int ev = ev_value(l, (int)sm.t16[SPREAD ? ix + (ix >> 7) : ix]);
+        constexpr int CX[5] = { 0, 3, 6, 1, 5 }, CY[5] = { 0, 0, 0, 1, 1 };       // cell (cx, cy): R in lane 2 cx + 32 cy, G1 + 1, G2 + 16, B + 17
+        int dr[5], db[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int l0 = 2 * CX[c] + 32 * CY[c];
+            const int r = __builtin_amdgcn_readlane(ev, l0), g1 = __builtin_amdgcn_readlane(ev, l0 + 1);
+            const int g2 = __builtin_amdgcn_readlane(ev, l0 + 16), b = __builtin_amdgcn_readlane(ev, l0 + 17);
+            const int ge = (g1 + g2) >> 1;
+            dr[c] = r - ge; db[c] = b - ge;
+        }
+        auto med5 = [](const int (&v)[5]) { return med3i(v[4], max(min(v[0], v[1]), min(v[2], v[3])), min(max(v[0], v[1]), max(v[2], v[3]))); };
+        ref_r = med5(dr);
+        ref_b = med5(db);
+    };
+    Pos cur = pos_of(min(t, max(band_end - 1, 0)));
+    {
+        const Src sa = src_of(cold_args());
+        issue_tile(sa, cur, tid);
+        issue_sample(sa, cur, tid);
+    }
+    __syncthreads();                           // T16 copy complete
+
+    int fb_skip = 0, fb_wait = KF_P_WAIT_MIN;  // tiles still to go to the list unseen; how many after the next uncertain tile
+    bool cont = false;
+    int par = 0;                               // tile parity: which of the two `unc` slots this tile uses
+    int low_prev = 1;                          // (the tile before this one: conservative until there is one)
+    bool have_smp = true;                      // the sample of this tile is on its way (else: fetched when the tile starts)
+    auto push = [&](int first, int n) {        // thread 0
+        KArgs ka = cold_args();
+        int *ctl = ka->wl_ctl;
+        const int i = atomicAdd(&ctl[0], 1);
+        ka->wl[i] = make_int2(first, n);
+        atomicAdd(&ctl[3], n);                 // (statistics: tiles listed since the stream's state was created)
+    };
+    while (t < band_end) {
+        if (fb_skip > 0) {
+            // ---- tiles that go to the list unseen: the rest of this run, or as many of it as are still to be skipped
+            const int n = min(fb_skip, t_end - t);
+            fb_skip -= n;
+            if (tid == 0) {
+                push(t, n);
+                int nt, ne;
+                if (t + n < t_end) { nt = t + n; ne = t_end; }
+                else draw(nt, ne);
+                sm.next_tile = nt; sm.next_end = ne;
+            }
+            lds_barrier();
+            t = __builtin_amdgcn_readfirstlane(sm.next_tile); t_end = __builtin_amdgcn_readfirstlane(sm.next_end);
+            lds_barrier();                     // (all have read: thread 0 may write the slots again)
+            cont = false;
+            if (t < band_end) {
+                cur = pos_of(t);
+                const Src sa = src_of(cold_args());
+                issue_tile(sa, cur, tid);
+                issue_sample(sa, cur, tid);
+                have_smp = true;
+            }
+            continue;
+        }
+        int nt = 0, ne = 0;
+        if (tid == 0) {                        // the tile after this one: known, or drawn now and back long before it is needed
+            if (t + 1 < t_end) { nt = t + 1; ne = t_end; }
+            else draw(nt, ne);
+        }
+        const int trow = cur.trow, tx0 = cur.tcol * 2 * TCW, ty0 = cur.trow * 2 * TCH;
+        const int tr = cur.trow * a.tiles_x + cur.tcol;
+        // ---- pixel-map entries of this tile (few tiles have any)
+        bool tile_patched = false;
+        int pbeg = 0, pend = 0;
+        int4 my_rec = make_int4(-1, 0, 0, 0);
+        if (a.patch) {
+            tile_patched = !pmap_ok || ((sm.has_patch[tr >> 5] >> (tr & 31)) & 1u);
+            if (tile_patched) {
+                KArgs ka = cold_args();
+                const int *toff = ka->tile_off;
+                pbeg = toff[tr];
+                pend = toff[tr + 1];
+                if (pbeg + tid < pend) my_rec = (ka->cells + (size_t)cur.f * ka->n_rec)[pbeg + tid];
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (!cont) {
+            if (!have_smp) issue_sample(src_of(cold_args()), cur, tid);
+            take_sample();
+        }
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        auto do_item = [&](const ItemLane &L, const uint32_t (&d0)[4], const uint32_t (&d1)[4], int p, int lk) {
+            uint32_t p0[8], p1[8];
+            unpack8<BPP>(d0, L.s0, L.s1, L.s23, p0);
+            unpack8<BPP>(d1, L.s0 ^ L.flip, L.s1 ^ L.flip, L.s23 ^ L.flip, p1);
+            uint32_t lo = min(p0[0], p1[0]), hi = max(p0[0], p1[0]);
+#pragma unroll
+            for (int i = 1; i < 8; i++) {
+                lo = min(min(lo, p0[i]), p1[i]);
+                if (!PACKED) hi = max(max(hi, p0[i]), p1[i]);
+            }
+            const bool odd = (int)lo <= a.black;
+            const bool beyond = (!PACKED && (int)hi - a.black > 16383) || (PACKED && a.black < 0);
+            const bool slow = (!PACKED || a.black < 0) && __any(beyond);
+            const bool dark = slow || __any(odd);
+            if (__any((int)lo <= a.black + 64)) sm.low[par] = 1;       // the stripes epilogue's "more than 64 above black" holds for no mask then
+            emit_item_p<METHOD, Smem>(sm, a.black, dark, slow, ref_r, ref_b, p, lk, L.edge, p0, p1);
+        };
+        if (!cont) {
+            // the first tile of a run (or of a column): the four plane rows above the tile's own, straight from memory -- threads
+            // 0..63 the main items of rows 0..3, 64..67 their edge items -- while the other waves convert the prefetched rows
+            if (tid_o < N_TOP) {
+                KArgs ka = cold_args();
+                const bool te = tid_o >= N_TOP_MAIN;
+                const int trw = te ? tid_o - N_TOP_MAIN : tid_o >> 4;
+                const ItemLane TL = item_lane<PACKED, VEC>(tid_o & 15, te);
+                uint32_t q0[4] = { 0, 0, 0, 0 }, q1[4] = { 0, 0, 0, 0 };
+                issue_item<BPP, true>(q0, q1, frame_rsrc(ka->src + (size_t)cur.f * ka->src_stride, ka->src_bytes), TL, a.w, a.h, tx0, ty0, trw);
+                do_item(TL, q0, q1, trw, tid_o & 15);
+            }
+        }
+        if (tid_o < N_ITEMS) {
+            const bool l_edge = tid_o >= N_MAIN;
+            do_item(item_lane<PACKED, VEC>(tid_o & 15, l_edge), r0, r1, NEW0 + (l_edge ? tid_o - N_MAIN : tid_o >> 4), tid_o & 15);
+        }
+        if (tid == 0) { sm.next_tile = nt; sm.next_end = ne; }
+        lds_barrier();
+        if (tid == 0) { sm.unc[par ^ 1] = 0; sm.low[par ^ 1] = 0; }          // (read by all before this barrier, written again behind the next tile's)
+        // pixels at most 64 above black among the rows this tile loaded (or patched); with those of the tile before: among its output rows
+        const int low_cur = __builtin_amdgcn_readfirstlane(sm.low[par]) | (tile_patched ? 1 : 0);
+        const int t_next = __builtin_amdgcn_readfirstlane(sm.next_tile), t_end_next = __builtin_amdgcn_readfirstlane(sm.next_end);
+        // the tile after this one continues it when it is the next of the list and not the top of a column
+        const bool cont_next = t_next == t + 1 && trow + 1 < a.tiles_y && t_next < band_end;
+        if (tile_patched) {
+            KArgs ka = cold_args();
+            const int4 *cells = ka->cells + (size_t)cur.f * ka->n_rec;
+            auto patch_one = [&](int4 rec) {
+                PatchCell c = patch_cell<METHOD, PACKED, Smem>(sm, a.black, rec, tx0, ty0);
+                if (c.i < 0) return;
+                sm.pk[c.j][c.i] = as_u(__builtin_amdgcn_cvt_pk_i16(__builtin_elementwise_sub_sat(c.dr, ref_r), __builtin_elementwise_sub_sat(c.db, ref_b)));
+                const int ii = c.i - HC, jj = c.j - HC;
+                if (ii >= 0 && ii < TCW && jj >= 0 && jj < RH) {
+                    sm.ge[jj][ii] = c.ge;
+                    *(uint32_t *)&sm.raw[2 * jj][2 * ii] = c.top;
+                    *(uint32_t *)&sm.raw[2 * jj + 1][2 * ii] = c.bot;
+                }
+            };
+            patch_one(my_rec);
+            for (int base = pbeg + 256; base < pend; base += 256)         // a dense map (focus pixels): the rest
+                patch_one(base + tid < pend ? cells[base + tid] : make_int4(-1, 0, 0, 0));
+            lds_barrier();
+        }
+        __builtin_amdgcn_s_setprio(1);
+        // ---- prefetch the next tile (and, where it starts anew, its sample) while the medians run
+        Pos nxt = pos_below(cur);
+        if (t_next != t + 1 || t_next >= band_end) nxt = pos_of(min(t_next, band_end - 1));
+        const Src sa = src_of(cold_args());
+        {
+            int tid_p = tid;
+            asm volatile("" : "+v"(tid_p));
+            issue_tile(sa, nxt, tid_p);
+            if (!cont_next) issue_sample(sa, nxt, tid_p);
+        }
+        // what the output stage needs of the cold arguments, in one go and early: the loads go out together, long before their first use
+        KArgs kt = cold_args();
+        const uint2 *o_e2d = kt->e2d;
+        uint8_t *o_dst = kt->dst;
+        const size_t o_dst_stride = kt->dst_stride;
+        const int o_stripes = kt->stripes, o_coef_pk = kt->coef_pk, o_coef_fast = kt->coef_fast, o_white = kt->white;
+        int o_co[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) o_co[i] = kt->coef[i];
+
+        // ---- medians + output: one thread = 4 cells = 8 px on two rows
+        int tid_m = tid;
+        asm volatile("" : "+v"(tid_m));
+        // lane -> (row j, strip k).  5x5: 17 consecutive lanes per tile row (16 strips and the halo group); other methods: 16
+        const int j_ = CHAIN ? (tid_m * 241) >> 12 : tid_m >> 4;
+        const int k = CHAIN ? tid_m - 17 * j_ : tid_m & 15;
+        const int j = min(j_, TCH - 1);
+        const bool is_strip = CHAIN ? (k < 16 && tid_m < 17 * TCH) : tid_m < N_MAIN;
+        const int y = ty0 + 2 * j, x = tx0 + 2 * STRIP * k;
+        const bool smooth_row = y >= 4 && y < a.h - 5;                                    // chroma_smooth.c:25
+        mlv_pk16 o[STRIP] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
+        if (CHAIN) {
+            const int lane = tid_m & 63;
+            const bool publishes = lane == 0 && tid_m != 0, collects = lane == 63 && tid_m < 192;
+            const int wv = tid_m >> 6;
+            PGroup g;
+            pchain_group(sm.pk, j, STRIP * k, g);
+            const bool early = tid_m >= 64;
+            if (early) {
+                mlv_quad_mid6(g.p0, g.p1, g.q);
+                if (publishes) pchain_publish(g, sm.xchg[wv - 1]);
+            }
+            lds_barrier();
+            PNext n;
+            pchain_fetch_lists(g, n);
+            if (collects) pchain_collect_lists(sm.xchg[wv], n);
+            if (!early) mlv_quad_mid6(g.p0, g.p1, g.q);
+            pchain_fetch_window(g, n);
+            if (collects) pchain_collect_window(sm.xchg[wv], n);
+            pchain_finish(g, n, o);
+        } else if (smooth_row) {
+            if (METHOD == 3) pstrip_median9(sm.pk, j, STRIP * k, o);
+            else pstrip_median5(sm.pk, j, STRIP * k, o);
+        }
+        if (is_strip && smooth_row && pk_uncertain(o)) sm.unc[par] = 1;
+        // ---- R / B replacement, stripes, store (k_frame's finish_strip with the medians relative to the reference)
+        if (is_strip) {
+            const mlv_i32x4 rs_e2d = table_rsrc(o_e2d, 8, E2D_RECORDS);
+            uint32_t top[STRIP], bot[STRIP];
+            const int4 g4 = *(const int4 *)&sm.ge[j][STRIP * k];
+            const int gev[STRIP] = { g4.x, g4.y, g4.z, g4.w };
+            int er[STRIP], eb[STRIP], ur[STRIP], ub[STRIP], cr[STRIP], cb[STRIP];
+            mlv_tab_u32x2 dr2[STRIP], db2[STRIP];
+#pragma unroll
+            for (int c = 0; c < STRIP; c++) {
+                er[c] = wadd(wadd(gev[c], ref_r), (int)o[c].x);
+                eb[c] = wadd(wadd(gev[c], ref_b), (int)o[c].y);
+                cr[c] = min(max(er[c], 0), MLV_EV_MAX); cb[c] = min(max(eb[c], 0), MLV_EV_MAX);
+                dr2[c] = mlv_sbl_x2(rs_e2d, cr[c] >> 5, 0, 0, KF_E2R_AUX);
+                db2[c] = mlv_sbl_x2(rs_e2d, cb[c] >> 5, 0, 0, KF_E2R_AUX);
+            }
+            {
+                const uint4 v0 = *(const uint4 *)&sm.raw[2 * j][2 * STRIP * k];
+                const uint4 v1 = *(const uint4 *)&sm.raw[2 * j + 1][2 * STRIP * k];
+                top[0] = v0.x; top[1] = v0.y; top[2] = v0.z; top[3] = v0.w;
+                bot[0] = v1.x; bot[1] = v1.y; bot[2] = v1.z; bot[3] = v1.w;
+            }
+            const bool x_margin = tx0 < 4 || tx0 + 2 * TCW > a.w - 4;
+            bool okc[STRIP];
+#pragma unroll
+            for (int c = 0; c < STRIP; c++) {
+                const int xc = x + 2 * c;
+                okc[c] = smooth_row && gev[c] >= 2 * MLV_EV_RES && er[c] > MLV_EV_RES && eb[c] > MLV_EV_RES;
+                if (x_margin) okc[c] = okc[c] && xc >= 4 && xc < a.w - 4;
+            }
+            asm volatile("" :: "v"(dr2[0]), "v"(dr2[1]), "v"(dr2[2]), "v"(dr2[3]), "v"(db2[0]), "v"(db2[1]), "v"(db2[2]), "v"(db2[3]));
+#pragma unroll
+            for (int c = 0; c < STRIP; c++) {
+                ur[c] = (int)(__builtin_popcount(bfe_low_bits(dr2[c].y, (uint32_t)cr[c])) + dr2[c].x);
+                ub[c] = (int)(__builtin_popcount(bfe_low_bits(db2[c].y, (uint32_t)cb[c])) + db2[c].x);
+            }
+#pragma unroll
+            for (int c = 0; c < STRIP; c++) {
+                const bool ok = okc[c];
+                top[c] = __builtin_amdgcn_perm((uint32_t)ur[c], top[c], ok ? 0x03020504u : 0x03020100u);
+                bot[c] = __builtin_amdgcn_perm((uint32_t)ub[c], bot[c], ok ? 0x05040100u : 0x03020100u);
+            }
+            if (o_stripes) {
+                const int black16 = (int)(uint16_t)a.black, white16 = (int)(uint16_t)o_white;
+                if (PACKED && o_coef_pk) {
+                    if (low_cur | low_prev) stripe_strip_pk<true>(top, bot, o_co, black16, white16);
+                    else stripe_strip_pk<false>(top, bot, o_co, black16, white16);
+                }
+                else if (o_coef_fast) stripe_strip<true>(top, bot, o_co, black16, white16);
+                else stripe_strip<false>(top, bot, o_co, black16, white16);
+            }
+            if (y < a.h && x < a.w) {
+                // the frame as a buffer whose base is the tile's first pixel: the lane's part of the address is (2 j w + 8 k) pixels
+                const uint32_t T = ((uint32_t)ty0 * (uint32_t)a.w + (uint32_t)tx0) * 2u;
+                const mlv_i32x4 rs_out = frame_rsrc(o_dst + (size_t)cur.f * o_dst_stride + T, (uint32_t)a.w * (uint32_t)a.h * 2u - T);
+                const uint32_t vo = (__umul24((uint32_t)(2 * j), (uint32_t)a.w) + 2 * STRIP * (uint32_t)k) * 2u;
+                const mlv_u32x4 vt = { top[0], top[1], top[2], top[3] }, vb = { bot[0], bot[1], bot[2], bot[3] };
+                mlv_rbs_x4(vt, rs_out, (int)vo, 0, 2);                                     // (2: non-temporal)
+                if (y + 1 < a.h) mlv_rbs_x4(vb, rs_out, (int)vo, a.w * 2, 2);
+            }
+        }
+        // ---- the rows the tile below shares with this one: read before the barrier that ends the tile, stored behind it
+        // (threads 0..67: packed rows TCH.. -> 0..3, 68..131: pixel rows, 132..163: green EVs; one 16-byte piece each)
+        constexpr int C_PL = 2 * HC * PW * 4 / 16, C_RAW = 2 * HC * 2 * TCW * 2 / 16, C_GE = HC * TCW * 4 / 16, C_ALL = C_PL + C_RAW + C_GE;
+        static_assert(C_ALL <= 256, "one 16-byte piece per thread");
+        int4 carry = make_int4(0, 0, 0, 0);
+        int tid_c = tid;
+        asm volatile("" : "+v"(tid_c));
+        const bool do_carry = cont_next && tid_c < C_ALL;
+        int c_dst = 0;
+        if (do_carry) {
+            int c_delta;
+            if (tid_c < C_PL) { c_dst = (int)offsetof(Smem, pk) + 16 * tid_c; c_delta = TCH * PW * 4; }
+            else if (tid_c < C_PL + C_RAW) { c_dst = (int)offsetof(Smem, raw) + 16 * (tid_c - C_PL); c_delta = 2 * TCH * 2 * TCW * 2; }
+            else { c_dst = (int)offsetof(Smem, ge) + 16 * (tid_c - C_PL - C_RAW); c_delta = TCH * TCW * 4; }
+            carry = *(const int4 *)((const char *)&sm + c_dst + c_delta);
+        }
+        lds_barrier();
+        const int unc = __builtin_amdgcn_readfirstlane(sm.unc[par]);
+        if (do_carry) *(int4 *)((char *)&sm + c_dst) = carry;
+        have_smp = !cont_next;
+        if (unc) {
+            // a tile with uncertain strips: to the list (k_frame does it again, whole), the next fb_wait tiles with it unseen; where
+            // none is skipped the next tile starts anew, with a reference of its own
+            if (tid == 0) push(t, 1);
+            fb_skip = fb_wait;
+            fb_wait = min(2 * fb_wait + 1, KF_P_WAIT_MAX);
+            cont = false;
+        } else {
+            fb_wait = KF_P_WAIT_MIN;
+            cont = cont_next;
+        }
+        low_prev = low_cur;
+        t = t_next;
+        t_end = t_end_next;
+        cur = nxt;
+        par ^= 1;
+    }
+    if (tid == 0) {
+        KArgs ka = cold_args();
+        const int groups = ka->groups;
+        int *tickets = ka->tickets;
+        if (atomicAdd(&tickets[2 * groups], 1) == (int)gridDim.x - 1)
+            for (int i = 0; i <= 2 * groups; i++) tickets[i] = 0;   // last workgroup out: ready for the next launch on this stream
+    }
+}
+
+bool frame_p_exists(int method, int vec) { return method != 0 && vec != 0; }
+
+void launch_frame_p_kernel(int method, bool packed, int vec, bool spread, int grid, hipStream_t stream, const FrameArgs &a)
+{
+#ifdef KFP_ONLY          // (tools: one or two instantiations, seconds to compile)
+    if (method == 5) hipLaunchKernelGGL((k_frame_p<5, true, 1, false>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((k_frame_p<2, true, 1, false>), dim3(grid), dim3(256), 0, stream, a);
+#else
+#define MLV_P(M, P, V, S) hipLaunchKernelGGL((k_frame_p<M, P, V, S>), dim3(grid), dim3(256), 0, stream, a)
+#define MLV_P_S(M, S)                                                                                             \
+    do {                                                                                                          \
+        if (packed) { if (vec == 1) MLV_P(M, true, 1, S); else if (vec == 2) MLV_P(M, true, 2, S);                \
+                      else if (vec == 3) MLV_P(M, true, 3, S); else if (vec == 4) MLV_P(M, true, 4, S); }         \
+        else { if (vec == 1) MLV_P(M, false, 1, S); else if (vec == 2) MLV_P(M, false, 2, S); }                   \
+    } while (0)
+#define MLV_P_M(M) do { if (spread) MLV_P_S(M, true); else MLV_P_S(M, false); } while (0)
+    if (method == 2) MLV_P_M(2);
+    else if (method == 3) MLV_P_M(3);
+    else if (method == 5) MLV_P_M(5);
+#undef MLV_P_M
+#undef MLV_P_S
+#undef MLV_P
+#endif
+}
+
+}  // namespace mlv
