@@ -58,16 +58,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         if (threadIdx.x == 0) list_done();
         return;
     }
-    if (METHOD != 0) {
-        if (SPREAD) {
-            const uint16_t *t16 = cold_args()->t16;
-            for (int i = threadIdx.x; i < MLV_T16_N; i += blockDim.x) sm.t16[i + (i >> 7)] = t16[i];
-        } else {
-            const uint4 *src = (const uint4 *)cold_args()->t16;
-            uint4 *dstl = (uint4 *)sm.t16;
-            for (int i = threadIdx.x; i < MLV_T16_N * 2 / 16; i += blockDim.x) dstl[i] = src[i];
-        }
-    }
+    if (METHOD != 0) load_t16_rel<SPREAD>(sm.t16, cold_args()->t16, threadIdx.x);
     // Which tiles of a frame have pixel-map entries: one bit per tile in LDS.  Reading the tile's list bounds from HBM in
     // every iteration made each wave wait for ALL its outstanding loads (the prefetch of the next tile included) before the
     // median phase; now only the few tiles that are touched fetch their bounds.
@@ -114,9 +105,8 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     // loader: threads 0..239 own the main item (row t / 16, group t % 16) of the tile's new rows, threads 240..254 the edge items
-    const bool l_edge = tid >= N_MAIN;
-    const int l_row = l_edge ? tid - N_MAIN : tid >> 4, l_k = tid & 15;
-    const ItemLane IL = item_lane<PACKED, VEC>(l_k, l_edge);
+    // (what a lane's item is, is derived from its number where it is needed -- a handful of operations per tile; kept in registers
+    // through the median phase the item descriptions were what the allocator spilt)
     // median phase: lane -> (row j, strip k).  5x5 (neighbour sharing): 17 consecutive lanes per tile row -- its 16 strips and, as
     // the 17th, the group of plane columns 64..67 (halo) that the last strip needs --, so that EVERY lane finds the group to its
     // right in the next lane; the plane reads are then linear in the thread number (16 bytes per lane: PW = 17 x 4) and free of
@@ -152,7 +142,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         int nt, ne;
         draw(nt, ne);
         sm.next_tile = nt; sm.next_end = ne;
-        sm.dark_items[0] = 0; sm.dark_items[1] = 0; sm.fb_count = 0;
+        sm.dark_items[0] = 0; sm.dark_items[1] = 0; sm.fb_count = 0; sm.low[0] = 0; sm.low[1] = 0;
     }
     __syncthreads();
     int t = __builtin_amdgcn_readfirstlane(sm.next_tile), t_end = __builtin_amdgcn_readfirstlane(sm.next_end);
@@ -182,13 +172,18 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     // iteration re-load a valid item / tile.  A conditional load would need the old
     // register value on the other path, and the copies the compiler inserts for that
     // merge wait for the load right where it is issued.
-    auto issue_tile = [&](const Pos &p) {
-        KArgs ka = cold_args();
-        const mlv_i32x4 rs = frame_rsrc(ka->src + (size_t)p.f * ka->src_stride, ka->src_bytes);
-        issue_item<BPP>(r0, r1, rs, IL, a.w, a.h, p.tcol * 2 * TCW, p.trow * 2 * TCH, NEW0 + l_row);
+    struct Src { const uint8_t *p; size_t stride; unsigned bytes; };
+    auto src_of = [](KArgs ka) { Src s; s.p = ka->src; s.stride = ka->src_stride; s.bytes = ka->src_bytes; return s; };
+    auto issue_tile = [&](const Src &sa, const Pos &p) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        const bool l_edge = tl >= N_MAIN;
+        const int l_row = l_edge ? tl - N_MAIN : tl >> 4;
+        const ItemLane IL = item_lane<PACKED, VEC>(tl & 15, l_edge);
+        issue_tile_rows<BPP, VEC>(r0, r1, sa.p + (size_t)p.f * sa.stride, sa.bytes, IL, l_row, a.w, a.h, p.tcol * 2 * TCW, p.trow * 2 * TCH, NEW0);
     };
     Pos cur = pos_of(min(t, max(band_end - 1, 0)));
-    if (vec) issue_tile(cur);
+    if (vec) issue_tile(src_of(cold_args()), cur);
     __syncthreads();                           // T16 copy complete
 
 #ifdef KF_DIAG_TIMES
@@ -200,6 +195,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     bool robust = false;                       // 5x5: rows of lanes agree on their references (robust_ref)
     int calm = 0;                              //      tiles in a row without an uncertain strip
     bool cont = false;                         // this tile lies right below the one this workgroup did before: its upper rows are in LDS
+    int lpar = 0, low_prev = 1;                // parity of the `low` slots; the flag of the tile before (conservative until there is one)
     while (t < band_end) {
         int nt = 0, ne = 0;
         if (threadIdx.x == 0) {                // the tile after this one: known, or drawn now and back long before it is needed
@@ -207,6 +203,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             else draw(nt, ne);
         }
         const int f = cur.f, trow = cur.trow, tx0 = cur.tcol * 2 * TCW, ty0 = cur.trow * 2 * TCH;
+        const Src sa = src_of(cold_args());      // (asked for here, needed when the next tile is prefetched: no wait there)
         const int tr = cur.trow * a.tiles_x + cur.tcol;          // the tile's number in the (row-major) pixel-map lists
         // ---- pixel-map entries of this tile (few tiles have any): list bounds now -- the wait that the uniform load implies is
         // for data the loader needs anyway --, the first 256 records themselves in flight while the loader phase runs
@@ -237,11 +234,12 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             if (vec) {
                 unpack8<BPP>(d0, L.s0, L.s1, L.s23, p0);
                 unpack8<BPP>(d1, L.s0 ^ L.flip, L.s1 ^ L.flip, L.s23 ^ L.flip, p1);
-            } else { KArgs ka = cold_args(); fetch_rows<BPP>(ka->src + (size_t)f * ka->src_stride, a.w, a.h, tx0, lk, ty0 - 2 * HC + 2 * p, L.edge, p0, p1); }
+            } else { fetch_rows<BPP>(sa.p + (size_t)f * sa.stride, a.w, a.h, tx0, lk, ty0 - 2 * HC + 2 * p, L.edge, p0, p1); }
             // Pixels at or below black (ev = INT_MIN / 0) or beyond the table need the fix-ups of cell_pair_ev: decided once
             // per item from the extremes of its 16 pixels (three-input min/max), wave-uniformly.
             // and, 16-bit input only, what lies beyond the table.
             bool odd = false, beyond = false;
+            uint32_t lo_px = 0;
             if (METHOD != 0) {
                 uint32_t lo = min(p0[0], p1[0]), hi = max(p0[0], p1[0]);
 #pragma unroll
@@ -250,6 +248,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                     if (!PACKED) hi = max(max(hi, p0[i]), p1[i]);
                 }
                 odd = (int)lo <= a.black;
+                lo_px = lo;
                 beyond = (!PACKED && (int)hi - a.black > 16383) || (PACKED && a.black < 0);
             }
 #ifdef KF_EXP_FASTLOADER
@@ -262,6 +261,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 const unsigned long long who = __ballot(odd || beyond);
                 if (lane == 0) atomicAdd(&sm.dark_items[par], __popcll(who));
             }
+            if (METHOD != 0 && __any((int)lo_px <= a.black + 64)) sm.low[lpar] = 1;       // (strip_output: no clamp, no stripes mask without)
             emit_item<METHOD, Smem>(sm, a.black, dark, slow, p, lk, L.edge, p0, p1);
         };
         if (METHOD != 0 && !cont) {
@@ -270,17 +270,25 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             if (tid_o < N_TOP) {
                 const bool te = tid_o >= N_TOP_MAIN;
                 const int trw = te ? tid_o - N_TOP_MAIN : tid_o >> 4;
-                const ItemLane TL = item_lane<PACKED, VEC>(l_k, te);
+                const ItemLane TL = item_lane<PACKED, VEC>(tid_o & 15, te);
                 uint32_t q0[4] = { 0, 0, 0, 0 }, q1[4] = { 0, 0, 0, 0 };
-                if (vec) { KArgs ka = cold_args(); issue_item<BPP, true>(q0, q1, frame_rsrc(ka->src + (size_t)f * ka->src_stride, ka->src_bytes), TL, a.w, a.h, tx0, ty0, trw); }
-                do_item(TL, q0, q1, trw, l_k);
+                if (vec) { issue_item<BPP, true>(q0, q1, frame_rsrc(sa.p + (size_t)f * sa.stride, sa.bytes), TL, a.w, a.h, tx0, ty0, trw); }
+                do_item(TL, q0, q1, trw, tid_o & 15);
             }
         }
         const bool has_item = METHOD == 0 ? tid_o < N_MAIN : tid_o < N_ITEMS;
-        if (has_item) do_item(IL, r0, r1, NEW0 + l_row, l_k);
+        if (has_item) {
+            const bool l_edge = tid_o >= N_MAIN;
+            do_item(item_lane<PACKED, VEC>(tid_o & 15, l_edge), r0, r1, NEW0 + (l_edge ? tid_o - N_MAIN : tid_o >> 4), tid_o & 15);
+        }
         if (threadIdx.x == 0) { sm.next_tile = nt; sm.next_end = ne; }
         lds_barrier();
         const int t_next = __builtin_amdgcn_readfirstlane(sm.next_tile), t_end_next = __builtin_amdgcn_readfirstlane(sm.next_end);
+        if (threadIdx.x == 0) sm.low[lpar ^ 1] = 0;          // (read by all before this barrier, written again behind the next tile's)
+        // pixels at most 64 above black among the rows this tile loaded (or patched); with those of the tile before: among its output rows.
+        // Without chroma smoothing the loader takes no minimum: always set.
+        const int low_cur = METHOD == 0 ? 1 : (__builtin_amdgcn_readfirstlane(sm.low[lpar]) | (tile_patched ? 1 : 0));
+        const bool low_any = (low_cur | low_prev) != 0;
         // the tile after this one continues it when it is the next of the list and not the top of a column
         const bool cont_next = METHOD != 0 && t_next == t + 1 && trow + 1 < a.tiles_y && t_next < band_end;       // scalar
         if (tile_patched) {
@@ -309,113 +317,21 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         // the tile "below" the list's last one would lie in a frame behind the buffer)
         Pos nxt = pos_below(cur);
         if (t_next != t + 1 || t_next >= band_end) nxt = pos_of(min(t_next, band_end - 1));
-        if (vec) issue_tile(nxt);
+        if (vec) issue_tile(sa, nxt);
+        // what the output stage needs of the cold arguments, in one go and early: the loads go out together, long before their first use
+        const OutArgs oa = out_args(cold_args());
 
         // ---- medians + output: one thread = 4 cells = 8 px on two rows
         // the rest of a strip once its medians are known: R / B replacement, stripes, store
         auto finish_strip = [&](int jj, int kk, bool smooth, const int (&mr)[STRIP], const int (&mb)[STRIP], bool store) {
-            const int y = ty0 + 2 * jj, x = tx0 + 2 * STRIP * kk;
-            uint32_t top[STRIP], bot[STRIP];        // (R | G1<<16), (G2 | B<<16)
-            // what this stage needs of the cold arguments, in one go: the loads go out together and are waited for once
-            KArgs kt = cold_args();
-            const uint2 *o_e2d = kt->e2d;
-            uint8_t *o_dst = kt->dst;
-            const size_t o_dst_stride = kt->dst_stride;
-            const int o_stripes = kt->stripes, o_coef_pk = kt->coef_pk, o_coef_fast = kt->coef_fast;
-            const int black16 = (int)(uint16_t)a.black, white16 = (int)(uint16_t)kt->white;
-            int co[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) co[i] = kt->coef[i];
-            const int stripe_mode = o_stripes ? ((PACKED && o_coef_pk) ? 1 : (o_coef_fast ? 2 : 3)) : 0;
-            const mlv_i32x4 rs_e2d = table_rsrc(o_e2d, 8, E2D_RECORDS);
-            uint16_t *out = (uint16_t *)(o_dst + (size_t)f * o_dst_stride);
-            auto read_raw = [&]() {
-                const uint4 v0 = *(const uint4 *)&sm.raw[2 * jj][2 * STRIP * kk];
-                const uint4 v1 = *(const uint4 *)&sm.raw[2 * jj + 1][2 * STRIP * kk];
-                top[0] = v0.x; top[1] = v0.y; top[2] = v0.z; top[3] = v0.w;
-                bot[0] = v1.x; bot[1] = v1.y; bot[2] = v1.z; bot[3] = v1.w;
-            };
-            if (METHOD == 0) read_raw();
+            int gev[STRIP] = { 0, 0, 0, 0 }, er[STRIP] = { 0, 0, 0, 0 }, eb[STRIP] = { 0, 0, 0, 0 };
             if (METHOD != 0) {
-                // (the green EVs first: the look-ups' indices wait for them; the raw pixels are read once the look-ups are under way)
                 const int4 g4 = *(const int4 *)&sm.ge[jj][STRIP * kk];
-                const int gev[STRIP] = { g4.x, g4.y, g4.z, g4.w };
-                // the output pixel by EV (112 KiB table, one 8-byte record per 32 EV steps): all 8 look-ups issued before the first use
-                int er[STRIP], eb[STRIP], ur[STRIP], ub[STRIP], cr[STRIP], cb[STRIP];
-                mlv_tab_u32x2 dr2[STRIP], db2[STRIP];
+                gev[0] = g4.x; gev[1] = g4.y; gev[2] = g4.z; gev[3] = g4.w;
 #pragma unroll
-                for (int c = 0; c < STRIP; c++) {
-                    er[c] = wadd(gev[c], mr[c]);
-                    eb[c] = wadd(gev[c], mb[c]);
-                    cr[c] = min(max(er[c], 0), MLV_EV_MAX); cb[c] = min(max(eb[c], 0), MLV_EV_MAX);
-#ifdef KF_EXP_NOLOOKUP
-                    dr2[c].x = cr[c]; dr2[c].y = 0; db2[c].x = cb[c]; db2[c].y = 0;
-#else
-                    dr2[c] = mlv_sbl_x2(rs_e2d, cr[c] >> 5, 0, 0, KF_E2R_AUX);
-                    db2[c] = mlv_sbl_x2(rs_e2d, cb[c] >> 5, 0, 0, KF_E2R_AUX);
-#endif
-                }
-                read_raw();
-                // chroma_smooth.c:27 leaves columns 0..3 and w-4.. alone: only the tiles at the frame's left and right margin test for that
-                const bool x_margin = tx0 < 4 || tx0 + 2 * TCW > a.w - 4;                   // scalar
-                // which cells take the smoothed values (chroma_smooth.c:28, 35, 64-65): decided while the look-ups are under way
-                bool okc[STRIP];
-#pragma unroll
-                for (int c = 0; c < STRIP; c++) {
-                    const int xc = x + 2 * c;
-                    okc[c] = smooth && gev[c] >= 2 * MLV_EV_RES && er[c] > MLV_EV_RES && eb[c] > MLV_EV_RES;
-                    if (x_margin) okc[c] = okc[c] && xc >= 4 && xc < a.w - 4;
-                }
-                // (the fence keeps the eight look-ups together and comes after the decisions in program order: the compiler
-                // schedules them under the look-ups' latency; with the masks as operands of the fence it also copied them)
-                asm volatile("" :: "v"(dr2[0]), "v"(dr2[1]), "v"(dr2[2]), "v"(dr2[3]), "v"(db2[0]), "v"(db2[1]), "v"(db2[2]), "v"(db2[3]));
-#pragma unroll
-                for (int c = 0; c < STRIP; c++) {             // v_bfe_u32 (the width operand's low five bits count), v_bcnt_u32_b32
-                    ur[c] = (int)(__builtin_popcount(__builtin_amdgcn_ubfe(dr2[c].y, 0u, (unsigned)cr[c] & 31u)) + dr2[c].x);
-                    ub[c] = (int)(__builtin_popcount(__builtin_amdgcn_ubfe(db2[c].y, 0u, (unsigned)cb[c] & 31u)) + db2[c].x);
-                }
-#pragma unroll
-                for (int c = 0; c < STRIP; c++) {
-                    const bool ok = okc[c];
-                    // R = the lower half of top, B = the upper half of bot: one v_perm_b32 each (selector: new value or the word as it is)
-                    top[c] = __builtin_amdgcn_perm((uint32_t)ur[c], top[c], ok ? 0x03020504u : 0x03020100u);
-                    bot[c] = __builtin_amdgcn_perm((uint32_t)ub[c], bot[c], ok ? 0x05040100u : 0x03020100u);
-                }
+                for (int c = 0; c < STRIP; c++) { er[c] = wadd(gev[c], mr[c]); eb[c] = wadd(gev[c], mb[c]); }
             }
-            if (stripe_mode != 0) {
-                // a strip starts at an x that is a multiple of 8, so pixel n of the strip has column phase n
-#ifdef KF_EXP_PKONLY
-                stripe_strip_pk(top, bot, co, black16, white16);
-#else
-                if (stripe_mode == 1) stripe_strip_pk(top, bot, co, black16, white16);
-                else if (stripe_mode == 2) stripe_strip<true>(top, bot, co, black16, white16);
-                else stripe_strip<false>(top, bot, co, black16, white16);
-#endif
-            }
-            if (store && y < a.h) {
-                if (vec) {
-                    if (x < a.w) {
-                        const uint32_t o = (uint32_t)y * (uint32_t)a.w + (uint32_t)x;           // < 2^28 pixels per frame
-                        // non-temporal stores: the output is not read again by this launch (same-box A/B, profiles/r04/ab_cache_policy.log: cs2x2
-                        // -1.3 ... -3.5 %, cs5x5 -1 ... -2.6 %; the stream LOADS marked nt or sc1 are 3-9 % slower: a line serves two loads)
-                        typedef unsigned kf_u4 __attribute__((ext_vector_type(4)));
-                        const kf_u4 vt = { top[0], top[1], top[2], top[3] }, vb = { bot[0], bot[1], bot[2], bot[3] };
-                        __builtin_nontemporal_store(vt, (kf_u4 *)(out + o));
-                        if (y + 1 < a.h) __builtin_nontemporal_store(vb, (kf_u4 *)(out + o + (uint32_t)a.w));
-                    }
-                } else {
-#pragma unroll 1
-                    for (int c = 0; c < STRIP; c++) {
-                        const int xc = x + 2 * c;
-                        if (xc < a.w) out[(size_t)y * a.w + xc] = (uint16_t)top[c];
-                        if (xc + 1 < a.w) out[(size_t)y * a.w + xc + 1] = (uint16_t)(top[c] >> 16);
-                        if (y + 1 < a.h) {
-                            if (xc < a.w) out[(size_t)(y + 1) * a.w + xc] = (uint16_t)bot[c];
-                            if (xc + 1 < a.w) out[(size_t)(y + 1) * a.w + xc + 1] = (uint16_t)(bot[c] >> 16);
-                        }
-                    }
-                }
-            }
+            strip_output<METHOD, PACKED, vec, Smem>(sm, oa, a.w, a.h, a.black, f, tx0, ty0, jj, kk, smooth, gev, er, eb, low_any, store);
         };
         const int y = ty0 + 2 * j;
         const bool smooth_row = METHOD != 0 && y >= 4 && y < a.h - 5;                       // chroma_smooth.c:25
@@ -550,6 +466,8 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         t_end = t_end_next;
         cont = cont_next;
         cur = nxt;
+        lpar ^= 1;
+        low_prev = low_cur;
         if (SPREAD) par ^= 1;
     }
     if (list_mode) {
@@ -686,8 +604,9 @@ void release_stream_state(int device, hipStream_t stream)
 __global__ __launch_bounds__(256) void k_build_e2d(const uint16_t *__restrict__ u16, int black, uint2 *__restrict__ e2d, int *__restrict__ bad)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= E2D_RECORDS) return;
+    if (b >= E2D_RECORDS_EXT) return;
     auto entry = [&](int i) { return (uint16_t)((((int)u16[i & 32767]) >> (13 - (i >> 15))) + black); };
+    if (b >= E2D_RECORDS) { e2d[b] = make_uint2(entry(E2R_ENTRIES - 1), 0u); return; }       // beyond the table: its last value
     unsigned bits = 0;
     uint16_t prev = entry(32 * b);
     const uint16_t base = prev;
@@ -721,11 +640,11 @@ static int e2r_table(const Device *dev, int black, const uint2 **out, hipStream_
         if (it != g_e2r.end()) { it->second.used = ++g_e2r_clock; *out = it->second.table; return MLVFS_AMD_OK; }
     }
     uint2 *t = nullptr;
-    MLV_HIP(hipMalloc(&t, sizeof(uint2) * (E2D_RECORDS + 1)));          // the records, then the counter of the check
-    int *d_bad = (int *)(t + E2D_RECORDS);
+    MLV_HIP(hipMalloc(&t, sizeof(uint2) * (E2D_RECORDS_EXT + 1)));          // the records, then the counter of the check
+    int *d_bad = (int *)(t + E2D_RECORDS_EXT);
     int bad = -1;
     (void)hipMemsetAsync(d_bad, 0, sizeof(int), stream);
-    hipLaunchKernelGGL(k_build_e2d, dim3((E2D_RECORDS + 255) / 256), dim3(256), 0, stream, dev->luts.u16, black, t, d_bad);
+    hipLaunchKernelGGL(k_build_e2d, dim3((E2D_RECORDS_EXT + 255) / 256), dim3(256), 0, stream, dev->luts.u16, black, t, d_bad);
     (void)hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess || bad != 0) {       // other streams use the table from now on
         (void)hipFree(t);

@@ -116,6 +116,7 @@ __device__ __forceinline__ mlv_i32x4 table_rsrc(const void *p, unsigned stride, 
 // benchmark's frames, 9.4 -> 7.0 in low light, 10.8 -> 8.75 on colour patches; cs5x5 8.35 -> 8.22 / 10.8 -> 10.55 / 12.4 -> 11.8.
 constexpr int E2R_ENTRIES = 14 * MLV_EV_RES;
 constexpr int E2D_RECORDS = E2R_ENTRIES / 32;
+constexpr int E2D_RECORDS_EXT = 2 * E2D_RECORDS;       // the table goes on with its last value up to 28 stops (k_frame_p looks up unclamped EVs)
 #ifdef KF_EXP_LEAN          // timing experiment: every rare path compiled out (results are wrong where one would have been taken)
 #define KF_EXP_PKONLY
 #define KF_EXP_NOFALLBACK
@@ -148,6 +149,7 @@ struct __align__(16) SmemT {
     int next_tile, next_end;            // the tile after this one and the end of the run it belongs to (thread 0 -> all)
     int dark_items[2];                  // loader items of the current / next tile that hold pixels at or below black (5x5 only)
     int walk[5];                        // thread 0's: first tile of the group's range, tiles that go out in runs, tiles per run, group, runs all out
+    int low[2];                         // some pixel this tile / the tile before loaded lies at most 64 above black (by tile parity)
 };
 static_assert(sizeof(SmemT<true, true>) <= 40 * 1024, "four workgroups per CU need <= 40 KiB of LDS each");
 
@@ -176,14 +178,35 @@ __device__ __forceinline__ void sort5(int (&v)[5])
 
 // raw2ev through the LDS mantissa table (main.c:163-167 semantics, see common.h):
 //   ev(lin) = T16[(lin << (13 - e)) & 8191] + (e << 15),  e = floor(log2 lin)
+// Round 5: LDS holds T'[m] = T16[m] - 4 m (load_t16_rel; T16[m] >= 4 m since log2(1 + x) >= x on [0, 1], checked where the host
+// builds the table).  The float of lin is (e + 127) << 23 | m << 10, so its bits >> 8 are (e + 127) << 15 | 4 m and
+//   ev(lin) + (127 << 15) = (float bits >> 8) + T'[m]
+// -- a shift and an add per pixel where exponent and table value took a bit-field extract and a shift-add (and the shift issues
+// faster than the extract: tools/valu_rate4.hip).
 // Pixels at or below black (ev = INT_MIN / 0) or beyond the table are the rare case: a
 // wave-wide vote picks the branch-free fast path unless some lane needs the fix-up.
 // Exponent and 13-bit mantissa fraction come out of the float conversion (exact for l < 2^24): one v_cvt + one v_bfe
 // instead of count-leading-zeros, variable shift and mask.
+template <bool SPREAD>
+__device__ __forceinline__ void load_t16_rel(uint16_t *dst, const uint16_t *src, int tid)
+{
+    if (SPREAD) {
+        for (int i = tid; i < MLV_T16_N; i += 256) dst[i + (i >> 7)] = (uint16_t)(src[i] - 4 * i);
+    } else {
+        const uint4 *s4 = (const uint4 *)src;
+        uint4 *d4 = (uint4 *)dst;
+        for (int i = tid; i < MLV_T16_N * 2 / 16; i += 256) {       // eight entries: 4 m = 32 i, 32 i + 4, ... (no borrow between the halves: T16[m] >= 4 m)
+            uint4 v = s4[i];
+            const uint32_t b = (uint32_t)(32 * i) * 0x10001u + 0x40000u;
+            v.x -= b; v.y -= b + 0x00080008u; v.z -= b + 0x00100010u; v.w -= b + 0x00180018u;
+            d4[i] = v;
+        }
+    }
+}
 __device__ __forceinline__ int ev_index(int l) { return (int)((__float_as_uint((float)(unsigned)l) >> 10) & 8191u); }
 __device__ __forceinline__ int ev_value(int l, int tv)
 {
-    return tv + (int)((__float_as_uint((float)(unsigned)l) >> 8) & 0xFFFF8000u) - (127 << 15);
+    return tv + (int)(__float_as_uint((float)(unsigned)l) >> 8) - (127 << 15);        // (tv: an entry of the relative table)
 }
 
 // v_bfe_u32 as written: the optimiser otherwise re-expands a bit-field extract whose result is shifted or scaled into
@@ -235,11 +258,11 @@ __device__ __forceinline__ void cell_pair_ev(const uint32_t *p0, const uint32_t 
         // otherwise sinks each read next to its use and waits for it there)
         uint32_t ex[8], eb[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) ex[i] = bfe_asm<23, 8>(fb[i]);                                    // while the reads are in flight
+        for (int i = 0; i < 8; i++) ex[i] = fb[i] >> 8;                                               // while the reads are in flight
         asm volatile("" :: "v"(ex[0]), "v"(ex[1]), "v"(ex[2]), "v"(ex[3]), "v"(ex[4]), "v"(ex[5]), "v"(ex[6]), "v"(ex[7]));
         asm volatile("" :: "v"(tv[0]), "v"(tv[1]), "v"(tv[2]), "v"(tv[3]), "v"(tv[4]), "v"(tv[5]), "v"(tv[6]), "v"(tv[7]));
 #pragma unroll
-        for (int i = 0; i < 8; i++) eb[i] = (ex[i] << 15) + (uint32_t)tv[i];                          // v_lshl_add_u32
+        for (int i = 0; i < 8; i++) eb[i] = ex[i] + (uint32_t)tv[i];
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const uint32_t gb = (eb[4 * c + 1] + eb[4 * c + 2]) >> 1;           // chroma_smooth.c:32,54 (both EVs >= 0: trunc == floor)
@@ -276,19 +299,20 @@ __device__ __forceinline__ void cell_multi_ev_fast(const uint32_t *p0, const uin
                                                    int (&ge)[NC], int (&dr)[NC], int (&db)[NC])
 {
     uint32_t fb[4 * NC], tv[4 * NC], ex[4 * NC], eb[4 * NC];
-    // float(px) - float(black) == float(px - black), exactly (integers below 2^24): v_sub_f32 issues at twice the rate of
-    // v_sub_u32 on gfx950 (tools/valu_rate2.hip: 0.45 against 0.29 per clock and SIMD)
-    const float fblack = (float)black;
+    // px | 0x4B000000 IS the float 2^23 + px; minus (2^23 + black) it is float(px - black), exactly (integers below 2^24): a v_or_b32
+    // with a literal and a v_sub_f32, both at twice the rate of the v_cvt_f32_u32 of rounds 3-4 (tools/valu_rate4.hip: 0.456 / 0.45
+    // against 0.245 per clock and SIMD)
+    const float fmagic = 8388608.0f + (float)black;
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const uint32_t px[4] = { p0[2 * c], p0[2 * c + 1], p1[2 * c], p1[2 * c + 1] };
 #pragma unroll
-        for (int i = 0; i < 4; i++) fb[4 * c + i] = __float_as_uint((float)px[i] - fblack);
+        for (int i = 0; i < 4; i++) fb[4 * c + i] = __float_as_uint(__uint_as_float(px[i] | 0x4B000000u) - fmagic);
     }
 #pragma unroll
     for (int i = 0; i < 4 * NC; i++) tv[i] = *(const uint16_t *)((const char *)t + t16_offset<SPREAD>(fb[i]));
 #pragma unroll
-    for (int i = 0; i < 4 * NC; i++) ex[i] = bfe_asm<23, 8>(fb[i]);
+    for (int i = 0; i < 4 * NC; i++) ex[i] = fb[i] >> 8;
 #pragma unroll
     for (int i = 0; i < 4 * NC; i += 8) {                // opaque uses: the reads stay unconditional and back to back
         asm volatile("" :: "v"(ex[i]), "v"(ex[i + 1]), "v"(ex[i + 2]), "v"(ex[i + 3]), "v"(ex[i + 4]), "v"(ex[i + 5]), "v"(ex[i + 6]), "v"(ex[i + 7]));
@@ -298,7 +322,7 @@ __device__ __forceinline__ void cell_multi_ev_fast(const uint32_t *p0, const uin
         asm volatile("" :: "v"(tv[i]), "v"(tv[i + 1]), "v"(tv[i + 2]), "v"(tv[i + 3]), "v"(tv[i + 4]), "v"(tv[i + 5]), "v"(tv[i + 6]), "v"(tv[i + 7]));
     }
 #pragma unroll
-    for (int i = 0; i < 4 * NC; i++) eb[i] = (ex[i] << 15) + tv[i];
+    for (int i = 0; i < 4 * NC; i++) eb[i] = ex[i] + tv[i];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const uint32_t gb = (eb[4 * c + 1] + eb[4 * c + 2]) >> 1;
@@ -322,13 +346,13 @@ __device__ __forceinline__ void cell_multi_ev_dark(const uint32_t *p0, const uin
                                                    int (&ge)[NC], int (&dr)[NC], int (&db)[NC])
 {
     uint32_t fb[4 * NC], tv[4 * NC], ex[4 * NC], eb[4 * NC], z[4 * NC];
-    const float fblack = (float)black;
+    const float fmagic = 8388608.0f + (float)black;
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const uint32_t px[4] = { p0[2 * c], p0[2 * c + 1], p1[2 * c], p1[2 * c + 1] };
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float f = (float)px[i] - fblack;
+            const float f = __uint_as_float(px[i] | 0x4B000000u) - fmagic;
             z[4 * c + i] = __float_as_uint(fabsf(f) - 0.5f);
             fb[4 * c + i] = __float_as_uint(fmaxf(f, 1.0f));
         }
@@ -336,7 +360,7 @@ __device__ __forceinline__ void cell_multi_ev_dark(const uint32_t *p0, const uin
 #pragma unroll
     for (int i = 0; i < 4 * NC; i++) tv[i] = *(const uint16_t *)((const char *)t + t16_offset<SPREAD>(fb[i]));
 #pragma unroll
-    for (int i = 0; i < 4 * NC; i++) ex[i] = bfe_asm<23, 8>(fb[i]);
+    for (int i = 0; i < 4 * NC; i++) ex[i] = fb[i] >> 8;
 #pragma unroll
     for (int i = 0; i < 4 * NC; i += 8) {
         asm volatile("" :: "v"(ex[i]), "v"(ex[i + 1]), "v"(ex[i + 2]), "v"(ex[i + 3]), "v"(ex[i + 4]), "v"(ex[i + 5]), "v"(ex[i + 6]), "v"(ex[i + 7]));
@@ -346,7 +370,7 @@ __device__ __forceinline__ void cell_multi_ev_dark(const uint32_t *p0, const uin
         asm volatile("" :: "v"(tv[i]), "v"(tv[i + 1]), "v"(tv[i + 2]), "v"(tv[i + 3]), "v"(tv[i + 4]), "v"(tv[i + 5]), "v"(tv[i + 6]), "v"(tv[i + 7]));
     }
 #pragma unroll
-    for (int i = 0; i < 4 * NC; i++) eb[i] = (z[i] & 0x80000000u) | ((ex[i] << 15) + tv[i]);      // v_lshl_add_u32, v_and_or_b32
+    for (int i = 0; i < 4 * NC; i++) eb[i] = (z[i] & 0x80000000u) | (ex[i] + tv[i]);      // v_add_u32, v_and_or_b32
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const uint32_t gb = (uint32_t)half_trunc((int)(eb[4 * c + 1] + eb[4 * c + 2]));
@@ -1047,9 +1071,179 @@ typedef const __attribute__((address_space(4))) FrameArgs *KArgs;
 __device__ __forceinline__ KArgs cold_args()
 {
     KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+#ifndef KF_EXP_WARM_ARGS           // (A/B: the compiler sees through, hoists every load out of the tile loop and keeps the arguments live)
     asm volatile("" : "+s"(p));
+#endif
     return p;
 }
 
+
+// ---------------------------------------------------------------- prefetch of a tile's new rows (both kernels)
+// the item of lane L (its row of the tile: l_row) of the tile at (tx0, ty0); new0: first plane row the tile loads itself
+template <int BPP, int VEC>
+__device__ __forceinline__ void issue_tile_rows(uint32_t (&r0)[4], uint32_t (&r1)[4], const uint8_t *frame, unsigned bytes, const ItemLane &L, int l_row,
+                                                int w, int h, int tx0, int ty0, int new0)
+{
+    const int ybase = ty0 - 2 * HC + 2 * new0;
+#ifdef KF_EXP_NO_FASTPREF
+    if (false) {
+#else
+    if (VEC != 2 && tx0 >= 8 && tx0 + 2 * TCW + 8 <= w && ybase + 2 * TCH <= h) {           // (scalar)
+#endif
+        // A tile whose new rows and halo columns lie inside the frame -- nine in ten -- clamps nothing, and with rows that are
+        // whole dwords (every layout but VEC 2) the dword alignment of a main item commutes with the row and tile offsets: what
+        // is left per lane is a constant, the tile's part goes into the buffer descriptor (16 bytes early: the left halo's
+        // group lies before the tile) and the second row is the first plus the pitch as the load's scalar offset.
+        // issue_item's general form costs 45 vector instructions per tile, this one a dozen.
+        constexpr uint32_t GB = (uint32_t)BPP;
+        const uint32_t pitch = (uint32_t)(w >> 3) * GB;
+        const uint32_t S = (uint32_t)ybase * pitch + (uint32_t)(tx0 >> 3) * GB - 16u;
+        const mlv_i32x4 rs = frame_rsrc(frame + S, bytes - S);
+        const uint32_t rowoff = __umul24((uint32_t)(2 * l_row), pitch) + 16u;
+        const uint32_t va = rowoff + ((uint32_t)((L.xoff_a >> 3) * (int)GB) & L.amask);
+        const uint32_t vb = rowoff + ((uint32_t)((L.xoff_b >> 3) * (int)GB) & L.amask) + L.boff;
+        const mlv_u32x2 a0 = mlv_rbl_x2(rs, (int)va, 0, KF_SRC_AUX), b0 = mlv_rbl_x2(rs, (int)vb, 0, KF_SRC_AUX);
+        const mlv_u32x2 a1 = mlv_rbl_x2(rs, (int)va, (int)pitch, KF_SRC_AUX), b1 = mlv_rbl_x2(rs, (int)vb, (int)pitch, KF_SRC_AUX);
+        r0[0] = a0.x; r0[1] = a0.y; r0[2] = b0.x; r0[3] = b0.y;
+        r1[0] = a1.x; r1[1] = a1.y; r1[2] = b1.x; r1[3] = b1.y;
+    } else
+        issue_item<BPP>(r0, r1, frame_rsrc(frame, bytes), L, w, h, tx0, ty0, new0 + l_row);
+}
+
+// ---------------------------------------------------------------- output stage (both kernels)
+// What the stage needs of the cold arguments, fetched in one go (the loads go out together and are waited for once)
+struct OutArgs {
+    const uint2 *e2d;
+    uint8_t *dst;
+    size_t dst_stride;
+    int stripes, coef_pk, coef_fast, white;
+    int co[8];
+};
+__device__ __forceinline__ OutArgs out_args(KArgs kt)
+{
+    OutArgs o;
+    o.e2d = kt->e2d; o.dst = kt->dst; o.dst_stride = kt->dst_stride;
+    o.stripes = kt->stripes; o.coef_pk = kt->coef_pk; o.coef_fast = kt->coef_fast; o.white = kt->white;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.co[i] = kt->coef[i];
+    return o;
+}
+
+// R is the lower half of a cell's top word, B the upper half of its bottom word: where `ok`, they take the looked-up values.  One
+// v_cndmask_b32_sdwa each (the condition in VCC, the other half of the destination preserved) -- rounds 2-4 chose a v_perm_b32
+// selector with a v_cndmask_b32 and permuted: two instructions per word.
+__device__ __forceinline__ void put_rb(uint32_t &top, uint32_t &bot, uint32_t ur, uint32_t ub, bool ok)
+{
+#ifdef KF_EXP_PERM_SELECT          // (A/B: the selector form of rounds 2-4)
+    top = __builtin_amdgcn_perm(ur, top, ok ? 0x03020504u : 0x03020100u);
+    bot = __builtin_amdgcn_perm(ub, bot, ok ? 0x05040100u : 0x03020100u);
+    return;
+#endif
+    const unsigned long long m = __ballot(ok);
+    asm("s_mov_b64 vcc, %4\n\t"
+        "v_cndmask_b32_sdwa %0, %0, %2, vcc dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+        "v_cndmask_b32_sdwa %1, %1, %3, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0"
+        : "+v"(top), "+v"(bot) : "v"(ur), "v"(ub), "s"(m) : "vcc");
+}
+
+// The rest of a strip once the EVs of its smoothed R and B are known (er = ge + median(dr), eb = ge + median(db), wrapping like the
+// reference's ints): look-up, R / B replacement (chroma_smooth.c:28, 35, 64-68), stripes (stripes.c:250-266), store.
+//   low_any (scalar): some pixel of the rows this tile holds lies at most 64 above black (or the tile holds pixel-map cells).  Without
+//   one, every EV involved lies in [6, 14] stops: er and eb stay below 28 stops -- where the table goes on with its last value
+//   (E2D_RECORDS_EXT) -- so the clamp of chroma_smooth.c:67 is the table's own, and one below zero belongs to a cell that keeps its
+//   pixel (er > 1 stop fails; its look-up is out of range and reads 0).  And the stripes epilogue's "more than 64 above black" holds
+//   for every pixel: no mask.
+//   VECST: rows of whole 8-pixel groups on 16-byte aligned buffers (two 16-byte stores); else pixel by pixel.
+template <int METHOD, bool PACKED, bool VECST, class SM>
+__device__ __forceinline__ void strip_output(const SM &sm, const OutArgs &oa, int w, int h, int black, int f, int tx0, int ty0, int jj, int kk,
+                                             bool smooth, const int (&gev)[STRIP], const int (&er)[STRIP], const int (&eb)[STRIP], bool low_any, bool store)
+{
+    const int y = ty0 + 2 * jj, x = tx0 + 2 * STRIP * kk;
+#ifdef KF_EXP_NO_LOWSKIP           // (A/B: always the clamp and the mask)
+    low_any = true;
+#endif
+    uint32_t top[STRIP], bot[STRIP];        // (R | G1<<16), (G2 | B<<16)
+    auto read_raw = [&]() {
+        const uint4 v0 = *(const uint4 *)&sm.raw[2 * jj][2 * STRIP * kk];
+        const uint4 v1 = *(const uint4 *)&sm.raw[2 * jj + 1][2 * STRIP * kk];
+        top[0] = v0.x; top[1] = v0.y; top[2] = v0.z; top[3] = v0.w;
+        bot[0] = v1.x; bot[1] = v1.y; bot[2] = v1.z; bot[3] = v1.w;
+    };
+    if (METHOD == 0) read_raw();
+    if (METHOD != 0) {
+        const mlv_i32x4 rs_e2d = table_rsrc(oa.e2d, 8, E2D_RECORDS_EXT);
+        // the output pixel by EV (one 8-byte record per 32 EV steps): all 8 look-ups issued before the first use
+        int ur[STRIP], ub[STRIP], cr[STRIP], cb[STRIP];
+        mlv_tab_u32x2 dr2[STRIP], db2[STRIP];
+#pragma unroll
+        for (int c = 0; c < STRIP; c++) {
+            cr[c] = er[c]; cb[c] = eb[c];
+            if (low_any) { cr[c] = min(max(er[c], 0), MLV_EV_MAX); cb[c] = min(max(eb[c], 0), MLV_EV_MAX); }
+#ifdef KF_EXP_NOLOOKUP
+            dr2[c].x = cr[c]; dr2[c].y = 0; db2[c].x = cb[c]; db2[c].y = 0;
+#else
+            dr2[c] = mlv_sbl_x2(rs_e2d, cr[c] >> 5, 0, 0, KF_E2R_AUX);
+            db2[c] = mlv_sbl_x2(rs_e2d, cb[c] >> 5, 0, 0, KF_E2R_AUX);
+#endif
+        }
+        read_raw();
+        // chroma_smooth.c:27 leaves columns 0..3 and w-4.. alone: only the tiles at the frame's left and right margin test for that
+        const bool x_margin = tx0 < 4 || tx0 + 2 * TCW > w - 4;                   // scalar
+        // which cells take the smoothed values: decided while the look-ups are under way
+        bool okc[STRIP];
+#pragma unroll
+        for (int c = 0; c < STRIP; c++) {
+            const int xc = x + 2 * c;
+            okc[c] = smooth && gev[c] >= 2 * MLV_EV_RES && er[c] > MLV_EV_RES && eb[c] > MLV_EV_RES;
+            if (x_margin) okc[c] = okc[c] && xc >= 4 && xc < w - 4;
+        }
+        // (the fence keeps the eight look-ups together and comes after the decisions in program order: the compiler
+        // schedules them under the look-ups' latency)
+        asm volatile("" :: "v"(dr2[0]), "v"(dr2[1]), "v"(dr2[2]), "v"(dr2[3]), "v"(db2[0]), "v"(db2[1]), "v"(db2[2]), "v"(db2[3]));
+#pragma unroll
+        for (int c = 0; c < STRIP; c++) {             // v_bfe_u32 (the width operand's low five bits count), v_bcnt_u32_b32
+            ur[c] = (int)(__builtin_popcount(bfe_low_bits(dr2[c].y, (uint32_t)cr[c])) + dr2[c].x);
+            ub[c] = (int)(__builtin_popcount(bfe_low_bits(db2[c].y, (uint32_t)cb[c])) + db2[c].x);
+        }
+#pragma unroll
+        for (int c = 0; c < STRIP; c++) put_rb(top[c], bot[c], (uint32_t)ur[c], (uint32_t)ub[c], okc[c]);
+    }
+    if (oa.stripes) {
+        // a strip starts at an x that is a multiple of 8, so pixel n of the strip has column phase n
+        const int black16 = (int)(uint16_t)black, white16 = (int)(uint16_t)oa.white;
+        if (PACKED && oa.coef_pk) {
+            if (low_any) stripe_strip_pk<true>(top, bot, oa.co, black16, white16);
+            else stripe_strip_pk<false>(top, bot, oa.co, black16, white16);
+        }
+        else if (oa.coef_fast) stripe_strip<true>(top, bot, oa.co, black16, white16);
+        else stripe_strip<false>(top, bot, oa.co, black16, white16);
+    }
+    if (store && y < h) {
+        if (VECST) {
+            if (x < w) {
+                // the frame as a buffer whose base is the tile's first pixel: the lane's part of the address is (2 j w + 8 k) pixels.
+                // Non-temporal stores: the output is not read again by this launch (profiles/r04/ab_cache_policy.log: -1 ... -3.5 %)
+                const uint32_t T = ((uint32_t)ty0 * (uint32_t)w + (uint32_t)tx0) * 2u;
+                const mlv_i32x4 rs_out = frame_rsrc(oa.dst + (size_t)f * oa.dst_stride + T, (uint32_t)w * (uint32_t)h * 2u - T);
+                const uint32_t vo = (__umul24((uint32_t)(2 * jj), (uint32_t)w) + 2 * STRIP * (uint32_t)kk) * 2u;
+                const mlv_u32x4 vt = { top[0], top[1], top[2], top[3] }, vb = { bot[0], bot[1], bot[2], bot[3] };
+                mlv_rbs_x4(vt, rs_out, (int)vo, 0, 2);                                     // (2: non-temporal)
+                if (y + 1 < h) mlv_rbs_x4(vb, rs_out, (int)vo, w * 2, 2);
+            }
+        } else {
+            uint16_t *out = (uint16_t *)(oa.dst + (size_t)f * oa.dst_stride);
+#pragma unroll 1
+            for (int c = 0; c < STRIP; c++) {
+                const int xc = x + 2 * c;
+                if (xc < w) out[(size_t)y * w + xc] = (uint16_t)top[c];
+                if (xc + 1 < w) out[(size_t)y * w + xc + 1] = (uint16_t)(top[c] >> 16);
+                if (y + 1 < h) {
+                    if (xc < w) out[(size_t)(y + 1) * w + xc] = (uint16_t)bot[c];
+                    if (xc + 1 < w) out[(size_t)(y + 1) * w + xc + 1] = (uint16_t)(bot[c] >> 16);
+                }
+            }
+        }
+    }
+}
 
 }  // namespace mlv

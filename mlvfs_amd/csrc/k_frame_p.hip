@@ -228,16 +228,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
     constexpr int NEW0 = 2 * HC;
     const int tid = threadIdx.x;
 
-    {
-        KArgs ka = cold_args();
-        if (SPREAD) {
-            for (int i = tid; i < MLV_T16_N; i += 256) sm.t16[i + (i >> 7)] = ka->t16[i];
-        } else {
-            const uint4 *src = (const uint4 *)ka->t16;
-            uint4 *dstl = (uint4 *)sm.t16;
-            for (int i = tid; i < MLV_T16_N * 2 / 16; i += 256) dstl[i] = src[i];
-        }
-    }
+    load_t16_rel<SPREAD>(sm.t16, cold_args()->t16, tid);
     const int tiles_per_frame = a.tiles_x * a.tiles_y;
     const bool pmap_ok = tiles_per_frame <= PMAP_WORDS * 32;
     int band_end;
@@ -311,28 +302,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
         const bool l_edge = tl >= N_MAIN;
         const int l_row = l_edge ? tl - N_MAIN : tl >> 4;
         const ItemLane L = item_lane<PACKED, VEC>(tl & 15, l_edge);
-        const uint8_t *frame = sa.p + (size_t)p.f * sa.stride;
-        const unsigned bytes = sa.bytes;
-        const int tx0 = p.tcol * 2 * TCW, ty0 = p.trow * 2 * TCH;
-        if (VEC != 2 && tx0 >= 8 && tx0 + 2 * TCW + 8 <= a.w && ty0 + 2 * TCH + 2 * HC <= a.h) {           // (scalar)
-            // A tile whose new rows and halo columns lie inside the frame -- nine in ten -- clamps nothing, and with rows that are
-            // whole dwords (every layout but VEC 2) the dword alignment of a main item commutes with the row and tile offsets: what
-            // is left per lane is a constant, the tile's part goes into the buffer descriptor (16 bytes early: the left halo's
-            // group lies before the tile) and the second row is the first plus the pitch as the load's scalar offset.
-            // issue_item's general form costs 45 vector instructions per tile, this one a dozen.
-            constexpr uint32_t GB = (uint32_t)BPP;
-            const uint32_t pitch = (uint32_t)(a.w >> 3) * GB;
-            const uint32_t S = (uint32_t)(ty0 + 2 * HC) * pitch + (uint32_t)(tx0 >> 3) * GB - 16u;
-            const mlv_i32x4 rs = frame_rsrc(frame + S, bytes - S);
-            const uint32_t rowoff = __umul24((uint32_t)(2 * l_row), pitch) + 16u;
-            const uint32_t va = rowoff + ((uint32_t)((L.xoff_a >> 3) * (int)GB) & L.amask);
-            const uint32_t vb = rowoff + ((uint32_t)((L.xoff_b >> 3) * (int)GB) & L.amask) + L.boff;
-            const mlv_u32x2 a0 = mlv_rbl_x2(rs, (int)va, 0, KF_SRC_AUX), b0 = mlv_rbl_x2(rs, (int)vb, 0, KF_SRC_AUX);
-            const mlv_u32x2 a1 = mlv_rbl_x2(rs, (int)va, (int)pitch, KF_SRC_AUX), b1 = mlv_rbl_x2(rs, (int)vb, (int)pitch, KF_SRC_AUX);
-            r0[0] = a0.x; r0[1] = a0.y; r0[2] = b0.x; r0[3] = b0.y;
-            r1[0] = a1.x; r1[1] = a1.y; r1[2] = b1.x; r1[3] = b1.y;
-        } else
-            issue_item<BPP>(r0, r1, frame_rsrc(frame, bytes), L, a.w, a.h, tx0, ty0, NEW0 + l_row);
+        issue_tile_rows<BPP, VEC>(r0, r1, sa.p + (size_t)p.f * sa.stride, sa.bytes, L, l_row, a.w, a.h, p.tcol * 2 * TCW, p.trow * 2 * TCH, NEW0);
     };
     // The reference of a tile that does not continue the one above: pixel (lane & 7, lane >> 3 & 1) of the 8 x 2 block at the tile's
     // centre (inside the frame, on even coordinates: R G1 / G2 B), one per lane; the loads go out with the tile's prefetch
@@ -425,6 +395,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
         }
         const int trow = cur.trow, tx0 = cur.tcol * 2 * TCW, ty0 = cur.trow * 2 * TCH;
         const int tr = cur.trow * a.tiles_x + cur.tcol;
+        const Src sa = src_of(cold_args());      // (asked for here, needed when the next tile is prefetched: no wait there)
         // ---- pixel-map entries of this tile (few tiles have any)
         bool tile_patched = false;
         int pbeg = 0, pend = 0;
@@ -441,7 +412,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
         }
         __builtin_amdgcn_s_setprio(0);
         if (!cont) {
-            if (!have_smp) issue_sample(src_of(cold_args()), cur, tid);
+            if (!have_smp) issue_sample(sa, cur, tid);
             take_sample();
         }
         int tid_o = tid;
@@ -467,19 +438,22 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
             // the first tile of a run (or of a column): the four plane rows above the tile's own, straight from memory -- threads
             // 0..63 the main items of rows 0..3, 64..67 their edge items -- while the other waves convert the prefetched rows
             if (tid_o < N_TOP) {
-                KArgs ka = cold_args();
                 const bool te = tid_o >= N_TOP_MAIN;
                 const int trw = te ? tid_o - N_TOP_MAIN : tid_o >> 4;
                 const ItemLane TL = item_lane<PACKED, VEC>(tid_o & 15, te);
                 uint32_t q0[4] = { 0, 0, 0, 0 }, q1[4] = { 0, 0, 0, 0 };
-                issue_item<BPP, true>(q0, q1, frame_rsrc(ka->src + (size_t)cur.f * ka->src_stride, ka->src_bytes), TL, a.w, a.h, tx0, ty0, trw);
+                issue_item<BPP, true>(q0, q1, frame_rsrc(sa.p + (size_t)cur.f * sa.stride, sa.bytes), TL, a.w, a.h, tx0, ty0, trw);
                 do_item(TL, q0, q1, trw, tid_o & 15);
             }
         }
+#ifndef KFP_EXP_NOLOAD
         if (tid_o < N_ITEMS) {
             const bool l_edge = tid_o >= N_MAIN;
             do_item(item_lane<PACKED, VEC>(tid_o & 15, l_edge), r0, r1, NEW0 + (l_edge ? tid_o - N_MAIN : tid_o >> 4), tid_o & 15);
         }
+#else
+        asm volatile("" :: "v"(r0[0]), "v"(r0[1]), "v"(r0[2]), "v"(r0[3]), "v"(r1[0]), "v"(r1[1]), "v"(r1[2]), "v"(r1[3]));
+#endif
         if (tid == 0) { sm.next_tile = nt; sm.next_end = ne; }
         lds_barrier();
         if (tid == 0) { sm.unc[par ^ 1] = 0; sm.low[par ^ 1] = 0; }          // (read by all before this barrier, written again behind the next tile's)
@@ -511,22 +485,16 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
         // ---- prefetch the next tile (and, where it starts anew, its sample) while the medians run
         Pos nxt = pos_below(cur);
         if (t_next != t + 1 || t_next >= band_end) nxt = pos_of(min(t_next, band_end - 1));
-        const Src sa = src_of(cold_args());
+#ifndef KFP_EXP_NOPREF
         {
             int tid_p = tid;
             asm volatile("" : "+v"(tid_p));
             issue_tile(sa, nxt, tid_p);
             if (!cont_next) issue_sample(sa, nxt, tid_p);
         }
+#endif
         // what the output stage needs of the cold arguments, in one go and early: the loads go out together, long before their first use
-        KArgs kt = cold_args();
-        const uint2 *o_e2d = kt->e2d;
-        uint8_t *o_dst = kt->dst;
-        const size_t o_dst_stride = kt->dst_stride;
-        const int o_stripes = kt->stripes, o_coef_pk = kt->coef_pk, o_coef_fast = kt->coef_fast, o_white = kt->white;
-        int o_co[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) o_co[i] = kt->coef[i];
+        const OutArgs oa = out_args(cold_args());
 
         // ---- medians + output: one thread = 4 cells = 8 px on two rows
         int tid_m = tid;
@@ -539,6 +507,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
         const int y = ty0 + 2 * j, x = tx0 + 2 * STRIP * k;
         const bool smooth_row = y >= 4 && y < a.h - 5;                                    // chroma_smooth.c:25
         mlv_pk16 o[STRIP] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
+#ifndef KFP_EXP_NOMED
         if (CHAIN) {
             const int lane = tid_m & 63;
             const bool publishes = lane == 0 && tid_m != 0, collects = lane == 63 && tid_m < 192;
@@ -563,66 +532,24 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
             else pstrip_median5(sm.pk, j, STRIP * k, o);
         }
         if (is_strip && smooth_row && pk_uncertain(o)) sm.unc[par] = 1;
-        // ---- R / B replacement, stripes, store (k_frame's finish_strip with the medians relative to the reference)
+#else
+        { const uint4 v = *(const uint4 *)&sm.pk[j + 2][STRIP * k]; o[0] = as_pk(v.x); o[1] = as_pk(v.y); o[2] = as_pk(v.z); o[3] = as_pk(v.w); }
+#endif
+        // ---- R / B replacement, stripes, store: the medians come relative to the reference
+#ifdef KFP_EXP_NOOUT
+        if (is_strip && o[0].x == 12345 && o[1].y == 321) {
+#else
         if (is_strip) {
-            const mlv_i32x4 rs_e2d = table_rsrc(o_e2d, 8, E2D_RECORDS);
-            uint32_t top[STRIP], bot[STRIP];
+#endif
             const int4 g4 = *(const int4 *)&sm.ge[j][STRIP * k];
             const int gev[STRIP] = { g4.x, g4.y, g4.z, g4.w };
-            int er[STRIP], eb[STRIP], ur[STRIP], ub[STRIP], cr[STRIP], cb[STRIP];
-            mlv_tab_u32x2 dr2[STRIP], db2[STRIP];
+            int er[STRIP], eb[STRIP];
 #pragma unroll
             for (int c = 0; c < STRIP; c++) {
                 er[c] = wadd(wadd(gev[c], ref_r), (int)o[c].x);
                 eb[c] = wadd(wadd(gev[c], ref_b), (int)o[c].y);
-                cr[c] = min(max(er[c], 0), MLV_EV_MAX); cb[c] = min(max(eb[c], 0), MLV_EV_MAX);
-                dr2[c] = mlv_sbl_x2(rs_e2d, cr[c] >> 5, 0, 0, KF_E2R_AUX);
-                db2[c] = mlv_sbl_x2(rs_e2d, cb[c] >> 5, 0, 0, KF_E2R_AUX);
             }
-            {
-                const uint4 v0 = *(const uint4 *)&sm.raw[2 * j][2 * STRIP * k];
-                const uint4 v1 = *(const uint4 *)&sm.raw[2 * j + 1][2 * STRIP * k];
-                top[0] = v0.x; top[1] = v0.y; top[2] = v0.z; top[3] = v0.w;
-                bot[0] = v1.x; bot[1] = v1.y; bot[2] = v1.z; bot[3] = v1.w;
-            }
-            const bool x_margin = tx0 < 4 || tx0 + 2 * TCW > a.w - 4;
-            bool okc[STRIP];
-#pragma unroll
-            for (int c = 0; c < STRIP; c++) {
-                const int xc = x + 2 * c;
-                okc[c] = smooth_row && gev[c] >= 2 * MLV_EV_RES && er[c] > MLV_EV_RES && eb[c] > MLV_EV_RES;
-                if (x_margin) okc[c] = okc[c] && xc >= 4 && xc < a.w - 4;
-            }
-            asm volatile("" :: "v"(dr2[0]), "v"(dr2[1]), "v"(dr2[2]), "v"(dr2[3]), "v"(db2[0]), "v"(db2[1]), "v"(db2[2]), "v"(db2[3]));
-#pragma unroll
-            for (int c = 0; c < STRIP; c++) {
-                ur[c] = (int)(__builtin_popcount(bfe_low_bits(dr2[c].y, (uint32_t)cr[c])) + dr2[c].x);
-                ub[c] = (int)(__builtin_popcount(bfe_low_bits(db2[c].y, (uint32_t)cb[c])) + db2[c].x);
-            }
-#pragma unroll
-            for (int c = 0; c < STRIP; c++) {
-                const bool ok = okc[c];
-                top[c] = __builtin_amdgcn_perm((uint32_t)ur[c], top[c], ok ? 0x03020504u : 0x03020100u);
-                bot[c] = __builtin_amdgcn_perm((uint32_t)ub[c], bot[c], ok ? 0x05040100u : 0x03020100u);
-            }
-            if (o_stripes) {
-                const int black16 = (int)(uint16_t)a.black, white16 = (int)(uint16_t)o_white;
-                if (PACKED && o_coef_pk) {
-                    if (low_cur | low_prev) stripe_strip_pk<true>(top, bot, o_co, black16, white16);
-                    else stripe_strip_pk<false>(top, bot, o_co, black16, white16);
-                }
-                else if (o_coef_fast) stripe_strip<true>(top, bot, o_co, black16, white16);
-                else stripe_strip<false>(top, bot, o_co, black16, white16);
-            }
-            if (y < a.h && x < a.w) {
-                // the frame as a buffer whose base is the tile's first pixel: the lane's part of the address is (2 j w + 8 k) pixels
-                const uint32_t T = ((uint32_t)ty0 * (uint32_t)a.w + (uint32_t)tx0) * 2u;
-                const mlv_i32x4 rs_out = frame_rsrc(o_dst + (size_t)cur.f * o_dst_stride + T, (uint32_t)a.w * (uint32_t)a.h * 2u - T);
-                const uint32_t vo = (__umul24((uint32_t)(2 * j), (uint32_t)a.w) + 2 * STRIP * (uint32_t)k) * 2u;
-                const mlv_u32x4 vt = { top[0], top[1], top[2], top[3] }, vb = { bot[0], bot[1], bot[2], bot[3] };
-                mlv_rbs_x4(vt, rs_out, (int)vo, 0, 2);                                     // (2: non-temporal)
-                if (y + 1 < a.h) mlv_rbs_x4(vb, rs_out, (int)vo, a.w * 2, 2);
-            }
+            strip_output<METHOD, PACKED, true, Smem>(sm, oa, a.w, a.h, a.black, cur.f, tx0, ty0, j, k, smooth_row, gev, er, eb, (low_cur | low_prev) != 0, true);
         }
         // ---- the rows the tile below shares with this one: read before the barrier that ends the tile, stored behind it
         // (threads 0..67: packed rows TCH.. -> 0..3, 68..131: pixel rows, 132..163: green EVs; one 16-byte piece each)
@@ -641,7 +568,11 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
             carry = *(const int4 *)((const char *)&sm + c_dst + c_delta);
         }
         lds_barrier();
+#if defined(KFP_EXP_NOLOAD) || defined(KFP_EXP_NOPREF) || defined(KFP_EXP_NOMED) || defined(KFP_EXP_NOOUT)
+        const int unc = 0 * __builtin_amdgcn_readfirstlane(sm.unc[par]);       // (the experiments' planes hold garbage)
+#else
         const int unc = __builtin_amdgcn_readfirstlane(sm.unc[par]);
+#endif
         if (do_carry) *(int4 *)((char *)&sm + c_dst) = carry;
         have_smp = !cont_next;
         if (unc) {
@@ -670,7 +601,8 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
     }
 }
 
-bool frame_p_exists(int method, int vec) { return method != 0 && vec != 0; }
+// (2x2 and 3x3: k_frame's int32 networks compile to three-input min / max / med3 and win against the packed two-input ones)
+bool frame_p_exists(int method, int vec) { return method == 5 && vec != 0; }
 
 void launch_frame_p_kernel(int method, bool packed, int vec, bool spread, int grid, hipStream_t stream, const FrameArgs &a)
 {

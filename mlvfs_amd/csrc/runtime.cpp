@@ -172,6 +172,7 @@ static void build_luts()
         int v = g_raw2ev_lin[j] - 13 * MLV_EV_RES;
         if (v < 0 || v > 65535) ok = 0;
         g_t16[j - 8192] = (uint16_t)v;
+        if (v < 4 * (j - 8192)) ok = 0;                  // the fused kernels keep T16[m] - 4 m (k_frame_dev.h: load_t16_rel)
     }
     for (int f = 0; f < MLV_U16_N; f++) {
         int v = g_ev2raw[(13 + 10) * MLV_EV_RES + f];

@@ -13,6 +13,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_WAVES SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU --output-format csv -d $O/p3 -- $B > $O/p3.log 2>&1
 cd $R
 python tools/pmc_summary.py "$O/p1/**/*counter_collection.csv" "$O/p2/**/*counter_collection.csv" "$O/p3/**/*counter_collection.csv" > $O/pmc_all.txt 2>&1 || true
-grep -A26 "k_frame<5, true" $O/pmc_all.txt > $O/pmc_k_frame.txt || true
+grep -A26 "k_frame" $O/pmc_all.txt > $O/pmc_k_frame.txt || true
 rm -rf $O/p1 $O/p2 $O/p3
 cat $O/pmc_k_frame.txt; tail -2 $O/p3.log
