@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         if (threadIdx.x == 0) list_done();
         return;
     }
-    if (METHOD != 0) load_t16_rel<SPREAD>(sm.t16, cold_args()->t16, threadIdx.x);
+    if (METHOD != 0) load_t16_rel<SPREAD>(sm.t16, cold_args()->t16, threadIdx.x);       // (relative form: k_frame_dev.h)
     // Which tiles of a frame have pixel-map entries: one bit per tile in LDS.  Reading the tile's list bounds from HBM in
     // every iteration made each wave wait for ALL its outstanding loads (the prefetch of the next tile included) before the
     // median phase; now only the few tiles that are touched fetch their bounds.
@@ -105,8 +105,9 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     // loader: threads 0..239 own the main item (row t / 16, group t % 16) of the tile's new rows, threads 240..254 the edge items
-    // (what a lane's item is, is derived from its number where it is needed -- a handful of operations per tile; kept in registers
-    // through the median phase the item descriptions were what the allocator spilt)
+    const bool l_edge = tid >= N_MAIN;
+    const int l_row = l_edge ? tid - N_MAIN : tid >> 4;
+    const ItemLane IL = item_lane<PACKED, VEC>(tid & 15, l_edge);
     // median phase: lane -> (row j, strip k).  5x5 (neighbour sharing): 17 consecutive lanes per tile row -- its 16 strips and, as
     // the 17th, the group of plane columns 64..67 (halo) that the last strip needs --, so that EVERY lane finds the group to its
     // right in the next lane; the plane reads are then linear in the thread number (16 bytes per lane: PW = 17 x 4) and free of
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         int nt, ne;
         draw(nt, ne);
         sm.next_tile = nt; sm.next_end = ne;
-        sm.dark_items[0] = 0; sm.dark_items[1] = 0; sm.fb_count = 0; sm.low[0] = 0; sm.low[1] = 0;
+        sm.dark_items[0] = 0; sm.dark_items[1] = 0; sm.fb_count = 0;
     }
     __syncthreads();
     int t = __builtin_amdgcn_readfirstlane(sm.next_tile), t_end = __builtin_amdgcn_readfirstlane(sm.next_end);
@@ -172,18 +173,18 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     // iteration re-load a valid item / tile.  A conditional load would need the old
     // register value on the other path, and the copies the compiler inserts for that
     // merge wait for the load right where it is issued.
-    struct Src { const uint8_t *p; size_t stride; unsigned bytes; };
-    auto src_of = [](KArgs ka) { Src s; s.p = ka->src; s.stride = ka->src_stride; s.bytes = ka->src_bytes; return s; };
-    auto issue_tile = [&](const Src &sa, const Pos &p) {
-        int tl = tid;
-        asm volatile("" : "+v"(tl));
-        const bool l_edge = tl >= N_MAIN;
-        const int l_row = l_edge ? tl - N_MAIN : tl >> 4;
-        const ItemLane IL = item_lane<PACKED, VEC>(tl & 15, l_edge);
-        issue_tile_rows<BPP, VEC>(r0, r1, sa.p + (size_t)p.f * sa.stride, sa.bytes, IL, l_row, a.w, a.h, p.tcol * 2 * TCW, p.trow * 2 * TCH, NEW0);
+    struct Src { const uint8_t *src; size_t src_stride; unsigned src_bytes; };
+    auto src_of = [](KArgs ka) { Src s; s.src = ka->src; s.src_stride = ka->src_stride; s.src_bytes = ka->src_bytes; return s; };
+    auto issue_tile = [&](const Src *ka, const Pos &p) {
+#ifndef KF_W_OLD_PREFETCH
+        issue_tile_rows<BPP, VEC>(r0, r1, ka->src + (size_t)p.f * ka->src_stride, ka->src_bytes, IL, l_row, a.w, a.h, p.tcol * 2 * TCW, p.trow * 2 * TCH, NEW0);
+#else
+        const mlv_i32x4 rs = frame_rsrc(ka->src + (size_t)p.f * ka->src_stride, ka->src_bytes);
+        issue_item<BPP>(r0, r1, rs, IL, a.w, a.h, p.tcol * 2 * TCW, p.trow * 2 * TCH, NEW0 + l_row);
+#endif
     };
     Pos cur = pos_of(min(t, max(band_end - 1, 0)));
-    if (vec) issue_tile(src_of(cold_args()), cur);
+    { const Src s0 = src_of(cold_args()); if (vec) issue_tile(&s0, cur); }
     __syncthreads();                           // T16 copy complete
 
 #ifdef KF_DIAG_TIMES
@@ -195,7 +196,6 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     bool robust = false;                       // 5x5: rows of lanes agree on their references (robust_ref)
     int calm = 0;                              //      tiles in a row without an uncertain strip
     bool cont = false;                         // this tile lies right below the one this workgroup did before: its upper rows are in LDS
-    int lpar = 0, low_prev = 1;                // parity of the `low` slots; the flag of the tile before (conservative until there is one)
     while (t < band_end) {
         int nt = 0, ne = 0;
         if (threadIdx.x == 0) {                // the tile after this one: known, or drawn now and back long before it is needed
@@ -203,7 +203,9 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             else draw(nt, ne);
         }
         const int f = cur.f, trow = cur.trow, tx0 = cur.tcol * 2 * TCW, ty0 = cur.trow * 2 * TCH;
+#ifdef KF_W_HOIST_SRC
         const Src sa = src_of(cold_args());      // (asked for here, needed when the next tile is prefetched: no wait there)
+#endif
         const int tr = cur.trow * a.tiles_x + cur.tcol;          // the tile's number in the (row-major) pixel-map lists
         // ---- pixel-map entries of this tile (few tiles have any): list bounds now -- the wait that the uniform load implies is
         // for data the loader needs anyway --, the first 256 records themselves in flight while the loader phase runs
@@ -234,12 +236,11 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             if (vec) {
                 unpack8<BPP>(d0, L.s0, L.s1, L.s23, p0);
                 unpack8<BPP>(d1, L.s0 ^ L.flip, L.s1 ^ L.flip, L.s23 ^ L.flip, p1);
-            } else { fetch_rows<BPP>(sa.p + (size_t)f * sa.stride, a.w, a.h, tx0, lk, ty0 - 2 * HC + 2 * p, L.edge, p0, p1); }
+            } else { KArgs ka = cold_args(); fetch_rows<BPP>(ka->src + (size_t)f * ka->src_stride, a.w, a.h, tx0, lk, ty0 - 2 * HC + 2 * p, L.edge, p0, p1); }
             // Pixels at or below black (ev = INT_MIN / 0) or beyond the table need the fix-ups of cell_pair_ev: decided once
             // per item from the extremes of its 16 pixels (three-input min/max), wave-uniformly.
             // and, 16-bit input only, what lies beyond the table.
             bool odd = false, beyond = false;
-            uint32_t lo_px = 0;
             if (METHOD != 0) {
                 uint32_t lo = min(p0[0], p1[0]), hi = max(p0[0], p1[0]);
 #pragma unroll
@@ -248,7 +249,6 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                     if (!PACKED) hi = max(max(hi, p0[i]), p1[i]);
                 }
                 odd = (int)lo <= a.black;
-                lo_px = lo;
                 beyond = (!PACKED && (int)hi - a.black > 16383) || (PACKED && a.black < 0);
             }
 #ifdef KF_EXP_FASTLOADER
@@ -261,7 +261,6 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 const unsigned long long who = __ballot(odd || beyond);
                 if (lane == 0) atomicAdd(&sm.dark_items[par], __popcll(who));
             }
-            if (METHOD != 0 && __any((int)lo_px <= a.black + 64)) sm.low[lpar] = 1;       // (strip_output: no clamp, no stripes mask without)
             emit_item<METHOD, Smem>(sm, a.black, dark, slow, p, lk, L.edge, p0, p1);
         };
         if (METHOD != 0 && !cont) {
@@ -272,23 +271,15 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 const int trw = te ? tid_o - N_TOP_MAIN : tid_o >> 4;
                 const ItemLane TL = item_lane<PACKED, VEC>(tid_o & 15, te);
                 uint32_t q0[4] = { 0, 0, 0, 0 }, q1[4] = { 0, 0, 0, 0 };
-                if (vec) { issue_item<BPP, true>(q0, q1, frame_rsrc(sa.p + (size_t)f * sa.stride, sa.bytes), TL, a.w, a.h, tx0, ty0, trw); }
+                if (vec) { KArgs ka = cold_args(); issue_item<BPP, true>(q0, q1, frame_rsrc(ka->src + (size_t)f * ka->src_stride, ka->src_bytes), TL, a.w, a.h, tx0, ty0, trw); }
                 do_item(TL, q0, q1, trw, tid_o & 15);
             }
         }
         const bool has_item = METHOD == 0 ? tid_o < N_MAIN : tid_o < N_ITEMS;
-        if (has_item) {
-            const bool l_edge = tid_o >= N_MAIN;
-            do_item(item_lane<PACKED, VEC>(tid_o & 15, l_edge), r0, r1, NEW0 + (l_edge ? tid_o - N_MAIN : tid_o >> 4), tid_o & 15);
-        }
+        if (has_item) do_item(IL, r0, r1, NEW0 + l_row, tid_o & 15);
         if (threadIdx.x == 0) { sm.next_tile = nt; sm.next_end = ne; }
         lds_barrier();
         const int t_next = __builtin_amdgcn_readfirstlane(sm.next_tile), t_end_next = __builtin_amdgcn_readfirstlane(sm.next_end);
-        if (threadIdx.x == 0) sm.low[lpar ^ 1] = 0;          // (read by all before this barrier, written again behind the next tile's)
-        // pixels at most 64 above black among the rows this tile loaded (or patched); with those of the tile before: among its output rows.
-        // Without chroma smoothing the loader takes no minimum: always set.
-        const int low_cur = METHOD == 0 ? 1 : (__builtin_amdgcn_readfirstlane(sm.low[lpar]) | (tile_patched ? 1 : 0));
-        const bool low_any = (low_cur | low_prev) != 0;
         // the tile after this one continues it when it is the next of the list and not the top of a column
         const bool cont_next = METHOD != 0 && t_next == t + 1 && trow + 1 < a.tiles_y && t_next < band_end;       // scalar
         if (tile_patched) {
@@ -317,13 +308,18 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         // the tile "below" the list's last one would lie in a frame behind the buffer)
         Pos nxt = pos_below(cur);
         if (t_next != t + 1 || t_next >= band_end) nxt = pos_of(min(t_next, band_end - 1));
-        if (vec) issue_tile(sa, nxt);
-        // what the output stage needs of the cold arguments, in one go and early: the loads go out together, long before their first use
-        const OutArgs oa = out_args(cold_args());
+#ifdef KF_W_HOIST_SRC
+        if (vec) issue_tile(&sa, nxt);
+#else
+        { const Src s1 = src_of(cold_args()); if (vec) issue_tile(&s1, nxt); }
+#endif
 
         // ---- medians + output: one thread = 4 cells = 8 px on two rows
         // the rest of a strip once its medians are known: R / B replacement, stripes, store
-        auto finish_strip = [&](int jj, int kk, bool smooth, const int (&mr)[STRIP], const int (&mb)[STRIP], bool store) {
+        // the rest of a strip once its medians are known: R / B replacement, stripes, store (strip_output, k_frame_dev.h; this kernel
+        // keeps no record of low pixels: always the clamped look-up and the masked stripes epilogue)
+        const OutArgs oa = out_args(cold_args());
+        auto finish_strip = [&](int jj, int kk, unsigned long long msmooth, const int (&mr)[STRIP], const int (&mb)[STRIP], bool store) {
             int gev[STRIP] = { 0, 0, 0, 0 }, er[STRIP] = { 0, 0, 0, 0 }, eb[STRIP] = { 0, 0, 0, 0 };
             if (METHOD != 0) {
                 const int4 g4 = *(const int4 *)&sm.ge[jj][STRIP * kk];
@@ -331,10 +327,11 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 #pragma unroll
                 for (int c = 0; c < STRIP; c++) { er[c] = wadd(gev[c], mr[c]); eb[c] = wadd(gev[c], mb[c]); }
             }
-            strip_output<METHOD, PACKED, vec, Smem>(sm, oa, a.w, a.h, a.black, f, tx0, ty0, jj, kk, smooth, gev, er, eb, low_any, store);
+            strip_output<METHOD, PACKED, vec, Smem>(sm, oa, a.w, a.h, a.black, f, tx0, ty0, jj, kk, msmooth, gev, er, eb, true, store);
         };
         const int y = ty0 + 2 * j;
         const bool smooth_row = METHOD != 0 && y >= 4 && y < a.h - 5;                       // chroma_smooth.c:25
+        const unsigned long long msmooth_row = METHOD != 0 ? (lanes_ge(y, 4) & lanes_lt(y, a.h - 5)) : 0ull;
         int mr[STRIP] = { 0, 0, 0, 0 }, mb[STRIP] = { 0, 0, 0, 0 };
         bool skip_packed = false;
         if (CHAIN) {
@@ -394,7 +391,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
             unknown = false;
 #endif
             if (unknown) sm.fb_queue[atomicAdd(&sm.fb_count, 1)] = (uint8_t)(j * 16 + k);      // settled below, densely
-            if (is_strip && !unknown) finish_strip(j, k, smooth_row, mr, mb, true);
+            if (is_strip && !unknown) finish_strip(j, k, msmooth_row, mr, mb, true);
         } else {
             if (smooth_row) {
                 if (METHOD == 3) {
@@ -405,7 +402,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                     strip_median5(sm.db, j + 1, STRIP * k + 1, mb);
                 }
             }
-            if (is_strip) finish_strip(j, k, smooth_row, mr, mb, true);
+            if (is_strip) finish_strip(j, k, msmooth_row, mr, mb, true);
         }
         // ---- the rows the tile below shares with this one: read before the barrier that ends the tile, stored behind it
         int4 carry = make_int4(0, 0, 0, 0);
@@ -454,7 +451,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                     asm volatile("" : "+s"(z));                        // (keeps these plane loads apart from the packed path's)
                     strip_median25(sm.dr, j2 + z, STRIP * k2, mr);
                     strip_median25(sm.db, j2 + z, STRIP * k2, mb);
-                    finish_strip(j2, k2, true, mr, mb, tid < nfb);
+                    finish_strip(j2, k2, ~0ull, mr, mb, tid < nfb);
                 }
                 lds_barrier();
                 if (tid == 0) sm.fb_count = 0;
@@ -466,8 +463,6 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         t_end = t_end_next;
         cont = cont_next;
         cur = nxt;
-        lpar ^= 1;
-        low_prev = low_cur;
         if (SPREAD) par ^= 1;
     }
     if (list_mode) {

@@ -1079,35 +1079,66 @@ __device__ __forceinline__ KArgs cold_args()
 
 
 // ---------------------------------------------------------------- prefetch of a tile's new rows (both kernels)
-// the item of lane L (its row of the tile: l_row) of the tile at (tx0, ty0); new0: first plane row the tile loads itself
+// the item of lane L (its row of the tile: l_row) of the tile at (tx0, ty0); new0: first plane row the tile loads itself.
+// The two forms below differ in how the four byte offsets (and the descriptor) come about; the LOADS are issued once, behind the
+// branch: loads in both arms would be merged by copies, and those wait for the data right where the loads are issued (the same trap
+// as a conditional prefetch, see k_frame) -- measured: +54 % of SQ_WAIT_ANY, the kernel 15 % slower with 2 % fewer instructions
+// (profiles/r05/w8_pmc.log, w9_pmc.log).
+// what of a lane's item the interior form needs: its two byte offsets relative to the tile (a constant of the lane for the launch)
+template <int BPP>
+__device__ __forceinline__ void item_tile_offsets(const ItemLane &L, int l_row, int w, uint32_t &pre_a, uint32_t &pre_b)
+{
+    constexpr uint32_t GB = (uint32_t)BPP;
+    const uint32_t pitch = (uint32_t)(w >> 3) * GB;
+    const uint32_t rowoff = __umul24((uint32_t)(2 * l_row), pitch) + 16u;
+    pre_a = rowoff + ((uint32_t)((L.xoff_a >> 3) * (int)GB) & L.amask);
+    pre_b = rowoff + ((uint32_t)((L.xoff_b >> 3) * (int)GB) & L.amask) + L.boff;
+}
+// LANE: a callable that yields the lane's ItemLane and row (called in the general form only: k_frame_p keeps just the two offsets)
+template <int BPP, int VEC, class LANE>
+__device__ __forceinline__ void issue_tile_rows_pre(uint32_t (&r0)[4], uint32_t (&r1)[4], const uint8_t *frame, unsigned bytes, uint32_t pre_a, uint32_t pre_b,
+                                                    LANE lane_of, int w, int h, int tx0, int ty0, int new0)
+{
+    constexpr uint32_t GB = (uint32_t)BPP;              // bytes per 8-pixel group
+    const uint32_t pitch = (uint32_t)(w >> 3) * GB;
+    const int ybase = ty0 - 2 * HC + 2 * new0;
+    uint32_t oa0, ob0, oa1, ob1, S = 0;
+    if (VEC != 2 && tx0 >= 8 && tx0 + 2 * TCW + 8 <= w && ybase + 2 * TCH <= h) {           // (scalar)
+        // A tile whose new rows and halo columns lie inside the frame -- nine in ten -- clamps nothing, and with rows that are
+        // whole dwords (every layout but VEC 2) the dword alignment of a main item commutes with the row and tile offsets: what
+        // is left per lane is a constant, the tile's part goes into the buffer descriptor (16 bytes early: the left halo's
+        // group lies before the tile).  issue_item's general form costs 45 vector instructions per tile, this one a dozen.
+        S = (uint32_t)ybase * pitch + (uint32_t)(tx0 >> 3) * GB - 16u;
+        oa0 = pre_a;
+        ob0 = pre_b;
+        oa1 = oa0 + pitch;
+        ob1 = ob0 + pitch;
+    } else {
+        // (issue_item's arithmetic: rows and groups clamped to the frame)
+        int l_row;
+        const ItemLane L = lane_of(l_row);
+        const int y = ybase + 2 * l_row;
+        const int gmax = (w >> 3) - 1, g0 = tx0 >> 3;
+        const uint32_t ga = __umul24((uint32_t)min(g0 + (L.xoff_a >> 3), gmax), GB);
+        const uint32_t gb = __umul24((uint32_t)max(min(g0 + (L.xoff_b >> 3), gmax), 0), GB);
+        const uint32_t row0 = __umul24((uint32_t)min(y, h - 1), pitch), row1 = __umul24((uint32_t)min(y + 1, h - 1), pitch);
+        oa0 = (row0 + ga) & L.amask; ob0 = ((row0 + gb) & L.amask) + L.boff;
+        oa1 = (row1 + ga) & L.amask; ob1 = ((row1 + gb) & L.amask) + L.boff;
+        asm volatile("" : "+v"(oa0), "+v"(ob0));       // (keeps this arm a branch target: as plain arithmetic the compiler runs BOTH arms on every tile and selects)
+    }
+    const mlv_i32x4 rs = frame_rsrc(frame + S, bytes - S);
+    const mlv_u32x2 a0 = mlv_rbl_x2(rs, (int)oa0, 0, KF_SRC_AUX), b0 = mlv_rbl_x2(rs, (int)ob0, 0, KF_SRC_AUX);
+    const mlv_u32x2 a1 = mlv_rbl_x2(rs, (int)oa1, 0, KF_SRC_AUX), b1 = mlv_rbl_x2(rs, (int)ob1, 0, KF_SRC_AUX);
+    r0[0] = a0.x; r0[1] = a0.y; r0[2] = b0.x; r0[3] = b0.y;
+    r1[0] = a1.x; r1[1] = a1.y; r1[2] = b1.x; r1[3] = b1.y;
+}
 template <int BPP, int VEC>
 __device__ __forceinline__ void issue_tile_rows(uint32_t (&r0)[4], uint32_t (&r1)[4], const uint8_t *frame, unsigned bytes, const ItemLane &L, int l_row,
                                                 int w, int h, int tx0, int ty0, int new0)
 {
-    const int ybase = ty0 - 2 * HC + 2 * new0;
-#ifdef KF_EXP_NO_FASTPREF
-    if (false) {
-#else
-    if (VEC != 2 && tx0 >= 8 && tx0 + 2 * TCW + 8 <= w && ybase + 2 * TCH <= h) {           // (scalar)
-#endif
-        // A tile whose new rows and halo columns lie inside the frame -- nine in ten -- clamps nothing, and with rows that are
-        // whole dwords (every layout but VEC 2) the dword alignment of a main item commutes with the row and tile offsets: what
-        // is left per lane is a constant, the tile's part goes into the buffer descriptor (16 bytes early: the left halo's
-        // group lies before the tile) and the second row is the first plus the pitch as the load's scalar offset.
-        // issue_item's general form costs 45 vector instructions per tile, this one a dozen.
-        constexpr uint32_t GB = (uint32_t)BPP;
-        const uint32_t pitch = (uint32_t)(w >> 3) * GB;
-        const uint32_t S = (uint32_t)ybase * pitch + (uint32_t)(tx0 >> 3) * GB - 16u;
-        const mlv_i32x4 rs = frame_rsrc(frame + S, bytes - S);
-        const uint32_t rowoff = __umul24((uint32_t)(2 * l_row), pitch) + 16u;
-        const uint32_t va = rowoff + ((uint32_t)((L.xoff_a >> 3) * (int)GB) & L.amask);
-        const uint32_t vb = rowoff + ((uint32_t)((L.xoff_b >> 3) * (int)GB) & L.amask) + L.boff;
-        const mlv_u32x2 a0 = mlv_rbl_x2(rs, (int)va, 0, KF_SRC_AUX), b0 = mlv_rbl_x2(rs, (int)vb, 0, KF_SRC_AUX);
-        const mlv_u32x2 a1 = mlv_rbl_x2(rs, (int)va, (int)pitch, KF_SRC_AUX), b1 = mlv_rbl_x2(rs, (int)vb, (int)pitch, KF_SRC_AUX);
-        r0[0] = a0.x; r0[1] = a0.y; r0[2] = b0.x; r0[3] = b0.y;
-        r1[0] = a1.x; r1[1] = a1.y; r1[2] = b1.x; r1[3] = b1.y;
-    } else
-        issue_item<BPP>(r0, r1, frame_rsrc(frame, bytes), L, w, h, tx0, ty0, new0 + l_row);
+    uint32_t pre_a, pre_b;
+    item_tile_offsets<BPP>(L, l_row, w, pre_a, pre_b);
+    issue_tile_rows_pre<BPP, VEC>(r0, r1, frame, bytes, pre_a, pre_b, [&](int &row) { row = l_row; return L; }, w, h, tx0, ty0, new0);
 }
 
 // ---------------------------------------------------------------- output stage (both kernels)
@@ -1129,39 +1160,40 @@ __device__ __forceinline__ OutArgs out_args(KArgs kt)
     return o;
 }
 
-// R is the lower half of a cell's top word, B the upper half of its bottom word: where `ok`, they take the looked-up values.  One
-// v_cndmask_b32_sdwa each (the condition in VCC, the other half of the destination preserved) -- rounds 2-4 chose a v_perm_b32
-// selector with a v_cndmask_b32 and permuted: two instructions per word.
-__device__ __forceinline__ void put_rb(uint32_t &top, uint32_t &bot, uint32_t ur, uint32_t ub, bool ok)
+// R is the lower half of a cell's top word, B the upper half of its bottom word: in the lanes of mask `m` they take the looked-up
+// values.  One v_cndmask_b32_sdwa each (the condition in VCC, the other half of the destination preserved) -- rounds 2-4 chose a
+// v_perm_b32 selector with a v_cndmask_b32 and permuted: two instructions per word.
+__device__ __forceinline__ void put_rb(uint32_t &top, uint32_t &bot, uint32_t ur, uint32_t ub, unsigned long long m)
 {
-#ifdef KF_EXP_PERM_SELECT          // (A/B: the selector form of rounds 2-4)
-    top = __builtin_amdgcn_perm(ur, top, ok ? 0x03020504u : 0x03020100u);
-    bot = __builtin_amdgcn_perm(ub, bot, ok ? 0x05040100u : 0x03020100u);
-    return;
-#endif
-    const unsigned long long m = __ballot(ok);
     asm("s_mov_b64 vcc, %4\n\t"
         "v_cndmask_b32_sdwa %0, %0, %2, vcc dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n\t"
         "v_cndmask_b32_sdwa %1, %1, %3, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0"
         : "+v"(top), "+v"(bot) : "v"(ur), "v"(ub), "s"(m) : "vcc");
 }
+// lane masks of signed compares (v_cmp into a scalar register pair; the conditions of a cell are ANDed there, in the scalar unit:
+// as `bool`s the compiler turned them into 0 / 1 registers and back -- eight vector instructions per cell)
+__device__ __forceinline__ unsigned long long lanes_gt(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 38); }       // a > b
+__device__ __forceinline__ unsigned long long lanes_ge(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 39); }       // a >= b
+__device__ __forceinline__ unsigned long long lanes_lt(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 40); }       // a < b
 
 // The rest of a strip once the EVs of its smoothed R and B are known (er = ge + median(dr), eb = ge + median(db), wrapping like the
 // reference's ints): look-up, R / B replacement (chroma_smooth.c:28, 35, 64-68), stripes (stripes.c:250-266), store.
-//   low_any (scalar): some pixel of the rows this tile holds lies at most 64 above black (or the tile holds pixel-map cells).  Without
-//   one, every EV involved lies in [6, 14] stops: er and eb stay below 28 stops -- where the table goes on with its last value
-//   (E2D_RECORDS_EXT) -- so the clamp of chroma_smooth.c:67 is the table's own, and one below zero belongs to a cell that keeps its
-//   pixel (er > 1 stop fails; its look-up is out of range and reads 0).  And the stripes epilogue's "more than 64 above black" holds
-//   for every pixel: no mask.
+//   msmooth: the lanes whose row takes chroma smoothing at all (chroma_smooth.c:25).
+//   CLAMP = false: the caller knows that no pixel of the rows the tile holds lies at most 64 above black (and the tile holds no
+//   pixel-map cells).  Then every EV involved lies in [6, 14] stops: er and eb stay below 28 stops -- where the table goes on with
+//   its last value (E2D_RECORDS_EXT) -- so the clamp of chroma_smooth.c:67 is the table's own, and one below zero belongs to a cell
+//   that keeps its pixel (er > 1 stop fails; its look-up is out of range and reads 0).  And the stripes epilogue's "more than 64
+//   above black" holds for every pixel: no mask.
+//   XM: the tile touches the frame's left or right margin (chroma_smooth.c:27 leaves columns 0..3 and w-4.. alone).
 //   VECST: rows of whole 8-pixel groups on 16-byte aligned buffers (two 16-byte stores); else pixel by pixel.
-template <int METHOD, bool PACKED, bool VECST, class SM>
-__device__ __forceinline__ void strip_output(const SM &sm, const OutArgs &oa, int w, int h, int black, int f, int tx0, int ty0, int jj, int kk,
-                                             bool smooth, const int (&gev)[STRIP], const int (&er)[STRIP], const int (&eb)[STRIP], bool low_any, bool store)
+// The variants are separate instantiations chosen by scalar branches: written as conditions inside one body the compiler computed
+// both sides for every strip and selected (profiles/r05: 207 instead of 178 vector instructions per strip).
+//   ANYSTRIPES: the stripes epilogue in all its forms (else: the packed 16-bit one or none -- what a launch has is a scalar of the launch).
+template <int METHOD, bool PACKED, bool VECST, bool CLAMP, bool XM, bool ANYSTRIPES, class SM>
+__device__ __forceinline__ void strip_output_t(const SM &sm, const OutArgs &oa, int w, int h, int black, int f, int tx0, int ty0, int jj, int kk,
+                                               unsigned long long msmooth, const int (&gev)[STRIP], const int (&er)[STRIP], const int (&eb)[STRIP], bool store)
 {
     const int y = ty0 + 2 * jj, x = tx0 + 2 * STRIP * kk;
-#ifdef KF_EXP_NO_LOWSKIP           // (A/B: always the clamp and the mask)
-    low_any = true;
-#endif
     uint32_t top[STRIP], bot[STRIP];        // (R | G1<<16), (G2 | B<<16)
     auto read_raw = [&]() {
         const uint4 v0 = *(const uint4 *)&sm.raw[2 * jj][2 * STRIP * kk];
@@ -1177,8 +1209,8 @@ __device__ __forceinline__ void strip_output(const SM &sm, const OutArgs &oa, in
         mlv_tab_u32x2 dr2[STRIP], db2[STRIP];
 #pragma unroll
         for (int c = 0; c < STRIP; c++) {
-            cr[c] = er[c]; cb[c] = eb[c];
-            if (low_any) { cr[c] = min(max(er[c], 0), MLV_EV_MAX); cb[c] = min(max(eb[c], 0), MLV_EV_MAX); }
+            cr[c] = CLAMP ? min(max(er[c], 0), MLV_EV_MAX) : er[c];
+            cb[c] = CLAMP ? min(max(eb[c], 0), MLV_EV_MAX) : eb[c];
 #ifdef KF_EXP_NOLOOKUP
             dr2[c].x = cr[c]; dr2[c].y = 0; db2[c].x = cb[c]; db2[c].y = 0;
 #else
@@ -1187,18 +1219,7 @@ __device__ __forceinline__ void strip_output(const SM &sm, const OutArgs &oa, in
 #endif
         }
         read_raw();
-        // chroma_smooth.c:27 leaves columns 0..3 and w-4.. alone: only the tiles at the frame's left and right margin test for that
-        const bool x_margin = tx0 < 4 || tx0 + 2 * TCW > w - 4;                   // scalar
-        // which cells take the smoothed values: decided while the look-ups are under way
-        bool okc[STRIP];
-#pragma unroll
-        for (int c = 0; c < STRIP; c++) {
-            const int xc = x + 2 * c;
-            okc[c] = smooth && gev[c] >= 2 * MLV_EV_RES && er[c] > MLV_EV_RES && eb[c] > MLV_EV_RES;
-            if (x_margin) okc[c] = okc[c] && xc >= 4 && xc < w - 4;
-        }
-        // (the fence keeps the eight look-ups together and comes after the decisions in program order: the compiler
-        // schedules them under the look-ups' latency)
+        // (the fence keeps the eight look-ups together)
         asm volatile("" :: "v"(dr2[0]), "v"(dr2[1]), "v"(dr2[2]), "v"(dr2[3]), "v"(db2[0]), "v"(db2[1]), "v"(db2[2]), "v"(db2[3]));
 #pragma unroll
         for (int c = 0; c < STRIP; c++) {             // v_bfe_u32 (the width operand's low five bits count), v_bcnt_u32_b32
@@ -1206,15 +1227,17 @@ __device__ __forceinline__ void strip_output(const SM &sm, const OutArgs &oa, in
             ub[c] = (int)(__builtin_popcount(bfe_low_bits(db2[c].y, (uint32_t)cb[c])) + db2[c].x);
         }
 #pragma unroll
-        for (int c = 0; c < STRIP; c++) put_rb(top[c], bot[c], (uint32_t)ur[c], (uint32_t)ub[c], okc[c]);
+        for (int c = 0; c < STRIP; c++) {             // which cells take the smoothed values (one mask at a time: four of them live cost eight scalar registers)
+            unsigned long long okm = msmooth & lanes_ge(gev[c], 2 * MLV_EV_RES) & lanes_gt(er[c], MLV_EV_RES) & lanes_gt(eb[c], MLV_EV_RES);
+            if (XM) okm &= lanes_ge(x + 2 * c, 4) & lanes_lt(x + 2 * c, w - 4);
+            put_rb(top[c], bot[c], (uint32_t)ur[c], (uint32_t)ub[c], okm);
+        }
     }
     if (oa.stripes) {
         // a strip starts at an x that is a multiple of 8, so pixel n of the strip has column phase n
         const int black16 = (int)(uint16_t)black, white16 = (int)(uint16_t)oa.white;
-        if (PACKED && oa.coef_pk) {
-            if (low_any) stripe_strip_pk<true>(top, bot, oa.co, black16, white16);
-            else stripe_strip_pk<false>(top, bot, oa.co, black16, white16);
-        }
+        if (!ANYSTRIPES) stripe_strip_pk<CLAMP>(top, bot, oa.co, black16, white16);
+        else if (PACKED && oa.coef_pk) stripe_strip_pk<true>(top, bot, oa.co, black16, white16);
         else if (oa.coef_fast) stripe_strip<true>(top, bot, oa.co, black16, white16);
         else stripe_strip<false>(top, bot, oa.co, black16, white16);
     }
@@ -1243,6 +1266,23 @@ __device__ __forceinline__ void strip_output(const SM &sm, const OutArgs &oa, in
                 }
             }
         }
+    }
+}
+
+// low_any (scalar): some pixel of the rows this tile holds lies at most 64 above black, or the tile holds pixel-map cells
+template <int METHOD, bool PACKED, bool VECST, class SM>
+__device__ __forceinline__ void strip_output(const SM &sm, const OutArgs &oa, int w, int h, int black, int f, int tx0, int ty0, int jj, int kk,
+                                             unsigned long long msmooth, const int (&gev)[STRIP], const int (&er)[STRIP], const int (&eb)[STRIP], bool low_any, bool store)
+{
+    const bool xm = tx0 < 4 || tx0 + 2 * TCW > w - 4;                   // scalar
+    if (oa.stripes && !(PACKED && oa.coef_pk)) {        // (gains beyond the packed form's range, 16-bit input: one variant, everything tested)
+        strip_output_t<METHOD, PACKED, VECST, true, true, true, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, er, eb, store);
+    } else if (low_any) {
+        if (xm) strip_output_t<METHOD, PACKED, VECST, true, true, false, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, er, eb, store);
+        else strip_output_t<METHOD, PACKED, VECST, true, false, false, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, er, eb, store);
+    } else {
+        if (xm) strip_output_t<METHOD, PACKED, VECST, false, true, false, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, er, eb, store);
+        else strip_output_t<METHOD, PACKED, VECST, false, false, false, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, er, eb, store);
     }
 }
 

@@ -293,16 +293,22 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
         return p;
     };
     uint32_t r0[4], r1[4];                               // prefetch registers of this thread's item
+    // of the lane's item the prefetch of an interior tile needs two byte offsets: kept in registers; the item's full description is
+    // derived from the lane's number where the loader (and the prefetch of a tile at the frame's border) needs it
+    uint32_t pre_a, pre_b;
+    {
+        const bool e0 = tid >= N_MAIN;
+        item_tile_offsets<BPP>(item_lane<PACKED, VEC>(tid & 15, e0), e0 ? tid - N_MAIN : tid >> 4, a.w, pre_a, pre_b);
+    }
     // loader: threads 0..239 own the main item (row t / 16, group t % 16) of the tile's new rows, threads 240..254 the edge items;
     // what a lane's item is, is derived from its number where it is needed (a handful of operations per tile: kept in registers
     // through the median phase the item descriptions were what the allocator spilt)
     struct Src { const uint8_t *p; size_t stride; unsigned bytes; };
     auto src_of = [](KArgs ka) { Src s; s.p = ka->src; s.stride = ka->src_stride; s.bytes = ka->src_bytes; return s; };
     auto issue_tile = [&](const Src &sa, const Pos &p, int tl) {
-        const bool l_edge = tl >= N_MAIN;
-        const int l_row = l_edge ? tl - N_MAIN : tl >> 4;
-        const ItemLane L = item_lane<PACKED, VEC>(tl & 15, l_edge);
-        issue_tile_rows<BPP, VEC>(r0, r1, sa.p + (size_t)p.f * sa.stride, sa.bytes, L, l_row, a.w, a.h, p.tcol * 2 * TCW, p.trow * 2 * TCH, NEW0);
+        issue_tile_rows_pre<BPP, VEC>(r0, r1, sa.p + (size_t)p.f * sa.stride, sa.bytes, pre_a, pre_b,
+                                      [&](int &row) { const bool l_edge = tl >= N_MAIN; row = l_edge ? tl - N_MAIN : tl >> 4; return item_lane<PACKED, VEC>(tl & 15, l_edge); },
+                                      a.w, a.h, p.tcol * 2 * TCW, p.trow * 2 * TCH, NEW0);
     };
     // The reference of a tile that does not continue the one above: pixel (lane & 7, lane >> 3 & 1) of the 8 x 2 block at the tile's
     // centre (inside the frame, on even coordinates: R G1 / G2 B), one per lane; the loads go out with the tile's prefetch
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
                 er[c] = wadd(wadd(gev[c], ref_r), (int)o[c].x);
                 eb[c] = wadd(wadd(gev[c], ref_b), (int)o[c].y);
             }
-            strip_output<METHOD, PACKED, true, Smem>(sm, oa, a.w, a.h, a.black, cur.f, tx0, ty0, j, k, smooth_row, gev, er, eb, (low_cur | low_prev) != 0, true);
+            strip_output<METHOD, PACKED, true, Smem>(sm, oa, a.w, a.h, a.black, cur.f, tx0, ty0, j, k, lanes_ge(y, 4) & lanes_lt(y, a.h - 5), gev, er, eb, (low_cur | low_prev) != 0, true);
         }
         // ---- the rows the tile below shares with this one: read before the barrier that ends the tile, stored behind it
         // (threads 0..67: packed rows TCH.. -> 0..3, 68..131: pixel rows, 132..163: green EVs; one 16-byte piece each)

@@ -10,7 +10,7 @@ if [ "$1" == "build" ]; then
   BASE="-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function -I../../include -mllvm --amdgpu-sched-strategy=max-ilp -fno-slp-vectorize"
   OBJS=$(ls *.o | grep -v '^k_frame_p.o$')
   for v in $V; do
-    D=""; [ $v != full ] && D="-DKFP_EXP_$v"
+    D="-DKFP_HOIST_IL"; [ $v != full ] && D="-DKFP_HOIST_IL -DKFP_EXP_$v"
     /opt/rocm/bin/hipcc $BASE $D -c k_frame_p.hip -o ../../build/ab/kfp_$v.o &
   done
   wait
