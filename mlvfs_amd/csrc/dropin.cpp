@@ -219,7 +219,14 @@ int lazy_run(ThreadCtx *c, bool at_sync)
         c->res_host = nullptr; c->res_dirty = false;
         return rc;
     }
-    if (rc) { c->res_host = nullptr; c->res_dirty = false; return rc; }
+    if (rc) {
+        // A recorded frame that had to run EARLY (a stage that cannot join the launch: pattern noise, dual ISO, a focus map, a clip's
+        // first frame) and failed: the host buffer is still what process_frame's malloc returned, and the stages that follow would
+        // take it for the frame -- it is served black like a failed unpack.  At the fetch the caller does the same.
+        if (!at_sync) unfilled_frame(z.host, z.bytes, "a recorded frame's launch");
+        c->res_host = nullptr; c->res_dirty = false;
+        return rc;
+    }
     c->res_cur = 0;
     c->res_rank = z.rank;
     c->res_host = z.host;
@@ -329,7 +336,8 @@ int finish_frame(ThreadCtx *c, void *host, size_t bytes, int rank, int which, in
 // forgotten, so the failed stage is skipped and nothing earlier is lost.
 void abandon_stage(ThreadCtx *c, void *host, size_t bytes, int which, bool was_dirty)
 {
-    if (was_dirty) (void)download(c, host, c->d_res[which], bytes);
+    // (the only up-to-date copy could not be brought back either: black, not the caller's old bytes)
+    if (was_dirty && download(c, host, c->d_res[which], bytes) != MLVFS_AMD_OK) unfilled_frame(host, bytes, "the frame's download after a failed stage");
     c->res_dirty = false;
     c->res_host = nullptr;
 }

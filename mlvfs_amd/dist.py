@@ -43,6 +43,14 @@ def describe_ranks(device_ids, rehearsal: bool = False) -> dict:
     return info
 
 
+def device_identity(bus_id: str, local_rank: int, host: str | None = None) -> str:
+    """The identity of a rank's card for describe_ranks: "<hostname>/<PCI bus id>".  Bus ids repeat across the nodes of a job (rank 0 of
+    every node sits on the same 0000:xx:00.0), and so does the fallback "cuda:<local rank>" where a bus id cannot be read: without the
+    host in front a multi-node run would end with "ranks share a GPU" (ADVICE r4 #3)."""
+    import socket
+    return f"{host if host is not None else socket.gethostname()}/{bus_id if bus_id else f'cuda:{local_rank}'}"
+
+
 def gather_device_ids(my_id: str, group=None):
     """all_gather of each rank's device identity (a group of one included: the collective still runs)."""
     if not dist.is_initialized():

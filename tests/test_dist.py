@@ -73,6 +73,20 @@ def test_ranges():
     assert mdist.row_range(1320, 3, 8) == (495, 660)
 
 
+def test_device_identity_tells_two_hosts_with_the_same_bus_id_apart():
+    """ADVICE r4 #3: rank 0 of every node reports the same PCI bus id (and the same fallback where none can be read)."""
+    from mlvfs_amd import dist as mdist
+    a = mdist.device_identity("0000:05:00.0", 0, host="node-a")
+    b = mdist.device_identity("0000:05:00.0", 0, host="node-b")
+    assert a != b and a.endswith("/0000:05:00.0")
+    info = mdist.describe_ranks([a, b])
+    assert info["devices_seen"] == 2 and info["shared"] is None
+    fa, fb = mdist.device_identity("", 0, host="node-a"), mdist.device_identity("", 0, host="node-b")
+    assert fa == "node-a/cuda:0" and mdist.describe_ranks([fa, fb])["devices_seen"] == 2
+    with pytest.raises(RuntimeError):                             # the same card of the same host twice is still refused
+        mdist.describe_ranks([a, mdist.device_identity("0000:05:00.0", 1, host="node-a")])
+
+
 def test_describe_ranks_counts_devices_and_refuses_shared_cards():
     """bench.py gathers every rank's PCI bus id; N ranks on fewer than N cards is an error outside the rehearsal mode."""
     from mlvfs_amd import dist as mdist

@@ -66,6 +66,36 @@ def test_a_failed_fused_launch_or_download_inside_a_bracket_serves_a_black_frame
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("stage", ["pattern_noise", "dual_iso"])
+def test_a_recorded_frame_that_must_run_early_and_fails_is_served_black(gpu, stage, capfd):
+    """pattern noise and the dual-ISO conversion cannot join the fused launch, so the recorded frame runs when they are
+    called; if that launch fails the host buffer is still malloc's bytes and the stage would process them as the frame."""
+    w, h = 416, 264
+    f = synth.dual_iso_frame(w, h)
+    fh = abi.make_frame_headers(w, h, black=BLACK, white=WHITE)
+    p = _packed(f)
+    img = np.full((h, w), 0xABCD, np.uint16)
+    gpu.mlvfs_amd_dualiso_reset()
+    assert gpu.mlvfs_amd_frame_begin() == 0
+    assert gpu.dng_get_image_data(C.byref(fh), lib.ptr(p), lib.ptr(img), 0, img.nbytes) == img.nbytes
+    assert (img == 0xABCD).all()                                  # deferred
+    gpu.mlvfs_amd_test_fail_next(1)
+    if stage == "pattern_noise":
+        gpu.fix_pattern_noise(lib.ptr(img), w, h, fh.rawi_hdr.raw_info.white_level, 0)
+    else:
+        gpu.cr2hdr20_convert_data(C.byref(fh), lib.ptr(img), 0, 1, 1, 0, 0)
+    gpu.mlvfs_amd_frame_end()
+    assert b"served black" in capfd.readouterr().err.encode()
+    assert not (img == 0xABCD).any(), "the caller's uninitialised bytes survived the failed launch"
+    # the thread works again afterwards
+    img[:] = 0xABCD
+    gpu.mlvfs_amd_frame_begin()
+    gpu.dng_get_image_data(C.byref(fh), lib.ptr(p), lib.ptr(img), 0, img.nbytes)
+    assert gpu.mlvfs_amd_frame_end() == 0
+    assert np.array_equal(img, f)
+
+
+@pytest.mark.gpu
 def test_a_failed_download_outside_a_bracket(gpu, oracle, capfd):
     w, h = 416, 264
     f = synth.normal_frame(w, h)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab_bench.sh "NAME[:ENV=V,...]"... -- on the GPU box: the default bench.py headline (100 frames per step, preheated) once per variant
+# tools/ab_bench.sh "NAME[:ENV=V,...]"... -- on the GPU box: the default bench.py headline (400 frames per step since round 4, preheated; `config.value_at_100_frames_per_step` beside it) once per variant
 # library build/ab/NAME.so, two rounds round-robin; prints value / ms_per_step / roofline.frac per run
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
