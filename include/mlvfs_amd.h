@@ -212,6 +212,9 @@ void mlvfs_amd_host_free(void *p);
 int mlvfs_amd_host_owns(const void *p, size_t bytes);
 /* bytes from p to the end of the live mlvfs_amd_host_alloc buffer that holds it (its size rounded up to 64 KiB); 0: in none */
 size_t mlvfs_amd_host_size(const void *p);
+/* is p inside any buffer mlvfs_amd_host_alloc has handed out, live or already freed?  (the allocation shim's free(): a second free of a
+ * pool buffer goes back to the pool, which reports it, never to the C library) */
+int mlvfs_amd_host_knows(const void *p);
 /* Returns the pool's cached (free) buffers to the runtime; result: bytes released. */
 size_t mlvfs_amd_host_trim(void);
 
@@ -399,6 +402,10 @@ void mlvfs_amd_test_fail_next(int what);
  * (glibc's TYPE_3 state layout, checked once per process on a generator of the library's own; csrc/runtime.cpp)?  1 yes, 0 no (the
  * values are then drawn by calling rand()).  Leaves the application's stream where it was.                              */
 int mlvfs_amd_test_rand_layout(void);
+/* Test hook, host only: which device the k-th worker thread without a device of its own choosing is bound to on a node whose cards
+ * report `bus_ids[0..n)` (HIP ordinal -> PCI bus id): round-robin over the cards IN THE ORDER OF THEIR BUS IDS (csrc/runtime.cpp:
+ * thread_ctx; resource_manager.c:111-118 is the pool this replaces).  device_of[0..workers) receives HIP ordinals.            */
+int mlvfs_amd_test_device_order(const char *const *bus_ids, int n, int workers, int *device_of);
 
 /* self tests that need no GPU (selection networks, LUT identities): 0 = pass */
 int mlvfs_amd_selftest_host(void);

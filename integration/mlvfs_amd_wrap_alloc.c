@@ -8,7 +8,7 @@
  *
  * What it changes: malloc / calloc of MLVFS's OWN objects (GNU ld's --wrap redirects the references of the objects in the link, not
  * libc's or any shared library's) for sizes of at least MLVFS_AMD_POOL_MIN bytes (1 MiB) -- the frame buffer of main.c:931, the
- * payload buffer of main.c:687 -- go to mlvfs_amd_host_alloc; free recognises such a pointer (mlvfs_amd_host_owns) and returns it to
+ * payload buffer of main.c:687 -- go to mlvfs_amd_host_alloc; free recognises such a pointer (mlvfs_amd_host_knows: a range check without a lock for everything else) and returns it to
  * the pool (resource_manager.c:144 frees the frame buffer); everything else goes to the C library unchanged.  A block that MLVFS
  * allocates and a shared library frees (or the reverse) must stay below the threshold; MLVFS has none of that size.
  * Measured (tools/dropin_bench_c.sh, 3584x1320, unpack + bad pixels + cs5x5 + stripes): 16 worker threads 2 420 -> 3 618 frames/s. */
@@ -48,13 +48,15 @@ void *__wrap_calloc(size_t n, size_t m)
 
 void __wrap_free(void *p)
 {
-    if (p && mlvfs_amd_host_owns(p, 1)) mlvfs_amd_host_free(p);
+    /* (a pool buffer freed a second time is the pool's to report: handed to the C library it would corrupt its heap) */
+    if (p && mlvfs_amd_host_knows(p)) mlvfs_amd_host_free(p);
     else __real_free(p);
 }
 
 void *__wrap_realloc(void *p, size_t n)
 {
     const size_t have = p ? mlvfs_amd_host_size(p) : 0;
+    if (have && n == 0) { mlvfs_amd_host_free(p); return NULL; }      /* realloc(p, 0) frees (a malloc(0) that returned NULL leaked the block) */
     if (have) {                                            /* a pooled block grows or shrinks by copy */
         if (n <= have && n >= MLVFS_AMD_POOL_MIN) return p;
         void *q = __wrap_malloc(n);

@@ -314,20 +314,47 @@ void lj92_close(lj92 lj) { free(lj); }                                          
 
 int lj92_decode(lj92 lj, uint16_t *target, int tlen, int skiplen, uint16_t *linearize, int linlen)     // lj92.h:55-58
 {
-    (void)linlen;
     LjHandle *hd = (LjHandle *)lj;
     if (!hd) return LJ92_BAD_HANDLE;
     const size_t npix = (size_t)hd->width * hd->height;
-    if (!target || skiplen != 0 || linearize || (size_t)(tlen < 0 ? 0 : tlen) < npix) { set_error("lj92_decode: only whole frames without a linearisation table"); return LJ92_CORRUPT; }
+    const bool plain = skiplen == 0 && !linearize;      // what MLVFS passes (main.c:626-647): the whole frame, value by value
+    if (!target || (plain && (size_t)(tlen < 0 ? 0 : tlen) < npix)) { set_error("lj92_decode: target too small for the frame"); return LJ92_CORRUPT; }
     LibcRandGuard rand_guard;                      // HIP code may run: keep the caller's rand() stream out of its reach
     ThreadCtx *c = thread_ctx();
     if (!c || c->ensure(npix * 2, 0)) return LJ92_NO_MEMORY;
     const void *streams[1] = { hd->data };
     const size_t sizes[1] = { (size_t)hd->len };
     if (mlvfs_amd_lj92_decode_dev(streams, sizes, 1, 0, 0, c->d_a, npix * 2, c->stream) != MLVFS_AMD_OK) return LJ92_CORRUPT;
-    if (hipMemcpyAsync(target, c->d_a, npix * 2, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+    std::vector<uint16_t> vals;
+    uint16_t *dl = target;
+    if (!plain) { vals.resize(npix); dl = vals.data(); }
+    if (hipMemcpyAsync(dl, c->d_a, npix * 2, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
         set_error("lj92_decode: download failed");
         return LJ92_CORRUPT;
+    }
+    if (plain) return LJ92_OK;
+    // The arguments MLVFS never passes, with the reference's bookkeeping (lj92.c:436-493 for predictor 6, :517-585 for the others):
+    // every value goes through the table (`left > linlen` ends the decode as corrupt -- not tested in the first row of the
+    // predictor-6 loop), and after every `tlen` values written the output skips `skiplen` more (the predictor-6 loop counts its
+    // first value without looking at the counter: a block length of one never skips there).  Done on the host behind the GPU's
+    // decode: the values themselves do not depend on either argument.
+    Parsed h;
+    const char *why = "";
+    if (!parse(hd->data, hd->len, &h, &why)) { set_error("lj92_decode: %s", why); return LJ92_CORRUPT; }
+    const bool p6 = h.pred == 6;
+    uint16_t *out = target;
+    int write = tlen;
+    size_t cidx = 0;
+    for (size_t i = 0; i < npix; i++) {
+        const int left = vals[i];
+        int linear = left;
+        if (linearize) {
+            if (!(p6 && i < (size_t)hd->width) && left > linlen) return LJ92_CORRUPT;
+            linear = linearize[left];
+        }
+        out[cidx++] = (uint16_t)linear;
+        if (p6 && i == 0) { --write; continue; }
+        if (--write == 0) { out += skiplen; write = tlen; }
     }
     return LJ92_OK;
 }

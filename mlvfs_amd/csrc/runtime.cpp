@@ -122,6 +122,15 @@ bool LibcRandGuard::put_app_state(const uint32_t x[31])
     return true;
 }
 
+// The layout probe runs once, when the library is loaded: no worker thread of the library exists yet, none can be inside a HIP call
+// while the probe switches the process's generator back and forth.
+static const bool g_rg_probed_at_load = [] {
+    LibcRandGuard guard;
+    uint32_t x[31];
+    (void)LibcRandGuard::take_app_state(x);
+    return true;
+}();
+
 void LibcRandGuard::draw_mod1024(uint16_t *out, long long n)
 {
     std::lock_guard<std::mutex> lk(g_rg_mu);
@@ -291,26 +300,48 @@ int bind_device(int device)
 // visible GPUs IN THE ORDER OF THEIR PCI BUS IDS: the k-th worker gets the same physical card whatever order the runtime enumerates
 // them in, and neighbours in that order are neighbours on the node's xGMI / PCIe topology.  The mapping is logged once per process
 // (MLVFS_AMD_QUIET=1 silences it); VERDICT r3 weak #9.
+// (the order itself is host arithmetic on the cards' bus ids: mlvfs_amd_test_device_order lets the CPU tests give it a faked node)
+static std::vector<int> order_by_bus_id(const std::vector<std::string> &bus)
+{
+    std::vector<std::pair<std::string, int>> ids;
+    for (size_t d = 0; d < bus.size(); d++) ids.push_back({ bus[d], (int)d });
+    std::sort(ids.begin(), ids.end());
+    std::vector<int> order;
+    for (auto &kv : ids) order.push_back(kv.second);
+    return order;
+}
+static int device_of_worker(const std::vector<int> &order, long long k) { return order[(size_t)(k % (long long)order.size())]; }
+
 static std::vector<int> g_dev_order;            // position in PCI order -> HIP device ordinal
 static std::once_flag g_dev_order_once;
 static const std::vector<int> &device_order(int n)
 {
     std::call_once(g_dev_order_once, [n] {
-        std::vector<std::pair<std::string, int>> ids;
+        std::vector<std::string> bus_ids;
         for (int d = 0; d < n; d++) {
             char bus[64] = "";
             if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, d) != hipSuccess) snprintf(bus, sizeof bus, "unknown-%04d", d);
-            ids.push_back({ bus, d });
+            bus_ids.push_back(bus);
         }
-        std::sort(ids.begin(), ids.end());
-        for (auto &kv : ids) g_dev_order.push_back(kv.second);
+        g_dev_order = order_by_bus_id(bus_ids);
         const char *q = getenv("MLVFS_AMD_QUIET");
         if (n > 1 && !(q && q[0] == '1')) {
             fprintf(stderr, "mlvfs_amd: %d GPUs, worker threads are bound round-robin in PCI order:", n);
-            for (size_t k = 0; k < ids.size(); k++) fprintf(stderr, " worker %zu -> device %d (%s)%s", k, ids[k].second, ids[k].first.c_str(), k + 1 < ids.size() ? "," : "\n");
+            for (size_t k = 0; k < g_dev_order.size(); k++)
+                fprintf(stderr, " worker %zu -> device %d (%s)%s", k, g_dev_order[k], bus_ids[g_dev_order[k]].c_str(), k + 1 < g_dev_order.size() ? "," : "\n");
         }
     });
     return g_dev_order;
+}
+
+extern "C" int mlvfs_amd_test_device_order(const char *const *bus_ids, int n, int workers, int *device_of)
+{
+    if (!bus_ids || n <= 0 || workers < 0 || !device_of) return MLVFS_AMD_ERR_ARG;
+    std::vector<std::string> bus;
+    for (int d = 0; d < n; d++) bus.push_back(bus_ids[d] ? bus_ids[d] : "");
+    const std::vector<int> order = order_by_bus_id(bus);
+    for (int k = 0; k < workers; k++) device_of[k] = device_of_worker(order, k);
+    return MLVFS_AMD_OK;
 }
 
 ThreadCtx *thread_ctx()
@@ -322,7 +353,7 @@ ThreadCtx *thread_ctx()
         if (env) t_device = atoi(env) % n;
         else {
             const std::vector<int> &order = device_order(n);
-            t_device = order[(size_t)g_thread_counter.fetch_add(1) % order.size()];
+            t_device = device_of_worker(order, (long long)g_thread_counter.fetch_add(1));
         }
     }
     auto it = t_ctxs.m.find(t_device);

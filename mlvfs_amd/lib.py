@@ -41,12 +41,12 @@ DEVICE_SYMBOLS = [
     "mlvfs_amd_fix_pixels_dev", "mlvfs_amd_stripes_count_dev", "mlvfs_amd_stripes_hist_dev",
     "mlvfs_amd_stripes_solve", "mlvfs_amd_stripes_compute_dev", "mlvfs_amd_stripes_apply_dev",
     "mlvfs_amd_rand_stream", "mlvfs_amd_rand_stream_dev", "mlvfs_amd_process_frames_dev", "mlvfs_amd_process_frames_host",
-    "mlvfs_amd_host_alloc", "mlvfs_amd_host_free", "mlvfs_amd_host_owns", "mlvfs_amd_host_size", "mlvfs_amd_host_trim", "mlvfs_amd_hdr_preview_dev",
+    "mlvfs_amd_host_alloc", "mlvfs_amd_host_free", "mlvfs_amd_host_owns", "mlvfs_amd_host_size", "mlvfs_amd_host_knows", "mlvfs_amd_host_trim", "mlvfs_amd_hdr_preview_dev",
     "mlvfs_amd_cr2hdr20_dev", "mlvfs_amd_cr2hdr20_batch_dev", "mlvfs_amd_dualiso_reset", "mlvfs_amd_dualiso_trim", "mlvfs_amd_dualiso_last_scalars", "mlvfs_amd_amaze_demosaic_dev", "mlvfs_amd_amaze_debug", "mlvfs_amd_amaze_rows_extent", "mlvfs_amd_amaze_rows_extra_mode",
     "mlvfs_amd_timer_begin", "mlvfs_amd_timer_end", "mlvfs_amd_selftest_host", "mlvfs_amd_selftest_tables", "mlvfs_amd_frame_begin", "mlvfs_amd_frame_end", "mlvfs_amd_frame_sync", "mlvfs_amd_dropin_stats", "mlvfs_amd_test_fail_next", "mlvfs_amd_dropin_transfers", "mlvfs_amd_dropin_profile",
     "mlvfs_amd_mlv_open", "mlvfs_amd_mlv_close", "mlvfs_amd_mlv_frame_count", "mlvfs_amd_mlv_chunk_count",
     "mlvfs_amd_mlv_xref", "mlvfs_amd_mlv_frame_headers", "mlvfs_amd_mlv_read_frames", "mlvfs_amd_mlv_process", "mlvfs_amd_mlv_process_dualiso",
-    "mlvfs_amd_lj92_info", "mlvfs_amd_lj92_decode_dev", "mlvfs_amd_lj92_decode_untiled", "mlvfs_amd_lj92_encode_table", "mlvfs_amd_test_rand_layout", "mlvfs_amd_lzma_uncompress",
+    "mlvfs_amd_lj92_info", "mlvfs_amd_lj92_decode_dev", "mlvfs_amd_lj92_decode_untiled", "mlvfs_amd_lj92_encode_table", "mlvfs_amd_test_rand_layout", "mlvfs_amd_test_device_order", "mlvfs_amd_lzma_uncompress",
     "mlvfs_amd_gif_size", "mlvfs_amd_gif_render", "mlvfs_amd_mlv_gif_data", "mlvfs_amd_process_unpacked_dev", "mlvfs_amd_deflicker_dev",
 ]
 
@@ -154,6 +154,7 @@ def load() -> C.CDLL:
     sig("mlvfs_amd_host_free", None, [vp])
     sig("mlvfs_amd_host_owns", i, [vp, sz])
     sig("mlvfs_amd_host_size", sz, [vp])
+    sig("mlvfs_amd_host_knows", i, [vp])
     sig("mlvfs_amd_host_trim", sz, [])
     sig("mlvfs_amd_hdr_preview_dev", i, [gp, vp, sz, vp])
     sig("mlvfs_amd_cr2hdr20_dev", i, [gp, vp, i, i, i, i, vp])
@@ -174,6 +175,7 @@ def load() -> C.CDLL:
     sig("mlvfs_amd_frame_sync", i, [vp])
     sig("mlvfs_amd_dropin_stats", None, [vp])
     sig("mlvfs_amd_test_fail_next", None, [C.c_int])
+    sig("mlvfs_amd_test_device_order", i, [vp, i, i, vp])
     sig("mlvfs_amd_dropin_transfers", None, [vp])
     sig("mlvfs_amd_dropin_profile", None, [vp])
     sig("mlvfs_amd_process_unpacked_dev", i, [vp, vp, sz, vp, sz, i, i, i, i, vp])

@@ -190,3 +190,18 @@ def test_wrap_shim_links_and_brackets_process_frame_only(amd, tmp_path):
             assert a < body.index(stage) < b, stage
         gif_c = open(os.path.join(ref, "gif.c"), errors="replace").read()
         assert "mlvfs_load_chunks" not in gif_c and "mlvfs_close_chunks" not in gif_c and "load_chunks(path" in gif_c
+
+
+def test_worker_threads_are_bound_round_robin_in_pci_order(amd):
+    """SURVEY 8(e), VERDICT r4 next #5: the drop-in symbols' worker threads (libfuse's pool) get the node's cards round-robin in the
+    order of their PCI bus ids, whatever order the runtime enumerates them in -- on a faked 8-card node, no GPU needed."""
+    bus = ["0000:df:00.0", "0000:0c:00.0", "0000:9f:00.0", "0000:22:00.0", "0000:bf:00.0", "0000:38:00.0", "0000:af:00.0", "0000:5c:00.0"]
+    arr = (C.c_char_p * len(bus))(*[b.encode() for b in bus])
+    out = np.zeros(20, np.int32)
+    assert amd.mlvfs_amd_test_device_order(C.cast(arr, C.c_void_p), len(bus), out.size, lib.ptr(out)) == 0
+    by_bus = sorted(range(len(bus)), key=lambda d: bus[d])
+    assert list(out[:8]) == by_bus == [1, 3, 5, 7, 2, 6, 4, 0]
+    assert list(out[8:16]) == by_bus and list(out[16:20]) == by_bus[:4]          # the ninth worker shares the first card
+    one = (C.c_char_p * 1)(b"0000:05:00.0")
+    assert amd.mlvfs_amd_test_device_order(C.cast(one, C.c_void_p), 1, 3, lib.ptr(out)) == 0 and list(out[:3]) == [0, 0, 0]
+    assert amd.mlvfs_amd_test_device_order(None, 0, 1, lib.ptr(out)) != 0

@@ -234,13 +234,52 @@ def test_dropin_lj92_symbols_equal_the_reference_decoder(gpu, oracle, reference)
     hd = C.c_void_p()
     assert gpu.lj92_open(C.byref(hd), C.c_void_p(buf.ctypes.data), buf.size, None, None, None) == 0
     out = np.zeros(136 * 72, np.uint16)
-    lin = np.zeros(16, np.uint16)
-    assert gpu.lj92_decode(hd, C.c_void_p(out.ctypes.data), out.size, 4, None, 0) != 0             # skiplen
-    assert gpu.lj92_decode(hd, C.c_void_p(out.ctypes.data), out.size, 0, C.c_void_p(lin.ctypes.data), 16) != 0
+    lin = np.zeros(1 << 14, np.uint16)          # (the first row of a predictor-6 stream goes through the table unchecked, lj92.c:436-441)
+    assert gpu.lj92_decode(hd, C.c_void_p(out.ctypes.data), out.size, 0, C.c_void_p(lin.ctypes.data), 16) != 0     # a value beyond the table: corrupt, like the reference
     assert gpu.lj92_decode(hd, C.c_void_p(out.ctypes.data), out.size - 1, 0, None, 0) != 0         # target too small
     assert gpu.lj92_decode(hd, C.c_void_p(out.ctypes.data), out.size, 0, None, 0) == 0
     gpu.lj92_close(hd)
     assert gpu.lj92_decode(None, C.c_void_p(out.ctypes.data), out.size, 0, None, 0) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pred", [1, 4, 6, 7])
+def test_dropin_lj92_decode_with_skip_length_and_linearisation_table(gpu, reference, pred):
+    """The two arguments MLVFS never passes (main.c:626-647), against the reference's own lj92_decode (lj92.c:436-493, 517-585): blocks of
+    `writeLength` values `skipLength` apart (a tile written into a wider image), every value through a table; a block length of one;
+    a value beyond the table.  VERDICT r4 missing #4."""
+    import ctypes as C
+    w, h = 136, 72
+    img = images(w, h)["noise"]
+    s = enc.encode(img, pred, 14)
+    buf = np.frombuffer(s, np.uint8).copy()
+    RL = reference.L
+    for L in (RL, gpu):
+        L.lj92_open.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.lj92_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.lj92_close.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(5)
+    table = rng.integers(0, 65535, 1 << 14).astype(np.uint16)
+    short = table.copy()                            # (passed with a length the frame's values go beyond)
+    cases = [(w, 24, None, 0), (w // 2, 7, None, 0), (1, 3, None, 0), (w * h, 0, table, table.size), (w, 16, table, table.size), (w, 0, short, 9000)]
+    for wl, sl, lin, linlen in cases:
+        nblocks = -(-w * h // wl)
+        size = w * h + nblocks * sl + 64
+        res = []
+        for L in (RL, gpu):
+            hd = C.c_void_p()
+            ww, hh, bb = C.c_int(), C.c_int(), C.c_int()
+            assert L.lj92_open(C.byref(hd), C.c_void_p(buf.ctypes.data), buf.size, C.byref(ww), C.byref(hh), C.byref(bb)) == 0
+            out = np.full(size, 0xABCD, np.uint16)
+            st = L.lj92_decode(hd, C.c_void_p(out.ctypes.data), wl, sl, None if lin is None else C.c_void_p(lin.ctypes.data), linlen)
+            L.lj92_close(hd)
+            res.append((st != 0, out))
+        assert res[0][0] == res[1][0], (wl, sl, linlen)
+        if not res[0][0]:
+            assert np.array_equal(res[0][1], res[1][1]), (wl, sl, linlen)
+        else:                                       # (the reference stops where the value leaves the table: what it wrote until then is the same)
+            n = int(np.argmax(res[0][1] == 0xABCD)) if (res[0][1] == 0xABCD).any() else size
+            assert np.array_equal(res[0][1][:n], res[1][1][:n])
 
 
 @pytest.mark.gpu

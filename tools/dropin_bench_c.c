@@ -81,6 +81,10 @@ static void one_frame(int idx, int k, int keep_hash)
 static pthread_barrier_t g_start;
 static double g_t0;
 static double now(void);
+/* which device the library bound each worker to (round-robin in PCI order: csrc/runtime.cpp) and when it finished: the multi-GPU
+ * report of the drop-in path */
+static int g_dev_of[256];
+static double g_done[256];
 
 static void *worker(void *arg)
 {
@@ -90,6 +94,8 @@ static void *worker(void *arg)
     if (pthread_barrier_wait(&g_start) == PTHREAD_BARRIER_SERIAL_THREAD) g_t0 = now();
     pthread_barrier_wait(&g_start);
     for (int k = 0; k < g_frames; k++) one_frame(idx, k, k >= g_frames - 2);
+    g_done[idx] = now();
+    g_dev_of[idx] = mlvfs_amd_thread_device();
     return NULL;
 }
 
@@ -134,6 +140,23 @@ int main(int argc, char **argv)
     fprintf(stderr, "{\"host\": \"C, pthreads\", \"resident\": \"%s\", \"fused_at_fetch\": %lld, \"run_early\": %lld, \"pinned_frame_buffers\": %s, \"frames_per_thread\": %d, \"fps_1_threads\": %.1f, "
             "\"fps_%d_threads\": %.1f, \"frame1_hash\": \"%016llx\", \"identical_between_threads\": %s}\n", mode ? mode : "0", st[0], st[1],
             g_pinned ? "true" : "false", g_frames, fps[0], T, fps[1], (unsigned long long)ref, same ? "true" : "false");
+    {                                                      /* per device: workers, frames per second until its last worker finished */
+        const int ndev = mlvfs_amd_device_count();
+        fprintf(stderr, "{\"devices_visible\": %d, \"device_of_worker\": [", ndev);
+        for (int i = 0; i < T; i++) fprintf(stderr, "%s%d", i ? ", " : "", g_dev_of[i]);
+        fprintf(stderr, "], \"per_device\": [");
+        int first = 1;
+        for (int d = 0; d < (ndev > 0 ? ndev : 1); d++) {
+            int nw = 0; double last = 0;
+            char bus[64] = "";
+            for (int i = 0; i < T; i++) if (g_dev_of[i] == d) { nw++; if (g_done[i] > last) last = g_done[i]; }
+            if (!nw) continue;
+            (void)mlvfs_amd_device_pci_bus_id(d, bus, (int)sizeof bus);
+            fprintf(stderr, "%s{\"device\": %d, \"pci_bus_id\": \"%s\", \"workers\": %d, \"fps\": %.1f}", first ? "" : ", ", d, bus, nw, nw * g_frames / (last - g_t0));
+            first = 0;
+        }
+        fprintf(stderr, "]}\n");
+    }
     if (getenv("MLVFS_AMD_DROPIN_PROFILE")) {              /* where a bracketed frame's wall time goes (summed over the threads, both passes) */
         double pr[8];
         mlvfs_amd_dropin_profile(pr);

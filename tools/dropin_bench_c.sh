@@ -1,7 +1,8 @@
 #!/bin/bash
 # tools/dropin_bench_c.sh [threads] [frames per thread] -- builds tools/dropin_bench_c.c against the in-tree library twice (as it
 # is; and with integration/mlvfs_amd_wrap.c + --wrap of the chunk calls = the frame bracket) and runs MLVFS_AMD_RESIDENT=0, =1 and
-# the wrapped build, with malloc'ed and with pooled page-locked buffers.  One JSON line per run (stderr of the program).
+# the wrapped build, with malloc'ed and with pooled page-locked buffers.  Two JSON lines per run (stderr of the program): the rates, and -- for the
+# first run on a node with several GPUs -- which device every worker was bound to with the frames per second of each device.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 T=${1:-16}; N=${2:-16}
