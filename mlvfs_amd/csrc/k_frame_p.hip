@@ -158,28 +158,54 @@ __device__ __forceinline__ void pstrip_median9(const uint32_t (*pk)[PW], int jro
         o[c] = pk_med3(mlv_mx(mlv_mx(lo[c], lo[c + 1]), lo[c + 2]), pk_med3(mi[c], mi[c + 1], mi[c + 2]),
                        mlv_mn(mlv_mn(hi[c], hi[c + 1]), hi[c + 2]));
 }
-// certain: every half of every median strictly inside (-32768, 32767).  t = v + 32767 (wraps) is in [0, 65533] exactly then;
-// the unsigned saturating t - 65533 is what is left over otherwise
+// certain: every half of every median strictly inside (-32768, 32767).  t = v + 32769 (wraps) is 1 for -32768, 0 for 32767 and at
+// least 2 otherwise: the smallest t of the strip's eight halves tells (four adds, three minima, one saturating subtract)
 __device__ __forceinline__ bool pk_uncertain(const mlv_pk16 (&o)[STRIP])
 {
     typedef unsigned short upk16 __attribute__((ext_vector_type(2)));
-    const upk16 off = { 32767, 32767 }, span = { 65533, 65533 };
-    upk16 excess = { 0, 0 };
+    const upk16 off = { 32769, 32769 }, two = { 2, 2 };
+    upk16 m = __builtin_bit_cast(upk16, o[0]) + off;
 #pragma unroll
-    for (int c = 0; c < STRIP; c++) excess |= __builtin_elementwise_sub_sat(__builtin_bit_cast(upk16, o[c]) + off, span);
-    return __builtin_bit_cast(uint32_t, excess) != 0u;
+    for (int c = 1; c < STRIP; c++) m = __builtin_elementwise_min(m, (upk16)(__builtin_bit_cast(upk16, o[c]) + off));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(m, two)) != 0x00020002u;
 }
 
-// EV triples of NC cells on the loader's common path with the colour differences packed against the tile's reference
+// EV triples of NC cells on the loader's common path with the colour differences packed against the tile's reference: k_frame_dev.h's
+// cell_multi_ev_fast with the end rearranged -- R's (and B's) exponent part, table value and -(green + reference) meet in ONE
+// three-input add (the biased EV of R is never formed): 9 operations per cell behind the look-ups where ev + cells + pack took 11
 template <int NC, bool SPREAD>
 __device__ __forceinline__ void cell_multi_pk_fast(const uint32_t *p0, const uint32_t *p1, int black, const uint16_t *t, int ref_r, int ref_b,
                                                    int (&ge)[NC], uint32_t (&pk)[NC])
 {
-    int dr[NC], db[NC];
-    cell_multi_ev_fast<NC, SPREAD>(p0, p1, black, t, ge, dr, db);
+    uint32_t fb[4 * NC], tv[4 * NC], ex[4 * NC];
+    const float fmagic = 8388608.0f + (float)black;
 #pragma unroll
-    for (int c = 0; c < NC; c++)       // |dr|, |db|, |ref| < 2^20 here: the plain difference does not wrap
-        pk[c] = as_u(__builtin_amdgcn_cvt_pk_i16(dr[c] - ref_r, db[c] - ref_b));
+    for (int c = 0; c < NC; c++) {
+        const uint32_t px[4] = { p0[2 * c], p0[2 * c + 1], p1[2 * c], p1[2 * c + 1] };
+#pragma unroll
+        for (int i = 0; i < 4; i++) fb[4 * c + i] = __float_as_uint(__uint_as_float(px[i] | 0x4B000000u) - fmagic);
+    }
+#pragma unroll
+    for (int i = 0; i < 4 * NC; i++) tv[i] = *(const uint16_t *)((const char *)t + t16_offset<SPREAD>(fb[i]));
+#pragma unroll
+    for (int i = 0; i < 4 * NC; i++) ex[i] = fb[i] >> 8;
+#pragma unroll
+    for (int i = 0; i < 4 * NC; i += 8) {                // opaque uses: the reads stay unconditional and back to back
+        asm volatile("" :: "v"(ex[i]), "v"(ex[i + 1]), "v"(ex[i + 2]), "v"(ex[i + 3]), "v"(ex[i + 4]), "v"(ex[i + 5]), "v"(ex[i + 6]), "v"(ex[i + 7]));
+    }
+#pragma unroll
+    for (int i = 0; i < 4 * NC; i += 8) {
+        asm volatile("" :: "v"(tv[i]), "v"(tv[i + 1]), "v"(tv[i + 2]), "v"(tv[i + 3]), "v"(tv[i + 4]), "v"(tv[i + 5]), "v"(tv[i + 6]), "v"(tv[i + 7]));
+    }
+    const uint32_t nref_r = 0u - (uint32_t)ref_r, nref_b = 0u - (uint32_t)ref_b;       // (scalar)
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const uint32_t gb = (ex[4 * c + 1] + ex[4 * c + 2] + tv[4 * c + 1] + tv[4 * c + 2]) >> 1;     // biased EV of the cell's green (both EVs >= 0: trunc == floor)
+        ge[c] = (int)(gb - (127u << 15));
+        const uint32_t ngr = nref_r - gb, ngb = nref_b - gb;
+        // |dr|, |db|, |ref| < 2^20 here: the plain differences do not wrap
+        pk[c] = as_u(__builtin_amdgcn_cvt_pk_i16((int)(ex[4 * c + 0] + tv[4 * c + 0] + ngr), (int)(ex[4 * c + 3] + tv[4 * c + 3] + ngb)));
+    }
 }
 
 template <int METHOD, class SM>
@@ -506,8 +532,8 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
         int tid_m = tid;
         asm volatile("" : "+v"(tid_m));
         // lane -> (row j, strip k).  5x5: 17 consecutive lanes per tile row (16 strips and the halo group); other methods: 16
-        const int j_ = CHAIN ? (tid_m * 241) >> 12 : tid_m >> 4;
-        const int k = CHAIN ? tid_m - 17 * j_ : tid_m & 15;
+        const int j_ = CHAIN ? (int)(__umul24((uint32_t)tid_m, 241u) >> 12) : tid_m >> 4;       // tid / 17 for tid < 256 (24-bit multiply: v_mul_lo_u32 takes twice the issue slots)
+        const int k = CHAIN ? tid_m - (int)__umul24((uint32_t)j_, 17u) : tid_m & 15;
         const int j = min(j_, TCH - 1);
         const bool is_strip = CHAIN ? (k < 16 && tid_m < 17 * TCH) : tid_m < N_MAIN;
         const int y = ty0 + 2 * j, x = tx0 + 2 * STRIP * k;
@@ -520,18 +546,16 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
             const int wv = tid_m >> 6;
             PGroup g;
             pchain_group(sm.pk, j, STRIP * k, g);
-            const bool early = tid_m >= 64;
-            if (early) {
-                mlv_quad_mid6(g.p0, g.p1, g.q);
-                if (publishes) pchain_publish(g, sm.xchg[wv - 1]);
-            }
+            // (every wave makes its rank window before the hand-over: k_frame lets wave 0, which publishes nothing, make it behind the
+            // barrier -- two copies of the network and the register moves that merge them)
+            mlv_quad_mid6(g.p0, g.p1, g.q);
+            uint32_t *const xo = (uint32_t *)((char *)&sm.xchg[0][0] + __umul24((uint32_t)wv, (uint32_t)(XCHG_WORDS * 4)));      // record of this wave's last lane
+            if (publishes) pchain_publish(g, xo - XCHG_WORDS);
             lds_barrier();
             PNext n;
             pchain_fetch_lists(g, n);
-            if (collects) pchain_collect_lists(sm.xchg[wv], n);
-            if (!early) mlv_quad_mid6(g.p0, g.p1, g.q);
             pchain_fetch_window(g, n);
-            if (collects) pchain_collect_window(sm.xchg[wv], n);
+            if (collects) { pchain_collect_lists(xo, n); pchain_collect_window(xo, n); }
             pchain_finish(g, n, o);
         } else if (smooth_row) {
             if (METHOD == 3) pstrip_median9(sm.pk, j, STRIP * k, o);
