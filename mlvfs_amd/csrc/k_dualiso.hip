@@ -33,6 +33,18 @@ namespace mlv {
 
 __device__ __forceinline__ int di_bright(const DiParams &p, int y) { return (p.is_bright_bits >> (y & 3)) & 1; }
 
+// Which 256-pixel piece of a pass a workgroup of the grid-stride kernels takes.  The dispatcher deals workgroups b, b + 1, ... to the
+// chip's eight XCDs in turn, each with an L2 of its own: with piece = b the fourteen pieces of a 3584-pixel row, and the rows two
+// above and below that every one of these kernels also reads, lie in eight different L2s and every line is fetched several times.
+// Workgroup b takes piece (b % 8) * (G / 8) + b / 8 instead (G = the grid's size, a multiple of 8: flat_grid): an XCD's workgroups
+// cover one band of consecutive rows per pass, its neighbours' rows are in its own L2.  OFF by default (flat_grid: measured, slower);
+// MLVFS_AMD_DI_XCD=1 in the launcher's environment switches it on (a grid that is no multiple of 8 keeps the plain order).
+__device__ __forceinline__ unsigned di_xcd_block()
+{
+    const unsigned b = blockIdx.x, G = gridDim.x;
+    return (G & 7u) ? b : (b & 7u) * (G >> 3) + (b >> 3);
+}
+
 // The frame of a batch this workgroup works on -- blockIdx.y, or blockIdx.z for the kernels whose grid is two-dimensional -- and
 // its parameters (dualiso.h: DiBatch); false: the batch leaves this frame alone.
 template <int DIM>
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(256) void k_di_match(const uint16_t *__restrict__ i
     if (ev) ev += (size_t)f * bt.S;
     const size_t n = (size_t)p.w * p.h;
     const double a = p.a, b20 = p.b20;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)di_xcd_block() * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         int v = (int)(((uint32_t)img[i] << 6) & 0xFFFFFu);
         if (v != 0) {
             const int y = (int)(i / p.w);
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
     const int w = p.w, h = p.h;
     const size_t n = (size_t)w * h;
     const int *ir2e = L.interp_raw2ev, *ie2r = L.interp_ev2raw;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)di_xcd_block() * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % w), y = (int)(i / w);
         const int br = di_bright(p, y);
         auto R = [&](int xx, int yy) { return (int)raw[xx + (size_t)yy * w]; };
@@ -445,7 +457,7 @@ __global__ __launch_bounds__(256) void k_di_amaze_ev(const float *__restrict__ r
     // (four pixels per thread -- float4 in, int4 out, sixteen look-ups in flight -- made this kernel 10 % shorter and the batch of 8
     // 4.5 % LONGER, three rounds round-robin: it runs beside AMaZE's kernels on the other stream and took more of the chip from them;
     // profiles/r04/ab_di_bench.log)
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)di_xcd_block() * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float fb = (float)black, hi = 1048575.0f;
         const float g = (green[i] - fb) * 2.0f + fb, r = red[i], b = blue[i];
         const float gc = g < hi ? (g > 0.0f ? g : 0.0f) : hi, rc = r < hi ? (r > 0.0f ? r : 0.0f) : hi, bc = b < hi ? (b > 0.0f ? b : 0.0f) : hi;
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(256) void k_di_alias_err(const uint32_t *__restrict
     if (!di_frame<1>(bt, f, p)) return;
     bright += (size_t)f * bt.S; fullres_s += (size_t)f * bt.S; halfres_s += (size_t)f * bt.S; amap += (size_t)f * bt.S;
     const size_t n = (size_t)p.w * p.h;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    for (size_t i = (size_t)di_xcd_block() * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         amap[i] = (uint16_t)di_alias_err(p, L, (int)bright[i], (int)fullres_s[i], (int)halfres_s[i]);
 }
 
@@ -691,7 +703,7 @@ __global__ __launch_bounds__(256) void k_di_blend(const uint32_t *__restrict__ d
     const int w = p.w, h = p.h;
     const size_t n = (size_t)w * h;
     const int *r2e = L.blend_raw2ev, *e2r = L.blend_ev2raw;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)di_xcd_block() * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % w), y = (int)(i / w);
         const int b = (int)bright[i], d = (int)dark[i];
         // overexposure blur, hdr.c:1631-1651
@@ -1180,6 +1192,12 @@ static inline dim3 flat_grid(size_t n, int nframes = 1)
     size_t b = (n + 255) / 256;
     const size_t cap = nframes > 4 ? 2048 : 8192;       // a batch fills the chip with its frames
     if (b > cap) b = cap;
+    // (di_xcd_block: measured and left OFF -- profiles/r05/di_xcd/: 6 % less traffic per conversion, k_di_blend's fetches -31 %, but
+    // k_di_interp 216 -> 270 us, k_di_amaze_ev 93 -> 113 us per frame: a band of rows per XCD concentrates each pass on few memory
+    // channels, and the traffic of these kernels is gathers in the 4 MB tables, not re-read rows.  MLVFS_AMD_DI_XCD=1 switches it on.)
+    static const bool xcd = [] { const char *e = getenv("MLVFS_AMD_DI_XCD"); return e && e[0] == '1'; }();
+    if (xcd) b = (b + 7) / 8 * 8;                       // (workgroups beyond the last piece find nothing to do)
+    else if ((b & 7) == 0) b += 1;                      // (an odd grid keeps the plain order)
     return dim3((unsigned)b, (unsigned)nframes);
 }
 
