@@ -44,6 +44,8 @@ struct __align__(16) SmemP {
     int low[2];                         // some pixel this tile / the tile before loaded lies at most 64 above black
     int next_tile, next_end;
     int walk[5];                        // thread 0's: first tile of the group's range, tiles that go out in runs, tiles per run, group, runs all out
+    int2 carry_at[256];                 // per thread: byte offsets {from, to} of the 16-byte piece it hands down to the tile below (2 KiB)
+    uint4 carry_spare;                  // (what threads without a piece copy)
 };
 
 struct PGroup {
@@ -255,6 +257,16 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
     const int tid = threadIdx.x;
 
     load_t16_rel<SPREAD>(sm.t16, cold_args()->t16, tid);
+    {
+        // rows handed down to the tile below: threads 0..67 the packed rows TCH.. -> 0..3, 68..131 the pixel rows, 132..163 the green EVs
+        constexpr int C_PL = 2 * HC * PW * 4 / 16, C_RAW = 2 * HC * 2 * TCW * 2 / 16, C_GE = HC * TCW * 4 / 16, C_ALL = C_PL + C_RAW + C_GE;
+        static_assert(C_ALL <= 256, "one 16-byte piece per thread");
+        int to = (int)offsetof(Smem, carry_spare), delta = 0;
+        if (tid < C_PL) { to = (int)offsetof(Smem, pk) + 16 * tid; delta = TCH * PW * 4; }
+        else if (tid < C_PL + C_RAW) { to = (int)offsetof(Smem, raw) + 16 * (tid - C_PL); delta = 2 * TCH * 2 * TCW * 2; }
+        else if (tid < C_ALL) { to = (int)offsetof(Smem, ge) + 16 * (tid - C_PL - C_RAW); delta = TCH * TCW * 4; }
+        sm.carry_at[tid] = make_int2(to + delta, to);
+    }
     const int tiles_per_frame = a.tiles_x * a.tiles_y;
     const bool pmap_ok = tiles_per_frame <= PMAP_WORDS * 32;
     int band_end;
@@ -581,21 +593,15 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
             }
             strip_output<METHOD, PACKED, true, Smem>(sm, oa, a.w, a.h, a.black, cur.f, tx0, ty0, j, k, lanes_ge(y, 4) & lanes_lt(y, a.h - 5), gev, er, eb, (low_cur | low_prev) != 0, true);
         }
-        // ---- the rows the tile below shares with this one: read before the barrier that ends the tile, stored behind it
-        // (threads 0..67: packed rows TCH.. -> 0..3, 68..131: pixel rows, 132..163: green EVs; one 16-byte piece each)
-        constexpr int C_PL = 2 * HC * PW * 4 / 16, C_RAW = 2 * HC * 2 * TCW * 2 / 16, C_GE = HC * TCW * 4 / 16, C_ALL = C_PL + C_RAW + C_GE;
-        static_assert(C_ALL <= 256, "one 16-byte piece per thread");
+        // ---- the rows the tile below shares with this one: read before the barrier that ends the tile, stored behind it -- one
+        // 16-byte piece per thread, from and to where the thread's entry of the table says (threads without a piece copy a spare
+        // 16 bytes onto themselves: no predicate, no address arithmetic; deriving the piece from the thread's number cost 19 vector
+        // instructions per tile and wave)
         int4 carry = make_int4(0, 0, 0, 0);
-        int tid_c = tid;
-        asm volatile("" : "+v"(tid_c));
-        const bool do_carry = cont_next && tid_c < C_ALL;
-        int c_dst = 0;
-        if (do_carry) {
-            int c_delta;
-            if (tid_c < C_PL) { c_dst = (int)offsetof(Smem, pk) + 16 * tid_c; c_delta = TCH * PW * 4; }
-            else if (tid_c < C_PL + C_RAW) { c_dst = (int)offsetof(Smem, raw) + 16 * (tid_c - C_PL); c_delta = 2 * TCH * 2 * TCW * 2; }
-            else { c_dst = (int)offsetof(Smem, ge) + 16 * (tid_c - C_PL - C_RAW); c_delta = TCH * TCW * 4; }
-            carry = *(const int4 *)((const char *)&sm + c_dst + c_delta);
+        int2 c_at = make_int2(0, 0);
+        if (cont_next) {
+            c_at = sm.carry_at[tid];
+            carry = *(const int4 *)((const char *)&sm + c_at.x);
         }
         lds_barrier();
 #if defined(KFP_EXP_NOLOAD) || defined(KFP_EXP_NOPREF) || defined(KFP_EXP_NOMED) || defined(KFP_EXP_NOOUT)
@@ -603,7 +609,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
 #else
         const int unc = __builtin_amdgcn_readfirstlane(sm.unc[par]);
 #endif
-        if (do_carry) *(int4 *)((char *)&sm + c_dst) = carry;
+        if (cont_next) *(int4 *)((char *)&sm + c_at.y) = carry;
         have_smp = !cont_next;
         if (unc) {
             // a tile with uncertain strips: to the list (k_frame does it again, whole), the next fb_wait tiles with it unseen; where
@@ -631,8 +637,13 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
     }
 }
 
-// (2x2 and 3x3: k_frame's int32 networks compile to three-input min / max / med3 and win against the packed two-input ones)
-bool frame_p_exists(int method, int vec) { return method == 5 && vec != 0; }
+// (2x2 and 3x3: k_frame's int32 networks compile to three-input min / max / med3 and the packed two-input ones save them nothing;
+// MLVFS_AMD_KF_P_ALL=1 sends them through k_frame_p all the same: A/B)
+bool frame_p_exists(int method, int vec)
+{
+    static const bool all = [] { const char *e = getenv("MLVFS_AMD_KF_P_ALL"); return e && e[0] == '1'; }();
+    return (method == 5 || (all && method != 0)) && vec != 0;
+}
 
 void launch_frame_p_kernel(int method, bool packed, int vec, bool spread, int grid, hipStream_t stream, const FrameArgs &a)
 {

@@ -1,24 +1,18 @@
 #!/usr/bin/env python3
 """tools/isa_classes.py -- where the vector instructions of the headline kernel go, by ISSUE-RATE CLASS and weighted by how often
-each instruction runs per tile, from the compiler's own assembly of k_frame<5, true, 1, false> (METHOD, PACKED, VEC, SPREAD).
-
-VERDICT r2 weak #2: the flat "VALU floor" of round 2 priced every vector instruction at the 0.24 wave-instructions per clock and
-SIMD of v_min/max_i32, although tools/valu_rate*.hip measured v_mov_b32 / v_*_f32 / unpacked 16-bit min/max at ~0.45 and plain
-adds, logic and constant shifts at ~0.31.  This tool produces the class-weighted floor bench.py reports instead.
+each instruction runs per tile, from the compiler's own assembly of k_frame_p<5, true, 1, false> (METHOD, PACKED, VEC, SPREAD) --
+the packed-once kernel of round 5 (mlvfs_amd/csrc/k_frame_p.hip + k_frame_dev.h); rounds 2-4 analysed k_frame<5, true, 1, false>.
 
 How (no GPU needed):
- 1. compiles mlvfs_amd/csrc/k_frame.hip twice with the production flags -- once plainly, once with -gline-tables-only -- and checks
-    that the kernel's instruction stream is the same in both (line tables must not change code generation);
+ 1. compiles k_frame_p.hip twice with the production flags -- once plainly, once with -gline-tables-only -- and checks that the
+    kernel's instruction stream is the same in both (line tables must not change code generation);
  2. walks the annotated assembly: every instruction carries its source location INCLUDING the inlined-at chain
-    (".loc ... ; k_frame.hip:L @[ k_frame.hip:L' @[ ... ] ]");
+    (".loc ... ; k_frame_p.hip:L @[ k_frame_dev.h:L' @[ ... ] ]");
  3. gives every instruction a weight = wave-executions per tile on the benchmark's frames (common path), from WHERE in the source
-    it sits -- found by searching the source for the statements that delimit each region, so the table below survives edits:
-        loader, items of 4 cells          4   (all four waves: 255 items per tile since round 4)
-        the rows above a run's first tile 0.2 (waves 0-1, one tile in nine)
-        cell_pair_ev, slow path           0   (pixels at / below black: not on these frames)   ... and so on, see weight_of
+    it sits -- found by searching the source for the statements that delimit each region, so the table survives edits (weight_of);
  4. classes every instruction by mnemonic and prices the class with the measured rates (profiles/r01/valu_rate2.log,
-    profiles/r03/valu_rate3.log; unknown mnemonics at the quarter rate);
- 5. checks the weighted total against SQ_INSTS_VALU of the same build (profiles/r03/*pmc*: per frame / tiles per frame) when given.
+    profiles/r03/valu_rate3.log, profiles/r05/valu_rate4.log; unknown mnemonics at the quarter rate);
+ 5. checks the weighted total against SQ_INSTS_VALU of the same build when given.
 
 usage: python tools/isa_classes.py [--pmc-valu-per-frame N] [--clock-ghz 2.35] [--json out.json]
 """
@@ -30,10 +24,12 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "mlvfs_amd", "csrc", "k_frame.hip")
-KERNEL = "_ZN3mlv7k_frameILi5ELb1ELi1ELb0EEEvNS_9FrameArgsE"
+CSRC = os.path.join(ROOT, "mlvfs_amd", "csrc")
+SRC = os.path.join(CSRC, "k_frame_p.hip")
+DEV = os.path.join(CSRC, "k_frame_dev.h")
+KERNEL = "_ZN3mlv9k_frame_pILi5ELb1ELi1ELb0EEEvNS_9FrameArgsE"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"),
-         "-mllvm", "--amdgpu-sched-strategy=max-ilp", "-fno-slp-vectorize"]
+         "-mllvm", "--amdgpu-sched-strategy=max-ilp", "-fno-slp-vectorize", "-DKFP_ONLY"]
 W, H, TCW, TCH5 = 3584, 1320, 64, 15
 TILES_PER_FRAME = ((W // 2 + TCW - 1) // TCW) * ((H // 2 + TCH5 - 1) // TCH5)
 
@@ -42,11 +38,11 @@ def compile_asm(out_dir, debug):
     tag = "g" if debug else "prod"
     d = os.path.join(out_dir, tag)
     os.makedirs(d, exist_ok=True)
-    cmd = ["/opt/rocm/bin/hipcc", *FLAGS, *(["-gline-tables-only"] if debug else []), "--save-temps=obj", "-c", SRC, "-o", os.path.join(d, "k_frame.o")]
-    subprocess.run(cmd, check=True, capture_output=True, cwd=os.path.dirname(SRC))
-    text = open(os.path.join(d, "k_frame-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    cmd = ["/opt/rocm/bin/hipcc", *FLAGS, *(["-gline-tables-only"] if debug else []), "--save-temps=obj", "-c", SRC, "-o", os.path.join(d, "k_frame_p.o")]
+    subprocess.run(cmd, check=True, capture_output=True, cwd=CSRC)
+    text = open(os.path.join(d, "k_frame_p-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     start = text.index("\n" + KERNEL + ":")
-    end = text.index("s_endpgm", start)
+    end = text.index(".Lfunc_end", start)
     return text[start:end].splitlines()
 
 
@@ -64,161 +60,128 @@ def instruction_stream(lines):
 
 
 # ---------------------------------------------------------------- source regions
-def source_index():
-    src = open(SRC).read().splitlines()
+def _index(path):
+    src = open(path).read().splitlines()
 
-    def find(text, after=0, nth=1):
-        for i in range(after, len(src)):
-            if text in src[i]:
+    def find(text, nth=1):
+        for i, l in enumerate(src, 1):
+            if text in l:
                 nth -= 1
                 if nth == 0:
-                    return i + 1
-        raise SystemExit(f"isa_classes: marker not found in k_frame.hip: {text!r}")
+                    return i
+        raise SystemExit(f"isa_classes: marker not found in {os.path.basename(path)}: {text!r}")
 
-    def block_end(line):                      # the closing brace that matches the first '{' at or after `line`
+    def block(text, nth=1):                     # from the marker's line to the brace that closes the first '{' at or after it
+        a = find(text, nth)
         depth, seen = 0, False
-        for i in range(line - 1, len(src)):
-            code = src[i].split("//")[0]
-            for ch in code:
+        for i in range(a - 1, len(src)):
+            for ch in src[i].split("//")[0]:
                 if ch == "{":
                     depth += 1
                     seen = True
                 elif ch == "}":
                     depth -= 1
                     if seen and depth == 0:
-                        return i + 1
+                        return a, i + 1
         raise SystemExit("isa_classes: unbalanced braces")
-
-    def func(name):
-        a = find(name)
-        return a, block_end(a)
-
-    idx = {"find": find, "block_end": block_end, "func": func, "src": src}
-    return idx
+    return find, block
 
 
 def build_regions():
-    ix = source_index()
-    find, block_end, func = ix["find"], ix["block_end"], ix["func"]
-    R = {}
-    R["kernel"] = func("__global__ __launch_bounds__(256, 4) void k_frame(")
-    k0 = R["kernel"][0]
-
-    def block(marker, after=k0):
-        a = find(marker, after)
-        return a, block_end(a)
-
-    def line(marker, after=k0):
-        a = find(marker, after)
-        return a, a
-
-    R["loop"] = block("while (t < band_end) {")
-    R["top_rows"] = block("if (METHOD != 0 && !cont) {")                  # the four plane rows above a run's first tile
-    R["loader"] = line("if (has_item) do_item(IL, r0, r1, NEW0 + l_row, l_k);")
-    R["dark_items"] = block("if (METHOD == 5 && SPREAD && dark) {")
-    R["chain32"] = block("if (skip_packed) {")
-    R["packed"] = (find("ChainGroup g;", k0), find("unknown = chain_finish(g, n, mr, mb);", k0))
-    R["early"] = block("if (early) {")
-    R["own_window"] = line("if (!early) chain_group_window(g);")
-    R["collect"] = (find("if (collects) chain_collect_lists", k0), find("if (collects) chain_collect_window", k0))
-    R["queue_push"] = line("if (unknown) sm.fb_queue[")
-    R["fallback"] = block("if (nfb > 0) {")
-    R["patch_fetch"] = block("if (tile_patched) {")
-    R["patch_store"] = block("if (tile_patched) {", R["patch_fetch"][1])
-    R["carry_read"] = line("if (do_carry) carry = ")
-    R["carry_write"] = line("if (do_carry) *(int4 *)((char *)&sm + c_dst) = carry;")
-    R["draw"] = line("else draw(nt, ne);")
-    R["pos_of"] = line("if (t_next != t + 1 || t_next >= band_end) nxt = pos_of(")
-    R["novec_store"] = (find("} else {", find("if (store && y < a.h) {", k0)), None)
-    R["novec_store"] = (R["novec_store"][0], block_end(R["novec_store"][0]))
-    R["stripe_slow"] = (find("else if (stripe_mode == 2)", k0), find("else stripe_strip<false>", k0))
-    for name, sig in {"cell_pair_ev": "__device__ __forceinline__ void cell_pair_ev(", "cell_multi_ev_fast": "__device__ __forceinline__ void cell_multi_ev_fast(",
-                      "cell_multi_ev_dark": "__device__ __forceinline__ void cell_multi_ev_dark(",
-                      "fetch_rows": "__device__ __forceinline__ void fetch_rows(", "fetch_clamped": "__device__ __forceinline__ uint32_t fetch_clamped(",
-                      "emit_item": "__device__ __forceinline__ void emit_item(",
-                      "strip_median25": "__device__ __forceinline__ void strip_median25(", "robust_ref": "__device__ __forceinline__ int robust_ref(",
-                      "chain_publish": "__device__ __forceinline__ void chain_publish(", "patch_cell_fn": "__device__ __forceinline__ PatchCell patch_cell(",
-                      "patch_store_fn": "__device__ __forceinline__ void patch_store(", "stripe_px": "__device__ __forceinline__ uint32_t stripe_px(",
-                      "stripe_strip": "__device__ __forceinline__ void stripe_strip("}.items():
-        R[name] = func(sig)
-    R["chain32_fns"] = (find("struct Chain32 {"), func("__device__ __forceinline__ void chain32_finish(")[1])
-    R["sort5_32"] = func("__device__ __forceinline__ void sort5(int (&v)[5])")
-    cp = R["cell_pair_ev"][0]
-    R["cell_pair_slow"] = (find("int l[8];", cp) - 1, R["cell_pair_ev"][1])        # the block after `if (!slow) { ... return; }`
-    return R
+    find, block = _index(SRC)
+    dfind, dblock = _index(DEV)
+    P = {"loop": block("    while (t < band_end) {"), "skip": block("        if (fb_skip > 0) {"),
+         "sample": block("        if (!cont) {", 1), "top": block("        if (!cont) {", 2),
+         "patch_fetch": block("        if (a.patch) {"), "patch": block("        if (tile_patched) {", 2),
+         "draw": (find("else draw(nt, ne);", 2),) * 2, "loader": block("        if (tid_o < N_ITEMS) {"),
+         "prefetch": (find("Pos nxt = pos_below(cur);"), find("const OutArgs oa = out_args(cold_args());")),
+         "medians": (find("int tid_m = tid;"), find("if (is_strip && smooth_row && pk_uncertain(o))")),
+         "output": block("        if (is_strip) {"), "carry": (find("int4 carry = make_int4(0, 0, 0, 0);"), find("par ^= 1;")),
+         "uncertain": block("        if (unc) {")}
+    D = {n: dblock(sig) for n, sig in {"dark": "void cell_multi_ev_dark(", "pair": "void cell_pair_ev(", "stripe_px": "uint32_t stripe_px(",
+                                        "stripe_strip": "void stripe_strip(uint32_t", "fetch_clamped": "uint32_t fetch_clamped("}.items()}
+    D["issue_general"] = (dfind("// (issue_item's arithmetic: rows and groups clamped to the frame)"), dfind("asm volatile(\"\" : \"+v\"(oa0), \"+v\"(ob0));"))
+    # the output stage's instantiations, by the line of their call in strip_output: (CLAMP, XM) and the all-stripes one
+    for name, args in {"out_generic": "true, true, true, SM>", "out_low_xm": "true, true, false, SM>", "out_low": "true, false, false, SM>",
+                       "out_xm": "false, true, false, SM>", "out_plain": "false, false, false, SM>"}.items():
+        D[name] = (dfind("strip_output_t<METHOD, PACKED, VECST, " + args),) * 2
+    return P, D
 
 
 def inside(line, rng):
     return rng[0] <= line <= rng[1]
 
 
-# tiles of the benchmark's launch that do NOT continue the tile above them (first tiles of runs, tiles drawn singly): runs of 22 tiles
-# and 33 single tiles per 481-tile range (k_frame.hip, launch_frame_t) -> 21 + 33 of 481
-FIRST_TILE_SHARE = (481 - 33) / 22 / 481 + 33 / 481
+# tiles of the benchmark's launch that do NOT continue the tile above them (first tiles of runs, tiles drawn singly, column tops)
+FIRST_TILE_SHARE = 0.11
+BORDER_TILE_SHARE = 1 - (26 / 28) * (43 / 44)          # tiles whose new rows or halo columns leave the frame (general prefetch form)
+LOW_TILE_SHARE = 0.15                                   # tiles that hold a pixel at most 64 above black or pixel-map cells (with the tile above)
+MARGIN_TILE_SHARE = 2 / 28                              # tiles at the frame's left or right margin
 
 
 def weight_of(chain, R, tiles_per_workgroup):
-    """chain: k_frame.hip lines from the innermost frame to the outermost (the line in k_frame's own body is last)."""
+    """chain: [(is_dev_header, line)] from the innermost frame to the outermost (the line in k_frame_p's own body is last)."""
+    P, D = R
     if not chain:
         return 4.0, "unattributed"
-    if any(inside(l, R["chain32_fns"]) or inside(l, R["sort5_32"]) for l in chain):
-        return 0.0, "32-bit chain (tiles that skip the packed attempt)"
-    outer = chain[-1]
-    if not inside(outer, R["kernel"]):
-        return 4.0, "unattributed"
-    if not inside(outer, R["loop"]):
+    dev = [l for d, l in chain if d]
+    own = [l for d, l in chain if not d]
+    o = own[-1] if own else 0
+    if any(inside(l, D[k]) for l in dev for k in ("dark", "pair")):
+        return 0.0, "loader: pixels at or below black / beyond the table (not on these frames)"
+    if any(inside(l, D[k]) for l in dev for k in ("stripe_px", "stripe_strip")):
+        return 0.0, "stripes, 32-bit / generic epilogue (not this launch)"
+    if not inside(o, P["loop"]):
         return 4.0 / tiles_per_workgroup, "prologue / epilogue (per workgroup)"
-    inner = set(chain)
-
-    def any_in(name):
-        return any(inside(l, R[name]) for l in inner)
-
-    # paths the benchmark's frames do not take
-    if any_in("cell_pair_slow"):
-        return 0.0, "loader: out-of-table pixels (slow path)"
-    if any_in("cell_multi_ev_dark") or inside(outer, R["dark_items"]):
-        return 0.0, "loader: items with pixels at or below black"
-    if any_in("fetch_rows") or any_in("fetch_clamped") or any_in("novec_store"):
-        return 0.0, "widths that are no multiple of 8"
-    if inside(outer, R["chain32"]):
-        return 0.0, "32-bit chain (tiles that skip the packed attempt)"
-    if inside(outer, R["fallback"]) or inside(outer, R["queue_push"]) or any_in("strip_median25"):
-        return 0.0, "uncertain strips (32-bit networks, dense pass)"
-    if any_in("robust_ref"):
-        return 0.0, "shared references (noisy shadows)"
-    if any_in("stripe_px") or any_in("stripe_strip") or inside(outer, R["stripe_slow"]):
-        return 0.0, "stripes, 32-bit / generic epilogue"
-    if inside(outer, R["patch_fetch"]) or inside(outer, R["patch_store"]) or any_in("patch_cell_fn") or any_in("patch_store_fn"):
+    if inside(o, P["skip"]) or inside(o, P["uncertain"]):
+        return 0.0, "tiles listed for k_frame (none on these frames)"
+    if inside(o, P["patch_fetch"]) or inside(o, P["patch"]):
         return 0.4, "pixel-map cells (one tile in ten has any; all four waves)"
-    if inside(outer, R["top_rows"]):
+    if inside(o, P["top"]):
         return 2.0 * FIRST_TILE_SHARE, "loader: the four rows above a run's first tile (waves 0-1, one tile in nine)"
-    if inside(outer, R["loader"]):
-        return 4.0, "loader: items of 4 cells (all waves)"
-    if inside(outer, R["pos_of"]):
-        return 4.0 * FIRST_TILE_SHARE, "coordinates of a run's first tile (two divisions, one tile in nine)"
-    if inside(outer, R["draw"]):
-        return 0.25 * FIRST_TILE_SHARE, "drawing the next run (one wave, one tile in nine)"
-    if inside(outer, R["carry_read"]) or inside(outer, R["carry_write"]):
-        return 4.0 * (1 - FIRST_TILE_SHARE), "rows handed down to the tile below"
-    if inside(outer, R["packed"]):
-        if any_in("chain_publish") or inside(outer, R["collect"]):
-            return 3.0, "medians: hand-over between waves (lane 0 of waves 1-3 publishes, lane 63 of waves 0-2 collects)"
-        if inside(outer, R["early"]):
-            return 3.0, "medians: own rank window, waves 1-3"
-        if inside(outer, R["own_window"]):
-            return 1.0, "medians: own rank window, wave 0"
-        return 4.0, "medians: packed neighbour-sharing chain"
-    return 4.0, "output stage, prefetch, loop control (all waves)"
+    if inside(o, P["sample"]):
+        return 4.0 * FIRST_TILE_SHARE, "reference sample of a run's first tile"
+    if inside(o, P["draw"]):
+        return 0.25 * FIRST_TILE_SHARE, "drawing the next run (one wave)"
+    if inside(o, P["loader"]):
+        return 4.0, "loader: items of 4 cells, packed against the tile's reference (all waves)"
+    if inside(o, P["prefetch"]):
+        if any(inside(l, D["issue_general"]) for l in dev):
+            return 4.0 * BORDER_TILE_SHARE, "prefetch: tiles at the frame's border (general form)"
+        if any(inside(l, D["fetch_clamped"]) for l in dev):
+            return 4.0 * FIRST_TILE_SHARE, "reference sample of a run's first tile"
+        return 4.0, "prefetch of the next tile, coordinates"
+    if inside(o, P["medians"]):
+        return 4.0, "medians: packed-once neighbour-sharing chain, hand-over, certainty test"
+    if inside(o, P["output"]):
+        if any(inside(l, D["out_generic"]) for l in dev):
+            return 0.0, "stripes, 32-bit / generic epilogue (not this launch)"
+        for name, share, what in (("out_plain", (1 - LOW_TILE_SHARE) * (1 - MARGIN_TILE_SHARE), "no clamp, no stripes mask"),
+                                  ("out_low", LOW_TILE_SHARE * (1 - MARGIN_TILE_SHARE), "tiles with low pixels or pixel-map cells"),
+                                  ("out_xm", (1 - LOW_TILE_SHARE) * MARGIN_TILE_SHARE, "tiles at the frame's left / right margin"),
+                                  ("out_low_xm", LOW_TILE_SHARE * MARGIN_TILE_SHARE, "margin tiles with low pixels")):
+            if any(inside(l, D[name]) for l in dev):
+                return 4.0 * share, "output stage: look-ups, R / B replacement, stripes, stores -- " + what
+        return 4.0, "output stage: what the variants share (green EVs, EV sums, dispatch)"
+    if inside(o, P["carry"]):
+        return 4.0, "rows handed down to the tile below, end of tile"
+    return 4.0, "loop control, tile bookkeeping"
 
 
 # ---------------------------------------------------------------- instruction classes
 def load_rates():
     rates = {}
-    for rel in ("profiles/r01/valu_rate2.log", "profiles/r03/valu_rate3.log"):
+    for rel in ("profiles/r01/valu_rate2.log", "profiles/r03/valu_rate3.log", "profiles/r05/valu_rate4.log"):
         p = os.path.join(ROOT, rel)
         if not os.path.exists(p):
             continue
         for ln in open(p):
+            m4 = re.match(r"(v_[a-z0-9_]+)([^\n]*?)\s+([0-9.]+) sequences/clk/SIMD .* clk per sequence of 1$", ln.rstrip())
+            if m4:                                              # (valu_rate4's format: single-instruction rows only)
+                key = m4.group(1) + ("_dpp" if "row_" in m4.group(2) or "wave_" in m4.group(2) else "")
+                if m4.group(1) != "v_cndmask_b32":
+                    rates.setdefault(key, float(m4.group(3)))
+                continue
             m = re.match(r"(v_[a-z0-9_]+)(.*?)thr=\s*(\d+)\s+([0-9.]+) wave-instr", ln)
             if m and int(m.group(3)) == 1024:
                 key = m.group(1) + ("_dpp" if "row_" in m.group(2) or "wave_" in m.group(2) else "")
@@ -273,13 +236,13 @@ def main():
     rates = load_rates()
     tiles_per_wg = TILES_PER_FRAME * a.frames_per_launch / a.workgroups
 
-    loc_re = re.compile(r"k_frame\.hip:(\d+):\d+")
+    loc_re = re.compile(r"(k_frame_p\.hip|k_frame_dev\.h):(\d+):\d+")
     chain = []
     per_region, per_class, unknown = {}, {}, {}
     counts = {"valu": 0.0, "salu": 0.0, "lds": 0.0, "vmem": 0.0, "static_valu": 0, "static_all": 0}
     for ln in dbg_lines:
         if ln.startswith("\t.loc"):
-            found = [int(x) for x in loc_re.findall(ln.split(";", 1)[1] if ";" in ln else "") if int(x) > 0]
+            found = [(f.endswith(".h"), int(x)) for f, x in loc_re.findall(ln.split(";", 1)[1] if ";" in ln else "") if int(x) > 0]
             if found:                                          # (a location without a line in k_frame.hip is compiler-made, "line 0":
                 chain = found                                  #  such instructions stay with the code around them)
             continue
@@ -318,7 +281,7 @@ def main():
     weighted_clk = sum(c["clk"] for c in per_class.values())
     us = lambda clk_per_tile: clk_per_tile * tiles / simds / (a.clock_ghz * 1e3)
     res = {
-        "kernel": "k_frame<5, true, 1, false>", "same_instruction_stream_with_line_tables": same,
+        "kernel": "k_frame_p<5, true, 1, false>", "same_instruction_stream_with_line_tables": same,
         "static_instructions": counts["static_all"], "static_valu": counts["static_valu"],
         "tiles_per_frame": tiles, "valu_wave_instructions_per_tile": round(counts["valu"], 1),
         "valu_wave_instructions_per_frame": round(counts["valu"] * tiles),
