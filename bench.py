@@ -694,7 +694,7 @@ def main():
     # ---- the same hot path at 100 frames per launch, the default of rounds 1-3 (round-to-round deltas must not mix kernel
     # changes with the change of the launch size): a few launches, wall clock, beside the headline -- never `value`
     at100 = None
-    if F > 100 and not grouped:
+    if F > 100 and not grouped and not args.no_extras:       # (an extra: --no-extras keeps a profiled run to launches of one size)
         n100 = 16
         for i in range(4):
             s.process(packed[(i % 4) * 100:(i % 4 + 1) * 100], out[(i % 4) * 100:(i % 4 + 1) * 100], cs=args.cs, fix_pixels=True, stripes=True)

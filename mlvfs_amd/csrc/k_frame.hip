@@ -41,21 +41,27 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     using Smem = SmemT<SPREAD, CHAIN>;
     __shared__ Smem sm;                                  // static: a compile-time LDS base (a dynamic one costs an add per access)
 
-    // list mode: the runs of tiles that k_frame_p (same stream, before this launch) left to this kernel.  Nothing listed -- the
-    // common case -- ends the workgroup before it copies its tables.
     // (the arguments the common path touches once per tile or less are read where they are used: cold_args, k_frame_dev.h)
-    auto list_done = [&]() {                             // thread 0 of a list-mode workgroup that ends
+    // list mode: the runs of tiles that k_frame_p (same stream, before this launch) left to this kernel.  Every workgroup draws a
+    // run first thing, so those whose number is beyond the list's length find none and end at once -- without touching a counter
+    // (an empty list, the common case: 1 024 workgroups adding to one address made the empty launch 14 us long); the last of the
+    // others to end zeroes the counters and leaves the stream's statistic in the host's word.
+    const int list_mode = a.list_mode;
+    const int wl_n = list_mode ? cold_args()->wl_ctl[0] : 0;     // (written by the launch before this one: final)
+    auto list_done = [&]() {                             // thread 0 of a list-mode workgroup that had work and ends
         KArgs ka = cold_args();
         int *ctl = ka->wl_ctl, *stat = ka->wl_stat;
-        if (atomicAdd(&ctl[2], 1) == (int)gridDim.x - 1) {
+        if (atomicAdd(&ctl[2], 1) == min((int)gridDim.x, wl_n) - 1) {
             ctl[0] = 0; ctl[1] = 0; ctl[2] = 0;
             if (stat) { __atomic_store_n(stat, ctl[3], __ATOMIC_RELAXED); __threadfence_system(); }
         }
     };
-    const int list_mode = a.list_mode;
-    const int wl_n = list_mode ? cold_args()->wl_ctl[0] : 0;     // (written by the launch before this one: final)
-    if (list_mode && (int)blockIdx.x >= wl_n) {          // (every workgroup draws a run first thing: those beyond the list's length find none)
-        if (threadIdx.x == 0) list_done();
+    if (list_mode && (int)blockIdx.x >= wl_n) {
+        if (wl_n == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+            KArgs ka = cold_args();
+            int *stat = ka->wl_stat;
+            if (stat) { __atomic_store_n(stat, ka->wl_ctl[3], __ATOMIC_RELAXED); __threadfence_system(); }
+        }
         return;
     }
     if (METHOD != 0) load_t16_rel<SPREAD>(sm.t16, cold_args()->t16, threadIdx.x);       // (relative form: k_frame_dev.h)

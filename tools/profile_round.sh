@@ -17,4 +17,4 @@ cd $R
 python tools/pmc_summary.py "$O/pmc_fetch/**/*counter_collection.csv" "$O/pmc_write/**/*counter_collection.csv" "$O/pmc_sq/**/*counter_collection.csv" > $O/pmc_summary.txt 2>&1 || true
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq
-tail -3 $O/gpu_tests.log; tail -1 $O/bench_default.log | cut -c1-600; grep -A6 "k_frame<5, true, 1" $O/pmc_summary.txt
+tail -3 $O/gpu_tests.log; tail -1 $O/bench_default.log | cut -c1-600; grep -A6 "k_frame" $O/pmc_summary.txt
