@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         int nt, ne;
         draw(nt, ne);
         sm.next_tile = nt; sm.next_end = ne;
-        sm.dark_items[0] = 0; sm.dark_items[1] = 0; sm.fb_count = 0;
+        sm.dark_items[0] = 0; sm.dark_items[1] = 0; sm.fb_count = 0; sm.low[0] = 0; sm.low[1] = 0;
     }
     __syncthreads();
     int t = __builtin_amdgcn_readfirstlane(sm.next_tile), t_end = __builtin_amdgcn_readfirstlane(sm.next_end);
@@ -198,6 +198,9 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
     unsigned long long diag_n[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
     int par = 0;                               // tile parity: which of the two dark_items counters this tile uses
+#ifdef KF_W_LOW
+    int lpar = 0, low_prev = 3;                // which of the two low-pixel records; the record of the tile before (bit 0: low, bit 1: dim)
+#endif
     int fb_skip = 0, fb_wait = FB_WAIT_MIN;    // 5x5: tiles still to go straight to the 32-bit chain; how many after the next busy tile
     bool robust = false;                       // 5x5: rows of lanes agree on their references (robust_ref)
     int calm = 0;                              //      tiles in a row without an uncertain strip
@@ -256,6 +259,13 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
                 }
                 odd = (int)lo <= a.black;
                 beyond = (!PACKED && (int)hi - a.black > 16383) || (PACKED && a.black < 0);
+#ifdef KF_W_LOW
+                // what strip_output may skip: bit 1 = some pixel less than 256 above black (or 16-bit input), bit 0 = at most 64 above
+                if (!PACKED || a.black < 0 || __any((int)lo <= a.black + 255)) {
+                    const int v = (PACKED && a.black >= 0 && !__any((int)lo <= a.black + 64)) ? 2 : 3;
+                    if (lane == 0) atomicOr(&sm.low[lpar], v);        // (several waves: OR, not store)
+                }
+#endif
             }
 #ifdef KF_EXP_FASTLOADER
             const bool slow = false, dark = false;
@@ -286,6 +296,10 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         if (threadIdx.x == 0) { sm.next_tile = nt; sm.next_end = ne; }
         lds_barrier();
         const int t_next = __builtin_amdgcn_readfirstlane(sm.next_tile), t_end_next = __builtin_amdgcn_readfirstlane(sm.next_end);
+#ifdef KF_W_LOW
+        if (tid == 0) sm.low[lpar ^ 1] = 0;      // (read by all before this barrier, written again behind the next tile's)
+        const int low_cur = (METHOD == 0 || tile_patched) ? 3 : __builtin_amdgcn_readfirstlane(sm.low[lpar]);
+#endif
         // the tile after this one continues it when it is the next of the list and not the top of a column
         const bool cont_next = METHOD != 0 && t_next == t + 1 && trow + 1 < a.tiles_y && t_next < band_end;       // scalar
         if (tile_patched) {
@@ -324,6 +338,11 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         // the rest of a strip once its medians are known: R / B replacement, stripes, store
         // the rest of a strip once its medians are known: R / B replacement, stripes, store (strip_output, k_frame_dev.h; this kernel
         // keeps no record of low pixels: always the clamped look-up and the masked stripes epilogue)
+#ifdef KF_W_LOW
+        const bool w_low_any = ((low_cur | low_prev) & 1) != 0, w_bright = (low_cur | low_prev) == 0;
+#else
+        const bool w_low_any = true, w_bright = false;
+#endif
         const OutArgs oa = out_args(cold_args());
         auto finish_strip = [&](int jj, int kk, unsigned long long msmooth, const int (&mr)[STRIP], const int (&mb)[STRIP], bool store) {
             int gev[STRIP] = { 0, 0, 0, 0 }, er[STRIP] = { 0, 0, 0, 0 }, eb[STRIP] = { 0, 0, 0, 0 };
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
 #pragma unroll
                 for (int c = 0; c < STRIP; c++) { er[c] = wadd(gev[c], mr[c]); eb[c] = wadd(gev[c], mb[c]); }
             }
-            strip_output<METHOD, PACKED, vec, Smem>(sm, oa, a.w, a.h, a.black, f, tx0, ty0, jj, kk, msmooth, gev, er, eb, true, store);
+            strip_output<METHOD, PACKED, vec, Smem>(sm, oa, a.w, a.h, a.black, f, tx0, ty0, jj, kk, msmooth, gev, 0, er, eb, w_low_any, w_bright, store);
         };
         const int y = ty0 + 2 * j;
         const bool smooth_row = METHOD != 0 && y >= 4 && y < a.h - 5;                       // chroma_smooth.c:25
@@ -470,6 +489,9 @@ __global__ __launch_bounds__(256, 4) void k_frame(const FrameArgs a)
         cont = cont_next;
         cur = nxt;
         if (SPREAD) par ^= 1;
+#ifdef KF_W_LOW
+        lpar ^= 1; low_prev = low_cur;
+#endif
     }
     if (list_mode) {
         if (threadIdx.x == 0) list_done();
@@ -693,7 +715,8 @@ template <int METHOD, bool PACKED, int VEC, bool SPREAD>
 static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
 {
     const long long total = (long long)a_in.tiles_x * a_in.tiles_y * a_in.nframes;
-    int grid = num_cu > 0 ? num_cu * 4 : 1024;          // 4 workgroups per CU (39 KiB LDS, <= 128 VGPRs)
+    static const int env_wgs = [] { const char *e = getenv("MLVFS_AMD_KF_WGS_PER_CU"); return e ? atoi(e) : 0; }();      // (occupancy experiments)
+    int grid = (num_cu > 0 ? num_cu : 256) * (env_wgs > 0 ? env_wgs : 4);          // 4 workgroups per CU (39 KiB LDS, <= 128 VGPRs)
     grid = (grid + 7) / 8 * 8;
     if (grid > total) grid = (int)((total + 7) / 8 * 8);
     auto kern = k_frame<METHOD, PACKED, VEC, SPREAD>;

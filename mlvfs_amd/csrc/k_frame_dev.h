@@ -1189,9 +1189,9 @@ __device__ __forceinline__ unsigned long long lanes_lt(int a, int b) { return __
 // The variants are separate instantiations chosen by scalar branches: written as conditions inside one body the compiler computed
 // both sides for every strip and selected (profiles/r05: 207 instead of 178 vector instructions per strip).
 //   ANYSTRIPES: the stripes epilogue in all its forms (else: the packed 16-bit one or none -- what a launch has is a scalar of the launch).
-template <int METHOD, bool PACKED, bool VECST, bool CLAMP, bool XM, bool ANYSTRIPES, class SM>
+template <int METHOD, bool PACKED, bool VECST, bool CLAMP, bool XM, bool ANYSTRIPES, bool BRIGHT, class SM>
 __device__ __forceinline__ void strip_output_t(const SM &sm, const OutArgs &oa, int w, int h, int black, int f, int tx0, int ty0, int jj, int kk,
-                                               unsigned long long msmooth, const int (&gev)[STRIP], const int (&er)[STRIP], const int (&eb)[STRIP], bool store)
+                                               unsigned long long msmooth, const int (&gev)[STRIP], int gev_off, const int (&er)[STRIP], const int (&eb)[STRIP], bool store)
 {
     const int y = ty0 + 2 * jj, x = tx0 + 2 * STRIP * kk;
     uint32_t top[STRIP], bot[STRIP];        // (R | G1<<16), (G2 | B<<16)
@@ -1228,7 +1228,10 @@ __device__ __forceinline__ void strip_output_t(const SM &sm, const OutArgs &oa, 
         }
 #pragma unroll
         for (int c = 0; c < STRIP; c++) {             // which cells take the smoothed values (one mask at a time: four of them live cost eight scalar registers)
-            unsigned long long okm = msmooth & lanes_ge(gev[c], 2 * MLV_EV_RES) & lanes_gt(er[c], MLV_EV_RES) & lanes_gt(eb[c], MLV_EV_RES);
+            unsigned long long okm = msmooth;
+            // (gev holds the green EV + gev_off, wrapping: k_frame_p keeps it with its reference added; the subtraction lives here so that the
+            // bright variant, which tests nothing, does not pay for it)
+            if (!BRIGHT) okm &= lanes_ge((int)((uint32_t)gev[c] - (uint32_t)gev_off), 2 * MLV_EV_RES) & lanes_gt(er[c], MLV_EV_RES) & lanes_gt(eb[c], MLV_EV_RES);
             if (XM) okm &= lanes_ge(x + 2 * c, 4) & lanes_lt(x + 2 * c, w - 4);
             put_rb(top[c], bot[c], (uint32_t)ur[c], (uint32_t)ub[c], okm);
         }
@@ -1270,19 +1273,28 @@ __device__ __forceinline__ void strip_output_t(const SM &sm, const OutArgs &oa, 
 }
 
 // low_any (scalar): some pixel of the rows this tile holds lies at most 64 above black, or the tile holds pixel-map cells
+// bright (scalar; implies !low_any): every pixel of those rows lies at least 256 above black (and below 2^14).  Then every EV lies in
+// [8, 14) stops, every green EV too, every colour difference in (-6, 6) and every smoothed EV above 8 - 6 = 2 stops: the three
+// conditions of chroma_smooth.c:64-66 (green >= 2 stops, smoothed R and B > 1 stop) hold for every cell and are not evaluated.
 template <int METHOD, bool PACKED, bool VECST, class SM>
 __device__ __forceinline__ void strip_output(const SM &sm, const OutArgs &oa, int w, int h, int black, int f, int tx0, int ty0, int jj, int kk,
-                                             unsigned long long msmooth, const int (&gev)[STRIP], const int (&er)[STRIP], const int (&eb)[STRIP], bool low_any, bool store)
+                                             unsigned long long msmooth, const int (&gev)[STRIP], int gev_off, const int (&er)[STRIP], const int (&eb)[STRIP], bool low_any, bool bright,
+                                             bool store)
 {
     const bool xm = tx0 < 4 || tx0 + 2 * TCW > w - 4;                   // scalar
     if (oa.stripes && !(PACKED && oa.coef_pk)) {        // (gains beyond the packed form's range, 16-bit input: one variant, everything tested)
-        strip_output_t<METHOD, PACKED, VECST, true, true, true, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, er, eb, store);
+        strip_output_t<METHOD, PACKED, VECST, true, true, true, false, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, gev_off, er, eb, store);
     } else if (low_any) {
-        if (xm) strip_output_t<METHOD, PACKED, VECST, true, true, false, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, er, eb, store);
-        else strip_output_t<METHOD, PACKED, VECST, true, false, false, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, er, eb, store);
+        if (xm) strip_output_t<METHOD, PACKED, VECST, true, true, false, false, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, gev_off, er, eb, store);
+        else strip_output_t<METHOD, PACKED, VECST, true, false, false, false, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, gev_off, er, eb, store);
+    } else if (xm) {
+        strip_output_t<METHOD, PACKED, VECST, false, true, false, false, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, gev_off, er, eb, store);
     } else {
-        if (xm) strip_output_t<METHOD, PACKED, VECST, false, true, false, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, er, eb, store);
-        else strip_output_t<METHOD, PACKED, VECST, false, false, false, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, er, eb, store);
+#ifndef KF_EXP_NO_BRIGHT
+        if (bright) strip_output_t<METHOD, PACKED, VECST, false, false, false, true, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, gev_off, er, eb, store);
+        else
+#endif
+        strip_output_t<METHOD, PACKED, VECST, false, false, false, false, SM>(sm, oa, w, h, black, f, tx0, ty0, jj, kk, msmooth, gev, gev_off, er, eb, store);
     }
 }
 

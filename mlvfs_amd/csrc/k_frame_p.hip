@@ -42,10 +42,14 @@ struct __align__(16) SmemP {
     uint32_t xchg[CHAIN_ ? 3 : 1][XCHG_WORDS];
     int unc[2];                         // some strip of this tile / of the tile before is uncertain (by tile parity)
     int low[2];                         // some pixel this tile / the tile before loaded lies at most 64 above black
+    int dim[2];                         // ... lies less than 256 above black (or the tile took the loader's slow form)
     int next_tile, next_end;
     int walk[5];                        // thread 0's: first tile of the group's range, tiles that go out in runs, tiles per run, group, runs all out
     int2 carry_at[256];                 // per thread: byte offsets {from, to} of the 16-byte piece it hands down to the tile below (2 KiB)
     uint4 carry_spare;                  // (what threads without a piece copy)
+#ifdef KFP_EXP_LDSPAD
+    char exp_pad[KFP_EXP_LDSPAD];       // (occupancy experiment: fewer workgroups per CU)
+#endif
 };
 
 struct PGroup {
@@ -175,11 +179,17 @@ __device__ __forceinline__ bool pk_uncertain(const mlv_pk16 (&o)[STRIP])
 // EV triples of NC cells on the loader's common path with the colour differences packed against the tile's reference: k_frame_dev.h's
 // cell_multi_ev_fast with the end rearranged -- R's (and B's) exponent part, table value and -(green + reference) meet in ONE
 // three-input add (the biased EV of R is never formed): 9 operations per cell behind the look-ups where ev + cells + pack took 11
+__device__ __forceinline__ uint32_t add3_u32(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 template <int NC, bool SPREAD>
 __device__ __forceinline__ void cell_multi_pk_fast(const uint32_t *p0, const uint32_t *p1, int black, const uint16_t *t, int ref_r, int ref_b,
                                                    int (&ge)[NC], uint32_t (&pk)[NC])
 {
-    uint32_t fb[4 * NC], tv[4 * NC], ex[4 * NC];
+    uint32_t fb[4 * NC], tv[4 * NC];
     const float fmagic = 8388608.0f + (float)black;
 #pragma unroll
     for (int c = 0; c < NC; c++) {
@@ -189,24 +199,28 @@ __device__ __forceinline__ void cell_multi_pk_fast(const uint32_t *p0, const uin
     }
 #pragma unroll
     for (int i = 0; i < 4 * NC; i++) tv[i] = *(const uint16_t *)((const char *)t + t16_offset<SPREAD>(fb[i]));
+    // (exponent parts: R and B each, the two greens as ONE shift of their sum -- the low ten bits of a pixel's float are zero)
+    uint32_t exr[NC], exb[NC], exg[NC];
 #pragma unroll
-    for (int i = 0; i < 4 * NC; i++) ex[i] = fb[i] >> 8;
+    for (int c = 0; c < NC; c++) { exr[c] = fb[4 * c] >> 8; exb[c] = fb[4 * c + 3] >> 8; exg[c] = (fb[4 * c + 1] + fb[4 * c + 2]) >> 8; }
 #pragma unroll
-    for (int i = 0; i < 4 * NC; i += 8) {                // opaque uses: the reads stay unconditional and back to back
-        asm volatile("" :: "v"(ex[i]), "v"(ex[i + 1]), "v"(ex[i + 2]), "v"(ex[i + 3]), "v"(ex[i + 4]), "v"(ex[i + 5]), "v"(ex[i + 6]), "v"(ex[i + 7]));
+    for (int c = 0; c < NC; c += 2) {                    // opaque uses: the reads stay unconditional and back to back
+        asm volatile("" :: "v"(exr[c]), "v"(exb[c]), "v"(exg[c]), "v"(exr[c + 1]), "v"(exb[c + 1]), "v"(exg[c + 1]));
     }
 #pragma unroll
     for (int i = 0; i < 4 * NC; i += 8) {
         asm volatile("" :: "v"(tv[i]), "v"(tv[i + 1]), "v"(tv[i + 2]), "v"(tv[i + 3]), "v"(tv[i + 4]), "v"(tv[i + 5]), "v"(tv[i + 6]), "v"(tv[i + 7]));
     }
-    const uint32_t nref_r = 0u - (uint32_t)ref_r, nref_b = 0u - (uint32_t)ref_b;       // (scalar)
+    uint32_t nref_r = 0u - (uint32_t)ref_r, nref_b = 0u - (uint32_t)ref_b;
+    asm("" : "+v"(nref_r), "+v"(nref_b));       // (opaque: else -(ref + green) is formed, two instructions where one subtract does)
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        const uint32_t gb = (ex[4 * c + 1] + ex[4 * c + 2] + tv[4 * c + 1] + tv[4 * c + 2]) >> 1;     // biased EV of the cell's green (both EVs >= 0: trunc == floor)
+        const uint32_t gb = add3_u32(exg[c], tv[4 * c + 1], tv[4 * c + 2]) >> 1;        // biased EV of the cell's green (both EVs >= 0: trunc == floor)
         ge[c] = (int)(gb - (127u << 15));
-        const uint32_t ngr = nref_r - gb, ngb = nref_b - gb;
-        // |dr|, |db|, |ref| < 2^20 here: the plain differences do not wrap
-        pk[c] = as_u(__builtin_amdgcn_cvt_pk_i16((int)(ex[4 * c + 0] + tv[4 * c + 0] + ngr), (int)(ex[4 * c + 3] + tv[4 * c + 3] + ngb)));
+        uint32_t ngr = nref_r - gb, ngb = nref_b - gb;
+        // |dr|, |db|, |ref| < 2^20 here: the plain differences do not wrap.  (The three-input adds are written out: left to itself the
+        // compiler forms every pixel's EV and (reference + green) first -- six more instructions per cell)
+        pk[c] = as_u(__builtin_amdgcn_cvt_pk_i16((int)add3_u32(exr[c], tv[4 * c + 0], ngr), (int)add3_u32(exb[c], tv[4 * c + 3], ngb)));
     }
 }
 
@@ -310,7 +324,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
         int nt, ne;
         draw(nt, ne);
         sm.next_tile = nt; sm.next_end = ne;
-        sm.unc[0] = 0; sm.unc[1] = 0; sm.low[0] = 0; sm.low[1] = 0;
+        sm.unc[0] = 0; sm.unc[1] = 0; sm.low[0] = 0; sm.low[1] = 0; sm.dim[0] = 0; sm.dim[1] = 0;
     }
     __syncthreads();
     int t = __builtin_amdgcn_readfirstlane(sm.next_tile), t_end = __builtin_amdgcn_readfirstlane(sm.next_end);
@@ -398,7 +412,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
     int fb_skip = 0, fb_wait = KF_P_WAIT_MIN;  // tiles still to go to the list unseen; how many after the next uncertain tile
     bool cont = false;
     int par = 0;                               // tile parity: which of the two `unc` slots this tile uses
-    int low_prev = 1;                          // (the tile before this one: conservative until there is one)
+    int low_prev = 3;                          // (the tile before this one: conservative until there is one)
     bool have_smp = true;                      // the sample of this tile is on its way (else: fetched when the tile starts)
     auto push = [&](int first, int n) {        // thread 0
         KArgs ka = cold_args();
@@ -475,7 +489,10 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
             const bool beyond = (!PACKED && (int)hi - a.black > 16383) || (PACKED && a.black < 0);
             const bool slow = (!PACKED || a.black < 0) && __any(beyond);
             const bool dark = slow || __any(odd);
-            if (__any((int)lo <= a.black + 64)) sm.low[par] = 1;       // the stripes epilogue's "more than 64 above black" holds for no mask then
+            if (__any((int)lo <= a.black + 255) || slow) {             // (strip_output: what a tile of pixels >= 256 above black may skip)
+                sm.dim[par] = 1;
+                if (__any((int)lo <= a.black + 64)) sm.low[par] = 1;   // the stripes epilogue's "more than 64 above black" holds for no mask then
+            }
             emit_item_p<METHOD, Smem>(sm, a.black, dark, slow, ref_r, ref_b, p, lk, L.edge, p0, p1);
         };
         if (!cont) {
@@ -500,9 +517,10 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
 #endif
         if (tid == 0) { sm.next_tile = nt; sm.next_end = ne; }
         lds_barrier();
-        if (tid == 0) { sm.unc[par ^ 1] = 0; sm.low[par ^ 1] = 0; }          // (read by all before this barrier, written again behind the next tile's)
+        if (tid == 0) { sm.unc[par ^ 1] = 0; sm.low[par ^ 1] = 0; sm.dim[par ^ 1] = 0; }          // (read by all before this barrier, written again behind the next tile's)
         // pixels at most 64 above black among the rows this tile loaded (or patched); with those of the tile before: among its output rows
-        const int low_cur = __builtin_amdgcn_readfirstlane(sm.low[par]) | (tile_patched ? 1 : 0);
+        // (one scalar for both: bit 0 = low, bit 1 = dim)
+        const int low_cur = tile_patched ? 3 : (__builtin_amdgcn_readfirstlane(sm.low[par]) | __builtin_amdgcn_readfirstlane(sm.dim[par]) << 1);
         const int t_next = __builtin_amdgcn_readfirstlane(sm.next_tile), t_end_next = __builtin_amdgcn_readfirstlane(sm.next_end);
         // the tile after this one continues it when it is the next of the list and not the top of a column
         const bool cont_next = t_next == t + 1 && trow + 1 < a.tiles_y && t_next < band_end;
@@ -591,7 +609,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_p(const FrameArgs a)
                 er[c] = wadd(wadd(gev[c], ref_r), (int)o[c].x);
                 eb[c] = wadd(wadd(gev[c], ref_b), (int)o[c].y);
             }
-            strip_output<METHOD, PACKED, true, Smem>(sm, oa, a.w, a.h, a.black, cur.f, tx0, ty0, j, k, lanes_ge(y, 4) & lanes_lt(y, a.h - 5), gev, er, eb, (low_cur | low_prev) != 0, true);
+            strip_output<METHOD, PACKED, true, Smem>(sm, oa, a.w, a.h, a.black, cur.f, tx0, ty0, j, k, lanes_ge(y, 4) & lanes_lt(y, a.h - 5), gev, 0, er, eb, ((low_cur | low_prev) & 1) != 0, (low_cur | low_prev) == 0, true);
         }
         // ---- the rows the tile below shares with this one: read before the barrier that ends the tile, stored behind it -- one
         // 16-byte piece per thread, from and to where the thread's entry of the table says (threads without a piece copy a spare

@@ -102,8 +102,9 @@ def build_regions():
                                         "stripe_strip": "void stripe_strip(uint32_t", "fetch_clamped": "uint32_t fetch_clamped("}.items()}
     D["issue_general"] = (dfind("// (issue_item's arithmetic: rows and groups clamped to the frame)"), dfind("asm volatile(\"\" : \"+v\"(oa0), \"+v\"(ob0));"))
     # the output stage's instantiations, by the line of their call in strip_output: (CLAMP, XM) and the all-stripes one
-    for name, args in {"out_generic": "true, true, true, SM>", "out_low_xm": "true, true, false, SM>", "out_low": "true, false, false, SM>",
-                       "out_xm": "false, true, false, SM>", "out_plain": "false, false, false, SM>"}.items():
+    for name, args in {"out_generic": "true, true, true, false, SM>", "out_low_xm": "true, true, false, false, SM>", "out_low": "true, false, false, false, SM>",
+                       "out_xm": "false, true, false, false, SM>", "out_plain": "false, false, false, false, SM>",
+                       "out_bright": "false, false, false, true, SM>"}.items():
         D[name] = (dfind("strip_output_t<METHOD, PACKED, VECST, " + args),) * 2
     return P, D
 
@@ -156,7 +157,9 @@ def weight_of(chain, R, tiles_per_workgroup):
     if inside(o, P["output"]):
         if any(inside(l, D["out_generic"]) for l in dev):
             return 0.0, "stripes, 32-bit / generic epilogue (not this launch)"
-        for name, share, what in (("out_plain", (1 - LOW_TILE_SHARE) * (1 - MARGIN_TILE_SHARE), "no clamp, no stripes mask"),
+        # (the benchmark's frames: every tile without low pixels or pixel-map cells that is not at the margin holds pixels >= 256 above black only)
+        for name, share, what in (("out_bright", (1 - LOW_TILE_SHARE) * (1 - MARGIN_TILE_SHARE), "bright tiles: no clamp, no stripes mask, no conditions"),
+                                  ("out_plain", 0.0, "no clamp, no stripes mask"),
                                   ("out_low", LOW_TILE_SHARE * (1 - MARGIN_TILE_SHARE), "tiles with low pixels or pixel-map cells"),
                                   ("out_xm", (1 - LOW_TILE_SHARE) * MARGIN_TILE_SHARE, "tiles at the frame's left / right margin"),
                                   ("out_low_xm", LOW_TILE_SHARE * MARGIN_TILE_SHARE, "margin tiles with low pixels")):
