@@ -205,3 +205,16 @@ def test_worker_threads_are_bound_round_robin_in_pci_order(amd):
     one = (C.c_char_p * 1)(b"0000:05:00.0")
     assert amd.mlvfs_amd_test_device_order(C.cast(one, C.c_void_p), 1, 3, lib.ptr(out)) == 0 and list(out[:3]) == [0, 0, 0]
     assert amd.mlvfs_amd_test_device_order(None, 0, 1, lib.ptr(out)) != 0
+
+
+def test_fix_pattern_noise_refuses_odd_sizes_before_touching_anything(amd):
+    """patternnoise.c:284-310 index its half-size planes with x/2 + (y/2)*(w/2): with an odd width the last column of every row lands
+    in the next row's first slot, with an odd height the last row lies behind the malloc'ed plane (heap overflow) -- the reference has
+    no defined result to match (MLVFS only passes even raw sizes).  The library reports the frame and leaves it alone; the check comes
+    before any device call, so it holds without a GPU."""
+    for w, h in ((65, 48), (64, 47), (33, 33), (1, 2)):
+        f = (np.arange(w * h, dtype=np.int16).reshape(h, w) * 7 + 2048).astype(np.int16)
+        g = f.copy()
+        amd.fix_pattern_noise(lib.ptr(g), w, h, 15000, 0)
+        assert np.array_equal(g, f)
+        assert b"not supported" in amd.mlvfs_amd_last_error()
