@@ -197,70 +197,114 @@ constexpr int WG_WORDS = WG_CHUNKS * CHUNK_BYTES / 4;   // 2048
 
 constexpr int CMAP_PITCH = ENTRIES + 2;                 // 17 words per row: the threads' rows start in different banks
 
-struct WalkSmem {
-    uint32_t words[WG_WORDS + 4 + (WG_WORDS + 4) / 32 + 1];
-    uint16_t cmap[WG_CHUNKS][CMAP_PITCH];               // exit offset | symbols << 5
-    uint16_t lut[LJ_LUT_MAX];
-    union {
-        uint32_t cstart[WG_CHUNKS][2];                  // true entry offset, index of the first symbol (k_lj_decode)
-        uint16_t ring[32][WG_CHUNKS];                   // k_lj_chunk_maps: {exit, symbols} of the 32 positions ahead, per thread
+// A workgroup's 8 KiB of stream (+ 16 bytes of look-ahead) and the Huffman table into LDS: 16-byte loads, all of a thread's loads issued
+// before its first store.  (As loops of 4- and 2-byte loads -- eight and fourteen dependent passes of global-memory latency -- this
+// prologue was most of the decode kernel's 58 k cycles per wave: profiles/r05/lj_steps.txt.)
+// LENGTHS: the table's plain entries, (ssss << 8) | code length, become the symbol's whole length code + ssss (1 for "no such code", as
+// symbol() steps) -- all that k_lj_chunk_maps wants of a symbol; entries that point to a second-level table stay as they are.
+template <bool LENGTHS>
+__device__ __forceinline__ void load_stream_and_table(const LjFrame &f, uint32_t wg, uint32_t *words, uint16_t *lut)
+{
+    static_assert(WG_WORDS + 4 == 4 * 513 && LJ_LUT_MAX == 8 * 448, "two passes of 256 threads each");
+    const uint4 *src = (const uint4 *)(f.ust + (size_t)wg * WG_CHUNKS * CHUNK_BYTES);      // ust is 16-byte aligned, LJ_TAIL bytes of zeros behind it
+    const uint4 *l4 = (const uint4 *)f.lut;                                                // LJ_LUT_MAX entries, 256-byte aligned
+    const uint32_t t = threadIdx.x;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    const uint4 w0 = src[t], w1 = src[t + 256], w2 = t == 0 ? src[512] : zero;
+    uint4 t0 = l4[t], t1 = t < 192 ? l4[t + 256] : zero;
+    if (LENGTHS) {
+        auto len1 = [](uint32_t e) -> uint32_t {
+            if (e & 0x8000u) return e;
+            const uint32_t used = e & 0xFFu, ss = e >> 8;
+            return (used == 0 || ss > 16) ? 1u : used + ss;
+        };
+        auto len2 = [&](uint32_t v) { return len1(v & 0xFFFFu) | (len1(v >> 16) << 16); };
+        t0 = make_uint4(len2(t0.x), len2(t0.y), len2(t0.z), len2(t0.w));
+        t1 = make_uint4(len2(t1.x), len2(t1.y), len2(t1.z), len2(t1.w));
+    }
+    auto put = [&](uint32_t q, const uint4 &v) {
+        words[pad_word(4 * q)] = bswap(v.x); words[pad_word(4 * q + 1)] = bswap(v.y);
+        words[pad_word(4 * q + 2)] = bswap(v.z); words[pad_word(4 * q + 3)] = bswap(v.w);
     };
-};
-
-__device__ __forceinline__ void load_window(const LjFrame &f, uint32_t wg, WalkSmem &sm)
-{
-    const uint32_t *src = (const uint32_t *)(f.ust + (size_t)wg * WG_CHUNKS * CHUNK_BYTES);      // ust is 16-byte aligned
-    for (int i = threadIdx.x; i < WG_WORDS + 4; i += blockDim.x) sm.words[pad_word(i)] = bswap(src[i]);
-    for (int i = threadIdx.x; i < f.lut_entries; i += blockDim.x) sm.lut[i] = f.lut[i];
-}
-
-// length only (k_lj_chunk_maps)
-__device__ __forceinline__ uint32_t symbol_len(const Window &win, const uint16_t *lut, int huffbits, uint32_t p)
-{
-    const uint32_t e = lut_entry(lut, huffbits, win.at(p));
-    const uint32_t used = e & 0xFFu, t = e >> 8;
-    return (used == 0 || t > 16) ? 1u : used + t;
+    put(t, w0); put(t + 256, w1);
+    if (t == 0) put(512, w2);
+    ((uint4 *)lut)[t] = t0;
+    if (t < 192) ((uint4 *)lut)[t + 256] = t1;
 }
 
 constexpr int SEGS = 16, SEG_CHUNKS = WG_CHUNKS / SEGS;     // the decode kernel walks 16 + 16 maps instead of 256
 
-// chunk maps of one workgroup + their composition
+// chunk maps of one workgroup + their composition.  33 KiB of LDS -- four workgroups per CU: the maps take the place of the stream
+// words and the Huffman table once the walk is over, the segment maps that of the ring (all of them side by side were 53 KiB, three
+// workgroups per CU, in a kernel that waits on dependent LDS reads most of the time).
+struct alignas(16) MapSmem {
+    union {
+        struct { uint32_t words[WG_WORDS + 4 + (WG_WORDS + 4) / 32 + 1]; alignas(16) uint16_t lut[LJ_LUT_MAX]; } in;
+        uint16_t cmap[WG_CHUNKS][CMAP_PITCH];           // exit offset | symbols << 5
+    };
+    union {
+        uint16_t ring[32][WG_CHUNKS];                   // {exit, symbols} of the 32 positions ahead, per thread
+        uint2 segm[SEGS][ENTRIES];
+    };
+};
+static_assert(sizeof(MapSmem) * 4 <= 160 * 1024, "four workgroups per CU");
+
 __global__ __launch_bounds__(256) void k_lj_chunk_maps(const LjFrame *frames)
 {
     const LjFrame &f = frames[blockIdx.y];
     const uint32_t wg = blockIdx.x;
     if (wg >= f.nwg) return;
-    __shared__ WalkSmem sm;
-    load_window(f, wg, sm);
+    __shared__ MapSmem sm;
+    load_stream_and_table<true>(f, wg, sm.in.words, sm.in.lut);
     __syncthreads();
-    const Window win{ sm.words };
     const uint32_t c0 = threadIdx.x * CHUNK_BITS;
     // From the last bit of the chunk backwards: a walk that starts at bit q continues at q + length(q), which is at most 32
     // bits ahead, so {exit offset, symbols} of the 32 positions ahead (a ring in LDS) are all that is needed.  256 symbol
     // look-ups per chunk instead of one walk per entry offset (~30 symbols each, 32 of them).
     for (int q = 0; q < 32; q++) sm.ring[q][threadIdx.x] = (uint16_t)q;              // positions 256..287: already outside
     // The symbol lengths of different positions do not depend on each other: 16 look-ups are issued together (their LDS
-    // latencies overlap), then the 16 dependent ring steps follow.
-    for (int q0 = CHUNK_BITS - 16; q0 >= 0; q0 -= 16) {
-        uint32_t len[16];
+    // latencies overlap), then the 16 dependent ring steps follow.  32 positions share two stream words, their bit offsets are
+    // compile-time constants (one v_alignbit_b32 per window), and the table holds whole lengths (load_stream_and_table<true>):
+    // 9 vector instructions per position where the general symbol() path took 22.
+    const int b1 = f.huffbits < LJ_L1_BITS ? f.huffbits : LJ_L1_BITS, b2 = f.huffbits - b1;
+    const uint16_t *lut = sm.in.lut;
+    uint16_t *ring_t = &sm.ring[0][threadIdx.x];
+    for (int qq = CHUNK_BITS - 32; qq >= 0; qq -= 32) {
+        const uint32_t wi = (c0 + (uint32_t)qq) >> 5;
+        const uint32_t w0 = sm.in.words[pad_word(wi)], w1 = sm.in.words[pad_word(wi + 1)];
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-            len[i] = symbol_len(win, sm.lut, f.huffbits, c0 + q0 + i);
+        for (int half = 1; half >= 0; half--) {
+            uint32_t bits[16], len[16];
 #pragma unroll
-        for (int i = 15; i >= 0; i--) {
-            const int q = q0 + i;
-            const uint16_t v = (uint16_t)(sm.ring[(q + len[i]) & 31][threadIdx.x] + 32);  // one more symbol on that walk
-            sm.ring[q & 31][threadIdx.x] = v;        // (q + 32) & 31 == q & 31: read above before it is overwritten here
-            if (q0 < ENTRIES) sm.cmap[threadIdx.x][q] = v;
+            for (int i = 0; i < 16; i++) {
+                const int sft = 16 * half + i;                                           // bit offset in w0: a constant
+                bits[i] = sft == 0 ? w0 : __builtin_amdgcn_alignbit(w0, w1, 32 - sft);
+                len[i] = lut[bits[i] >> (32 - b1)];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                if (len[i] & 0x8000u) len[i] = lut[(len[i] & 0x7FFFu) + ((bits[i] << b1) >> (32 - b2))];
+#pragma unroll
+            for (int i = 15; i >= 0; i--) {
+                const int q = qq + 16 * half + i;
+                const uint16_t v = (uint16_t)(ring_t[(((uint32_t)q + len[i]) & 31u) * WG_CHUNKS] + 32);   // one more symbol on that walk
+                ring_t[(q & 31) * WG_CHUNKS] = v;       // (q + 32) & 31 == q & 31: read above before it is overwritten here
+            }
         }
     }
-    __syncthreads();
+    __syncthreads();                                     // every thread is done with the stream words and the table: the maps take their place
+    // the ring now holds positions 0..31, the chunk's map: thread t's column becomes row t (conflict-free both ways)
+    uint16_t mine[ENTRIES];
+#pragma unroll
+    for (int q = 0; q < ENTRIES; q++) mine[q] = sm.ring[q][threadIdx.x];
+#pragma unroll
+    for (int q = 0; q < ENTRIES; q++) sm.cmap[threadIdx.x][q] = mine[q];
+    __syncthreads();                                     // (and the ring is free for the segment maps)
     uint32_t *dst = (uint32_t *)(f.cmap + (size_t)wg * WG_CHUNKS * ENTRIES);
     for (int i = threadIdx.x; i < WG_CHUNKS * ENTRIES / 2; i += blockDim.x)
         dst[i] = *(const uint32_t *)&sm.cmap[i / (ENTRIES / 2)][2 * (i % (ENTRIES / 2))];
     // maps of the 16 segments of 16 chunks (32 lanes each, two rounds), then 32 lanes compose those into the workgroup's map
     uint2 *smap = f.smap + (size_t)wg * SEGS * ENTRIES;
-    __shared__ uint2 segm[SEGS][ENTRIES];
     for (int round = 0; round < 2; round++) {
         const int seg = round * 8 + (threadIdx.x >> 5);
         uint32_t e = threadIdx.x & 31, n = 0;
@@ -269,14 +313,14 @@ __global__ __launch_bounds__(256) void k_lj_chunk_maps(const LjFrame *frames)
             e = m & 31u;
             n += m >> 5;
         }
-        segm[seg][threadIdx.x & 31] = make_uint2(e, n);
+        sm.segm[seg][threadIdx.x & 31] = make_uint2(e, n);
         smap[seg * ENTRIES + (threadIdx.x & 31)] = make_uint2(e, n);
     }
     __syncthreads();
     if (threadIdx.x < ENTRIES) {
         uint32_t e = threadIdx.x, n = 0;
         for (int sgi = 0; sgi < SEGS; sgi++) {
-            const uint2 m = segm[sgi][e];
+            const uint2 m = sm.segm[sgi][e];
             e = m.x;
             n += m.y;
         }
@@ -284,54 +328,96 @@ __global__ __launch_bounds__(256) void k_lj_chunk_maps(const LjFrame *frames)
     }
 }
 
-// map of GROUP_WGS consecutive workgroup maps
-__global__ __launch_bounds__(64) void k_lj_group_maps(const LjFrame *frames)
+// map of GROUP_WGS consecutive workgroup maps.  The maps (8 KiB) are fetched into LDS in one go and walked there: walked in global
+// memory, this kernel, k_lj_top and k_lj_group_starts were chains of 32, ~18 and 32 dependent loads of memory latency -- 12 + 11 + 20 us
+// per sub-batch for a few kilobytes of work (profiles/r05/lj_steps.txt).
+__device__ __forceinline__ void load_group_wmaps(const LjFrame &f, uint32_t g, uint2 (*wm)[ENTRIES])
+{
+    const uint32_t w0 = g * GROUP_WGS, n = min(f.nwg, w0 + GROUP_WGS) - w0;               // wmap is 256-byte aligned, a map 256 bytes
+    const uint4 *src = (const uint4 *)(f.wmap + (size_t)w0 * ENTRIES);
+    uint4 *dst = (uint4 *)&wm[0][0];
+    for (uint32_t i = threadIdx.x; i < n * (ENTRIES / 2); i += blockDim.x) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void k_lj_group_maps(const LjFrame *frames)
 {
     const LjFrame &f = frames[blockIdx.y];
     const uint32_t g = blockIdx.x;
-    if (g >= f.ngrp || threadIdx.x >= ENTRIES) return;
+    if (g >= f.ngrp) return;
+    __shared__ __align__(16) uint2 wm[GROUP_WGS][ENTRIES];
+    load_group_wmaps(f, g, wm);
+    __syncthreads();
+    if (threadIdx.x >= ENTRIES) return;
     uint32_t e = threadIdx.x, n = 0;
-    const uint32_t w1 = min(f.nwg, (g + 1) * GROUP_WGS);
-    for (uint32_t w = g * GROUP_WGS; w < w1; w++) {
-        const uint2 m = f.wmap[(size_t)w * ENTRIES + e];
+    const uint32_t cnt = min(f.nwg, (g + 1) * GROUP_WGS) - g * GROUP_WGS;
+    for (uint32_t w = 0; w < cnt; w++) {
+        const uint2 m = wm[w][e];
         e = m.x;
         n += m.y;
     }
     f.gmap[(size_t)g * ENTRIES + threadIdx.x] = make_uint2(e, n);
 }
 
-// the scan starts on a symbol: offset 0 of group 0.  One thread per frame walks the group maps.
-__global__ void k_lj_top(const LjFrame *frames, int nframes)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nframes) return;
-    const LjFrame &f = frames[i];
-    uint32_t e = 0, n = 0;
-    for (uint32_t g = 0; g < f.ngrp; g++) {
-        f.gstart[g] = make_uint2(e, n);
-        const uint2 m = f.gmap[(size_t)g * ENTRIES + e];
-        e = m.x;
-        n += m.y;
-    }
-    if (n < (uint32_t)f.W * (uint32_t)f.H) atomicOr(f.err, LJ_ERR_SHORT);           // fewer symbols than pixels
-}
-
-__global__ __launch_bounds__(64) void k_lj_group_starts(const LjFrame *frames)
+// The scan starts on a symbol: offset 0 of group 0.  Every group's workgroup walks the group maps before it (a few dozen steps in
+// LDS) for its own entry offset and first symbol index, then its workgroups' maps for theirs.  The last group also knows the total.
+constexpr int GMAP_TILE = 32;                           // group maps walked per pass (8 KiB of LDS)
+__global__ __launch_bounds__(256) void k_lj_group_starts(const LjFrame *frames)
 {
     const LjFrame &f = frames[blockIdx.y];
-    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t g = blockIdx.x;
     if (g >= f.ngrp) return;
-    uint2 s = f.gstart[g];
-    const uint32_t w1 = min(f.nwg, (g + 1) * GROUP_WGS);
-    for (uint32_t w = g * GROUP_WGS; w < w1; w++) {
-        f.wstart[w] = s;
-        const uint2 m = f.wmap[(size_t)w * ENTRIES + s.x];
-        s.x = m.x;
-        s.y += m.y;
+    __shared__ __align__(16) uint2 wm[GROUP_WGS][ENTRIES];
+    __shared__ __align__(16) uint2 gm[GMAP_TILE][ENTRIES];
+    __shared__ uint2 at;
+    if (threadIdx.x == 0) at = make_uint2(0, 0);
+    load_group_wmaps(f, g, wm);
+    for (uint32_t g0 = 0; g0 < g; g0 += GMAP_TILE) {
+        const uint32_t cnt = min(g - g0, (uint32_t)GMAP_TILE);
+        __syncthreads();
+        const uint4 *src = (const uint4 *)(f.gmap + (size_t)g0 * ENTRIES);
+        for (uint32_t i = threadIdx.x; i < cnt * (ENTRIES / 2); i += blockDim.x) ((uint4 *)&gm[0][0])[i] = src[i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint2 s = at;
+            for (uint32_t k = 0; k < cnt; k++) {
+                const uint2 m = gm[k][s.x];
+                s.x = m.x;
+                s.y += m.y;
+            }
+            at = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint2 s = at;
+        const uint32_t w0 = g * GROUP_WGS, cnt = min(f.nwg, w0 + GROUP_WGS) - w0;
+        for (uint32_t w = 0; w < cnt; w++) {
+            f.wstart[w0 + w] = s;
+            const uint2 m = wm[w][s.x];
+            s.x = m.x;
+            s.y += m.y;
+        }
+        if (g == f.ngrp - 1 && s.y < (uint32_t)f.W * (uint32_t)f.H) atomicOr(f.err, LJ_ERR_SHORT);      // fewer symbols than pixels
     }
 }
 
-// every chunk decodes its true symbols and stores the differences at their pixel index
+// every chunk decodes its true symbols; the workgroup's differences -- one contiguous range of pixel indices -- are collected in LDS
+// and leave as whole lines.  (Stored by the decoding threads themselves, 16 bytes at a time, each of a wave's 64 lanes wrote into a
+// line of its own: WRITE_SIZE said 357 MB per four 3584x1320 frames for 76 MB of differences, profiles/r05/lj_pmc_before.txt.)
+constexpr int DEC_STAGE = 9184;                         // differences a workgroup can hold (8 KiB of stream at >= 7.14 bits per symbol); the rest goes out directly
+struct alignas(16) DecSmem {
+    uint32_t words[WG_WORDS + 4 + (WG_WORDS + 4) / 32 + 1];
+    alignas(16) uint16_t lut[LJ_LUT_MAX];
+    uint32_t cstart[WG_CHUNKS][2];                      // true entry offset, index of the first symbol
+    uint2 segstart[SEGS];
+    uint32_t end_idx;
+    alignas(16) union {
+        struct { uint16_t cmap[WG_CHUNKS][CMAP_PITCH]; alignas(16) uint2 segm[SEGS][ENTRIES]; } m;      // until the chunks' starts are known
+        int stage[DEC_STAGE];
+    };
+};
+static_assert(sizeof(DecSmem) * 3 <= 160 * 1024, "three workgroups per CU");
+
 __global__ __launch_bounds__(256) void k_lj_decode(const LjFrame *frames)
 {
     const LjFrame &f = frames[blockIdx.y];
@@ -340,70 +426,93 @@ __global__ __launch_bounds__(256) void k_lj_decode(const LjFrame *frames)
     const uint32_t npx = (uint32_t)f.W * (uint32_t)f.H;
     const uint2 start = f.wstart[wg];
     if (start.y >= npx) return;                          // everything behind the last pixel is padding / the EOI marker
-    __shared__ WalkSmem sm;
-    load_window(f, wg, sm);
-    const uint32_t *srcm = (const uint32_t *)(f.cmap + (size_t)wg * WG_CHUNKS * ENTRIES);
-    for (int i = threadIdx.x; i < WG_CHUNKS * ENTRIES / 2; i += blockDim.x)
-        *(uint32_t *)&sm.cmap[i / (ENTRIES / 2)][2 * (i % (ENTRIES / 2))] = srcm[i];
-    __shared__ uint2 segm[SEGS][ENTRIES];
-    for (int i = threadIdx.x; i < SEGS * ENTRIES; i += blockDim.x) (&segm[0][0])[i] = f.smap[(size_t)wg * SEGS * ENTRIES + i];
+    __shared__ DecSmem sm;
+    {
+        // the workgroup's chunk maps (16 KiB) and segment maps (4 KiB): 16-byte loads issued together, like the stream's
+        static_assert(WG_CHUNKS * ENTRIES * 2 == 1024 * 16 && SEGS * ENTRIES * 8 == 256 * 16, "four passes + one");
+        const uint4 *cm = (const uint4 *)(f.cmap + (size_t)wg * WG_CHUNKS * ENTRIES);
+        const uint4 *sg = (const uint4 *)(f.smap + (size_t)wg * SEGS * ENTRIES);
+        const uint32_t t = threadIdx.x;
+        const uint4 c0 = cm[t], c1 = cm[t + 256], c2 = cm[t + 512], c3 = cm[t + 768], s0 = sg[t];
+        load_stream_and_table<false>(f, wg, sm.words, sm.lut);
+        auto put = [&](uint32_t u, const uint4 &v) {        // piece u: eight entries of chunk u / 4 (rows of 34: dword stores)
+            uint32_t *row = (uint32_t *)&sm.m.cmap[u >> 2][0] + 4 * (u & 3);
+            row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
+        };
+        put(t, c0); put(t + 256, c1); put(t + 512, c2); put(t + 768, c3);
+        ((uint4 *)&sm.m.segm[0][0])[t] = s0;
+    }
     __syncthreads();
-    __shared__ uint2 segstart[SEGS];
     if (threadIdx.x == 0) {                              // 16 segment maps from the workgroup's true start ...
         uint32_t e = start.x, n = start.y;
         for (int sgi = 0; sgi < SEGS; sgi++) {
-            segstart[sgi] = make_uint2(e, n);
-            const uint2 m = segm[sgi][e];
+            sm.segstart[sgi] = make_uint2(e, n);
+            const uint2 m = sm.m.segm[sgi][e];
             e = m.x;
             n += m.y;
         }
     }
     __syncthreads();
     if (threadIdx.x < SEGS) {                            // ... then 16 lanes walk the 16 chunk maps of their segment
-        uint32_t e = segstart[threadIdx.x].x, n = segstart[threadIdx.x].y;
+        uint32_t e = sm.segstart[threadIdx.x].x, n = sm.segstart[threadIdx.x].y;
         for (int c = threadIdx.x * SEG_CHUNKS; c < (threadIdx.x + 1) * SEG_CHUNKS; c++) {
             sm.cstart[c][0] = e;
             sm.cstart[c][1] = n;
-            const uint32_t m = sm.cmap[c][e];
+            const uint32_t m = sm.m.cmap[c][e];
             e = m & 31u;
             n += m >> 5;
         }
     }
-    __syncthreads();
-    const Window win{ sm.words };
+    __syncthreads();                                     // (the maps are done with: the stage takes their place)
     const uint32_t c0 = threadIdx.x * CHUNK_BITS;
     uint32_t p = c0 + sm.cstart[threadIdx.x][0], idx = sm.cstart[threadIdx.x][1];
     const uint64_t end_bit = (uint64_t)*f.ust_len * 8, wg_bit0 = (uint64_t)wg * WG_CHUNKS * CHUNK_BITS;
+    const uint32_t base = start.y;
     bool bad_any = false;
-    int4 q4 = make_int4(0, 0, 0, 0);
-    uint32_t held = 0;
+    // The thread's stream runs through a 64-bit register window (the next symbol's bits on top) that is refilled a word at a time from a
+    // word fetched one refill ahead: a symbol's dependent chain is the table look-up and a shift, not two reads of the stream first
+    // (profiles/r05/lj_pmc_before.txt: two thirds of the kernel's wave cycles were waits, a thousand cycles per symbol).
+    uint32_t wi = p >> 5;
+    uint64_t buf = (((uint64_t)sm.words[pad_word(wi)] << 32) | sm.words[pad_word(wi + 1)]) << (p & 31);
+    int avail = 64 - (int)(p & 31);
+    wi += 2;
+    uint32_t nextw = sm.words[pad_word(min(wi, (uint32_t)(WG_WORDS + 3)))];
+    const int huffbits = f.huffbits;
     while (p < c0 + CHUNK_BITS && idx < npx) {
-        int d;
+        const uint32_t bits = (uint32_t)(buf >> 32);
+        const uint32_t e = lut_entry(sm.lut, huffbits, bits);
+        const uint32_t used = e & 0xFFu, t = e >> 8;
         bool bad = false;
-        const uint32_t len = symbol(win, sm.lut, f.huffbits, p, &d, &bad);
+        uint32_t len;
+        int d = 0;
+        if (used == 0 || t > 16) { bad = true; len = 1; }                   // no such code: step on, the frame is reported corrupt
+        else {
+            if (t) {
+                d = (int)((bits << used) >> (32 - t));
+                if (d < (1 << (t - 1))) d += (int)(0xFFFFFFFFu << t) + 1;
+            }
+            len = used + t;
+        }
         if (wg_bit0 + p + len > end_bit) bad = true;      // a pixel decoded from bits behind the end of the data
         bad_any |= bad;
-        // a thread's ~30 differences are consecutive in memory but 64 lanes write 64 different lines: groups of four
-        // aligned values leave as one 16-byte store
-        const uint32_t slot = idx & 3u;
-        q4.x = slot == 0 ? d : q4.x; q4.y = slot == 1 ? d : q4.y; q4.z = slot == 2 ? d : q4.z; q4.w = slot == 3 ? d : q4.w;
-        held++;
-        if (slot == 3) {
-            if (held >= 4) *(int4 *)(f.diff + (idx - 3)) = q4;
-            else {                                         // the thread's first values did not start on a multiple of four
-                if (held >= 3) f.diff[idx - 2] = q4.y;
-                if (held >= 2) f.diff[idx - 1] = q4.z;
-                f.diff[idx] = q4.w;
-            }
-            held = 0;
-        }
+        const uint32_t at = idx - base;
+        if (at < (uint32_t)DEC_STAGE) sm.stage[at] = d;
+        else f.diff[idx] = d;
         idx++;
         p += len;
+        buf <<= len;
+        avail -= (int)len;
+        if (avail < 32) {                                 // (len <= 32: one word per refill is enough)
+            buf |= (uint64_t)nextw << (32 - avail);
+            avail += 32;
+            wi++;
+            nextw = sm.words[pad_word(min(wi, (uint32_t)(WG_WORDS + 3)))];
+        }
     }
-    if (held) {                                            // an unfinished group: `held` values ending at idx - 1
-        const uint32_t first = idx - held;                 // same group of four: slots first & 3 .. (idx - 1) & 3
-        for (uint32_t i = first; i < idx; i++) f.diff[i] = (i & 3u) == 0 ? q4.x : (i & 3u) == 1 ? q4.y : (i & 3u) == 2 ? q4.z : q4.w;
-    }
+    if (threadIdx.x == WG_CHUNKS - 1) sm.end_idx = min(idx, npx);      // (the chunks' ranges follow each other: the last one's end is the workgroup's)
+    __syncthreads();
+    const uint32_t n = min(sm.end_idx - base, (uint32_t)DEC_STAGE);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) f.diff[base + i] = sm.stage[i];
     if (bad_any) atomicOr(f.err, LJ_ERR_CODE);
 }
 
@@ -415,10 +524,17 @@ struct RowView {
     __device__ __forceinline__ int &operator[](int i) const { return p[padded ? i + (i >> 5) : i]; }
 };
 
+// LDS of k_lj_rows for rows of up to max_w values: carries (one per block of 32 columns, + 2), the staged row when it fits
+static size_t row_lds_bytes(int max_w)
+{
+    const size_t carries = (size_t)((max_w + 31) / 32 + 2) * sizeof(long long);
+    return carries + (max_w <= ROW_LDS ? (size_t)(max_w + max_w / 32 + 2) * sizeof(int) : 0);
+}
+
 // one workgroup per row.  HALVING rows (predictor 6, r >= 1): e[c] = (e[c-1] >> 1) + d[c] in blocks of 32 columns.
 // SCAN rows (row 0 always, every row of predictor 1): inclusive prefix sum; row 0 also carries the base 2^(bits-1).
 // The row is rewritten in place (diff -> e).
-__global__ __launch_bounds__(256) void k_lj_rows(const LjFrame *frames)
+__global__ __launch_bounds__(256) void k_lj_rows(const LjFrame *frames, int max_w)
 {
     const LjFrame &f = frames[blockIdx.y];
     const int r = blockIdx.x;
@@ -429,10 +545,14 @@ __global__ __launch_bounds__(256) void k_lj_rows(const LjFrame *frames)
     if (!scan_row && f.pred != 6) return;
     int *grow = f.diff + (size_t)r * f.W;
     const int W = f.W;
-    __shared__ long long carry[2048 + 1];               // W <= 65535: at most 2048 blocks of 32 columns
+    // Dynamic LDS, sized by the launcher from the widest frame of the batch (row_lds_bytes): the carries of the row's blocks of 32
+    // columns, then the staged row.  (Sized statically for the widest possible row it was 50 KiB -- three rows in flight per CU in a
+    // kernel that is all latency: a row's load, 112 dependent carry steps, its store.)
+    extern __shared__ long long row_lds[];
+    long long *const carry = row_lds;                   // (W + 31) / 32 + 1 entries
     // rows up to ROW_LDS values are staged in LDS (coalesced in, coalesced out; one spare word per 32 keeps the threads,
     // which each work on 32 consecutive values, in different banks); longer rows are worked on in place
-    __shared__ int stage[ROW_LDS + ROW_LDS / 32 + 2];
+    int *const stage = (int *)(row_lds + ((max_w + 31) / 32 + 2));
     const bool staged = W <= ROW_LDS;
     if (staged) {
         for (int i = threadIdx.x; i < W; i += blockDim.x) stage[i + (i >> 5)] = grow[i];
@@ -652,12 +772,11 @@ int lj92_launch(const LjFrame *d_frames, int nframes, uint32_t max_raw, uint32_t
     hipLaunchKernelGGL(k_lj_unstuff_scan, dim3(nframes), dim3(256), 0, s, d_frames);
     hipLaunchKernelGGL(k_lj_unstuff_scatter, dim3(ublk + 1, nframes), dim3(256), 0, s, d_frames);
     hipLaunchKernelGGL(k_lj_chunk_maps, dim3(max_nwg, nframes), dim3(256), 0, s, d_frames);
-    hipLaunchKernelGGL(k_lj_group_maps, dim3(max_ngrp, nframes), dim3(64), 0, s, d_frames);
-    hipLaunchKernelGGL(k_lj_top, dim3((nframes + 63) / 64), dim3(64), 0, s, d_frames, nframes);
-    hipLaunchKernelGGL(k_lj_group_starts, dim3((max_ngrp + 63) / 64, nframes), dim3(64), 0, s, d_frames);
+    hipLaunchKernelGGL(k_lj_group_maps, dim3(max_ngrp, nframes), dim3(256), 0, s, d_frames);
+    hipLaunchKernelGGL(k_lj_group_starts, dim3(max_ngrp, nframes), dim3(256), 0, s, d_frames);
     hipLaunchKernelGGL(k_lj_decode, dim3(max_nwg, nframes), dim3(256), 0, s, d_frames);
     if (preds & (1u << 5)) hipLaunchKernelGGL(k_lj_vhalve, dim3((max_w + 255) / 256, nframes), dim3(256), 0, s, d_frames);
-    hipLaunchKernelGGL(k_lj_rows, dim3(max_h, nframes), dim3(256), 0, s, d_frames);
+    hipLaunchKernelGGL(k_lj_rows, dim3(max_h, nframes), dim3(256), row_lds_bytes(max_w), s, d_frames, max_w);
     if (preds & (1u << 3)) hipLaunchKernelGGL(k_lj_diagonals, dim3((max_w + max_h + 255) / 256, nframes), dim3(256), 0, s, d_frames);
     if (preds & (1u << 7)) hipLaunchKernelGGL(k_lj_wavefront, dim3(nframes), dim3(1024), 0, s, d_frames);
     hipLaunchKernelGGL(k_lj_column_sums, dim3((max_w + 255) / 256 * COL_SEGS, nframes), dim3(256), 0, s, d_frames);
