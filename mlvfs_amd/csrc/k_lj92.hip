@@ -261,14 +261,17 @@ __global__ __launch_bounds__(256) void k_lj_chunk_maps(const LjFrame *frames)
     // From the last bit of the chunk backwards: a walk that starts at bit q continues at q + length(q), which is at most 32
     // bits ahead, so {exit offset, symbols} of the 32 positions ahead (a ring in LDS) are all that is needed.  256 symbol
     // look-ups per chunk instead of one walk per entry offset (~30 symbols each, 32 of them).
-    for (int q = 0; q < 32; q++) sm.ring[q][threadIdx.x] = (uint16_t)q;              // positions 256..287: already outside
+    // (a thread's column of the ring: lanes 0..31 of a wave take the low halves of 32 consecutive dwords, lanes 32..63 the high halves --
+    // LDS serves a wave's 64 lanes in two halves of 32, and in thread order each half had two lanes per bank)
+    const uint32_t rcol = (threadIdx.x & ~63u) + 2u * (threadIdx.x & 31u) + ((threadIdx.x >> 5) & 1u);
+    for (int q = 0; q < 32; q++) sm.ring[q][rcol] = (uint16_t)q;                     // positions 256..287: already outside
     // The symbol lengths of different positions do not depend on each other: 16 look-ups are issued together (their LDS
     // latencies overlap), then the 16 dependent ring steps follow.  32 positions share two stream words, their bit offsets are
     // compile-time constants (one v_alignbit_b32 per window), and the table holds whole lengths (load_stream_and_table<true>):
     // 9 vector instructions per position where the general symbol() path took 22.
     const int b1 = f.huffbits < LJ_L1_BITS ? f.huffbits : LJ_L1_BITS, b2 = f.huffbits - b1;
     const uint16_t *lut = sm.in.lut;
-    uint16_t *ring_t = &sm.ring[0][threadIdx.x];
+    uint16_t *ring_t = &sm.ring[0][rcol];
     for (int qq = CHUNK_BITS - 32; qq >= 0; qq -= 32) {
         const uint32_t wi = (c0 + (uint32_t)qq) >> 5;
         const uint32_t w0 = sm.in.words[pad_word(wi)], w1 = sm.in.words[pad_word(wi + 1)];
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void k_lj_chunk_maps(const LjFrame *frames)
     // the ring now holds positions 0..31, the chunk's map: thread t's column becomes row t (conflict-free both ways)
     uint16_t mine[ENTRIES];
 #pragma unroll
-    for (int q = 0; q < ENTRIES; q++) mine[q] = sm.ring[q][threadIdx.x];
+    for (int q = 0; q < ENTRIES; q++) mine[q] = sm.ring[q][rcol];
 #pragma unroll
     for (int q = 0; q < ENTRIES; q++) sm.cmap[threadIdx.x][q] = mine[q];
     __syncthreads();                                     // (and the ring is free for the segment maps)

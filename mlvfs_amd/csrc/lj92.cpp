@@ -114,6 +114,9 @@ struct Work {                              // per host thread and device, grow-o
     size_t cap_arena = 0, cap_stage = 0;
     hipStream_t sub[2] = { nullptr, nullptr };          // sub-batches alternate between two streams: uploads overlap kernels
     hipEvent_t ready = nullptr, done[2] = { nullptr, nullptr };
+    std::vector<std::pair<const void *, size_t>> last_key;      // (MLVFS_AMD_LJ92_NOUPLOAD: the frames of the call before)
+    size_t last_arena = 0;
+    bool same_as_before = false;
     Work() = default;
     Work(const Work &) = delete;
     ~Work()                                             // with the host thread that owned it
@@ -228,6 +231,12 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
     Work &w = t_work[c->dev->id];
     int rc = w.ensure(arena, stage + (size_t)nframes * sizeof(int));
     if (rc) return rc;
+    {   // the same frames as the call before? (pointers, sizes, layout)
+        std::vector<std::pair<const void *, size_t>> key(nframes);
+        for (int i = 0; i < nframes; i++) key[i] = { streams[i], sizes[i] };
+        w.same_as_before = key == w.last_key && arena == w.last_arena;
+        w.last_key.swap(key); w.last_arena = arena;
+    }
     LjFrame *fr = (LjFrame *)(w.h_stage + frames_at);
     for (int i = 0; i < nframes; i++) {
         const Off &o = off[i];
@@ -259,6 +268,10 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
         const int n = std::min(SUB, nframes - j0);
         hipStream_t sj = w.sub[j & 1];
         if (j < 2) MLV_HIP(hipStreamWaitEvent(sj, w.ready, 0));
+        // (MLVFS_AMD_LJ92_NOUPLOAD=1, measurement only: a call with the same frames as the call before it finds their bytes where that
+        // call put them -- what the kernels do when no link stands before them; tools/lj92_bench.py)
+        static const bool no_upload = [] { const char *e = getenv("MLVFS_AMD_LJ92_NOUPLOAD"); return e && atoi(e) != 0; }();
+        if (!(no_upload && w.same_as_before))
         for (int i = j0; i < j0 + n; i++)
             MLV_HIP(hipMemcpyAsync(w.d_arena + off[i].raw, (const uint8_t *)streams[i] + hdr[i].scan, off[i].raw_len, hipMemcpyHostToDevice, sj));
         unsigned preds = 0;

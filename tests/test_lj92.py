@@ -294,6 +294,27 @@ def test_gpu_full_size_frame(gpu, oracle, reference):
 
 
 @pytest.mark.gpu
+def test_gpu_workgroups_with_more_symbols_than_their_stage_holds(gpu, oracle, reference):
+    """k_lj_decode collects a workgroup's differences (8 KiB of stream) in LDS, 9 184 of them; highly compressible content -- flat
+    areas at 4 bits per symbol with the reference's own table, 16 000 symbols per workgroup -- overflows that stage and the rest takes the direct path.  Frames
+    that mix flat halves, noise (8 000 symbols per workgroup) and a ramp, in one batch with different lengths."""
+    w, h = 1536, 640
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:h, 0:w]
+    flat = np.full((h, w), 3000, np.uint16)
+    half = flat.copy(); half[:, w // 2:] = rng.integers(0, 16384, (h, w - w // 2))
+    rows = flat.copy(); rows[h // 3: 2 * h // 3] = rng.integers(2000, 2400, (2 * h // 3 - h // 3, w))
+    ramp = (2048 + 3 * xx + yy).clip(0, 16383).astype(np.uint16)
+    frames = [flat, half, rows.astype(np.uint16), ramp]
+    streams = [reference.lj92_encode(quadrants(f), 14) for f in frames]
+    assert len(streams[0]) * 8 / (w * h) < 4.5                               # (the flat frame: 16 000 symbols per 8 KiB, the stage holds 9 184)
+    got = gpu_decode(streams, w, h)
+    for k, f in enumerate(frames):
+        assert np.array_equal(got[k], f), k
+    assert np.array_equal(got[1], want(oracle, streams[1], w, h))
+
+
+@pytest.mark.gpu
 def test_gpu_rejects_damage_and_unsupported(gpu, oracle):
     w, h = 136, 72
     img = images(w, h)["smooth"]
