@@ -114,6 +114,8 @@ struct Work {                              // per host thread and device, grow-o
     size_t cap_arena = 0, cap_stage = 0;
     hipStream_t sub[2] = { nullptr, nullptr };          // sub-batches alternate between two streams: uploads overlap kernels
     hipEvent_t ready = nullptr, done[2] = { nullptr, nullptr };
+    hipStream_t up = nullptr;                            // every sub-batch's upload, in order, on ONE stream (see the call)
+    std::vector<hipEvent_t> uploaded;                   // one per sub-batch
     std::vector<std::pair<const void *, size_t>> last_key;      // (MLVFS_AMD_LJ92_NOUPLOAD: the frames of the call before)
     size_t last_arena = 0;
     bool same_as_before = false;
@@ -126,6 +128,8 @@ struct Work {                              // per host thread and device, grow-o
             if (done[k]) (void)hipEventDestroy(done[k]);
         }
         if (ready) (void)hipEventDestroy(ready);
+        if (up) { (void)hipStreamSynchronize(up); (void)hipStreamDestroy(up); }
+        for (hipEvent_t e : uploaded) (void)hipEventDestroy(e);
         if (d_arena) (void)hipFree(d_arena);
         if (h_stage) (void)hipHostFree(h_stage);
     }
@@ -136,6 +140,7 @@ struct Work {                              // per host thread and device, grow-o
                 MLV_HIP(hipStreamCreateWithFlags(&sub[k], hipStreamNonBlocking));
                 MLV_HIP(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
             }
+            MLV_HIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
             MLV_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
         }
         if (arena > cap_arena) {
@@ -264,16 +269,26 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
     // entropy-coded bytes go straight from the caller's memory (page-locked when they come from the reader's staging).
     static const int sub_env = [] { const char *e = getenv("MLVFS_AMD_LJ92_SUB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();   // experiments
     const int SUB = sub_env ? sub_env : (nframes >= 8 ? 4 : (nframes + 1) / 2);
+    // The uploads of all sub-batches go out on one stream of their own, in order: two streams' copies ran on two copy engines at 27 GB/s
+    // together where one stream's run at 53 (tools/h2d_chunks.py, profiles/r05/h2d_chunks.log).  MLVFS_AMD_LJ92_UPSTREAM=0: as before.
+    static const bool one_up = [] { const char *e = getenv("MLVFS_AMD_LJ92_UPSTREAM"); return !e || atoi(e) != 0; }();
+    if (one_up) MLV_HIP(hipStreamWaitEvent(w.up, w.ready, 0));
     for (int j0 = 0, j = 0; j0 < nframes; j0 += SUB, j++) {
         const int n = std::min(SUB, nframes - j0);
         hipStream_t sj = w.sub[j & 1];
+        hipStream_t su = one_up ? w.up : sj;
         if (j < 2) MLV_HIP(hipStreamWaitEvent(sj, w.ready, 0));
         // (MLVFS_AMD_LJ92_NOUPLOAD=1, measurement only: a call with the same frames as the call before it finds their bytes where that
         // call put them -- what the kernels do when no link stands before them; tools/lj92_bench.py)
         static const bool no_upload = [] { const char *e = getenv("MLVFS_AMD_LJ92_NOUPLOAD"); return e && atoi(e) != 0; }();
         if (!(no_upload && w.same_as_before))
         for (int i = j0; i < j0 + n; i++)
-            MLV_HIP(hipMemcpyAsync(w.d_arena + off[i].raw, (const uint8_t *)streams[i] + hdr[i].scan, off[i].raw_len, hipMemcpyHostToDevice, sj));
+            MLV_HIP(hipMemcpyAsync(w.d_arena + off[i].raw, (const uint8_t *)streams[i] + hdr[i].scan, off[i].raw_len, hipMemcpyHostToDevice, su));
+        if (one_up) {
+            while ((int)w.uploaded.size() <= j) { hipEvent_t e; MLV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); w.uploaded.push_back(e); }
+            MLV_HIP(hipEventRecord(w.uploaded[j], w.up));
+            MLV_HIP(hipStreamWaitEvent(sj, w.uploaded[j], 0));
+        }
         unsigned preds = 0;
         for (int i = j0; i < j0 + n; i++) preds |= 1u << hdr[i].pred;
         rc = lj92_launch((const LjFrame *)(w.d_arena + frames_at) + j0, n, max_raw, max_nwg, max_ngrp, max_w, max_h, preds, sj);
