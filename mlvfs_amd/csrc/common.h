@@ -151,6 +151,7 @@ void preload_k_unpack();
 void preload_k_pixfix();
 void preload_k_stripes();
 void preload_k_frame();
+void preload_k_frame_p();
 int luts_ok();
 
 struct Geom {

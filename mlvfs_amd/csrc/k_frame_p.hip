@@ -686,4 +686,8 @@ void launch_frame_p_kernel(int method, bool packed, int vec, bool spread, int gr
 #endif
 }
 
+// the code object of this file loaded when the device context is created, like the other files of the frame path (runtime.cpp:
+// get_device): without it the first clip of a process paid 1.7 ms for it at its first fused launch
+void preload_k_frame_p() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)k_frame_p<5, true, 1, false>); (void)hipGetLastError(); }
+
 }  // namespace mlv
