@@ -280,7 +280,13 @@ extern "C" int mlvfs_amd_lj92_decode_dev(const void *const *streams, const size_
         if (j < 2) MLV_HIP(hipStreamWaitEvent(sj, w.ready, 0));
         // (MLVFS_AMD_LJ92_NOUPLOAD=1, measurement only: a call with the same frames as the call before it finds their bytes where that
         // call put them -- what the kernels do when no link stands before them; tools/lj92_bench.py)
-        static const bool no_upload = [] { const char *e = getenv("MLVFS_AMD_LJ92_NOUPLOAD"); return e && atoi(e) != 0; }();
+        static const bool no_upload = [] {
+            const char *e = getenv("MLVFS_AMD_LJ92_NOUPLOAD");
+            const bool on = e && atoi(e) != 0;
+            if (on) fprintf(stderr, "mlvfs_amd: MLVFS_AMD_LJ92_NOUPLOAD=1 -- a call with the same stream pointers and sizes as the call before it skips "
+                                    "their upload (measurement only: stale results if the bytes behind the pointers changed)\n");
+            return on;
+        }();
         if (!(no_upload && w.same_as_before))
         for (int i = j0; i < j0 + n; i++)
             MLV_HIP(hipMemcpyAsync(w.d_arena + off[i].raw, (const uint8_t *)streams[i] + hdr[i].scan, off[i].raw_len, hipMemcpyHostToDevice, su));
