@@ -182,9 +182,10 @@ def _kernel_timed(L, lib, fn, launches=1):
     return float(ms[:n].mean()) if n else float("nan")
 
 
-def extra_cs2x2(golden, fnv1a, F=50):
+def extra_cs2x2(golden, fnv1a, F=400):
     """configs[1]: 3584x1320 unpack + cs2x2 (no pixel map, no stripes), resident stream; output checked against the
-    reference's hashes for frames 0 and 1."""
+    reference's hashes for frames 0 and 1.  F frames per launch: the headline's 400 since round 5 (rounds 1-4: 50 -- a launch of
+    0.27 ms loses a tenth to its tail and the gaps around it; the same kernel at 50 / 400 frames per launch: 5.4 / 4.8 us per frame)."""
     import torch
     from mlvfs_amd import lib, synth
     from mlvfs_amd.stream import ClipStream, to_numpy_u16
@@ -207,6 +208,7 @@ def extra_cs2x2(golden, fnv1a, F=50):
     s.close()
     kms = float(np.median(ms))
     return {"workload": "configs[1]: 3584x1320 14-bit unpack + cs2x2, stream resident in HBM", "frames_per_launch": F,
+            "kernel": "k_frame_s (cs2x2 without a pixel map: one wave per column of the frame, no barriers; MLVFS_AMD_KF_S=0: k_frame<2>)",
             "fps": round(F / wall, 1), "Mpix/s": round(F * W * H / wall / 1e6, 1), "kernel_us_per_frame": round(kms * 1e3 / F, 2),
             "hbm_frac": round(F * W * H * BYTES_PER_PX / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "parity": {"hashes": got, "reference": want, "ok": got == want}}

@@ -152,6 +152,7 @@ void preload_k_pixfix();
 void preload_k_stripes();
 void preload_k_frame();
 void preload_k_frame_p();
+void preload_k_frame_s();
 int luts_ok();
 
 struct Geom {

@@ -710,6 +710,9 @@ static int e2r_table(const Device *dev, int black, const uint2 **out, hipStream_
 // k_frame's alone.  MLVFS_AMD_KF_P=0 sends every launch to k_frame as rounds 1-4 did (A/B).
 bool frame_p_exists(int method, int vec);
 void launch_frame_p_kernel(int method, bool packed, int vec, bool spread, int grid, hipStream_t stream, const FrameArgs &a);
+// k_frame_s.hip: cs2x2 as a streaming kernel without barriers (what it takes: frame_s_takes)
+bool frame_s_takes(int method, bool packed, int vec, const FrameArgs &a);
+void launch_frame_s_kernel(bool spread, int num_cu, hipStream_t stream, const FrameArgs &a);
 
 template <int METHOD, bool PACKED, int VEC, bool SPREAD>
 static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
@@ -719,6 +722,21 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
     int grid = (num_cu > 0 ? num_cu : 256) * (env_wgs > 0 ? env_wgs : 4);          // 4 workgroups per CU (39 KiB LDS, <= 128 VGPRs)
     grid = (grid + 7) / 8 * 8;
     if (grid > total) grid = (int)((total + 7) / 8 * 8);
+    if (frame_s_takes(METHOD, PACKED, VEC, a_in)) {
+        FrameArgs as = a_in;
+        StreamState sst;
+        bool both = false;
+        const int rcs = stream_state(stream, 0, 0, &sst, &both);
+        if (rcs) return rcs;
+        as.tickets = sst.tickets;
+        KernelTimer &tms = kernel_timer();
+        const bool timed_s = tms.on && tms.used + 2 <= (int)tms.ev.size();
+        if (timed_s) MLV_HIP(hipEventRecord(tms.ev[tms.used], stream));
+        launch_frame_s_kernel(SPREAD, num_cu, stream, as);
+        if (timed_s) { MLV_HIP(hipEventRecord(tms.ev[tms.used + 1], stream)); tms.used += 2; }
+        MLV_HIP(hipGetLastError());
+        return MLVFS_AMD_OK;
+    }
     auto kern = k_frame<METHOD, PACKED, VEC, SPREAD>;
     // MLVFS_AMD_KF_P: 0 = k_frame alone (rounds 1-4), 1 = both kernels, k_frame alone while the footage is busy (default), 2 = always both
     static const int env_p = [] { const char *e = getenv("MLVFS_AMD_KF_P"); return e ? atoi(e) : 1; }();

@@ -1189,17 +1189,26 @@ __device__ __forceinline__ unsigned long long lanes_lt(int a, int b) { return __
 // The variants are separate instantiations chosen by scalar branches: written as conditions inside one body the compiler computed
 // both sides for every strip and selected (profiles/r05: 207 instead of 178 vector instructions per strip).
 //   ANYSTRIPES: the stripes epilogue in all its forms (else: the packed 16-bit one or none -- what a launch has is a scalar of the launch).
-template <int METHOD, bool PACKED, bool VECST, bool CLAMP, bool XM, bool ANYSTRIPES, bool BRIGHT, class SM>
+//   RAWREG (k_frame_s): the strip's pixels come in registers (rtop / rbot) instead of from the tile's LDS rows, and go back there
+//   (store = false: the caller stores them).
+struct NoSmem {};
+template <int METHOD, bool PACKED, bool VECST, bool CLAMP, bool XM, bool ANYSTRIPES, bool BRIGHT, class SM, bool RAWREG = false>
 __device__ __forceinline__ void strip_output_t(const SM &sm, const OutArgs &oa, int w, int h, int black, int f, int tx0, int ty0, int jj, int kk,
-                                               unsigned long long msmooth, const int (&gev)[STRIP], int gev_off, const int (&er)[STRIP], const int (&eb)[STRIP], bool store)
+                                               unsigned long long msmooth, const int (&gev)[STRIP], int gev_off, const int (&er)[STRIP], const int (&eb)[STRIP], bool store,
+                                               uint32_t *rtop = nullptr, uint32_t *rbot = nullptr)
 {
     const int y = ty0 + 2 * jj, x = tx0 + 2 * STRIP * kk;
     uint32_t top[STRIP], bot[STRIP];        // (R | G1<<16), (G2 | B<<16)
     auto read_raw = [&]() {
-        const uint4 v0 = *(const uint4 *)&sm.raw[2 * jj][2 * STRIP * kk];
-        const uint4 v1 = *(const uint4 *)&sm.raw[2 * jj + 1][2 * STRIP * kk];
-        top[0] = v0.x; top[1] = v0.y; top[2] = v0.z; top[3] = v0.w;
-        bot[0] = v1.x; bot[1] = v1.y; bot[2] = v1.z; bot[3] = v1.w;
+        if constexpr (RAWREG) {
+#pragma unroll
+            for (int c = 0; c < STRIP; c++) { top[c] = rtop[c]; bot[c] = rbot[c]; }
+        } else {
+            const uint4 v0 = *(const uint4 *)&sm.raw[2 * jj][2 * STRIP * kk];
+            const uint4 v1 = *(const uint4 *)&sm.raw[2 * jj + 1][2 * STRIP * kk];
+            top[0] = v0.x; top[1] = v0.y; top[2] = v0.z; top[3] = v0.w;
+            bot[0] = v1.x; bot[1] = v1.y; bot[2] = v1.z; bot[3] = v1.w;
+        }
     };
     if (METHOD == 0) read_raw();
     if (METHOD != 0) {
@@ -1243,6 +1252,10 @@ __device__ __forceinline__ void strip_output_t(const SM &sm, const OutArgs &oa, 
         else if (PACKED && oa.coef_pk) stripe_strip_pk<true>(top, bot, oa.co, black16, white16);
         else if (oa.coef_fast) stripe_strip<true>(top, bot, oa.co, black16, white16);
         else stripe_strip<false>(top, bot, oa.co, black16, white16);
+    }
+    if constexpr (RAWREG) {
+#pragma unroll
+        for (int c = 0; c < STRIP; c++) { rtop[c] = top[c]; rbot[c] = bot[c]; }
     }
     if (store && y < h) {
         if (VECST) {

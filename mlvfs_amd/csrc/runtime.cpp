@@ -248,7 +248,7 @@ static Device *get_device(int id)
     // path, 2 ms for k_frame's 68 instantiations -- paid here, once per device, instead of inside the first frame of the first
     // clip (bench.py first_frame_split_ms; MLVFS_AMD_PRELOAD=0 leaves them lazy).  The dual-ISO, LJ92 and preview files stay lazy.
     static const bool preload = [] { const char *e = getenv("MLVFS_AMD_PRELOAD"); return !(e && e[0] == '0'); }();
-    if (preload) { preload_k_unpack(); preload_k_pixfix(); preload_k_frame(); preload_k_frame_p(); preload_k_stripes(); }
+    if (preload) { preload_k_unpack(); preload_k_pixfix(); preload_k_frame(); preload_k_frame_p(); preload_k_frame_s(); preload_k_stripes(); }
     g_devices[id] = d;
     return d;
 }
