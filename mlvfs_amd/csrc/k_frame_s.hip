@@ -12,6 +12,10 @@
 //   * a step unpacks and converts row r, then finishes row r - 1: medians, look-ups, R / B replacement, stripes, two 16-byte stores;
 //   * no s_barrier after the table is in LDS, 16 KiB of LDS per workgroup (the raw2ev table), five workgroups per CU.
 // Same arithmetic as k_frame: the loader's cell functions, mlv_median5, strip_output_t (k_frame_dev.h) -- results identical.
+// Measured and not kept (profiles/r05/ab_kframe_s.log): compiled for five workgroups per CU (<= 96 VGPRs: 14-43 spilled, 6.7-10.5 us per
+// frame against 4.75); a third row of prefetch with the previous row's pixels parked in LDS (+-0); a form that finishes row r - 2 while
+// row r's table look-ups are under way, so that neither wait is exposed (186 VGPRs: the in-flight conversion, three rows of colour
+// differences, the medians' operands and two sets of look-ups do not fit four waves per SIMD).
 // What it takes: 14-bit streams whose rows are whole 16-pixel groups, even heights, no pixel map, stripes in the packed 16-bit form
 // (or none), black >= 0.  Everything else stays with k_frame (k_frame.hip: launch_frame_t).
 #include "k_frame_dev.h"
