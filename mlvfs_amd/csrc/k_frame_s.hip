@@ -16,7 +16,7 @@
 // frame against 4.75); a third row of prefetch with the previous row's pixels parked in LDS (+-0); a form that finishes row r - 2 while
 // row r's table look-ups are under way, so that neither wait is exposed (186 VGPRs: the in-flight conversion, three rows of colour
 // differences, the medians' operands and two sets of look-ups do not fit four waves per SIMD).
-// What it takes: 14-bit streams whose rows are whole 16-pixel groups, even heights, no pixel map, stripes in the packed 16-bit form
+// What it takes: 14-bit streams whose rows are whole 8-pixel groups (on the buffers the vector path wants), even heights, no pixel map, stripes in the packed 16-bit form
 // (or none), black >= 0.  Everything else stays with k_frame (k_frame.hip: launch_frame_t).
 #include "k_frame_dev.h"
 
@@ -41,7 +41,9 @@ constexpr int S_OUT = 62;             // output items per wave and row (lanes 1.
 
 __device__ __forceinline__ int dpp_prev_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, true); }        // wave_shr:1: lane l gets lane l - 1's
 
-template <bool SPREAD>
+// VEC = 1: rows of whole 16-pixel groups (every row starts dword-aligned); VEC = 2: w % 16 == 8 (odd pixel rows start two bytes into a
+// dword: their groups' alignment is the other way round -- the selectors flip, as in k_frame's loader)
+template <bool SPREAD, int VEC>
 __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, int cols, int segs, int seg_rows)
 {
     constexpr int BPP = 14;
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
     const int w = a.w, h = a.h, black = a.black;
     const int rows = h >> 1, gmax = (w >> 3) - 1;
     const int per_frame = cols * segs, ntasks = a.nframes * per_frame;
-    const uint32_t pitch = (uint32_t)(w >> 3) * 14u;     // bytes per pixel row (a multiple of 28: rows start dword-aligned)
+    const uint32_t pitch = (uint32_t)(w >> 3) * 14u;     // bytes per pixel row (VEC 1: a multiple of 28, rows start dword-aligned)
     const OutArgs oa = out_args(cold_args());
     int *tickets = a.tickets;
     for (;;) {
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
         const uint32_t gbyte = (uint32_t)g * 14u;
         const bool mis = (g & 1) != 0;                   // the group starts in the upper half of a dword
         const uint32_t sel = mis ? SEL_MIS : SEL_SWAP;
+        const uint32_t sel1 = VEC == 2 ? sel ^ (SEL_SWAP ^ SEL_MIS) : sel;      // the odd pixel row of the pair
         const mlv_i32x4 rs_in = frame_rsrc(a.src + (size_t)f * a.src_stride, a.src_bytes);
         const mlv_i32x4 rs_out = frame_rsrc(oa.dst + (size_t)f * oa.dst_stride, (uint32_t)w * (uint32_t)h * 2u);
         const int tx0 = 8 * (c * S_OUT - 1);             // x of lane 0's item
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
         auto step = [&](int r, uint32_t (&d0)[4], uint32_t (&d1)[4]) {
             uint32_t p0[8], p1[8];
             unpack8<BPP>(d0, sel, sel, sel, p0);
-            unpack8<BPP>(d1, sel, sel, sel, p1);
+            unpack8<BPP>(d1, sel1, sel1, sel1, p1);
             if (r + KF_S_DEPTH <= j1) issue(r + KF_S_DEPTH, d0, d1);       // the row this set is needed for next goes out while this one is converted
             uint32_t lo = min(p0[0], p1[0]);
 #pragma unroll
@@ -213,12 +216,12 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
 bool frame_s_takes(int method, bool packed, int vec, const FrameArgs &a)
 {
     static const bool off = [] { const char *e = getenv("MLVFS_AMD_KF_S"); return e && atoi(e) == 0; }();
-    if (off || method != 2 || !packed || vec != 1) return false;
+    if (off || method != 2 || !packed || (vec != 1 && vec != 2)) return false;
     if (a.patch || (a.stripes && !a.coef_pk) || a.black < 0) return false;
-    return a.w >= 16 && a.w % 16 == 0 && a.h >= 2 && a.h % 2 == 0;
+    return a.w >= 16 && a.w % 8 == 0 && a.h >= 2 && a.h % 2 == 0;
 }
 
-void launch_frame_s_kernel(bool spread, int num_cu, hipStream_t stream, const FrameArgs &a)
+void launch_frame_s_kernel(bool spread, int vec, int num_cu, hipStream_t stream, const FrameArgs &a)
 {
     const int cols = (a.w + 8 * S_OUT - 1) / (8 * S_OUT), rows = a.h / 2;
     static const int env_seg = [] { const char *e = getenv("MLVFS_AMD_KF_S_SEG"); return e ? atoi(e) : 0; }();
@@ -226,10 +229,15 @@ void launch_frame_s_kernel(bool spread, int num_cu, hipStream_t stream, const Fr
     const long long tasks = (long long)a.nframes * cols * segs;
     int grid = (num_cu > 0 ? num_cu : 256) * KF_S_WGS;   // five workgroups per CU: 20 waves, 80 KiB of LDS (five copies of the table)
     if ((long long)grid * 4 > tasks) grid = (int)((tasks + 3) / 4);
-    if (spread) hipLaunchKernelGGL((k_frame_s<true>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows);
-    else hipLaunchKernelGGL((k_frame_s<false>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows);
+    if (vec == 2) {
+        if (spread) hipLaunchKernelGGL((k_frame_s<true, 2>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows);
+        else hipLaunchKernelGGL((k_frame_s<false, 2>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows);
+    } else {
+        if (spread) hipLaunchKernelGGL((k_frame_s<true, 1>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows);
+        else hipLaunchKernelGGL((k_frame_s<false, 1>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows);
+    }
 }
 
-void preload_k_frame_s() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)k_frame_s<false>); (void)hipGetLastError(); }
+void preload_k_frame_s() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)k_frame_s<false, 1>); (void)hipGetLastError(); }
 
 }  // namespace mlv
