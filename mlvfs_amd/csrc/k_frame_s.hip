@@ -10,14 +10,16 @@
 //   * the colour differences of the row above and the row being loaded stay in registers (the stencil's vertical taps), the
 //     horizontal taps of a lane's outer cells come from the neighbouring lanes (v_mov_b32_dpp wave_shr / wave_shl);
 //   * a step unpacks and converts row r, then finishes row r - 1: medians, look-ups, R / B replacement, stripes, two 16-byte stores;
-//   * no s_barrier after the table is in LDS, 16 KiB of LDS per workgroup (the raw2ev table), five workgroups per CU.
+//     the words of rows r + 1 and r + 2 are under way meanwhile (one row ahead: 6.7 us per frame, two: 4.75);
+//   * no s_barrier after the table is in LDS, 16 KiB of LDS per workgroup (the raw2ev table), 126 VGPRs: four workgroups per CU;
+//   * waves draw their tasks (frame, column, 60 rows) from one counter; the last wave out zeroes it for the next launch.
 // Same arithmetic as k_frame: the loader's cell functions, mlv_median5, strip_output_t (k_frame_dev.h) -- results identical.
 // Measured and not kept (profiles/r05/ab_kframe_s.log): compiled for five workgroups per CU (<= 96 VGPRs: 14-43 spilled, 6.7-10.5 us per
 // frame against 4.75); a third row of prefetch with the previous row's pixels parked in LDS (+-0); a form that finishes row r - 2 while
 // row r's table look-ups are under way, so that neither wait is exposed (186 VGPRs: the in-flight conversion, three rows of colour
 // differences, the medians' operands and two sets of look-ups do not fit four waves per SIMD).
-// What it takes: 14-bit streams whose rows are whole 8-pixel groups (on the buffers the vector path wants), even heights, no pixel map, stripes in the packed 16-bit form
-// (or none), black >= 0.  Everything else stays with k_frame (k_frame.hip: launch_frame_t).
+// What it takes: 14-bit streams whose rows are whole 8-pixel groups (on the buffers the vector path wants), even heights, no pixel
+// map, stripes in the packed 16-bit form (or none), black >= 0.  Everything else stays with k_frame (k_frame.hip: launch_frame_t).
 #include "k_frame_dev.h"
 
 namespace mlv {
@@ -48,9 +50,8 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
 {
     constexpr int BPP = 14;
     __shared__ __align__(16) uint16_t t16[MLV_T16_N + (SPREAD ? 64 : 0)];
-    // a row's pixels wait one step for their medians: parked in LDS (the wave's own 4 KiB: no barrier involved), two
-    // slots by row parity, so that the registers they would hold carry a third row of prefetch instead
-#if KF_S_PARK
+#if KF_S_PARK                                            // (experiment: a row's pixels wait one step for their medians in LDS -- the wave's own
+                                                         // 4 KiB, two slots by row parity, no barrier involved -- instead of in registers)
     __shared__ uint4 park[4][2][2][64];
 #endif
     load_t16_rel<SPREAD>(t16, a.t16, (int)threadIdx.x);
