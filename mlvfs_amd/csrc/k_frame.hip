@@ -538,10 +538,19 @@ struct StreamState {
     int stat_seen = 0;           // h_stat when it was last looked at
     long long pending_tiles = 0; // tiles of the two-kernel launches whose list counts have not been seen yet
     int wide_left = 0, hold = 0; // launches still to go to k_frame alone; how many after the next busy probe
+    // the same for the streaming cs2x2 kernel (k_frame_s.hip): its steps that took the loader's form for pixels at or below black,
+    // out of all steps (word 1 of h_stat; the cumulative count lives in tickets[S_STAT_AT])
+    int s_seen = 0;
+    long long s_pending = 0;
+    int s_wide_left = 0, s_hold = 0;
 };
 std::mutex g_ticket_mu;
 std::map<std::pair<int, hipStream_t>, StreamState> g_tickets;
-constexpr int TICKET_INTS = 2 * MAX_GROUPS + 1 + 4;
+constexpr int TICKET_INTS = 2 * MAX_GROUPS + 1 + 4 + 2;
+constexpr int S_STAT_AT = 2 * MAX_GROUPS + 1 + 4;      // k_frame_s: cumulative dark steps
+#ifndef KF_S_BUSY_PERCENT
+#define KF_S_BUSY_PERCENT 10
+#endif
 }
 // wl_tiles > 0: the launch may use both kernels and then needs a work list that holds that many entries; *two says whether it does
 static int stream_state(hipStream_t stream, long long wl_tiles, int policy, StreamState *out, bool *two)
@@ -566,7 +575,7 @@ static int stream_state(hipStream_t stream, long long wl_tiles, int policy, Stre
     if (wl_tiles > 0 && policy != 0) {
         if (!st.h_stat) {                                 // (without the word every launch uses both kernels)
             if (hipHostMalloc((void **)&st.h_stat, 64, hipHostMallocMapped) == hipSuccess) {
-                st.h_stat[0] = 0;
+                st.h_stat[0] = 0; st.h_stat[1] = 0;
                 if (hipHostGetDevicePointer((void **)&st.d_stat, st.h_stat, 0) != hipSuccess) { (void)hipHostFree(st.h_stat); st.h_stat = nullptr; st.d_stat = nullptr; }
             } else st.h_stat = nullptr;
             (void)hipGetLastError();
@@ -601,6 +610,48 @@ static int stream_state(hipStream_t stream, long long wl_tiles, int policy, Stre
             *two = true;
         }
     }
+    *out = st;
+    return MLVFS_AMD_OK;
+}
+// k_frame_s's launches: `steps` wave-steps are about to be launched; *use_s says whether the streaming kernel takes them.  Footage
+// with pixels at or below black in most rows (deep shadows, colour patches) runs the loader's slower form in whole waves there, and
+// k_frame -- which decides per item group and hides it behind its other workgroups -- is faster (cs2x2, 3584x1320: low light 5.4
+// against 6.7 us per frame, colour patches 6.0 against 8.4; the benchmark's frames 4.8 against 4.7): such streams go back to
+// k_frame for a while, like the packed-once kernel's (stream_state).
+static int stream_state_s(hipStream_t stream, long long steps, StreamState *out, bool *use_s)
+{
+    bool two = false;
+    int rc = stream_state(stream, 0, 0, out, &two);
+    if (rc) return rc;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_ticket_mu);
+    StreamState &st = g_tickets[{ dev, stream }];
+    *use_s = true;
+    const char *e = getenv("MLVFS_AMD_KF_S");
+    const int policy = e ? atoi(e) : 1;                      // 2: always (frame_s_takes)
+    if (policy == 1) {
+        if (!st.h_stat) {
+            if (hipHostMalloc((void **)&st.h_stat, 64, hipHostMallocMapped) == hipSuccess) {
+                st.h_stat[0] = 0; st.h_stat[1] = 0;
+                if (hipHostGetDevicePointer((void **)&st.d_stat, st.h_stat, 0) != hipSuccess) { (void)hipHostFree(st.h_stat); st.h_stat = nullptr; st.d_stat = nullptr; }
+            } else st.h_stat = nullptr;
+            (void)hipGetLastError();
+        }
+        if (st.h_stat) {
+            const int seen = __atomic_load_n(&st.h_stat[1], __ATOMIC_RELAXED);
+            if (seen != st.s_seen) {
+                const long long dark = (long long)(unsigned)(seen - st.s_seen);
+                const bool busy = dark * 100 > st.s_pending * KF_S_BUSY_PERCENT;
+                if (busy) { st.s_hold = st.s_hold ? std::min(2 * st.s_hold, KF_P_HOLD_MAX) : KF_P_HOLD_MIN; st.s_wide_left = st.s_hold; }
+                else st.s_hold = 0;
+                st.s_seen = seen;
+                st.s_pending = 0;
+            }
+            if (st.s_wide_left > 0) { st.s_wide_left--; *use_s = false; }
+        }
+    }
+    if (*use_s) st.s_pending += steps;
     *out = st;
     return MLVFS_AMD_OK;
 }
@@ -711,8 +762,9 @@ static int e2r_table(const Device *dev, int black, const uint2 **out, hipStream_
 bool frame_p_exists(int method, int vec);
 void launch_frame_p_kernel(int method, bool packed, int vec, bool spread, int grid, hipStream_t stream, const FrameArgs &a);
 // k_frame_s.hip: cs2x2 as a streaming kernel without barriers (what it takes: frame_s_takes)
-bool frame_s_takes(int method, bool packed, int vec, const FrameArgs &a);
+bool frame_s_takes(int method, bool packed, int vec, int num_cu, const FrameArgs &a);
 void launch_frame_s_kernel(bool spread, int vec, int num_cu, hipStream_t stream, const FrameArgs &a);
+long long frame_s_steps(const FrameArgs &a);
 
 template <int METHOD, bool PACKED, int VEC, bool SPREAD>
 static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
@@ -722,13 +774,16 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
     int grid = (num_cu > 0 ? num_cu : 256) * (env_wgs > 0 ? env_wgs : 4);          // 4 workgroups per CU (39 KiB LDS, <= 128 VGPRs)
     grid = (grid + 7) / 8 * 8;
     if (grid > total) grid = (int)((total + 7) / 8 * 8);
-    if (frame_s_takes(METHOD, PACKED, VEC, a_in)) {
+    if (frame_s_takes(METHOD, PACKED, VEC, num_cu, a_in)) {
         FrameArgs as = a_in;
         StreamState sst;
-        bool both = false;
-        const int rcs = stream_state(stream, 0, 0, &sst, &both);
+        bool use_s = true;
+        const int rcs = stream_state_s(stream, frame_s_steps(a_in), &sst, &use_s);
         if (rcs) return rcs;
+        if (use_s) {
         as.tickets = sst.tickets;
+        as.wl_ctl = sst.tickets + S_STAT_AT;                  // (k_frame_s: [0] its cumulative count of dark steps)
+        as.wl_stat = sst.d_stat ? sst.d_stat + 1 : nullptr;
         KernelTimer &tms = kernel_timer();
         const bool timed_s = tms.on && tms.used + 2 <= (int)tms.ev.size();
         if (timed_s) MLV_HIP(hipEventRecord(tms.ev[tms.used], stream));
@@ -736,6 +791,7 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
         if (timed_s) { MLV_HIP(hipEventRecord(tms.ev[tms.used + 1], stream)); tms.used += 2; }
         MLV_HIP(hipGetLastError());
         return MLVFS_AMD_OK;
+        }
     }
     auto kern = k_frame<METHOD, PACKED, VEC, SPREAD>;
     // MLVFS_AMD_KF_P: 0 = k_frame alone (rounds 1-4), 1 = both kernels, k_frame alone while the footage is busy (default), 2 = always both

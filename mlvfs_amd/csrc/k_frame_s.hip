@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
         uint32_t top1[STRIP] = { 0, 0, 0, 0 }, bot1[STRIP] = { 0, 0, 0, 0 };
 #endif
         int flags1 = 3, flags2 = 3;                      // bit 0: a pixel at most 64 above black, bit 1: less than 256 above (rows r - 1, r - 2)
+        int dark_steps = 0;
         issue(j0 - 1, dA0, dA1);
         issue(j0, dB0, dB1);
         if (KF_S_DEPTH == 3) issue(j0 + 1, dC0, dC1);
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
 #pragma unroll
             for (int i = 1; i < 8; i++) lo = min(min(lo, p0[i]), p1[i]);
             const bool dark = __any((int)lo <= black);
+            dark_steps += dark ? 1 : 0;
             int flags0 = 0;
             if (__any((int)lo <= black + 255)) flags0 = __any((int)lo <= black + 64) ? 3 : 2;
             int ge[STRIP], dr[STRIP], db[STRIP];
@@ -205,21 +207,41 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
             if (r + 1 <= j1) step(r + 1, dB0, dB1);
             if (KF_S_DEPTH == 3 && r + 2 <= j1) step(r + 2, dC0, dC1);
         }
+        if (lane == 0 && dark_steps) atomicAdd(&a.wl_ctl[0], dark_steps);       // (what the host's choice of kernel for this stream looks at)
     }
     // the last wave out leaves the two counters as it found them (the next launch on this stream starts from zero)
     if (lane == 0) {
         const int nwaves = (int)gridDim.x * 4;
-        if (atomicAdd(&tickets[1], 1) == nwaves - 1) { tickets[0] = 0; tickets[1] = 0; }
+        if (atomicAdd(&tickets[1], 1) == nwaves - 1) {
+            tickets[0] = 0; tickets[1] = 0;
+            if (a.wl_stat) { __atomic_store_n(a.wl_stat, a.wl_ctl[0], __ATOMIC_RELAXED); __threadfence_system(); }
+        }
     }
 }
 
 // does the streaming kernel take this launch?  (k_frame.hip: launch_frame_t asks before it sets up its own)
-bool frame_s_takes(int method, bool packed, int vec, const FrameArgs &a)
+bool frame_s_takes(int method, bool packed, int vec, int num_cu, const FrameArgs &a)
 {
-    static const bool off = [] { const char *e = getenv("MLVFS_AMD_KF_S"); return e && atoi(e) == 0; }();
-    if (off || method != 2 || !packed || (vec != 1 && vec != 2)) return false;
+    // MLVFS_AMD_KF_S: 0 never, 1 (default) long launches of footage without many pixels at or below black, 2 whenever the kernel can
+    // (read at every launch: the tests switch it)
+    const char *e = getenv("MLVFS_AMD_KF_S");
+    const int policy = e ? atoi(e) : 1;
+    if (policy == 0 || method != 2 || !packed || (vec != 1 && vec != 2)) return false;
     if (a.patch || (a.stripes && !a.coef_pk) || a.black < 0) return false;
-    return a.w >= 16 && a.w % 8 == 0 && a.h >= 2 && a.h % 2 == 0;
+    if (!(a.w >= 16 && a.w % 8 == 0 && a.h >= 2 && a.h % 2 == 0)) return false;
+    // Long launches only: a task is a column of 60 rows (~50 us of one wave), and a wave needs a handful of them for the chip to end
+    // together -- 3584x1320, us per frame at 8 / 25 / 50 / 100 / 200 / 400 frames per launch: k_frame 10.7 / 5.7 / 5.7 / 5.5 / 5.3 / 4.9,
+    // this kernel 13.1 / 7.3 / 7.1 / 5.5 / 5.0 / 4.8 (shorter tasks do not help: two rows of warm-up each; profiles/r05/ab_kframe_s.log)
+    const long long cols = (a.w + 8 * S_OUT - 1) / (8 * S_OUT), segs = (a.h / 2 + KF_S_SEG - 1) / KF_S_SEG;
+    const long long waves = (long long)(num_cu > 0 ? num_cu : 256) * KF_S_WGS * 4;
+    return policy == 2 || (long long)a.nframes * cols * segs * 2 >= waves * 7;             // >= 3.5 tasks per wave
+}
+
+// wave-steps of a launch (what the dark steps it reports are a share of)
+long long frame_s_steps(const FrameArgs &a)
+{
+    const long long cols = (a.w + 8 * S_OUT - 1) / (8 * S_OUT);
+    return (long long)a.nframes * cols * (a.h / 2);
 }
 
 void launch_frame_s_kernel(bool spread, int vec, int num_cu, hipStream_t stream, const FrameArgs &a)
