@@ -224,9 +224,10 @@ bool frame_s_takes(int method, bool packed, int vec, int num_cu, const FrameArgs
 {
     // MLVFS_AMD_KF_S: 0 never, 1 (default) long launches of footage without many pixels at or below black, 2 whenever the kernel can
     // (read at every launch: the tests switch it)
+    if (method != 2 || !packed || (vec != 1 && vec != 2)) return false;
     const char *e = getenv("MLVFS_AMD_KF_S");
     const int policy = e ? atoi(e) : 1;
-    if (policy == 0 || method != 2 || !packed || (vec != 1 && vec != 2)) return false;
+    if (policy == 0) return false;
     if (a.patch || (a.stripes && !a.coef_pk) || a.black < 0) return false;
     if (!(a.w >= 16 && a.w % 8 == 0 && a.h >= 2 && a.h % 2 == 0)) return false;
     // Long launches only: a task is a column of 60 rows (~50 us of one wave), and a wave needs a handful of them for the chip to end
