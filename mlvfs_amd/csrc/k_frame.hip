@@ -763,7 +763,7 @@ bool frame_p_exists(int method, int vec);
 void launch_frame_p_kernel(int method, bool packed, int vec, bool spread, int grid, hipStream_t stream, const FrameArgs &a);
 // k_frame_s.hip: cs2x2 as a streaming kernel without barriers (what it takes: frame_s_takes)
 bool frame_s_takes(int method, bool packed, int vec, int num_cu, const FrameArgs &a);
-void launch_frame_s_kernel(bool spread, int vec, int num_cu, hipStream_t stream, const FrameArgs &a);
+void launch_frame_s_kernel(int method, bool spread, int vec, int num_cu, hipStream_t stream, const FrameArgs &a);
 long long frame_s_steps(const FrameArgs &a);
 
 template <int METHOD, bool PACKED, int VEC, bool SPREAD>
@@ -787,7 +787,7 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
         KernelTimer &tms = kernel_timer();
         const bool timed_s = tms.on && tms.used + 2 <= (int)tms.ev.size();
         if (timed_s) MLV_HIP(hipEventRecord(tms.ev[tms.used], stream));
-        launch_frame_s_kernel(SPREAD, VEC, num_cu, stream, as);
+        launch_frame_s_kernel(METHOD, SPREAD, VEC, num_cu, stream, as);
         if (timed_s) { MLV_HIP(hipEventRecord(tms.ev[tms.used + 1], stream)); tms.used += 2; }
         MLV_HIP(hipGetLastError());
         return MLVFS_AMD_OK;

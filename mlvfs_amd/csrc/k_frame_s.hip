@@ -1,5 +1,5 @@
-// k_frame_s.hip -- the fused pass for cs2x2 (chroma_smooth.c:22-71 with CHROMA_SMOOTH_2X2: the plus-shaped five) as a STREAMING
-// kernel without barriers and without planes in LDS (round 5, end).
+// k_frame_s.hip -- the fused pass for cs2x2 and cs3x3 (chroma_smooth.c:22-71 with CHROMA_SMOOTH_2X2 / _3X3: the plus-shaped five, the
+// nine) as a STREAMING kernel without barriers and without planes in LDS (round 5, end).
 //
 // k_frame's cs2x2 instantiation executes 5 % fewer instructions than it did and takes the same time: its time is the
 // dependent chain of a tile -- prefetched words -> unpack -> table gathers -> barrier -> medians -> look-ups -> stores -> barrier --
@@ -45,7 +45,9 @@ __device__ __forceinline__ int dpp_prev_i(int v) { return __builtin_amdgcn_mov_d
 
 // VEC = 1: rows of whole 16-pixel groups (every row starts dword-aligned); VEC = 2: w % 16 == 8 (odd pixel rows start two bytes into a
 // dword: their groups' alignment is the other way round -- the selectors flip, as in k_frame's loader)
-template <bool SPREAD, int VEC>
+// METHOD = 2: the plus-shaped five; METHOD = 3: the 3x3 nine (chroma_smooth.c with CHROMA_SMOOTH_3X3) -- the same rows in registers,
+// sorted columns of three (k_frame_dev.h: strip_median9's scheme), the neighbouring lanes' edge columns by DPP
+template <bool SPREAD, int VEC, int METHOD>
 __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, int cols, int segs, int seg_rows)
 {
     constexpr int BPP = 14;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
                     bot1[0] = b4.x; bot1[1] = b4.y; bot1[2] = b4.z; bot1[3] = b4.w;
                 }
 #endif
-                if (smooth_row) {
+                if (smooth_row && METHOD == 2) {
                     const int lr = dpp_prev_i(dr1[3]), lb = dpp_prev_i(db1[3]);                // the cell left of cell 0: the lane before's last
                     const int rr_ = dpp_next_i(dr1[0]), rb = dpp_next_i(db1[0]);               // the cell right of cell 3: the next lane's first
 #pragma unroll
@@ -175,10 +177,30 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
                         mlv_median5(vb, o); eb[cc] = wadd(ge1[cc], o[0]);
                     }
                 }
+                if (smooth_row && METHOD == 3) {
+                    // columns of three (rows r - 2, r - 1, r) sorted once; the lane before's last column and the next lane's first by DPP
+                    auto med9 = [&](const int (&up)[STRIP], const int (&mid)[STRIP], const int (&dn)[STRIP], int (&e)[STRIP]) {
+                        int lo[STRIP + 2], mi[STRIP + 2], hi[STRIP + 2];
+#pragma unroll
+                        for (int cc = 0; cc < STRIP; cc++) {
+                            lo[cc + 1] = min(min(up[cc], mid[cc]), dn[cc]);
+                            hi[cc + 1] = max(max(up[cc], mid[cc]), dn[cc]);
+                            mi[cc + 1] = med3i(up[cc], mid[cc], dn[cc]);
+                        }
+                        lo[0] = dpp_prev_i(lo[STRIP]); mi[0] = dpp_prev_i(mi[STRIP]); hi[0] = dpp_prev_i(hi[STRIP]);
+                        lo[STRIP + 1] = dpp_next_i(lo[1]); mi[STRIP + 1] = dpp_next_i(mi[1]); hi[STRIP + 1] = dpp_next_i(hi[1]);
+#pragma unroll
+                        for (int cc = 0; cc < STRIP; cc++)
+                            e[cc] = wadd(ge1[cc], med3i(max(max(lo[cc], lo[cc + 1]), lo[cc + 2]), med3i(mi[cc], mi[cc + 1], mi[cc + 2]),
+                                                         min(min(hi[cc], hi[cc + 1]), hi[cc + 2])));
+                    };
+                    med9(dr2, dr1, dr, er);
+                    med9(db2, db1, db, eb);
+                }
                 const unsigned long long msmooth = lanes_ge(y, 4) & lanes_lt(y, h - 5);       // (a lane mask in a register pair: put_rb moves it to VCC)
                 const int fl = flags0 | flags1 | flags2;
                 // (the variants of strip_output, chosen by scalars: margins, low pixels, bright rows)
-#define KFS_OUT(CLAMP, XM, BRIGHT) strip_output_t<2, true, true, CLAMP, XM, false, BRIGHT, NoSmem, true>(NoSmem(), oa, w, h, black, f, tx0, 0, jr, lane, msmooth, \
+#define KFS_OUT(CLAMP, XM, BRIGHT) strip_output_t<METHOD, true, true, CLAMP, XM, false, BRIGHT, NoSmem, true>(NoSmem(), oa, w, h, black, f, tx0, 0, jr, lane, msmooth, \
                                                                                                          ge1, 0, er, eb, false, top1, bot1)
                 if (fl & 1) { if (xm) KFS_OUT(true, true, false); else KFS_OUT(true, false, false); }
                 else if (xm) KFS_OUT(false, true, false);
@@ -224,7 +246,7 @@ bool frame_s_takes(int method, bool packed, int vec, int num_cu, const FrameArgs
 {
     // MLVFS_AMD_KF_S: 0 never, 1 (default) long launches of footage without many pixels at or below black, 2 whenever the kernel can
     // (read at every launch: the tests switch it)
-    if (method != 2 || !packed || (vec != 1 && vec != 2)) return false;
+    if ((method != 2 && method != 3) || !packed || (vec != 1 && vec != 2)) return false;
     const char *e = getenv("MLVFS_AMD_KF_S");
     const int policy = e ? atoi(e) : 1;
     if (policy == 0) return false;
@@ -245,7 +267,7 @@ long long frame_s_steps(const FrameArgs &a)
     return (long long)a.nframes * cols * (a.h / 2);
 }
 
-void launch_frame_s_kernel(bool spread, int vec, int num_cu, hipStream_t stream, const FrameArgs &a)
+void launch_frame_s_kernel(int method, bool spread, int vec, int num_cu, hipStream_t stream, const FrameArgs &a)
 {
     const int cols = (a.w + 8 * S_OUT - 1) / (8 * S_OUT), rows = a.h / 2;
     static const int env_seg = [] { const char *e = getenv("MLVFS_AMD_KF_S_SEG"); return e ? atoi(e) : 0; }();
@@ -253,15 +275,14 @@ void launch_frame_s_kernel(bool spread, int vec, int num_cu, hipStream_t stream,
     const long long tasks = (long long)a.nframes * cols * segs;
     int grid = (num_cu > 0 ? num_cu : 256) * KF_S_WGS;   // five workgroups per CU: 20 waves, 80 KiB of LDS (five copies of the table)
     if ((long long)grid * 4 > tasks) grid = (int)((tasks + 3) / 4);
-    if (vec == 2) {
-        if (spread) hipLaunchKernelGGL((k_frame_s<true, 2>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows);
-        else hipLaunchKernelGGL((k_frame_s<false, 2>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows);
-    } else {
-        if (spread) hipLaunchKernelGGL((k_frame_s<true, 1>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows);
-        else hipLaunchKernelGGL((k_frame_s<false, 1>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows);
-    }
+#define KFS_GO(S, V, M) hipLaunchKernelGGL((k_frame_s<S, V, M>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows)
+#define KFS_M(S, V) do { if (method == 3) KFS_GO(S, V, 3); else KFS_GO(S, V, 2); } while (0)
+    if (vec == 2) { if (spread) KFS_M(true, 2); else KFS_M(false, 2); }
+    else { if (spread) KFS_M(true, 1); else KFS_M(false, 1); }
+#undef KFS_M
+#undef KFS_GO
 }
 
-void preload_k_frame_s() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)k_frame_s<false, 1>); (void)hipGetLastError(); }
+void preload_k_frame_s() { hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)k_frame_s<false, 1, 2>); (void)hipGetLastError(); }
 
 }  // namespace mlv

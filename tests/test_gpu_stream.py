@@ -93,9 +93,9 @@ def test_fused_pipeline_rows_of_half_groups(torch_cuda, oracle, w, h, cs):
 
 
 @pytest.mark.parametrize("w,h", [(256, 130), (1008, 44), (16, 12), (48, 10), (496, 122), (512, 124), (1736, 64), (136, 62), (3584, 66)])
-@pytest.mark.parametrize("stripes", [0, 1])
-def test_streaming_cs2x2_kernel_matches_oracle(torch_cuda, oracle, w, h, stripes, monkeypatch):
-    """k_frame_s (cs2x2 without a pixel map: a wave per 62-item column, rows in registers, no barriers) takes long launches only
+@pytest.mark.parametrize("cs,stripes", [(2, 0), (2, 1), (3, 0), (3, 1)])
+def test_streaming_kernel_matches_oracle(torch_cuda, oracle, w, h, cs, stripes, monkeypatch):
+    """k_frame_s (cs2x2 / cs3x3 without a pixel map: a wave per 62-item column, rows in registers, no barriers) takes long launches only
     (and hands footage with many pixels at or below black back to k_frame); MLVFS_AMD_KF_S=2 forces it wherever it can run, so that
     its corners are compared with the oracle: one and several columns (496 px each), a last column of one item, widths that are 8
     mod 16, two-row frames, frames of one task and of several, every footage kind (the loader's form for pixels at or below
@@ -107,14 +107,14 @@ def test_streaming_cs2x2_kernel_matches_oracle(torch_cuda, oracle, w, h, stripes
             frames = [getattr(synth, kind + "_frame")(w, h, seed=3 + k) for k in range(3)]
         else:
             frames = [getattr(synth, kind + "_frame")(w, h, frame=k) for k in range(3)]
-        want, _, corr = oracle_clip(oracle, frames, w, h, 2, 0, stripes)
+        want, _, corr = oracle_clip(oracle, frames, w, h, cs, 0, stripes)
         out = {}
         for mode in ("2", "0"):
             monkeypatch.setenv("MLVFS_AMD_KF_S", mode)
             s = make_stream(w, h)
             packed = s.upload_packed([synth.pack_bits(f) for f in frames])
-            s.analyse_first_frame(packed, cs=2, bad_pix=0, stripes=bool(stripes), rand_mode=1)
-            out[mode] = to_numpy_u16(s.process(packed, cs=2, fix_pixels=False, stripes=bool(stripes)))
+            s.analyse_first_frame(packed, cs=cs, bad_pix=0, stripes=bool(stripes), rand_mode=1)
+            out[mode] = to_numpy_u16(s.process(packed, cs=cs, fix_pixels=False, stripes=bool(stripes)))
             s.close()
         for k in range(3):
             assert np.array_equal(out["2"][k], want[k]), f"{kind} frame {k}: {(out['2'][k] != want[k]).sum()} px differ (k_frame_s)"

@@ -31,7 +31,7 @@ s.detect_bad_pixels(frame0[0], 0)
 s.set_stripes(1, [65536, 65536, 65354, 65738, 65241, 65868, 65450, 65640])
 variants = {"m0": (0, True, True), "m2": (2, True, True), "m3": (3, True, True), "m5": (5, True, True),
             "m5_nopatch_nostripes": (5, False, False), "m5_patch_only": (5, True, False), "m5_stripes_only": (5, False, True), "unpack_only": (0, False, False),
-            "m2_plain": (2, False, False), "m2_stripes": (2, False, True)}       # (what k_frame_s takes: no pixel map)
+            "m2_plain": (2, False, False), "m2_stripes": (2, False, True), "m3_plain": (3, False, False), "m3_stripes": (3, False, True)}       # (what k_frame_s takes: no pixel map)
 if os.environ.get("KB_ONLY"):                           # KB_ONLY=m2,m5: just these rows (profiler runs)
     variants = {k: v for k, v in variants.items() if k in os.environ["KB_ONLY"].split(",")}
 res = {k: [] for k in variants}
