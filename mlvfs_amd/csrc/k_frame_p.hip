@@ -663,8 +663,302 @@ bool frame_p_exists(int method, int vec)
     return (method == 5 || (all && method != 0)) && vec != 0;
 }
 
+// ================================================================ k_frame_p5: the packed-once pass as a streaming kernel (round 5, end)
+// k_frame_s's form (k_frame_s.hip) for cs5x5: a WAVE owns a column of the frame 62 items wide (lanes 0 / 63: the halo items), walks down it a
+// cell row per step, keeps the five packed rows of the window in registers, gets the right-hand group's sorted columns and rank window
+// from the next lane (v_mov_b32_dpp wave_shl, as k_frame_p's lanes do inside a row) and finishes row r - 2 when row r is in.  No
+// s_barrier after the table load, no planes in LDS (only the pixels of the three rows between load and output wait there, in the
+// wave's own 6 KiB): 113 VGPRs, 40 KiB of LDS, four workgroups per CU -- and 6.0 instead of 6.8 us per frame (profiles/r05/ab_p5.log).
+//   * Reference: one per task (a column of KF_P5_SEG rows), the median of five cells at its centre like k_frame_p's.
+//   * A strip whose packed median is not provably exact marks its lane and row; when the task ends, the tiles of k_frame's geometry
+//     that those strips lie in go on the launch's work list and the list-mode k_frame does them again (what this kernel wrote there
+//     is overwritten).
+//   * Pixel-map cells: the records of the tiles that overlap the task's region are collected, one per lane (at most 64: a denser map
+//     sends the whole region to the list), and replace the cell's pixels in the step that loads their row.
+//   * Rows with pixels at or below black take the loader's second form, whole waves at a time; the output stage's variants are
+//     chosen per row from the five rows of its window.
+// Takes long launches of 14-bit streams (rows of whole 8-pixel groups, even heights, black >= 0, stripes packed or none); everything
+// else, and every short launch, stays with k_frame_p / k_frame.
+#ifndef KF_P5_SEG
+#define KF_P5_SEG 60
+#endif
+__device__ __forceinline__ int dpp_prev_ii(int v) { return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, true); }
+template <bool SPREAD, int VEC>
+__global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols, int segs, int seg_rows)
+{
+    constexpr int BPP = 14, S_OUT = 62;
+    __shared__ __align__(16) uint16_t t16[MLV_T16_N + (SPREAD ? 64 : 0)];
+    __shared__ uint4 park[4][3][2][64];
+    load_t16_rel<SPREAD>(t16, a.t16, (int)threadIdx.x);
+    __syncthreads();                                     // the only barrier
+    const int lane = (int)threadIdx.x & 63;
+    const int w = a.w, h = a.h, black = a.black;
+    const int rows = h >> 1, gmax = (w >> 3) - 1;
+    const int per_frame = cols * segs, ntasks = a.nframes * per_frame;
+    const uint32_t pitch = (uint32_t)(w >> 3) * 14u;
+    const OutArgs oa = out_args(cold_args());
+    int *tickets = a.tickets;
+    uint4 (*const mypark)[2][64] = park[threadIdx.x >> 6];
+    for (;;) {
+        int task = 0;
+        if (lane == 0) task = atomicAdd(&tickets[0], 1);
+        task = __builtin_amdgcn_readfirstlane(task);
+        if (task >= ntasks) break;
+        const int f = task / per_frame, rem = task - f * per_frame, c = rem / segs, sg = rem - c * segs;
+        const int j0 = sg * seg_rows, j1 = min(j0 + seg_rows, rows);
+        const int g_true = c * S_OUT + lane - 1;
+        const int g = min(max(g_true, 0), gmax);
+        const bool writes = lane >= 1 && lane <= S_OUT && g_true <= gmax;
+        const uint32_t gbyte = (uint32_t)g * 14u;
+        const uint32_t sel = (g & 1) ? SEL_MIS : SEL_SWAP;
+        const uint32_t sel1 = VEC == 2 ? sel ^ (SEL_SWAP ^ SEL_MIS) : sel;
+        const uint8_t *const frame = a.src + (size_t)f * a.src_stride;
+        const mlv_i32x4 rs_in = frame_rsrc(frame, a.src_bytes);
+        const mlv_i32x4 rs_out = frame_rsrc(oa.dst + (size_t)f * oa.dst_stride, (uint32_t)w * (uint32_t)h * 2u);
+        const int tx0 = 8 * (c * S_OUT - 1);
+        const bool xm = c == 0 || 8 * (c * S_OUT + S_OUT) > w - 4;
+        uint32_t dA0[4], dA1[4], dB0[4], dB1[4];
+        auto issue = [&](int r, uint32_t (&d0)[4], uint32_t (&d1)[4]) {
+            const int rr = min(max(r, 0), rows - 1);
+            const uint32_t o0 = (__umul24((uint32_t)(2 * rr), pitch) + gbyte) & ~3u, o1 = (__umul24((uint32_t)(2 * rr + 1), pitch) + gbyte) & ~3u;
+            const mlv_u32x2 a0 = mlv_rbl_x2(rs_in, (int)o0, 0, KF_SRC_AUX), b0 = mlv_rbl_x2(rs_in, (int)o0 + 8, 0, KF_SRC_AUX);
+            const mlv_u32x2 a1 = mlv_rbl_x2(rs_in, (int)o1, 0, KF_SRC_AUX), b1 = mlv_rbl_x2(rs_in, (int)o1 + 8, 0, KF_SRC_AUX);
+            d0[0] = a0.x; d0[1] = a0.y; d0[2] = b0.x; d0[3] = b0.y;
+            d1[0] = a1.x; d1[1] = a1.y; d1[2] = b1.x; d1[3] = b1.y;
+        };
+        issue(j0 - 2, dA0, dA1);
+        issue(j0 - 1, dB0, dB1);
+        // ---- the task's reference: median of five cells (no two of them neighbours) of the 16 x 4 block at its centre
+        int ref_r, ref_b;
+        {
+            const int x0 = min(max(8 * (c * S_OUT + S_OUT / 2), 0), (w - 16) & ~1), y0 = min(j0 + j1, (h - 4) & ~1) & ~1;
+            const uint32_t px = fetch_clamped<BPP>(frame, w, h, x0 + (lane & 15), y0 + (lane >> 4));
+            const int l = min(max((int)px - black, 1), 16383);
+            const int ix = ev_index(l);
+            const int ev = ev_value(l, (int)t16[SPREAD ? ix + (ix >> 7) : ix]);
+            constexpr int CX[5] = { 0, 3, 6, 1, 5 }, CY[5] = { 0, 0, 0, 1, 1 };
+            int sdr[5], sdb[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int l0 = 2 * CX[k] + 32 * CY[k];
+                const int rr = __builtin_amdgcn_readlane(ev, l0), g1 = __builtin_amdgcn_readlane(ev, l0 + 1);
+                const int g2 = __builtin_amdgcn_readlane(ev, l0 + 16), bb = __builtin_amdgcn_readlane(ev, l0 + 17);
+                const int gg = (g1 + g2) >> 1;
+                sdr[k] = rr - gg; sdb[k] = bb - gg;
+            }
+            auto med5 = [](const int (&v)[5]) { return med3i(v[4], max(min(v[0], v[1]), min(v[2], v[3])), min(max(v[0], v[1]), max(v[2], v[3]))); };
+            ref_r = med5(sdr);
+            ref_b = med5(sdb);
+        }
+        // ---- pixel-map cells of the region (rows j0 - 2 .. j1 + 1, this wave's 256 cells): one record per lane
+        int n_pm = 0, pm_cell = -1;                      // (lane k < n_pm holds record k: cell = cy << 16 | cx)
+        uint32_t pm_top = 0, pm_bot = 0;
+        bool list_all = false;                           // more records than lanes: the whole region goes to k_frame
+        if (a.patch) {
+            // The host lists a cell in every tile whose plane holds it (k_frame's tiles, halo included), tile by tile in row-major order:
+            // one contiguous range of records per tile row of the region.  All ranges are fetched at once (at most six tile rows for 64
+            // rows of cells, 64 records each: a denser map sends the region to the list); a cell counts where its own tile row is read
+            // (its copies in the tiles left and right of its own remain: the same pixels twice).
+            KArgs ka = cold_args();
+            const int4 *cells = ka->cells + (size_t)f * ka->n_rec;
+            const int *toff = ka->tile_off;
+            const int tx_n = ka->tiles_x, ty_n = ka->tiles_y;
+            const int cx_lo = 4 * (c * S_OUT - 1), cx_hi = cx_lo + 256;        // cells of lanes 0 .. 63
+            const int cy_lo = j0 - 2, cy_hi = j1 + 2;
+            const int tc0 = max(cx_lo - HC, 0) / TCW, tc1 = min((cx_hi - 1 + HC) / TCW, tx_n - 1);
+            const int tr0 = max(cy_lo, 0) / TCH, tr1 = min((cy_hi - 1) / TCH, ty_n - 1), ntr = tr1 - tr0 + 1;
+            constexpr int MAXTR = 6;
+            int my_lo = 0, my_hi = 0;
+            if (lane < ntr && lane < MAXTR) { my_lo = toff[(tr0 + lane) * tx_n + tc0]; my_hi = toff[(tr0 + lane) * tx_n + tc1 + 1]; }
+            if (ntr > MAXTR) list_all = true;
+            int4 rec[MAXTR];
+#pragma unroll
+            for (int i = 0; i < MAXTR; i++) {
+                const int rb = __builtin_amdgcn_readlane(my_lo, i), re = __builtin_amdgcn_readlane(my_hi, i);
+                rec[i] = (i < ntr && rb + lane < re) ? cells[rb + lane] : make_int4(-1, 0, 0, 0);
+                if (i < ntr && re - rb > 64) list_all = true;
+            }
+#pragma unroll
+            for (int i = 0; i < MAXTR; i++) {
+                const int rcx = rec[i].x & 0xFFFF, rcy = rec[i].x >> 16;
+                const bool in = rec[i].x >= 0 && rcx >= cx_lo && rcx < cx_hi && rcy >= cy_lo && rcy < cy_hi && rcy / TCH == tr0 + i;
+                unsigned long long m = __ballot(in);
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    if (n_pm < 64) {
+                        const int vx = __builtin_amdgcn_readlane(rec[i].x, src), vy = __builtin_amdgcn_readlane(rec[i].y, src), vz = __builtin_amdgcn_readlane(rec[i].z, src);
+                        if (lane == n_pm) { pm_cell = vx; pm_top = (uint32_t)vy; pm_bot = (uint32_t)vz; }
+                        n_pm++;
+                    } else list_all = true;
+                }
+            }
+        }
+        uint32_t pkr[5][4] = {};                          // packed rows r - 4 .. r
+        int ge2[4] = { 0, 0, 0, 0 }, ge1[4] = { 0, 0, 0, 0 };
+        int fl1 = 3, fl2 = 3, fl3 = 3, fl4 = 3;          // low / dim flags of rows r - 1 .. r - 4 (k_frame_s.hip)
+        unsigned long long unc_lanes = 0;                // lanes with an uncertain strip in some row of the task
+        int unc_r0 = 1 << 30, unc_r1 = -1;               // ... and the rows
+        const uint32_t nref_r = 0u - (uint32_t)ref_r, nref_b = 0u - (uint32_t)ref_b;
+        auto step = [&](int r, uint32_t (&d0)[4], uint32_t (&d1)[4]) {
+            uint32_t p0[8], p1[8];
+            unpack8<BPP>(d0, sel, sel, sel, p0);
+            unpack8<BPP>(d1, sel1, sel1, sel1, p1);
+            if (r + 2 <= j1 + 1) issue(r + 2, d0, d1);
+            if (n_pm) {                                   // pixel-map cells of this row: the owning lane takes the record's pixels
+                unsigned long long m = __ballot(lane < n_pm && (pm_cell >> 16) == r);
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int cell = __builtin_amdgcn_readlane(pm_cell, src);
+                    const uint32_t t_ = (uint32_t)__builtin_amdgcn_readlane((int)pm_top, src), b_ = (uint32_t)__builtin_amdgcn_readlane((int)pm_bot, src);
+                    const int cxr = (cell & 0xFFFF) - 4 * (c * S_OUT - 1);                 // cell within the wave's 256
+                    const bool mine = (cxr >> 2) == lane;
+                    const int cc = cxr & 3;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (mine && cc == k) { p0[2 * k] = t_ & 0xFFFFu; p0[2 * k + 1] = t_ >> 16; p1[2 * k] = b_ & 0xFFFFu; p1[2 * k + 1] = b_ >> 16; }
+                }
+            }
+            uint32_t lo = min(p0[0], p1[0]);
+#pragma unroll
+            for (int i = 1; i < 8; i++) lo = min(min(lo, p0[i]), p1[i]);
+            const bool dark = __any((int)lo <= black);
+            int fl0 = 0;
+            if (__any((int)lo <= black + 255)) fl0 = __any((int)lo <= black + 64) ? 3 : 2;
+            int ge[4];
+            uint32_t pk[4];
+            if (!dark) cell_multi_pk_fast<4, SPREAD>(p0, p1, black, t16, ref_r, ref_b, ge, pk);
+            else {
+#pragma unroll
+                for (int cc = 0; cc < 4; cc += 2) {
+                    int g2[2], r2[2], b2[2];
+                    cell_multi_ev_dark<2, SPREAD>(p0 + 2 * cc, p1 + 2 * cc, black, t16, g2, r2, b2);
+                    ge[cc] = g2[0]; ge[cc + 1] = g2[1];
+                    pk[cc] = as_u(__builtin_amdgcn_cvt_pk_i16(__builtin_elementwise_sub_sat(r2[0], ref_r), __builtin_elementwise_sub_sat(b2[0], ref_b)));
+                    pk[cc + 1] = as_u(__builtin_amdgcn_cvt_pk_i16(__builtin_elementwise_sub_sat(r2[1], ref_r), __builtin_elementwise_sub_sat(b2[1], ref_b)));
+                }
+            }
+            {
+                uint4 (&slot)[2][64] = mypark[(unsigned)(r + 6) % 3u];
+                slot[0][lane] = make_uint4(p0[0] | (p0[1] << 16), p0[2] | (p0[3] << 16), p0[4] | (p0[5] << 16), p0[6] | (p0[7] << 16));
+                slot[1][lane] = make_uint4(p1[0] | (p1[1] << 16), p1[2] | (p1[3] << 16), p1[4] | (p1[5] << 16), p1[6] | (p1[7] << 16));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) { pkr[0][i] = pkr[1][i]; pkr[1][i] = pkr[2][i]; pkr[2][i] = pkr[3][i]; pkr[3][i] = pkr[4][i]; pkr[4][i] = pk[i]; }
+            const int jr = r - 2, y = 2 * jr;
+            if (jr >= j0 && jr < j1) {
+                const bool smooth_row = y >= 4 && y < h - 5;                               // chroma_smooth.c:25
+                mlv_pk16 o[STRIP] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
+                if (smooth_row) {
+                    PGroup gq;
+                    {
+                        mlv_pk16 col[4][5];
+#pragma unroll
+                        for (int rr = 0; rr < 5; rr++)
+#pragma unroll
+                            for (int cc = 0; cc < 4; cc++) col[cc][rr] = as_pk(pkr[rr][cc]);
+#pragma unroll
+                        for (int cc = 0; cc < 4; cc++) mlv_sort5(col[cc], gq.s[cc]);
+                        mlv_merge55(gq.s[0], gq.s[1], gq.p0);
+                        mlv_merge55(gq.s[2], gq.s[3], gq.p1);
+                    }
+                    mlv_quad_mid6(gq.p0, gq.p1, gq.q);
+                    PNext n;
+                    pchain_fetch_lists(gq, n);
+                    pchain_fetch_window(gq, n);
+                    mlv_pk16 oc[STRIP];
+                    pchain_finish(gq, n, oc);
+                    // the chain's four medians are those of the lane's cells 2, 3 and of the NEXT lane's cells 0, 1 (its window is the lane's
+                    // group and the next one): the lane's own cells 0, 1 come from the lane before
+                    o[0] = as_pk((uint32_t)dpp_prev_ii((int)as_u(oc[2]))); o[1] = as_pk((uint32_t)dpp_prev_ii((int)as_u(oc[3])));
+                    o[2] = oc[0]; o[3] = oc[1];
+                    const unsigned long long um = __ballot(writes && pk_uncertain(o));
+                    if (um) { unc_lanes |= um; unc_r0 = min(unc_r0, jr); unc_r1 = max(unc_r1, jr); }
+                }
+                int er[STRIP], eb[STRIP];
+#pragma unroll
+                for (int cc = 0; cc < STRIP; cc++) {
+                    er[cc] = wadd(wadd(ge2[cc], ref_r), (int)o[cc].x);
+                    eb[cc] = wadd(wadd(ge2[cc], ref_b), (int)o[cc].y);
+                }
+                uint32_t top[STRIP], bot[STRIP];
+                {
+                    const uint4 (&slot)[2][64] = mypark[(unsigned)(jr + 6) % 3u];
+                    const uint4 t4 = slot[0][lane], b4 = slot[1][lane];
+                    top[0] = t4.x; top[1] = t4.y; top[2] = t4.z; top[3] = t4.w;
+                    bot[0] = b4.x; bot[1] = b4.y; bot[2] = b4.z; bot[3] = b4.w;
+                }
+                const unsigned long long msmooth = lanes_ge(y, 4) & lanes_lt(y, h - 5);
+                const int fl = fl0 | fl1 | fl2 | fl3 | fl4;                                 // the five rows of the window
+#define KFP5_OUT(CLAMP, XM, BRIGHT) strip_output_t<5, true, true, CLAMP, XM, false, BRIGHT, NoSmem, true>(NoSmem(), oa, w, h, black, f, tx0, 0, jr, lane, msmooth, \
+                                                                                                          ge2, 0, er, eb, false, top, bot)
+                if (fl & 1) { if (xm) KFP5_OUT(true, true, false); else KFP5_OUT(true, false, false); }
+                else if (xm) KFP5_OUT(false, true, false);
+                else if (fl == 0) KFP5_OUT(false, false, true);
+                else KFP5_OUT(false, false, false);
+#undef KFP5_OUT
+                if (writes) {
+                    const uint32_t vo = (__umul24((uint32_t)y, (uint32_t)w) + (uint32_t)(8 * g)) * 2u;
+                    const mlv_u32x4 vt = { top[0], top[1], top[2], top[3] }, vb_ = { bot[0], bot[1], bot[2], bot[3] };
+                    mlv_rbs_x4(vt, rs_out, (int)vo, 0, 2);
+                    mlv_rbs_x4(vb_, rs_out, (int)vo, w * 2, 2);
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) { ge2[cc] = ge1[cc]; ge1[cc] = ge[cc]; }
+            fl4 = fl3; fl3 = fl2; fl2 = fl1; fl1 = fl0;
+        };
+        (void)nref_r; (void)nref_b;
+        for (int r = j0 - 2; r <= j1 + 1; r += 2) {
+            step(r, dA0, dA1);
+            if (r + 1 <= j1 + 1) step(r + 1, dB0, dB1);
+        }
+        // ---- what this task could not settle goes to k_frame: the tiles (64 x 15 cells) its uncertain strips lie in
+        if (list_all) { unc_lanes = ~0ull; unc_r0 = j0; unc_r1 = j1 - 1; }
+        if (unc_lanes && lane == 0) {
+            const int l0 = __builtin_ctzll(unc_lanes), l1 = 63 - __builtin_clzll(unc_lanes);
+            const int cx0 = max(4 * (c * S_OUT + l0 - 1), 0), cx1 = min(4 * (c * S_OUT + l1 - 1) + 3, w / 2 - 1);
+            const int tc0 = cx0 / TCW, tc1 = min(cx1 / TCW, a.tiles_x - 1), tr0 = unc_r0 / TCH, tr1 = min(unc_r1 / TCH, a.tiles_y - 1);
+            const int tpf = a.tiles_x * a.tiles_y;
+            for (int tc = tc0; tc <= tc1; tc++) {
+                const int i = atomicAdd(&a.wl_ctl[0], 1);
+                a.wl[i] = make_int2(f * tpf + tc * a.tiles_y + tr0, tr1 - tr0 + 1);
+                atomicAdd(&a.wl_ctl[3], tr1 - tr0 + 1);
+            }
+        }
+    }
+    if (lane == 0) {
+        const int nwaves = (int)gridDim.x * 4;
+        if (atomicAdd(&tickets[1], 1) == nwaves - 1) { tickets[0] = 0; tickets[1] = 0; }
+    }
+}
+
+// does the streaming form take this two-kernel launch?  (launch_frame_p_kernel)
+static bool frame_p5_takes(int method, bool packed, int vec, int num_cu, const FrameArgs &a)
+{
+    if (method != 5 || !packed || (vec != 1 && vec != 2)) return false;
+    const char *e = getenv("MLVFS_AMD_KF_P5");                                  // 0 never, 1 (default) long launches, 2 whenever it can
+    const int policy = e ? atoi(e) : 1;
+    if (policy == 0) return false;
+    if ((a.stripes && !a.coef_pk) || a.black < 0) return false;
+    if (!(a.w >= 16 && a.w % 8 == 0 && a.h >= 2 && a.h % 2 == 0)) return false;
+    const long long cols = (a.w + 8 * 62 - 1) / (8 * 62), segs = (a.h / 2 + KF_P5_SEG - 1) / KF_P5_SEG;
+    const long long waves = (long long)(num_cu > 0 ? num_cu : 256) * 16;
+    return policy == 2 || (long long)a.nframes * cols * segs * 2 >= waves * 7;     // >= 3.5 tasks per wave (k_frame_s.hip: why)
+}
 void launch_frame_p_kernel(int method, bool packed, int vec, bool spread, int grid, hipStream_t stream, const FrameArgs &a)
 {
+#ifndef KFP_ONLY
+    if (frame_p5_takes(method, packed, vec, grid / 4, a)) {
+        const int cols = (a.w + 8 * 62 - 1) / (8 * 62), segs = (a.h / 2 + KF_P5_SEG - 1) / KF_P5_SEG;
+#define KFP5_GO(S, V) hipLaunchKernelGGL((k_frame_p5<S, V>), dim3(grid), dim3(256), 0, stream, a, cols, segs, (int)KF_P5_SEG)
+        if (vec == 2) { if (spread) KFP5_GO(true, 2); else KFP5_GO(false, 2); }
+        else { if (spread) KFP5_GO(true, 1); else KFP5_GO(false, 1); }
+#undef KFP5_GO
+        return;
+    }
+#endif
 #ifdef KFP_ONLY          // (tools: one or two instantiations, seconds to compile)
     if (method == 5) hipLaunchKernelGGL((k_frame_p<5, true, 1, false>), dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((k_frame_p<2, true, 1, false>), dim3(grid), dim3(256), 0, stream, a);
