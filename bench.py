@@ -794,6 +794,14 @@ def main():
             traffic = None
 
     two_kernels = args.cs == 5 and os.environ.get("MLVFS_AMD_KF_P", "1") != "0"
+    # which kernel does the tiles' first pass: the library's rule (csrc/k_frame_p.hip: frame_p5_takes) -- the streaming form
+    # k_frame_p5 takes launches of at least 3.5 tasks (a 62-item column x 60 rows) per wave, k_frame_p the shorter ones
+    streaming = False
+    if two_kernels and os.environ.get("MLVFS_AMD_KF_P5", "1") != "0":
+        cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        tasks = F * ((W + 495) // 496) * ((H // 2 + 59) // 60)
+        streaming = os.environ.get("MLVFS_AMD_KF_P5") == "2" or tasks * 2 >= cus * 16 * 7
+    first_pass = "void mlv::k_frame_p5<false, 1>(mlv::FrameArgs, int, int, int)" if streaming else "void mlv::k_frame_p<5, true, 1, false>(mlv::FrameArgs)"
     result = {
         "metric": "Mpix/s, 3584x1320 14-bit unpack+badpix+cs5x5+stripes (fused, stream resident in HBM)",
         "value": round(total_px / dt / 1e6, 1),
@@ -814,12 +822,13 @@ def main():
         "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": ("void mlv::k_frame_p<5, true, 1, false>(mlv::FrameArgs)" if two_kernels else "void mlv::k_frame<5, true, 1, false>(mlv::FrameArgs)") if args.cs == 5 else f"void mlv::k_frame<{args.cs}, true, 1, false>(mlv::FrameArgs)",
-                     "kernel_template_arguments": "METHOD (chroma smoothing 2 / 3 / 5), PACKED (14-bit stream in), VEC (1: width % 16 == 0; 2: width % 16 == 8; 0: any width), SPREAD (dark-clip table layout)",
+                     "kernel": (first_pass if two_kernels else "void mlv::k_frame<5, true, 1, false>(mlv::FrameArgs)") if args.cs == 5 else f"void mlv::k_frame<{args.cs}, true, 1, false>(mlv::FrameArgs)",
+                     "kernel_template_arguments": "k_frame / k_frame_p: METHOD (chroma smoothing 2 / 3 / 5), PACKED (14-bit stream in), VEC (1: width % 16 == 0; 2: width % 16 == 8; 0: any width), SPREAD (dark-clip table layout); k_frame_p5: SPREAD, VEC",
                      "kernel_ms_per_launch": round(kern_ms, 4),
-                     "kernel_ms_per_launch_covers": ("one pass = k_frame_p (every tile whose packed medians are certain) + the list-mode k_frame that follows it on the "
-                                                     "stream (the tiles k_frame_p listed; none on these frames: its workgroups end at once): the HIP events bracket both, "
-                                                     "the rocprofv3 averages of the two add up to this") if two_kernels else "k_frame",
+                     "kernel_ms_per_launch_covers": ("one pass = " + ("k_frame_p5 (the packed-once pass as a streaming kernel: a wave per 62-item column of the frame; long launches)"
+                                                                     if streaming else "k_frame_p (every tile whose packed medians are certain)") +
+                                                     " + the list-mode k_frame that follows it on the stream (the tiles the first kernel listed; none on these frames: its "
+                                                     "workgroups end at once): the HIP events bracket both, the rocprofv3 averages of the two add up to this") if two_kernels else "k_frame",
                      "algorithmic_bytes_per_launch": int(F * npx * BYTES_PER_PX)},
         "parity": parity,
     }

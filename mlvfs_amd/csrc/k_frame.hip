@@ -795,7 +795,8 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
     }
     auto kern = k_frame<METHOD, PACKED, VEC, SPREAD>;
     // MLVFS_AMD_KF_P: 0 = k_frame alone (rounds 1-4), 1 = both kernels, k_frame alone while the footage is busy (default), 2 = always both
-    static const int env_p = [] { const char *e = getenv("MLVFS_AMD_KF_P"); return e ? atoi(e) : 1; }();
+    const char *e_p = getenv("MLVFS_AMD_KF_P");                 // (read at every launch: the tests switch it)
+    const int env_p = e_p ? atoi(e_p) : 1;
     FrameArgs a = a_in;
     StreamState st;
     bool two = false;

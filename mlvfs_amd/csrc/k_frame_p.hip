@@ -688,17 +688,21 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
 {
     constexpr int BPP = 14, S_OUT = 62;
     __shared__ __align__(16) uint16_t t16[MLV_T16_N + (SPREAD ? 64 : 0)];
-    __shared__ uint4 park[4][3][2][64];
-    load_t16_rel<SPREAD>(t16, a.t16, (int)threadIdx.x);
+    // (the dark-clip table layout is 128 bytes longer: there only the 62 lanes that write a row park it, which keeps the workgroup at 40 KiB)
+    constexpr int PARK_LANES = SPREAD ? 62 : 64;
+    __shared__ uint4 park[4][3][2][PARK_LANES];
+    load_t16_rel<SPREAD>(t16, cold_args()->t16, (int)threadIdx.x);
     __syncthreads();                                     // the only barrier
     const int lane = (int)threadIdx.x & 63;
     const int w = a.w, h = a.h, black = a.black;
     const int rows = h >> 1, gmax = (w >> 3) - 1;
-    const int per_frame = cols * segs, ntasks = a.nframes * per_frame;
+    const int per_frame = cols * segs, ntasks = cold_args()->nframes * per_frame;
     const uint32_t pitch = (uint32_t)(w >> 3) * 14u;
     const OutArgs oa = out_args(cold_args());
-    int *tickets = a.tickets;
-    uint4 (*const mypark)[2][64] = park[threadIdx.x >> 6];
+    int *tickets = cold_args()->tickets;
+    uint4 (*const mypark)[2][PARK_LANES] = park[threadIdx.x >> 6];
+    const int plane = SPREAD ? min(max(lane - 1, 0), 61) : lane;       // the lane's slot (SPREAD: lanes 0 and 63 share their neighbours', unused)
+    const bool parks = !SPREAD || (lane >= 1 && lane <= 62);
     for (;;) {
         int task = 0;
         if (lane == 0) task = atomicAdd(&tickets[0], 1);
@@ -712,8 +716,9 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
         const uint32_t gbyte = (uint32_t)g * 14u;
         const uint32_t sel = (g & 1) ? SEL_MIS : SEL_SWAP;
         const uint32_t sel1 = VEC == 2 ? sel ^ (SEL_SWAP ^ SEL_MIS) : sel;
-        const uint8_t *const frame = a.src + (size_t)f * a.src_stride;
-        const mlv_i32x4 rs_in = frame_rsrc(frame, a.src_bytes);
+        KArgs kt = cold_args();                          // (what a task needs once: read here, not held in scalar registers through the launch)
+        const uint8_t *const frame = kt->src + (size_t)f * kt->src_stride;
+        const mlv_i32x4 rs_in = frame_rsrc(frame, kt->src_bytes);
         const mlv_i32x4 rs_out = frame_rsrc(oa.dst + (size_t)f * oa.dst_stride, (uint32_t)w * (uint32_t)h * 2u);
         const int tx0 = 8 * (c * S_OUT - 1);
         const bool xm = c == 0 || 8 * (c * S_OUT + S_OUT) > w - 4;
@@ -754,12 +759,12 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
         int n_pm = 0, pm_cell = -1;                      // (lane k < n_pm holds record k: cell = cy << 16 | cx)
         uint32_t pm_top = 0, pm_bot = 0;
         bool list_all = false;                           // more records than lanes: the whole region goes to k_frame
-        if (a.patch) {
+        if (kt->patch) {
             // The host lists a cell in every tile whose plane holds it (k_frame's tiles, halo included), tile by tile in row-major order:
             // one contiguous range of records per tile row of the region.  All ranges are fetched at once (at most six tile rows for 64
             // rows of cells, 64 records each: a denser map sends the region to the list); a cell counts where its own tile row is read
             // (its copies in the tiles left and right of its own remain: the same pixels twice).
-            KArgs ka = cold_args();
+            KArgs ka = kt;
             const int4 *cells = ka->cells + (size_t)f * ka->n_rec;
             const int *toff = ka->tile_off;
             const int tx_n = ka->tiles_x, ty_n = ka->tiles_y;
@@ -799,7 +804,6 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
         int fl1 = 3, fl2 = 3, fl3 = 3, fl4 = 3;          // low / dim flags of rows r - 1 .. r - 4 (k_frame_s.hip)
         unsigned long long unc_lanes = 0;                // lanes with an uncertain strip in some row of the task
         int unc_r0 = 1 << 30, unc_r1 = -1;               // ... and the rows
-        const uint32_t nref_r = 0u - (uint32_t)ref_r, nref_b = 0u - (uint32_t)ref_b;
         auto step = [&](int r, uint32_t (&d0)[4], uint32_t (&d1)[4]) {
             uint32_t p0[8], p1[8];
             unpack8<BPP>(d0, sel, sel, sel, p0);
@@ -840,9 +844,11 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
                 }
             }
             {
-                uint4 (&slot)[2][64] = mypark[(unsigned)(r + 6) % 3u];
-                slot[0][lane] = make_uint4(p0[0] | (p0[1] << 16), p0[2] | (p0[3] << 16), p0[4] | (p0[5] << 16), p0[6] | (p0[7] << 16));
-                slot[1][lane] = make_uint4(p1[0] | (p1[1] << 16), p1[2] | (p1[3] << 16), p1[4] | (p1[5] << 16), p1[6] | (p1[7] << 16));
+                uint4 (&slot)[2][PARK_LANES] = mypark[(unsigned)(r + 6) % 3u];
+                if (parks) {
+                    slot[0][plane] = make_uint4(p0[0] | (p0[1] << 16), p0[2] | (p0[3] << 16), p0[4] | (p0[5] << 16), p0[6] | (p0[7] << 16));
+                    slot[1][plane] = make_uint4(p1[0] | (p1[1] << 16), p1[2] | (p1[3] << 16), p1[4] | (p1[5] << 16), p1[6] | (p1[7] << 16));
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) { pkr[0][i] = pkr[1][i]; pkr[1][i] = pkr[2][i]; pkr[2][i] = pkr[3][i]; pkr[3][i] = pkr[4][i]; pkr[4][i] = pk[i]; }
@@ -884,8 +890,8 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
                 }
                 uint32_t top[STRIP], bot[STRIP];
                 {
-                    const uint4 (&slot)[2][64] = mypark[(unsigned)(jr + 6) % 3u];
-                    const uint4 t4 = slot[0][lane], b4 = slot[1][lane];
+                    const uint4 (&slot)[2][PARK_LANES] = mypark[(unsigned)(jr + 6) % 3u];
+                    const uint4 t4 = slot[0][plane], b4 = slot[1][plane];
                     top[0] = t4.x; top[1] = t4.y; top[2] = t4.z; top[3] = t4.w;
                     bot[0] = b4.x; bot[1] = b4.y; bot[2] = b4.z; bot[3] = b4.w;
                 }
@@ -909,7 +915,6 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
             for (int cc = 0; cc < 4; cc++) { ge2[cc] = ge1[cc]; ge1[cc] = ge[cc]; }
             fl4 = fl3; fl3 = fl2; fl2 = fl1; fl1 = fl0;
         };
-        (void)nref_r; (void)nref_b;
         for (int r = j0 - 2; r <= j1 + 1; r += 2) {
             step(r, dA0, dA1);
             if (r + 1 <= j1 + 1) step(r + 1, dB0, dB1);
@@ -919,12 +924,14 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
         if (unc_lanes && lane == 0) {
             const int l0 = __builtin_ctzll(unc_lanes), l1 = 63 - __builtin_clzll(unc_lanes);
             const int cx0 = max(4 * (c * S_OUT + l0 - 1), 0), cx1 = min(4 * (c * S_OUT + l1 - 1) + 3, w / 2 - 1);
-            const int tc0 = cx0 / TCW, tc1 = min(cx1 / TCW, a.tiles_x - 1), tr0 = unc_r0 / TCH, tr1 = min(unc_r1 / TCH, a.tiles_y - 1);
-            const int tpf = a.tiles_x * a.tiles_y;
+            KArgs kl = cold_args();
+            const int tnx = kl->tiles_x, tny = kl->tiles_y;
+            const int tc0 = cx0 / TCW, tc1 = min(cx1 / TCW, tnx - 1), tr0 = unc_r0 / TCH, tr1 = min(unc_r1 / TCH, tny - 1);
+            int *ctl = kl->wl_ctl;
             for (int tc = tc0; tc <= tc1; tc++) {
-                const int i = atomicAdd(&a.wl_ctl[0], 1);
-                a.wl[i] = make_int2(f * tpf + tc * a.tiles_y + tr0, tr1 - tr0 + 1);
-                atomicAdd(&a.wl_ctl[3], tr1 - tr0 + 1);
+                const int i = atomicAdd(&ctl[0], 1);
+                kl->wl[i] = make_int2(f * tnx * tny + tc * tny + tr0, tr1 - tr0 + 1);
+                atomicAdd(&ctl[3], tr1 - tr0 + 1);
             }
         }
     }

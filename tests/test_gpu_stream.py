@@ -121,6 +121,33 @@ def test_streaming_kernel_matches_oracle(torch_cuda, oracle, w, h, cs, stripes, 
             assert np.array_equal(out["0"][k], want[k]), f"{kind} frame {k}: k_frame"
 
 
+@pytest.mark.parametrize("w,h", [(256, 130), (1008, 64), (16, 12), (496, 122), (512, 124), (1736, 64), (3584, 66)])
+@pytest.mark.parametrize("bad,stripes", [(0, 0), (1, 1), (2, 0)])
+def test_streaming_cs5x5_kernel_matches_oracle(torch_cuda, oracle, w, h, bad, stripes, monkeypatch):
+    """k_frame_p5 (the packed-once pass as a streaming kernel: a wave per 62-item column, the five packed rows of the window in
+    registers, pixel-map records collected per task, uncertain strips' tiles to the work list for the list-mode k_frame) takes long
+    launches only; MLVFS_AMD_KF_P5=2 with MLVFS_AMD_KF_P=2 forces it (and the list-mode launch behind it) wherever it can run: one
+    and several columns, a last column of one item, widths that are 8 mod 16, tasks of a few rows, every footage kind (adversarial:
+    thousands of pixel-map cells and pixels at black -- the dense-map and the dark-row paths; colour patches: everything uncertain),
+    pixel maps of both detection modes, with and without stripes."""
+    from mlvfs_amd.stream import to_numpy_u16
+    monkeypatch.setenv("MLVFS_AMD_KF_P", "2")
+    monkeypatch.setenv("MLVFS_AMD_KF_P5", "2")
+    for kind in ("normal", "low_light", "colour_cast", "adversarial"):
+        if kind in ("low_light", "colour_cast"):
+            frames = [getattr(synth, kind + "_frame")(w, h, seed=3 + k) for k in range(3)]
+        else:
+            frames = [getattr(synth, kind + "_frame")(w, h, frame=k) for k in range(3)]
+        want, pixels, corr = oracle_clip(oracle, frames, w, h, 5, bad, stripes)
+        s = make_stream(w, h)
+        packed = s.upload_packed([synth.pack_bits(f) for f in frames])
+        s.analyse_first_frame(packed, cs=5, bad_pix=bad, stripes=bool(stripes), rand_mode=1)
+        got = to_numpy_u16(s.process(packed, cs=5, fix_pixels=bool(bad), stripes=bool(stripes)))
+        s.close()
+        for k in range(3):
+            assert np.array_equal(got[k], want[k]), f"{kind} frame {k}: {(got[k] != want[k]).sum()} px differ"
+
+
 def test_fused_adversarial(torch_cuda, oracle):
     """INT_MIN-heavy frame (40 % of pixels at black+-4) with thousands of bad pixels:
     exercises wrap-around EV arithmetic and multi-level ordered repair."""
