@@ -941,25 +941,32 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
     }
 }
 
-// does the streaming form take this two-kernel launch?  (launch_frame_p_kernel)
-static bool frame_p5_takes(int method, bool packed, int vec, int num_cu, const FrameArgs &a)
+// does the streaming form take this two-kernel launch, and in tasks of how many rows?  0: no  (launch_frame_p_kernel)
+static int frame_p5_takes(int method, bool packed, int vec, int num_cu, const FrameArgs &a)
 {
-    if (method != 5 || !packed || (vec != 1 && vec != 2)) return false;
+    if (method != 5 || !packed || (vec != 1 && vec != 2)) return 0;
     const char *e = getenv("MLVFS_AMD_KF_P5");                                  // 0 never, 1 (default) long launches, 2 whenever it can
     const int policy = e ? atoi(e) : 1;
-    if (policy == 0) return false;
-    if ((a.stripes && !a.coef_pk) || a.black < 0) return false;
-    if (!(a.w >= 16 && a.w % 8 == 0 && a.h >= 2 && a.h % 2 == 0)) return false;
-    const long long cols = (a.w + 8 * 62 - 1) / (8 * 62), segs = (a.h / 2 + KF_P5_SEG - 1) / KF_P5_SEG;
+    if (policy == 0) return 0;
+    if ((a.stripes && !a.coef_pk) || a.black < 0) return 0;
+    if (!(a.w >= 16 && a.w % 8 == 0 && a.h >= 2 && a.h % 2 == 0)) return 0;
+    static const int env_seg = [] { const char *e = getenv("MLVFS_AMD_KF_P5_SEG"); return e ? atoi(e) : 0; }();      // (experiments)
+    if (env_seg > 0) return env_seg;
+    // at least 3.5 tasks per wave (k_frame_s.hip: why), in tasks of 60 rows or, for launches half as long, of 30 (two warm-up rows per
+    // task: 3584x1320, us per frame at 50 / 100 / 200 / 400 frames per launch: k_frame_p 7.7 / 7.4 / 7.1 / 6.9, tasks of 60 rows 8.3 /
+    // 7.4 / 6.6 / 6.1, of 30 rows 8.6 / 6.9 / 6.7 / 6.2; profiles/r05/ab_p5.log)
+    const long long cols = (a.w + 8 * 62 - 1) / (8 * 62), rows = a.h / 2;
     const long long waves = (long long)(num_cu > 0 ? num_cu : 256) * 16;
-    return policy == 2 || (long long)a.nframes * cols * segs * 2 >= waves * 7;     // >= 3.5 tasks per wave (k_frame_s.hip: why)
+    for (int seg : { KF_P5_SEG, KF_P5_SEG / 2 })
+        if ((long long)a.nframes * cols * ((rows + seg - 1) / seg) * 2 >= waves * 7) return seg;
+    return policy == 2 ? KF_P5_SEG / 2 : 0;
 }
 void launch_frame_p_kernel(int method, bool packed, int vec, bool spread, int grid, hipStream_t stream, const FrameArgs &a)
 {
 #ifndef KFP_ONLY
-    if (frame_p5_takes(method, packed, vec, grid / 4, a)) {
-        const int cols = (a.w + 8 * 62 - 1) / (8 * 62), segs = (a.h / 2 + KF_P5_SEG - 1) / KF_P5_SEG;
-#define KFP5_GO(S, V) hipLaunchKernelGGL((k_frame_p5<S, V>), dim3(grid), dim3(256), 0, stream, a, cols, segs, (int)KF_P5_SEG)
+    if (const int seg_rows = frame_p5_takes(method, packed, vec, grid / 4, a)) {
+        const int cols = (a.w + 8 * 62 - 1) / (8 * 62), segs = (a.h / 2 + seg_rows - 1) / seg_rows;
+#define KFP5_GO(S, V) hipLaunchKernelGGL((k_frame_p5<S, V>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows)
         if (vec == 2) { if (spread) KFP5_GO(true, 2); else KFP5_GO(false, 2); }
         else { if (spread) KFP5_GO(true, 1); else KFP5_GO(false, 1); }
 #undef KFP5_GO
