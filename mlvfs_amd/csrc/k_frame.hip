@@ -538,6 +538,8 @@ struct StreamState {
     int stat_seen = 0;           // h_stat when it was last looked at
     long long pending_tiles = 0; // tiles of the two-kernel launches whose list counts have not been seen yet
     int wide_left = 0, hold = 0; // launches still to go to k_frame alone; how many after the next busy probe
+    bool some_listed = false;    // the last verdict found more than KF_P5_CALM_PERCENT of the tiles listed: the tile kernel k_frame_p, which
+                                 // skips the tiles behind an uncertain one unseen, does better there than the streaming k_frame_p5
     // the same for the streaming cs2x2 kernel (k_frame_s.hip): its steps that took the loader's form for pixels at or below black,
     // out of all steps (word 1 of h_stat; the cumulative count lives in tickets[S_STAT_AT])
     int s_seen = 0;
@@ -547,6 +549,9 @@ struct StreamState {
 std::mutex g_ticket_mu;
 std::map<std::pair<int, hipStream_t>, StreamState> g_tickets;
 constexpr int TICKET_INTS = 2 * MAX_GROUPS + 1 + 4 + 2;
+#ifndef KF_P5_CALM_PERCENT
+#define KF_P5_CALM_PERCENT 5
+#endif
 constexpr int S_STAT_AT = 2 * MAX_GROUPS + 1 + 4;      // k_frame_s: cumulative dark steps
 #ifndef KF_S_BUSY_PERCENT
 #define KF_S_BUSY_PERCENT 10
@@ -589,6 +594,7 @@ static int stream_state(hipStream_t stream, long long wl_tiles, int policy, Stre
                 const long long listed = (long long)(unsigned)(seen - st.stat_seen);
                 if (seen != st.stat_seen) {
                     const bool busy = listed * 100 > st.pending_tiles * KF_P_BUSY_PERCENT;
+                    st.some_listed = listed * 100 > st.pending_tiles * KF_P5_CALM_PERCENT;
                     if (busy) { st.hold = st.hold ? std::min(2 * st.hold, KF_P_HOLD_MAX) : KF_P_HOLD_MIN; st.wide_left = st.hold; }
                     else st.hold = 0;
                     st.stat_seen = seen;
@@ -760,7 +766,7 @@ static int e2r_table(const Device *dev, int black, const uint2 **out, hipStream_
 // The packed-once kernel (k_frame_p.hip) exists for the chroma-smoothing methods on the vector layouts; everything else is
 // k_frame's alone.  MLVFS_AMD_KF_P=0 sends every launch to k_frame as rounds 1-4 did (A/B).
 bool frame_p_exists(int method, int vec);
-void launch_frame_p_kernel(int method, bool packed, int vec, bool spread, int grid, hipStream_t stream, const FrameArgs &a);
+void launch_frame_p_kernel(int method, bool packed, int vec, bool spread, int grid, hipStream_t stream, const FrameArgs &a, bool prefer_tiles);
 // k_frame_s.hip: cs2x2 as a streaming kernel without barriers (what it takes: frame_s_takes)
 bool frame_s_takes(int method, bool packed, int vec, int num_cu, const FrameArgs &a);
 void launch_frame_s_kernel(int method, bool spread, int vec, int num_cu, hipStream_t stream, const FrameArgs &a);
@@ -837,7 +843,7 @@ static int launch_frame_t(const FrameArgs &a_in, int num_cu, hipStream_t stream)
     if (two) {
         // k_frame_p does every tile whose packed medians are certain and lists the rest; k_frame in list mode does those again
         // (nothing listed: its workgroups end at once).  Both inside the timer's bracket: the pair is the pass.
-        launch_frame_p_kernel(METHOD, PACKED, VEC, SPREAD, grid, stream, a);
+        launch_frame_p_kernel(METHOD, PACKED, VEC, SPREAD, grid, stream, a, st.some_listed);
         a.list_mode = 1;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, stream, a);
     } else
