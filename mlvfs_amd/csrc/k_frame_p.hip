@@ -684,7 +684,7 @@ bool frame_p_exists(int method, int vec)
 #endif
 __device__ __forceinline__ int dpp_prev_ii(int v) { return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, true); }
 template <bool SPREAD, int VEC>
-__global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols, int segs, int seg_rows)
+__global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols, int segs, int seg_rows, int fold)
 {
     constexpr int BPP = 14, S_OUT = 62;
     __shared__ __align__(16) uint16_t t16[MLV_T16_N + (SPREAD ? 64 : 0)];
@@ -696,9 +696,12 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
     const int lane = (int)threadIdx.x & 63;
     const int w = a.w, h = a.h, black = a.black;
     const int rows = h >> 1, gmax = (w >> 3) - 1;
-    const int per_frame = cols * segs, ntasks = cold_args()->nframes * per_frame;
+    // fold > 1: the frame's last column is at most 64 / fold - 2 items wide and a wave takes `fold` of its segments at once, one per
+    // group of 64 / fold lanes (each with its own two halo lanes): 3584 px = 7 columns of 62 items and one of 14 -- 7.25 columns' worth
+    // of steps instead of 8
+    const int ncols_full = fold > 1 ? cols - 1 : cols, nfolded = fold > 1 ? (segs + fold - 1) / fold : 0;
+    const int per_frame = ncols_full * segs + nfolded, ntasks = cold_args()->nframes * per_frame;
     const uint32_t pitch = (uint32_t)(w >> 3) * 14u;
-    const OutArgs oa = out_args(cold_args());
     int *tickets = cold_args()->tickets;
     uint4 (*const mypark)[2][PARK_LANES] = park[threadIdx.x >> 6];
     const int plane = SPREAD ? min(max(lane - 1, 0), 61) : lane;       // the lane's slot (SPREAD: lanes 0 and 63 share their neighbours', unused)
@@ -708,24 +711,29 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
         if (lane == 0) task = atomicAdd(&tickets[0], 1);
         task = __builtin_amdgcn_readfirstlane(task);
         if (task >= ntasks) break;
-        const int f = task / per_frame, rem = task - f * per_frame, c = rem / segs, sg = rem - c * segs;
-        const int j0 = sg * seg_rows, j1 = min(j0 + seg_rows, rows);
-        const int g_true = c * S_OUT + lane - 1;
+        const int f = task / per_frame, rem = task - f * per_frame;
+        const bool folded = rem >= ncols_full * segs;
+        const int c = folded ? ncols_full : rem / segs, sg = folded ? (rem - ncols_full * segs) * fold : rem - c * segs;
+        const int j0 = sg * seg_rows, j1 = min(j0 + seg_rows, rows);              // (of the first group of lanes; the others lie roff rows further down)
+        const int nparts = folded ? fold : 1, P = folded ? 64 / fold : 64;
+        const int pl = lane & (P - 1), part = folded ? lane / P : 0;
+        const int roff = part * seg_rows;
+        const int g_true = c * S_OUT + pl - 1;
         const int g = min(max(g_true, 0), gmax);
-        const bool writes = lane >= 1 && lane <= S_OUT && g_true <= gmax;
+        const bool writes = pl >= 1 && pl <= P - 2 && g_true <= gmax && j0 + roff < rows;
         const uint32_t gbyte = (uint32_t)g * 14u;
         const uint32_t sel = (g & 1) ? SEL_MIS : SEL_SWAP;
         const uint32_t sel1 = VEC == 2 ? sel ^ (SEL_SWAP ^ SEL_MIS) : sel;
         KArgs kt = cold_args();                          // (what a task needs once: read here, not held in scalar registers through the launch)
         const uint8_t *const frame = kt->src + (size_t)f * kt->src_stride;
         const mlv_i32x4 rs_in = frame_rsrc(frame, kt->src_bytes);
-        const mlv_i32x4 rs_out = frame_rsrc(oa.dst + (size_t)f * oa.dst_stride, (uint32_t)w * (uint32_t)h * 2u);
+        const mlv_i32x4 rs_out = frame_rsrc(kt->dst + (size_t)f * kt->dst_stride, (uint32_t)w * (uint32_t)h * 2u);
         const int tx0 = 8 * (c * S_OUT - 1);
         const bool xm = c == 0 || 8 * (c * S_OUT + S_OUT) > w - 4;
         uint32_t dA0[4], dA1[4], dB0[4], dB1[4];
         auto issue = [&](int r, uint32_t (&d0)[4], uint32_t (&d1)[4]) {
-            const int rr = min(max(r, 0), rows - 1);
-            const uint32_t o0 = (__umul24((uint32_t)(2 * rr), pitch) + gbyte) & ~3u, o1 = (__umul24((uint32_t)(2 * rr + 1), pitch) + gbyte) & ~3u;
+            const int rr = min(max(r + roff, 0), rows - 1);
+            const uint32_t o0u = __umul24((uint32_t)(2 * rr), pitch) + gbyte, o0 = o0u & ~3u, o1 = (o0u + pitch) & ~3u;
             const mlv_u32x2 a0 = mlv_rbl_x2(rs_in, (int)o0, 0, KF_SRC_AUX), b0 = mlv_rbl_x2(rs_in, (int)o0 + 8, 0, KF_SRC_AUX);
             const mlv_u32x2 a1 = mlv_rbl_x2(rs_in, (int)o1, 0, KF_SRC_AUX), b1 = mlv_rbl_x2(rs_in, (int)o1 + 8, 0, KF_SRC_AUX);
             d0[0] = a0.x; d0[1] = a0.y; d0[2] = b0.x; d0[3] = b0.y;
@@ -768,34 +776,40 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
             const int4 *cells = ka->cells + (size_t)f * ka->n_rec;
             const int *toff = ka->tile_off;
             const int tx_n = ka->tiles_x, ty_n = ka->tiles_y;
-            const int cx_lo = 4 * (c * S_OUT - 1), cx_hi = cx_lo + 256;        // cells of lanes 0 .. 63
-            const int cy_lo = j0 - 2, cy_hi = j1 + 2;
+            const int cx_lo = 4 * (c * S_OUT - 1), cx_hi = cx_lo + 4 * P;      // cells of a group's lanes
             const int tc0 = max(cx_lo - HC, 0) / TCW, tc1 = min((cx_hi - 1 + HC) / TCW, tx_n - 1);
-            const int tr0 = max(cy_lo, 0) / TCH, tr1 = min((cy_hi - 1) / TCH, ty_n - 1), ntr = tr1 - tr0 + 1;
-            constexpr int MAXTR = 6;
-            int my_lo = 0, my_hi = 0;
-            if (lane < ntr && lane < MAXTR) { my_lo = toff[(tr0 + lane) * tx_n + tc0]; my_hi = toff[(tr0 + lane) * tx_n + tc1 + 1]; }
-            if (ntr > MAXTR) list_all = true;
-            int4 rec[MAXTR];
+            for (int q = 0; q < nparts; q++) {
+                const int j0q = j0 + q * seg_rows, j1q = min(j0q + seg_rows, rows);
+                if (j0q >= rows) break;
+                const int cy_lo = j0q - 2, cy_hi = j1q + 2;
+                const int tr0 = max(cy_lo, 0) / TCH, tr1 = min((cy_hi - 1) / TCH, ty_n - 1), ntr = tr1 - tr0 + 1;
+                constexpr int MAXTR = 6;
+                int my_lo = 0, my_hi = 0;
+                if (lane < ntr && lane < MAXTR) { my_lo = toff[(tr0 + lane) * tx_n + tc0]; my_hi = toff[(tr0 + lane) * tx_n + tc1 + 1]; }
+                if (ntr > MAXTR) list_all = true;
+                int4 rec[MAXTR];
 #pragma unroll
-            for (int i = 0; i < MAXTR; i++) {
-                const int rb = __builtin_amdgcn_readlane(my_lo, i), re = __builtin_amdgcn_readlane(my_hi, i);
-                rec[i] = (i < ntr && rb + lane < re) ? cells[rb + lane] : make_int4(-1, 0, 0, 0);
-                if (i < ntr && re - rb > 64) list_all = true;
-            }
+                for (int i = 0; i < MAXTR; i++) {
+                    const int rb = __builtin_amdgcn_readlane(my_lo, i), re = __builtin_amdgcn_readlane(my_hi, i);
+                    rec[i] = (i < ntr && rb + lane < re) ? cells[rb + lane] : make_int4(-1, 0, 0, 0);
+                    if (i < ntr && re - rb > 64) list_all = true;
+                }
 #pragma unroll
-            for (int i = 0; i < MAXTR; i++) {
-                const int rcx = rec[i].x & 0xFFFF, rcy = rec[i].x >> 16;
-                const bool in = rec[i].x >= 0 && rcx >= cx_lo && rcx < cx_hi && rcy >= cy_lo && rcy < cy_hi && rcy / TCH == tr0 + i;
-                unsigned long long m = __ballot(in);
-                while (m) {
-                    const int src = __builtin_ctzll(m);
-                    m &= m - 1;
-                    if (n_pm < 64) {
-                        const int vx = __builtin_amdgcn_readlane(rec[i].x, src), vy = __builtin_amdgcn_readlane(rec[i].y, src), vz = __builtin_amdgcn_readlane(rec[i].z, src);
-                        if (lane == n_pm) { pm_cell = vx; pm_top = (uint32_t)vy; pm_bot = (uint32_t)vz; }
-                        n_pm++;
-                    } else list_all = true;
+                for (int i = 0; i < MAXTR; i++) {
+                    const int rcx = rec[i].x & 0xFFFF, rcy = rec[i].x >> 16;
+                    const bool in = rec[i].x >= 0 && rcx >= cx_lo && rcx < cx_hi && rcy >= cy_lo && rcy < cy_hi && rcy / TCH == tr0 + i;
+                    unsigned long long m = __ballot(in);
+                    while (m) {
+                        const int src = __builtin_ctzll(m);
+                        m &= m - 1;
+                        if (n_pm < 64) {
+                            const int vx = __builtin_amdgcn_readlane(rec[i].x, src), vy = __builtin_amdgcn_readlane(rec[i].y, src), vz = __builtin_amdgcn_readlane(rec[i].z, src);
+                            // kept as (the step that loads the cell's row) << 16 | (lane << 2 | cell of the lane's four)
+                            const int at = (((vx >> 16) - q * seg_rows) << 16) | (4 * P * q + (vx & 0xFFFF) - cx_lo);
+                            if (lane == n_pm) { pm_cell = at; pm_top = (uint32_t)vy; pm_bot = (uint32_t)vz; }
+                            n_pm++;
+                        } else list_all = true;
+                    }
                 }
             }
         }
@@ -816,7 +830,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
                     m &= m - 1;
                     const int cell = __builtin_amdgcn_readlane(pm_cell, src);
                     const uint32_t t_ = (uint32_t)__builtin_amdgcn_readlane((int)pm_top, src), b_ = (uint32_t)__builtin_amdgcn_readlane((int)pm_bot, src);
-                    const int cxr = (cell & 0xFFFF) - 4 * (c * S_OUT - 1);                 // cell within the wave's 256
+                    const int cxr = cell & 0xFFFF;                                         // cell within the wave's 256
                     const bool mine = (cxr >> 2) == lane;
                     const int cc = cxr & 3;
 #pragma unroll
@@ -852,9 +866,10 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) { pkr[0][i] = pkr[1][i]; pkr[1][i] = pkr[2][i]; pkr[2][i] = pkr[3][i]; pkr[3][i] = pkr[4][i]; pkr[4][i] = pk[i]; }
-            const int jr = r - 2, y = 2 * jr;
+            const int jr = r - 2, y = 2 * jr, yl = y + 2 * roff;
             if (jr >= j0 && jr < j1) {
-                const bool smooth_row = y >= 4 && y < h - 5;                               // chroma_smooth.c:25
+                const unsigned long long msmooth = lanes_ge(yl, 4) & lanes_lt(yl, h - 5);  // chroma_smooth.c:25
+                const bool smooth_row = y + 2 * (nparts - 1) * seg_rows >= 4 && y < h - 5; // (some group's row)
                 mlv_pk16 o[STRIP] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
                 if (smooth_row) {
                     PGroup gq;
@@ -879,7 +894,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
                     // group and the next one): the lane's own cells 0, 1 come from the lane before
                     o[0] = as_pk((uint32_t)dpp_prev_ii((int)as_u(oc[2]))); o[1] = as_pk((uint32_t)dpp_prev_ii((int)as_u(oc[3])));
                     o[2] = oc[0]; o[3] = oc[1];
-                    const unsigned long long um = __ballot(writes && pk_uncertain(o));
+                    const unsigned long long um = __ballot(writes && pk_uncertain(o)) & msmooth;
                     if (um) { unc_lanes |= um; unc_r0 = min(unc_r0, jr); unc_r1 = max(unc_r1, jr); }
                 }
                 int er[STRIP], eb[STRIP];
@@ -895,9 +910,9 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
                     top[0] = t4.x; top[1] = t4.y; top[2] = t4.z; top[3] = t4.w;
                     bot[0] = b4.x; bot[1] = b4.y; bot[2] = b4.z; bot[3] = b4.w;
                 }
-                const unsigned long long msmooth = lanes_ge(y, 4) & lanes_lt(y, h - 5);
+                const OutArgs oa = out_args(cold_args());          // (read here, not held through the step: 39 -> 17 spilled scalars)
                 const int fl = fl0 | fl1 | fl2 | fl3 | fl4;                                 // the five rows of the window
-#define KFP5_OUT(CLAMP, XM, BRIGHT) strip_output_t<5, true, true, CLAMP, XM, false, BRIGHT, NoSmem, true>(NoSmem(), oa, w, h, black, f, tx0, 0, jr, lane, msmooth, \
+#define KFP5_OUT(CLAMP, XM, BRIGHT) strip_output_t<5, true, true, CLAMP, XM, false, BRIGHT, NoSmem, true>(NoSmem(), oa, w, h, black, f, tx0, 0, jr, pl, msmooth, \
                                                                                                           ge2, 0, er, eb, false, top, bot)
                 if (fl & 1) { if (xm) KFP5_OUT(true, true, false); else KFP5_OUT(true, false, false); }
                 else if (xm) KFP5_OUT(false, true, false);
@@ -905,7 +920,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
                 else KFP5_OUT(false, false, false);
 #undef KFP5_OUT
                 if (writes) {
-                    const uint32_t vo = (__umul24((uint32_t)y, (uint32_t)w) + (uint32_t)(8 * g)) * 2u;
+                    const uint32_t vo = (__umul24((uint32_t)yl, (uint32_t)w) + (uint32_t)(8 * g)) * 2u;  // (rows below the frame: beyond the buffer's range)
                     const mlv_u32x4 vt = { top[0], top[1], top[2], top[3] }, vb_ = { bot[0], bot[1], bot[2], bot[3] };
                     mlv_rbs_x4(vt, rs_out, (int)vo, 0, 2);
                     mlv_rbs_x4(vb_, rs_out, (int)vo, w * 2, 2);
@@ -922,16 +937,21 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
         // ---- what this task could not settle goes to k_frame: the tiles (64 x 15 cells) its uncertain strips lie in
         if (list_all) { unc_lanes = ~0ull; unc_r0 = j0; unc_r1 = j1 - 1; }
         if (unc_lanes && lane == 0) {
-            const int l0 = __builtin_ctzll(unc_lanes), l1 = 63 - __builtin_clzll(unc_lanes);
-            const int cx0 = max(4 * (c * S_OUT + l0 - 1), 0), cx1 = min(4 * (c * S_OUT + l1 - 1) + 3, w / 2 - 1);
             KArgs kl = cold_args();
             const int tnx = kl->tiles_x, tny = kl->tiles_y;
-            const int tc0 = cx0 / TCW, tc1 = min(cx1 / TCW, tnx - 1), tr0 = unc_r0 / TCH, tr1 = min(unc_r1 / TCH, tny - 1);
             int *ctl = kl->wl_ctl;
-            for (int tc = tc0; tc <= tc1; tc++) {
-                const int i = atomicAdd(&ctl[0], 1);
-                kl->wl[i] = make_int2(f * tnx * tny + tc * tny + tr0, tr1 - tr0 + 1);
-                atomicAdd(&ctl[3], tr1 - tr0 + 1);
+            for (int q = 0; q < nparts; q++) {
+                const unsigned long long mq = P == 64 ? unc_lanes : (unc_lanes >> (q * P)) & ((1ull << P) - 1);
+                const int r0 = unc_r0 + q * seg_rows, r1 = min(unc_r1 + q * seg_rows, rows - 1);
+                if (!mq || r0 >= rows) continue;
+                const int l0 = __builtin_ctzll(mq), l1 = 63 - __builtin_clzll(mq);
+                const int cx0 = max(4 * (c * S_OUT + l0 - 1), 0), cx1 = min(4 * (c * S_OUT + l1 - 1) + 3, w / 2 - 1);
+                const int tc0 = cx0 / TCW, tc1 = min(cx1 / TCW, tnx - 1), tr0 = r0 / TCH, tr1 = min(r1 / TCH, tny - 1);
+                for (int tc = tc0; tc <= tc1; tc++) {
+                    const int i = atomicAdd(&ctl[0], 1);
+                    kl->wl[i] = make_int2(f * tnx * tny + tc * tny + tr0, tr1 - tr0 + 1);
+                    atomicAdd(&ctl[3], tr1 - tr0 + 1);
+                }
             }
         }
     }
@@ -971,7 +991,12 @@ void launch_frame_p_kernel(int method, bool packed, int vec, bool spread, int gr
     if (prefer_tiles && !(e5 && atoi(e5) == 2)) {}
     else if (const int seg_rows = frame_p5_takes(method, packed, vec, grid / 4, a)) {
         const int cols = (a.w + 8 * 62 - 1) / (8 * 62), segs = (a.h / 2 + seg_rows - 1) / seg_rows;
-#define KFP5_GO(S, V) hipLaunchKernelGGL((k_frame_p5<S, V>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows)
+        // a narrow last column: several of its segments side by side in one wave (k_frame_p5: fold)
+        static const int env_fold = [] { const char *e = getenv("MLVFS_AMD_KF_P5_FOLD"); return e ? atoi(e) : -1; }();           // (experiments: 1 = never)
+        const int last_items = a.w / 8 - (cols - 1) * 62;
+        int fold = last_items + 2 <= 16 ? 4 : last_items + 2 <= 32 ? 2 : 1;
+        if (segs < 2 || env_fold == 1) fold = 1;
+#define KFP5_GO(S, V) hipLaunchKernelGGL((k_frame_p5<S, V>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows, fold)
         if (vec == 2) { if (spread) KFP5_GO(true, 2); else KFP5_GO(false, 2); }
         else { if (spread) KFP5_GO(true, 1); else KFP5_GO(false, 1); }
 #undef KFP5_GO

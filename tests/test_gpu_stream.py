@@ -121,7 +121,7 @@ def test_streaming_kernel_matches_oracle(torch_cuda, oracle, w, h, cs, stripes, 
             assert np.array_equal(out["0"][k], want[k]), f"{kind} frame {k}: k_frame"
 
 
-@pytest.mark.parametrize("w,h", [(256, 130), (1008, 64), (16, 12), (496, 122), (512, 124), (1736, 64), (3584, 66)])
+@pytest.mark.parametrize("w,h", [(256, 130), (1008, 64), (16, 12), (496, 122), (512, 124), (1736, 64), (3584, 66), (656, 190), (608, 250)])
 @pytest.mark.parametrize("bad,stripes", [(0, 0), (1, 1), (2, 0)])
 def test_streaming_cs5x5_kernel_matches_oracle(torch_cuda, oracle, w, h, bad, stripes, monkeypatch):
     """k_frame_p5 (the packed-once pass as a streaming kernel: a wave per 62-item column, the five packed rows of the window in
