@@ -1192,6 +1192,16 @@ __device__ __forceinline__ unsigned long long lanes_lt(int a, int b) { return __
 //   RAWREG (k_frame_s): the strip's pixels come in registers (rtop / rbot) instead of from the tile's LDS rows, and go back there
 //   (store = false: the caller stores them).
 struct NoSmem {};
+// The streaming kernels' (k_frame_s, k_frame_p5) columns are 62 items wide.  A last column of at most 14 (30) items is folded: a
+// wave takes four (two) of its segments side by side, one per group of 16 (32) lanes, each group with its own two halo lanes.
+// MLVFS_AMD_KF_FOLD=1: never (A/B).
+static inline int frame_stream_fold(int w, int cols, int segs)
+{
+    static const int env_fold = [] { const char *e = getenv("MLVFS_AMD_KF_FOLD"); return e ? atoi(e) : 0; }();
+    const int last_items = w / 8 - (cols - 1) * 62;
+    if (segs < 2 || env_fold == 1) return 1;
+    return last_items + 2 <= 16 ? 4 : last_items + 2 <= 32 ? 2 : 1;
+}
 template <int METHOD, bool PACKED, bool VECST, bool CLAMP, bool XM, bool ANYSTRIPES, bool BRIGHT, class SM, bool RAWREG = false>
 __device__ __forceinline__ void strip_output_t(const SM &sm, const OutArgs &oa, int w, int h, int black, int f, int tx0, int ty0, int jj, int kk,
                                                unsigned long long msmooth, const int (&gev)[STRIP], int gev_off, const int (&er)[STRIP], const int (&eb)[STRIP], bool store,

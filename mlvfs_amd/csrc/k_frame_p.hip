@@ -992,10 +992,7 @@ void launch_frame_p_kernel(int method, bool packed, int vec, bool spread, int gr
     else if (const int seg_rows = frame_p5_takes(method, packed, vec, grid / 4, a)) {
         const int cols = (a.w + 8 * 62 - 1) / (8 * 62), segs = (a.h / 2 + seg_rows - 1) / seg_rows;
         // a narrow last column: several of its segments side by side in one wave (k_frame_p5: fold)
-        static const int env_fold = [] { const char *e = getenv("MLVFS_AMD_KF_P5_FOLD"); return e ? atoi(e) : -1; }();           // (experiments: 1 = never)
-        const int last_items = a.w / 8 - (cols - 1) * 62;
-        int fold = last_items + 2 <= 16 ? 4 : last_items + 2 <= 32 ? 2 : 1;
-        if (segs < 2 || env_fold == 1) fold = 1;
+        const int fold = frame_stream_fold(a.w, cols, segs);
 #define KFP5_GO(S, V) hipLaunchKernelGGL((k_frame_p5<S, V>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows, fold)
         if (vec == 2) { if (spread) KFP5_GO(true, 2); else KFP5_GO(false, 2); }
         else { if (spread) KFP5_GO(true, 1); else KFP5_GO(false, 1); }

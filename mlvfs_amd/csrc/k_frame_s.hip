@@ -48,7 +48,7 @@ __device__ __forceinline__ int dpp_prev_i(int v) { return __builtin_amdgcn_mov_d
 // METHOD = 2: the plus-shaped five; METHOD = 3: the 3x3 nine (chroma_smooth.c with CHROMA_SMOOTH_3X3) -- the same rows in registers,
 // sorted columns of three (k_frame_dev.h: strip_median9's scheme), the neighbouring lanes' edge columns by DPP
 template <bool SPREAD, int VEC, int METHOD>
-__global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, int cols, int segs, int seg_rows)
+__global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, int cols, int segs, int seg_rows, int fold)
 {
     constexpr int BPP = 14;
     __shared__ __align__(16) uint16_t t16[MLV_T16_N + (SPREAD ? 64 : 0)];
@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
     const int lane = (int)threadIdx.x & 63;
     const int w = a.w, h = a.h, black = a.black;
     const int rows = h >> 1, gmax = (w >> 3) - 1;
-    const int per_frame = cols * segs, ntasks = a.nframes * per_frame;
+    // fold > 1: a last column of at most 64 / fold - 2 items, `fold` of its segments side by side in one wave (k_frame_p.hip: k_frame_p5)
+    const int ncols_full = fold > 1 ? cols - 1 : cols, nfolded = fold > 1 ? (segs + fold - 1) / fold : 0;
+    const int per_frame = ncols_full * segs + nfolded, ntasks = a.nframes * per_frame;
     const uint32_t pitch = (uint32_t)(w >> 3) * 14u;     // bytes per pixel row (VEC 1: a multiple of 28, rows start dword-aligned)
     const OutArgs oa = out_args(cold_args());
     int *tickets = a.tickets;
@@ -70,13 +72,17 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
         if (lane == 0) task = atomicAdd(&tickets[0], 1);
         task = __builtin_amdgcn_readfirstlane(task);
         if (task >= ntasks) break;
-        const int f = task / per_frame, rem = task - f * per_frame, c = rem / segs, sg = rem - c * segs;
-        const int j0 = sg * seg_rows, j1 = min(j0 + seg_rows, rows);
+        const int f = task / per_frame, rem = task - f * per_frame;
+        const bool folded = rem >= ncols_full * segs;
+        const int c = folded ? ncols_full : rem / segs, sg = folded ? (rem - ncols_full * segs) * fold : rem - c * segs;
+        const int j0 = sg * seg_rows, j1 = min(j0 + seg_rows, rows);              // (of the first group of lanes; the others lie roff rows further down)
+        const int nparts = folded ? fold : 1, P = folded ? 64 / fold : 64;
+        const int pl = lane & (P - 1), roff = folded ? lane / P * seg_rows : 0;
         // the lane's 8-pixel group; lanes outside the frame (the halo lanes of the first and last column, the lanes behind a narrow
         // last column) take a group inside it: their values are never used, and never "dark"
-        const int g_true = c * S_OUT + lane - 1;
+        const int g_true = c * S_OUT + pl - 1;
         const int g = min(max(g_true, 0), gmax);
-        const bool writes = lane >= 1 && lane <= S_OUT && g_true <= gmax;
+        const bool writes = pl >= 1 && pl <= P - 2 && g_true <= gmax && j0 + roff < rows;
         const uint32_t gbyte = (uint32_t)g * 14u;
         const bool mis = (g & 1) != 0;                   // the group starts in the upper half of a dword
         const uint32_t sel = mis ? SEL_MIS : SEL_SWAP;
@@ -91,8 +97,8 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
         uint4 (*const mypark)[2][64] = park[threadIdx.x >> 6];
 #endif
         auto issue = [&](int r, uint32_t (&d0)[4], uint32_t (&d1)[4]) {
-            const int rr = min(max(r, 0), rows - 1);     // (rows above / below the frame: never used either)
-            const uint32_t o0 = (__umul24((uint32_t)(2 * rr), pitch) + gbyte) & ~3u, o1 = (__umul24((uint32_t)(2 * rr + 1), pitch) + gbyte) & ~3u;
+            const int rr = min(max(r + roff, 0), rows - 1);     // (rows above / below the frame: never used either)
+            const uint32_t o0u = __umul24((uint32_t)(2 * rr), pitch) + gbyte, o0 = o0u & ~3u, o1 = (o0u + pitch) & ~3u;
             const mlv_u32x2 a0 = mlv_rbl_x2(rs_in, (int)o0, 0, KF_SRC_AUX), b0 = mlv_rbl_x2(rs_in, (int)o0 + 8, 0, KF_SRC_AUX);
             const mlv_u32x2 a1 = mlv_rbl_x2(rs_in, (int)o1, 0, KF_SRC_AUX), b1 = mlv_rbl_x2(rs_in, (int)o1 + 8, 0, KF_SRC_AUX);
             d0[0] = a0.x; d0[1] = a0.y; d0[2] = b0.x; d0[3] = b0.y;
@@ -153,8 +159,8 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
 #endif
             if (r - 1 >= j0) {
                 // ---- row r - 1: medians of the plus-shaped five, then k_frame's output stage on registers
-                const int jr = r - 1, y = 2 * jr;
-                const bool smooth_row = y >= 4 && y < h - 5;                                   // chroma_smooth.c:25 (scalar)
+                const int jr = r - 1, y = 2 * jr, yl = y + 2 * roff;
+                const bool smooth_row = y + 2 * (nparts - 1) * seg_rows >= 4 && y < h - 5;     // chroma_smooth.c:25 (scalar: some group's row)
                 int er[STRIP] = { 0, 0, 0, 0 }, eb[STRIP] = { 0, 0, 0, 0 };
 #if KF_S_PARK
                 uint32_t top1[STRIP], bot1[STRIP];
@@ -197,10 +203,10 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
                     med9(dr2, dr1, dr, er);
                     med9(db2, db1, db, eb);
                 }
-                const unsigned long long msmooth = lanes_ge(y, 4) & lanes_lt(y, h - 5);       // (a lane mask in a register pair: put_rb moves it to VCC)
+                const unsigned long long msmooth = lanes_ge(yl, 4) & lanes_lt(yl, h - 5);       // (a lane mask in a register pair: put_rb moves it to VCC)
                 const int fl = flags0 | flags1 | flags2;
                 // (the variants of strip_output, chosen by scalars: margins, low pixels, bright rows)
-#define KFS_OUT(CLAMP, XM, BRIGHT) strip_output_t<METHOD, true, true, CLAMP, XM, false, BRIGHT, NoSmem, true>(NoSmem(), oa, w, h, black, f, tx0, 0, jr, lane, msmooth, \
+#define KFS_OUT(CLAMP, XM, BRIGHT) strip_output_t<METHOD, true, true, CLAMP, XM, false, BRIGHT, NoSmem, true>(NoSmem(), oa, w, h, black, f, tx0, 0, jr, pl, msmooth, \
                                                                                                          ge1, 0, er, eb, false, top1, bot1)
                 if (fl & 1) { if (xm) KFS_OUT(true, true, false); else KFS_OUT(true, false, false); }
                 else if (xm) KFS_OUT(false, true, false);
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
                 else KFS_OUT(false, false, false);
 #undef KFS_OUT
                 if (writes) {
-                    const uint32_t vo = (__umul24((uint32_t)y, (uint32_t)w) + (uint32_t)(8 * g)) * 2u;
+                    const uint32_t vo = (__umul24((uint32_t)yl, (uint32_t)w) + (uint32_t)(8 * g)) * 2u;     // (rows below the frame: beyond the buffer's range)
                     const mlv_u32x4 vt = { top1[0], top1[1], top1[2], top1[3] }, vb_ = { bot1[0], bot1[1], bot1[2], bot1[3] };
                     mlv_rbs_x4(vt, rs_out, (int)vo, 0, 2);                                     // (2: non-temporal)
                     mlv_rbs_x4(vb_, rs_out, (int)vo, w * 2, 2);
@@ -264,7 +270,8 @@ bool frame_s_takes(int method, bool packed, int vec, int num_cu, const FrameArgs
 long long frame_s_steps(const FrameArgs &a)
 {
     const long long cols = (a.w + 8 * S_OUT - 1) / (8 * S_OUT);
-    return (long long)a.nframes * cols * (a.h / 2);
+    const int fold = frame_stream_fold(a.w, (int)cols, (a.h / 2 + KF_S_SEG - 1) / KF_S_SEG);
+    return (long long)a.nframes * ((cols - 1) * fold + 1) * (a.h / 2) / fold;
 }
 
 void launch_frame_s_kernel(int method, bool spread, int vec, int num_cu, hipStream_t stream, const FrameArgs &a)
@@ -272,10 +279,11 @@ void launch_frame_s_kernel(int method, bool spread, int vec, int num_cu, hipStre
     const int cols = (a.w + 8 * S_OUT - 1) / (8 * S_OUT), rows = a.h / 2;
     static const int env_seg = [] { const char *e = getenv("MLVFS_AMD_KF_S_SEG"); return e ? atoi(e) : 0; }();
     const int seg_rows = std::max(env_seg > 0 ? env_seg : KF_S_SEG, 1), segs = (rows + seg_rows - 1) / seg_rows;
-    const long long tasks = (long long)a.nframes * cols * segs;
+    const int fold = frame_stream_fold(a.w, cols, segs);
+    const long long tasks = (long long)a.nframes * (fold > 1 ? (cols - 1) * segs + (segs + fold - 1) / fold : cols * segs);
     int grid = (num_cu > 0 ? num_cu : 256) * KF_S_WGS;   // five workgroups per CU: 20 waves, 80 KiB of LDS (five copies of the table)
     if ((long long)grid * 4 > tasks) grid = (int)((tasks + 3) / 4);
-#define KFS_GO(S, V, M) hipLaunchKernelGGL((k_frame_s<S, V, M>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows)
+#define KFS_GO(S, V, M) hipLaunchKernelGGL((k_frame_s<S, V, M>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows, fold)
 #define KFS_M(S, V) do { if (method == 3) KFS_GO(S, V, 3); else KFS_GO(S, V, 2); } while (0)
     if (vec == 2) { if (spread) KFS_M(true, 2); else KFS_M(false, 2); }
     else { if (spread) KFS_M(true, 1); else KFS_M(false, 1); }

@@ -92,7 +92,7 @@ def test_fused_pipeline_rows_of_half_groups(torch_cuda, oracle, w, h, cs):
         s.close()
 
 
-@pytest.mark.parametrize("w,h", [(256, 130), (1008, 44), (16, 12), (48, 10), (496, 122), (512, 124), (1736, 64), (136, 62), (3584, 66)])
+@pytest.mark.parametrize("w,h", [(256, 130), (1008, 44), (16, 12), (48, 10), (496, 122), (512, 124), (1736, 64), (136, 62), (3584, 66), (608, 250), (656, 190), (3584, 252)])
 @pytest.mark.parametrize("cs,stripes", [(2, 0), (2, 1), (3, 0), (3, 1)])
 def test_streaming_kernel_matches_oracle(torch_cuda, oracle, w, h, cs, stripes, monkeypatch):
     """k_frame_s (cs2x2 / cs3x3 without a pixel map: a wave per 62-item column, rows in registers, no barriers) takes long launches only
