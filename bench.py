@@ -801,7 +801,7 @@ def main():
     streaming = False
     if two_kernels and os.environ.get("MLVFS_AMD_KF_P5", "1") != "0":
         cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-        tasks = F * ((W + 495) // 496) * ((H // 2 + 29) // 30)             # (tasks of 60 rows, or of 30 for launches half as long)
+        tasks = F * ((W // 8 + 61) // 62) * ((H // 2 + 29) // 30)           # (tasks of 60 rows, or of 30 for launches half as long)
         streaming = os.environ.get("MLVFS_AMD_KF_P5") == "2" or tasks * 2 >= cus * 16 * 7
     first_pass = "void mlv::k_frame_p5<false, 1>(mlv::FrameArgs, int, int, int, int)" if streaming else "void mlv::k_frame_p<5, true, 1, false>(mlv::FrameArgs)"
     result = {

@@ -684,9 +684,9 @@ bool frame_p_exists(int method, int vec)
 #endif
 __device__ __forceinline__ int dpp_prev_ii(int v) { return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, true); }
 template <bool SPREAD, int VEC>
-__global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols, int segs, int seg_rows, int fold)
+__global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols, int segs, int seg_rows, int fold, int S_OUT)
 {
-    constexpr int BPP = 14, S_OUT = 62;
+    constexpr int BPP = 14;                              // (S_OUT: items a wave writes per row, k_frame_dev.h: frame_stream_colw)
     __shared__ __align__(16) uint16_t t16[MLV_T16_N + (SPREAD ? 64 : 0)];
     // (the dark-clip table layout is 128 bytes longer: there only the 62 lanes that write a row park it, which keeps the workgroup at 40 KiB)
     constexpr int PARK_LANES = SPREAD ? 62 : 64;
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256, 4) void k_frame_p5(const FrameArgs a, int cols
         const int roff = part * seg_rows;
         const int g_true = c * S_OUT + pl - 1;
         const int g = min(max(g_true, 0), gmax);
-        const bool writes = pl >= 1 && pl <= P - 2 && g_true <= gmax && j0 + roff < rows;
+        const bool writes = pl >= 1 && pl <= min(S_OUT, P - 2) && g_true <= gmax && j0 + roff < rows;
         const uint32_t gbyte = (uint32_t)g * 14u;
         const uint32_t sel = (g & 1) ? SEL_MIS : SEL_SWAP;
         const uint32_t sel1 = VEC == 2 ? sel ^ (SEL_SWAP ^ SEL_MIS) : sel;
@@ -993,7 +993,7 @@ static int frame_p5_takes(int method, bool packed, int vec, int num_cu, const Fr
     // at least 3.5 tasks per wave (k_frame_s.hip: why), in tasks of 60 rows or, for launches half as long, of 30 (two warm-up rows per
     // task: 3584x1320, us per frame at 50 / 100 / 200 / 400 frames per launch: k_frame_p 7.7 / 7.4 / 7.1 / 6.9, tasks of 60 rows 8.3 /
     // 7.4 / 6.6 / 6.1, of 30 rows 8.6 / 6.9 / 6.7 / 6.2; profiles/r05/ab_p5.log)
-    const long long cols = (a.w + 8 * 62 - 1) / (8 * 62), rows = a.h / 2;
+    const long long cols = frame_stream_cols(a.w), rows = a.h / 2;
     const long long waves = (long long)(num_cu > 0 ? num_cu : 256) * 16;
     for (int seg : { KF_P5_SEG, KF_P5_SEG / 2 })
         if ((long long)a.nframes * cols * ((rows + seg - 1) / seg) * 2 >= waves * 7) return seg;
@@ -1008,10 +1008,10 @@ void launch_frame_p_kernel(int method, bool packed, int vec, bool spread, int gr
     const char *e5 = getenv("MLVFS_AMD_KF_P5");
     if (prefer_tiles && !(e5 && atoi(e5) == 2)) {}
     else if (const int seg_rows = frame_p5_takes(method, packed, vec, grid / 4, a)) {
-        const int cols = (a.w + 8 * 62 - 1) / (8 * 62), segs = (a.h / 2 + seg_rows - 1) / seg_rows;
+        const int cols = frame_stream_cols(a.w), segs = (a.h / 2 + seg_rows - 1) / seg_rows;
         // a narrow last column: several of its segments side by side in one wave (k_frame_p5: fold)
         const int fold = frame_stream_fold(a.w, cols, segs);
-#define KFP5_GO(S, V) hipLaunchKernelGGL((k_frame_p5<S, V>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows, fold)
+#define KFP5_GO(S, V) hipLaunchKernelGGL((k_frame_p5<S, V>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows, fold, frame_stream_colw())
         if (vec == 2) { if (spread) KFP5_GO(true, 2); else KFP5_GO(false, 2); }
         else { if (spread) KFP5_GO(true, 1); else KFP5_GO(false, 1); }
 #undef KFP5_GO

@@ -24,7 +24,6 @@
 
 namespace mlv {
 
-constexpr int S_OUT = 62;             // output items per wave and row (lanes 1..62)
 #ifndef KF_S_SEG
 #define KF_S_SEG 60
 #endif
@@ -48,7 +47,7 @@ __device__ __forceinline__ int dpp_prev_i(int v) { return __builtin_amdgcn_mov_d
 // METHOD = 2: the plus-shaped five; METHOD = 3: the 3x3 nine (chroma_smooth.c with CHROMA_SMOOTH_3X3) -- the same rows in registers,
 // sorted columns of three (k_frame_dev.h: strip_median9's scheme), the neighbouring lanes' edge columns by DPP
 template <bool SPREAD, int VEC, int METHOD>
-__global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, int cols, int segs, int seg_rows, int fold)
+__global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, int cols, int segs, int seg_rows, int fold, int S_OUT)
 {
     constexpr int BPP = 14;
     __shared__ __align__(16) uint16_t t16[MLV_T16_N + (SPREAD ? 64 : 0)];
@@ -82,7 +81,7 @@ __global__ __launch_bounds__(256, KF_S_WGS) void k_frame_s(const FrameArgs a, in
         // last column) take a group inside it: their values are never used, and never "dark"
         const int g_true = c * S_OUT + pl - 1;
         const int g = min(max(g_true, 0), gmax);
-        const bool writes = pl >= 1 && pl <= P - 2 && g_true <= gmax && j0 + roff < rows;
+        const bool writes = pl >= 1 && pl <= min(S_OUT, P - 2) && g_true <= gmax && j0 + roff < rows;
         const uint32_t gbyte = (uint32_t)g * 14u;
         const bool mis = (g & 1) != 0;                   // the group starts in the upper half of a dword
         const uint32_t sel = mis ? SEL_MIS : SEL_SWAP;
@@ -261,7 +260,7 @@ bool frame_s_takes(int method, bool packed, int vec, int num_cu, const FrameArgs
     // Long launches only: a task is a column of 60 rows (~50 us of one wave), and a wave needs a handful of them for the chip to end
     // together -- 3584x1320, us per frame at 8 / 25 / 50 / 100 / 200 / 400 frames per launch: k_frame 10.7 / 5.7 / 5.7 / 5.5 / 5.3 / 4.9,
     // this kernel 13.1 / 7.3 / 7.1 / 5.5 / 5.0 / 4.8 (shorter tasks do not help: two rows of warm-up each; profiles/r05/ab_kframe_s.log)
-    const long long cols = (a.w + 8 * S_OUT - 1) / (8 * S_OUT), segs = (a.h / 2 + KF_S_SEG - 1) / KF_S_SEG;
+    const long long cols = frame_stream_cols(a.w), segs = (a.h / 2 + KF_S_SEG - 1) / KF_S_SEG;
     const long long waves = (long long)(num_cu > 0 ? num_cu : 256) * KF_S_WGS * 4;
     return policy == 2 || (long long)a.nframes * cols * segs * 2 >= waves * 7;             // >= 3.5 tasks per wave
 }
@@ -269,21 +268,21 @@ bool frame_s_takes(int method, bool packed, int vec, int num_cu, const FrameArgs
 // wave-steps of a launch (what the dark steps it reports are a share of)
 long long frame_s_steps(const FrameArgs &a)
 {
-    const long long cols = (a.w + 8 * S_OUT - 1) / (8 * S_OUT);
+    const long long cols = frame_stream_cols(a.w);
     const int fold = frame_stream_fold(a.w, (int)cols, (a.h / 2 + KF_S_SEG - 1) / KF_S_SEG);
     return (long long)a.nframes * ((cols - 1) * fold + 1) * (a.h / 2) / fold;
 }
 
 void launch_frame_s_kernel(int method, bool spread, int vec, int num_cu, hipStream_t stream, const FrameArgs &a)
 {
-    const int cols = (a.w + 8 * S_OUT - 1) / (8 * S_OUT), rows = a.h / 2;
+    const int cols = frame_stream_cols(a.w), rows = a.h / 2;
     static const int env_seg = [] { const char *e = getenv("MLVFS_AMD_KF_S_SEG"); return e ? atoi(e) : 0; }();
     const int seg_rows = std::max(env_seg > 0 ? env_seg : KF_S_SEG, 1), segs = (rows + seg_rows - 1) / seg_rows;
     const int fold = frame_stream_fold(a.w, cols, segs);
     const long long tasks = (long long)a.nframes * (fold > 1 ? (cols - 1) * segs + (segs + fold - 1) / fold : cols * segs);
     int grid = (num_cu > 0 ? num_cu : 256) * KF_S_WGS;   // five workgroups per CU: 20 waves, 80 KiB of LDS (five copies of the table)
     if ((long long)grid * 4 > tasks) grid = (int)((tasks + 3) / 4);
-#define KFS_GO(S, V, M) hipLaunchKernelGGL((k_frame_s<S, V, M>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows, fold)
+#define KFS_GO(S, V, M) hipLaunchKernelGGL((k_frame_s<S, V, M>), dim3(grid), dim3(256), 0, stream, a, cols, segs, seg_rows, fold, frame_stream_colw())
 #define KFS_M(S, V) do { if (method == 3) KFS_GO(S, V, 3); else KFS_GO(S, V, 2); } while (0)
     if (vec == 2) { if (spread) KFS_M(true, 2); else KFS_M(false, 2); }
     else { if (spread) KFS_M(true, 1); else KFS_M(false, 1); }
