@@ -5,6 +5,7 @@ Everything is bit-exact (u16 / int32 work).
 """
 import ctypes as C
 
+import os
 import numpy as np
 import pytest
 
@@ -146,6 +147,43 @@ def test_streaming_cs5x5_kernel_matches_oracle(torch_cuda, oracle, w, h, bad, st
         s.close()
         for k in range(3):
             assert np.array_equal(got[k], want[k]), f"{kind} frame {k}: {(got[k] != want[k]).sum()} px differ"
+
+
+@pytest.mark.parametrize("kind", ["normal", "low_light", "colour_cast"])
+@pytest.mark.parametrize("cs,bad", [(5, 1), (5, 0), (2, 0)])
+def test_long_launches_default_policy(torch_cuda, oracle, kind, cs, bad):
+    """The library's own choice of kernels (no switches set) on launches long enough for the streaming kernels -- 3 600 frames of
+    512x124: k_frame_p5 / k_frame_s take the first launch, the status words of finished launches then move low-light footage to
+    k_frame_p + list and colour patches to k_frame alone (csrc/k_frame.hip: stream_state, stream_state_s).  Five launches in a row,
+    the first three with the stream drained in between (every status word seen), the last two back to back: every launch's first,
+    middle and last frames equal the oracle's."""
+    import torch
+    from mlvfs_amd.stream import to_numpy_u16
+    for v in ("MLVFS_AMD_KF_P", "MLVFS_AMD_KF_P5", "MLVFS_AMD_KF_S"):
+        assert v not in os.environ
+    w, h, nf = 512, 124, 3600
+    if kind == "normal":
+        frames = [synth.normal_frame(w, h, frame=k) for k in range(8)]
+    else:
+        frames = [getattr(synth, kind + "_frame")(w, h, seed=5 + k) for k in range(8)]
+    want, pixels, corr = oracle_clip(oracle, frames, w, h, cs, bad, 1)
+    s = make_stream(w, h)
+    base = s.upload_packed([synth.pack_bits(f) for f in frames])
+    s.analyse_first_frame(base, cs=cs, bad_pix=bad, stripes=True, rand_mode=1)
+    packed = s.alloc_packed(nf)
+    for i in range(0, nf, 8):
+        packed[i:i + 8] = base
+    out = s.alloc_out(nf)
+    sample = list(range(8)) + list(range(1796, 1804)) + list(range(nf - 8, nf))
+    for launch in range(5):
+        out.zero_()
+        s.process(packed, out, cs=cs, fix_pixels=bool(bad), stripes=True)
+        if launch < 3:
+            torch.cuda.synchronize()
+        got = to_numpy_u16(out[sample])
+        for n, i in enumerate(sample):
+            assert np.array_equal(got[n], want[i % 8]), f"{kind} cs{cs} launch {launch} frame {i}: {(got[n] != want[i % 8]).sum()} px differ"
+    s.close()
 
 
 def test_fused_adversarial(torch_cuda, oracle):
