@@ -803,7 +803,7 @@ def main():
         cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
         tasks = F * ((W // 8 + 61) // 62) * ((H // 2 + 29) // 30)           # (tasks of 60 rows, or of 30 for launches half as long)
         streaming = os.environ.get("MLVFS_AMD_KF_P5") == "2" or tasks * 2 >= cus * 16 * 7
-    first_pass = "void mlv::k_frame_p5<false, 1>(mlv::FrameArgs, int, int, int, int)" if streaming else "void mlv::k_frame_p<5, true, 1, false>(mlv::FrameArgs)"
+    first_pass = "void mlv::k_frame_p5<false, 1>(mlv::FrameArgs, int, int, int, int, int)" if streaming else "void mlv::k_frame_p<5, true, 1, false>(mlv::FrameArgs)"
     result = {
         "metric": "Mpix/s, 3584x1320 14-bit unpack+badpix+cs5x5+stripes (fused, stream resident in HBM)",
         "value": round(total_px / dt / 1e6, 1),

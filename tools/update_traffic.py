@@ -8,7 +8,7 @@ path, frames = sys.argv[1], int(sys.argv[2])
 # one pass of the hot path = k_frame_p (round 5: every tile whose packed medians are certain) + the list-mode k_frame behind it (the rest):
 # the counters of both are summed, per launch of each (they are launched in pairs)
 # (the first pass of a long launch is the streaming form k_frame_p5, of a short one k_frame_p: whichever the summary holds)
-kernels = ["void mlv::k_frame_p5<false, 1>(mlv::FrameArgs, int, int, int, int)", "void mlv::k_frame_p<5, true, 1, false>(mlv::FrameArgs)",
+kernels = ["void mlv::k_frame_p5<false, 1>(mlv::FrameArgs, int, int, int, int, int)", "void mlv::k_frame_p<5, true, 1, false>(mlv::FrameArgs)",
            "void mlv::k_frame<5, true, 1, false>(mlv::FrameArgs)"]
 vals, on = {}, False
 per_kernel = {}
