@@ -62,6 +62,18 @@ __device__ __forceinline__ float diag_bound(float rb, float centre, float lo, fl
     return r > CLIP_PT ? ulim(r, lo, hi) : r;
 }
 
+// What the dual-ISO conversion looks up of the three planes (hdr.c:1041-1062; k_dualiso.hip: k_di_amaze_ev did this in a pass of its own
+// until round 5): green's scaling undone, the three clamped to 20 bits, interp_raw2ev of each and of the gray value.  r, g, b: the
+// planes' values as the kernels would store them (65535 x the tile's value).
+__device__ __forceinline__ void ev_of_planes(const int *__restrict__ r2e, int black, float r, float g_stored, float b, int &ev_r, int &ev_g, int &ev_b, int &ev_gray)
+{
+    const float fb = (float)black, hi = 1048575.0f;
+    const float g = (g_stored - fb) * 2.0f + fb;
+    const float gc = g < hi ? (g > 0.0f ? g : 0.0f) : hi, rc = r < hi ? (r > 0.0f ? r : 0.0f) : hi, bc = b < hi ? (b > 0.0f ? b : 0.0f) : hi;
+    ev_g = r2e[(int)gc]; ev_r = r2e[(int)rc]; ev_b = r2e[(int)bc];
+    ev_gray = r2e[(unsigned)(gc / 2 + rc / 4 + bc / 4)];
+}
+
 }  // namespace amz
 
 }  // namespace mlv

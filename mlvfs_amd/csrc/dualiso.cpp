@@ -480,7 +480,7 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
 
     DiBatch bt{};
     bt.pp = (const DiParams *)(B + o_pp);
-    bt.p0.w = w; bt.p0.h = H;
+    bt.p0.w = w; bt.p0.h = H; bt.p0.black20 = black14 * 64;       // (the black level is the call's, the same for every frame)
     bt.p0.use_fullres = o.use_fullres; bt.p0.use_alias_map = o.use_alias_map; bt.p0.chroma_smooth = cs ? o.chroma_smooth_method : 0;
     bt.S = S; bt.img_stride = img_stride; bt.nframes = nframes;
     DiDecideBuffers D{};

@@ -99,7 +99,9 @@ constexpr int AMAZE_TILE_FLOATS = 13 * AMAZE_TS * AMAZE_TS + 13 * AMAZE_TS * AMA
 // gives the rows of each frame, 0 = skip the frame
 int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, float *d_scratch, hipStream_t s,
                  int nframes = 1, size_t plane_stride = 0, size_t scratch_stride = 0, const int *h_of = nullptr, int h_stride = 0,
-                 float *d_rows_dbg = nullptr);
+                 float *d_rows_dbg = nullptr, const int *d_r2e = nullptr, int ev_black = 0, int *d_gray = nullptr);
+// d_r2e (round 5): the three plane pointers are INT planes and take interp_raw2ev of the clamped plane values, d_gray that of the gray
+// value (what k_di_amaze_ev made of the float planes in a pass of its own: amaze_math.h, ev_of_planes)
 size_t amaze_scratch_bytes(int w, int h);
 // k_amaze_rows.hip: the complete tiles (the first nfx x nfy of the tile grid), row-streamed through LDS
 extern int g_amaze_rows_mode;
@@ -107,7 +109,8 @@ extern int g_amaze_rows_extra_mode;
 void amaze_rows_extent(int w, int h, int *nfx, int *nfy);
 int amaze_rows_extra(int w, int h, int nframes);            // heads of k_amaze.hip's chains that k_amaze_rows takes too (rows 0 .. n - 1 of column nfx)
 int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, hipStream_t s, int nframes,
-                      size_t plane_stride, const int *h_of, int h_stride, float *d_dbg, int *d_ctr /* nframes zeroed ints: the tile counters */);
+                      size_t plane_stride, const int *h_of, int h_stride, float *d_dbg, int *d_ctr /* nframes zeroed ints: the tile counters */,
+                      const int *d_r2e = nullptr, int ev_black = 0, int *d_gray = nullptr);
 int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s,
                            hipEvent_t after_amaze = nullptr, hipStream_t tail = nullptr);
 // incl. the exposure match; after_amaze: recorded on s when AMaZE is through; tail: the stream that takes over from there (waits for after_amaze)

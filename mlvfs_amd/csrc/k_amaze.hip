@@ -62,7 +62,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
                                                  float *__restrict__ green_out, float *__restrict__ blue, float *__restrict__ scratch,
                                                  int tiles_x, int row0, int wgs_per_row, int chain_len, int rows_per_wg, int copy_from,
                                                  size_t plane_stride, size_t scratch_stride, const int *__restrict__ h_of, int h_stride,
-                                                 int nfx, int nfy, int dead_rows)
+                                                 int nfx, int nfy, int dead_rows, const int *__restrict__ r2e, int ev_black, int *__restrict__ gray)
 {
     __shared__ unsigned char s_nyq[HALF];
     __shared__ float s_w[HALF];
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
         const size_t f = blockIdx.y;
         if (h_of && h_of[f * (size_t)h_stride] != h) return;
         raw += f * plane_stride; red += f * plane_stride; green_out += f * plane_stride; blue += f * plane_stride;
+        if (r2e) gray += f * plane_stride;
         scratch += f * scratch_stride;
     }
     const int ty0 = row0 + (int)(blockIdx.x / wgs_per_row), tx0 = (int)(blockIdx.x % wgs_per_row);
@@ -579,6 +580,14 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
                 r = 65535.0f * (g[i] - t.dgrb0[i / 2]);
                 b = 65535.0f * (g[i] - t.dgrb1[i / 2]);
             }
+            if (r2e) {
+                // the conversion's look-ups instead of the planes (amaze_math.h: ev_of_planes; the three pointers are int planes then;
+                // widths the conversion accepts are multiples of 4: green is written wherever red and blue are)
+                int er, eg, eb, ey;
+                amz::ev_of_planes(r2e, ev_black, r, g[i] * 65535.0f, b, er, eg, eb, ey);
+                ((int *)red)[o] = er; ((int *)green_out)[o] = eg; ((int *)blue)[o] = eb; gray[o] = ey;
+                continue;
+            }
             red[o] = r;
             blue[o] = b;
             if (cc - 16 < gcols) green_out[o] = g[i] * 65535.0f;
@@ -590,8 +599,10 @@ __global__ __launch_bounds__(1024) void k_amaze(const float *__restrict__ raw, i
 }
 
 int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, float *d_scratch, hipStream_t s,
-                 int nframes, size_t plane_stride, size_t scratch_stride, const int *h_of, int h_stride, float *d_rows_dbg)
+                 int nframes, size_t plane_stride, size_t scratch_stride, const int *h_of, int h_stride, float *d_rows_dbg,
+                 const int *d_r2e, int ev_black, int *d_gray)
 {
+    if (d_r2e && (w % 4 != 0 || d_rows_dbg || !d_gray)) { set_error("amaze_launch: EV planes need a width that is a multiple of 4 and no debug planes"); return MLVFS_AMD_ERR_ARG; }
     const int step = AMAZE_TS - 32;
     const int tiles_x = (w + 16 + step - 1) / step, tiles_y = (h + 16 + step - 1) / step;
     const int cc1_last = w + 16 - (-16 + (tiles_x - 1) * step), rr1_last = h + 16 - (-16 + (tiles_y - 1) * step);
@@ -601,7 +612,7 @@ int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green,
     const int dead_rows = d_rows_dbg ? 0 : amaze_rows_extra(w, h, nframes);               // and so do the heads of chains that have no output
     auto launch = [&](int row0, int nrows, int wgs_per_row, int chain_len, int rows_per_wg, int copy_from) {
         hipLaunchKernelGGL(k_amaze, dim3(nrows * wgs_per_row, nframes), dim3(threads), 0, s, d_raw, w, h, d_red, d_green, d_blue, d_scratch, tiles_x,
-                           row0, wgs_per_row, chain_len, rows_per_wg, copy_from, plane_stride, scratch_stride, h_of, h_stride, nfx, nfy, dead_rows);
+                           row0, wgs_per_row, chain_len, rows_per_wg, copy_from, plane_stride, scratch_stride, h_of, h_stride, nfx, nfy, dead_rows, d_r2e, ev_black, d_gray);
     };
     // The complete tiles run on a side stream, next to this stream's launches for the incomplete ones: those are few workgroups in
     // two dependent launches (1.5 ms of a mostly idle chip per batch of 8 at 3584x1320); k_amaze_rows draws its tiles from a counter,
@@ -639,7 +650,7 @@ int amaze_launch(const float *d_raw, int w, int h, float *d_red, float *d_green,
     auto rows_now = [&]() -> int {                                              // after this stream's first launch has been submitted
         if (!rows_pending) return MLVFS_AMD_OK;
         rows_pending = false;
-        const int rc = amaze_rows_launch(d_raw, w, h, d_red, d_green, d_blue, side->st, nframes, plane_stride, h_of, h_stride, d_rows_dbg, side->ctr);
+        const int rc = amaze_rows_launch(d_raw, w, h, d_red, d_green, d_blue, side->st, nframes, plane_stride, h_of, h_stride, d_rows_dbg, side->ctr, d_r2e, ev_black, d_gray);
         if (rc) return rc;
         MLV_HIP(hipEventRecord(side->done, side->st));
         return MLVFS_AMD_OK;

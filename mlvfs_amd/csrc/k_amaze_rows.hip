@@ -180,13 +180,15 @@ template <bool DBG>
 __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ raw, int w, int h, float *__restrict__ red,
                                                       float *__restrict__ green_out, float *__restrict__ blue, int nfx, int ntiles, int nrect,
                                                       size_t plane_stride, const int *__restrict__ h_of, int h_stride,
-                                                      float *__restrict__ dbg, unsigned long long *__restrict__ prof, unsigned skip_mask, int *__restrict__ tile_ctr)
+                                                      float *__restrict__ dbg, unsigned long long *__restrict__ prof, unsigned skip_mask, int *__restrict__ tile_ctr,
+                                                      const int *__restrict__ r2e, int ev_black, int *__restrict__ gray)
 {
     __shared__ float sm[LDS_FLOATS];                          // static: row offsets are compile-time constants (a dynamic array costs an add each)
     {
         const size_t f = blockIdx.y;
         if (h_of && h_of[f * (size_t)h_stride] != h) return;
         raw += f * plane_stride; red += f * plane_stride; green_out += f * plane_stride; blue += f * plane_stride;
+        if (r2e) gray += f * plane_stride;
         if (DBG) dbg += f * (size_t)ntiles * AMAZE_TILE_FLOATS;
     }
     if ((int)blockIdx.x >= ntiles) return;
@@ -848,9 +850,15 @@ __global__ __launch_bounds__(1024) void k_amaze_rows(const float *__restrict__ r
                         rv = 65535.0f * (g - FP(R_DGRB0, 0)[hc]);
                         bv = 65535.0f * (g - FP(R_DGRB1, 0)[hc]);
                     }
-                    red[o] = rv;
-                    blue[o] = bv;
-                    green_out[o] = g * 65535.0f;
+                    if (r2e) {                                                    // (k_amaze.hip: the conversion's look-ups instead of the planes)
+                        int er, eg, eb, ey;
+                        amz::ev_of_planes(r2e, ev_black, rv, g * 65535.0f, bv, er, eg, eb, ey);
+                        ((int *)red)[o] = er; ((int *)green_out)[o] = eg; ((int *)blue)[o] = eb; gray[o] = ey;
+                    } else {
+                        red[o] = rv;
+                        blue[o] = bv;
+                        green_out[o] = g * 65535.0f;
+                    }
                 } break;
                 default: break;
                 }
@@ -931,7 +939,7 @@ int amaze_rows_extra(int w, int h, int nframes)
 }
 
 int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_green, float *d_blue, hipStream_t s, int nframes,
-                      size_t plane_stride, const int *h_of, int h_stride, float *d_dbg, int *d_ctr)
+                      size_t plane_stride, const int *h_of, int h_stride, float *d_dbg, int *d_ctr, const int *d_r2e, int ev_black, int *d_gray)
 {
     // MLVFS_AMD_AMAZE_ROWS_PROF=1: cycles per item of each pass and per wave at the barriers (workgroup 0, steady state), printed at exit
     static unsigned long long *d_prof = [] {
@@ -1026,10 +1034,10 @@ int amaze_rows_launch(const float *d_raw, int w, int h, float *d_red, float *d_g
     per_frame = per_frame < 1 ? 1 : (per_frame > ntiles ? ntiles : per_frame);
     if (d_dbg)
         hipLaunchKernelGGL(k_amaze_rows<true>, dim3(per_frame, nframes), dim3(1024), 0, s, d_raw, w, h, d_red, d_green, d_blue, nfx,
-                           ntiles, nrect, plane_stride, h_of, h_stride, d_dbg, d_prof, skip, d_ctr);
+                           ntiles, nrect, plane_stride, h_of, h_stride, d_dbg, d_prof, skip, d_ctr, d_r2e, ev_black, d_gray);
     else
         hipLaunchKernelGGL(k_amaze_rows<false>, dim3(per_frame, nframes), dim3(1024), 0, s, d_raw, w, h, d_red, d_green, d_blue, nfx,
-                           ntiles, nrect, plane_stride, h_of, h_stride, d_dbg, d_prof, skip, d_ctr);
+                           ntiles, nrect, plane_stride, h_of, h_stride, d_dbg, d_prof, skip, d_ctr, d_r2e, ev_black, d_gray);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }

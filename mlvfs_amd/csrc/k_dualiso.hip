@@ -1310,14 +1310,23 @@ int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, co
     MLV_HIP(hipMemsetAsync(P.stats + (size_t)b.f0 * 4 * DI_STAT_SLOTS, 0, 4 * sizeof(unsigned) * nf * DI_STAT_SLOTS, s));
     hipLaunchKernelGGL(k_di_match, flat_grid(n, nf), dim3(256), 0, s, (const uint16_t *)d_img, P.raw, b, P.sq_dst, sq_stride, h_launch, P.cfa,
                        (const int *)nullptr, (int *)nullptr);
+    // AMaZE's output stage makes the look-ups of the planes itself (amaze_math.h: ev_of_planes): the three int planes and the gray
+    // plane are what it writes, the float planes and k_di_amaze_ev's pass over them (134 MB and 93 us per 3584x1320 frame) are gone.
+    // MLVFS_AMD_DI_EV_FUSED=0: the separate pass (A/B; identical results)
+    static const bool ev_fused = [] { const char *e = getenv("MLVFS_AMD_DI_EV_FUSED"); return !e || atoi(e) != 0; }();
+    const bool fused = ev_fused && w % 4 == 0;
+    float *const o_red = fused ? (float *)P.ev_red : P.red, *const o_green = fused ? (float *)P.ev_green : P.green, *const o_blue = fused ? (float *)P.ev_blue : P.blue;
+    const int *const r2e = fused ? L.interp_raw2ev : nullptr;
+    int *const o_gray = fused ? P.gray_ev : nullptr;
     // a frame's AMaZE geometry follows its own row count (one less for GBRG): the launch plan is made per distinct height
     int rc = MLVFS_AMD_OK;
     if (b.pp) {
         static_assert(sizeof(DiParams) % sizeof(int) == 0, "h of frame f sits f * sizeof(DiParams) / 4 ints behind h of frame 0");
         for (int k = 0; k < b.nheights && !rc; k++)
-            rc = amaze_launch(P.cfa + fo, w, b.heights[k], P.red + fo, P.green + fo, P.blue + fo, P.amaze_scratch + (size_t)b.f0 * P.amaze_scratch_stride, s,
-                              nf, b.S, P.amaze_scratch_stride, &b.pp[b.f0].h, (int)(sizeof(DiParams) / sizeof(int)));
-    } else rc = amaze_launch(P.cfa, w, b.p0.h, P.red, P.green, P.blue, P.amaze_scratch, s);
+            rc = amaze_launch(P.cfa + fo, w, b.heights[k], o_red + fo, o_green + fo, o_blue + fo, P.amaze_scratch + (size_t)b.f0 * P.amaze_scratch_stride, s,
+                              nf, b.S, P.amaze_scratch_stride, &b.pp[b.f0].h, (int)(sizeof(DiParams) / sizeof(int)), nullptr, r2e, b.p0.black20,
+                              o_gray ? o_gray + fo : nullptr);
+    } else rc = amaze_launch(P.cfa, w, b.p0.h, o_red, o_green, o_blue, P.amaze_scratch, s, 1, 0, 0, nullptr, 0, nullptr, r2e, b.p0.black20, o_gray);
     if (rc) return rc;
     if (after_amaze) MLV_HIP(hipEventRecord(after_amaze, s));
     if (tail && tail != s) {                                           // what follows AMaZE goes on with the planes on another stream
@@ -1325,8 +1334,9 @@ int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, co
         MLV_HIP(hipStreamWaitEvent(tail, after_amaze, 0));
         s = tail;
     }
-    hipLaunchKernelGGL(k_di_amaze_ev, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b, L.interp_raw2ev, P.ev_red, P.ev_green, P.ev_blue,
-                       P.gray_ev);
+    if (!fused)
+        hipLaunchKernelGGL(k_di_amaze_ev, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b, L.interp_raw2ev, P.ev_red, P.ev_green, P.ev_blue,
+                           P.gray_ev);
     static const int edge_rows = [] { const char *e = getenv("MLVFS_AMD_EDGE_ROWS"); const int v = e ? atoi(e) : 4; return v > 0 ? v : 4; }();   // rows per workgroup
     hipLaunchKernelGGL(k_di_edge_dir, dim3((w + 255) / 256, (h_launch + edge_rows - 1) / edge_rows, nf), dim3(256), 0, s, P.raw, P.gray_ev, b, P.sq_row, sq_stride,
                        L.fullres_thr, P.dir, P.stats);
