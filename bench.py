@@ -359,10 +359,10 @@ def extra_dualiso(golden, fnv1a, batch=8, reps=4, threads=3):
     # SURVEY 8(d)'s convention for this path too: packed in + 16-bit out per frame against the HBM peak
     res["hbm_frac_compulsory_bytes"] = round(best * W * H * BYTES_PER_PX / 1e9 / HBM_PEAK_GBS, 5)
     # ... and what the conversion really moves and executes ("report the actual multi-pass bytes separately"): counters of a
-    # batch of 8 from separate rocprofv3 --pmc passes (tools/dualiso_traffic.sh -> profiles/r05/di_plain/dualiso_traffic.json), scaled by
+    # batch of 8 from separate rocprofv3 --pmc passes (tools/dualiso_traffic.sh -> profiles/r05/di_fused/dualiso_traffic.json), scaled by
     # THIS run's batch rate.  The path is bound by instruction issue in AMaZE and by table gathers behind it, not by HBM.
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r05", "di_plain", "dualiso_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r05", "di_fused", "dualiso_traffic.json")))
         rate = res["batch_8_threads_1"]["conversions_per_s"]
         res["roofline"] = {
             "bound": "instruction issue (AMaZE) / L2 gathers (interpolation, blend); HBM for reference",
@@ -375,7 +375,7 @@ def extra_dualiso(golden, fnv1a, batch=8, reps=4, threads=3):
             "dominant_kernel": tj["dominant_kernel"], "dominant_kernel_us_per_frame": tj["dominant_kernel_us_per_frame"],
             "kernel_us_per_frame_sum": tj["kernel_us_per_frame_sum"], "amaze_share_of_kernel_sum": tj["amaze_share_of_kernel_sum"],
             "k_amaze_share_of_kernel_sum": tj["k_amaze_share_of_kernel_sum"],
-            "source": "profiles/r05/di_plain/dualiso_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE, SQ_INSTS_VALU, --kernel-trace --stats; separate passes): "
+            "source": "profiles/r05/di_fused/dualiso_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE, SQ_INSTS_VALU, --kernel-trace --stats; separate passes): "
                       "not measured in this run, scaled by its batch_8_threads_1 rate"}
     except Exception as e:
         res["roofline"] = {"unavailable": str(e)[:120]}
