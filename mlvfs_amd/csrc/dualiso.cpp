@@ -642,10 +642,17 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
             const int nparts = nframes / part > 1 ? nframes / part : 1;
             MLV_HIP(hipEventRecord(hf.fork, stream));
             MLV_HIP(hipStreamWaitEvent(hf.st, hf.fork, 0));
+            // The last part is smaller than the others (3/4 of an even share: 8 frames = 5 + 3): what follows its AMaZE -- interpolation,
+            // alias map, blend -- runs with the chip to itself, and the less of that the better (1 037 -> 1 074 conversions/s,
+            // profiles/r05/di_experiments.log).  MLVFS_AMD_DI_FIRST=n (two parts): n frames in the first one (experiments).
+            static const int first_env = [] { const char *e = getenv("MLVFS_AMD_DI_FIRST"); return e ? atoi(e) : 0; }();
+            const int even = nframes / nparts, last = nparts > 1 ? std::max(1, (3 * even + 2) / 4) : nframes, front = nframes - last;
             for (int k = 0; k < nparts; k++) {
                 DiBatch bk = bt;
-                bk.f0 = (int)((long long)nframes * k / nparts);
-                bk.nframes = (int)((long long)nframes * (k + 1) / nparts) - bk.f0;
+                if (nparts == 1) { bk.f0 = 0; bk.nframes = nframes; }
+                else if (k == nparts - 1) { bk.f0 = front; bk.nframes = last; }
+                else { bk.f0 = (int)((long long)front * k / (nparts - 1)); bk.nframes = (int)((long long)front * (k + 1) / (nparts - 1)) - bk.f0; }
+                if (first_env > 0 && first_env < nframes && nparts == 2) { bk.f0 = k ? first_env : 0; bk.nframes = k ? nframes - first_env : first_env; }
                 rc = di_launch_amaze_interp(d_frames, bk, H, L, P, stream, hf.amaze_a, hf.st);
                 if (!rc) rc = di_launch_convert(bk, H, L, P, amaze, d_frames, hf.st);
                 if (rc) break;
