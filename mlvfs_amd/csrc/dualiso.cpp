@@ -634,7 +634,7 @@ int cr2hdr20_batch(ThreadCtx *c, struct frame_headers *fh, void *d_frames, size_
             }
             // frames per part: enough complete AMaZE tiles for about four rounds of k_amaze_rows' 256 workgroups (3584x1320: 282 per
             // frame -> 4 frames; 1736x976: 84 -> 13, a batch of 8 stays whole -- in parts of 4 it took 4.4 instead of 3.9 ms)
-            static const int part_env = [] { const char *e = getenv("MLVFS_AMD_DI_PART"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+            const int part_env = [] { const char *e = getenv("MLVFS_AMD_DI_PART"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();   // (read per call: tests)
             int nfx = 0, nfy = 0;
             amaze_rows_extent(w, H, &nfx, &nfy);
             const int per_frame = nfx * nfy > 0 ? nfx * nfy : 1;

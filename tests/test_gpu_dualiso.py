@@ -231,6 +231,24 @@ def test_cr2hdr20_batch_equals_the_oracle_frame_by_frame(gpu, oracle, interp, cs
         assert r1 == res[k] and np.array_equal(one, got[k]), k
 
 
+def test_cr2hdr20_batch_in_parts_equals_the_oracle(gpu, oracle, monkeypatch):
+    """A batch that goes out in PARTS (csrc/dualiso.cpp: batches of 8 and more of large frames; here forced with MLVFS_AMD_DI_PART=2
+    on nine small ones: parts of 2, 2, 3 and 2 frames -- the last part is smaller than an even share): AMaZE of one part on the
+    caller's stream beside interpolation and blend of the part before on a second one.  Frame by frame the oracle's bytes."""
+    monkeypatch.setenv("MLVFS_AMD_DI_PART", "2")
+    w, h = 416, 264
+    frames = [synth.dual_iso_frame(w, h, seed=3), synth.dual_iso_frame(w, h, seed=5, frame=2), synth.normal_frame(w, h),
+              np.minimum(synth.dual_iso_frame(w, h, seed=4), 12000).astype(np.uint16), synth.dual_iso_frame(w, h, seed=7),
+              synth.dual_iso_frame(w, h + 2, seed=6)[1:h + 1].copy(), synth.dual_iso_frame(w, h, seed=8, frame=1),
+              synth.dual_iso_frame(w, h, seed=9), synth.dual_iso_frame(w, h, seed=3)]
+    oracle.L.orc_dualiso_reset()
+    want = [oracle.cr2hdr20(f, BLACK, WHITE, 0, 1, 1, 0, reset=False) for f in frames]
+    res, got = batch_convert(gpu, frames, 0, 1, 1, 0)
+    assert list(res) == [r for r, _, _ in want]
+    for k, (r, img, _) in enumerate(want):
+        assert np.array_equal(got[k], img), f"frame {k}: {(got[k] != img).sum()} px differ"
+
+
 def test_cr2hdr20_batch_decisions_equal_the_oracle(gpu, oracle):
     """The device-side decisions, scalar by scalar, for the last frame of a batch (mlvfs_amd_dualiso_last_scalars) on frames whose
     white levels, fits and patterns differ."""
