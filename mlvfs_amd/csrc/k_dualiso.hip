@@ -369,6 +369,67 @@ struct DiAmazeIn {              // inputs of the edge-directed interpolation (nu
     size_t sq_stride;           // ints between the frames' squeezed-row maps
 };
 
+// one pixel of the interpolation and everything behind it (the body of k_di_interp).  DIR >= 0: the edge direction comes with the
+// call (k_di_edge_interp), else from A.dir
+template <bool AMAZE>
+__device__ __forceinline__ void di_interp_pixel(const DiParams &p, const DiLuts &L, const DiAmazeIn &A, const uint32_t *__restrict__ raw,
+                                                size_t i, int x, int y, int dir_given,
+                                                uint32_t *__restrict__ dark, uint32_t *__restrict__ bright,
+                                                uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
+                                                uint16_t *__restrict__ over, uint16_t *__restrict__ amap, bool ev_out)
+{
+    const int w = p.w, h = p.h;
+    const int *ir2e = L.interp_raw2ev, *ie2r = L.interp_ev2raw;
+    const int br = di_bright(p, y);
+    auto R = [&](int xx, int yy) { return (int)raw[xx + (size_t)yy * w]; };
+    int native, interp;
+    // precedence of the reference's loops: column borders (y >= 2) over row borders over the interior
+    if (y >= 2 && x < 2) { interp = R(x, y - 2); native = R(x, y); }
+    else if (y >= 2 && x >= w - 3) { interp = R(x - 2, y - 2); native = R(x - 2, y); }
+    else if (y < 3) { interp = R(x, y + 2); native = R(x, y); }
+    else if (y >= h - 4) { interp = R(x, y - 2); native = R(x, y); }
+    else if (AMAZE) {                                         // hdr.c:940-952, 1181-1208
+        const int s = (di_bright(p, y) == di_bright(p, y + 1)) ? -1 : 1;
+        const int *plane = (y & 1) == 0 ? ((x & 1) == 0 ? A.red : A.green) : ((x & 1) == 0 ? A.green : A.blue);
+        const int d = dir_given >= 0 ? dir_given : (int)A.dir[i];
+        const int dd[3] = { d, min(d + 1, 10), max(d - 1, 0) };
+        // of a direction's table row only a.x and b.x vary (a.y = 1, b.y = -2 for all eleven, hdr.c:916-938): two rows of the
+        // plane for the three directions, the column offsets from two packed constants instead of twelve byte loads per pixel
+        const int *row_a = plane + (size_t)A.sq_row[y + s] * w + x, *row_b = plane + (size_t)A.sq_row[y - 2 * s] * w + x;
+        constexpr unsigned long long AX = 0x43332221110ull, BX = 0x01233455678ull;       // a.x + 2, b.x + 4 of directions 0..10, 4 bits each
+        int pi[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int ax = (int)((AX >> (4 * dd[k])) & 15) - 2, bx = (int)((BX >> (4 * dd[k])) & 15) - 4;
+            const int ea = row_a[ax];                                                    // raw2ev of the clamped plane value
+            const int eb = row_b[bx];
+            pi[k] = (ea * 2 + eb) / 3;
+        }
+        interp = ie2r[(2 * pi[0] + pi[1] + pi[2]) / 4];
+        native = R(x, y);
+    } else {
+        const int wl = !br ? p.white_darkened : p.white20;
+        const int wev = ir2e[wl];
+        auto E = [&](int xx, int yy) { return A.red[xx + (size_t)yy * w]; };        // (mean23: A.red is raw2ev of the matched frame)
+        const int s = (di_bright(p, y) == di_bright(p, y + 1)) ? -1 : 1;
+        const int xe = x & ~1;                                // the pair (xe, xe+1) is produced together
+        int ev;
+        if ((y & 1) == 0) {
+            if (x == xe) ev = di_mean2(E(xe, y - 2), E(xe, y + 2), wev);
+            else ev = di_mean3(E(xe + 2, y + s), E(xe, y + s), E(xe + 1, y - 2 * s), wev);
+        } else {
+            if (x == xe) ev = di_mean3(E(xe + 1, y + s), E(xe - 1, y + s), E(xe, y - 2 * s), wev);
+            else ev = di_mean2(E(xe + 1, y - 2), E(xe + 1, y + 2), wev);
+        }
+        interp = ie2r[ev];
+        native = R(x, y);
+    }
+    const int b = br ? native : interp, d = br ? interp : native;
+    bright[i] = (uint32_t)b;
+    dark[i] = (uint32_t)d;
+    di_mix_pixel_packed(p, L, i, br, b, d, fullres, halfres, over, amap, ev_out);
+}
+
 template <bool AMAZE>
 __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ raw, DiBatch bt, DiLuts L, DiAmazeIn A,
                                                    uint32_t *__restrict__ dark, uint32_t *__restrict__ bright,
@@ -386,58 +447,8 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
     }
     const int w = p.w, h = p.h;
     const size_t n = (size_t)w * h;
-    const int *ir2e = L.interp_raw2ev, *ie2r = L.interp_ev2raw;
-    for (size_t i = (size_t)di_xcd_block() * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % w), y = (int)(i / w);
-        const int br = di_bright(p, y);
-        auto R = [&](int xx, int yy) { return (int)raw[xx + (size_t)yy * w]; };
-        int native, interp;
-        // precedence of the reference's loops: column borders (y >= 2) over row borders over the interior
-        if (y >= 2 && x < 2) { interp = R(x, y - 2); native = R(x, y); }
-        else if (y >= 2 && x >= w - 3) { interp = R(x - 2, y - 2); native = R(x - 2, y); }
-        else if (y < 3) { interp = R(x, y + 2); native = R(x, y); }
-        else if (y >= h - 4) { interp = R(x, y - 2); native = R(x, y); }
-        else if (AMAZE) {                                         // hdr.c:940-952, 1181-1208
-            const int s = (di_bright(p, y) == di_bright(p, y + 1)) ? -1 : 1;
-            const int *plane = (y & 1) == 0 ? ((x & 1) == 0 ? A.red : A.green) : ((x & 1) == 0 ? A.green : A.blue);
-            const int d = A.dir[i];
-            const int dd[3] = { d, min(d + 1, 10), max(d - 1, 0) };
-            // of a direction's table row only a.x and b.x vary (a.y = 1, b.y = -2 for all eleven, hdr.c:916-938): two rows of the
-            // plane for the three directions, the column offsets from two packed constants instead of twelve byte loads per pixel
-            const int *row_a = plane + (size_t)A.sq_row[y + s] * w + x, *row_b = plane + (size_t)A.sq_row[y - 2 * s] * w + x;
-            constexpr unsigned long long AX = 0x43332221110ull, BX = 0x01233455678ull;       // a.x + 2, b.x + 4 of directions 0..10, 4 bits each
-            int pi[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int ax = (int)((AX >> (4 * dd[k])) & 15) - 2, bx = (int)((BX >> (4 * dd[k])) & 15) - 4;
-                const int ea = row_a[ax];                                                    // raw2ev of the clamped plane value
-                const int eb = row_b[bx];
-                pi[k] = (ea * 2 + eb) / 3;
-            }
-            interp = ie2r[(2 * pi[0] + pi[1] + pi[2]) / 4];
-            native = R(x, y);
-        } else {
-            const int wl = !br ? p.white_darkened : p.white20;
-            const int wev = ir2e[wl];
-            auto E = [&](int xx, int yy) { return A.red[xx + (size_t)yy * w]; };        // (mean23: A.red is raw2ev of the matched frame)
-            const int s = (di_bright(p, y) == di_bright(p, y + 1)) ? -1 : 1;
-            const int xe = x & ~1;                                // the pair (xe, xe+1) is produced together
-            int ev;
-            if ((y & 1) == 0) {
-                if (x == xe) ev = di_mean2(E(xe, y - 2), E(xe, y + 2), wev);
-                else ev = di_mean3(E(xe + 2, y + s), E(xe, y + s), E(xe + 1, y - 2 * s), wev);
-            } else {
-                if (x == xe) ev = di_mean3(E(xe + 1, y + s), E(xe - 1, y + s), E(xe, y - 2 * s), wev);
-                else ev = di_mean2(E(xe + 1, y - 2), E(xe + 1, y + 2), wev);
-            }
-            interp = ie2r[ev];
-            native = R(x, y);
-        }
-        const int b = br ? native : interp, d = br ? interp : native;
-        bright[i] = (uint32_t)b;
-        dark[i] = (uint32_t)d;
-        di_mix_pixel_packed(p, L, i, br, b, d, fullres, halfres, over, amap, ev_out);
-    }
+    for (size_t i = (size_t)di_xcd_block() * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        di_interp_pixel<AMAZE>(p, L, A, raw, i, (int)(i % w), (int)(i / w), -1, dark, bright, fullres, halfres, over, amap, ev_out);
 }
 
 // ------------------------------------------------------------------ AMaZE-based interpolation, hdr.c:954-1229
@@ -537,6 +548,91 @@ __global__ __launch_bounds__(256) void k_di_edge_dir(const uint32_t *__restrict_
         }
     }
     if (x < w) dir[i] = (uint8_t)best;
+    __syncthreads();                                                             // (s_rows is reused by the next row)
+    }
+    {   // the reference's four counters: semi-overexposed / not (bright rows), deep shadow / not (dark rows)
+        unsigned a = n_search & 0xFFFFu, b = n_plain & 0xFFFFu, c = n_search >> 16, d = n_plain >> 16;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); d += __shfl_xor(d, o); }
+        if ((threadIdx.x & 63) == 0) {
+            if (a) atomicAdd(&stats[0], a);
+            if (b) atomicAdd(&stats[1], b);
+            if (c) atomicAdd(&stats[2], c);
+            if (d) atomicAdd(&stats[3], d);
+        }
+    }
+}
+
+// k_di_edge_dir and k_di_interp<true> in one (round 5): the direction a pixel's search finds goes straight into its interpolation --
+// no direction plane, one pass over the matched frame instead of two, and the search's arithmetic runs beside the interpolation's
+// table look-ups in the same workgroup
+__global__ __launch_bounds__(256, 4) void k_di_edge_interp(const uint32_t *__restrict__ raw, const int *__restrict__ gray_sq, DiBatch bt,
+                                                        const int *__restrict__ sq_row, size_t sq_stride, int fullres_thr,
+                                                        unsigned *__restrict__ stats, DiLuts L, DiAmazeIn A,
+                                                        uint32_t *__restrict__ dark, uint32_t *__restrict__ bright,
+                                                        uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
+                                                        uint16_t *__restrict__ over, uint16_t *__restrict__ amap, bool ev_out)
+{
+    constexpr int REACH = 11, SPAN = 256 + 2 * REACH, BIAS = 10 * DI_EVR;        // raw2ev >= -10 EV
+    __shared__ unsigned s_rows[4][SPAN];
+    int f; DiParams p;
+    if (!di_frame<2>(bt, f, p)) return;
+    raw += (size_t)f * bt.S; gray_sq += (size_t)f * bt.S; sq_row += (size_t)f * sq_stride;
+    {
+        const size_t o = (size_t)f * bt.S;
+        dark += o; bright += o; fullres += o; halfres += o; over += o;
+        if (amap) amap += o;
+        A.red += o; A.green += o; A.blue += o; A.sq_row = sq_row;
+    }
+    stats += ((size_t)f * DI_STAT_SLOTS + ((blockIdx.x + blockIdx.y) & (DI_STAT_SLOTS - 1))) * 4;
+    const int w = p.w, h = p.h, x0 = blockIdx.x * 256, x = x0 + (int)threadIdx.x;
+    unsigned n_search = 0, n_plain = 0;                                          // this lane's pixels, bright rows in the low half, dark rows << 16
+    // (consecutive rows per workgroup, unlike k_di_edge_dir's stride of gridDim.y: the rows of the planes and of the gray image that
+    // one row reads are the next row's too -- with the stride the kernel fetched 582 MB per frame, 136 more than the two kernels it replaces)
+    const int rows_per = (h + (int)gridDim.y - 1) / (int)gridDim.y;
+    for (int y = (int)blockIdx.y * rows_per, y_end = min(y + rows_per, h); y < y_end; y++) {                            // (a band of rows per workgroup: 4 atomics per workgroup, not per row)
+    const size_t i = (size_t)y * w + x;
+    const int br = di_bright(p, y);
+    bool search = false;
+    if (x >= 5 && x < w - 5 && y >= 5 && y < h - 5) {
+        const int v = (int)raw[i];
+        search = br ? !(v < p.white_darkened) : v < fullres_thr;                  // !(fullres_curve[v] > 0.8)
+        if (search) n_search += br ? 1u : 0x10000u; else n_plain += br ? 1u : 0x10000u;
+    }
+    int best = 5;
+    if (__syncthreads_or(search)) {
+        const int s = (br == di_bright(p, y + 1)) ? -1 : 1;
+        for (int k = threadIdx.x; k < 4 * SPAN; k += 256) {
+            const int rr = k / SPAN, cc = k - rr * SPAN;
+            const int row = y + (rr == 0 ? 2 : rr == 1 ? 1 : rr == 2 ? -2 : -3) * s;
+            int gy = row, gx = x0 + cc - REACH;                                  // the reference indexes the gray image flat: columns off
+            if (gx < 0) { gy--; gx += w; }                                       // the row's ends are the neighbouring rows'
+            while (gx >= w && gy < h - 1) { gy++; gx -= w; }
+            gx = gx < w ? gx : w - 1;                                            // (beyond the image's last pixel: nobody reads it)
+            s_rows[rr][cc] = (unsigned)(gray_sq[(size_t)sq_row[gy] * w + gx] + BIAS);    // de-squeezed here (hdr.c:1055-1059)
+        }
+        __syncthreads();
+        if (search) {
+            unsigned win[4][2 * REACH + 1];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+                for (int c = 0; c < 2 * REACH + 1; c++) win[rr][c] = s_rows[rr][threadIdx.x + c];
+            unsigned e_best = 0xFFFFFFFFu;
+#pragma unroll
+            for (int d = 0; d < 11; d++) {
+                unsigned err = (unsigned)((d > 5 ? d - 5 : 5 - d) * DI_EVR / 8);
+#pragma unroll
+                for (int j = -5; j <= 5; j++) {
+                    const unsigned p1 = win[0][REACH + EDGE_DIRS[d][0] + j], p2 = win[1][REACH + EDGE_DIRS[d][2] + j];
+                    const unsigned p3 = win[2][REACH + EDGE_DIRS[d][4] + j], p4 = win[3][REACH + EDGE_DIRS[d][6] + j];
+                    err = di_sad(p1, p2, err); err = di_sad(p2, p3, err); err = di_sad(p3, p4, err);
+                }
+                if (err < e_best) { e_best = err; best = d; }
+            }
+        }
+    }
+    if (x < w) di_interp_pixel<true>(p, L, A, raw, i, x, y, best, dark, bright, fullres, halfres, over, amap, ev_out);
     __syncthreads();                                                             // (s_rows is reused by the next row)
     }
     {   // the reference's four counters: semi-overexposed / not (bright rows), deep shadow / not (dark rows)
@@ -1302,6 +1398,12 @@ int di_launch_match(const void *d_img, const DiBatch &b, int h_launch, const DiL
 
 // squeeze -> AMaZE -> clamp -> gray -> edge directions; the planes feed k_di_interp<true>.  P.sq_dst: per frame sq_dst | sq_row of
 // h_launch ints each
+// rows per workgroup of the edge search.  MLVFS_AMD_DI_EDGE_FUSED=1: direction search and interpolation in one kernel (k_di_edge_interp;
+// identical results).  OFF: 4 % more conversions per second in batches of 8 (985 -> 1 026 on one box), but 582-636 MB of HBM-side
+// traffic per frame where the two kernels need 446 (profiles/r05/di_experiments.log) -- the wrong direction for VERDICT r4 #3 until
+// the table look-ups of the interpolation are localised.
+static int di_edge_rows() { static const int v = [] { const char *e = getenv("MLVFS_AMD_EDGE_ROWS"); const int r = e ? atoi(e) : 4; return r > 0 ? r : 4; }(); return v; }
+static bool di_edge_fused() { const char *e = getenv("MLVFS_AMD_DI_EDGE_FUSED"); return e && atoi(e) != 0; }
 int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, const DiLuts &L, const DiPlanes &P, hipStream_t s, hipEvent_t after_amaze,
                            hipStream_t tail)
 {
@@ -1337,9 +1439,9 @@ int di_launch_amaze_interp(const void *d_img, const DiBatch &b, int h_launch, co
     if (!fused)
         hipLaunchKernelGGL(k_di_amaze_ev, flat_grid(n, nf), dim3(256), 0, s, P.red, P.green, P.blue, b, L.interp_raw2ev, P.ev_red, P.ev_green, P.ev_blue,
                            P.gray_ev);
-    static const int edge_rows = [] { const char *e = getenv("MLVFS_AMD_EDGE_ROWS"); const int v = e ? atoi(e) : 4; return v > 0 ? v : 4; }();   // rows per workgroup
-    hipLaunchKernelGGL(k_di_edge_dir, dim3((w + 255) / 256, (h_launch + edge_rows - 1) / edge_rows, nf), dim3(256), 0, s, P.raw, P.gray_ev, b, P.sq_row, sq_stride,
-                       L.fullres_thr, P.dir, P.stats);
+    if (!di_edge_fused())                                             // (fused: the search runs inside the interpolation's kernel, di_launch_convert)
+        hipLaunchKernelGGL(k_di_edge_dir, dim3((w + 255) / 256, (h_launch + di_edge_rows() - 1) / di_edge_rows(), nf), dim3(256), 0, s, P.raw, P.gray_ev, b, P.sq_row, sq_stride,
+                           L.fullres_thr, P.dir, P.stats);
     MLV_HIP(hipGetLastError());
     return MLVFS_AMD_OK;
 }
@@ -1353,7 +1455,10 @@ int di_launch_convert(const DiBatch &b, int h_launch, const DiLuts &L, const DiP
     uint16_t *amap_fused = (p.use_alias_map && !p.chroma_smooth) ? P.amap : nullptr;
     const DiAmazeIn A{ P.ev_red, P.ev_green, P.ev_blue, P.dir, P.sq_row, 3 * (size_t)h_launch };
     const bool ev_planes = !p.chroma_smooth && L.blend_is_mix;                // halfres / fullres travel as EV (the blend's lookups, done early)
-    if (amaze)
+    if (amaze && di_edge_fused())
+        hipLaunchKernelGGL(k_di_edge_interp, dim3((p.w + 255) / 256, (h_launch + di_edge_rows() - 1) / di_edge_rows(), nf), dim3(256), 0, s, P.raw, P.gray_ev, b, P.sq_row,
+                           3 * (size_t)h_launch, L.fullres_thr, P.stats, L, A, P.dark, P.bright, P.fullres, P.halfres, P.over, amap_fused, ev_planes);
+    else if (amaze)
         hipLaunchKernelGGL(k_di_interp<true>, flat_grid(n, nf), dim3(256), 0, s, P.raw, b, L, A, P.dark, P.bright, P.fullres, P.halfres,
                            P.over, amap_fused, ev_planes);
     else
