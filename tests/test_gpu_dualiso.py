@@ -249,6 +249,30 @@ def test_cr2hdr20_batch_in_parts_equals_the_oracle(gpu, oracle, monkeypatch):
         assert np.array_equal(got[k], img), f"frame {k}: {(got[k] != img).sum()} px differ"
 
 
+def test_cr2hdr20_edge_search_inside_the_interpolation(gpu, oracle, monkeypatch):
+    """MLVFS_AMD_DI_EDGE_FUSED=1 (off by default: csrc/k_dualiso.hip, di_edge_fused): direction search and interpolation as one
+    kernel, k_di_edge_interp -- the oracle's bytes frame by frame, and the hash of the reference's output at 3584x1320."""
+    import json
+    import os
+    from conftest import fnv1a
+    monkeypatch.setenv("MLVFS_AMD_DI_EDGE_FUSED", "1")
+    w, h = 416, 264
+    frames = [synth.dual_iso_frame(w, h, seed=3), synth.dual_iso_frame(w, h, seed=5, frame=2),
+              synth.dual_iso_frame(w, h + 2, seed=6)[1:h + 1].copy()]
+    oracle.L.orc_dualiso_reset()
+    want = [oracle.cr2hdr20(f, BLACK, WHITE, 0, 1, 1, 0, reset=False) for f in frames]
+    res, got = batch_convert(gpu, frames, 0, 1, 1, 0)
+    assert list(res) == [r for r, _, _ in want]
+    for k, (r, img, _) in enumerate(want):
+        assert np.array_equal(got[k], img), f"frame {k}: {(got[k] != img).sum()} px differ"
+    full = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))["full_size"]
+    f = synth.dual_iso_frame(3584, 1320)
+    res, got = batch_convert(gpu, [f, f], 0, 1, 1, 0, pad_rows=0)
+    assert list(res) == [1, 1]
+    for g in got:
+        assert fnv1a(g) == full["dualiso_3584x1320_i0_f1_a1_cs0"]
+
+
 def test_cr2hdr20_batch_decisions_equal_the_oracle(gpu, oracle):
     """The device-side decisions, scalar by scalar, for the last frame of a batch (mlvfs_amd_dualiso_last_scalars) on frames whose
     white levels, fits and patterns differ."""
