@@ -86,6 +86,7 @@ static void host_lut_build(HostLut &L, int black, int white)          // hdr.c:8
 struct HostCurves {              // build_fullres_curve (hdr.c:890-913) + the log2 part of the mix curve (hdr.c:1566)
     int black = -1;
     int thr = N20;                   // fullres[i] > 0.8 <=> i >= thr
+    int fr_lo = 0, fr_hi = N20;      // fullres[i] == fullres[0] below fr_lo, == fullres[N20 - 1] from fr_hi on
     unsigned version = 0;
     std::vector<double> fullres, log2sig;
 };
@@ -104,7 +105,6 @@ struct DeviceTables {            // per device copies + the host version they mi
     unsigned ver[4] = { 0, 0, 0, 0 };
     double *fullres = nullptr, *log2sig = nullptr, *evf = nullptr;
     unsigned curves_ver = 0;
-    DiBright *by_bright = nullptr;       // curves + the mix table, re-packed (DiLuts::by_bright, mix_pair)
     int2 *mix_pair = nullptr;
     unsigned packed_curves_ver = 0, packed_mix_ver = 0, same_mix_ver = 0, same_blend_ver = 0;
     int blend_is_mix = 0;
@@ -184,6 +184,10 @@ static int prepare_tables(int device, int black, int white, int interp_method, D
         for (int i = 0; i < thr; i++)
             if (g_curves.fullres[i] > 0.8) { set_error("dual ISO: the full-res curve is not monotone"); return MLVFS_AMD_ERR_ARG; }
         g_curves.thr = thr;
+        int lo = 0, hi = N20;
+        while (lo < N20 && g_curves.fullres[lo] == g_curves.fullres[0]) lo++;
+        while (hi > 0 && g_curves.fullres[hi - 1] == g_curves.fullres[N20 - 1]) hi--;
+        g_curves.fr_lo = lo; g_curves.fr_hi = hi > lo ? hi : lo;
         g_curves.black = black;
         g_curves.version++;
     }
@@ -196,21 +200,18 @@ static int prepare_tables(int device, int black, int white, int interp_method, D
         MLV_HIP(hipMemcpy(T.log2sig, g_curves.log2sig.data(), sizeof(double) * N20, hipMemcpyHostToDevice));
         T.curves_ver = g_curves.version;
     }
-    if (T.packed_curves_ver != g_curves.version || T.packed_mix_ver != g_lut_mix.version || !T.by_bright) {
-        T.retire(T.by_bright); T.retire(T.mix_pair);
-        T.by_bright = nullptr; T.mix_pair = nullptr;
-        std::vector<DiBright> bb(N20);
-        for (int i = 0; i < N20; i++) bb[i] = DiBright{ g_curves.log2sig[i], g_lut_mix.raw2ev[i], g_curves.fullres[i] > 0.8 ? 1 : 0 };
+    if (T.packed_curves_ver != g_curves.version || T.packed_mix_ver != g_lut_mix.version || !T.mix_pair) {
+        T.retire(T.mix_pair);
+        T.mix_pair = nullptr;
         std::vector<int2> mp((size_t)24 * EVR);
         for (int i = 0; i < 24 * EVR; i++) { const int r = g_lut_mix.ev2raw[i]; mp[i] = int2{ r, g_lut_mix.raw2ev[r] }; }
-        MLV_HIP(hipMalloc(&T.by_bright, sizeof(DiBright) * N20));
         MLV_HIP(hipMalloc(&T.mix_pair, sizeof(int2) * 24 * EVR));
-        MLV_HIP(hipMemcpy(T.by_bright, bb.data(), sizeof(DiBright) * N20, hipMemcpyHostToDevice));
         MLV_HIP(hipMemcpy(T.mix_pair, mp.data(), sizeof(int2) * 24 * EVR, hipMemcpyHostToDevice));
         T.packed_curves_ver = g_curves.version; T.packed_mix_ver = g_lut_mix.version;
     }
-    L->by_bright = T.by_bright; L->mix_pair = T.mix_pair + 10 * EVR;
+    L->mix_pair = T.mix_pair + 10 * EVR;
     L->fullres_thr = g_curves.thr;
+    L->fr_lo = g_curves.fr_lo; L->fr_hi = g_curves.fr_hi; L->fr_lo_val = g_curves.fullres[0]; L->fr_hi_val = g_curves.fullres[N20 - 1];
     if (T.same_mix_ver != g_lut_mix.version || T.same_blend_ver != g_lut_blend.version) {
         T.blend_is_mix = g_lut_mix.raw2ev == g_lut_blend.raw2ev;
         T.same_mix_ver = g_lut_mix.version; T.same_blend_ver = g_lut_blend.version;
@@ -323,6 +324,27 @@ struct PhaseTimer {
 // device (k_di_decide_*), `ta` are the candidate slopes.
 struct DiOptions { int interp_method, use_fullres, use_alias_map, chroma_smooth_method; };
 
+// The weight of the half-res mix (hdr.c:1562-1575) is a function of the bright value b alone: t = log2(max(b / 64 - black / 64, 1)) +
+// corr_ev - (max_ev - overlap), clamped to [0, overlap].  log2 is monotone, so the clamps cut the 20-bit range in three: t = 0 below
+// mix_lo, t = overlap from mix_hi on, and only the band between needs the table and the cosine.  The two bounds by bisection, with
+// the expressions of the kernel (and of the table: prepare_tables).
+static void mix_band(DiParams &p)
+{
+    const int black = p.black20;
+    auto t_of = [&](int i) {
+        const double sig = i / 64.0 - black / 64.0;
+        const double ev = log2(sig > 1 ? sig : 1) + p.corr_ev;
+        return ev - (p.max_ev - p.overlap);
+    };
+    auto first = [&](auto pred) {                              // first i in [0, 2^20] with pred(i), pred monotone false -> true
+        int lo = 0, hi = 1 << 20;
+        while (lo < hi) { const int mid = (lo + hi) / 2; if (pred(mid)) hi = mid; else lo = mid + 1; }
+        return lo;
+    };
+    p.mix_lo = first([&](int i) { return t_of(i) > 0; });
+    p.mix_hi = first([&](int i) { return !(t_of(i) < p.overlap); });
+}
+
 static int finish_decisions(const DiDecide &d, const double *ta, int w, int H, int black14, const DiOptions &o, DiParams *out, double scalars[8])
 {
     DiParams p{};
@@ -373,6 +395,7 @@ static int finish_decisions(const DiDecide &d, const double *ta, int w, int H, i
     printf("Half-res blending...\n");
     p.corr_ev = corr_ev; p.overlap = overlap;
     p.max_ev = log2(white / 64 - black / 64);
+    mix_band(p);
     scalars[0] = rggb; scalars[1] = is_bright[0] * 8 + is_bright[1] * 4 + is_bright[2] * 2 + is_bright[3];
     scalars[2] = white; scalars[3] = white_bright; scalars[4] = a; scalars[5] = b; scalars[6] = corr_ev; scalars[7] = p.white_darkened;
     if (o.chroma_smooth_method) printf("Chroma smoothing...\n");

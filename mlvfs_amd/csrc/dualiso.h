@@ -28,6 +28,8 @@ struct DiParams {
     int white_darkened;
     int dark_noise;            // 8 * 64 (hdr.c:329-333, 1817)
     int use_fullres, use_alias_map, chroma_smooth;   // chroma_smooth: 0, 2, 3, 5
+    int mix_lo, mix_hi;        // bright values below mix_lo mix with the weight of t = 0, from mix_hi on with that of t = overlap (hdr.c:1567-1575;
+                               // dualiso.cpp: mix_band): only the band between them needs log2 of the signal and the cosine
     double a, b20, corr_ev, max_ev, overlap;
 };
 
@@ -68,13 +70,13 @@ struct DiLuts {                // device pointers; *_ev2raw are indexable from -
     const double *fullres_curve;   // [2^20]
     const double *log2sig;         // [2^20] log2(max(i/64 - black/64, 1))
     // the same tables re-packed for k_di_interp, whose time is the number of its table gathers (1.2 GB of L2 requests per batch of 8):
-    const struct DiBright *by_bright;  // [2^20] what the mix needs of a bright value in one 16-byte entry
     const int2 *mix_pair;              // indexable from -10*32768: { mix_ev2raw[e], mix_raw2ev[mix_ev2raw[e]] }
     int fullres_thr;                   // fullres_curve[i] > 0.8 <=> i >= fullres_thr (the curve is monotone; checked when it is built)
+    int fr_lo, fr_hi;                  // fullres_curve[i] == fr_lo_val for every i < fr_lo, == fr_hi_val for every i >= fr_hi (found in the table
+    double fr_lo_val, fr_hi_val;       // when it is built): k_di_blend reads the 8 MB of doubles only for the band between
     int blend_is_mix;                  // the blend's raw2ev table equals the mix's (always, in practice: both are rebuilt in the same call with
                                        // the same levels): without chroma smoothing the interpolation hands the blend EV values instead of raw ones
 };
-struct alignas(16) DiBright { double log2sig; int mix_raw2ev; int fullres_hi; };       // fullres_hi: fullres_curve[i] > 0.8
 
 constexpr int DI_STAT_SLOTS = 64;     // k_di_edge_dir spreads its four counters per frame over this many slots (same-address atomics serialise)
 struct DiPlanes {

@@ -315,14 +315,28 @@ __device__ __forceinline__ int di_alias_err(const DiParams &p, const DiLuts &L, 
 
 // everything that follows the interpolation for one pixel: full-res pick (hdr.c:1355-1380), half-res mix (hdr.c:1588-1612),
 // overexposure flag (hdr.c:1620-1626) and, when no chroma smoothing sits in between, the alias error --
-// with the re-packed tables (DiLuts::by_bright, mix_pair): 4 gathers instead of 8 -- one entry for everything that is looked
+// with the re-packed table (DiLuts::mix_pair; until round 5 also a 16-byte entry per bright value): 4 gathers instead of 8 -- what is looked
 // up at the bright value, the full-res pick f is b or d (its table value is already here), and ev2raw comes with its raw2ev
 // ev_out: the two planes go out as EV values (what k_di_blend looks up of them anyway, when no chroma smoothing sits in between)
+// the weight of the half-res mix at t (hdr.c:1572-1575)
+__device__ __forceinline__ double di_mix_weight(const DiParams &p, double t)
+{
+    double k = (-cos(t * 3.14159265358979323846 / p.overlap) + 1) / 2;
+    return k < 0 ? 0 : (k > 1 ? 1 : k);
+}
+// Round 5: the weight depends on the bright value alone and is constant outside a band of it (DiParams::mix_lo / mix_hi): k_lo / k_hi are
+// the weights at t = 0 and t = overlap, evaluated once per thread with the same expression; only pixels inside the band read log2 of
+// their signal (8 MB of doubles) and take the cosine.  What was looked up at the bright value in one 16-byte entry (DiLuts::by_bright,
+// 16 MB) is then mix_raw2ev -- the table the dark value goes through anyway -- and a comparison with fullres_thr.
 __device__ __forceinline__ void di_mix_pixel_packed(const DiParams &p, const DiLuts &L, size_t i, int br, int b, int d,
                                                     uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
-                                                    uint16_t *__restrict__ over, uint16_t *__restrict__ amap, bool ev_out)
+                                                    uint16_t *__restrict__ over, uint16_t *__restrict__ amap, bool ev_out, double k_lo, double k_hi)
 {
-    const DiBright tb = L.by_bright[b & 0xFFFFF];
+    const int bm = b & 0xFFFFF;
+    const bool in_band = bm >= p.mix_lo && bm < p.mix_hi;
+    double log2sig = 0;
+    if (in_band) log2sig = L.log2sig[bm];                                          // (issued with the other look-ups, not behind them)
+    struct { int mix_raw2ev; int fullres_hi; } tb = { L.mix_raw2ev[bm], bm >= L.fullres_thr };
     const int ev_b = tb.mix_raw2ev, ev_d = L.mix_raw2ev[d];
     int f = 0, ev_f = 0;
     if (p.use_fullres) {
@@ -331,12 +345,14 @@ __device__ __forceinline__ void di_mix_pixel_packed(const DiParams &p, const DiL
         ev_f = take_b ? ev_b : ev_d;
     } else if (ev_out || amap) ev_f = L.mix_raw2ev[0];
     fullres[i] = ev_out ? (uint32_t)ev_f : (uint32_t)f;
-    const double ev = tb.log2sig + p.corr_ev;
-    double t = ev - (p.max_ev - p.overlap);
-    t = t < p.overlap ? t : p.overlap;
-    t = t > 0 ? t : 0;
-    double k = (-cos(t * 3.14159265358979323846 / p.overlap) + 1) / 2;
-    k = k < 0 ? 0 : (k > 1 ? 1 : k);
+    double k = bm < p.mix_lo ? k_lo : k_hi;
+    if (in_band) {
+        const double ev = log2sig + p.corr_ev;
+        double t = ev - (p.max_ev - p.overlap);
+        t = t < p.overlap ? t : p.overlap;
+        t = t > 0 ? t : 0;
+        k = di_mix_weight(p, t);
+    }
     const int mixed = (int)(ev_b * (1 - k) + ev_d * k);
     const int2 hp = L.mix_pair[mixed];
     const int hr = hp.x;
@@ -376,7 +392,7 @@ __device__ __forceinline__ void di_interp_pixel(const DiParams &p, const DiLuts 
                                                 size_t i, int x, int y, int dir_given,
                                                 uint32_t *__restrict__ dark, uint32_t *__restrict__ bright,
                                                 uint32_t *__restrict__ fullres, uint32_t *__restrict__ halfres,
-                                                uint16_t *__restrict__ over, uint16_t *__restrict__ amap, bool ev_out)
+                                                uint16_t *__restrict__ over, uint16_t *__restrict__ amap, bool ev_out, double k_lo, double k_hi)
 {
     const int w = p.w, h = p.h;
     const int *ir2e = L.interp_raw2ev, *ie2r = L.interp_ev2raw;
@@ -427,7 +443,7 @@ __device__ __forceinline__ void di_interp_pixel(const DiParams &p, const DiLuts 
     const int b = br ? native : interp, d = br ? interp : native;
     bright[i] = (uint32_t)b;
     dark[i] = (uint32_t)d;
-    di_mix_pixel_packed(p, L, i, br, b, d, fullres, halfres, over, amap, ev_out);
+    di_mix_pixel_packed(p, L, i, br, b, d, fullres, halfres, over, amap, ev_out, k_lo, k_hi);
 }
 
 template <bool AMAZE>
@@ -447,8 +463,9 @@ __global__ __launch_bounds__(256) void k_di_interp(const uint32_t *__restrict__ 
     }
     const int w = p.w, h = p.h;
     const size_t n = (size_t)w * h;
+    const double k_lo = di_mix_weight(p, 0.0), k_hi = di_mix_weight(p, p.overlap);
     for (size_t i = (size_t)di_xcd_block() * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        di_interp_pixel<AMAZE>(p, L, A, raw, i, (int)(i % w), (int)(i / w), -1, dark, bright, fullres, halfres, over, amap, ev_out);
+        di_interp_pixel<AMAZE>(p, L, A, raw, i, (int)(i % w), (int)(i / w), -1, dark, bright, fullres, halfres, over, amap, ev_out, k_lo, k_hi);
 }
 
 // ------------------------------------------------------------------ AMaZE-based interpolation, hdr.c:954-1229
@@ -584,6 +601,7 @@ __global__ __launch_bounds__(256, 4) void k_di_edge_interp(const uint32_t *__res
         if (amap) amap += o;
         A.red += o; A.green += o; A.blue += o; A.sq_row = sq_row;
     }
+    const double k_lo = di_mix_weight(p, 0.0), k_hi = di_mix_weight(p, p.overlap);
     stats += ((size_t)f * DI_STAT_SLOTS + ((blockIdx.x + blockIdx.y) & (DI_STAT_SLOTS - 1))) * 4;
     const int w = p.w, h = p.h, x0 = blockIdx.x * 256, x = x0 + (int)threadIdx.x;
     unsigned n_search = 0, n_plain = 0;                                          // this lane's pixels, bright rows in the low half, dark rows << 16
@@ -632,7 +650,7 @@ __global__ __launch_bounds__(256, 4) void k_di_edge_interp(const uint32_t *__res
             }
         }
     }
-    if (x < w) di_interp_pixel<true>(p, L, A, raw, i, x, y, best, dark, bright, fullres, halfres, over, amap, ev_out);
+    if (x < w) di_interp_pixel<true>(p, L, A, raw, i, x, y, best, dark, bright, fullres, halfres, over, amap, ev_out, k_lo, k_hi);
     __syncthreads();                                                             // (s_rows is reused by the next row)
     }
     {   // the reference's four counters: semi-overexposed / not (bright rows), deep shadow / not (dark rows)
@@ -824,7 +842,8 @@ __global__ __launch_bounds__(256) void k_di_blend(const uint32_t *__restrict__ d
         int hrev, frev, frsev;
         if (ev_planes) { hrev = (int)halfres_s[i]; frev = frsev = (int)fullres[i]; }                       // k_di_interp<true> wrote EV values
         else { hrev = r2e[halfres_s[i]]; frev = r2e[fullres[i]]; frsev = fullres_s == fullres ? frev : r2e[fullres_s[i]]; }
-        double f = L.fullres_curve[b & 0xFFFFF];
+        const int bm = b & 0xFFFFF;                                                  // (the curve is constant outside a band of b: DiLuts::fr_lo / fr_hi)
+        double f = bm < L.fr_lo ? L.fr_lo_val : (bm >= L.fr_hi ? L.fr_hi_val : L.fullres_curve[bm]);
         double ovf = ov / 200.0;
         ovf = ovf < 0 ? 0 : (ovf > 1 ? 1 : ovf);
         c = c > ovf ? c : ovf;
