@@ -407,6 +407,11 @@ int mlvfs_amd_test_rand_layout(void);
  * thread_ctx; resource_manager.c:111-118 is the pool this replaces).  device_of[0..workers) receives HIP ordinals.            */
 int mlvfs_amd_test_device_order(const char *const *bus_ids, int n, int workers, int *device_of);
 
+/* Test hook, host only: how the streaming forms of the fused pass (csrc/k_frame_s.hip, k_frame_p5 in csrc/k_frame_p.hip) cut a frame
+ * into tasks -- columns of 62 items (8 pixels each), segments of seg_rows cell rows, `fold` segments of a narrow last column side by
+ * side in one wave (a last column of <= 14 items: 4, <= 30 items: 2), tasks per frame.                                              */
+int mlvfs_amd_test_stream_plan(int width, int height, int seg_rows, int *cols, int *segs, int *fold, int *tasks_per_frame);
+
 /* self tests that need no GPU (selection networks, LUT identities): 0 = pass */
 int mlvfs_amd_selftest_host(void);
 /* the library's host EV tables against raw2ev_lin[16384] (index = pixel - black) and ev2raw[24 * 32768] (index 0 = EV -10 * 32768):

@@ -46,7 +46,7 @@ DEVICE_SYMBOLS = [
     "mlvfs_amd_timer_begin", "mlvfs_amd_timer_end", "mlvfs_amd_selftest_host", "mlvfs_amd_selftest_tables", "mlvfs_amd_frame_begin", "mlvfs_amd_frame_end", "mlvfs_amd_frame_sync", "mlvfs_amd_dropin_stats", "mlvfs_amd_test_fail_next", "mlvfs_amd_dropin_transfers", "mlvfs_amd_dropin_profile",
     "mlvfs_amd_mlv_open", "mlvfs_amd_mlv_close", "mlvfs_amd_mlv_frame_count", "mlvfs_amd_mlv_chunk_count",
     "mlvfs_amd_mlv_xref", "mlvfs_amd_mlv_frame_headers", "mlvfs_amd_mlv_read_frames", "mlvfs_amd_mlv_process", "mlvfs_amd_mlv_process_dualiso",
-    "mlvfs_amd_lj92_info", "mlvfs_amd_lj92_decode_dev", "mlvfs_amd_lj92_decode_untiled", "mlvfs_amd_lj92_encode_table", "mlvfs_amd_test_rand_layout", "mlvfs_amd_test_device_order", "mlvfs_amd_lzma_uncompress",
+    "mlvfs_amd_lj92_info", "mlvfs_amd_lj92_decode_dev", "mlvfs_amd_lj92_decode_untiled", "mlvfs_amd_lj92_encode_table", "mlvfs_amd_test_rand_layout", "mlvfs_amd_test_device_order", "mlvfs_amd_test_stream_plan", "mlvfs_amd_lzma_uncompress",
     "mlvfs_amd_gif_size", "mlvfs_amd_gif_render", "mlvfs_amd_mlv_gif_data", "mlvfs_amd_process_unpacked_dev", "mlvfs_amd_deflicker_dev",
 ]
 
@@ -176,6 +176,7 @@ def load() -> C.CDLL:
     sig("mlvfs_amd_dropin_stats", None, [vp])
     sig("mlvfs_amd_test_fail_next", None, [C.c_int])
     sig("mlvfs_amd_test_device_order", i, [vp, i, i, vp])
+    sig("mlvfs_amd_test_stream_plan", i, [i, i, i, vp, vp, vp, vp])
     sig("mlvfs_amd_dropin_transfers", None, [vp])
     sig("mlvfs_amd_dropin_profile", None, [vp])
     sig("mlvfs_amd_process_unpacked_dev", i, [vp, vp, sz, vp, sz, i, i, i, i, vp])

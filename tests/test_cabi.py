@@ -218,3 +218,20 @@ def test_fix_pattern_noise_refuses_odd_sizes_before_touching_anything(amd):
         amd.fix_pattern_noise(lib.ptr(g), w, h, 15000, 0)
         assert np.array_equal(g, f)
         assert b"not supported" in amd.mlvfs_amd_last_error()
+
+
+def test_streaming_kernels_plan():
+    """Host arithmetic of the streaming kernels' launch plan (no GPU): 3584 px = 7 columns of 62 items and one of 14, which is folded
+    four segments to a wave -- 7.25 columns of steps per frame instead of 8; a last column of up to 30 items folds in two."""
+    amd = lib.load()
+    amd.mlvfs_amd_test_stream_plan.restype = C.c_int
+    def plan(w, h, seg=60):
+        v = [C.c_int() for _ in range(4)]
+        rc = amd.mlvfs_amd_test_stream_plan(w, h, seg, *[C.byref(x) for x in v])
+        return rc, tuple(x.value for x in v)
+    assert plan(3584, 1320) == (0, (8, 11, 4, 7 * 11 + 3))
+    assert plan(1920, 1080) == (0, (4, 9, 1, 36))
+    assert plan(512, 124, 30) == (0, (2, 3, 4, 3 + 1))           # 64 items: 62 + 2
+    assert plan(656, 190, 30) == (0, (2, 4, 2, 4 + 2))           # 82 items: 62 + 20
+    assert plan(3584, 66) == (0, (8, 1, 1, 8))                   # one segment: nothing to fold
+    assert plan(3583, 1320)[0] != 0 and plan(3584, 1321)[0] != 0
