@@ -1192,26 +1192,7 @@ __device__ __forceinline__ unsigned long long lanes_lt(int a, int b) { return __
 //   RAWREG (k_frame_s): the strip's pixels come in registers (rtop / rbot) instead of from the tile's LDS rows, and go back there
 //   (store = false: the caller stores them).
 struct NoSmem {};
-// The streaming kernels' (k_frame_s, k_frame_p5) columns: a wave's lanes 1 .. S write S items of a row, lanes 0 and S + 1 are the halo.
-// S = 62.  MLVFS_AMD_KF_COLW=60 makes a column's output rows whole 64-byte pieces (columns of 62 items share a piece with their
-// neighbour at every edge, written by two waves at different times): the bare traffic of 3584x1320 takes 3.61 instead of 3.94 us
-// per frame that way (tools/stream_floor.hip), the kernels themselves gain nothing -- k_frame_s +-0, k_frame_p5 +3.5 % (7.5 instead
-// of 7.25 columns of steps; profiles/r05/ab_colw.log).
-static inline int frame_stream_colw()
-{
-    static const int colw = [] { const char *e = getenv("MLVFS_AMD_KF_COLW"); const int v = e ? atoi(e) : 0; return v >= 8 && v <= 62 ? v : 62; }();
-    return colw;
-}
-static inline int frame_stream_cols(int w) { return (w / 8 + frame_stream_colw() - 1) / frame_stream_colw(); }
-// A last column of at most 14 (30) items is folded: a wave takes four (two) of its segments side by side, one per group of 16 (32)
-// lanes, each group with its own two halo lanes.  MLVFS_AMD_KF_FOLD=1: never (A/B).
-static inline int frame_stream_fold(int w, int cols, int segs)
-{
-    static const int env_fold = [] { const char *e = getenv("MLVFS_AMD_KF_FOLD"); return e ? atoi(e) : 0; }();
-    const int last_items = w / 8 - (cols - 1) * frame_stream_colw();
-    if (segs < 2 || env_fold == 1) return 1;
-    return last_items + 2 <= 16 ? 4 : last_items + 2 <= 32 ? 2 : 1;
-}
+// (frame_stream_colw / _cols / _fold -- the streaming kernels' launch plan, host arithmetic -- live in common.h)
 template <int METHOD, bool PACKED, bool VECST, bool CLAMP, bool XM, bool ANYSTRIPES, bool BRIGHT, class SM, bool RAWREG = false>
 __device__ __forceinline__ void strip_output_t(const SM &sm, const OutArgs &oa, int w, int h, int black, int f, int tx0, int ty0, int jj, int kk,
                                                unsigned long long msmooth, const int (&gev)[STRIP], int gev_off, const int (&er)[STRIP], const int (&eb)[STRIP], bool store,

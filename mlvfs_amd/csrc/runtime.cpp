@@ -465,3 +465,16 @@ const char *mlvfs_amd_last_error(void) { return mlv::g_err; }
 const char *mlvfs_amd_version(void) { return "mlvfs_amd 0.1.0 (gfx950)"; }
 
 }
+
+// Test hook, host only (no GPU): how the streaming kernels (k_frame_s, k_frame_p5) cut a frame of width x height pixels into tasks of
+// seg_rows cell rows -- columns, segments, how many segments of the last column a wave takes side by side (k_frame_dev.h:
+// frame_stream_fold), tasks per frame.  0, or MLVFS_AMD_ERR_ARG for a frame the kernels do not take.
+extern "C" int mlvfs_amd_test_stream_plan(int width, int height, int seg_rows, int *cols, int *segs, int *fold, int *tasks_per_frame)
+{
+    if (width < 16 || width % 8 || height < 2 || height % 2 || seg_rows < 1 || !cols || !segs || !fold || !tasks_per_frame) return MLVFS_AMD_ERR_ARG;
+    const int c = mlv::frame_stream_cols(width), sg = (height / 2 + seg_rows - 1) / seg_rows, f = mlv::frame_stream_fold(width, c, sg);
+    *cols = c; *segs = sg; *fold = f;
+    *tasks_per_frame = f > 1 ? (c - 1) * sg + (sg + f - 1) / f : c * sg;
+    return MLVFS_AMD_OK;
+}
+
